@@ -1,0 +1,546 @@
+// Host graph substrate of gmsx: synthetic generators, edge-list -> CSR builder, degree relabelling,
+// .el / .sg readers and the .sg writer.  Pure host C++17 + OpenMP; no device code.
+//
+// Behavioural contract = the reference loader (paths relative to the spcl/gms tree):
+//   generator  gms/third_party/gapbs/generator.h:52-127   (R-MAT A/B/C = .57/.19/.19, uniform, id permutation)
+//   builder    gms/third_party/gapbs/builder.h:108-117,145-156,206-298 (n = max id + 1, symmetrise, sort/unique/no-loop rows)
+//   relabel    gms/third_party/gapbs/builder.h:1699-1733, gapbs/benchmark.h:50-68,158-176 (WorthRelabelling)
+//   files      gms/third_party/gapbs/reader.h:49-56,252-305, writer.h:39-69
+// The CSR it produces is bit-identical to the reference's (tests/test_loader.py: FNV fingerprints of
+// SURVEY Appendix B and array equality against the compiled reference).
+//
+// Three pieces of libstdc++ behaviour fix the reference's output and are restated here explicitly
+// (so the result does not depend on which libstdc++ this file is compiled against):
+//   - std::uniform_real_distribution<float>(0,1) on mt19937  -> canonical_float()
+//   - std::uniform_int_distribution on mt19937 (GCC >= 11: Lemire's method) -> bounded_u32()
+//   - std::shuffle's two-swaps-per-draw fast path for n <= 65535 -> shuffle_ids()
+// std::mt19937 itself is fully specified by the C++ standard and is used as is.
+#include "gmsx_internal.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <memory>
+#include <new>
+#include <random>
+#include <string>
+#include <utility>
+#include <vector>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace gmsx {
+
+static constexpr uint32_t kSeed = 27491095u;         // gapbs/util.h:25
+static constexpr int64_t kGenBlock = int64_t(1) << 18;  // generator.h:152: rng reseeded per 2^18-edge block
+
+// ---- restated libstdc++ distributions ------------------------------------------------------
+
+// generate_canonical<float,24> on a 32-bit engine: one draw, float(x) / 2^32 in float arithmetic,
+// clamped below 1.0f (float(x) rounds to nearest, so the quotient can reach 1.0f).
+static inline float canonical_float(std::mt19937 &rng) {
+    float r = static_cast<float>(static_cast<uint32_t>(rng())) / 4294967296.0f;
+    if (r >= 1.0f) r = std::nextafter(1.0f, 0.0f);
+    return r;
+}
+
+// Unbiased integer in [0, range), range in [1, 2^32): Lemire's nearly-divisionless reduction with a
+// 32x32->64 product and rejection of the low part below (2^32 mod range).
+static inline uint32_t bounded_u32(std::mt19937 &rng, uint32_t range) {
+    uint64_t prod = uint64_t(uint32_t(rng())) * range;
+    uint32_t low = uint32_t(prod);
+    if (low < range) {
+        uint32_t threshold = (0u - range) % range;
+        while (low < threshold) {
+            prod = uint64_t(uint32_t(rng())) * range;
+            low = uint32_t(prod);
+        }
+    }
+    return uint32_t(prod >> 32);
+}
+// closed interval [0, hi]
+static inline uint32_t uniform_closed(std::mt19937 &rng, uint32_t hi) {
+    if (hi == 0xFFFFFFFFu) return uint32_t(rng());
+    return bounded_u32(rng, hi + 1u);
+}
+
+// Fisher-Yates as libstdc++ runs it on random-access iterators with a 32-bit engine.
+static void shuffle_ids(int32_t *a, int64_t n, std::mt19937 &rng) {
+    if (n <= 1) return;
+    const uint64_t un = uint64_t(n);
+    if (0xFFFFFFFFull / un >= un) {  // n*n fits the engine range: one draw feeds two swaps
+        int64_t i = 1;
+        if ((un % 2) == 0) {
+            std::swap(a[i], a[uniform_closed(rng, 1)]);
+            ++i;
+        }
+        while (i != n) {
+            const uint64_t r0 = uint64_t(i) + 1, r1 = r0 + 1;
+            const uint32_t x = uniform_closed(rng, uint32_t(r0 * r1 - 1));
+            std::swap(a[i], a[x / r1]);
+            ++i;
+            std::swap(a[i], a[x % r1]);
+            ++i;
+        }
+        return;
+    }
+    for (int64_t i = 1; i < n; ++i) std::swap(a[i], a[uniform_closed(rng, uint32_t(i))]);
+}
+
+// ---- edge lists ------------------------------------------------------------------------------
+
+struct EdgeList {
+    int64_t m = 0;
+    std::unique_ptr<int32_t[]> u, v;
+    int alloc(int64_t edges) {
+        m = edges;
+        u.reset(new (std::nothrow) int32_t[size_t(std::max<int64_t>(edges, 1))]);
+        v.reset(new (std::nothrow) int32_t[size_t(std::max<int64_t>(edges, 1))]);
+        return (u && v) ? GMSX_OK : GMSX_ERR_NOMEM;
+    }
+};
+
+static int make_rmat(int scale, int degree, EdgeList &el) {
+    const int64_t n = int64_t(1) << scale, m = n * degree;
+    if (int rc = el.alloc(m)) return rc;
+    const float A = 0.57f, B = 0.19f, C = 0.19f;
+    const float AB = A + B, ABC = A + B + C;  // float sums, as the reference compares against
+    int32_t *eu = el.u.get(), *ev = el.v.get();
+#pragma omp parallel
+    {
+        std::mt19937 rng;
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t block = 0; block < m; block += kGenBlock) {
+            rng.seed(uint32_t(kSeed + block / kGenBlock));
+            const int64_t end = std::min(block + kGenBlock, m);
+            for (int64_t e = block; e < end; ++e) {
+                int32_t src = 0, dst = 0;
+                for (int depth = 0; depth < scale; ++depth) {
+                    const float p = canonical_float(rng);
+                    src <<= 1;
+                    dst <<= 1;
+                    if (p < AB) {
+                        if (p > A) dst++;
+                    } else {
+                        src++;
+                        if (p > ABC) dst++;
+                    }
+                }
+                eu[e] = src;
+                ev[e] = dst;
+            }
+        }
+    }
+    // id permutation (generator.h:52-62): identity shuffled once with mt19937(kSeed), applied to both ends
+    std::unique_ptr<int32_t[]> perm(new (std::nothrow) int32_t[size_t(n)]);
+    if (!perm) return GMSX_ERR_NOMEM;
+    for (int64_t i = 0; i < n; ++i) perm[i] = int32_t(i);
+    std::mt19937 prng(kSeed);
+    shuffle_ids(perm.get(), n, prng);
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < m; ++e) {
+        eu[e] = perm[eu[e]];
+        ev[e] = perm[ev[e]];
+    }
+    return GMSX_OK;
+}
+
+static int make_uniform(int scale, int degree, EdgeList &el) {
+    const int64_t n = int64_t(1) << scale, m = n * degree;
+    if (int rc = el.alloc(m)) return rc;
+    int32_t *eu = el.u.get(), *ev = el.v.get();
+    const uint32_t hi = uint32_t(n - 1);
+#pragma omp parallel
+    {
+        std::mt19937 rng;
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t block = 0; block < m; block += kGenBlock) {
+            rng.seed(uint32_t(kSeed + block / kGenBlock));
+            const int64_t end = std::min(block + kGenBlock, m);
+            for (int64_t e = block; e < end; ++e) {
+                // The reference constructs Edge(udist(rng), udist(rng)) (generator.h:74); argument evaluation
+                // order is unspecified and its GCC-built binary draws the SECOND argument first.  Pinned by the
+                // uniform-graph fingerprint test.
+                const uint32_t second = uniform_closed(rng, hi);
+                const uint32_t first = uniform_closed(rng, hi);
+                eu[e] = int32_t(first);
+                ev[e] = int32_t(second);
+            }
+        }
+    }
+    return GMSX_OK;
+}
+
+// ---- CSR construction --------------------------------------------------------------------------
+
+static int alloc_csr(Csr &g, int64_t n, int64_t nnz) {
+    g.n = n;
+    g.nnz = nnz;
+    g.off.reset(new (std::nothrow) int64_t[size_t(n + 1)]);
+    g.neigh.reset(new (std::nothrow) int32_t[size_t(std::max<int64_t>(nnz, 1))]);
+    return (g.off && g.neigh) ? GMSX_OK : GMSX_ERR_NOMEM;
+}
+
+// exclusive prefix sum of per-vertex counts into off[0..n]; two-pass blocked so large n stays parallel
+static void prefix_sum(const int64_t *cnt, int64_t n, int64_t *off) {
+    int nt = 1;
+#ifdef _OPENMP
+    nt = omp_get_max_threads();
+#endif
+    std::vector<int64_t> part(size_t(nt) + 1, 0);
+    const int64_t chunk = (n + nt - 1) / std::max(nt, 1);
+#pragma omp parallel num_threads(nt)
+    {
+        int t = 0;
+#ifdef _OPENMP
+        t = omp_get_thread_num();
+#endif
+        const int64_t lo = std::min<int64_t>(n, t * chunk), hi = std::min<int64_t>(n, lo + chunk);
+        int64_t s = 0;
+        for (int64_t i = lo; i < hi; ++i) s += cnt[i];
+        part[size_t(t) + 1] = s;
+#pragma omp barrier
+#pragma omp single
+        for (int i = 0; i < nt; ++i) part[size_t(i) + 1] += part[size_t(i)];
+        s = part[size_t(t)];
+        for (int64_t i = lo; i < hi; ++i) {
+            off[i] = s;
+            s += cnt[i];
+        }
+    }
+    off[n] = part[size_t(nt)];
+}
+
+// Edge list -> canonical symmetric CSR.  Equivalent to MakeGraphFromEL + SquishGraph: both directions
+// of every pair, rows sorted, duplicates and self-loops removed, n = max id + 1 unless given.
+static int build_from_el(const EdgeList &el, int64_t num_nodes, bool symmetrize, Csr &out) {
+    const int64_t m = el.m;
+    const int32_t *eu = el.u.get(), *ev = el.v.get();
+    if (num_nodes < 0) {
+        int32_t mx = 0;  // reference starts its max-reduction at 0, so an empty list gives n = 1
+#pragma omp parallel for reduction(max : mx) schedule(static)
+        for (int64_t e = 0; e < m; ++e) mx = std::max(mx, std::max(eu[e], ev[e]));
+        num_nodes = int64_t(mx) + 1;
+    }
+    const int64_t n = num_nodes;
+    for (int64_t e = 0; e < m; ++e)  // cheap guard; the generators never trip it
+        if (eu[e] < 0 || ev[e] < 0 || eu[e] >= n || ev[e] >= n) return GMSX_ERR_INVALID;
+
+    // pass 1: raw row sizes (self-loops dropped here already; duplicates later)
+    std::unique_ptr<std::atomic<int64_t>[]> cnt(new (std::nothrow) std::atomic<int64_t>[size_t(n + 1)]);
+    std::unique_ptr<int64_t[]> raw_off(new (std::nothrow) int64_t[size_t(n + 1)]);
+    if (!cnt || !raw_off) return GMSX_ERR_NOMEM;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i <= n; ++i) cnt[i].store(0, std::memory_order_relaxed);
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < m; ++e) {
+        if (eu[e] == ev[e]) continue;
+        cnt[eu[e]].fetch_add(1, std::memory_order_relaxed);
+        if (symmetrize) cnt[ev[e]].fetch_add(1, std::memory_order_relaxed);
+    }
+    prefix_sum(reinterpret_cast<int64_t *>(cnt.get()), n, raw_off.get());
+    const int64_t raw_nnz = raw_off[n];
+    std::unique_ptr<int32_t[]> raw(new (std::nothrow) int32_t[size_t(std::max<int64_t>(raw_nnz, 1))]);
+    if (!raw) return GMSX_ERR_NOMEM;
+    // pass 2: scatter (placement inside a row is racy, the per-row sort below makes the result deterministic)
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) cnt[i].store(raw_off[i], std::memory_order_relaxed);
+#pragma omp parallel for schedule(static)
+    for (int64_t e = 0; e < m; ++e) {
+        if (eu[e] == ev[e]) continue;
+        raw[cnt[eu[e]].fetch_add(1, std::memory_order_relaxed)] = ev[e];
+        if (symmetrize) raw[cnt[ev[e]].fetch_add(1, std::memory_order_relaxed)] = eu[e];
+    }
+    // pass 3: sort + unique each row, record the surviving length
+    std::unique_ptr<int64_t[]> len(new (std::nothrow) int64_t[size_t(n + 1)]);
+    if (!len) return GMSX_ERR_NOMEM;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t u = 0; u < n; ++u) {
+        int32_t *b = raw.get() + raw_off[u], *e = raw.get() + raw_off[u + 1];
+        std::sort(b, e);
+        len[u] = std::unique(b, e) - b;
+    }
+    cnt.reset();
+    // pass 4: compact
+    std::unique_ptr<int64_t[]> off(new (std::nothrow) int64_t[size_t(n + 1)]);
+    if (!off) return GMSX_ERR_NOMEM;
+    prefix_sum(len.get(), n, off.get());
+    if (int rc = alloc_csr(out, n, off[n])) return rc;
+    std::memcpy(out.off.get(), off.get(), size_t(n + 1) * sizeof(int64_t));
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t u = 0; u < n; ++u)
+        std::copy(raw.get() + raw_off[u], raw.get() + raw_off[u] + len[u], out.neigh.get() + off[u]);
+    out.directed = !symmetrize;
+    return GMSX_OK;
+}
+
+// ---- relabel by decreasing degree ----------------------------------------------------------------
+
+// gapbs/benchmark.h:158-176 with SourcePicker (gapbs/benchmark.h:50-68): 1000 draws of a non-isolated
+// vertex from mt19937(kSeed); relabel iff mean/1.3 > median of the sampled degrees and m/n >= 10.
+bool worth_relabelling(const Csr &g) {
+    if (g.n <= 0) return false;
+    const int64_t avg = (g.nnz / 2) / g.n;
+    if (avg < 10) return false;
+    std::mt19937 rng(kSeed);
+    const int64_t samples = std::min<int64_t>(1000, g.n);
+    std::vector<int64_t> s(static_cast<size_t>(samples));
+    int64_t total = 0;
+    for (int64_t t = 0; t < samples; ++t) {
+        int64_t src;
+        do {
+            src = int64_t(uniform_closed(rng, uint32_t(g.n - 1)));
+        } while (g.off[src + 1] == g.off[src]);
+        s[size_t(t)] = g.off[src + 1] - g.off[src];
+        total += s[size_t(t)];
+    }
+    std::sort(s.begin(), s.end());
+    const double mean = double(total) / double(samples);
+    const double median = double(s[size_t(samples / 2)]);
+    return mean / 1.3 > median;
+}
+
+// builder.h:1699-1733: new id = position in the descending (degree, old id) order; rows re-sorted.
+int relabel_by_degree(const Csr &g, Csr &out) {
+    if (g.directed) return GMSX_ERR_DIRECTED;
+    const int64_t n = g.n;
+    std::vector<std::pair<int64_t, int32_t>> key(static_cast<size_t>(n));
+#pragma omp parallel for schedule(static)
+    for (int64_t v = 0; v < n; ++v) key[size_t(v)] = {g.off[v + 1] - g.off[v], int32_t(v)};
+    std::sort(key.begin(), key.end(), std::greater<std::pair<int64_t, int32_t>>());
+    std::unique_ptr<int32_t[]> new_id(new (std::nothrow) int32_t[size_t(std::max<int64_t>(n, 1))]);
+    std::unique_ptr<int64_t[]> deg(new (std::nothrow) int64_t[size_t(n + 1)]);
+    if (!new_id || !deg) return GMSX_ERR_NOMEM;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        deg[i] = key[size_t(i)].first;
+        new_id[key[size_t(i)].second] = int32_t(i);
+    }
+    if (int rc = alloc_csr(out, n, g.nnz)) return rc;
+    prefix_sum(deg.get(), n, out.off.get());
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t u = 0; u < n; ++u) {
+        int32_t *dst = out.neigh.get() + out.off[new_id[u]];
+        int64_t k = 0;
+        for (int64_t e = g.off[u]; e < g.off[u + 1]; ++e) dst[k++] = new_id[g.neigh[e]];
+        std::sort(dst, dst + k);
+    }
+    out.directed = false;
+    return GMSX_OK;
+}
+
+static int finish(Csr &&built, int relabel, gmsx_csr **out) {
+    std::unique_ptr<gmsx_csr> h(new (std::nothrow) gmsx_csr);
+    if (!h) return GMSX_ERR_NOMEM;
+    const bool do_relabel = !built.directed && (relabel == GMSX_RELABEL_ALWAYS ||
+                                                (relabel == GMSX_RELABEL_AUTO && worth_relabelling(built)));
+    if (do_relabel) {
+        if (int rc = relabel_by_degree(built, h->g)) return rc;
+        h->relabelled = true;
+    } else {
+        h->g = std::move(built);
+    }
+    *out = h.release();
+    return GMSX_OK;
+}
+
+// ---- files ---------------------------------------------------------------------------------------
+
+static std::string suffix_of(const std::string &p) {
+    const size_t k = p.rfind('.');
+    return k == std::string::npos ? std::string() : p.substr(k);
+}
+
+static int read_el(const std::string &path, EdgeList &el) {
+    std::ifstream in(path);
+    if (!in.is_open()) return GMSX_ERR_IO;
+    std::vector<int32_t> us, vs;
+    int64_t a, b;
+    while (in >> a >> b) {  // reader.h:49-56: whitespace-separated pairs until the first parse failure
+        if (a < 0 || b < 0 || a > std::numeric_limits<int32_t>::max() || b > std::numeric_limits<int32_t>::max())
+            return GMSX_ERR_OVERFLOW;
+        us.push_back(int32_t(a));
+        vs.push_back(int32_t(b));
+    }
+    if (int rc = el.alloc(int64_t(us.size()))) return rc;
+    std::copy(us.begin(), us.end(), el.u.get());
+    std::copy(vs.begin(), vs.end(), el.v.get());
+    return GMSX_OK;
+}
+
+// .sg layout (writer.h:39-69): bool directed; int64 nnz; int64 n; int64 offsets[n+1]; int32 neigh[nnz]
+static int read_sg(const std::string &path, Csr &g) {
+    std::FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) return GMSX_ERR_IO;
+    struct Closer { std::FILE *f; ~Closer() { std::fclose(f); } } closer{f};
+    unsigned char directed = 0;
+    int64_t nnz = 0, n = 0;
+    if (std::fread(&directed, 1, 1, f) != 1 || std::fread(&nnz, 8, 1, f) != 1 || std::fread(&n, 8, 1, f) != 1)
+        return GMSX_ERR_FORMAT;
+    if (n < 0 || nnz < 0 || n > std::numeric_limits<int32_t>::max()) return GMSX_ERR_FORMAT;
+    if (int rc = alloc_csr(g, n, nnz)) return rc;
+    if (std::fread(g.off.get(), 8, size_t(n + 1), f) != size_t(n + 1)) return GMSX_ERR_FORMAT;
+    if (nnz && std::fread(g.neigh.get(), 4, size_t(nnz), f) != size_t(nnz)) return GMSX_ERR_FORMAT;
+    if (g.off[0] != 0 || g.off[n] != nnz) return GMSX_ERR_FORMAT;
+    g.directed = directed != 0;
+    return GMSX_OK;
+}
+
+}  // namespace gmsx
+
+// ================================================================================================
+// C-ABI (include/gmsx.h, "Host graph substrate")
+// ================================================================================================
+using namespace gmsx;
+
+extern "C" {
+
+int gmsx_csr_generate(int generator, int scale, int degree, int relabel, int threads, gmsx_csr **out) {
+    if (!out || scale < 1 || degree < 1 || relabel < 0 || relabel > 2) return GMSX_ERR_INVALID;
+    if (scale > 30) return GMSX_ERR_OVERFLOW;  // ids are int32 (generator.h:41-48 exits with -31)
+    if (generator != GMSX_GEN_KRONECKER && generator != GMSX_GEN_UNIFORM) return GMSX_ERR_INVALID;
+#ifdef _OPENMP
+    const int saved = omp_get_max_threads();
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+    int rc;
+    {
+        Csr g;
+        {
+            EdgeList el;
+            rc = generator == GMSX_GEN_UNIFORM ? make_uniform(scale, degree, el) : make_rmat(scale, degree, el);
+            if (!rc) rc = build_from_el(el, -1, true, g);
+        }
+        if (!rc) rc = finish(std::move(g), relabel, out);
+    }
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(saved);
+#endif
+    return rc;
+}
+
+int gmsx_csr_from_edges(int64_t num_nodes, int64_t num_edges, const int32_t *src, const int32_t *dst,
+                        int symmetrize, int relabel, gmsx_csr **out) {
+    if (!out || num_edges < 0 || (num_edges && (!src || !dst)) || relabel < 0 || relabel > 2) return GMSX_ERR_INVALID;
+    EdgeList el;
+    if (int rc = el.alloc(num_edges)) return rc;
+    if (num_edges) {
+        std::memcpy(el.u.get(), src, size_t(num_edges) * 4);
+        std::memcpy(el.v.get(), dst, size_t(num_edges) * 4);
+    }
+    Csr g;
+    if (int rc = build_from_el(el, num_nodes, symmetrize != 0, g)) return rc;
+    return finish(std::move(g), relabel, out);
+}
+
+int gmsx_csr_load(const char *path, int symmetrize, int relabel, gmsx_csr **out) {
+    if (!path || !out || relabel < 0 || relabel > 2) return GMSX_ERR_INVALID;
+    const std::string p(path), suf = suffix_of(p);
+    Csr g;
+    if (suf == ".sg") {
+        if (int rc = read_sg(p, g)) return rc;
+    } else if (suf == ".el") {
+        EdgeList el;
+        if (int rc = read_el(p, el)) return rc;
+        if (int rc = build_from_el(el, -1, symmetrize != 0, g)) return rc;
+    } else {
+        return GMSX_ERR_FORMAT;
+    }
+    return finish(std::move(g), relabel, out);
+}
+
+int gmsx_csr_save_sg(const gmsx_csr *h, const char *path) {
+    if (!h || !path) return GMSX_ERR_INVALID;
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return GMSX_ERR_IO;
+    const Csr &g = h->g;
+    const unsigned char directed = g.directed ? 1 : 0;
+    bool ok = std::fwrite(&directed, 1, 1, f) == 1 && std::fwrite(&g.nnz, 8, 1, f) == 1 &&
+              std::fwrite(&g.n, 8, 1, f) == 1 && std::fwrite(g.off.get(), 8, size_t(g.n + 1), f) == size_t(g.n + 1) &&
+              (g.nnz == 0 || std::fwrite(g.neigh.get(), 4, size_t(g.nnz), f) == size_t(g.nnz));
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? GMSX_OK : GMSX_ERR_IO;
+}
+
+int gmsx_csr_from_arrays(int64_t n, const int64_t *offsets, const int32_t *neigh, gmsx_csr **out) {
+    if (!out || n < 0 || !offsets || n > std::numeric_limits<int32_t>::max()) return GMSX_ERR_INVALID;
+    if (offsets[0] != 0) return GMSX_ERR_INVALID;
+    for (int64_t i = 0; i < n; ++i)
+        if (offsets[i + 1] < offsets[i]) return GMSX_ERR_INVALID;
+    const int64_t nnz = offsets[n];
+    if (nnz && !neigh) return GMSX_ERR_INVALID;
+    for (int64_t e = 0; e < nnz; ++e)
+        if (neigh[e] < 0 || neigh[e] >= n) return GMSX_ERR_INVALID;
+    std::unique_ptr<gmsx_csr> h(new (std::nothrow) gmsx_csr);
+    if (!h) return GMSX_ERR_NOMEM;
+    if (int rc = alloc_csr(h->g, n, nnz)) return rc;
+    std::memcpy(h->g.off.get(), offsets, size_t(n + 1) * 8);
+    if (nnz) std::memcpy(h->g.neigh.get(), neigh, size_t(nnz) * 4);
+    *out = h.release();
+    return GMSX_OK;
+}
+
+int gmsx_csr_worth_relabelling(const gmsx_csr *h) { return h ? int(worth_relabelling(h->g)) : GMSX_ERR_INVALID; }
+
+int gmsx_csr_relabel_by_degree(const gmsx_csr *h, gmsx_csr **out) {
+    if (!h || !out) return GMSX_ERR_INVALID;
+    std::unique_ptr<gmsx_csr> r(new (std::nothrow) gmsx_csr);
+    if (!r) return GMSX_ERR_NOMEM;
+    if (int rc = relabel_by_degree(h->g, r->g)) return rc;
+    r->relabelled = true;
+    *out = r.release();
+    return GMSX_OK;
+}
+
+int64_t gmsx_csr_num_nodes(const gmsx_csr *h) { return h ? h->g.n : int64_t(GMSX_ERR_INVALID); }
+int64_t gmsx_csr_num_edges(const gmsx_csr *h) { return h ? (h->g.directed ? h->g.nnz : h->g.nnz / 2) : int64_t(GMSX_ERR_INVALID); }
+int64_t gmsx_csr_num_edges_directed(const gmsx_csr *h) { return h ? h->g.nnz : int64_t(GMSX_ERR_INVALID); }
+const int64_t *gmsx_csr_offsets(const gmsx_csr *h) { return h ? h->g.off.get() : nullptr; }
+const int32_t *gmsx_csr_neighbors(const gmsx_csr *h) { return h ? h->g.neigh.get() : nullptr; }
+
+uint64_t gmsx_csr_merge_elements(const gmsx_csr *h) {
+    if (!h) return 0;
+    const Csr &g = h->g;
+    uint64_t s = 0;
+#pragma omp parallel for reduction(+ : s) schedule(dynamic, 1024)
+    for (int64_t u = 0; u < g.n; ++u) {
+        const uint64_t du = uint64_t(g.off[u + 1] - g.off[u]);
+        for (int64_t e = g.off[u]; e < g.off[u + 1]; ++e) {
+            const int32_t v = g.neigh[e];
+            if (u < v) s += du + uint64_t(g.off[v + 1] - g.off[v]);
+        }
+    }
+    return s;
+}
+
+uint64_t gmsx_csr_fingerprint(const gmsx_csr *h, int which) {
+    if (!h) return 0;
+    const unsigned char *p;
+    size_t len;
+    if (which == 0) {
+        p = reinterpret_cast<const unsigned char *>(h->g.off.get());
+        len = size_t(h->g.n + 1) * 8;
+    } else {
+        p = reinterpret_cast<const unsigned char *>(h->g.neigh.get());
+        len = size_t(h->g.nnz) * 4;
+    }
+    uint64_t x = 1469598103934665603ull;
+    for (size_t i = 0; i < len; ++i) {
+        x ^= p[i];
+        x *= 1099511628211ull;
+    }
+    return x;
+}
+
+void gmsx_csr_free(gmsx_csr *h) { delete h; }
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+/* gmsx.h — C-ABI of the MI355X-native set-intersection / subgraph-enumeration backend for GMS.
+ *
+ * Plain C: opaque handles, raw pointers and sizes, int status codes.  No exceptions, no exit(),
+ * no torch / STL types cross this boundary.  This is the boundary a GMS maintainer binds to; the
+ * C++ adaptor that plugs it under the reference's template concept is include/gmsx_set_graph.hpp
+ * and the reference-side glue is shown in INTEGRATION.md.
+ *
+ * Every entry point names the reference interface it replaces (paths relative to the spcl/gms
+ * tree, i.e. /root/reference).
+ *
+ * Conventions
+ *   - status: 0 = GMSX_OK, negative = error (gmsx_strerror()).  Outputs are written only on success.
+ *   - host buffers stay caller-owned; the library copies what it keeps.
+ *   - graphs are symmetric CSR: int64 offsets[n+1], int32 neigh[offsets[n]], each row sorted
+ *     ascending, duplicate- and loop-free (exactly what the reference loader yields,
+ *     gms/third_party/gapbs/builder.h:206-235); gmsx_csr_* builds such graphs, and
+ *     gmsx_graph_upload() verifies the invariant on the device unless told not to.
+ *   - one device per process (one process per GPU); handles are immutable after creation and may be
+ *     used from one host thread at a time, like the reference's main-thread kernel invocation
+ *     (gms/common/benchmark.h:111-118).
+ */
+#ifndef GMSX_H
+#define GMSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GMSX_VERSION 100
+
+/* ---- status codes ---- */
+enum {
+    GMSX_OK = 0,
+    GMSX_ERR_INVALID = -1,      /* bad argument (NULL, negative size, k out of range, …) */
+    GMSX_ERR_NOMEM = -2,        /* host allocation failed */
+    GMSX_ERR_IO = -3,           /* file could not be opened / parsed (reference: exit(-2)/(-6), reader.h:223-229,270-273) */
+    GMSX_ERR_FORMAT = -4,       /* unknown suffix or malformed file (reference: exit(-3), reader.h:243-245) */
+    GMSX_ERR_DIRECTED = -5,     /* a directed graph where the path needs an undirected one (reference: exit(100), cli/cli.h:166-171) */
+    GMSX_ERR_NO_DEVICE = -6,    /* no HIP device / gmsx_init() not called / HIP runtime error */
+    GMSX_ERR_DEVICE_MEM = -7,   /* hipMalloc failed */
+    GMSX_ERR_NOT_CANONICAL = -8,/* CSR rows not sorted / not loop-free / not symmetric where required */
+    GMSX_ERR_OVERFLOW = -9,     /* ids do not fit int32 (reference: exit(-31), generator.h:41-48) */
+    GMSX_ERR_UNSUPPORTED = -10, /* valid request outside what this build implements */
+    GMSX_ERR_KERNEL = -11       /* a kernel launch or device synchronisation failed */
+};
+const char *gmsx_strerror(int status);
+int gmsx_version(void);
+
+/* =====================================================================================
+ * Host graph substrate  (replaces gms/third_party/gapbs: generator.h, builder.h, reader.h, writer.h)
+ * ===================================================================================== */
+typedef struct gmsx_csr gmsx_csr; /* host-resident CSR, replaces CSRGraph (gapbs/graph.h:93-374) */
+
+enum { GMSX_GEN_KRONECKER = 0, GMSX_GEN_UNIFORM = 1 }; /* "-g kronecker|uniform" (cli/cli.h:111-114) */
+enum {
+    GMSX_RELABEL_NEVER = 0,
+    GMSX_RELABEL_AUTO = 1,  /* relabel by decreasing degree iff WorthRelabelling (gapbs/benchmark.h:158-176) — what parse_and_load does (cli/cli.h:174-176) */
+    GMSX_RELABEL_ALWAYS = 2
+};
+
+/* Generator::GenerateEL + Builder::MakeGraph (+ optional RelabelByDegree): bit-identical CSR to the
+ * reference's "-g kronecker|uniform <scale> --deg <degree>" (generator.h:64-127, builder.h:1642-1660).
+ * threads<=0: OpenMP default.  The output does not depend on the thread count. */
+int gmsx_csr_generate(int generator, int scale, int degree, int relabel, int threads, gmsx_csr **out);
+
+/* Builder::MakeGraphFromEL + SquishGraph on a caller-supplied edge list (builder.h:279-298,237-251):
+ * num_nodes<0 → max id + 1; symmetrize!=0 inserts both directions (the only mode the hot path accepts).
+ * Rows come out sorted, de-duplicated and loop-free. */
+int gmsx_csr_from_edges(int64_t num_nodes, int64_t num_edges, const int32_t *src, const int32_t *dst,
+                        int symmetrize, int relabel, gmsx_csr **out);
+
+/* Reader::ReadFile / ReadSerializedGraph by suffix: ".el" (text pairs, reader.h:49-56) and ".sg"
+ * (binary CSR, reader.h:252-305).  Other suffixes → GMSX_ERR_FORMAT. */
+int gmsx_csr_load(const char *path, int symmetrize, int relabel, gmsx_csr **out);
+/* Writer::WriteSerializedGraph (writer.h:39-69). */
+int gmsx_csr_save_sg(const gmsx_csr *g, const char *path);
+/* Wrap (copy) caller arrays; validates monotone offsets and id range. */
+int gmsx_csr_from_arrays(int64_t n, const int64_t *offsets, const int32_t *neigh, gmsx_csr **out);
+
+int gmsx_csr_worth_relabelling(const gmsx_csr *g);                  /* gapbs/benchmark.h:158-176; 1/0 */
+int gmsx_csr_relabel_by_degree(const gmsx_csr *g, gmsx_csr **out);  /* builder.h:1699-1733 */
+
+int64_t gmsx_csr_num_nodes(const gmsx_csr *g);          /* CSRGraph::num_nodes */
+int64_t gmsx_csr_num_edges(const gmsx_csr *g);          /* CSRGraph::num_edges  (= nnz/2, graph.h:186) */
+int64_t gmsx_csr_num_edges_directed(const gmsx_csr *g); /* nnz */
+const int64_t *gmsx_csr_offsets(const gmsx_csr *g);     /* n+1 entries; valid until gmsx_csr_free */
+const int32_t *gmsx_csr_neighbors(const gmsx_csr *g);   /* nnz entries */
+/* Σ_{(u,v)∈E,u<v}(d_u+d_v): element count behind the algorithmic-bytes figure. */
+uint64_t gmsx_csr_merge_elements(const gmsx_csr *g);
+/* FNV-1a-64 of the offsets / neighbour arrays (loader fingerprints). */
+uint64_t gmsx_csr_fingerprint(const gmsx_csr *g, int which /*0 offsets, 1 neighbours*/);
+void gmsx_csr_free(gmsx_csr *g);
+
+/* =====================================================================================
+ * Device side
+ * ===================================================================================== */
+typedef struct gmsx_graph gmsx_graph; /* device-resident graph; replaces SetGraph<Set> (representations/graphs/set_graph.h:10-233) */
+
+typedef struct gmsx_stats {
+    double kernel_ms;          /* HIP-event time of the counting kernels of the last call (on the library's stream) */
+    double setup_ms;           /* HIP-event time of per-call setup kernels (memsets, bin prep), not in kernel_ms */
+    uint64_t units;            /* work units processed: intersect_count calls (edges) / root vertices */
+    uint64_t alg_elements;     /* Σ(d_u+d_v) over the units of this call, 0 if n/a */
+    uint64_t probes;           /* set-membership probes the kernels actually issued (work-efficiency numerator) */
+    int32_t launches;          /* number of kernel launches inside kernel_ms */
+    int32_t reserved;
+} gmsx_stats;
+
+/* Bind this process to one HIP device.  device<0 → current device. */
+int gmsx_init(int device);
+/* Use a caller-owned HIP stream (hipStream_t passed as void*) for all subsequent launches; NULL → library stream. */
+int gmsx_set_stream(void *hip_stream);
+int gmsx_device_info(char *name, size_t name_len, int *compute_units, int64_t *hbm_bytes);
+
+enum {
+    GMSX_UPLOAD_DEFAULT = 0,
+    GMSX_UPLOAD_TRUSTED = 1 /* skip the device-side check of the canonical-row invariant */
+};
+/* SetGraph::FromCGraph (set_graph.h:86-89,152-181): copies the CSR into HBM and builds the device-side
+ * set representations (degree-oriented DAG rows; the analogue of the per-row SortedSet / RoaringSet
+ * construction, sorted_set.h:64-66 / roaring_set.h:49-54).  Timed by callers as "GraphExec buildTime"
+ * like the reference (common/benchmark.h:105-109). */
+int gmsx_graph_upload(int64_t n, const int64_t *offsets, const int32_t *neigh, uint32_t flags, gmsx_graph **out);
+int gmsx_graph_upload_csr(const gmsx_csr *g, uint32_t flags, gmsx_graph **out);
+int gmsx_graph_free(gmsx_graph *g);
+int64_t gmsx_graph_num_nodes(const gmsx_graph *g);   /* SetGraph::num_nodes, set_graph.h:115-118 */
+int64_t gmsx_graph_num_edges(const gmsx_graph *g);   /* undirected edges m */
+int64_t gmsx_graph_device_bytes(const gmsx_graph *g);
+int32_t gmsx_graph_max_out_degree(const gmsx_graph *g); /* max d+ of the degree-oriented DAG */
+
+/* ---- triangle counting: gms/algorithms/set_based/triangle_count ---- */
+enum {
+    GMSX_TC_AUTO = 0,
+    GMSX_TC_ORIENTED = 1, /* each edge intersects the degree-oriented rows N+(u) ∩ N+(v): every triangle met once */
+    GMSX_TC_FULL = 2      /* the reference's formulation verbatim: every edge u<v intersects the FULL rows, total/3
+                             (parallel/total.h:13-23); all m full-row intersect_count calls are executed on the device */
+};
+/* Par::count_total / Seq::count_total (parallel/total.h:7-24, sequential/total.h:7-23): number of triangles. */
+int gmsx_tc_total(const gmsx_graph *g, int algo, uint64_t *triangles, gmsx_stats *stats);
+/* Shard `part` of `nparts` (cost-balanced, disjoint, covering): returns the UN-divided partial sum so that
+ * Σ_parts partial / gmsx_tc_divisor(algo) = triangles.  This is what each rank computes before the single
+ * all-reduce of SURVEY §8(e) (the OpenMP reduction(+:total) of parallel/total.h:12). */
+int gmsx_tc_partial(const gmsx_graph *g, int algo, int part, int nparts, uint64_t *partial, gmsx_stats *stats);
+int gmsx_tc_divisor(int algo); /* 1 for ORIENTED/AUTO, 3 for FULL */
+/* Par::vertex_count2 / vertex_count2_once (parallel/vertex.h:14-49): counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| (= 2·triangles at u). */
+int gmsx_tc_vertex_count2(const gmsx_graph *g, int64_t *counts /* n, host */, gmsx_stats *stats);
+
+/* ---- generic batched Set::intersect_count (sorted_set.h:176-182 / roaring_set.h:144-152) over graph rows:
+ * out[i] = |N(u[i]) ∩ N(v[i])| on the full rows.  u, v, out are host arrays. */
+int gmsx_intersect_count_batch(const gmsx_graph *g, int64_t n_pairs, const int32_t *u, const int32_t *v,
+                               uint32_t *out, gmsx_stats *stats);
+
+/* ---- k-clique counting: CliqueCount (k_clique_count/k_clique_count_set_based.h:19-31).
+ * *ordered_count = the reference's return value k!·C_k (mod 2^64, like size_t); *cliques = C_k (may be NULL). */
+int gmsx_kclique_count(const gmsx_graph *g, int k, uint64_t *ordered_count, uint64_t *cliques, gmsx_stats *stats);
+int gmsx_kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint64_t *cliques_partial, gmsx_stats *stats);
+
+/* ---- Bron–Kerbosch maximal-clique count: BkEppsteinPar::mceBench with -DBK_COUNT
+ * (maximal_clique_enum/parallel/eppsteinPAR.h:18-53 over sequential/tomita.h:12-86).
+ * rank: n entries in rank format, or NULL → degree rank (preprocessing/parallel/degree.h:26-62).
+ * The count does not depend on the rank. */
+int gmsx_bk_count(const gmsx_graph *g, const int32_t *rank, uint64_t *maximal_cliques, gmsx_stats *stats);
+int gmsx_bk_partial(const gmsx_graph *g, const int32_t *rank, int part, int nparts, uint64_t *partial, gmsx_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GMSX_H */

@@ -1,0 +1,172 @@
+// oracle/ref_shim.cc — TEST INFRASTRUCTURE, not product code.
+//
+// A thin extern "C" driver around the *reference's own headers*, compiled from the sources
+// where they lie under /root/reference (never copied here) by oracle/Makefile into
+// oracle/_ref/libgms_ref.so.  It exists to (1) pin oracle/gms_oracle.c against the real
+// reference and (2) generate the golden vectors under tests/golden/ (tools/make_golden.py).
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+//
+// Reference entry points exercised (paths relative to /root/reference):
+//   loader      gms/common/cli/cli.h:157-184 (parse_and_load: generate/load + WorthRelabelling + RelabelByDegree)
+//   TC          gms/algorithms/set_based/triangle_count/parallel/total.h:7-24, parallel/vertex.h:14-49
+//   k-clique    gms/algorithms/set_based/k_clique_count/k_clique_count_set_based.h:5-31
+//   BK          gms/algorithms/set_based/maximal_clique_enum/parallel/eppsteinPAR.h:18-53 (+ sequential/tomita.h:12-86)
+//   set algebra gms/representations/sets/sorted_set.h:21-272, roaring_set.h:15-229
+#include "gms/third_party/gapbs/benchmark.h"
+#include <gms/common/cli/cli.h>
+#include <gms/common/types.h>
+#include <gms/representations/graphs/set_graph.h>
+#include <gms/common/benchmark.h>
+#include <gms/algorithms/set_based/triangle_count/triangle_count.h>
+#include <gms/algorithms/set_based/k_clique_count/k_clique_count_set_based.h>
+#include <gms/algorithms/set_based/maximal_clique_enum/bron_kerbosch.h>
+
+#include <cstdint>
+#include <cstring>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+using namespace GMS;
+
+namespace {
+struct Quiet {  // the reference prints progress to std::cout; keep the host process quiet
+    std::streambuf *old; std::ostringstream sink;
+    Quiet() : old(std::cout.rdbuf(sink.rdbuf())) {}
+    ~Quiet() { std::cout.rdbuf(old); }
+};
+struct RefGraph { CSRGraph g; };
+
+CSRGraph load(std::vector<std::string> argv_s, bool relabel) {
+    std::vector<char *> argv;
+    for (auto &s : argv_s) argv.push_back(const_cast<char *>(s.c_str()));
+    CLI::Parser parser;
+    if (relabel) {
+        auto [args, g] = parser.parse_and_load((int)argv.size(), argv.data());
+        (void)args;
+        return std::move(g);
+    }
+    CLI::Args args = parser.parse((int)argv.size(), argv.data());
+    return args.load_graph();
+}
+template <class Set> int64_t emit(const Set &s, int32_t *out) {
+    int64_t i = 0;
+    for (auto v : s) out[i++] = (int32_t)v;
+    return i;
+}
+template <class Set>
+int64_t set_op(int op, const int32_t *a, int64_t na, const int32_t *b, int64_t nb, int32_t *out) {
+    Set A(a, (size_t)na), B(b, (size_t)nb);
+    switch (op) {
+        case 0: return (int64_t)A.intersect_count(B);
+        case 1: return emit(A.intersect(B), out);
+        case 2: return emit(A.difference(B), out);
+        case 3: return emit(A.union_with(B), out);
+        case 4: return (int64_t)A.union_count(B);
+        case 5: { A.intersect_inplace(B); return emit(A, out); }
+        case 6: { A.difference_inplace(B); return emit(A, out); }
+        case 7: { A.union_inplace(B); return emit(A, out); }
+        case 8: return (int64_t)A.cardinality();
+        case 9: return nb > 0 ? (int64_t)A.contains(b[0]) : -1;
+        default: return -1;
+    }
+}
+template <class SGraph> uint64_t bk(const CSRGraph &g, int order) {
+    SGraph sg = SGraph::FromCGraph(g);
+    pvector<NodeId> rank(sg.num_nodes());
+    if (order == 0)
+        PpParallel::getDegreeOrdering<SGraph, true, pvector<NodeId>>(sg, rank);
+    else if (order == 1)
+        PpParallel::getDegeneracyOrderingApproxSGraph<PpParallel::boundary_function::averageDegree, true, SGraph, pvector<NodeId>>(sg, rank, 0.001);
+    else
+        PpSequential::getDegeneracyOrderingMatula<SGraph, true, pvector<NodeId>>(sg, rank);
+    BK_CLIQUE_COUNTER = 0;
+    BkEppsteinPar::mceBench<SGraph>(sg, rank);
+    uint64_t c = BK_CLIQUE_COUNTER;
+    BK_CLIQUE_COUNTER = 0;
+    return c;
+}
+}  // namespace
+
+extern "C" {
+
+// kind: 0 = "-g kronecker", 1 = "-g uniform".  relabel: 1 = full parse_and_load behaviour.
+void *ref_graph_generate(int kind, int scale, int deg, int relabel, int threads) {
+    Quiet q;
+    std::vector<std::string> a = {"ref", "-g", kind ? "uniform" : "kronecker", std::to_string(scale),
+                                  "--deg", std::to_string(deg)};
+    if (threads > 0) { a.push_back("-t"); a.push_back(std::to_string(threads)); }
+    return new RefGraph{load(a, relabel != 0)};
+}
+void *ref_graph_file(const char *path, int relabel) {
+    Quiet q;
+    return new RefGraph{load({"ref", "-f", path}, relabel != 0)};
+}
+void ref_graph_free(void *h) { delete static_cast<RefGraph *>(h); }
+int64_t ref_num_nodes(void *h) { return static_cast<RefGraph *>(h)->g.num_nodes(); }
+int64_t ref_nnz(void *h) { return static_cast<RefGraph *>(h)->g.num_edges_directed(); }
+void ref_csr_copy(void *h, int64_t *offsets, int32_t *neigh) {
+    const CSRGraph &g = static_cast<RefGraph *>(h)->g;
+    int64_t n = g.num_nodes(), pos = 0;
+    for (int64_t u = 0; u < n; u++) {
+        offsets[u] = pos;
+        for (NodeId v : g.out_neigh(u)) neigh[pos++] = v;
+    }
+    offsets[n] = pos;
+}
+// set_kind: 0 SortedSet, 1 RoaringSet.  variant: 0 Par::count_total, 1 Seq::count_total
+uint64_t ref_tc_total(void *h, int set_kind, int variant) {
+    Quiet q;
+    const CSRGraph &g = static_cast<RefGraph *>(h)->g;
+    if (set_kind == 0) {
+        auto sg = SortedSetGraph::FromCGraph(g);
+        return variant ? TriangleCount::Seq::count_total(sg) : TriangleCount::Par::count_total(sg);
+    }
+    auto sg = RoaringGraph::FromCGraph(g);
+    return variant ? TriangleCount::Seq::count_total(sg) : TriangleCount::Par::count_total(sg);
+}
+// variant: 0 Par::vertex_count2, 1 Par::vertex_count2_once, 2 Seq::vertex_count2
+void ref_tc_vertex_count2(void *h, int set_kind, int variant, int64_t *out) {
+    Quiet q;
+    const CSRGraph &g = static_cast<RefGraph *>(h)->g;
+    std::vector<int64_t> c;
+    auto run = [&](auto &sg) {
+        if (variant == 0) TriangleCount::Par::vertex_count2(sg, c);
+        else if (variant == 1) { c.assign(sg.num_nodes(), 0); TriangleCount::Par::vertex_count2_once(sg, c); }
+        else TriangleCount::Seq::vertex_count2(sg, c);
+    };
+    if (set_kind == 0) { auto sg = SortedSetGraph::FromCGraph(g); run(sg); }
+    else { auto sg = RoaringGraph::FromCGraph(g); run(sg); }
+    std::memcpy(out, c.data(), c.size() * sizeof(int64_t));
+}
+uint64_t ref_kclique(void *h, int k, int set_kind) {
+    Quiet q;
+    CSRGraph &g = static_cast<RefGraph *>(h)->g;
+    if (set_kind == 0) return CliqueCount<SortedSet, SortedSetGraph, SortedSet>(g, (size_t)k);
+    return CliqueCount<RoaringSet, RoaringGraph, RoaringSet>(g, (size_t)k);
+}
+// order: 0 degree rank, 1 ADG (eps 0.001, as the driver), 2 Matula degeneracy
+uint64_t ref_bk_count(void *h, int set_kind, int order) {
+    Quiet q;
+    const CSRGraph &g = static_cast<RefGraph *>(h)->g;
+    return set_kind == 0 ? bk<SortedSetGraph>(g, order) : bk<RoaringGraph>(g, order);
+}
+// rank vectors as the BK driver computes them (for pinning our own rank providers)
+void ref_rank(void *h, int order, int32_t *out) {
+    Quiet q;
+    const CSRGraph &g = static_cast<RefGraph *>(h)->g;
+    auto sg = SortedSetGraph::FromCGraph(g);
+    pvector<NodeId> rank(sg.num_nodes());
+    if (order == 0) PpParallel::getDegreeOrdering<SortedSetGraph, true, pvector<NodeId>>(sg, rank);
+    else if (order == 1)
+        PpParallel::getDegeneracyOrderingApproxSGraph<PpParallel::boundary_function::averageDegree, true, SortedSetGraph, pvector<NodeId>>(sg, rank, 0.001);
+    else PpSequential::getDegeneracyOrderingMatula<SortedSetGraph, true, pvector<NodeId>>(sg, rank);
+    for (int64_t i = 0; i < sg.num_nodes(); i++) out[i] = rank[i];
+}
+// op codes: see set_op above.  `out` must hold na+nb elements.  Returns count / cardinality.
+int64_t ref_set_op(int set_kind, int op, const int32_t *a, int64_t na, const int32_t *b, int64_t nb, int32_t *out) {
+    return set_kind == 0 ? set_op<SortedSet>(op, a, na, b, nb, out) : set_op<RoaringSet>(op, a, na, b, nb, out);
+}
+int ref_omp_threads(void) { return omp_get_max_threads(); }
+}
