@@ -240,7 +240,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     GMSX_HIP(hipGetLastError());
 
     if (st) {  // untimed bookkeeping
-        const int64_t hi = g->bin_end[6];
+        const int64_t hi = g->n;  // every oriented edge is a unit, also those of pivots with d+ < 2 (no work)
         const int64_t cnt = part_count(0, hi, nparts, part);
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);

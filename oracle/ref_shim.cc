@@ -21,7 +21,11 @@
 #include <gms/algorithms/set_based/k_clique_count/k_clique_count_set_based.h>
 #include <gms/algorithms/set_based/maximal_clique_enum/bron_kerbosch.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <iostream>
 #include <sstream>
@@ -31,10 +35,19 @@
 using namespace GMS;
 
 namespace {
-struct Quiet {  // the reference prints progress to std::cout; keep the host process quiet
-    std::streambuf *old; std::ostringstream sink;
-    Quiet() : old(std::cout.rdbuf(sink.rdbuf())) {}
-    ~Quiet() { std::cout.rdbuf(old); }
+struct Quiet {  // the reference prints progress to std::cout and printf; keep the host process quiet
+    std::streambuf *old; std::ostringstream sink; int saved_fd;
+    Quiet() : old(std::cout.rdbuf(sink.rdbuf())) {
+        std::fflush(stdout);
+        saved_fd = dup(1);
+        int devnull = open("/dev/null", O_WRONLY);
+        if (devnull >= 0) { dup2(devnull, 1); close(devnull); }
+    }
+    ~Quiet() {
+        std::fflush(stdout);
+        if (saved_fd >= 0) { dup2(saved_fd, 1); close(saved_fd); }
+        std::cout.rdbuf(old);
+    }
 };
 struct RefGraph { CSRGraph g; };
 

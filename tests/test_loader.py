@@ -1,0 +1,112 @@
+"""CPU: the host graph substrate (gms_amd/csrc/host/loader.cpp) against the reference loader's fingerprints
+(SURVEY.md Appendix B = tests/golden/graphs.json) and, when present, the compiled reference's arrays."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, edges_to_csr, host_graph, load_golden
+
+GRAPHS = load_golden("graphs.json")
+FP = [k for k, v in GRAPHS.items() if "offsets_fnv64" in v and v["scale"] <= 16]
+
+
+@pytest.mark.parametrize("key", FP)
+def test_fingerprints(capi, key):
+    rec = GRAPHS[key]
+    csr = host_graph(capi, rec["generator"], rec["scale"], rec["degree"], rec["relabel"])
+    fo, fn = csr.fingerprint()
+    assert (csr.num_nodes, csr.num_edges) == (rec["n"], rec["m"])
+    assert "%016x" % fo == rec["offsets_fnv64"] and "%016x" % fn == rec["neigh_fnv64"]
+
+
+def test_fingerprint_scale18_and_thread_independence(capi):
+    rec = GRAPHS["kronecker-18-16-relabel"]
+    a = capi.HostCSR.generate("kronecker", 18, 16, capi.RELABEL_AUTO, threads=0)
+    assert ["%016x" % x for x in a.fingerprint()] == [rec["offsets_fnv64"], rec["neigh_fnv64"]]
+    raw = GRAPHS["kronecker-14-16-raw"]
+    for t in (1, 3):
+        b = capi.HostCSR.generate("kronecker", 14, 16, capi.RELABEL_NEVER, threads=t)
+        assert ["%016x" % x for x in b.fingerprint()] == [raw["offsets_fnv64"], raw["neigh_fnv64"]]
+
+
+def test_rows_are_canonical(capi):
+    csr = host_graph(capi, "kronecker", 12)
+    off, ng = csr.offsets(), csr.neighbors()
+    n = csr.num_nodes
+    assert off[0] == 0 and off[-1] == ng.size == 2 * csr.num_edges
+    src = np.repeat(np.arange(n), np.diff(off))
+    assert (ng != src).all()                                  # no self loops
+    same_row = src[1:] == src[:-1]
+    assert (ng[1:][same_row] > ng[:-1][same_row]).all()       # strictly ascending rows
+    fwd = set(zip(src.tolist(), ng.tolist()))
+    assert all((v, u) in fwd for u, v in list(fwd)[:5000])    # symmetric
+    deg = np.diff(off)
+    assert (deg[:-1] >= deg[1:]).all()                        # relabelled by decreasing degree (builder.h:1699-1733)
+
+
+def test_relabel_heuristic(capi):
+    assert host_graph(capi, "kronecker", 12, relabel=False).worth_relabelling()
+    assert not host_graph(capi, "uniform", 10, relabel=False).worth_relabelling()
+    raw = host_graph(capi, "kronecker", 10, relabel=False)
+    rel = raw.relabel_by_degree()
+    assert ["%016x" % x for x in rel.fingerprint()] == [GRAPHS["kronecker-10-16-relabel"][k] for k in ("offsets_fnv64", "neigh_fnv64")]
+
+
+def test_from_edges_and_files(capi, tmp_path):
+    # duplicates, both directions, a self loop, an isolated middle vertex: n = max id + 1 (builder.h:284-285)
+    csr = edges_to_csr(capi, [(0, 1), (1, 0), (0, 1), (2, 2), (5, 0)])
+    assert csr.num_nodes == 6 and csr.num_edges == 2
+    assert csr.offsets().tolist() == [0, 2, 3, 3, 3, 3, 4] and csr.neighbors().tolist() == [1, 5, 0, 0]
+    # .el text and .sg binary round trips
+    el = tmp_path / "g.el"
+    el.write_text("0 1\n1 2\n2 0\n3 4\n")
+    a = capi.HostCSR.load(str(el), relabel=capi.RELABEL_NEVER)
+    assert a.num_nodes == 5 and a.num_edges == 4
+    sg = tmp_path / "g.sg"
+    a.save_sg(str(sg))
+    b = capi.HostCSR.load(str(sg), relabel=capi.RELABEL_NEVER)
+    assert a.fingerprint() == b.fingerprint()
+    raw = sg.read_bytes()  # writer.h:39-69: bool directed; int64 nnz; int64 n; offsets; neigh
+    assert raw[0] == 0 and np.frombuffer(raw[1:17], dtype=np.int64).tolist() == [8, 5]
+    assert len(raw) == 1 + 16 + 6 * 8 + 8 * 4
+    big = host_graph(capi, "kronecker", 10)
+    big.save_sg(str(tmp_path / "k10.sg"))
+    assert capi.HostCSR.load(str(tmp_path / "k10.sg"), relabel=capi.RELABEL_NEVER).fingerprint() == big.fingerprint()
+
+
+def test_empty_and_errors(capi, tmp_path):
+    e = capi.HostCSR.from_edges(np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert e.num_nodes == 1 and e.num_edges == 0          # FindMaxNodeId starts at 0 (builder.h:108-117)
+    with pytest.raises(capi.GmsxError) as ei:
+        capi.HostCSR.load(str(tmp_path / "missing.el"))
+    assert ei.value.status == capi.ERR_IO
+    (tmp_path / "x.foo").write_text("0 1\n")
+    with pytest.raises(capi.GmsxError) as ei:
+        capi.HostCSR.load(str(tmp_path / "x.foo"))
+    assert ei.value.status == capi.ERR_FORMAT
+    with pytest.raises(capi.GmsxError) as ei:
+        capi.HostCSR.generate("kronecker", 31)
+    assert ei.value.status == capi.ERR_OVERFLOW
+    with pytest.raises(capi.GmsxError) as ei:
+        capi.HostCSR.from_arrays(np.array([0, 2, 1], dtype=np.int64), np.array([1, 0], dtype=np.int32))
+    assert ei.value.status == capi.ERR_INVALID
+
+
+def test_reference_test_graph_files_load(capi):
+    tg = load_golden("testgraphs.json")
+    for name, rec in tg.items():
+        csr = capi.HostCSR.load(os.path.join(GOLDEN, "testGraphs", name))
+        assert (csr.num_nodes, csr.num_edges) == (rec["n"], rec["m"])
+
+
+@pytest.mark.parametrize("spec", [("kronecker", 13, 16, True), ("kronecker", 9, 3, True), ("uniform", 12, 16, True), ("kronecker", 16, 16, False)])
+def test_arrays_equal_compiled_reference(capi, reference, spec):
+    kind, scale, deg, relabel = spec
+    g = reference.generate(kind, scale, deg, relabel=relabel)
+    try:
+        off, ng = reference.csr(g)
+        csr = capi.HostCSR.generate(kind, scale, deg, capi.RELABEL_AUTO if relabel else capi.RELABEL_NEVER)
+        assert np.array_equal(csr.offsets(), off) and np.array_equal(csr.neighbors(), ng)
+    finally:
+        reference.free(g)

@@ -1,0 +1,150 @@
+"""CPU: pins the oracle (oracle/gms_oracle.c) against the golden vectors generated from the compiled reference
+(tools/make_golden.py) and, when oracle/_ref is present, against the compiled reference directly."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, edges_to_csr, host_graph, load_golden
+
+
+def test_set_ops_literal_cases(oracle):
+    for case in load_golden("set_ops.json")["cases"]:
+        a, b, exp = oracle.make_set(case["a"]), oracle.make_set(case["b"]), case["expect"]
+        assert oracle.intersect_count(a, b) == exp["intersect_count"]
+        assert oracle.intersect_count(b, a) == exp["intersect_count"]  # symmetric (testing/sets.cpp:108-115)
+        assert oracle.intersect(a, b).tolist() == exp["intersect"] == exp["intersect_inplace"]
+        assert oracle.difference(a, b).tolist() == exp["difference"] == exp["difference_inplace"]
+        assert oracle.union(a, b).tolist() == exp["union"] == exp["union_inplace"]
+        assert oracle.union_count(a, b) == exp["union_count"]
+        assert a.size == exp["cardinality"]
+
+
+def test_set_ops_random_cases(oracle):
+    z = np.load(os.path.join(GOLDEN, "set_ops_random.npz"))
+    i = 0
+    while f"a{i}" in z:
+        a, b = oracle.make_set(z[f"a{i}"]), oracle.make_set(z[f"b{i}"])
+        ic, uc, card = (int(x) for x in z[f"counts{i}"])
+        assert oracle.intersect_count(a, b) == ic and oracle.union_count(a, b) == uc and a.size == card
+        assert np.array_equal(oracle.intersect(a, b), z[f"intersect{i}"])
+        assert np.array_equal(oracle.difference(a, b), z[f"difference{i}"])
+        assert np.array_equal(oracle.union(a, b), z[f"union{i}"])
+        i += 1
+    assert i >= 10
+
+
+GRAPHS = load_golden("graphs.json")
+SMALL = [k for k, v in GRAPHS.items() if v.get("scale", 99) <= 14 and "offsets_fnv64" in v]
+
+
+@pytest.mark.parametrize("key", SMALL)
+def test_graph_counts_match_reference_goldens(oracle, capi, key):
+    rec = GRAPHS[key]
+    csr = host_graph(capi, rec["generator"], rec["scale"], rec["degree"], rec["relabel"])
+    off, ng = csr.offsets(), csr.neighbors()
+    assert (csr.num_nodes, csr.num_edges) == (rec["n"], rec["m"])
+    if "triangles" in rec:
+        t, raw = oracle.tc_total(off, ng, raw=True)
+        assert raw % 3 == 0 and t == rec["triangles"]
+    for k in (3, 4, 5):
+        if f"kc{k}" in rec and (rec["scale"] <= 12 or k == 3):
+            assert oracle.kclique(off, ng, k) == rec[f"kc{k}"]
+    if "bk" in rec and rec["scale"] <= 12:
+        assert oracle.bk_count(off, ng) == rec["bk"]
+
+
+def test_kclique_s14_k4(oracle, capi):
+    rec = GRAPHS["kronecker-14-16-relabel"]
+    csr = host_graph(capi, "kronecker", 14)
+    assert oracle.kclique(csr.offsets(), csr.neighbors(), 4) == rec["kc4"]
+
+
+def test_vertex_count2(oracle, capi):
+    z = np.load(os.path.join(GOLDEN, "vertex_count2.npz"))
+    for key in z.files:
+        rec = GRAPHS[key]
+        csr = host_graph(capi, rec["generator"], rec["scale"], rec["degree"], rec["relabel"])
+        off, ng = csr.offsets(), csr.neighbors()
+        assert np.array_equal(oracle.tc_vertex_count2(off, ng), z[key])
+        assert np.array_equal(oracle.tc_vertex_count2(off, ng, once=True), z[key])
+        assert int(z[key].sum()) == 6 * rec["triangles"]  # verifier.h:44-85: 3*T == Σ counts / 2
+
+
+def test_reference_test_graphs(oracle, capi):
+    tg = load_golden("testgraphs.json")
+    assert tg["triangles_3.el"]["triangles"] == 3 and tg["triangles_3.el"]["bk"] == 7
+    for name, rec in tg.items():
+        csr = capi.HostCSR.load(os.path.join(GOLDEN, "testGraphs", name))
+        off, ng = csr.offsets(), csr.neighbors()
+        assert off.tolist() == rec["offsets"] and ng.tolist() == rec["neigh"]
+        assert oracle.tc_total(off, ng) == rec["triangles"]
+        assert oracle.kclique(off, ng, 3) == rec["kc3"] and oracle.kclique(off, ng, 4) == rec["kc4"]
+        assert oracle.bk_count(off, ng) == rec["bk"]
+
+
+def test_known_answers(oracle, capi):
+    ka = load_golden("known_answers.json")
+    fact = {2: 2, 3: 6, 4: 24}
+    for c in ka["kclique"]:  # testing/clique_counting/CliqueCounter2_tests.h:45-271
+        csr = edges_to_csr(capi, c["edges"])
+        off, ng = csr.offsets(), csr.neighbors()
+        assert oracle.kclique(off, ng, c["k"]) == c["ordered"] == fact[c["k"]] * c["cliques"], c["name"]
+        assert oracle.tc_total(off, ng) == c["triangles"] and oracle.bk_count(off, ng) == c["bk"]
+    for c in ka["bk_random"]:  # concrete instances of testing/bron_kerbosch.cpp:256-268
+        csr = edges_to_csr(capi, c["edges"], n=c["n"])
+        off, ng = csr.offsets(), csr.neighbors()
+        assert oracle.bk_count(off, ng) == c["bk"]
+        assert oracle.bk_count(off, ng, rank=np.arange(c["n"], dtype=np.int32)) == c["bk"]  # rank-independent
+        assert oracle.tc_total(off, ng) == c["triangles"] and oracle.kclique(off, ng, 4) == c["kc4"]
+
+
+def test_sample_covers_the_whole_loop(oracle, capi):
+    csr = host_graph(capi, "kronecker", 10)
+    off, ng = csr.offsets(), csr.neighbors()
+    _, raw = oracle.tc_total(off, ng, raw=True)
+    parts = [oracle.tc_total_sample(off, ng, 5, p) for p in range(5)]
+    assert sum(p[0] for p in parts) == raw
+    assert sum(p[1] for p in parts) == csr.num_edges
+    assert sum(p[2] for p in parts) == oracle.tc_elements(off, ng) == csr.merge_elements()
+
+
+def test_edge_cases(oracle):
+    off = np.zeros(1, dtype=np.int64)
+    ng = np.zeros(0, dtype=np.int32)
+    assert oracle.tc_total(off, ng) == 0 and oracle.kclique(off, ng, 4) == 0 and oracle.bk_count(off, ng) == 0
+    off = np.zeros(4, dtype=np.int64)  # three isolated vertices: each is a maximal clique (eppsteinPAR.h:32-47)
+    assert oracle.bk_count(off, ng) == 3 and oracle.tc_total(off, ng) == 0
+
+
+# ---- against the compiled reference itself (when oracle/_ref is present) --------------------------------
+
+@pytest.mark.parametrize("spec", [("kronecker", 9, 8), ("kronecker", 11, 16), ("uniform", 11, 12), ("kronecker", 7, 30)])
+def test_oracle_equals_compiled_reference(oracle, reference, spec):
+    kind, scale, deg = spec
+    g = reference.generate(kind, scale, deg, relabel=True)
+    try:
+        off, ng = reference.csr(g)
+        assert oracle.tc_total(off, ng) == reference.tc_total(g, 0) == reference.tc_total(g, 1)
+        assert oracle.kclique(off, ng, 4) == reference.kclique(g, 4, 0)
+        assert oracle.kclique(off, ng, 5) == reference.kclique(g, 5, 1)
+        assert oracle.bk_count(off, ng) == reference.bk_count(g, 1, 0) == reference.bk_count(g, 0, 2)
+        assert np.array_equal(oracle.tc_vertex_count2(off, ng), reference.tc_vertex_count2(g, 0, 0))
+        assert np.array_equal(oracle.degree_rank(off), reference.rank(g, 0))
+    finally:
+        reference.free(g)
+
+
+def test_set_ops_against_compiled_reference(oracle, reference):
+    rng = np.random.default_rng(7)
+    for _ in range(200):
+        hi = int(rng.choice([8, 64, 1000, 1 << 17, 1 << 24]))
+        a = rng.choice(hi, size=int(rng.integers(0, min(hi, 400))), replace=False).astype(np.int32)
+        b = rng.choice(hi, size=int(rng.integers(0, min(hi, 400))), replace=False).astype(np.int32)
+        sa, sb = oracle.make_set(a), oracle.make_set(b)
+        for kind in (0, 1):
+            assert oracle.intersect_count(sa, sb) == reference.set_op(kind, "intersect_count", a, b)
+            assert np.array_equal(oracle.intersect(sa, sb), np.sort(reference.set_op(kind, "intersect", a, b)))
+            assert np.array_equal(oracle.difference(sa, sb), np.sort(reference.set_op(kind, "difference", a, b)))
+            assert np.array_equal(oracle.union(sa, sb), np.sort(reference.set_op(kind, "union", a, b)))
+            assert oracle.union_count(sa, sb) == reference.set_op(kind, "union_count", a, b)

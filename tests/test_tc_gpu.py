@@ -1,0 +1,141 @@
+"""GPU parity tests of the HIP triangle-count path, called through the C-ABI (include/gmsx.h) and compared with the
+oracle on the same inputs (bit-exact: integer counts), with the committed reference goldens, and — at sizes the
+oracle cannot finish — with reference goldens / size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, edges_to_csr, host_graph, load_golden
+
+pytestmark = pytest.mark.gpu
+GRAPHS = load_golden("graphs.json")
+
+
+def upload(gpu, csr, **kw):
+    return gpu.DeviceGraph.from_csr(csr, **kw)
+
+
+@pytest.mark.parametrize("key", [k for k, v in GRAPHS.items() if "triangles" in v and v["scale"] <= 18])
+def test_tc_equals_reference_golden_and_oracle(gpu, oracle, key):
+    rec = GRAPHS[key]
+    csr = host_graph(gpu, rec["generator"], rec["scale"], rec["degree"], rec["relabel"])
+    g = upload(gpu, csr)
+    assert (g.num_nodes, g.num_edges) == (rec["n"], rec["m"])
+    t, st = g.tc_total(stats=True)
+    assert t == rec["triangles"]
+    if rec["scale"] <= 14:
+        assert t == oracle.tc_total(csr.offsets(), csr.neighbors())
+    assert st["units"] == rec["m"] and st["alg_elements"] == csr.merge_elements() and st["kernel_ms"] > 0
+    g.free()
+
+
+@pytest.mark.parametrize("spec", [("kronecker", 9, 3), ("kronecker", 13, 40), ("uniform", 13, 30), ("kronecker", 15, 8), ("uniform", 8, 100)])
+def test_tc_other_shapes_vs_oracle(gpu, oracle, spec):
+    kind, scale, deg = spec
+    for relabel in (True, False):
+        csr = host_graph(gpu, kind, scale, deg, relabel)
+        g = upload(gpu, csr)
+        assert g.tc_total() == oracle.tc_total(csr.offsets(), csr.neighbors())
+        assert g.tc_total(gpu.TC_ORIENTED) == g.tc_total(gpu.TC_AUTO)
+        g.free()
+
+
+def test_partials_cover_the_graph_exactly_once(gpu):
+    csr = host_graph(gpu, "kronecker", 15)
+    g = upload(gpu, csr)
+    total = g.tc_total()
+    for nparts in (1, 2, 3, 8):
+        parts = [g.tc_partial(p, nparts, stats=True) for p in range(nparts)]
+        assert sum(p[0] for p in parts) == total * gpu.lib().gmsx_tc_divisor(gpu.TC_AUTO)
+        assert sum(p[1]["units"] for p in parts) == csr.num_edges
+    g.free()
+
+
+def test_reference_test_graphs_and_known_answers(gpu, oracle):
+    for name, rec in load_golden("testgraphs.json").items():
+        csr = gpu.HostCSR.load(os.path.join(GOLDEN, "testGraphs", name))
+        g = upload(gpu, csr)
+        assert g.tc_total() == rec["triangles"], name
+        g.free()
+    ka = load_golden("known_answers.json")
+    for c in ka["kclique"] + ka["bk_random"]:
+        csr = edges_to_csr(gpu, c["edges"], n=c.get("n", -1))
+        g = upload(gpu, csr)
+        assert g.tc_total() == c["triangles"]
+        g.free()
+
+
+def test_edge_cases(gpu):
+    # empty graph (n = 1, no edges), isolated vertices, one edge, a star (no triangles), K_n, a long path
+    for edges, n, expect in [([], -1, 0), ([(0, 1)], 5, 0), ([(0, i) for i in range(1, 300)], -1, 0),
+                             ([(i, i + 1) for i in range(1000)], -1, 0)]:
+        g = upload(gpu, edges_to_csr(gpu, edges, n=n))
+        assert g.tc_total() == expect
+        g.free()
+    for k in (3, 4, 65, 130, 700):  # complete graphs: C(k,3); k=700 exercises the workgroup kernels with d+ up to 699
+        iu = np.triu_indices(k, 1)
+        csr = gpu.HostCSR.from_edges(iu[0].astype(np.int32), iu[1].astype(np.int32))
+        g = upload(gpu, csr)
+        assert g.tc_total() == k * (k - 1) * (k - 2) // 6
+        assert g.max_out_degree == k - 1
+        g.free()
+
+
+def test_large_out_degree_tiles(gpu, oracle):
+    """A dense block big enough that pivot rows exceed every table bin (d+ up to ~3000) plus random sparse noise."""
+    rng = np.random.default_rng(3)
+    k = 3000
+    keep = rng.random((k, k)) < 0.35
+    iu = np.triu_indices(k, 1)
+    sel = keep[iu]
+    src, dst = iu[0][sel].astype(np.int32), iu[1][sel].astype(np.int32)
+    csr = gpu.HostCSR.from_edges(src, dst)
+    g = upload(gpu, csr)
+    a = np.zeros((k, k), dtype=np.float32)
+    a[src, dst] = 1
+    a[dst, src] = 1
+    expect = int(round(np.trace(a @ a @ a))) // 6  # exact in fp32? no: use float64 for the trace
+    expect = int(round(np.einsum("ij,ji->", (a.astype(np.float64) @ a), a))) // 6
+    assert g.tc_total() == expect
+    g.free()
+
+
+def test_upload_rejects_non_canonical_input(gpu):
+    off = np.array([0, 2, 3, 4], dtype=np.int64)
+    bad_sorted = np.array([2, 1, 0, 0], dtype=np.int32)       # row 0 not ascending
+    asym = np.array([1, 2, 0, 1], dtype=np.int32)             # 2 -> 1 but 1 -/-> 2
+    loop = np.array([0, 1, 0, 0], dtype=np.int32)
+    for arr in (bad_sorted, asym, loop):
+        with pytest.raises(gpu.GmsxError) as ei:
+            gpu.DeviceGraph.upload(off, arr)
+        assert ei.value.status == gpu.ERR_NOT_CANONICAL
+    with pytest.raises(gpu.GmsxError) as ei:
+        gpu.DeviceGraph.upload(off, np.array([1, 7, 0, 0], dtype=np.int32))
+    assert ei.value.status == gpu.ERR_NOT_CANONICAL
+
+
+def test_relabel_invariance_and_golden_scale20(gpu):
+    """Counts are label-invariant (the loader's relabel only shapes locality): raw and relabelled graphs agree,
+    and scale 20 matches the reference golden 423 625 371."""
+    a = host_graph(gpu, "kronecker", 16, relabel=False)
+    b = host_graph(gpu, "kronecker", 16, relabel=True)
+    ga, gb = upload(gpu, a), upload(gpu, b)
+    assert ga.tc_total() == gb.tc_total() == GRAPHS["kronecker-16-16-relabel"]["triangles"]
+    ga.free(), gb.free()
+    csr = gpu.HostCSR.generate("kronecker", 20)
+    g = upload(gpu, csr)
+    assert g.tc_total() == GRAPHS["kronecker-20-16-relabel"]["triangles"]
+    g.free()
+
+
+@pytest.mark.skipif(os.environ.get("GMSX_FULL_SIZE", "0") != "1", reason="set GMSX_FULL_SIZE=1: generates RMAT scale 24 (~1 min, ~12 GB host)")
+def test_config2_scale24_golden(gpu):
+    rec = GRAPHS["kronecker-24-16-relabel"]
+    csr = gpu.HostCSR.generate("kronecker", 24)
+    assert (csr.num_nodes, csr.num_edges) == (rec["n"], rec["m"]) and csr.merge_elements() == rec["merge_elements"]
+    g = upload(gpu, csr, flags=gpu.UPLOAD_DEFAULT)
+    assert g.tc_total() == rec["triangles"]
+    parts = [g.tc_partial(p, 8) for p in range(8)]
+    assert sum(parts) == rec["triangles"]
+    g.free()
