@@ -37,10 +37,13 @@ def cpu_baseline(csr, seconds):
     cores = O.max_threads()
     total_elems = csr.merge_elements()
     m = csr.num_edges
-    # ~0.3e9 merged ids/s/thread is what the scalar two-pointer merge sustains; size the sample for `seconds`
-    target = seconds * 0.3e9 * cores
-    stride = max(1, int(round(total_elems / max(target, 1.0))))
-    phase = stride // 2  # vertex `phase`, `phase+stride`, … (avoids handing the single biggest hub to a tiny sample)
+    # calibrate on a ~1 s sample, then size the real sample for `seconds` (the rate depends heavily on the host)
+    stride = max(1, int(round(total_elems / (0.1e9 * cores))))
+    t0 = time.perf_counter()
+    _, _, e0 = O.tc_total_sample(off, ng, stride, stride // 2)
+    rate0 = e0 / max(time.perf_counter() - t0, 1e-6)
+    stride = max(1, int(round(total_elems / max(seconds * rate0, 1.0))))
+    phase = stride // 2  # vertices phase, phase+stride, … (a tiny sample is not handed the single biggest hub)
     t0 = time.perf_counter()
     raw, edges, elems = O.tc_total_sample(off, ng, stride, phase)
     dt = time.perf_counter() - t0
