@@ -209,7 +209,8 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     if (!(flags & GMSX_UPLOAD_TRUSTED) && m * 2 != g->nnz) return GMSX_ERR_NOT_CANONICAL;
 
     // 3. DAG rows
-    if (int rc = dmalloc(&g->dadj, m, g)) return rc;
+    if (int rc = dmalloc(&g->dadj, m + 8, g)) return rc;  // +8: the 16-byte row loads of the count kernels may overrun the last row
+    GMSX_HIP(hipMemsetAsync(g->dadj + m, 0xff, 8 * sizeof(int32_t), s));
     if (n > 0) hipLaunchKernelGGL(k_fill_dag, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, g->doff, g->dadj);
 
     // 4. work-sorted launch order: vertices by decreasing d+, plus the bin boundaries

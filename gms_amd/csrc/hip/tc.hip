@@ -46,6 +46,56 @@ __device__ __forceinline__ int64_t readlane64(int64_t x, int l) {
     return int64_t((uint64_t(hi) << 32) | lo);
 }
 
+// 4-byte-aligned 16-byte load: rows start at arbitrary dword offsets, the hardware only needs dword alignment
+struct __attribute__((packed, aligned(4))) i4u { int32_t x, y, z, w; };
+
+__device__ __forceinline__ unsigned probe4(const int32_t *tbl, uint32_t mask, int shift, i4u w, int valid) {
+    // first-slot reads of the four ids are issued together (four LDS reads in flight); at load <= 0.25 most
+    // probes resolve there, the rest continue down the chain
+    const uint32_t h0 = hash_slot(w.x, shift), h1 = hash_slot(w.y, shift), h2 = hash_slot(w.z, shift), h3 = hash_slot(w.w, shift);
+    const int32_t x0 = tbl[h0], x1 = tbl[h1], x2 = tbl[h2], x3 = tbl[h3];
+    unsigned c = 0;
+    if (valid > 0) { if (x0 == w.x) c++; else if (x0 != -1) c += set_contains(tbl, mask, shift, w.x); }
+    if (valid > 1) { if (x1 == w.y) c++; else if (x1 != -1) c += set_contains(tbl, mask, shift, w.y); }
+    if (valid > 2) { if (x2 == w.z) c++; else if (x2 != -1) c += set_contains(tbl, mask, shift, w.z); }
+    if (valid > 3) { if (x3 == w.w) c++; else if (x3 != -1) c += set_contains(tbl, mask, shift, w.w); }
+    return c;
+}
+
+// Streams `rows` rows against the LDS set.  Lane l holds the extent (rb, rl) of row l.  The wave works as four
+// 16-lane groups, each streaming its own row with 16-byte loads (64 ids per group step, two steps in flight), so a
+// wave keeps up to eight independent 256-byte requests outstanding instead of one.
+__device__ __forceinline__ unsigned long long scan_rows(const int32_t *tbl, uint32_t mask, int shift,
+                                                        const int32_t *__restrict__ dadj, int64_t rb, int rl, int rows,
+                                                        int lane) {
+    const int grp = lane >> 4, sub4 = (lane & 15) * 4;
+    unsigned long long cnt = 0;
+    for (int r0 = 0; r0 < rows; r0 += 4) {
+        // extents of rows r0..r0+3 through wave-uniform readlanes (lanes >= rows hold length 0), then a per-group
+        // select: a per-lane __shfl here gets sunk under the row-count predicate by the compiler and then reads
+        // inactive lanes
+        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
+        const int64_t b0 = readlane64(rb, m0), b1 = readlane64(rb, m1), b2 = readlane64(rb, m2), b3 = readlane64(rb, m3);
+        const int l0 = __builtin_amdgcn_readlane(rl, m0), l1 = __builtin_amdgcn_readlane(rl, m1),
+                  l2 = __builtin_amdgcn_readlane(rl, m2), l3 = __builtin_amdgcn_readlane(rl, m3);
+        const int64_t b = grp == 0 ? b0 : grp == 1 ? b1 : grp == 2 ? b2 : b3;
+        const int l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
+        const int32_t *row = dadj + b;
+        int j = sub4;
+        for (; j + 64 < l; j += 128) {  // two 64-id steps per iteration
+            const i4u a = *reinterpret_cast<const i4u *>(row + j);
+            const i4u c = *reinterpret_cast<const i4u *>(row + j + 64);
+            cnt += probe4(tbl, mask, shift, a, 4);
+            cnt += probe4(tbl, mask, shift, c, l - (j + 64));
+        }
+        if (j < l) {
+            const i4u a = *reinterpret_cast<const i4u *>(row + j);
+            cnt += probe4(tbl, mask, shift, a, l - j);
+        }
+    }
+    return cnt;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Workgroup per pivot (d+ >= 64).  256 threads = 4 waves share one LDS set; wave w streams the rows of the
 // pivot-list entries w, w+4, ….  Pivot rows longer than half the table are processed in tiles.
@@ -85,11 +135,7 @@ __global__ __launch_bounds__(256) void k_tc_oriented_block(const int64_t *__rest
                 rl = int(doff[v + 1] - rb);
             }
             const int rows = min(64, (dp - base - wave + 3) >> 2);
-            for (int r = 0; r < rows; ++r) {
-                const int64_t b = readlane64(rb, r);
-                const int l = __builtin_amdgcn_readlane(rl, r);
-                for (int j = lane; j < l; j += 64) cnt += set_contains(tbl, mask, shift, dadj[b + j]);
-            }
+            cnt += scan_rows(tbl, mask, shift, dadj, rb, rl, rows, lane);
         }
     }
     for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
@@ -134,11 +180,7 @@ __global__ __launch_bounds__(256) void k_tc_oriented_wave(const int64_t *__restr
             rl = int(doff[v + 1] - rb);
         }
         __builtin_amdgcn_wave_barrier();
-        for (int r = 0; r < dp; ++r) {
-            const int64_t b = readlane64(rb, r);
-            const int l = __builtin_amdgcn_readlane(rl, r);
-            for (int j = lane; j < l; j += 64) cnt += set_contains(tbl, MASK, SHIFT, dadj[b + j]);
-        }
+        cnt += scan_rows(tbl, MASK, SHIFT, dadj, rb, rl, dp, lane);
         __builtin_amdgcn_wave_barrier();
     }
     for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
