@@ -23,12 +23,6 @@ int ensure_init() { return ctx().device >= 0 ? GMSX_OK : gmsx_init(-1); }
 
 // ---- preprocessing kernels ------------------------------------------------------------------
 
-__device__ __forceinline__ bool oriented_before(int64_t du, int32_t u, int64_t dv, int32_t v) {
-    // u -> v  iff  (deg u, u) < (deg v, v): edges point from the lower- to the higher-degree endpoint,
-    // which bounds d+ by O(sqrt(m)) on any graph.
-    return du < dv || (du == dv && u < v);
-}
-
 // One wave per row: checks the canonical-row invariant and accumulates Σ_{u<v}(d_u+d_v) and max degree.
 // flags[0] |= 1 unsorted/duplicate, 2 id out of range, 4 self loop, 8 asymmetric
 __global__ __launch_bounds__(256) void k_validate(int64_t n, const int64_t *__restrict__ off,
@@ -74,70 +68,99 @@ __global__ __launch_bounds__(256) void k_validate(int64_t n, const int64_t *__re
     }
 }
 
-// d+ per vertex (as int64 so the exclusive scan runs in 64 bits)
-__global__ __launch_bounds__(256) void k_out_degree(int64_t n, const int64_t *__restrict__ off,
-                                                    const int32_t *__restrict__ adj, int64_t *__restrict__ dplus) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
-    for (int64_t u = wave0; u < n; u += nwaves) {
-        const int64_t b = off[u], e = off[u + 1];
-        const int64_t du = e - b;
-        int c = 0;
-        for (int64_t j = b + lane; j < e; j += 64) {
-            const int32_t v = adj[j];
-            c += oriented_before(du, int32_t(u), off[v + 1] - off[v], v) ? 1 : 0;
-        }
-        for (int s = 32; s > 0; s >>= 1) c += __shfl_down(c, s);
-        if (lane == 0) dplus[u] = c;
-    }
+// ---- rank ids: vertices by decreasing (degree, id) -----------------------------------------------
+__global__ void k_rank_keys(int64_t n, const int64_t *__restrict__ off, unsigned long long *__restrict__ keys) {
+    const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (u < n) keys[u] = ((unsigned long long)(off[u + 1] - off[u]) << 32) | (unsigned long long)u;
 }
-
-// order-preserving compaction of the oriented neighbours into dadj
-__global__ __launch_bounds__(256) void k_fill_dag(int64_t n, const int64_t *__restrict__ off,
-                                                  const int32_t *__restrict__ adj, const int64_t *__restrict__ doff,
-                                                  int32_t *__restrict__ dadj) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
-    for (int64_t u = wave0; u < n; u += nwaves) {
-        const int64_t b = off[u], e = off[u + 1];
-        const int64_t du = e - b;
-        int64_t out = doff[u];
-        for (int64_t base = b; base < e; base += 64) {
-            const int64_t j = base + lane;
-            bool keep = false;
-            int32_t v = 0;
-            if (j < e) {
-                v = adj[j];
-                keep = oriented_before(du, int32_t(u), off[v + 1] - off[v], v);
-            }
-            const unsigned long long mask = __ballot(keep);
-            if (keep) dadj[out + __popcll(mask & ((1ull << lane) - 1ull))] = v;
-            out += __popcll(mask);
-        }
-    }
-}
-
-__global__ void k_sort_keys(int64_t n, const int64_t *__restrict__ doff, int32_t *__restrict__ keys, int32_t *__restrict__ vals) {
+__global__ void k_assign_ids(int64_t n, const unsigned long long *__restrict__ sorted_keys, int32_t *__restrict__ oldid,
+                             int32_t *__restrict__ newid) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) {
-        keys[i] = int32_t(doff[i + 1] - doff[i]);
+        const int32_t o = int32_t(sorted_keys[i] & 0xffffffffull);
+        oldid[i] = o;
+        newid[o] = int32_t(i);
+    }
+}
+
+// sizes of the two oriented containers of every vertex, written at its rank id (hub size padded to even)
+__global__ __launch_bounds__(256) void k_count_parts(int64_t n, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                                     const int32_t *__restrict__ newid, int64_t *__restrict__ hcnt,
+                                                     int64_t *__restrict__ tcnt, int32_t *__restrict__ dplus) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t u = wave0; u < n; u += nwaves) {
+        const int64_t b = off[u], e = off[u + 1];
+        const int32_t nu = newid[u];
+        int ch = 0, ct = 0;
+        for (int64_t j = b + lane; j < e; j += 64) {
+            const int32_t nv = newid[adj[j]];
+            if (nv < nu) {
+                if (nv < kHub) ch++; else ct++;
+            }
+        }
+        for (int s = 32; s > 0; s >>= 1) {
+            ch += __shfl_down(ch, s);
+            ct += __shfl_down(ct, s);
+        }
+        if (lane == 0) {
+            hcnt[nu] = (ch + 1) & ~1;
+            tcnt[nu] = ct;
+            dplus[nu] = ch + ct;
+        }
+    }
+}
+
+// order-preserving compaction of the oriented neighbours (as rank ids) into the hub / tail containers
+__global__ __launch_bounds__(256) void k_fill_parts(int64_t n, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                                    const int32_t *__restrict__ newid, const int64_t *__restrict__ hoff,
+                                                    const int64_t *__restrict__ toff, uint16_t *__restrict__ hadj,
+                                                    int32_t *__restrict__ tadj) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t u = wave0; u < n; u += nwaves) {
+        const int64_t b = off[u], e = off[u + 1];
+        const int32_t nu = newid[u];
+        int64_t ho = hoff[nu], to = toff[nu];
+        const int64_t hend = hoff[nu + 1];
+        for (int64_t base = b; base < e; base += 64) {
+            const int64_t j = base + lane;
+            bool kh = false, kt = false;
+            int32_t nv = 0;
+            if (j < e) {
+                nv = newid[adj[j]];
+                kh = nv < nu && nv < kHub;
+                kt = nv < nu && nv >= kHub;
+            }
+            const unsigned long long mh = __ballot(kh), mt = __ballot(kt);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (kh) hadj[ho + __popcll(mh & below)] = uint16_t(nv);
+            if (kt) tadj[to + __popcll(mt & below)] = nv;
+            ho += __popcll(mh);
+            to += __popcll(mt);
+        }
+        if (lane == 0 && ho < hend) hadj[ho] = 0xFFFF;  // pad to an even count
+    }
+}
+
+__global__ void k_order_keys(int64_t n, const int32_t *__restrict__ dplus, int32_t *__restrict__ keys, int32_t *__restrict__ vals) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) {
+        keys[i] = dplus[i];
         vals[i] = int32_t(i);
     }
 }
 
-// keys are descending; out[t] = number of keys >= thr[t]
-__global__ void k_bin_bounds(int64_t n, const int32_t *__restrict__ keys, int nthr, const int32_t *__restrict__ thr,
-                             int64_t *__restrict__ out) {
-    const int t = threadIdx.x;
-    if (t >= nthr) return;
+// keys are descending; out[0] = number of keys >= thr
+__global__ void k_count_ge(int64_t n, const int32_t *__restrict__ keys, int32_t thr, int64_t *__restrict__ out) {
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] >= thr[t]) lo = mid + 1; else hi = mid;
+        if (keys[mid] >= thr) lo = mid + 1; else hi = mid;
     }
-    out[t] = lo;
+    out[0] = lo;
 }
 
 static int grid_for_waves(int64_t rows) {
@@ -159,15 +182,37 @@ static int dmalloc(T **p, int64_t count, gmsx_graph *g) {
     return GMSX_OK;
 }
 
+struct DevGuard {
+    void *p;
+    ~DevGuard() { (void)hipFree(p); }
+};
+
 static void free_graph(gmsx_graph *g) {
     if (!g) return;
     (void)hipFree(g->off);
     (void)hipFree(g->adj);
-    (void)hipFree(g->doff);
-    (void)hipFree(g->dadj);
+    (void)hipFree(g->newid);
+    (void)hipFree(g->oldid);
+    (void)hipFree(g->hoff);
+    (void)hipFree(g->hadj);
+    (void)hipFree(g->toff);
+    (void)hipFree(g->tadj);
+    (void)hipFree(g->dplus);
     (void)hipFree(g->order);
+    (void)hipFree(g->sorted_dplus);
     (void)hipFree(g->scratch);
     delete g;
+}
+
+static int exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t count, hipStream_t s) {
+    size_t tmp_bytes = 0;
+    GMSX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, int64_t(0), size_t(count), rocprim::plus<int64_t>(), s));
+    void *tmp = nullptr;
+    GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+    DevGuard g_tmp{tmp};
+    GMSX_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, in, out, int64_t(0), size_t(count), rocprim::plus<int64_t>(), s));
+    GMSX_HIP(hipStreamSynchronize(s));
+    return GMSX_OK;
 }
 
 static int build_device_sets(gmsx_graph *g, uint32_t flags) {
@@ -184,68 +229,94 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     GMSX_HIP(hipStreamSynchronize(s));
     if (!(flags & GMSX_UPLOAD_TRUSTED) && acc[0] != 0) return GMSX_ERR_NOT_CANONICAL;
     if ((flags & GMSX_UPLOAD_TRUSTED) && (acc[0] & 2)) return GMSX_ERR_NOT_CANONICAL;  // out-of-range ids are never tolerated
+    if (!(flags & GMSX_UPLOAD_TRUSTED) && (g->nnz & 1)) return GMSX_ERR_NOT_CANONICAL;
     g->alg_elements = acc[1];
     g->max_deg = int32_t(acc[2]);
+    g->m = g->nnz / 2;
 
-    // 2. d+ -> exclusive scan -> doff
-    int64_t *dplus = nullptr;
-    if (int rc = dmalloc(&dplus, n + 1, nullptr)) return rc;
-    struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g_dplus{dplus};
-    GMSX_HIP(hipMemsetAsync(dplus, 0, size_t(n + 1) * sizeof(int64_t), s));
-    if (n > 0) hipLaunchKernelGGL(k_out_degree, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, dplus);
-    if (int rc = dmalloc(&g->doff, n + 1, g)) return rc;
-    {
+    const unsigned tb = unsigned((n + 255) / 256);
+    // 2. rank ids: sort (degree, id) descending
+    if (int rc = dmalloc(&g->newid, n, g)) return rc;
+    if (int rc = dmalloc(&g->oldid, n, g)) return rc;
+    if (n > 0) {
+        unsigned long long *k_in = nullptr, *k_out = nullptr;
+        if (int rc = dmalloc(&k_in, n, nullptr)) return rc;
+        DevGuard g1{k_in};
+        if (int rc = dmalloc(&k_out, n, nullptr)) return rc;
+        DevGuard g2{k_out};
+        hipLaunchKernelGGL(k_rank_keys, dim3(tb), dim3(256), 0, s, n, g->off, k_in);
         size_t tmp_bytes = 0;
-        GMSX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, dplus, g->doff, int64_t(0), size_t(n + 1), rocprim::plus<int64_t>(), s));
+        GMSX_HIP(rocprim::radix_sort_keys_desc(nullptr, tmp_bytes, k_in, k_out, size_t(n), 0, 64, s));
         void *tmp = nullptr;
         GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-        Guard g_tmp{tmp};
-        GMSX_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, dplus, g->doff, int64_t(0), size_t(n + 1), rocprim::plus<int64_t>(), s));
+        DevGuard g3{tmp};
+        GMSX_HIP(rocprim::radix_sort_keys_desc(tmp, tmp_bytes, k_in, k_out, size_t(n), 0, 64, s));
+        hipLaunchKernelGGL(k_assign_ids, dim3(tb), dim3(256), 0, s, n, k_out, g->oldid, g->newid);
         GMSX_HIP(hipStreamSynchronize(s));
     }
-    int64_t m = 0;
-    GMSX_HIP(hipMemcpy(&m, g->doff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
-    g->m = m;
-    if (!(flags & GMSX_UPLOAD_TRUSTED) && m * 2 != g->nnz) return GMSX_ERR_NOT_CANONICAL;
 
-    // 3. DAG rows
-    if (int rc = dmalloc(&g->dadj, m + 8, g)) return rc;  // +8: the 16-byte row loads of the count kernels may overrun the last row
-    GMSX_HIP(hipMemsetAsync(g->dadj + m, 0xff, 8 * sizeof(int32_t), s));
-    if (n > 0) hipLaunchKernelGGL(k_fill_dag, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, g->doff, g->dadj);
+    // 3. container sizes -> offsets
+    int64_t *hcnt = nullptr, *tcnt = nullptr;
+    if (int rc = dmalloc(&hcnt, n + 1, nullptr)) return rc;
+    DevGuard g_h{hcnt};
+    if (int rc = dmalloc(&tcnt, n + 1, nullptr)) return rc;
+    DevGuard g_t{tcnt};
+    GMSX_HIP(hipMemsetAsync(hcnt, 0, size_t(n + 1) * sizeof(int64_t), s));
+    GMSX_HIP(hipMemsetAsync(tcnt, 0, size_t(n + 1) * sizeof(int64_t), s));
+    if (int rc = dmalloc(&g->dplus, n, g)) return rc;
+    if (n > 0)
+        hipLaunchKernelGGL(k_count_parts, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, g->newid, hcnt, tcnt, g->dplus);
+    if (int rc = dmalloc(&g->hoff, n + 1, g)) return rc;
+    if (int rc = dmalloc(&g->toff, n + 1, g)) return rc;
+    if (int rc = exclusive_scan_i64(hcnt, g->hoff, n + 1, s)) return rc;
+    if (int rc = exclusive_scan_i64(tcnt, g->toff, n + 1, s)) return rc;
+    GMSX_HIP(hipMemcpy(&g->hub_entries, g->hoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+    GMSX_HIP(hipMemcpy(&g->tail_entries, g->toff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
 
-    // 4. work-sorted launch order: vertices by decreasing d+, plus the bin boundaries
+    // 4. containers (+16 bytes of slack each: the 16-byte row loads of the count kernels may overrun the last row)
+    if (int rc = dmalloc(&g->hadj, g->hub_entries + 8, g)) return rc;
+    if (int rc = dmalloc(&g->tadj, g->tail_entries + 4, g)) return rc;
+    GMSX_HIP(hipMemsetAsync(g->hadj + g->hub_entries, 0xff, 8 * sizeof(uint16_t), s));
+    GMSX_HIP(hipMemsetAsync(g->tadj + g->tail_entries, 0xff, 4 * sizeof(int32_t), s));
+    if (n > 0)
+        hipLaunchKernelGGL(k_fill_parts, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, g->newid, g->hoff, g->toff,
+                           g->hadj, g->tadj);
+
+    // 5. work-sorted launch order: rank ids by decreasing d+
     if (int rc = dmalloc(&g->order, n, g)) return rc;
-    int32_t *keys_in = nullptr, *keys_out = nullptr, *vals_in = nullptr;
-    if (int rc = dmalloc(&keys_in, n, nullptr)) return rc;
-    Guard g_ki{keys_in};
-    if (int rc = dmalloc(&keys_out, n, nullptr)) return rc;
-    Guard g_ko{keys_out};
-    if (int rc = dmalloc(&vals_in, n, nullptr)) return rc;
-    Guard g_vi{vals_in};
+    if (int rc = dmalloc(&g->sorted_dplus, n, g)) return rc;
     if (n > 0) {
-        hipLaunchKernelGGL(k_sort_keys, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->doff, keys_in, vals_in);
+        int32_t *keys_in = nullptr, *vals_in = nullptr;
+        if (int rc = dmalloc(&keys_in, n, nullptr)) return rc;
+        DevGuard g_ki{keys_in};
+        if (int rc = dmalloc(&vals_in, n, nullptr)) return rc;
+        DevGuard g_vi{vals_in};
+        hipLaunchKernelGGL(k_order_keys, dim3(tb), dim3(256), 0, s, n, g->dplus, keys_in, vals_in);
         size_t tmp_bytes = 0;
-        GMSX_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, keys_in, keys_out, vals_in, g->order, size_t(n), 0, 32, s));
+        GMSX_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, keys_in, g->sorted_dplus, vals_in, g->order, size_t(n), 0, 32, s));
         void *tmp = nullptr;
         GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-        Guard g_tmp{tmp};
-        GMSX_HIP(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, keys_out, vals_in, g->order, size_t(n), 0, 32, s));
-        int32_t *d_thr = nullptr;
-        int64_t *d_out = nullptr;
-        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_thr), sizeof(kBinThr)));
-        Guard g_thr{d_thr};
-        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_out), sizeof(int64_t) * gmsx_graph::kBins));
-        Guard g_out{d_out};
-        GMSX_HIP(hipMemcpyAsync(d_thr, kBinThr, sizeof(kBinThr), hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_bin_bounds, dim3(1), dim3(64), 0, s, n, keys_out, gmsx_graph::kBins, d_thr, d_out);
-        GMSX_HIP(hipMemcpyAsync(g->bin_end, d_out, sizeof(int64_t) * gmsx_graph::kBins, hipMemcpyDeviceToHost, s));
+        DevGuard g_tmp{tmp};
+        GMSX_HIP(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, g->sorted_dplus, vals_in, g->order, size_t(n), 0, 32, s));
         int32_t top = 0;
-        GMSX_HIP(hipMemcpyAsync(&top, keys_out, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipMemcpyAsync(&top, g->sorted_dplus, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         GMSX_HIP(hipStreamSynchronize(s));
         g->max_dplus = top;
     }
     GMSX_HIP(hipStreamSynchronize(s));
     GMSX_HIP(hipGetLastError());
+    return GMSX_OK;
+}
+
+int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out) {
+    if (g->n == 0) {
+        *out = 0;
+        return GMSX_OK;
+    }
+    hipStream_t s = ctx().stream;
+    hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, g->n, g->sorted_dplus, threshold, reinterpret_cast<int64_t *>(g->scratch + 8));
+    GMSX_HIP(hipMemcpyAsync(out, g->scratch + 8, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipStreamSynchronize(s));
     return GMSX_OK;
 }
 

@@ -7,22 +7,39 @@
 #include "gmsx.h"
 
 // Layout in HBM (all arrays hipMalloc'd once at upload, read-only afterwards):
-//   off  int64[n+1], adj  int32[nnz]   full symmetric CSR, rows ascending       (the reference's CSRGraph rows)
-//   doff int64[n+1], dadj int32[m]     degree-oriented DAG: N+(u) = { v in N(u) : (deg v, v) > (deg u, u) },
-//                                      rows ascending; every undirected edge appears exactly once
-//   order int32[n]                     vertices by decreasing d+ (work-sorted launch order, heavy first)
+//
+//   off  int64[n+1], adj int32[nnz]   the caller's symmetric CSR, rows ascending (the reference's CSRGraph rows)
+//
+//   Internal vertex numbering ("rank ids"): vertices sorted by DEcreasing (degree, id); rank id 0 is the biggest
+//   hub.  newid[old] / oldid[rank] convert.  Edges are oriented from the lower- to the higher-degree endpoint,
+//   i.e. towards the SMALLER rank id:  N+(u) = { v in N(u) : rank(v) < rank(u) }, so every undirected edge appears
+//   exactly once and d+ = O(sqrt(m)).
+//
+//   The oriented rows are stored Roaring-style in two containers per vertex, indexed by rank id:
+//     hub part   hoff int64[n+1], hadj uint16[...]   targets with rank id < kHub (=65535), 2 bytes each; every row
+//                                                     is padded to an even count with 0xFFFF (never a valid target)
+//     tail part  toff int64[n+1], tadj int32[...]    targets with rank id >= kHub, 4 bytes each
+//   On power-law graphs >85 % of all entries and >95 % of the streamed ids are hub entries.
+//
+//   dplus int32[n]                     true out-degree (hub + tail) per rank id
+//   order int32[n]                     rank ids by decreasing d+ (work-sorted launch order, heavy first);
+//   sorted_dplus int32[n]              dplus[order[i]] (for bin boundaries)
 struct gmsx_graph {
     int64_t n = 0, nnz = 0, m = 0;
     int64_t *off = nullptr;
     int32_t *adj = nullptr;
-    int64_t *doff = nullptr;
-    int32_t *dadj = nullptr;
+    int32_t *newid = nullptr;
+    int32_t *oldid = nullptr;
+    int64_t *hoff = nullptr;
+    uint16_t *hadj = nullptr;
+    int64_t *toff = nullptr;
+    int32_t *tadj = nullptr;
+    int32_t *dplus = nullptr;
     int32_t *order = nullptr;
+    int32_t *sorted_dplus = nullptr;
+    int64_t hub_entries = 0, tail_entries = 0;
     int32_t max_dplus = 0;
     int32_t max_deg = 0;
-    // positions in `order` where d+ drops below a threshold (host copy): bin_end[i] = #vertices with d+ >= kBinThr[i]
-    static constexpr int kBins = 8;
-    int64_t bin_end[kBins] = {0};
     unsigned long long *scratch = nullptr;  // device: a few u64 accumulators
     uint64_t alg_elements = 0;              // Σ_{u<v}(d_u+d_v), computed on the device at upload
     int64_t device_bytes = 0;
@@ -30,8 +47,8 @@ struct gmsx_graph {
 
 namespace gmsx {
 
-// d+ thresholds of the launch bins (descending): a vertex with d+ >= kBinThr[i] and < kBinThr[i-1] is in bin i
-static constexpr int32_t kBinThr[gmsx_graph::kBins] = {8192, 2048, 512, 128, 64, 16, 2, 0};
+static constexpr int kHub = 65535;         // rank ids below this live in the 16-bit hub containers
+static constexpr int kBitmapWords = 2048;  // 65536-bit LDS bitmap over the hub id range
 
 struct Ctx {
     int device = -1;
@@ -42,6 +59,8 @@ struct Ctx {
 };
 Ctx &ctx();
 int ensure_init();
+// number of vertices with d+ >= threshold (= position in `order` where d+ drops below it)
+int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out);
 
 #define GMSX_HIP(call)                                                    \
     do {                                                                  \

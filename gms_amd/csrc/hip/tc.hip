@@ -1,36 +1,102 @@
 // Triangle counting on gfx950: the device replacement for
 //   GMS::TriangleCount::Par::count_total   (gms/algorithms/set_based/triangle_count/parallel/total.h:7-24)
 // whose inner operator is Set::intersect_count (representations/sets/sorted_set.h:176-182 ->
-// sorted_set_operations.h:44-71).
+// sorted_set_operations.h:44-71; roaring_set.h:144-152 -> roaring.c:10090-10118 for the RoaringSet flavour).
 //
-// Formulation (GMSX_TC_ORIENTED).  The reference evaluates, for every undirected edge {u,v}, one
-// intersect_count on the full rows and divides the sum by 3.  Here every undirected edge is still one
-// intersect_count, but on the degree-oriented rows:  T = Σ_{u} Σ_{v∈N+(u)} |N+(u) ∩ N+(v)|,
-// which meets every triangle exactly once, so the returned count is the same integer.
+// Formulation (GMSX_TC_ORIENTED).  The reference evaluates, for every undirected edge {u,v}, one intersect_count
+// on the full rows and divides the sum by 3.  Here every undirected edge is still exactly one intersect_count, but
+// on the degree-oriented rows:  T = Σ_u Σ_{v∈N+(u)} |N+(u) ∩ N+(v)|, which meets every triangle once, so the
+// returned integer is the same.
 //
-// Kernel shape (one pivot vertex u per workgroup or per wave):
-//   1. the pivot row N+(u) is staged into LDS as an open-addressing hash set (load <= 0.5, usually <= 0.25);
-//   2. the rows N+(v), v ∈ N+(u), are streamed from HBM/L2 with coalesced 64-lane loads;
-//   3. every streamed id probes the LDS set; hits are counted per lane, reduced per workgroup, and added to one
-//      of 64 spread u64 accumulators (one atomic per workgroup).
-// No MFMA: this is integer/indexing work bounded by HBM/L2 row streaming and LDS probe rate.
+// Kernel shape — one pivot vertex u per workgroup (d+ >= 64) or per wave (2 <= d+ < 64), Roaring-style sets:
+//   1. the pivot row N+(u) is staged into LDS: its hub part (rank ids < 65535) as a 65536-bit BITMAP (8 KB), its
+//      tail part as a small open-addressing hash set;
+//   2. the rows N+(v), v ∈ N+(u), are streamed from HBM/L2 with coalesced 16-byte loads: hub containers carry
+//      eight 16-bit ids per lane per load, tail containers 32-bit ids;
+//   3. every streamed hub id is one LDS word read + bit test (bitmap AND, no collisions, no branches); tail ids
+//      probe the hash set; hits are counted per lane, reduced per workgroup, and added to one of 64 spread u64
+//      accumulators (one atomic per workgroup).
+// No MFMA: integer/indexing work bounded by row streaming (HBM/MALL/L2) and the LDS probe rate.
 #include "device_graph.hpp"
 
+#include <algorithm>
 #include <cstdio>
 
 namespace gmsx {
 
-static constexpr int kAccSlots = 64;     // spread accumulators, 128 B apart
-static constexpr int kAccStride = 16;    // in u64
+static constexpr int kAccSlots = 64;   // spread accumulators, 128 B apart
+static constexpr int kAccStride = 16;  // in u64
 
+// 4-byte-aligned 16-byte load: container rows start at arbitrary dword offsets; the hardware needs dword alignment only
+struct __attribute__((packed, aligned(4))) u4u { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ int64_t readlane64(int64_t x, int l) {
+    const uint32_t lo = __builtin_amdgcn_readlane(uint32_t(uint64_t(x)), l);
+    const uint32_t hi = __builtin_amdgcn_readlane(uint32_t(uint64_t(x) >> 32), l);
+    return int64_t((uint64_t(hi) << 32) | lo);
+}
+
+// ---- hub side: 65536-bit bitmap in LDS ---------------------------------------------------------------
+__device__ __forceinline__ uint32_t bit_lo(const uint32_t *bm, uint32_t p) {  // id = p & 0xffff
+    const uint32_t word = bm[(p >> 5) & 0x7ffu];
+    return __builtin_amdgcn_ubfe(word, p & 31u, 1u);
+}
+__device__ __forceinline__ uint32_t bit_hi(const uint32_t *bm, uint32_t p) {  // id = p >> 16
+    const uint32_t q = p >> 16;
+    const uint32_t word = bm[q >> 5];
+    return __builtin_amdgcn_ubfe(word, q & 31u, 1u);
+}
+__device__ __forceinline__ uint32_t hub_hits8(const uint32_t *bm, u4u p) {
+    return bit_lo(bm, p.x) + bit_hi(bm, p.x) + bit_lo(bm, p.y) + bit_hi(bm, p.y) + bit_lo(bm, p.z) + bit_hi(bm, p.z) +
+           bit_lo(bm, p.w) + bit_hi(bm, p.w);
+}
+
+// Streams the hub containers of `rows` rows against the LDS bitmap.  Lane l holds the extent (rb, rl) of row l
+// (rl = padded, even entry count; lanes >= rows hold 0).  The wave works as four 16-lane groups, each streaming
+// its own row: 16 lanes x 8 ids per step, two steps (two 16-byte loads per lane) in flight.
+__device__ __forceinline__ uint32_t scan_hub_rows(const uint32_t *bm, const uint16_t *__restrict__ hadj, int64_t rb, int rl,
+                                                  int rows, int lane) {
+    const int grp = lane >> 4, sub8 = (lane & 15) * 8;
+    uint32_t cnt = 0;
+    for (int r0 = 0; r0 < rows; r0 += 4) {
+        // extents of rows r0..r0+3 through wave-uniform readlanes, then a per-group select (a per-lane __shfl here
+        // gets sunk under the row-count predicate by the compiler and then reads inactive lanes)
+        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
+        const int64_t b0 = readlane64(rb, m0), b1 = readlane64(rb, m1), b2 = readlane64(rb, m2), b3 = readlane64(rb, m3);
+        const int l0 = __builtin_amdgcn_readlane(rl, m0), l1 = __builtin_amdgcn_readlane(rl, m1),
+                  l2 = __builtin_amdgcn_readlane(rl, m2), l3 = __builtin_amdgcn_readlane(rl, m3);
+        const int64_t b = grp == 0 ? b0 : grp == 1 ? b1 : grp == 2 ? b2 : b3;
+        const int l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
+        const uint16_t *row = hadj + b;
+        int j = sub8;
+        for (; j + 128 + 8 <= l; j += 256) {  // two full 128-id group steps
+            const u4u p = *reinterpret_cast<const u4u *>(row + j);
+            const u4u q = *reinterpret_cast<const u4u *>(row + j + 128);
+            cnt += hub_hits8(bm, p);
+            cnt += hub_hits8(bm, q);
+        }
+        for (; j < l; j += 128) {  // remaining steps; the last may be partial (l - j in {2,4,6}: whole dwords)
+            u4u p = *reinterpret_cast<const u4u *>(row + j);
+            const int valid = l - j;
+            if (valid < 8) {  // ids beyond the row are neutralised to 0xFFFF, which is never set in the bitmap
+                if (valid < 6) p.z = 0xffffffffu;
+                if (valid < 4) p.y = 0xffffffffu;
+                p.w = 0xffffffffu;
+            }
+            cnt += hub_hits8(bm, p);
+        }
+    }
+    return cnt;
+}
+
+// ---- tail side: open-addressing hash set in LDS (keys are rank ids >= kHub; -1 = empty) ------------------------
 __device__ __forceinline__ uint32_t hash_slot(int32_t w, int shift) { return (uint32_t(w) * 0x9E3779B1u) >> shift; }
 
 __device__ __forceinline__ void set_insert(int32_t *tbl, uint32_t mask, int shift, int32_t w) {
     uint32_t h = hash_slot(w, shift);
     while (atomicCAS(&tbl[h], -1, w) != -1) h = (h + 1) & mask;
 }
-
-__device__ __forceinline__ unsigned set_contains(const int32_t *tbl, uint32_t mask, int shift, int32_t w) {
+__device__ __forceinline__ uint32_t set_contains(const int32_t *tbl, uint32_t mask, int shift, int32_t w) {
     uint32_t h = hash_slot(w, shift);
     while (true) {
         const int32_t x = tbl[h];
@@ -39,103 +105,98 @@ __device__ __forceinline__ unsigned set_contains(const int32_t *tbl, uint32_t ma
         h = (h + 1) & mask;
     }
 }
-
-__device__ __forceinline__ int64_t readlane64(int64_t x, int l) {
-    const uint32_t lo = __builtin_amdgcn_readlane(uint32_t(uint64_t(x)), l);
-    const uint32_t hi = __builtin_amdgcn_readlane(uint32_t(uint64_t(x) >> 32), l);
-    return int64_t((uint64_t(hi) << 32) | lo);
-}
-
-// 4-byte-aligned 16-byte load: rows start at arbitrary dword offsets, the hardware only needs dword alignment
-struct __attribute__((packed, aligned(4))) i4u { int32_t x, y, z, w; };
-
-__device__ __forceinline__ unsigned probe4(const int32_t *tbl, uint32_t mask, int shift, i4u w, int valid) {
-    // first-slot reads of the four ids are issued together (four LDS reads in flight); at load <= 0.25 most
-    // probes resolve there, the rest continue down the chain
-    const uint32_t h0 = hash_slot(w.x, shift), h1 = hash_slot(w.y, shift), h2 = hash_slot(w.z, shift), h3 = hash_slot(w.w, shift);
-    const int32_t x0 = tbl[h0], x1 = tbl[h1], x2 = tbl[h2], x3 = tbl[h3];
-    unsigned c = 0;
-    if (valid > 0) { if (x0 == w.x) c++; else if (x0 != -1) c += set_contains(tbl, mask, shift, w.x); }
-    if (valid > 1) { if (x1 == w.y) c++; else if (x1 != -1) c += set_contains(tbl, mask, shift, w.y); }
-    if (valid > 2) { if (x2 == w.z) c++; else if (x2 != -1) c += set_contains(tbl, mask, shift, w.z); }
-    if (valid > 3) { if (x3 == w.w) c++; else if (x3 != -1) c += set_contains(tbl, mask, shift, w.w); }
-    return c;
-}
-
-// Streams `rows` rows against the LDS set.  Lane l holds the extent (rb, rl) of row l.  The wave works as four
-// 16-lane groups, each streaming its own row with 16-byte loads (64 ids per group step, two steps in flight), so a
-// wave keeps up to eight independent 256-byte requests outstanding instead of one.
-__device__ __forceinline__ unsigned long long scan_rows(const int32_t *tbl, uint32_t mask, int shift,
-                                                        const int32_t *__restrict__ dadj, int64_t rb, int rl, int rows,
-                                                        int lane) {
-    const int grp = lane >> 4, sub4 = (lane & 15) * 4;
-    unsigned long long cnt = 0;
-    for (int r0 = 0; r0 < rows; r0 += 4) {
-        // extents of rows r0..r0+3 through wave-uniform readlanes (lanes >= rows hold length 0), then a per-group
-        // select: a per-lane __shfl here gets sunk under the row-count predicate by the compiler and then reads
-        // inactive lanes
-        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
-        const int64_t b0 = readlane64(rb, m0), b1 = readlane64(rb, m1), b2 = readlane64(rb, m2), b3 = readlane64(rb, m3);
-        const int l0 = __builtin_amdgcn_readlane(rl, m0), l1 = __builtin_amdgcn_readlane(rl, m1),
-                  l2 = __builtin_amdgcn_readlane(rl, m2), l3 = __builtin_amdgcn_readlane(rl, m3);
-        const int64_t b = grp == 0 ? b0 : grp == 1 ? b1 : grp == 2 ? b2 : b3;
-        const int l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
-        const int32_t *row = dadj + b;
-        int j = sub4;
-        for (; j + 64 < l; j += 128) {  // two 64-id steps per iteration
-            const i4u a = *reinterpret_cast<const i4u *>(row + j);
-            const i4u c = *reinterpret_cast<const i4u *>(row + j + 64);
-            cnt += probe4(tbl, mask, shift, a, 4);
-            cnt += probe4(tbl, mask, shift, c, l - (j + 64));
-        }
-        if (j < l) {
-            const i4u a = *reinterpret_cast<const i4u *>(row + j);
-            cnt += probe4(tbl, mask, shift, a, l - j);
-        }
+// tail containers are a few percent of the streamed ids: plain 64-lane row streaming
+__device__ __forceinline__ uint32_t scan_tail_rows(const int32_t *tbl, uint32_t mask, int shift, const int32_t *__restrict__ tadj,
+                                                   int64_t rb, int rl, int rows, int lane) {
+    uint32_t cnt = 0;
+    for (int r = 0; r < rows; ++r) {
+        const int l = __builtin_amdgcn_readlane(rl, r);
+        if (l == 0) continue;
+        const int64_t b = readlane64(rb, r);
+        for (int j = lane; j < l; j += 64) cnt += set_contains(tbl, mask, shift, tadj[b + j]);
     }
     return cnt;
 }
 
 // ---------------------------------------------------------------------------------------------
-// Workgroup per pivot (d+ >= 64).  256 threads = 4 waves share one LDS set; wave w streams the rows of the
-// pivot-list entries w, w+4, ….  Pivot rows longer than half the table are processed in tiles.
+// Workgroup per pivot (d+ >= 64).  256 threads = 4 waves share the pivot's bitmap + tail set; wave w streams the
+// rows of the pivot-list entries w, w+4, ….  LDS: 8 KB bitmap + 2^kBlockLog x 4 B hash; a tail longer than half the
+// table is processed in tiles.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tc_oriented_block(const int64_t *__restrict__ doff, const int32_t *__restrict__ dadj,
-                                                           const int32_t *__restrict__ order, int64_t first, int64_t end,
-                                                           int nparts, int part, int log_tbl,
-                                                           unsigned long long *__restrict__ acc) {
-    extern __shared__ int32_t tbl[];
+static constexpr int kBlockLog = 11;
+
+__global__ __launch_bounds__(256) void k_tc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                  const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                  const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
+                                                  int part, unsigned long long *__restrict__ acc) {
+    __shared__ uint32_t bm[kBitmapWords];
+    __shared__ int32_t tbl[1 << kBlockLog];
     __shared__ unsigned long long red[4];
+    constexpr int SIZE = 1 << kBlockLog, SHIFT = 32 - kBlockLog, TILE = SIZE / 2;
+    constexpr uint32_t MASK = SIZE - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t pos = first + int64_t(blockIdx.x) * nparts + part;
     if (pos >= end) return;  // uniform per block
     const int32_t u = order[pos];
-    const int64_t beg = doff[u];
-    const int dp = int(doff[u + 1] - beg);
-    const int tbl_size = 1 << log_tbl, shift = 32 - log_tbl;
-    const uint32_t mask = uint32_t(tbl_size - 1);
-    const int tile = tbl_size >> 1;
+    const int64_t hb = hoff[u], tb = toff[u];
+    const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
+
+    for (int i = tid; i < kBitmapWords; i += 256) bm[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < hl; i += 256) {
+        const uint32_t id = hadj[hb + i];
+        if (id != 0xFFFFu) atomicOr(&bm[id >> 5], 1u << (id & 31u));
+    }
+    __syncthreads();
 
     unsigned long long cnt = 0;
-    for (int t0 = 0; t0 < dp; t0 += tile) {
-        const int tn = min(tile, dp - t0);
-        __syncthreads();  // previous tile's probes are done
-        for (int i = tid; i < tbl_size; i += 256) tbl[i] = -1;
+    // (a) rows of the hub part of the pivot list: pure hub containers (a hub vertex has no tail container)
+    for (int base = 0; base < hl; base += 256) {
+        const int idx = base + lane * 4 + wave;
+        int64_t rb = 0;
+        int rl = 0;
+        if (idx < hl) {
+            const uint32_t v = hadj[hb + idx];
+            if (v != 0xFFFFu) {
+                rb = hoff[v];
+                rl = int(hoff[v + 1] - rb);
+            }
+        }
+        const int rows = min(64, (hl - base - wave + 3) >> 2);
+        cnt += scan_hub_rows(bm, hadj, rb, rl, rows, lane);
+    }
+    // (b) rows of the tail part of the pivot list: their hub containers against the bitmap …
+    for (int base = 0; base < tl; base += 256) {
+        const int idx = base + lane * 4 + wave;
+        int64_t rb = 0;
+        int rl = 0;
+        if (idx < tl) {
+            const int32_t v = tadj[tb + idx];
+            rb = hoff[v];
+            rl = int(hoff[v + 1] - rb);
+        }
+        const int rows = min(64, (tl - base - wave + 3) >> 2);
+        cnt += scan_hub_rows(bm, hadj, rb, rl, rows, lane);
+    }
+    // (c) … and their tail containers against the hash set of the pivot's tail part
+    for (int t0 = 0; t0 < tl; t0 += TILE) {
+        const int tn = min(TILE, tl - t0);
         __syncthreads();
-        for (int i = tid; i < tn; i += 256) set_insert(tbl, mask, shift, dadj[beg + t0 + i]);
+        for (int i = tid; i < SIZE; i += 256) tbl[i] = -1;
         __syncthreads();
-        // rows of the pivot list, 256 per batch: lane l of wave w prefetches the extent of row (base + 4l + w)
-        for (int base = 0; base < dp; base += 256) {
+        for (int i = tid; i < tn; i += 256) set_insert(tbl, MASK, SHIFT, tadj[tb + t0 + i]);
+        __syncthreads();
+        for (int base = 0; base < tl; base += 256) {
             const int idx = base + lane * 4 + wave;
             int64_t rb = 0;
             int rl = 0;
-            if (idx < dp) {
-                const int32_t v = dadj[beg + idx];
-                rb = doff[v];
-                rl = int(doff[v + 1] - rb);
+            if (idx < tl) {
+                const int32_t v = tadj[tb + idx];
+                rb = toff[v];
+                rl = int(toff[v + 1] - rb);
             }
-            const int rows = min(64, (dp - base - wave + 3) >> 2);
-            cnt += scan_rows(tbl, mask, shift, dadj, rb, rl, rows, lane);
+            const int rows = min(64, (tl - base - wave + 3) >> 2);
+            cnt += scan_tail_rows(tbl, MASK, SHIFT, tadj, rb, rl, rows, lane);
         }
     }
     for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
@@ -148,40 +209,68 @@ __global__ __launch_bounds__(256) void k_tc_oriented_block(const int64_t *__rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wave per pivot (2 <= d+ < 64).  Each of the 4 waves of a workgroup owns a private 2^LOG-entry LDS set and walks
-// its own pivots with a grid stride; one atomic per workgroup at the end.
+// Wave per pivot (2 <= d+ < 64).  Each of the 4 waves of a workgroup owns a private bitmap (8 KB) and a 256-entry
+// tail set and walks its pivots with a grid stride.  The bitmap is cleared once; each pivot sets its bits and
+// clears exactly those words again afterwards.  One atomic per workgroup at the end.
 // ---------------------------------------------------------------------------------------------
-template <int LOG>
-__global__ __launch_bounds__(256) void k_tc_oriented_wave(const int64_t *__restrict__ doff, const int32_t *__restrict__ dadj,
-                                                          const int32_t *__restrict__ order, int64_t first, int64_t end,
-                                                          int nparts, int part, unsigned long long *__restrict__ acc) {
-    constexpr int SIZE = 1 << LOG, SHIFT = 32 - LOG;
+__global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                 const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                 const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
+                                                 int part, unsigned long long *__restrict__ acc) {
+    constexpr int LOG = 8, SIZE = 1 << LOG, SHIFT = 32 - LOG;
     constexpr uint32_t MASK = SIZE - 1;
+    __shared__ uint32_t bm_all[4 * kBitmapWords];
     __shared__ int32_t tbl_all[4 * SIZE];
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *bm = bm_all + wave * kBitmapWords;
     int32_t *tbl = tbl_all + wave * SIZE;
+    for (int i = lane; i < kBitmapWords; i += 64) bm[i] = 0;
     const int64_t nwaves = int64_t(gridDim.x) * 4;
     unsigned long long cnt = 0;
     for (int64_t q = int64_t(blockIdx.x) * 4 + wave;; q += nwaves) {
         const int64_t pos = first + q * nparts + part;
         if (pos >= end) break;  // uniform per wave
         const int32_t u = order[pos];
-        const int64_t beg = doff[u];
-        const int dp = int(doff[u + 1] - beg);  // < 64
-        for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
+        const int64_t hb = hoff[u], tb = toff[u];
+        const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);  // hl <= 64 (padded), tl < 64
         __builtin_amdgcn_wave_barrier();
+        // hub part of the pivot list: set bits, fetch row extents
+        uint32_t hv = 0xFFFFu;
         int64_t rb = 0;
         int rl = 0;
-        if (lane < dp) {
-            const int32_t v = dadj[beg + lane];
-            set_insert(tbl, MASK, SHIFT, v);
-            rb = doff[v];
-            rl = int(doff[v + 1] - rb);
+        if (lane < hl) {
+            hv = hadj[hb + lane];
+            if (hv != 0xFFFFu) {
+                atomicOr(&bm[hv >> 5], 1u << (hv & 31u));
+                rb = hoff[hv];
+                rl = int(hoff[hv + 1] - rb);
+            }
+        }
+        // tail part: hash set + extents of both containers of every tail row
+        int64_t trb = 0, thb = 0;
+        int trl = 0, thl = 0;
+        if (tl > 0) {
+            for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < tl) {
+                const int32_t v = tadj[tb + lane];
+                set_insert(tbl, MASK, SHIFT, v);
+                thb = hoff[v];
+                thl = int(hoff[v + 1] - thb);
+                trb = toff[v];
+                trl = int(toff[v + 1] - trb);
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        cnt += scan_rows(tbl, MASK, SHIFT, dadj, rb, rl, dp, lane);
+        uint32_t c = scan_hub_rows(bm, hadj, rb, rl, hl, lane);
+        if (tl > 0) {
+            c += scan_hub_rows(bm, hadj, thb, thl, tl, lane);
+            c += scan_tail_rows(tbl, MASK, SHIFT, tadj, trb, trl, tl, lane);
+        }
+        cnt += c;
         __builtin_amdgcn_wave_barrier();
+        if (hv != 0xFFFFu) bm[hv >> 5] = 0;  // every bit in this wave's bitmap belongs to this pivot
     }
     for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
     if (lane == 0) red[wave] = cnt;
@@ -193,9 +282,11 @@ __global__ __launch_bounds__(256) void k_tc_oriented_wave(const int64_t *__restr
 }
 
 // units / probes of a partition (untimed bookkeeping for gmsx_stats): wave per pivot position
-__global__ __launch_bounds__(256) void k_tc_oriented_stats(const int64_t *__restrict__ doff, const int32_t *__restrict__ dadj,
-                                                           const int32_t *__restrict__ order, int64_t first, int64_t end,
-                                                           int nparts, int part, unsigned long long *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                  const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                  const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
+                                                  int64_t first, int64_t end, int nparts, int part,
+                                                  unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -204,12 +295,12 @@ __global__ __launch_bounds__(256) void k_tc_oriented_stats(const int64_t *__rest
         const int64_t pos = first + q * nparts + part;
         if (pos >= end) break;
         const int32_t u = order[pos];
-        const int64_t b = doff[u], e = doff[u + 1];
-        if (lane == 0) units += (unsigned long long)(e - b);
-        for (int64_t j = b + lane; j < e; j += 64) {
-            const int32_t v = dadj[j];
-            probes += (unsigned long long)(doff[v + 1] - doff[v]);
+        if (lane == 0) units += (unsigned long long)dplus[u];
+        for (int64_t j = hoff[u] + lane; j < hoff[u + 1]; j += 64) {
+            const uint32_t v = hadj[j];
+            if (v != 0xFFFFu) probes += (unsigned long long)dplus[v];
         }
+        for (int64_t j = toff[u] + lane; j < toff[u + 1]; j += 64) probes += (unsigned long long)dplus[tadj[j]];
     }
     for (int s = 32; s > 0; s >>= 1) {
         units += __shfl_down(units, s);
@@ -229,6 +320,9 @@ static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
 static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *partial, gmsx_stats *st) {
     Ctx &c = ctx();
     hipStream_t s = c.stream;
+    int64_t n_block = 0, n_work = 0;  // pivots with d+ >= 64, d+ >= 2
+    if (int rc = count_dplus_ge(g, 64, &n_block)) return rc;
+    if (int rc = count_dplus_ge(g, 2, &n_work)) return rc;
     unsigned long long *acc = nullptr;
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), sizeof(unsigned long long) * (kAccSlots * kAccStride + 2)));
     struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{acc};
@@ -237,44 +331,21 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     GMSX_HIP(hipEventRecord(c.ev[1], s));
 
     int launches = 0;
-    // block-per-pivot bins: d+ >= 64 -> bins 0..4 with table sizes 2^15, 2^15, 2^13, 2^11, 2^9
-    static const int kLogTbl[5] = {15, 15, 13, 11, 9};
-    static bool attr_set = false;
-    if (!attr_set) {
-        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_tc_oriented_block),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (1 << 15) * 4));
-        attr_set = true;
-    }
-    int64_t lo = 0;
-    for (int b = 0; b < 5; ++b) {
-        const int64_t hi = g->bin_end[b];
-        const int64_t cnt = part_count(lo, hi, nparts, part);
+    const int64_t cap_blocks = int64_t(c.compute_units > 0 ? c.compute_units : 256) * 16;
+    {
+        const int64_t cnt = part_count(0, n_block, nparts, part);
         if (cnt > 0) {
-            hipLaunchKernelGGL(k_tc_oriented_block, dim3(unsigned(cnt)), dim3(256), size_t(4) << kLogTbl[b], s, g->doff,
-                               g->dadj, g->order, lo, hi, nparts, part, kLogTbl[b], acc);
+            hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->order,
+                               int64_t(0), n_block, nparts, part, acc);
             ++launches;
         }
-        lo = hi;
     }
-    const int64_t cap_blocks = int64_t(c.compute_units > 0 ? c.compute_units : 256) * 32;
-    {  // 16 <= d+ < 64
-        const int64_t hi = g->bin_end[5];
-        const int64_t cnt = part_count(lo, hi, nparts, part);
+    {
+        const int64_t cnt = part_count(n_block, n_work, nparts, part);
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
-            hipLaunchKernelGGL(k_tc_oriented_wave<8>, dim3(unsigned(blocks)), dim3(256), 0, s, g->doff, g->dadj, g->order, lo,
-                               hi, nparts, part, acc);
-            ++launches;
-        }
-        lo = hi;
-    }
-    {  // 2 <= d+ < 16
-        const int64_t hi = g->bin_end[6];
-        const int64_t cnt = part_count(lo, hi, nparts, part);
-        if (cnt > 0) {
-            const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
-            hipLaunchKernelGGL(k_tc_oriented_wave<6>, dim3(unsigned(blocks)), dim3(256), 0, s, g->doff, g->dadj, g->order, lo,
-                               hi, nparts, part, acc);
+            hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->order,
+                               n_block, n_work, nparts, part, acc);
             ++launches;
         }
     }
@@ -282,12 +353,11 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     GMSX_HIP(hipGetLastError());
 
     if (st) {  // untimed bookkeeping
-        const int64_t hi = g->n;  // every oriented edge is a unit, also those of pivots with d+ < 2 (no work)
-        const int64_t cnt = part_count(0, hi, nparts, part);
+        const int64_t cnt = part_count(0, g->n, nparts, part);
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
-            hipLaunchKernelGGL(k_tc_oriented_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->doff, g->dadj, g->order,
-                               int64_t(0), hi, nparts, part, acc + kAccSlots * kAccStride);
+            hipLaunchKernelGGL(k_tc_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus,
+                               g->order, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
         }
     }
     unsigned long long host[kAccSlots * kAccStride + 2];
