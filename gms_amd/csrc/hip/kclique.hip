@@ -1,0 +1,395 @@
+// k-clique counting on gfx950: the device replacement for
+//   CliqueCount / RecursiveStepCliqueCount   (gms/algorithms/set_based/k_clique_count/k_clique_count_set_based.h:5-31)
+// whose inner operator is Set::intersect (sorted_set.h:160-166 -> sorted_set_operations.h:36-42).
+//
+// The reference recurses over the SYMMETRIC graph and returns k! * C_k (every clique once per vertex order).  Here
+// each clique is met once, on the degree-oriented DAG, and the result is multiplied by k! (mod 2^64, the reference's
+// size_t arithmetic) at the ABI.  Per pivot u (one workgroup, or one wave for d+ <= 32):
+//   1. BUILD ("LDS-staged intersect"): the pivot row N+(u) is staged into LDS as a hash map id -> local index; the
+//      rows N+(v), v in N+(u), are streamed from HBM and every id found in the map sets one bit of the local
+//      adjacency bit-matrix  rows[i] = N+(v_i) ∩ N+(u)  (d x d bits, in LDS up to d = 1024, else a global slab);
+//   2. COUNT: recursive set intersection on bit rows: cand' = cand & rows[j] (bitmap AND), popcount at the last
+//      level — the reference's `isect.intersect(N(vi))` recursion with sets as d-bit vectors, one 32-bit word per lane.
+#include "device_graph.hpp"
+
+#include <algorithm>
+
+namespace gmsx {
+
+static constexpr int kAccSlots = 64;
+static constexpr int kAccStride = 16;
+static constexpr int kMaxK = 10;
+
+__device__ __forceinline__ int64_t kc_readlane64(int64_t x, int l) {
+    const uint32_t lo = __builtin_amdgcn_readlane(uint32_t(uint64_t(x)), l);
+    const uint32_t hi = __builtin_amdgcn_readlane(uint32_t(uint64_t(x) >> 32), l);
+    return int64_t((uint64_t(hi) << 32) | lo);
+}
+
+// ---- id -> local index map (open addressing, keys -1 = empty) ---------------------------------------------
+__device__ __forceinline__ uint32_t kc_hash(int32_t w, int shift) { return (uint32_t(w) * 0x9E3779B1u) >> shift; }
+__device__ __forceinline__ void map_insert(int32_t *keys, uint16_t *vals, uint32_t mask, int shift, int32_t w, int idx) {
+    uint32_t h = kc_hash(w, shift);
+    while (atomicCAS(&keys[h], -1, w) != -1) h = (h + 1) & mask;
+    vals[h] = uint16_t(idx);
+}
+__device__ __forceinline__ int map_find(const int32_t *keys, const uint16_t *vals, uint32_t mask, int shift, int32_t w) {
+    uint32_t h = kc_hash(w, shift);
+    while (true) {
+        const int32_t x = keys[h];
+        if (x == w) return int(vals[h]);
+        if (x == -1) return -1;
+        h = (h + 1) & mask;
+    }
+}
+
+// stream both containers of the oriented row of rank id v; every id found in the map sets a bit of `row`
+template <class OrFn>
+__device__ __forceinline__ void build_row(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                          const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, int32_t v,
+                                          const int32_t *keys, const uint16_t *vals, uint32_t mask, int shift, int lane, OrFn or_bit) {
+    const int64_t hb = hoff[v], he = hoff[v + 1];
+    for (int64_t j = hb + lane; j < he; j += 64) {
+        const uint32_t w = hadj[j];
+        if (w != 0xFFFFu) {
+            const int idx = map_find(keys, vals, mask, shift, int32_t(w));
+            if (idx >= 0) or_bit(idx);
+        }
+    }
+    if (v >= kHub) {
+        const int64_t tb = toff[v], te = toff[v + 1];
+        for (int64_t j = tb + lane; j < te; j += 64) {
+            const int idx = map_find(keys, vals, mask, shift, tadj[j]);
+            if (idx >= 0) or_bit(idx);
+        }
+    }
+}
+
+// ---- counting ------------------------------------------------------------------------------------------------
+// Per-lane recursion for local graphs of <= 32 vertices (one 32-bit word per set).  Number of LV-cliques inside cand.
+template <int LV>
+__device__ __forceinline__ unsigned long long lane_cliques(const uint32_t *rows, uint32_t cand) {
+    if constexpr (LV == 1) {
+        return (unsigned long long)__popc(cand);
+    } else {
+        unsigned long long s = 0;
+        uint32_t it = cand;
+        while (it) {
+            const int j = __ffs(it) - 1;
+            it &= it - 1;
+            s += lane_cliques<LV - 1>(rows, cand & rows[j]);
+        }
+        return s;
+    }
+}
+
+// Wave-cooperative recursion: a set of up to 64*32*WPL local vertices is WPL words per lane.  Returns this lane's
+// share of the number of LV-cliques inside cand (sum over lanes = the count).  `rows` may be LDS or global.
+template <int LV, int WPL>
+__device__ __forceinline__ unsigned long long wave_cliques(const uint32_t *rows, int W, const uint32_t (&cand)[WPL], int lane);
+
+// expands every member of word-slice K of cand
+template <int LV, int WPL, int K>
+__device__ __forceinline__ unsigned long long expand_slice(const uint32_t *rows, int W, const uint32_t (&cand)[WPL], int lane) {
+    unsigned long long s = 0;
+    uint32_t it = cand[K];
+    while (true) {
+        const unsigned long long nz = __ballot(it != 0);
+        if (!nz) break;
+        const int L = __ffsll((long long)nz) - 1;                 // wave-uniform
+        const uint32_t word = __builtin_amdgcn_readlane(it, L);    // wave-uniform
+        const int bit = __ffs(word) - 1;
+        if (lane == L) it &= it - 1;
+        const int j = ((K * 64 + L) << 5) + bit;
+        const uint32_t *rj = rows + size_t(j) * W;
+        uint32_t nc[WPL];
+        nc[0] = lane < W ? (cand[0] & rj[lane]) : 0u;
+        if constexpr (WPL > 1) nc[1] = 64 + lane < W ? (cand[1] & rj[64 + lane]) : 0u;
+        s += wave_cliques<LV - 1, WPL>(rows, W, nc, lane);
+    }
+    return s;
+}
+
+template <int LV, int WPL>
+__device__ __forceinline__ unsigned long long wave_cliques(const uint32_t *rows, int W, const uint32_t (&cand)[WPL], int lane) {
+    static_assert(WPL == 1 || WPL == 2, "bit rows are one or two words per lane");
+    if constexpr (LV == 1) {
+        unsigned long long s = (unsigned long long)__popc(cand[0]);
+        if constexpr (WPL > 1) s += (unsigned long long)__popc(cand[1]);
+        return s;
+    } else {
+        unsigned long long s = expand_slice<LV, WPL, 0>(rows, W, cand, lane);
+        if constexpr (WPL > 1) s += expand_slice<LV, WPL, 1>(rows, W, cand, lane);
+        return s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// S: wave per pivot, 1 <= d+ <= 32.
+// ---------------------------------------------------------------------------------------------
+template <int LV>
+__global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                  const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                  const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
+                                                  int part, unsigned long long *__restrict__ acc) {
+    constexpr int LOG = 7, SIZE = 1 << LOG, SHIFT = 32 - LOG;
+    constexpr uint32_t MASK = SIZE - 1;
+    __shared__ int32_t keys_all[4 * SIZE];
+    __shared__ uint16_t vals_all[4 * SIZE];
+    __shared__ uint32_t rows_all[4 * 32];
+    __shared__ unsigned long long red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int32_t *keys = keys_all + wave * SIZE;
+    uint16_t *vals = vals_all + wave * SIZE;
+    uint32_t *rows = rows_all + wave * 32;
+    const int64_t nwaves = int64_t(gridDim.x) * 4;
+    unsigned long long cnt = 0;
+    for (int64_t q = int64_t(blockIdx.x) * 4 + wave;; q += nwaves) {
+        const int64_t pos = first + q * nparts + part;
+        if (pos >= end) break;  // uniform per wave
+        const int32_t u = order[pos];
+        const int64_t hb = hoff[u], tb = toff[u];
+        int hc = int(hoff[u + 1] - hb);
+        const int tc = int(toff[u + 1] - tb);
+        if (hc > 0 && hadj[hb + hc - 1] == 0xFFFFu) --hc;  // drop the pad
+        const int d = hc + tc;                               // <= 32
+        for (int i = lane; i < SIZE; i += 64) keys[i] = -1;
+        if (lane < 32) rows[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        int32_t my = -1;
+        if (lane < hc) my = int32_t(hadj[hb + lane]);
+        else if (lane < d) my = tadj[tb + (lane - hc)];
+        if (lane < d) map_insert(keys, vals, MASK, SHIFT, my, lane);
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < d; ++i) {
+            const int32_t v = __builtin_amdgcn_readlane(my, i);
+            build_row(hoff, hadj, toff, tadj, v, keys, vals, MASK, SHIFT, lane, [&](int idx) { atomicOr(&rows[i], 1u << idx); });
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < d) cnt += lane_cliques<LV>(rows, rows[lane]);
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
+    if (lane == 0) red[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long t = red[0] + red[1] + red[2] + red[3];
+        if (t) atomicAdd(&acc[(blockIdx.x & (kAccSlots - 1)) * kAccStride], t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// M / L: workgroup per pivot.  W = words per bit row.  GLOBAL_ROWS=false: bit-matrix in dynamic LDS (d <= 1024);
+// true: in a per-workgroup global slab (d up to 64*32*WPL), workgroups walk their pivots with a grid stride.
+// dynamic LDS layout: [rows: dmax*W u32 (LDS variant only)] [keys: 2^log i32] [vals: 2^log u16]
+// ---------------------------------------------------------------------------------------------
+template <int LV, int WPL, bool GLOBAL_ROWS>
+__global__ __launch_bounds__(256) void k_kc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                  const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                  const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
+                                                  int part, int dmax, int W, int log_map, uint32_t *__restrict__ slabs,
+                                                  unsigned long long *__restrict__ acc) {
+    extern __shared__ uint32_t smem[];
+    __shared__ unsigned long long red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int map_size = 1 << log_map, shift = 32 - log_map;
+    const uint32_t mask = uint32_t(map_size - 1);
+    uint32_t *rows = GLOBAL_ROWS ? slabs + size_t(blockIdx.x) * size_t(dmax) * size_t(W) : smem;
+    int32_t *keys = reinterpret_cast<int32_t *>(GLOBAL_ROWS ? smem : smem + size_t(dmax) * W);
+    uint16_t *vals = reinterpret_cast<uint16_t *>(keys + map_size);
+
+    unsigned long long cnt = 0;
+    for (int64_t q = blockIdx.x;; q += gridDim.x) {
+        const int64_t pos = first + q * nparts + part;
+        if (pos >= end) break;  // uniform per block
+        const int32_t u = order[pos];
+        const int64_t hb = hoff[u], tb = toff[u];
+        int hc = int(hoff[u + 1] - hb);
+        const int tc = int(toff[u + 1] - tb);
+        if (hc > 0 && hadj[hb + hc - 1] == 0xFFFFu) --hc;
+        const int d = hc + tc;
+        __syncthreads();  // previous pivot's counting is done
+        for (int i = tid; i < map_size; i += 256) keys[i] = -1;
+        for (int i = tid; i < d * W; i += 256) rows[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < d; i += 256) {
+            const int32_t v = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
+            map_insert(keys, vals, mask, shift, v, i);
+        }
+        if (GLOBAL_ROWS) __threadfence();
+        __syncthreads();
+        for (int i = wave; i < d; i += 4) {
+            const int32_t v = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
+            uint32_t *row = rows + size_t(i) * W;
+            build_row(hoff, hadj, toff, tadj, v, keys, vals, mask, shift, lane,
+                      [&](int idx) { atomicOr(&row[idx >> 5], 1u << (idx & 31)); });
+        }
+        if (GLOBAL_ROWS) {
+            __threadfence();
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop L1 lines of the slab cached for an earlier pivot
+        } else {
+            __syncthreads();
+        }
+        for (int i = wave; i < d; i += 4) {
+            uint32_t cand[WPL];
+            cand[0] = lane < W ? rows[size_t(i) * W + lane] : 0u;
+            if constexpr (WPL > 1) cand[1] = 64 + lane < W ? rows[size_t(i) * W + 64 + lane] : 0u;
+            cnt += wave_cliques<LV, WPL>(rows, W, cand, lane);
+        }
+    }
+    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
+    if (lane == 0) red[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long t = red[0] + red[1] + red[2] + red[3];
+        if (t) atomicAdd(&acc[(blockIdx.x & (kAccSlots - 1)) * kAccStride], t);
+    }
+}
+
+static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
+    const int64_t span = end - first - part;
+    return span <= 0 ? 0 : (span + nparts - 1) / nparts;
+}
+
+template <int LV>
+static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long long *acc, int *launches, uint32_t **slab_out) {
+    Ctx &c = ctx();
+    hipStream_t s = c.stream;
+    const int k = LV + 2;
+    // positions in the d+-sorted order
+    int64_t ge[8];
+    const int32_t thr[8] = {4097, 2049, 1025, 513, 257, 129, 65, 33};
+    for (int i = 0; i < 8; ++i)
+        if (int rc = count_dplus_ge(g, thr[i], &ge[i])) return rc;
+    int64_t n_min = 0;
+    if (int rc = count_dplus_ge(g, std::max(k - 1, 1), &n_min)) return rc;
+    if (ge[0] > 0) return GMSX_ERR_UNSUPPORTED;  // d+ > 4096: beyond the widest bit rows of this build
+    const int cu = c.compute_units > 0 ? c.compute_units : 256;
+
+    // L: 1024 < d+ <= 4096, bit-matrix in a global slab per workgroup
+    {
+        const int64_t lo = 0, hi = ge[2];
+        const int64_t cnt = part_count(lo, hi, nparts, part);
+        if (cnt > 0) {
+            const bool wide = ge[1] > 0;  // some d+ > 2048
+            const int dmax = wide ? 4096 : 2048, W = dmax / 32, log_map = wide ? 13 : 12;
+            const int64_t blocks = std::min<int64_t>(cnt, cu * 2);
+            uint32_t *slabs = nullptr;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(blocks) * dmax * W * sizeof(uint32_t)));
+            *slab_out = slabs;
+            const size_t lds = (size_t(4) << log_map) + (size_t(2) << log_map);
+            if (wide)
+                hipLaunchKernelGGL((k_kc_block<LV, 2, true>), dim3(unsigned(blocks)), dim3(256), lds, s, g->hoff, g->hadj, g->toff,
+                                   g->tadj, g->order, lo, hi, nparts, part, dmax, W, log_map, slabs, acc);
+            else
+                hipLaunchKernelGGL((k_kc_block<LV, 1, true>), dim3(unsigned(blocks)), dim3(256), lds, s, g->hoff, g->hadj, g->toff,
+                                   g->tadj, g->order, lo, hi, nparts, part, dmax, W, log_map, slabs, acc);
+            ++*launches;
+        }
+    }
+    // M: 32 < d+ <= 1024, bit-matrix in LDS; one launch per power-of-two bin
+    static bool attr_set[kMaxK] = {false};
+    if (!attr_set[LV]) {
+        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr_set[LV] = true;
+    }
+    for (int b = 0; b < 5; ++b) {
+        const int64_t lo = ge[2 + b], hi = std::min(ge[3 + b], n_min);
+        const int dmax = 1024 >> b, W = dmax / 32;
+        int log_map = 1;
+        while ((1 << log_map) < 2 * dmax) ++log_map;
+        const int64_t cnt = part_count(lo, hi, nparts, part);
+        if (cnt > 0) {
+            const size_t lds = size_t(dmax) * W * 4 + (size_t(4) << log_map) + (size_t(2) << log_map);
+            const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
+            hipLaunchKernelGGL((k_kc_block<LV, 1, false>), dim3(unsigned(blocks)), dim3(256), lds, s, g->hoff, g->hadj, g->toff,
+                               g->tadj, g->order, lo, hi, nparts, part, dmax, W, log_map, static_cast<uint32_t *>(nullptr), acc);
+            ++*launches;
+        }
+    }
+    // S: k-1 <= d+ <= 32
+    {
+        const int64_t lo = ge[7], hi = n_min;
+        const int64_t cnt = part_count(lo, hi, nparts, part);
+        if (cnt > 0) {
+            const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, int64_t(cu) * 32);
+            hipLaunchKernelGGL(k_kc_small<LV>, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->order,
+                               lo, hi, nparts, part, acc);
+            ++*launches;
+        }
+    }
+    return GMSX_OK;
+}
+
+static int kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint64_t *out, gmsx_stats *st) {
+    Ctx &c = ctx();
+    hipStream_t s = c.stream;
+    if (k == 2) {  // edges: Σ d+ over the shard
+        *out = 0;
+        if (part == 0) *out = uint64_t(g->m);  // every part but the first reports 0; the sum over parts is m
+        if (st) *st = gmsx_stats{0.0, 0.0, uint64_t(g->n), 0, 0, 0, 0};
+        return GMSX_OK;
+    }
+    unsigned long long *acc = nullptr;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), sizeof(unsigned long long) * kAccSlots * kAccStride));
+    struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{acc};
+    uint32_t *slabs = nullptr;
+    GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * kAccSlots * kAccStride, s));
+    GMSX_HIP(hipEventRecord(c.ev[0], s));
+    int launches = 0, rc = GMSX_OK;
+    switch (k) {
+        case 3: rc = launch_all<1>(g, part, nparts, acc, &launches, &slabs); break;
+        case 4: rc = launch_all<2>(g, part, nparts, acc, &launches, &slabs); break;
+        case 5: rc = launch_all<3>(g, part, nparts, acc, &launches, &slabs); break;
+        case 6: rc = launch_all<4>(g, part, nparts, acc, &launches, &slabs); break;
+        case 7: rc = launch_all<5>(g, part, nparts, acc, &launches, &slabs); break;
+        case 8: rc = launch_all<6>(g, part, nparts, acc, &launches, &slabs); break;
+        case 9: rc = launch_all<7>(g, part, nparts, acc, &launches, &slabs); break;
+        case 10: rc = launch_all<8>(g, part, nparts, acc, &launches, &slabs); break;
+        default: rc = GMSX_ERR_UNSUPPORTED;
+    }
+    Guard slab_guard{slabs};
+    if (rc) return rc;
+    GMSX_HIP(hipEventRecord(c.ev[1], s));
+    GMSX_HIP(hipGetLastError());
+    unsigned long long host[kAccSlots * kAccStride];
+    GMSX_HIP(hipMemcpyAsync(host, acc, sizeof(host), hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipStreamSynchronize(s));
+    unsigned long long total = 0;
+    for (int i = 0; i < kAccSlots; ++i) total += host[i * kAccStride];
+    *out = total;
+    if (st) {
+        float ms = 0.f;
+        GMSX_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+        *st = gmsx_stats{double(ms), 0.0, uint64_t(part_count(0, g->n, nparts, part)), 0, 0, launches, 0};
+    }
+    return GMSX_OK;
+}
+
+}  // namespace gmsx
+
+using namespace gmsx;
+
+extern "C" {
+
+int gmsx_kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint64_t *cliques_partial, gmsx_stats *stats) {
+    if (!g || !cliques_partial || nparts < 1 || part < 0 || part >= nparts || k < 2) return GMSX_ERR_INVALID;
+    if (k > kMaxK) return GMSX_ERR_UNSUPPORTED;
+    if (int rc = ensure_init()) return rc;
+    return kclique_partial(g, k, part, nparts, cliques_partial, stats);
+}
+
+int gmsx_kclique_count(const gmsx_graph *g, int k, uint64_t *ordered_count, uint64_t *cliques, gmsx_stats *stats) {
+    if (!ordered_count) return GMSX_ERR_INVALID;
+    uint64_t c = 0;
+    if (int rc = gmsx_kclique_partial(g, k, 0, 1, &c, stats)) return rc;
+    uint64_t fact = 1;
+    for (int i = 2; i <= k; ++i) fact *= uint64_t(i);  // mod 2^64, like the reference's size_t sum of ordered cliques
+    *ordered_count = c * fact;
+    if (cliques) *cliques = c;
+    return GMSX_OK;
+}
+
+}  // extern "C"

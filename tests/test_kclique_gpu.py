@@ -1,0 +1,95 @@
+"""GPU parity tests of the HIP k-clique path (gmsx_kclique_count = the reference's CliqueCount, k!*C_k) against the
+reference goldens, the oracle, and the known-answer cases of the reference's own clique-counting tests."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import edges_to_csr, host_graph, load_golden
+
+pytestmark = pytest.mark.gpu
+GRAPHS = load_golden("graphs.json")
+U64 = (1 << 64) - 1
+
+
+@pytest.mark.parametrize("key", [k for k, v in GRAPHS.items() if any(f"kc{i}" in v for i in (3, 4, 5))])
+def test_kclique_equals_reference_golden(gpu, key):
+    rec = GRAPHS[key]
+    g = gpu.DeviceGraph.from_csr(host_graph(gpu, rec["generator"], rec["scale"], rec["degree"], rec["relabel"]))
+    for k in (3, 4, 5):
+        if f"kc{k}" in rec:
+            ordered, cliques, st = g.kclique_count(k, stats=True)
+            assert ordered == rec[f"kc{k}"] and cliques * math.factorial(k) == ordered
+            assert st["kernel_ms"] > 0
+    if "triangles" in rec:
+        assert g.kclique_count(3)[1] == rec["triangles"] == g.tc_total()
+    assert g.kclique_count(2) == (2 * rec["m"], rec["m"])
+    g.free()
+
+
+@pytest.mark.parametrize("spec", [("kronecker", 9, 3), ("kronecker", 10, 30), ("uniform", 10, 40), ("kronecker", 12, 8)])
+def test_kclique_vs_oracle_k3_to_k7(gpu, oracle, spec):
+    kind, scale, deg = spec
+    csr = host_graph(gpu, kind, scale, deg, True)
+    g = gpu.DeviceGraph.from_csr(csr)
+    for k in (3, 4, 5, 6, 7):
+        if k >= 6 and (scale, deg) == (10, 30):
+            continue  # the oracle's k! * C recursion takes minutes there
+        want = oracle.kclique(csr.offsets(), csr.neighbors(), k)
+        assert g.kclique_count(k)[0] == want, (spec, k)
+    g.free()
+
+
+def test_known_answers_and_reference_test_graphs(gpu):
+    ka = load_golden("known_answers.json")
+    for c in ka["kclique"]:  # testing/clique_counting/CliqueCounter2_tests.h:45-271
+        g = gpu.DeviceGraph.from_csr(edges_to_csr(gpu, c["edges"]))
+        assert g.kclique_count(c["k"]) == (c["ordered"], c["cliques"]), c["name"]
+        g.free()
+    for c in ka["bk_random"]:
+        g = gpu.DeviceGraph.from_csr(edges_to_csr(gpu, c["edges"], n=c["n"]))
+        assert g.kclique_count(4)[0] == c["kc4"]
+        g.free()
+    import os
+    from conftest import GOLDEN
+    for name, rec in load_golden("testgraphs.json").items():
+        g = gpu.DeviceGraph.from_csr(gpu.HostCSR.load(os.path.join(GOLDEN, "testGraphs", name)))
+        assert g.kclique_count(3)[0] == rec["kc3"] and g.kclique_count(4)[0] == rec["kc4"]
+        g.free()
+
+
+def test_partials_sum_to_total(gpu):
+    g = gpu.DeviceGraph.from_csr(host_graph(gpu, "kronecker", 13, 16, True))
+    for k in (3, 4, 5):
+        total = g.kclique_count(k)[1]
+        for nparts in (2, 3, 8):
+            assert sum(g.kclique_partial(k, p, nparts) for p in range(nparts)) == total
+    g.free()
+
+
+def test_complete_graphs_exercise_every_bin(gpu):
+    # K_n: C_k = C(n,k); d+ runs 0..n-1, so n = 40 / 300 / 1100 / 2300 cover the wave kernel, the LDS bit-matrix bins,
+    # the global-slab kernel and its two-words-per-lane variant.  k! * C_k wraps mod 2^64 like the reference's size_t.
+    for n, ks in [(5, (3, 4, 5, 6)), (40, (3, 4, 5, 8, 10)), (300, (3, 4, 5)), (1100, (3, 4)), (2300, (3,))]:
+        iu = np.triu_indices(n, 1)
+        g = gpu.DeviceGraph.from_csr(gpu.HostCSR.from_edges(iu[0].astype(np.int32), iu[1].astype(np.int32)))
+        for k in ks:
+            ordered, cliques = g.kclique_count(k)
+            assert cliques == math.comb(n, k), (n, k)
+            assert ordered == (math.comb(n, k) * math.factorial(k)) & U64
+        g.free()
+
+
+def test_edge_cases_and_errors(gpu):
+    g = gpu.DeviceGraph.from_csr(edges_to_csr(gpu, [(0, 1), (1, 2)]))
+    assert g.kclique_count(3) == (0, 0) and g.kclique_count(2) == (4, 2) and g.kclique_count(10) == (0, 0)
+    with pytest.raises(gpu.GmsxError) as ei:
+        g.kclique_count(1)
+    assert ei.value.status == gpu.ERR_INVALID
+    with pytest.raises(gpu.GmsxError) as ei:
+        g.kclique_count(11)
+    assert ei.value.status == gpu.ERR_UNSUPPORTED
+    g.free()
+    e = gpu.DeviceGraph.from_csr(edges_to_csr(gpu, []))
+    assert e.kclique_count(4) == (0, 0)
+    e.free()
