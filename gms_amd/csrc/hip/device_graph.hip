@@ -85,7 +85,7 @@ __global__ void k_assign_ids(int64_t n, const unsigned long long *__restrict__ s
 
 // sizes of the two oriented containers of every vertex, written at its rank id (hub size padded to even)
 __global__ __launch_bounds__(256) void k_count_parts(int64_t n, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
-                                                     const int32_t *__restrict__ newid, int64_t *__restrict__ hcnt,
+                                                     const int32_t *__restrict__ newid, int hub_limit, int64_t *__restrict__ hcnt,
                                                      int64_t *__restrict__ tcnt, int32_t *__restrict__ dplus) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void k_count_parts(int64_t n, const int64_t *_
         for (int64_t j = b + lane; j < e; j += 64) {
             const int32_t nv = newid[adj[j]];
             if (nv < nu) {
-                if (nv < kHub) ch++; else ct++;
+                if (nv < hub_limit) ch++; else ct++;
             }
         }
         for (int s = 32; s > 0; s >>= 1) {
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_count_parts(int64_t n, const int64_t *_
 
 // order-preserving compaction of the oriented neighbours (as rank ids) into the hub / tail containers
 __global__ __launch_bounds__(256) void k_fill_parts(int64_t n, const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
-                                                    const int32_t *__restrict__ newid, const int64_t *__restrict__ hoff,
+                                                    const int32_t *__restrict__ newid, int hub_limit, const int64_t *__restrict__ hoff,
                                                     const int64_t *__restrict__ toff, uint16_t *__restrict__ hadj,
                                                     int32_t *__restrict__ tadj) {
     const int lane = threadIdx.x & 63;
@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void k_fill_parts(int64_t n, const int64_t *__
             int32_t nv = 0;
             if (j < e) {
                 nv = newid[adj[j]];
-                kh = nv < nu && nv < kHub;
-                kt = nv < nu && nv >= kHub;
+                kh = nv < nu && nv < hub_limit;
+                kt = nv < nu && nv >= hub_limit;
             }
             const unsigned long long mh = __ballot(kh), mt = __ballot(kt);
             const unsigned long long below = (1ull << lane) - 1ull;
@@ -255,7 +255,10 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         GMSX_HIP(hipStreamSynchronize(s));
     }
 
-    // 3. container sizes -> offsets
+    // 3. container sizes -> offsets.  Test hook: bits 8..23 of `flags` shrink the hub id range so that small graphs
+    //    exercise the tail containers (0 = the production value kHub).
+    int hub_limit = int((flags >> 8) & 0xffffu);
+    if (hub_limit == 0 || hub_limit > kHub) hub_limit = kHub;
     int64_t *hcnt = nullptr, *tcnt = nullptr;
     if (int rc = dmalloc(&hcnt, n + 1, nullptr)) return rc;
     DevGuard g_h{hcnt};
@@ -265,7 +268,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     GMSX_HIP(hipMemsetAsync(tcnt, 0, size_t(n + 1) * sizeof(int64_t), s));
     if (int rc = dmalloc(&g->dplus, n, g)) return rc;
     if (n > 0)
-        hipLaunchKernelGGL(k_count_parts, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, g->newid, hcnt, tcnt, g->dplus);
+        hipLaunchKernelGGL(k_count_parts, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, g->newid, hub_limit, hcnt, tcnt, g->dplus);
     if (int rc = dmalloc(&g->hoff, n + 1, g)) return rc;
     if (int rc = dmalloc(&g->toff, n + 1, g)) return rc;
     if (int rc = exclusive_scan_i64(hcnt, g->hoff, n + 1, s)) return rc;
@@ -279,7 +282,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     GMSX_HIP(hipMemsetAsync(g->hadj + g->hub_entries, 0xff, 8 * sizeof(uint16_t), s));
     GMSX_HIP(hipMemsetAsync(g->tadj + g->tail_entries, 0xff, 4 * sizeof(int32_t), s));
     if (n > 0)
-        hipLaunchKernelGGL(k_fill_parts, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, g->newid, g->hoff, g->toff,
+        hipLaunchKernelGGL(k_fill_parts, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, g->newid, hub_limit, g->hoff, g->toff,
                            g->hadj, g->tadj);
 
     // 5. work-sorted launch order: rank ids by decreasing d+

@@ -56,7 +56,7 @@ __device__ __forceinline__ void build_row(const int64_t *__restrict__ hoff, cons
             if (idx >= 0) or_bit(idx);
         }
     }
-    if (v >= kHub) {
+    {   // hub vertices simply have an empty tail container
         const int64_t tb = toff[v], te = toff[v + 1];
         for (int64_t j = tb + lane; j < te; j += 64) {
             const int idx = map_find(keys, vals, mask, shift, tadj[j]);

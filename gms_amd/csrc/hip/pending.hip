@@ -2,8 +2,6 @@
 // (GMSX_ERR_UNSUPPORTED) rather than fall back to any host path.
 #include "device_graph.hpp"
 extern "C" {
-int gmsx_tc_vertex_count2(const gmsx_graph *, int64_t *, gmsx_stats *) { return GMSX_ERR_UNSUPPORTED; }
-int gmsx_intersect_count_batch(const gmsx_graph *, int64_t, const int32_t *, const int32_t *, uint32_t *, gmsx_stats *) { return GMSX_ERR_UNSUPPORTED; }
 int gmsx_bk_count(const gmsx_graph *, const int32_t *, uint64_t *, gmsx_stats *) { return GMSX_ERR_UNSUPPORTED; }
 int gmsx_bk_partial(const gmsx_graph *, const int32_t *, int, int, uint64_t *, gmsx_stats *) { return GMSX_ERR_UNSUPPORTED; }
 }

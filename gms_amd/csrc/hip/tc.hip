@@ -393,7 +393,7 @@ int gmsx_tc_partial(const gmsx_graph *g, int algo, int part, int nparts, uint64_
     if (!g || !partial || nparts < 1 || part < 0 || part >= nparts) return GMSX_ERR_INVALID;
     if (algo != GMSX_TC_AUTO && algo != GMSX_TC_ORIENTED && algo != GMSX_TC_FULL) return GMSX_ERR_INVALID;
     if (int rc = ensure_init()) return rc;
-    if (algo == GMSX_TC_FULL) return GMSX_ERR_UNSUPPORTED;
+    if (algo == GMSX_TC_FULL) return tc_full_partial(g, part, nparts, partial, stats);
     return tc_oriented(g, part, nparts, partial, stats);
 }
 

@@ -118,7 +118,10 @@ int gmsx_device_info(char *name, size_t name_len, int *compute_units, int64_t *h
 enum {
     GMSX_UPLOAD_DEFAULT = 0,
     GMSX_UPLOAD_TRUSTED = 1 /* skip the device-side check of the canonical-row invariant */
+    /* bits 8..23 (test hook): if non-zero, the hub-container id range is [0, value) instead of [0, 65535), so that
+       small graphs exercise the 32-bit tail containers; results never depend on it */
 };
+#define GMSX_UPLOAD_HUB_LIMIT(x) ((uint32_t)(x) << 8)
 /* SetGraph::FromCGraph (set_graph.h:86-89,152-181): copies the CSR into HBM and builds the device-side
  * set representations (degree-oriented DAG rows; the analogue of the per-row SortedSet / RoaringSet
  * construction, sorted_set.h:64-66 / roaring_set.h:49-54).  Timed by callers as "GraphExec buildTime"

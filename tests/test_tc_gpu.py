@@ -139,3 +139,24 @@ def test_config2_scale24_golden(gpu):
     parts = [g.tc_partial(p, 8) for p in range(8)]
     assert sum(parts) == rec["triangles"]
     g.free()
+
+
+@pytest.mark.parametrize("hub_limit", [1, 16, 300, 5000])
+def test_tail_containers_and_tiling(gpu, oracle, hub_limit):
+    """Shrinking the hub id range (upload test hook) pushes ids into the 32-bit tail containers: same counts.
+    The dense block gives pivots with > 1024 tail entries, i.e. the tiled hash-set path."""
+    flags = gpu.UPLOAD_DEFAULT | (hub_limit << 8)
+    csr = host_graph(gpu, "kronecker", 13, 16, True)
+    g = gpu.DeviceGraph.from_csr(csr, flags=flags)
+    want = GRAPHS.get("kronecker-13-16-relabel", {}).get("triangles") or oracle.tc_total(csr.offsets(), csr.neighbors())
+    assert g.tc_total() == want
+    assert sum(g.tc_partial(p, 5) for p in range(5)) == want
+    ordered = g.kclique_count(4)[0]
+    assert ordered == oracle.kclique(csr.offsets(), csr.neighbors(), 4)
+    g.free()
+    k = 2600
+    iu = np.triu_indices(k, 1)
+    dense = gpu.HostCSR.from_edges(iu[0].astype(np.int32), iu[1].astype(np.int32))
+    g = gpu.DeviceGraph.from_csr(dense, flags=flags)
+    assert g.tc_total() == k * (k - 1) * (k - 2) // 6
+    g.free()
