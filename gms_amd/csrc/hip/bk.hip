@@ -1,0 +1,410 @@
+// Bron–Kerbosch maximal-clique COUNT on gfx950: the device replacement for
+//   BkEppsteinPar::mceBench   gms/algorithms/set_based/maximal_clique_enum/parallel/eppsteinPAR.h:18-53
+//   BkTomita::expand/findPivot gms/algorithms/set_based/maximal_clique_enum/sequential/tomita.h:12-86
+// compiled with -DBK_COUNT (the reference's count-only build: BK_CLIQUE_COUNTER, helper.h:15).
+//
+// Eppstein outer loop: every vertex v starts one search with cand = higher-ranked neighbours, fini = lower-ranked
+// ones.  The count does not depend on the rank, so the device uses its own degree rank: cand = the
+// oriented row N+(v) (|cand| <= d+max), fini = the in-neighbours N-(v).  Inside a search all sets are BITMAPS over the
+// local universe and every set operation of the reference becomes a word-wise AND ("RoaringSet bitmap-AND"):
+//   cand.intersect(N(q))  ->  P  & Cadj[q]      (c-bit rows, one 32-bit word per lane)
+//   fini.intersect(N(q))  ->  Xc & Cadj[q]  (finished candidates)   and   Xf & XT[q]  (the in-neighbours, x-bit rows)
+//   cand.difference(N(p)) ->  P & ~Cadj[p]
+//   findPivot             ->  argmax_u popc(P & Cadj[u]) over u in P ∪ Xc  (any pivot choice yields the same count)
+// One wave per start vertex runs the recursion with an explicit stack; tiny problems keep every structure in LDS,
+// larger ones in a per-wave slab of global memory (L2-resident).  Start vertices are pulled heavy-first from a queue.
+#include "device_graph.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace gmsx {
+
+static constexpr int kLdsSlabWords = 4096;  // 16 KB per wave
+static constexpr unsigned long long kEmptySlot = ~0ull;
+
+struct BkTask {
+    int32_t v;        // rank id of the start vertex
+    uint32_t words;   // slab words it needs
+};
+
+__host__ __device__ inline uint32_t bk_map_size(int c) {
+    uint32_t s = 64;
+    while (s < 2u * uint32_t(c)) s <<= 1;
+    return s;
+}
+__host__ __device__ inline unsigned long long bk_slab_words(int c, long long x) {
+    const unsigned long long cw = (unsigned long long)((c + 31) / 32), xw = (unsigned long long)((x + 31) / 32);
+    return 2ull * bk_map_size(c) + (unsigned long long)c * cw + (unsigned long long)c * xw +
+           (unsigned long long)(c + 1) * (3 * cw + xw + 1);
+}
+
+// per start vertex: slab requirement (0 = no search needed); isolated vertices are counted right here
+__global__ void k_bk_tasks(int64_t n, const int64_t *__restrict__ off, const int32_t *__restrict__ oldid,
+                           const int32_t *__restrict__ dplus, unsigned long long *__restrict__ keys, int32_t *__restrict__ vals,
+                           unsigned long long *__restrict__ acc /* [0] isolated count, [1] too-wide flag */) {
+    const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const int32_t o = oldid[v];
+    const long long deg = off[o + 1] - off[o];
+    const int c = dplus[v];
+    const long long x = deg - c;
+    unsigned long long w = 0;
+    if (c == 0) {
+        if (deg == 0) atomicAdd(&acc[0], 1ull);  // an isolated vertex is a maximal clique (eppsteinPAR.h:32-47, tomita.h:73-78)
+    } else {
+        w = bk_slab_words(c, x);
+        if (c > 2048) atomicOr(&acc[1], 1ull);
+    }
+    keys[v] = w;
+    vals[v] = int32_t(v);
+}
+
+__device__ __forceinline__ uint32_t bk_hash(int32_t w, uint32_t mask) { return (uint32_t(w) * 0x9E3779B1u >> 7) & mask; }
+
+__device__ __forceinline__ int bk_find(const unsigned long long *map, uint32_t mask, int32_t w) {
+    uint32_t h = bk_hash(w, mask);
+    while (true) {
+        const unsigned long long s = __hip_atomic_load(&map[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s == kEmptySlot) return -1;
+        if (int32_t(s >> 32) == w) return int(s & 0xffffffffull);
+        h = (h + 1) & mask;
+    }
+}
+
+// scan both oriented containers of rank id a; for every id that is a member of C call f(local index)
+template <class F>
+__device__ __forceinline__ void bk_scan_row(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                            const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, int32_t a,
+                                            const unsigned long long *map, uint32_t mask, int start, int stride, F f) {
+    const int64_t hb = hoff[a], he = hoff[a + 1];
+    for (int64_t j = hb + start; j < he; j += stride) {
+        const uint32_t w = hadj[j];
+        if (w != 0xFFFFu) {
+            const int k = bk_find(map, mask, int32_t(w));
+            if (k >= 0) f(k);
+        }
+    }
+    const int64_t tb = toff[a], te = toff[a + 1];
+    for (int64_t j = tb + start; j < te; j += stride) {
+        const int k = bk_find(map, mask, tadj[j]);
+        if (k >= 0) f(k);
+    }
+}
+
+__device__ __forceinline__ int wave_sum(int x) {
+    for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s);
+    return x;
+}
+
+// One wave per start vertex.  LDS_SLAB: every structure of the search lives in this wave's LDS slab (tasks of at most
+// kLdsSlabWords words); otherwise in slabs[wave_global_id * slab_words].
+template <bool LDS_SLAB>
+__global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
+                                                const int32_t *__restrict__ newid, const int32_t *__restrict__ oldid,
+                                                const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                const int32_t *__restrict__ dplus, const int32_t *__restrict__ task_v,
+                                                int64_t first, int64_t end, int nparts, int part,
+                                                unsigned long long *__restrict__ queue, uint32_t *__restrict__ slabs,
+                                                unsigned long long slab_words, unsigned long long *__restrict__ acc) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds_slab[LDS_SLAB ? kLdsSlabWords : 4];
+    __shared__ unsigned char xfne_stack[2052];  // per level: is Xf non-empty (written by one lane, read by all)
+    const int lane = threadIdx.x;
+    uint32_t *slab = LDS_SLAB ? lds_slab : slabs + size_t(blockIdx.x) * slab_words;
+    unsigned long long cnt = 0;
+    while (true) {
+        unsigned long long q0 = 0;
+        if (lane == 0) q0 = atomicAdd(queue, 1ull);
+        const int64_t qi = int64_t(__shfl(q0, 0));
+        const int64_t pos = first + qi * nparts + part;
+        if (pos >= end) break;
+        const int32_t v = task_v[pos];
+        const int32_t vo = oldid[v];
+        const int c = dplus[v];
+        const int64_t ob = off[vo], oe = off[vo + 1];
+        const int x = int(oe - ob) - c;
+        const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
+        const uint32_t msize = bk_map_size(c), mmask = msize - 1;
+        unsigned long long *map = reinterpret_cast<unsigned long long *>(slab);
+        uint32_t *Cadj = slab + 2 * size_t(msize);
+        uint32_t *XT = Cadj + size_t(c) * cw;
+        uint32_t *stack = XT + size_t(c) * xw;
+        const int lvl = 3 * cw + xw + 1;  // words per stack level: P, Xc, ext, Xf (+1 spare)
+
+        // ---- build: map, Cadj (symmetric closure of the DAG rows inside C), XT (C x X0 adjacency) -------------------
+        for (uint32_t i = lane; i < msize; i += 64) map[i] = kEmptySlot;
+        for (size_t i = lane; i < size_t(c) * cw + size_t(c) * xw; i += 64) Cadj[i] = 0;
+        if (!LDS_SLAB) __threadfence();
+        __builtin_amdgcn_wave_barrier();
+        const int64_t hb = hoff[v], tb = toff[v];
+        int hc = int(hoff[v + 1] - hb);
+        if (hc > 0 && hadj[hb + hc - 1] == 0xFFFFu) --hc;
+        for (int i = lane; i < c; i += 64) {
+            const int32_t a = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
+            uint32_t h = bk_hash(a, mmask);
+            const unsigned long long packed = ((unsigned long long)uint32_t(a) << 32) | (unsigned long long)uint32_t(i);
+            while (atomicCAS(&map[h], kEmptySlot, packed) != kEmptySlot) h = (h + 1) & mmask;
+        }
+        if (!LDS_SLAB) __threadfence();
+        __builtin_amdgcn_wave_barrier();
+        for (int i = 0; i < c; ++i) {  // rows of the candidates: all lanes stream one row
+            const int32_t a = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
+            bk_scan_row(hoff, hadj, toff, tadj, a, map, mmask, lane, 64, [&](int k) {
+                atomicOr(&Cadj[size_t(i) * cw + (k >> 5)], 1u << (k & 31));
+                atomicOr(&Cadj[size_t(k) * cw + (i >> 5)], 1u << (i & 31));
+            });
+        }
+        // rows of the in-neighbours: one lane per row (they are short); t = index of the in-neighbour in X0
+        int xbase = 0;
+        for (int64_t e0 = ob; e0 < oe; e0 += 64) {
+            const int64_t e = e0 + lane;
+            int32_t nw = -1;
+            bool keep = false;
+            if (e < oe) {
+                nw = newid[adj[e]];
+                keep = nw > v;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int t = xbase + __popcll(m & ((1ull << lane) - 1ull));
+                bk_scan_row(hoff, hadj, toff, tadj, nw, map, mmask, 0, 1,
+                            [&](int k) { atomicOr(&XT[size_t(k) * xw + (t >> 5)], 1u << (t & 31)); });
+            }
+            xbase += __popcll(m);
+        }
+        if (!LDS_SLAB) {
+            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop L1 lines of the slab cached for an earlier task
+        }
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- search: iterative Tomita recursion on bitmaps --------------------------------------------------------
+        // registers: this lane's word of P / Xc / ext (lanes >= cw hold 0); Xf levels and saved words live in `stack`
+        uint32_t P = 0, Xc = 0, ext = 0;
+        if (lane < cw) {
+            const int bits = c - lane * 32;
+            P = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+        }
+        for (int w = lane; w < xw; w += 64) {
+            const int bits = x - w * 32;
+            stack[3 * cw + w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+        }
+        int xf_ne = x > 0 ? 1 : 0;  // wave-uniform: is Xf of the current level non-empty
+        int depth = 0;
+        bool entering = true;
+        while (true) {
+            if (entering) {
+                if (__ballot(P != 0) == 0) {
+                    if (__ballot(Xc != 0) == 0 && !xf_ne) cnt++;
+                    entering = false;
+                    if (depth == 0) break;
+                    --depth;  // pop
+                    uint32_t *lv = stack + size_t(depth) * lvl;
+                    P = lane < cw ? lv[lane] : 0u;
+                    Xc = lane < cw ? lv[cw + lane] : 0u;
+                    ext = lane < cw ? lv[2 * cw + lane] : 0u;
+                    xf_ne = int(xfne_stack[depth]);
+                    continue;
+                }
+                // pivot: argmax over u in P ∪ Xc of |P ∩ N(u)|
+                uint32_t it = P | Xc;
+                int best = -1, best_score = -1;
+                while (true) {
+                    const unsigned long long nz = __ballot(it != 0);
+                    if (!nz) break;
+                    const int L = __ffsll((long long)nz) - 1;
+                    const uint32_t word = __builtin_amdgcn_readlane(it, L);
+                    const int bit = __ffs(word) - 1;
+                    if (lane == L) it &= it - 1;
+                    const int u = (L << 5) + bit;
+                    const uint32_t row = lane < cw ? Cadj[size_t(u) * cw + lane] : 0u;
+                    const int s = wave_sum(__popc(P & row));
+                    if (s > best_score) {
+                        best_score = s;
+                        best = u;
+                    }
+                }
+                const uint32_t prow = lane < cw ? Cadj[size_t(best) * cw + lane] : 0u;
+                ext = P & ~prow;
+                entering = false;
+            }
+            // next branch vertex q of this node
+            const unsigned long long nz = __ballot(ext != 0);
+            if (!nz) {
+                if (depth == 0) break;
+                --depth;  // pop
+                uint32_t *lv = stack + size_t(depth) * lvl;
+                P = lane < cw ? lv[lane] : 0u;
+                Xc = lane < cw ? lv[cw + lane] : 0u;
+                ext = lane < cw ? lv[2 * cw + lane] : 0u;
+                xf_ne = int(xfne_stack[depth]);
+                continue;
+            }
+            const int L = __ffsll((long long)nz) - 1;
+            const uint32_t word = __builtin_amdgcn_readlane(ext, L);
+            const int bit = __ffs(word) - 1;
+            const int q = (L << 5) + bit;
+            const uint32_t qrow = lane < cw ? Cadj[size_t(q) * cw + lane] : 0u;
+            const uint32_t Pn = P & qrow, Xcn = Xc & qrow;
+            uint32_t *lv = stack + size_t(depth) * lvl;
+            uint32_t *nx = lv + lvl;
+            int child_ne = 0;
+            if (xf_ne) {
+                uint32_t any = 0;
+                const uint32_t *xt = XT + size_t(q) * xw;
+                for (int w = lane; w < xw; w += 64) {
+                    const uint32_t t = lv[3 * cw + w] & xt[w];
+                    nx[3 * cw + w] = t;
+                    any |= t;
+                }
+                child_ne = __ballot(any != 0) != 0 ? 1 : 0;
+            }
+            // this node continues with q moved from cand to fini (tomita.h:68-70)
+            if (lane == L) {
+                ext &= ~(1u << bit);
+                P &= ~(1u << bit);
+                Xc |= 1u << bit;
+            }
+            if (lane < cw) {
+                lv[lane] = P;
+                lv[cw + lane] = Xc;
+                lv[2 * cw + lane] = ext;
+            }
+            if (lane == 0) xfne_stack[depth] = (unsigned char)xf_ne;
+            __builtin_amdgcn_wave_barrier();
+            ++depth;
+            P = Pn;
+            Xc = Xcn;
+            xf_ne = child_ne;
+            entering = true;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
+}
+
+static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
+    const int64_t span = end - first - part;
+    return span <= 0 ? 0 : (span + nparts - 1) / nparts;
+}
+
+static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, gmsx_stats *st) {
+    Ctx &c = ctx();
+    hipStream_t s = c.stream;
+    const int64_t n = g->n;
+    struct Guard { void *p = nullptr; ~Guard() { (void)hipFree(p); } } g_acc, g_ki, g_ko, g_vi, g_vo, g_tmp, g_slab;
+    unsigned long long *acc = nullptr;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), sizeof(unsigned long long) * (64 * 16 + 4)));
+    g_acc.p = acc;
+    GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * (64 * 16 + 4), s));
+    if (n == 0) {
+        *out = 0;
+        if (st) *st = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
+        return GMSX_OK;
+    }
+    // ---- tasks: slab requirement per start vertex, heavy first (untimed setup, like the reference's preprocessing step)
+    unsigned long long *k_in = nullptr, *k_out = nullptr;
+    int32_t *v_in = nullptr, *v_out = nullptr;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&k_in), size_t(n) * 8)); g_ki.p = k_in;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&k_out), size_t(n) * 8)); g_ko.p = k_out;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&v_in), size_t(n) * 4)); g_vi.p = v_in;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&v_out), size_t(n) * 4)); g_vo.p = v_out;
+    GMSX_HIP(hipEventRecord(c.ev[0], s));
+    hipLaunchKernelGGL(k_bk_tasks, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->off, g->oldid, g->dplus, k_in, v_in,
+                       acc + 64 * 16);
+    size_t tmp_bytes = 0;
+    GMSX_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, size_t(n), 0, 64, s));
+    void *tmp = nullptr;
+    GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+    g_tmp.p = tmp;
+    GMSX_HIP(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, k_in, k_out, v_in, v_out, size_t(n), 0, 64, s));
+    std::vector<unsigned long long> words(static_cast<size_t>(n));
+    unsigned long long head[4] = {0, 0, 0, 0};
+    GMSX_HIP(hipMemcpyAsync(words.data(), k_out, size_t(n) * 8, hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipMemcpyAsync(head, acc + 64 * 16, sizeof(head), hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipStreamSynchronize(s));
+    if (head[1]) return GMSX_ERR_UNSUPPORTED;  // a start vertex with more than 2048 candidates (one word per lane)
+    GMSX_HIP(hipEventRecord(c.ev[1], s));
+
+    // bins of the heavy-first task order by slab size: (4^k) steps; the last bin (<= kLdsSlabWords) runs out of LDS
+    int64_t n_tasks = 0;
+    while (n_tasks < n && words[size_t(n_tasks)] > 0) ++n_tasks;
+    const int cu = c.compute_units > 0 ? c.compute_units : 256;
+    size_t free_b = 0, total_b = 0;
+    GMSX_HIP(hipMemGetInfo(&free_b, &total_b));
+    const unsigned long long budget = std::min<unsigned long long>(free_b / 2, 32ull << 30);
+    int launches = 0;
+    unsigned long long *queue = acc + 64 * 16 + 2;
+    int64_t lo = 0;
+    while (lo < n_tasks) {
+        const unsigned long long top = words[size_t(lo)];
+        const bool lds = top <= (unsigned long long)kLdsSlabWords;
+        // tasks sharing this bin: down to a quarter of the largest slab (or everything that fits LDS)
+        int64_t hi = lo;
+        while (hi < n_tasks && (lds || words[size_t(hi)] * 4 > top)) ++hi;
+        const int64_t cnt = part_count(lo, hi, nparts, part);
+        if (cnt > 0) {
+            GMSX_HIP(hipMemsetAsync(queue, 0, 8, s));
+            if (lds) {
+                const int64_t waves = std::min<int64_t>(cnt, int64_t(cu) * 10);
+                hipLaunchKernelGGL(k_bk_wave<true>, dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff,
+                                   g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue,
+                                   static_cast<uint32_t *>(nullptr), 0ull, acc);
+            } else {
+                const unsigned long long slab_w = (top + 3ull) & ~3ull;  // 16-byte aligned slabs (64-bit map slots)
+                const unsigned long long slab_bytes = slab_w * 4ull;
+                if (slab_bytes > budget) return GMSX_ERR_DEVICE_MEM;
+                const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({cnt, int64_t(cu) * 16, int64_t(budget / slab_bytes)}));
+                uint32_t *slabs = nullptr;
+                GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(waves) * slab_bytes));
+                hipLaunchKernelGGL(k_bk_wave<false>, dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
+                                   g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc);
+                GMSX_HIP(hipStreamSynchronize(s));  // the slab is reused by the next bin
+                GMSX_HIP(hipFree(slabs));
+            }
+            ++launches;
+        }
+        lo = hi;
+    }
+    GMSX_HIP(hipEventRecord(c.ev[2], s));
+    GMSX_HIP(hipGetLastError());
+    unsigned long long host[64 * 16 + 4];
+    GMSX_HIP(hipMemcpyAsync(host, acc, sizeof(host), hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipStreamSynchronize(s));
+    unsigned long long total = 0;
+    for (int i = 0; i < 64; ++i) total += host[i * 16];
+    if (part == 0) total += host[64 * 16];  // isolated vertices, counted once
+    *out = total;
+    if (st) {
+        float ms_setup = 0.f, ms = 0.f;
+        GMSX_HIP(hipEventElapsedTime(&ms_setup, c.ev[0], c.ev[1]));
+        GMSX_HIP(hipEventElapsedTime(&ms, c.ev[1], c.ev[2]));
+        *st = gmsx_stats{double(ms), double(ms_setup), uint64_t(part_count(0, n, nparts, part)), 0, 0, launches, 0};
+    }
+    return GMSX_OK;
+}
+
+}  // namespace gmsx
+
+using namespace gmsx;
+
+extern "C" {
+
+int gmsx_bk_partial(const gmsx_graph *g, const int32_t *rank, int part, int nparts, uint64_t *partial, gmsx_stats *stats) {
+    // `rank` is accepted for interface parity with mceBench(graph, ordering); the number of maximal cliques does not
+    // depend on it, and the device always uses its own degree rank.
+    (void)rank;
+    if (!g || !partial || nparts < 1 || part < 0 || part >= nparts) return GMSX_ERR_INVALID;
+    if (int rc = ensure_init()) return rc;
+    return bk_partial(g, part, nparts, partial, stats);
+}
+
+int gmsx_bk_count(const gmsx_graph *g, const int32_t *rank, uint64_t *maximal_cliques, gmsx_stats *stats) {
+    return gmsx_bk_partial(g, rank, 0, 1, maximal_cliques, stats);
+}
+
+}  // extern "C"
