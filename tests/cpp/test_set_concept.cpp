@@ -1,0 +1,113 @@
+// CPU test of the C++ adaptor (include/gmsx_set_graph.hpp): gmsx::SortedSpanSet must behave like the reference's
+// Set concept on the literal cases of testing/sets.cpp (values restated from SURVEY §8b), and gmsx::HipSetGraph must
+// expose the SGraph surface.  With -DWITH_REFERENCE the reference's own generic algorithm templates are instantiated
+// over HipSetGraph on the host (no device call) and compared with the reference's SortedSetGraph.
+#include <cassert>
+#include <cstdio>
+#include <vector>
+
+#ifdef WITH_REFERENCE
+#include "gms/third_party/gapbs/benchmark.h"
+#include <gms/common/cli/cli.h>
+#include <gms/common/types.h>
+#include <gms/representations/graphs/set_graph.h>
+#include <gms/algorithms/set_based/triangle_count/triangle_count.h>
+#include <gms/algorithms/set_based/k_clique_count/k_clique_count_set_based.h>
+#include <gms/algorithms/set_based/maximal_clique_enum/bron_kerbosch.h>
+#endif
+
+#include "gmsx_set_graph.hpp"
+
+using S = gmsx::SortedSpanSet;
+#define CHECK(x) do { if (!(x)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #x); return 1; } } while (0)
+
+static std::vector<int> vec(const S &s) { return std::vector<int>(s.begin(), s.end()); }
+
+int main() {
+    // construction is order-insensitive and from unsorted input (sets.cpp:39,80-94)
+    CHECK(S({2, 4, 8}) == S({4, 2, 8}));
+    const int raw[] = {1, 5, 2, 7, 9, 0, 3};
+    CHECK(S(raw, 7).cardinality() == 7);
+    CHECK(S(raw, 0).cardinality() == 0);
+    CHECK(S(5).cardinality() == 1 && S(5).contains(5));
+    // intersect / intersect_count symmetric and consistent (sets.cpp:108-141)
+    const S e{}, a{1, 2, 3}, b{4, 5, 6}, c{1, 2, 3, 4, 5}, d{3, 4, 5, 6, 7}, f{1, 2, 3, 4, 5, 6, 7}, h{2, 4, 6, 8};
+    CHECK(e.intersect_count(e) == 0 && e.intersect_count(a) == 0 && a.intersect_count(e) == 0 && a.intersect_count(b) == 0);
+    CHECK(vec(c.intersect(d)) == (std::vector<int>{3, 4, 5}) && c.intersect_count(d) == 3 && d.intersect_count(c) == 3);
+    CHECK(vec(f.intersect(h)) == (std::vector<int>{2, 4, 6}) && vec(h.intersect(f)) == (std::vector<int>{2, 4, 6}));
+    CHECK(a.intersect(a) == a && a.intersect_count(a) == 3);
+    {   // intersect_inplace must not modify its argument (sets.cpp:144-158)
+        S x = c.clone(), y = d.clone();
+        x.intersect_inplace(y);
+        CHECK(vec(x) == (std::vector<int>{3, 4, 5}) && y == d);
+    }
+    // union (sets.cpp:194-292): union_count 0,3,6,7,5
+    CHECK(e.union_count(e) == 0 && e.union_count(a) == 3 && a.union_count(b) == 6 && c.union_count(d) == 7 && c.union_count(S{3, 4, 5}) == 5);
+    CHECK(vec(a.union_with(b)) == (std::vector<int>{1, 2, 3, 4, 5, 6}));
+    {
+        S x = a.union_with(9).union_with(0);
+        CHECK(vec(x) == (std::vector<int>{0, 1, 2, 3, 9}));
+        x.union_inplace(9);  // idempotent
+        CHECK(x.cardinality() == 5);
+        x.union_inplace(b);
+        CHECK(x.cardinality() == 8);
+    }
+    // difference both directions (sets.cpp:311-357): {1..5}\{3,4,5,6,8}={1,2}; reverse {6,8}; absent element is a no-op
+    const S g{3, 4, 5, 6, 8};
+    CHECK(vec(c.difference(g)) == (std::vector<int>{1, 2}) && vec(g.difference(c)) == (std::vector<int>{6, 8}));
+    CHECK(vec(c.difference(3)) == (std::vector<int>{1, 2, 4, 5}) && c.difference(42) == c);
+    {
+        S x = c.clone();
+        x.difference_inplace(g);
+        CHECK(vec(x) == (std::vector<int>{1, 2}));
+        x.remove(7);
+        CHECK(x.cardinality() == 2);
+        x.add(0); x.add(9); x.add(1);  // front / end / existing (sets.cpp:404-429)
+        CHECK(vec(x) == (std::vector<int>{0, 1, 2, 9}));
+    }
+    CHECK(c.contains(1) && c.contains(5) && !c.contains(0) && !c.contains(6) && !e.contains(0));
+    CHECK(S::Range(0).cardinality() == 0 && vec(S::Range(5)) == (std::vector<int>{0, 1, 2, 3, 4}));
+    {
+        int buf[3] = {-1, -1, -1};
+        e.toArray(buf);
+        CHECK(buf[0] == -1);  // empty set leaves the buffer untouched (sets.cpp:475-492)
+        a.toArray(buf);
+        CHECK(buf[0] + buf[1] + buf[2] == 6);
+    }
+    CHECK(c != d && !(c == d));
+
+    // SGraph surface on a tiny CSR through the C-ABI host substrate (no device call)
+    const int32_t src[] = {0, 1, 2, 2}, dst[] = {1, 2, 0, 3};
+    gmsx_csr *csr = nullptr;
+    CHECK(gmsx_csr_from_edges(-1, 4, src, dst, 1, GMSX_RELABEL_NEVER, &csr) == GMSX_OK);
+    gmsx::HipSetGraph hg = gmsx::HipSetGraph::FromCsr(csr);
+    CHECK(hg.num_nodes() == 4 && hg.out_degree(2) == 3 && vec(hg.out_neigh(2)) == (std::vector<int>{0, 1, 3}));
+    CHECK(hg.out_neigh(0).intersect_count(hg.out_neigh(1)) == 1);
+    gmsx_csr_free(csr);
+
+#ifdef WITH_REFERENCE
+    {   // the reference's generic templates instantiate over HipSetGraph and agree with its own SortedSetGraph (host only)
+        char a0[] = "t", a1[] = "-g", a2[] = "kronecker", a3[] = "8", a4[] = "--deg", a5[] = "16";
+        char *argv[] = {a0, a1, a2, a3, a4, a5};
+        auto [args, cg] = GMS::CLI::Parser().parse_and_load(6, argv);
+        (void)args;
+        auto ref = SortedSetGraph::FromCGraph(cg);
+        auto mine = gmsx::HipSetGraph::FromCGraph(cg);
+        CHECK(mine.num_nodes() == ref.num_nodes());
+        CHECK(GMS::TriangleCount::Seq::count_total(mine) == GMS::TriangleCount::Seq::count_total(ref));
+        CHECK(GMS::TriangleCount::Par::count_total(mine) == 10479);  // tests/golden/graphs.json kronecker-8
+        std::vector<int64_t> c1, c2;
+        GMS::TriangleCount::Par::vertex_count2(mine, c1);
+        GMS::TriangleCount::Par::vertex_count2(ref, c2);
+        CHECK(c1 == c2);
+        CHECK(RecursiveStepCliqueCount(mine, 3, mine.out_neigh(0)) == RecursiveStepCliqueCount(ref, 3, ref.out_neigh(0)));
+        pvector<NodeId> rank(mine.num_nodes());
+        PpParallel::getDegreeOrdering<gmsx::HipSetGraph, true, pvector<NodeId>>(mine, rank);
+        BK_CLIQUE_COUNTER = 0;
+        BkEppsteinPar::mceBench<gmsx::HipSetGraph>(mine, rank);
+        CHECK(BK_CLIQUE_COUNTER == 1808);  // tests/golden/graphs.json kronecker-8 bk
+    }
+#endif
+    std::printf("set concept ok\n");
+    return 0;
+}

@@ -1,0 +1,45 @@
+"""CPU: compiles and runs tests/cpp/test_set_concept.cpp against include/gmsx_set_graph.hpp + libgmsx.so; when the
+reference tree is present the reference's own algorithm templates are instantiated over gmsx::HipSetGraph too."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+REF = "/root/reference"
+
+
+@pytest.mark.parametrize("with_ref", [False, True])
+def test_set_concept(tmp_path, capi, with_ref):
+    if with_ref and not os.path.isdir(os.path.join(REF, "gms")):
+        pytest.skip("reference tree not present")
+    exe = str(tmp_path / "t")
+    cmd = ["g++", "-std=c++17", "-O1", "-fopenmp", "-w", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_set_concept.cpp"),
+           "-L", os.path.join(ROOT, "gms_amd", "lib"), "-lgmsx", "-Wl,-rpath," + os.path.join(ROOT, "gms_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    if with_ref:
+        cmd[1:1] = ["-DWITH_REFERENCE", "-DNOPAPIW", "-DBK_COUNT", "-I", REF]
+        cmd += [os.path.join(ROOT, "oracle", "_ref", "roaring.o")]
+    subprocess.run(cmd, check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "set concept ok" in out
+
+
+def test_driver_builds_and_rejects_bad_usage(capi):
+    exe = os.path.join(ROOT, "gms_amd", "lib", "gmsx_driver")
+    assert os.path.exists(exe), "make -C gms_amd/csrc builds the driver"
+    assert subprocess.run([exe]).returncode == 101                      # no graph given (cli/cli.h:131-133)
+    assert subprocess.run([exe, "tc", "--bogus"]).returncode == 100     # unparsable flags (cli/cli.h:122-127)
+
+
+@pytest.mark.gpu
+def test_driver_runs_every_kernel_with_reference_output_lines(gpu):
+    exe = os.path.join(ROOT, "gms_amd", "lib", "gmsx_driver")
+    expect = {"tc": "triangles: 483489", "kclique": "total 4-cliques: 96513528", "bk": "The Number of maximal clique counted: 692903", "vertex": "@@@"}
+    for kernel, needle in expect.items():
+        out = subprocess.run([exe, kernel, "-g", "kronecker", "12", "--deg", "16", "-n", "2", "-v"], check=True, capture_output=True, text=True).stdout
+        assert needle in out, out
+        assert "Graph has 4096 nodes and 48386 undirected edges for degree: 11" in out
+        assert "GraphExec buildTime:" in out and out.count("Trial Time:") == 2 and "Average Time:" in out
+        marks = [l for l in out.splitlines() if l.startswith("@@@ ")]
+        assert len(marks) == 2 and all(" PASS " in l for l in marks), out
