@@ -100,8 +100,202 @@ __device__ __forceinline__ int wave_sum(int x) {
     return x;
 }
 
-// One wave per start vertex.  LDS_SLAB: every structure of the search lives in this wave's LDS slab (tasks of at most
-// kLdsSlabWords words); otherwise in slabs[wave_global_id * slab_words].
+// ---- load balancing ------------------------------------------------------------------------------------------
+// A search that exceeds its node budget is not finished by its wave: the wave copies the start vertex's read-only
+// structures (Cadj, XT) to a persistent ARENA, writes every stack level that still has unexplored branches as a
+// resumable RECORD into the next round's pool, and moves on.  The host launches rounds until the pool is empty, so a
+// huge search tree is re-split level by level across thousands of waves without any inter-wave synchronisation
+// inside a kernel.  If the arena or the pool is full the wave simply keeps searching (correctness never depends on it).
+struct BkShared {
+    uint32_t *arena;
+    unsigned long long arena_cap;       // words
+    unsigned long long *arena_head;     // words used
+    uint32_t *pool;                     // next round's records
+    unsigned long long pool_cap;        // words
+    unsigned long long *pool_head;
+    unsigned long long *dir;            // word offsets of the records in `pool`
+    unsigned long long dir_cap;
+    unsigned long long *dir_count;
+    unsigned long long *max_stack;      // max (c+1)*lvl over the dumped records
+    unsigned budget;                    // nodes per task before it is split
+};
+static constexpr int kRecHeader = 8;  // v, c, x, xf_ne, arena offset (2 words), 2 spare
+static constexpr unsigned long long kNoArena = ~0ull;
+
+// Iterative Tomita recursion on bitmaps, resumable.  Registers: this lane's word of P / Xc / ext (lanes >= cw hold 0);
+// Xf levels and the saved words of the ancestors live in `stack` (level l at stack + l*lvl: P, Xc, ext, Xf).
+// `structs`/`struct_words`: where Cadj|XT currently live (for the copy to the arena); arena_off: kNoArena until copied.
+__device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *XT, uint32_t *stack, unsigned char *xfne_stack,
+                                          int32_t v, int c, int x, uint32_t P, uint32_t Xc, uint32_t ext, int xf_ne, bool entering,
+                                          int lane, unsigned long long &cnt, const BkShared &sh, unsigned long long arena_off,
+                                          bool global_structs) {
+    const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
+    const int lvl = 3 * cw + xw + 1;
+    unsigned budget = sh.budget, nodes = 0;
+    int depth = 0;
+    while (true) {
+        if (entering) {
+            ++nodes;
+            if (__ballot(P != 0) == 0) {
+                if (__ballot(Xc != 0) == 0 && !xf_ne) cnt++;
+                entering = false;
+                if (depth == 0) break;
+                --depth;  // pop
+                uint32_t *lv = stack + size_t(depth) * lvl;
+                P = lane < cw ? lv[lane] : 0u;
+                Xc = lane < cw ? lv[cw + lane] : 0u;
+                ext = lane < cw ? lv[2 * cw + lane] : 0u;
+                xf_ne = int(xfne_stack[depth]);
+                continue;
+            }
+            // pivot: argmax over u in P ∪ Xc of |P ∩ N(u)|
+            uint32_t it = P | Xc;
+            int best = -1, best_score = -1;
+            while (true) {
+                const unsigned long long nz = __ballot(it != 0);
+                if (!nz) break;
+                const int L = __ffsll((long long)nz) - 1;
+                const uint32_t word = __builtin_amdgcn_readlane(it, L);
+                const int bit = __ffs(word) - 1;
+                if (lane == L) it &= it - 1;
+                const int u = (L << 5) + bit;
+                const uint32_t row = lane < cw ? Cadj[size_t(u) * cw + lane] : 0u;
+                const int s = wave_sum(__popc(P & row));
+                if (s > best_score) {
+                    best_score = s;
+                    best = u;
+                }
+            }
+            const uint32_t prow = lane < cw ? Cadj[size_t(best) * cw + lane] : 0u;
+            ext = P & ~prow;
+            entering = false;
+        }
+        // next branch vertex q of this node
+        const unsigned long long nz = __ballot(ext != 0);
+        if (!nz) {
+            if (depth == 0) break;
+            --depth;  // pop
+            uint32_t *lv = stack + size_t(depth) * lvl;
+            P = lane < cw ? lv[lane] : 0u;
+            Xc = lane < cw ? lv[cw + lane] : 0u;
+            ext = lane < cw ? lv[2 * cw + lane] : 0u;
+            xf_ne = int(xfne_stack[depth]);
+            continue;
+        }
+        if (nodes >= budget) {
+            // ---- split: hand every level that still has branches to the next round --------------------------------
+            bool ok = true;
+            if (arena_off == kNoArena) {  // first split of this start vertex: persist Cadj | XT
+                const unsigned long long need = ((unsigned long long)c * cw + (unsigned long long)c * xw + 3ull) & ~3ull;
+                unsigned long long off0 = 0;
+                if (lane == 0) off0 = atomicAdd(sh.arena_head, need);
+                off0 = (unsigned long long)__shfl((long long)off0, 0);
+                if (off0 + need > sh.arena_cap) ok = false;
+                else {
+                    for (unsigned long long i = lane; i < (unsigned long long)c * cw + (unsigned long long)c * xw; i += 64)
+                        sh.arena[off0 + i] = Cadj[i];  // XT follows Cadj in the slab
+                    arena_off = off0;
+                }
+            }
+            int nrec = 0;
+            if (ok) {
+                // levels 0..depth-1 are in the stack, level `depth` is in registers: spill it so all look alike
+                uint32_t *cur = stack + size_t(depth) * lvl;
+                if (lane < cw) {
+                    cur[lane] = P;
+                    cur[cw + lane] = Xc;
+                    cur[2 * cw + lane] = ext;
+                }
+                if (lane == 0) xfne_stack[depth] = (unsigned char)xf_ne;
+                if (global_structs) __threadfence();
+                __builtin_amdgcn_wave_barrier();
+                for (int l = 0; l <= depth; ++l) {
+                    const uint32_t e = lane < cw ? stack[size_t(l) * lvl + 2 * cw + lane] : 0u;
+                    if (__ballot(e != 0)) ++nrec;
+                }
+                const unsigned long long rec_words = (unsigned long long)(kRecHeader + 3 * cw + xw);
+                unsigned long long p0 = 0, d0 = sh.dir_cap;
+                if (lane == 0) {
+                    p0 = atomicAdd(sh.pool_head, rec_words * nrec);
+                    if (p0 + rec_words * nrec <= sh.pool_cap) d0 = atomicAdd(sh.dir_count, (unsigned long long)nrec);
+                }
+                p0 = (unsigned long long)__shfl((long long)p0, 0);
+                d0 = (unsigned long long)__shfl((long long)d0, 0);
+                if (p0 + rec_words * nrec > sh.pool_cap || d0 + nrec > sh.dir_cap) {
+                    ok = false;  // directory slots that were claimed but not written keep their ~0 fill and are skipped
+                } else {
+                    int r = 0;
+                    for (int l = 0; l <= depth; ++l) {
+                        const uint32_t *lv = stack + size_t(l) * lvl;
+                        const uint32_t e = lane < cw ? lv[2 * cw + lane] : 0u;
+                        if (!__ballot(e != 0)) continue;
+                        uint32_t *rec = sh.pool + p0 + rec_words * r;
+                        if (lane == 0) {
+                            rec[0] = uint32_t(v);
+                            rec[1] = uint32_t(c);
+                            rec[2] = uint32_t(x);
+                            rec[3] = uint32_t(xfne_stack[l]);
+                            rec[4] = uint32_t(arena_off & 0xffffffffull);
+                            rec[5] = uint32_t(arena_off >> 32);
+                            rec[6] = rec[7] = 0;
+                            sh.dir[d0 + r] = p0 + rec_words * r;
+                        }
+                        if (lane < cw) {
+                            rec[kRecHeader + lane] = lv[lane];
+                            rec[kRecHeader + cw + lane] = lv[cw + lane];
+                            rec[kRecHeader + 2 * cw + lane] = e;
+                        }
+                        for (int w = lane; w < xw; w += 64) rec[kRecHeader + 3 * cw + w] = lv[3 * cw + w];
+                        ++r;
+                    }
+                    if (lane == 0) atomicMax(sh.max_stack, (unsigned long long)(c + 1) * (unsigned long long)lvl);
+                }
+            }
+            if (ok) return;          // the rest of this search belongs to the next round
+            budget = 0xffffffffu;    // no room: finish it here
+        }
+        const int L = __ffsll((long long)nz) - 1;
+        const uint32_t word = __builtin_amdgcn_readlane(ext, L);
+        const int bit = __ffs(word) - 1;
+        const int q = (L << 5) + bit;
+        const uint32_t qrow = lane < cw ? Cadj[size_t(q) * cw + lane] : 0u;
+        const uint32_t Pn = P & qrow, Xcn = Xc & qrow;
+        uint32_t *lv = stack + size_t(depth) * lvl;
+        uint32_t *nx = lv + lvl;
+        int child_ne = 0;
+        if (xf_ne) {
+            uint32_t any = 0;
+            const uint32_t *xt = XT + size_t(q) * xw;
+            for (int w = lane; w < xw; w += 64) {
+                const uint32_t t = lv[3 * cw + w] & xt[w];
+                nx[3 * cw + w] = t;
+                any |= t;
+            }
+            child_ne = __ballot(any != 0) != 0 ? 1 : 0;
+        }
+        // this node continues with q moved from cand to fini (tomita.h:68-70)
+        if (lane == L) {
+            ext &= ~(1u << bit);
+            P &= ~(1u << bit);
+            Xc |= 1u << bit;
+        }
+        if (lane < cw) {
+            lv[lane] = P;
+            lv[cw + lane] = Xc;
+            lv[2 * cw + lane] = ext;
+        }
+        if (lane == 0) xfne_stack[depth] = (unsigned char)xf_ne;
+        __builtin_amdgcn_wave_barrier();
+        ++depth;
+        P = Pn;
+        Xc = Xcn;
+        xf_ne = child_ne;
+        entering = true;
+    }
+}
+
+// Round 0: one wave per start vertex.  LDS_SLAB: every structure of the search lives in this wave's LDS slab (tasks of
+// at most kLdsSlabWords words); otherwise in slabs[block * slab_words].
 template <bool LDS_SLAB>
 __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                 const int32_t *__restrict__ newid, const int32_t *__restrict__ oldid,
@@ -110,7 +304,7 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
                                                 const int32_t *__restrict__ dplus, const int32_t *__restrict__ task_v,
                                                 int64_t first, int64_t end, int nparts, int part,
                                                 unsigned long long *__restrict__ queue, uint32_t *__restrict__ slabs,
-                                                unsigned long long slab_words, unsigned long long *__restrict__ acc) {
+                                                unsigned long long slab_words, unsigned long long *__restrict__ acc, BkShared sh) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_slab[LDS_SLAB ? kLdsSlabWords : 4];
     __shared__ unsigned char xfne_stack[2052];  // per level: is Xf non-empty (written by one lane, read by all)
     const int lane = threadIdx.x;
@@ -133,7 +327,6 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
         uint32_t *Cadj = slab + 2 * size_t(msize);
         uint32_t *XT = Cadj + size_t(c) * cw;
         uint32_t *stack = XT + size_t(c) * xw;
-        const int lvl = 3 * cw + xw + 1;  // words per stack level: P, Xc, ext, Xf (+1 spare)
 
         // ---- build: map, Cadj (symmetric closure of the DAG rows inside C), XT (C x X0 adjacency) -------------------
         for (uint32_t i = lane; i < msize; i += 64) map[i] = kEmptySlot;
@@ -182,9 +375,8 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- search: iterative Tomita recursion on bitmaps --------------------------------------------------------
-        // registers: this lane's word of P / Xc / ext (lanes >= cw hold 0); Xf levels and saved words live in `stack`
-        uint32_t P = 0, Xc = 0, ext = 0;
+        // ---- search from the root: P = C, Xc = {}, Xf = X0 ------------------------------------------------------
+        uint32_t P = 0;
         if (lane < cw) {
             const int bits = c - lane * 32;
             P = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
@@ -193,95 +385,42 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
             const int bits = x - w * 32;
             stack[3 * cw + w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
         }
-        int xf_ne = x > 0 ? 1 : 0;  // wave-uniform: is Xf of the current level non-empty
-        int depth = 0;
-        bool entering = true;
-        while (true) {
-            if (entering) {
-                if (__ballot(P != 0) == 0) {
-                    if (__ballot(Xc != 0) == 0 && !xf_ne) cnt++;
-                    entering = false;
-                    if (depth == 0) break;
-                    --depth;  // pop
-                    uint32_t *lv = stack + size_t(depth) * lvl;
-                    P = lane < cw ? lv[lane] : 0u;
-                    Xc = lane < cw ? lv[cw + lane] : 0u;
-                    ext = lane < cw ? lv[2 * cw + lane] : 0u;
-                    xf_ne = int(xfne_stack[depth]);
-                    continue;
-                }
-                // pivot: argmax over u in P ∪ Xc of |P ∩ N(u)|
-                uint32_t it = P | Xc;
-                int best = -1, best_score = -1;
-                while (true) {
-                    const unsigned long long nz = __ballot(it != 0);
-                    if (!nz) break;
-                    const int L = __ffsll((long long)nz) - 1;
-                    const uint32_t word = __builtin_amdgcn_readlane(it, L);
-                    const int bit = __ffs(word) - 1;
-                    if (lane == L) it &= it - 1;
-                    const int u = (L << 5) + bit;
-                    const uint32_t row = lane < cw ? Cadj[size_t(u) * cw + lane] : 0u;
-                    const int s = wave_sum(__popc(P & row));
-                    if (s > best_score) {
-                        best_score = s;
-                        best = u;
-                    }
-                }
-                const uint32_t prow = lane < cw ? Cadj[size_t(best) * cw + lane] : 0u;
-                ext = P & ~prow;
-                entering = false;
-            }
-            // next branch vertex q of this node
-            const unsigned long long nz = __ballot(ext != 0);
-            if (!nz) {
-                if (depth == 0) break;
-                --depth;  // pop
-                uint32_t *lv = stack + size_t(depth) * lvl;
-                P = lane < cw ? lv[lane] : 0u;
-                Xc = lane < cw ? lv[cw + lane] : 0u;
-                ext = lane < cw ? lv[2 * cw + lane] : 0u;
-                xf_ne = int(xfne_stack[depth]);
-                continue;
-            }
-            const int L = __ffsll((long long)nz) - 1;
-            const uint32_t word = __builtin_amdgcn_readlane(ext, L);
-            const int bit = __ffs(word) - 1;
-            const int q = (L << 5) + bit;
-            const uint32_t qrow = lane < cw ? Cadj[size_t(q) * cw + lane] : 0u;
-            const uint32_t Pn = P & qrow, Xcn = Xc & qrow;
-            uint32_t *lv = stack + size_t(depth) * lvl;
-            uint32_t *nx = lv + lvl;
-            int child_ne = 0;
-            if (xf_ne) {
-                uint32_t any = 0;
-                const uint32_t *xt = XT + size_t(q) * xw;
-                for (int w = lane; w < xw; w += 64) {
-                    const uint32_t t = lv[3 * cw + w] & xt[w];
-                    nx[3 * cw + w] = t;
-                    any |= t;
-                }
-                child_ne = __ballot(any != 0) != 0 ? 1 : 0;
-            }
-            // this node continues with q moved from cand to fini (tomita.h:68-70)
-            if (lane == L) {
-                ext &= ~(1u << bit);
-                P &= ~(1u << bit);
-                Xc |= 1u << bit;
-            }
-            if (lane < cw) {
-                lv[lane] = P;
-                lv[cw + lane] = Xc;
-                lv[2 * cw + lane] = ext;
-            }
-            if (lane == 0) xfne_stack[depth] = (unsigned char)xf_ne;
-            __builtin_amdgcn_wave_barrier();
-            ++depth;
-            P = Pn;
-            Xc = Xcn;
-            xf_ne = child_ne;
-            entering = true;
-        }
+        __builtin_amdgcn_wave_barrier();
+        bk_search(Cadj, XT, stack, xfne_stack, v, c, x, P, 0u, 0u, x > 0 ? 1 : 0, true, lane, cnt, sh, kNoArena, !LDS_SLAB);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
+}
+
+// Rounds >= 1: one wave per resumable record; Cadj | XT are read from the arena, the stack lives in this wave's slab.
+__global__ __launch_bounds__(64) void k_bk_resume(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in,
+                                                  unsigned long long n_records, unsigned long long *__restrict__ queue,
+                                                  uint32_t *__restrict__ slabs, unsigned long long slab_words,
+                                                  unsigned long long *__restrict__ acc, BkShared sh) {
+    __shared__ unsigned char xfne_stack[2052];
+    const int lane = threadIdx.x;
+    uint32_t *stack = slabs + size_t(blockIdx.x) * slab_words;
+    unsigned long long cnt = 0;
+    while (true) {
+        unsigned long long q0 = 0;
+        if (lane == 0) q0 = atomicAdd(queue, 1ull);
+        q0 = (unsigned long long)__shfl((long long)q0, 0);
+        if (q0 >= n_records) break;
+        const unsigned long long roff = dir_in[q0];
+        if (roff == ~0ull) continue;  // a claimed-but-unwritten directory slot (its wave kept the search)
+        const uint32_t *rec = pool_in + roff;
+        const int32_t v = int32_t(rec[0]);
+        const int c = int(rec[1]), x = int(rec[2]), xf_ne = int(rec[3]);
+        const unsigned long long aoff = (unsigned long long)rec[4] | ((unsigned long long)rec[5] << 32);
+        const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
+        const uint32_t *Cadj = sh.arena + aoff;
+        const uint32_t *XT = Cadj + size_t(c) * cw;
+        const uint32_t P = lane < cw ? rec[kRecHeader + lane] : 0u;
+        const uint32_t Xc = lane < cw ? rec[kRecHeader + cw + lane] : 0u;
+        const uint32_t ext = lane < cw ? rec[kRecHeader + 2 * cw + lane] : 0u;
+        for (int w = lane; w < xw; w += 64) stack[3 * cw + w] = rec[kRecHeader + 3 * cw + w];
+        __builtin_amdgcn_wave_barrier();
+        bk_search(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, xf_ne, false, lane, cnt, sh, aoff, true);
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
@@ -296,11 +435,12 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     const int64_t n = g->n;
-    struct Guard { void *p = nullptr; ~Guard() { (void)hipFree(p); } } g_acc, g_ki, g_ko, g_vi, g_vo, g_tmp, g_slab;
+    struct Guard { void *p = nullptr; ~Guard() { (void)hipFree(p); } } g_acc, g_ki, g_ko, g_vi, g_vo, g_tmp, g_arena, g_pool0, g_pool1, g_dir0, g_dir1;
     unsigned long long *acc = nullptr;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), sizeof(unsigned long long) * (64 * 16 + 4)));
+    constexpr int kCtl = 64 * 16;  // control words after the 64 spread accumulators
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), sizeof(unsigned long long) * (kCtl + 16)));
     g_acc.p = acc;
-    GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * (64 * 16 + 4), s));
+    GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * (kCtl + 16), s));
     if (n == 0) {
         *out = 0;
         if (st) *st = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
@@ -315,7 +455,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&v_out), size_t(n) * 4)); g_vo.p = v_out;
     GMSX_HIP(hipEventRecord(c.ev[0], s));
     hipLaunchKernelGGL(k_bk_tasks, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->off, g->oldid, g->dplus, k_in, v_in,
-                       acc + 64 * 16);
+                       acc + kCtl);
     size_t tmp_bytes = 0;
     GMSX_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, size_t(n), 0, 64, s));
     void *tmp = nullptr;
@@ -323,27 +463,48 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     g_tmp.p = tmp;
     GMSX_HIP(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, k_in, k_out, v_in, v_out, size_t(n), 0, 64, s));
     std::vector<unsigned long long> words(static_cast<size_t>(n));
-    unsigned long long head[4] = {0, 0, 0, 0};
+    unsigned long long head[2] = {0, 0};
     GMSX_HIP(hipMemcpyAsync(words.data(), k_out, size_t(n) * 8, hipMemcpyDeviceToHost, s));
-    GMSX_HIP(hipMemcpyAsync(head, acc + 64 * 16, sizeof(head), hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipMemcpyAsync(head, acc + kCtl, sizeof(head), hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     if (head[1]) return GMSX_ERR_UNSUPPORTED;  // a start vertex with more than 2048 candidates (one word per lane)
-    GMSX_HIP(hipEventRecord(c.ev[1], s));
 
-    // bins of the heavy-first task order by slab size: (4^k) steps; the last bin (<= kLdsSlabWords) runs out of LDS
-    int64_t n_tasks = 0;
-    while (n_tasks < n && words[size_t(n_tasks)] > 0) ++n_tasks;
+    // ---- arena + record pools of the load balancer
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
     size_t free_b = 0, total_b = 0;
     GMSX_HIP(hipMemGetInfo(&free_b, &total_b));
-    const unsigned long long budget = std::min<unsigned long long>(free_b / 2, 32ull << 30);
+    const unsigned long long budget_bytes = std::min<unsigned long long>(free_b / 4, 16ull << 30);
+    BkShared sh{};
+    sh.arena_cap = std::min<unsigned long long>(free_b / 8, 8ull << 30) / 4;
+    sh.pool_cap = std::min<unsigned long long>(free_b / 16, 2ull << 30) / 4;
+    sh.dir_cap = 8ull << 20;
+    uint32_t *pools[2] = {nullptr, nullptr};
+    unsigned long long *dirs[2] = {nullptr, nullptr};
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&sh.arena), sh.arena_cap * 4)); g_arena.p = sh.arena;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&pools[0]), sh.pool_cap * 4)); g_pool0.p = pools[0];
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&pools[1]), sh.pool_cap * 4)); g_pool1.p = pools[1];
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dirs[0]), sh.dir_cap * 8)); g_dir0.p = dirs[0];
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dirs[1]), sh.dir_cap * 8)); g_dir1.p = dirs[1];
+    unsigned long long *queue = acc + kCtl + 2;
+    sh.arena_head = acc + kCtl + 3;
+    sh.pool_head = acc + kCtl + 4;
+    sh.dir_count = acc + kCtl + 5;
+    sh.max_stack = acc + kCtl + 6;
+    sh.budget = 4096;
+    int cur = 0;
+    sh.pool = pools[cur];
+    sh.dir = dirs[cur];
+    GMSX_HIP(hipMemsetAsync(sh.dir, 0xff, sh.dir_cap * 8, s));
+    GMSX_HIP(hipEventRecord(c.ev[1], s));
+
+    // ---- round 0: start vertices, binned by slab size (4x steps); the last bin (<= kLdsSlabWords) runs out of LDS
+    int64_t n_tasks = 0;
+    while (n_tasks < n && words[size_t(n_tasks)] > 0) ++n_tasks;
     int launches = 0;
-    unsigned long long *queue = acc + 64 * 16 + 2;
     int64_t lo = 0;
     while (lo < n_tasks) {
         const unsigned long long top = words[size_t(lo)];
         const bool lds = top <= (unsigned long long)kLdsSlabWords;
-        // tasks sharing this bin: down to a quarter of the largest slab (or everything that fits LDS)
         int64_t hi = lo;
         while (hi < n_tasks && (lds || words[size_t(hi)] * 4 > top)) ++hi;
         const int64_t cnt = part_count(lo, hi, nparts, part);
@@ -353,37 +514,66 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 const int64_t waves = std::min<int64_t>(cnt, int64_t(cu) * 10);
                 hipLaunchKernelGGL(k_bk_wave<true>, dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff,
                                    g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue,
-                                   static_cast<uint32_t *>(nullptr), 0ull, acc);
+                                   static_cast<uint32_t *>(nullptr), 0ull, acc, sh);
             } else {
                 const unsigned long long slab_w = (top + 3ull) & ~3ull;  // 16-byte aligned slabs (64-bit map slots)
                 const unsigned long long slab_bytes = slab_w * 4ull;
-                if (slab_bytes > budget) return GMSX_ERR_DEVICE_MEM;
-                const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({cnt, int64_t(cu) * 16, int64_t(budget / slab_bytes)}));
+                if (slab_bytes > budget_bytes) return GMSX_ERR_DEVICE_MEM;
+                const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({cnt, int64_t(cu) * 16, int64_t(budget_bytes / slab_bytes)}));
                 uint32_t *slabs = nullptr;
                 GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(waves) * slab_bytes));
                 hipLaunchKernelGGL(k_bk_wave<false>, dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
-                                   g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc);
-                GMSX_HIP(hipStreamSynchronize(s));  // the slab is reused by the next bin
+                                   g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
+                GMSX_HIP(hipStreamSynchronize(s));
                 GMSX_HIP(hipFree(slabs));
             }
             ++launches;
         }
         lo = hi;
     }
+    // ---- rounds >= 1: resume the split searches until no record is left
+    int rounds = 0;
+    while (true) {
+        unsigned long long ctl[4] = {0, 0, 0, 0};  // pool_head, dir_count, max_stack
+        GMSX_HIP(hipMemcpyAsync(ctl, sh.pool_head, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        // a wave whose allocation overshot a capacity kept its search: only fully written records are below the caps
+        const unsigned long long n_rec = std::min(ctl[1], sh.dir_cap);
+        if (n_rec == 0) break;
+        const unsigned long long stack_w = (ctl[2] + 3ull) & ~3ull;
+        const uint32_t *pool_in = pools[cur];
+        const unsigned long long *dir_in = dirs[cur];
+        cur ^= 1;
+        sh.pool = pools[cur];
+        sh.dir = dirs[cur];
+        GMSX_HIP(hipMemsetAsync(queue, 0, 8, s));
+        GMSX_HIP(hipMemsetAsync(sh.pool_head, 0, 3 * sizeof(unsigned long long), s));
+        GMSX_HIP(hipMemsetAsync(sh.dir, 0xff, sh.dir_cap * 8, s));
+        const unsigned long long slab_bytes = std::max<unsigned long long>(stack_w * 4ull, 16);
+        if (slab_bytes > budget_bytes) return GMSX_ERR_DEVICE_MEM;
+        const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({int64_t(n_rec), int64_t(cu) * 16, int64_t(budget_bytes / slab_bytes)}));
+        uint32_t *slabs = nullptr;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(waves) * slab_bytes));
+        hipLaunchKernelGGL(k_bk_resume, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, slabs, stack_w, acc, sh);
+        GMSX_HIP(hipStreamSynchronize(s));
+        GMSX_HIP(hipFree(slabs));
+        ++launches;
+        if (++rounds > 100000) return GMSX_ERR_KERNEL;
+    }
     GMSX_HIP(hipEventRecord(c.ev[2], s));
     GMSX_HIP(hipGetLastError());
-    unsigned long long host[64 * 16 + 4];
+    unsigned long long host[kCtl + 16];
     GMSX_HIP(hipMemcpyAsync(host, acc, sizeof(host), hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     unsigned long long total = 0;
     for (int i = 0; i < 64; ++i) total += host[i * 16];
-    if (part == 0) total += host[64 * 16];  // isolated vertices, counted once
+    if (part == 0) total += host[kCtl];  // isolated vertices, counted once
     *out = total;
     if (st) {
         float ms_setup = 0.f, ms = 0.f;
         GMSX_HIP(hipEventElapsedTime(&ms_setup, c.ev[0], c.ev[1]));
         GMSX_HIP(hipEventElapsedTime(&ms, c.ev[1], c.ev[2]));
-        *st = gmsx_stats{double(ms), double(ms_setup), uint64_t(part_count(0, n, nparts, part)), 0, 0, launches, 0};
+        *st = gmsx_stats{double(ms), double(ms_setup), uint64_t(part_count(0, n, nparts, part)), 0, uint64_t(rounds), launches, 0};
     }
     return GMSX_OK;
 }
