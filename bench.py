@@ -79,6 +79,8 @@ def main():
     rank, local_rank, world = dist.init_process_group()
     if world != args.gpus:
         log(rank, f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: cuda:{local_rank} does not exist ({torch.cuda.device_count()} devices visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     capi.init(local_rank)
@@ -168,7 +170,9 @@ def main():
                      "kernel_ms": avg_kernel_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
                      "note": "achieved = B_alg/t with B_alg = 4*sum_{u<v}(d_u+d_v) + 8(n+1) + 4*nnz (SURVEY 8(d)): the bytes the "
                              "reference's full-row merges stream; the oriented kernel probes far fewer ids, so frac can exceed 1",
-                     "probes_per_launch": st["probes"], "probe_bytes_per_s_GB": 4.0 * st["probes"] / (avg_kernel_ms * 1e-3) / 1e9},
+                     "traffic_GBps": (traffic / (avg_kernel_ms * 1e-3) / 1e9) if traffic else None,
+                     "traffic_frac_of_peak": (traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "probes_per_launch": st["probes"]},
         "setup_s": {"generate_or_load": t_gen, "upload_and_build": t_upload},
     }
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
