@@ -26,7 +26,7 @@ ERR_DEVICE_MEM, ERR_NOT_CANONICAL, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_KERNEL = -
 # every symbol include/gmsx.h declares (tests/test_capi_symbols.py checks the header against this list)
 SYMBOLS = [
     "gmsx_strerror", "gmsx_version",
-    "gmsx_csr_generate", "gmsx_csr_from_edges", "gmsx_csr_load", "gmsx_csr_save_sg", "gmsx_csr_from_arrays",
+    "gmsx_csr_generate", "gmsx_csr_generate_rmat", "gmsx_csr_from_edges", "gmsx_csr_load", "gmsx_csr_save_sg", "gmsx_csr_from_arrays",
     "gmsx_csr_worth_relabelling", "gmsx_csr_relabel_by_degree", "gmsx_csr_num_nodes", "gmsx_csr_num_edges",
     "gmsx_csr_num_edges_directed", "gmsx_csr_offsets", "gmsx_csr_neighbors", "gmsx_csr_merge_elements",
     "gmsx_csr_fingerprint", "gmsx_csr_free",
@@ -67,6 +67,7 @@ def lib():
     L.gmsx_strerror.restype = C.c_char_p
     L.gmsx_strerror.argtypes = [C.c_int]
     L.gmsx_csr_generate.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vpp]
+    L.gmsx_csr_generate_rmat.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, vpp]
     L.gmsx_csr_from_edges.argtypes = [C.c_int64, C.c_int64, _i32p, _i32p, C.c_int, C.c_int, vpp]
     L.gmsx_csr_load.argtypes = [C.c_char_p, C.c_int, C.c_int, vpp]
     L.gmsx_csr_save_sg.argtypes = [vp, C.c_char_p]
@@ -127,6 +128,12 @@ class HostCSR:
         h = C.c_void_p()
         gen = GEN_UNIFORM if generator in ("uniform", "u", GEN_UNIFORM) else GEN_KRONECKER
         _check(lib().gmsx_csr_generate(gen, scale, degree, relabel, threads, C.byref(h)), "gmsx_csr_generate")
+        return cls(h)
+
+    @classmethod
+    def generate_rmat(cls, scale, degree, a, b, c, relabel=RELABEL_AUTO, threads=0):
+        h = C.c_void_p()
+        _check(lib().gmsx_csr_generate_rmat(scale, degree, a, b, c, relabel, threads, C.byref(h)), "gmsx_csr_generate_rmat")
         return cls(h)
 
     @classmethod

@@ -184,18 +184,21 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
 // dynamic LDS layout: [rows: dmax*W u32 (LDS variant only)] [keys: 2^log i32] [vals: 2^log u16]
 // ---------------------------------------------------------------------------------------------
 template <int LV, int WPL, bool GLOBAL_ROWS>
-__global__ __launch_bounds__(256) void k_kc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+__global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
-                                                  int part, int dmax, int W, int log_map, uint32_t *__restrict__ slabs,
+                                                  int part, int dmax, int W, int WS, int log_map, uint32_t *__restrict__ slabs,
                                                   unsigned long long *__restrict__ acc) {
     extern __shared__ uint32_t smem[];
-    __shared__ unsigned long long red[4];
+    __shared__ unsigned long long red[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nthreads = int(blockDim.x), nwaves = nthreads >> 6;  // 256 … 1024 threads: big LDS bit-matrices leave one workgroup per CU
     const int map_size = 1 << log_map, shift = 32 - log_map;
     const uint32_t mask = uint32_t(map_size - 1);
-    uint32_t *rows = GLOBAL_ROWS ? slabs + size_t(blockIdx.x) * size_t(dmax) * size_t(W) : smem;
-    int32_t *keys = reinterpret_cast<int32_t *>(GLOBAL_ROWS ? smem : smem + size_t(dmax) * W);
+    // WS = row stride in words: W for the wave-cooperative recursion (lane = word index), W + 1 for the lane-per-pair
+    // k = 4 count (random rows per lane: an odd stride spreads them over the LDS banks)
+    uint32_t *rows = GLOBAL_ROWS ? slabs + size_t(blockIdx.x) * size_t(dmax) * size_t(WS) : smem;
+    int32_t *keys = reinterpret_cast<int32_t *>(GLOBAL_ROWS ? smem : smem + size_t(dmax) * WS);
     uint16_t *vals = reinterpret_cast<uint16_t *>(keys + map_size);
 
     unsigned long long cnt = 0;
@@ -209,18 +212,18 @@ __global__ __launch_bounds__(256) void k_kc_block(const int64_t *__restrict__ ho
         if (hc > 0 && hadj[hb + hc - 1] == 0xFFFFu) --hc;
         const int d = hc + tc;
         __syncthreads();  // previous pivot's counting is done
-        for (int i = tid; i < map_size; i += 256) keys[i] = -1;
-        for (int i = tid; i < d * W; i += 256) rows[i] = 0;
+        for (int i = tid; i < map_size; i += nthreads) keys[i] = -1;
+        for (int i = tid; i < d * WS; i += nthreads) rows[i] = 0;
         __syncthreads();
-        for (int i = tid; i < d; i += 256) {
+        for (int i = tid; i < d; i += nthreads) {
             const int32_t v = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
             map_insert(keys, vals, mask, shift, v, i);
         }
         if (GLOBAL_ROWS) __threadfence();
         __syncthreads();
-        for (int i = wave; i < d; i += 4) {
+        for (int i = wave; i < d; i += nwaves) {
             const int32_t v = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
-            uint32_t *row = rows + size_t(i) * W;
+            uint32_t *row = rows + size_t(i) * WS;
             build_row(hoff, hadj, toff, tadj, v, keys, vals, mask, shift, lane,
                       [&](int idx) { atomicOr(&row[idx >> 5], 1u << (idx & 31)); });
         }
@@ -231,18 +234,38 @@ __global__ __launch_bounds__(256) void k_kc_block(const int64_t *__restrict__ ho
         } else {
             __syncthreads();
         }
-        for (int i = wave; i < d; i += 4) {
-            uint32_t cand[WPL];
-            cand[0] = lane < W ? rows[size_t(i) * W + lane] : 0u;
-            if constexpr (WPL > 1) cand[1] = 64 + lane < W ? rows[size_t(i) * W + 64 + lane] : 0u;
-            cnt += wave_cliques<LV, WPL>(rows, W, cand, lane);
+        if constexpr (LV == 2) {
+            // k = 4: Σ_i Σ_{j ∈ rows[i]} popc(rows[i] & rows[j]) with one LANE per matrix word: the lane walks the set
+            // bits j of its word and ANDs the two rows word by word (the reference's isect.intersect(N(vi)) at depth 2)
+            const int words = d * W;
+            for (int cell = tid; cell < words; cell += nthreads) {
+                const int i = cell / W, w = cell - i * W;
+                uint32_t bits = rows[size_t(i) * WS + w];
+                const uint32_t *ri = rows + size_t(i) * WS;
+                while (bits) {
+                    const int j = (w << 5) + __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    const uint32_t *rj = rows + size_t(j) * WS;
+                    uint32_t sum = 0;
+                    for (int t = 0; t < W; ++t) sum += __popc(ri[t] & rj[t]);
+                    cnt += sum;
+                }
+            }
+        } else {
+            for (int i = wave; i < d; i += nwaves) {
+                uint32_t cand[WPL];
+                cand[0] = lane < W ? rows[size_t(i) * WS + lane] : 0u;
+                if constexpr (WPL > 1) cand[1] = 64 + lane < W ? rows[size_t(i) * WS + 64 + lane] : 0u;
+                cnt += wave_cliques<LV, WPL>(rows, WS, cand, lane);
+            }
         }
     }
     for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
     if (lane == 0) red[wave] = cnt;
     __syncthreads();
     if (tid == 0) {
-        const unsigned long long t = red[0] + red[1] + red[2] + red[3];
+        unsigned long long t = 0;
+        for (int w = 0; w < nwaves; ++w) t += red[w];
         if (t) atomicAdd(&acc[(blockIdx.x & (kAccSlots - 1)) * kAccStride], t);
     }
 }
@@ -274,17 +297,18 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         if (cnt > 0) {
             const bool wide = ge[1] > 0;  // some d+ > 2048
             const int dmax = wide ? 4096 : 2048, W = dmax / 32, log_map = wide ? 13 : 12;
+            const int WS = LV == 2 ? W + 1 : W;
             const int64_t blocks = std::min<int64_t>(cnt, cu * 2);
             uint32_t *slabs = nullptr;
-            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(blocks) * dmax * W * sizeof(uint32_t)));
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(blocks) * dmax * WS * sizeof(uint32_t)));
             *slab_out = slabs;
             const size_t lds = (size_t(4) << log_map) + (size_t(2) << log_map);
             if (wide)
-                hipLaunchKernelGGL((k_kc_block<LV, 2, true>), dim3(unsigned(blocks)), dim3(256), lds, s, g->hoff, g->hadj, g->toff,
-                                   g->tadj, g->order, lo, hi, nparts, part, dmax, W, log_map, slabs, acc);
+                hipLaunchKernelGGL((k_kc_block<LV, 2, true>), dim3(unsigned(blocks)), dim3(512), lds, s, g->hoff, g->hadj, g->toff,
+                                   g->tadj, g->order, lo, hi, nparts, part, dmax, W, WS, log_map, slabs, acc);
             else
-                hipLaunchKernelGGL((k_kc_block<LV, 1, true>), dim3(unsigned(blocks)), dim3(256), lds, s, g->hoff, g->hadj, g->toff,
-                                   g->tadj, g->order, lo, hi, nparts, part, dmax, W, log_map, slabs, acc);
+                hipLaunchKernelGGL((k_kc_block<LV, 1, true>), dim3(unsigned(blocks)), dim3(512), lds, s, g->hoff, g->hadj, g->toff,
+                                   g->tadj, g->order, lo, hi, nparts, part, dmax, W, WS, log_map, slabs, acc);
             ++*launches;
         }
     }
@@ -292,20 +316,22 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     static bool attr_set[kMaxK] = {false};
     if (!attr_set[LV]) {
         GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr_set[LV] = true;
     }
     for (int b = 0; b < 5; ++b) {
         const int64_t lo = ge[2 + b], hi = std::min(ge[3 + b], n_min);
         const int dmax = 1024 >> b, W = dmax / 32;
+        const int WS = LV == 2 ? W + 1 : W;
         int log_map = 1;
         while ((1 << log_map) < 2 * dmax) ++log_map;
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (cnt > 0) {
-            const size_t lds = size_t(dmax) * W * 4 + (size_t(4) << log_map) + (size_t(2) << log_map);
+            const size_t lds = size_t(dmax) * WS * 4 + (size_t(4) << log_map) + (size_t(2) << log_map);
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
-            hipLaunchKernelGGL((k_kc_block<LV, 1, false>), dim3(unsigned(blocks)), dim3(256), lds, s, g->hoff, g->hadj, g->toff,
-                               g->tadj, g->order, lo, hi, nparts, part, dmax, W, log_map, static_cast<uint32_t *>(nullptr), acc);
+            const int threads = dmax >= 1024 ? 1024 : dmax >= 512 ? 512 : 256;
+            hipLaunchKernelGGL((k_kc_block<LV, 1, false>), dim3(unsigned(blocks)), dim3(threads), lds, s, g->hoff, g->hadj, g->toff,
+                               g->tadj, g->order, lo, hi, nparts, part, dmax, W, WS, log_map, static_cast<uint32_t *>(nullptr), acc);
             ++*launches;
         }
     }

@@ -107,10 +107,9 @@ struct EdgeList {
     }
 };
 
-static int make_rmat(int scale, int degree, EdgeList &el) {
+static int make_rmat(int scale, int degree, EdgeList &el, float A = 0.57f, float B = 0.19f, float C = 0.19f) {
     const int64_t n = int64_t(1) << scale, m = n * degree;
     if (int rc = el.alloc(m)) return rc;
-    const float A = 0.57f, B = 0.19f, C = 0.19f;
     const float AB = A + B, ABC = A + B + C;  // float sums, as the reference compares against
     int32_t *eu = el.u.get(), *ev = el.v.get();
 #pragma omp parallel
@@ -418,6 +417,32 @@ int gmsx_csr_generate(int generator, int scale, int degree, int relabel, int thr
         {
             EdgeList el;
             rc = generator == GMSX_GEN_UNIFORM ? make_uniform(scale, degree, el) : make_rmat(scale, degree, el);
+            if (!rc) rc = build_from_el(el, -1, true, g);
+        }
+        if (!rc) rc = finish(std::move(g), relabel, out);
+    }
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(saved);
+#endif
+    return rc;
+}
+
+int gmsx_csr_generate_rmat(int scale, int degree, double a, double b, double c, int relabel, int threads, gmsx_csr **out) {
+    if (!out || scale < 1 || degree < 1 || relabel < 0 || relabel > 2) return GMSX_ERR_INVALID;
+    if (!(a > 0 && b >= 0 && c >= 0 && a + b + c < 1.0)) return GMSX_ERR_INVALID;
+    if (scale > 30) return GMSX_ERR_OVERFLOW;
+#ifdef _OPENMP
+    const int saved = omp_get_max_threads();
+    if (threads > 0) omp_set_num_threads(threads);
+#else
+    (void)threads;
+#endif
+    int rc;
+    {
+        Csr g;
+        {
+            EdgeList el;
+            rc = make_rmat(scale, degree, el, float(a), float(b), float(c));
             if (!rc) rc = build_from_el(el, -1, true, g);
         }
         if (!rc) rc = finish(std::move(g), relabel, out);

@@ -66,6 +66,11 @@ enum {
  * threads<=0: OpenMP default.  The output does not depend on the thread count. */
 int gmsx_csr_generate(int generator, int scale, int degree, int relabel, int threads, gmsx_csr **out);
 
+/* The same generator/builder pipeline with caller-chosen R-MAT quadrant probabilities (the reference hard-codes
+ * A/B/C = .57/.19/.19, generator.h:82; with those values the result equals gmsx_csr_generate(KRONECKER)).  Used to
+ * calibrate the skew of the Bron–Kerbosch workload. */
+int gmsx_csr_generate_rmat(int scale, int degree, double a, double b, double c, int relabel, int threads, gmsx_csr **out);
+
 /* Builder::MakeGraphFromEL + SquishGraph on a caller-supplied edge list (builder.h:279-298,237-251):
  * num_nodes<0 → max id + 1; symmetrize!=0 inserts both directions (the only mode the hot path accepts).
  * Rows come out sorted, de-duplicated and loop-free. */

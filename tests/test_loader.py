@@ -110,3 +110,25 @@ def test_arrays_equal_compiled_reference(capi, reference, spec):
         assert np.array_equal(csr.offsets(), off) and np.array_equal(csr.neighbors(), ng)
     finally:
         reference.free(g)
+
+
+def test_custom_rmat_skew(capi, tmp_path):
+    """gmsx_csr_generate_rmat with the reference's A/B/C reproduces the reference graph; other skews are valid graphs
+    that the compiled reference loads back unchanged from the .sg file (when present)."""
+    a = capi.HostCSR.generate_rmat(10, 16, 0.57, 0.19, 0.19, capi.RELABEL_AUTO)
+    assert ["%016x" % x for x in a.fingerprint()] == [GRAPHS["kronecker-10-16-relabel"][k] for k in ("offsets_fnv64", "neigh_fnv64")]
+    b = capi.HostCSR.generate_rmat(11, 20, 0.45, 0.22, 0.22, capi.RELABEL_NEVER)
+    assert b.num_nodes <= 2048 and b.num_edges > 15000 and b.fingerprint() != a.fingerprint()
+    with pytest.raises(capi.GmsxError):
+        capi.HostCSR.generate_rmat(10, 16, 0.6, 0.3, 0.3)
+    from oracle import bindings
+    if bindings.have_ref():
+        R = bindings.Reference()
+        p = str(tmp_path / "r.sg")
+        b.save_sg(p)
+        g = R.load_file(p, relabel=False)
+        off, ng = R.csr(g)
+        assert np.array_equal(off, b.offsets()) and np.array_equal(ng, b.neighbors())
+        O = bindings.Oracle()
+        assert R.bk_count(g, 1, 0) == O.bk_count(off, ng) and R.tc_total(g, 0) == O.tc_total(off, ng)
+        R.free(g)
