@@ -60,6 +60,29 @@ def cpu_baseline(csr, seconds):
     }
 
 
+def reference_baseline(scale, degree):
+    """The COMPILED REFERENCE itself (oracle/_ref/libgms_ref.so: spcl/gms headers + CRoaring) timed on this host:
+    Par::count_total over SortedSetGraph and RoaringGraph on a smaller graph of the same family (the reference API
+    only runs whole graphs).  Secondary to `cpu_baseline`; skipped when the prebuilt library is absent/unloadable."""
+    try:
+        from oracle import bindings
+        if not bindings.have_ref():
+            return None
+        R = bindings.Reference()
+        g = R.generate("kronecker", scale, degree, relabel=True)
+        m = R.L.ref_nnz(g) // 2
+        out = {"graph": f"RMAT scale-{scale} ef={degree} (reference loader)", "m": int(m), "threads": int(R.L.ref_omp_threads())}
+        for name, kind in (("RoaringGraph", 1), ("SortedSetGraph", 0)):
+            t0 = time.perf_counter()
+            tri = R.tc_total(g, kind)  # includes SetGraph::FromCGraph, reported separately below is not possible through the shim
+            dt = time.perf_counter() - t0
+            out[name] = {"seconds_incl_setgraph_build": dt, "edges_per_s": m / dt, "triangles": int(tri)}
+        R.free(g)
+        return out
+    except Exception as e:  # noqa: BLE001 - a baseline must never break the bench line
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -70,6 +93,7 @@ def main():
     ap.add_argument("--generator", default="kronecker")
     ap.add_argument("--algo", default="auto", choices=["auto", "oriented", "full"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="size of the CPU-baseline sample; 0 disables it")
+    ap.add_argument("--ref-scale", type=int, default=20, help="scale of the graph the compiled reference is timed on; 0 disables")
     ap.add_argument("--cache-dir", default=os.environ.get("GMSX_CACHE", "/tmp/gmsx_cache"))
     args = ap.parse_args()
 
@@ -178,6 +202,8 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         g.free()
         out["cpu_baseline"] = cpu_baseline(csr, args.cpu_seconds)
+        if args.ref_scale > 0:
+            out["cpu_reference"] = reference_baseline(args.ref_scale, args.degree)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
