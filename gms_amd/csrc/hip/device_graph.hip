@@ -3,6 +3,7 @@
 // gfx950 only.
 #include "device_graph.hpp"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>  // before rocprim: its texture iterator calls the host memset
 #include <new>
@@ -145,6 +146,32 @@ __global__ __launch_bounds__(256) void k_fill_parts(int64_t n, const int64_t *__
     }
 }
 
+// ---- bitset containers of dense hub rows -------------------------------------------------------------------
+// words of the bitset of rank id v (covers ids [0, v)), rounded to 16 bytes; 0 if the list form is smaller
+__device__ __forceinline__ int64_t dense_words(int32_t v, int32_t dp) {
+    const int64_t nw = ((int64_t(v) + 31) / 32 + 3) & ~int64_t(3);
+    return (nw * 4 + 32 < int64_t(dp) * 2) ? nw : 0;
+}
+__global__ void k_dense_sizes(int32_t limit, const int32_t *__restrict__ dplus, int64_t *__restrict__ sizes) {
+    const int32_t v = int32_t(blockIdx.x * blockDim.x + threadIdx.x);
+    if (v < limit) sizes[v] = dense_words(v, dplus[v]);
+    if (v == limit) sizes[v] = 0;
+}
+__global__ __launch_bounds__(256) void k_dense_fill(int32_t limit, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                    const int64_t *__restrict__ bmoff, uint32_t *__restrict__ pool) {
+    const int lane = threadIdx.x & 63;
+    const int32_t wave0 = int32_t((int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6);
+    const int32_t nwaves = int32_t((int64_t(gridDim.x) * blockDim.x) >> 6);
+    for (int32_t v = wave0; v < limit; v += nwaves) {
+        const int64_t b = bmoff[v];
+        if (bmoff[v + 1] == b) continue;
+        for (int64_t j = hoff[v] + lane; j < hoff[v + 1]; j += 64) {
+            const uint32_t id = hadj[j];
+            if (id != 0xFFFFu) atomicOr(&pool[b + (id >> 5)], 1u << (id & 31u));
+        }
+    }
+}
+
 __global__ void k_order_keys(int64_t n, const int32_t *__restrict__ dplus, int32_t *__restrict__ keys, int32_t *__restrict__ vals) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < n) {
@@ -197,6 +224,8 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->hadj);
     (void)hipFree(g->toff);
     (void)hipFree(g->tadj);
+    (void)hipFree(g->bmoff);
+    (void)hipFree(g->bmpool);
     (void)hipFree(g->dplus);
     (void)hipFree(g->order);
     (void)hipFree(g->sorted_dplus);
@@ -284,6 +313,23 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     if (n > 0)
         hipLaunchKernelGGL(k_fill_parts, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, g->newid, hub_limit, g->hoff, g->toff,
                            g->hadj, g->tadj);
+
+    // 4b. bitset containers for dense hub rows (only rows of hub vertices can be dense: all their targets are < v < kHub)
+    g->dense_limit = int32_t(std::min<int64_t>(n, hub_limit));
+    {
+        const int32_t K = g->dense_limit;
+        int64_t *sizes = nullptr;
+        if (int rc = dmalloc(&sizes, int64_t(K) + 1, nullptr)) return rc;
+        DevGuard g_sz{sizes};
+        if (int rc = dmalloc(&g->bmoff, int64_t(K) + 1, g)) return rc;
+        hipLaunchKernelGGL(k_dense_sizes, dim3(unsigned(K / 256 + 1)), dim3(256), 0, s, K, g->dplus, sizes);
+        if (int rc = exclusive_scan_i64(sizes, g->bmoff, int64_t(K) + 1, s)) return rc;
+        GMSX_HIP(hipMemcpy(&g->bmpool_words, g->bmoff + K, sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (int rc = dmalloc(&g->bmpool, g->bmpool_words + 4, g)) return rc;
+        GMSX_HIP(hipMemsetAsync(g->bmpool, 0, size_t(g->bmpool_words + 4) * sizeof(uint32_t), s));
+        if (K > 0 && g->bmpool_words > 0)
+            hipLaunchKernelGGL(k_dense_fill, dim3(grid_for_waves(K)), dim3(256), 0, s, K, g->hoff, g->hadj, g->bmoff, g->bmpool);
+    }
 
     // 5. work-sorted launch order: rank ids by decreasing d+
     if (int rc = dmalloc(&g->order, n, g)) return rc;

@@ -20,6 +20,10 @@
 //                                                     is padded to an even count with 0xFFFF (never a valid target)
 //     tail part  toff int64[n+1], tadj int32[...]    targets with rank id >= kHub, 4 bytes each
 //   On power-law graphs >85 % of all entries and >95 % of the streamed ids are hub entries.
+//     bitset part bmoff int64[K+1], bmpool uint32[...]  DENSE hub rows (2*d+ bytes > v/8 bytes) additionally as a bitmap
+//                                                     over [0, v) (Roaring's bitset container): intersecting such a row with
+//                                                     the pivot bitmap is a word-wise AND + popcount, 32 ids per word.  These
+//                                                     few thousand rows carry >70 % of the streamed ids and fit the L2.
 //
 //   dplus int32[n]                     true out-degree (hub + tail) per rank id
 //   order int32[n]                     rank ids by decreasing d+ (work-sorted launch order, heavy first);
@@ -34,6 +38,10 @@ struct gmsx_graph {
     uint16_t *hadj = nullptr;
     int64_t *toff = nullptr;
     int32_t *tadj = nullptr;
+    int64_t *bmoff = nullptr;   // [dense_limit + 1] word offsets into bmpool (multiples of 4); equal neighbours = not dense
+    uint32_t *bmpool = nullptr; // bitset containers of the dense hub rows
+    int32_t dense_limit = 0;    // rank ids >= this never have a bitset container
+    int64_t dense_rows = 0, bmpool_words = 0;
     int32_t *dplus = nullptr;
     int32_t *order = nullptr;
     int32_t *sorted_dplus = nullptr;

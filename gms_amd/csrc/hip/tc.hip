@@ -52,10 +52,10 @@ __device__ __forceinline__ uint32_t hub_hits8(const uint32_t *bm, u4u p) {
 }
 
 // Streams the hub containers of `rows` rows against the LDS bitmap.  Lane l holds the extent (rb, rl) of row l
-// (rl = padded, even entry count; lanes >= rows hold 0).  The wave works as four 16-lane groups, each streaming
+// (rl = padded, even entry count, or -(words) with rb = word offset into bmpool for a dense row; lanes >= rows hold 0).  The wave works as four 16-lane groups, each streaming
 // its own row: 16 lanes x 8 ids per step, two steps (two 16-byte loads per lane) in flight.
-__device__ __forceinline__ uint32_t scan_hub_rows(const uint32_t *bm, const uint16_t *__restrict__ hadj, int64_t rb, int rl,
-                                                  int rows, int lane) {
+__device__ __forceinline__ uint32_t scan_hub_rows(const uint32_t *bm, const uint16_t *__restrict__ hadj,
+                                                  const uint32_t *__restrict__ bmpool, int64_t rb, int rl, int rows, int lane) {
     const int grp = lane >> 4, sub8 = (lane & 15) * 8;
     uint32_t cnt = 0;
     for (int r0 = 0; r0 < rows; r0 += 4) {
@@ -67,6 +67,16 @@ __device__ __forceinline__ uint32_t scan_hub_rows(const uint32_t *bm, const uint
                   l2 = __builtin_amdgcn_readlane(rl, m2), l3 = __builtin_amdgcn_readlane(rl, m3);
         const int64_t b = grp == 0 ? b0 : grp == 1 ? b1 : grp == 2 ? b2 : b3;
         const int l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
+        if (l < 0) {
+            // dense row: a bitset container over [0, v); AND it word-wise with the pivot bitmap (16 lanes x 4 words per step)
+            const uint32_t *brow = bmpool + b;
+            for (int j = sub8 >> 1; j < -l; j += 64) {
+                const uint4 p = *reinterpret_cast<const uint4 *>(brow + j);
+                const uint4 q = *reinterpret_cast<const uint4 *>(bm + j);
+                cnt += uint32_t(__popc(p.x & q.x) + __popc(p.y & q.y) + __popc(p.z & q.z) + __popc(p.w & q.w));
+            }
+            continue;
+        }
         const uint16_t *row = hadj + b;
         int j = sub8;
         for (; j + 128 + 8 <= l; j += 256) {  // two full 128-id group steps
@@ -87,6 +97,21 @@ __device__ __forceinline__ uint32_t scan_hub_rows(const uint32_t *bm, const uint
         }
     }
     return cnt;
+}
+
+// extent of the hub container of rank id v as the scanner wants it: the bitset form when v has one, else the list
+__device__ __forceinline__ void hub_row_extent(int32_t v, const int64_t *__restrict__ hoff, const int64_t *__restrict__ bmoff,
+                                               int32_t dense_limit, int64_t &rb, int &rl) {
+    if (v < dense_limit) {
+        const int64_t b0 = bmoff[v], b1 = bmoff[v + 1];
+        if (b1 > b0) {
+            rb = b0;
+            rl = -int(b1 - b0);
+            return;
+        }
+    }
+    rb = hoff[v];
+    rl = int(hoff[v + 1] - rb);
 }
 
 // ---- tail side: open-addressing hash set in LDS (keys are rank ids >= kHub; -1 = empty) ------------------------
@@ -126,10 +151,11 @@ __device__ __forceinline__ uint32_t scan_tail_rows(const int32_t *tbl, uint32_t 
 static constexpr int kBlockLog = 11;
 
 __global__ __launch_bounds__(256) void k_tc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                  const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool, int32_t dense_limit,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
                                                   int part, unsigned long long *__restrict__ acc) {
-    __shared__ uint32_t bm[kBitmapWords];
+    __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords];
     __shared__ int32_t tbl[1 << kBlockLog];
     __shared__ unsigned long long red[4];
     constexpr int SIZE = 1 << kBlockLog, SHIFT = 32 - kBlockLog, TILE = SIZE / 2;
@@ -157,13 +183,10 @@ __global__ __launch_bounds__(256) void k_tc_block(const int64_t *__restrict__ ho
         int rl = 0;
         if (idx < hl) {
             const uint32_t v = hadj[hb + idx];
-            if (v != 0xFFFFu) {
-                rb = hoff[v];
-                rl = int(hoff[v + 1] - rb);
-            }
+            if (v != 0xFFFFu) hub_row_extent(int32_t(v), hoff, bmoff, dense_limit, rb, rl);
         }
         const int rows = min(64, (hl - base - wave + 3) >> 2);
-        cnt += scan_hub_rows(bm, hadj, rb, rl, rows, lane);
+        cnt += scan_hub_rows(bm, hadj, bmpool, rb, rl, rows, lane);
     }
     // (b) rows of the tail part of the pivot list: their hub containers against the bitmap …
     for (int base = 0; base < tl; base += 256) {
@@ -176,7 +199,7 @@ __global__ __launch_bounds__(256) void k_tc_block(const int64_t *__restrict__ ho
             rl = int(hoff[v + 1] - rb);
         }
         const int rows = min(64, (tl - base - wave + 3) >> 2);
-        cnt += scan_hub_rows(bm, hadj, rb, rl, rows, lane);
+        cnt += scan_hub_rows(bm, hadj, bmpool, rb, rl, rows, lane);
     }
     // (c) … and their tail containers against the hash set of the pivot's tail part
     for (int t0 = 0; t0 < tl; t0 += TILE) {
@@ -214,12 +237,13 @@ __global__ __launch_bounds__(256) void k_tc_block(const int64_t *__restrict__ ho
 // clears exactly those words again afterwards.  One atomic per workgroup at the end.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                  const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool, int32_t dense_limit,
                                                  const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                  const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
                                                  int part, unsigned long long *__restrict__ acc) {
     constexpr int LOG = 8, SIZE = 1 << LOG, SHIFT = 32 - LOG;
     constexpr uint32_t MASK = SIZE - 1;
-    __shared__ uint32_t bm_all[4 * kBitmapWords];
+    __shared__ __attribute__((aligned(16))) uint32_t bm_all[4 * kBitmapWords];
     __shared__ int32_t tbl_all[4 * SIZE];
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -243,8 +267,7 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
             hv = hadj[hb + lane];
             if (hv != 0xFFFFu) {
                 atomicOr(&bm[hv >> 5], 1u << (hv & 31u));
-                rb = hoff[hv];
-                rl = int(hoff[hv + 1] - rb);
+                hub_row_extent(int32_t(hv), hoff, bmoff, dense_limit, rb, rl);
             }
         }
         // tail part: hash set + extents of both containers of every tail row
@@ -263,9 +286,9 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
             }
         }
         __builtin_amdgcn_wave_barrier();
-        uint32_t c = scan_hub_rows(bm, hadj, rb, rl, hl, lane);
+        uint32_t c = scan_hub_rows(bm, hadj, bmpool, rb, rl, hl, lane);
         if (tl > 0) {
-            c += scan_hub_rows(bm, hadj, thb, thl, tl, lane);
+            c += scan_hub_rows(bm, hadj, bmpool, thb, thl, tl, lane);
             c += scan_tail_rows(tbl, MASK, SHIFT, tadj, trb, trl, tl, lane);
         }
         cnt += c;
@@ -335,7 +358,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     {
         const int64_t cnt = part_count(0, n_block, nparts, part);
         if (cnt > 0) {
-            hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->order,
+            hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit, g->toff, g->tadj, g->order,
                                int64_t(0), n_block, nparts, part, acc);
             ++launches;
         }
@@ -344,7 +367,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
         const int64_t cnt = part_count(n_block, n_work, nparts, part);
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
-            hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->order,
+            hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit, g->toff, g->tadj, g->order,
                                n_block, n_work, nparts, part, acc);
             ++launches;
         }
