@@ -10,6 +10,7 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 
 #include "../host/gmsx_internal.hpp"
 
@@ -313,6 +314,24 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     if (n > 0)
         hipLaunchKernelGGL(k_fill_parts, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, g->newid, hub_limit, g->hoff, g->toff,
                            g->hadj, g->tadj);
+
+    // 4a. hub rows ascending by rank id (the 0xFFFF pad sorts last): the dense rows of a pivot list (smallest ids) then
+    //     sit together, so the 16-lane groups of a wave mostly take the same path in the count kernels
+    if (n > 0 && g->hub_entries > 0 && g->hub_entries < (int64_t(1) << 32) && n < (int64_t(1) << 32)) {
+        uint16_t *sorted = nullptr;
+        if (int rc = dmalloc(&sorted, g->hub_entries + 8, nullptr)) return rc;
+        DevGuard g_sorted{sorted};
+        size_t tmp_bytes = 0;
+        GMSX_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, g->hadj, sorted, unsigned(g->hub_entries), unsigned(n), g->hoff,
+                                                    g->hoff + 1, 0, 16, s));
+        void *tmp = nullptr;
+        GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+        DevGuard g_tmp{tmp};
+        GMSX_HIP(rocprim::segmented_radix_sort_keys(tmp, tmp_bytes, g->hadj, sorted, unsigned(g->hub_entries), unsigned(n), g->hoff,
+                                                    g->hoff + 1, 0, 16, s));
+        GMSX_HIP(hipMemcpyAsync(g->hadj, sorted, size_t(g->hub_entries) * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+    }
 
     // 4b. bitset containers for dense hub rows (only rows of hub vertices can be dense: all their targets are < v < kHub)
     g->dense_limit = int32_t(std::min<int64_t>(n, hub_limit));
