@@ -16,6 +16,7 @@
 #include "device_graph.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -129,6 +130,8 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                                           int32_t v, int c, int x, uint32_t P, uint32_t Xc, uint32_t ext, int xf_ne, bool entering,
                                           int lane, unsigned long long &cnt, const BkShared &sh, unsigned long long arena_off,
                                           bool global_structs) {
+    __shared__ uint32_t piv_P[64];             // the current P, readable by every lane (one wave per workgroup)
+    __shared__ unsigned short piv_list[2048];  // members of P ∪ Xc
     const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
     const int lvl = 3 * cw + xw + 1;
     unsigned budget = sh.budget, nodes = 0;
@@ -148,24 +151,46 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                 xf_ne = int(xfne_stack[depth]);
                 continue;
             }
-            // pivot: argmax over u in P ∪ Xc of |P ∩ N(u)|
-            uint32_t it = P | Xc;
-            int best = -1, best_score = -1;
-            while (true) {
-                const unsigned long long nz = __ballot(it != 0);
-                if (!nz) break;
-                const int L = __ffsll((long long)nz) - 1;
-                const uint32_t word = __builtin_amdgcn_readlane(it, L);
-                const int bit = __ffs(word) - 1;
-                if (lane == L) it &= it - 1;
-                const int u = (L << 5) + bit;
-                const uint32_t row = lane < cw ? Cadj[size_t(u) * cw + lane] : 0u;
-                const int s = wave_sum(__popc(P & row));
-                if (s > best_score) {
-                    best_score = s;
+            // pivot: argmax over u in P ∪ Xc of |P ∩ N(u)|.  One LANE per candidate: P is parked in LDS, the members of
+            // P ∪ Xc are expanded into an LDS list (wave prefix sum of the per-word popcounts), then every lane scores its
+            // own candidates with independent row loads (64 rows in flight instead of one dependent load per candidate).
+            const uint32_t U = P | Xc;
+            if (lane < cw) piv_P[lane] = P;
+            int pre = __popc(U);
+            const int mine = pre;
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const int o = __shfl_up(pre, sft);
+                if (lane >= sft) pre += o;
+            }
+            const int ncand = __shfl(pre, 63);
+            {
+                int at = pre - mine;
+                uint32_t bits = U;
+                while (bits) {
+                    piv_list[at++] = (unsigned short)((lane << 5) + __ffs(bits) - 1);
+                    bits &= bits - 1;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            int best = 0x7fffffff, best_score = -1;
+            for (int k = lane; k < ncand; k += 64) {
+                const int u = int(piv_list[k]);
+                const uint32_t *row = Cadj + size_t(u) * cw;
+                int sc = 0;
+                for (int w = 0; w < cw; ++w) sc += __popc(piv_P[w] & row[w]);
+                if (sc > best_score || (sc == best_score && u < best)) {
+                    best_score = sc;
                     best = u;
                 }
             }
+            for (int sft = 32; sft > 0; sft >>= 1) {  // wave argmax (ties -> smallest index, so every lane agrees)
+                const int os = __shfl_xor(best_score, sft), ob = __shfl_xor(best, sft);
+                if (os > best_score || (os == best_score && ob < best)) {
+                    best_score = os;
+                    best = ob;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
             const uint32_t prow = lane < cw ? Cadj[size_t(best) * cw + lane] : 0u;
             ext = P & ~prow;
             entering = false;
@@ -490,7 +515,11 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     sh.pool_head = acc + kCtl + 4;
     sh.dir_count = acc + kCtl + 5;
     sh.max_stack = acc + kCtl + 6;
-    sh.budget = 4096;
+    sh.budget = 2048;
+    if (const char *e = std::getenv("GMSX_BK_BUDGET")) {  // tuning knob: nodes a search may visit before it is re-split
+        const long v = std::atol(e);
+        if (v >= 16 && v <= (1l << 30)) sh.budget = unsigned(v);
+    }
     int cur = 0;
     sh.pool = pools[cur];
     sh.dir = dirs[cur];

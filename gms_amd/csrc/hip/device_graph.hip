@@ -381,10 +381,20 @@ int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out) {
         *out = 0;
         return GMSX_OK;
     }
+    for (int i = 0; i < g->ge_used; ++i)
+        if (g->ge_thr[i] == threshold) {
+            *out = g->ge_cnt[i];
+            return GMSX_OK;
+        }
     hipStream_t s = ctx().stream;
     hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, g->n, g->sorted_dplus, threshold, reinterpret_cast<int64_t *>(g->scratch + 8));
     GMSX_HIP(hipMemcpyAsync(out, g->scratch + 8, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
+    if (g->ge_used < 16) {
+        g->ge_thr[g->ge_used] = threshold;
+        g->ge_cnt[g->ge_used] = *out;
+        ++g->ge_used;
+    }
     return GMSX_OK;
 }
 

@@ -49,6 +49,12 @@ struct gmsx_graph {
     int32_t max_dplus = 0;
     int32_t max_deg = 0;
     unsigned long long *scratch = nullptr;  // device: a few u64 accumulators
+    // host-side memo of read-only facts about the immutable graph (filled lazily; handles are single-threaded)
+    mutable int32_t ge_thr[16] = {0};
+    mutable int64_t ge_cnt[16] = {0};
+    mutable int ge_used = 0;
+    mutable int stats_part = -1, stats_nparts = -1;  // shard whose TC bookkeeping (units, probes) is cached below
+    mutable uint64_t stats_units = 0, stats_probes = 0;
     uint64_t alg_elements = 0;              // Σ_{u<v}(d_u+d_v), computed on the device at upload
     int64_t device_bytes = 0;
 };

@@ -375,7 +375,8 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     GMSX_HIP(hipEventRecord(c.ev[2], s));
     GMSX_HIP(hipGetLastError());
 
-    if (st) {  // untimed bookkeeping
+    const bool need_stats = st && !(g->stats_part == part && g->stats_nparts == nparts);
+    if (need_stats) {  // untimed bookkeeping, once per shard (the graph is immutable)
         const int64_t cnt = part_count(0, g->n, nparts, part);
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
@@ -395,8 +396,14 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
         GMSX_HIP(hipEventElapsedTime(&ms_kernel, c.ev[1], c.ev[2]));
         st->kernel_ms = ms_kernel;
         st->setup_ms = ms_setup;
-        st->units = host[kAccSlots * kAccStride];
-        st->probes = host[kAccSlots * kAccStride + 1];
+        if (need_stats) {
+            g->stats_part = part;
+            g->stats_nparts = nparts;
+            g->stats_units = host[kAccSlots * kAccStride];
+            g->stats_probes = host[kAccSlots * kAccStride + 1];
+        }
+        st->units = g->stats_units;
+        st->probes = g->stats_probes;
         st->alg_elements = nparts == 1 ? g->alg_elements : 0;
         st->launches = launches;
         st->reserved = 0;
