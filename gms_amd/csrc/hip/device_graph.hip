@@ -333,6 +333,26 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         GMSX_HIP(hipStreamSynchronize(s));
     }
 
+    // tail rows ascending too: the k-clique kernels binary-search a pivot's (short) tail list
+    if (n > 0 && g->tail_entries > 0 && g->tail_entries < (int64_t(1) << 32) && n < (int64_t(1) << 32)) {
+        int32_t *sorted = nullptr;
+        if (int rc = dmalloc(&sorted, g->tail_entries + 4, nullptr)) return rc;
+        DevGuard g_sorted{sorted};
+        size_t tmp_bytes = 0;
+        GMSX_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, g->tadj, sorted, unsigned(g->tail_entries), unsigned(n), g->toff,
+                                                    g->toff + 1, 0, 32, s));
+        void *tmp = nullptr;
+        GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+        DevGuard g_tmp{tmp};
+        GMSX_HIP(rocprim::segmented_radix_sort_keys(tmp, tmp_bytes, g->tadj, sorted, unsigned(g->tail_entries), unsigned(n), g->toff,
+                                                    g->toff + 1, 0, 32, s));
+        GMSX_HIP(hipMemcpyAsync(g->tadj, sorted, size_t(g->tail_entries) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        g->rows_sorted = true;
+    }
+    if (g->hub_entries >= (int64_t(1) << 32) || n >= (int64_t(1) << 32)) g->rows_sorted = false;
+    if (g->tail_entries == 0 && g->hub_entries < (int64_t(1) << 32) && n < (int64_t(1) << 32)) g->rows_sorted = true;
+
     // 4b. bitset containers for dense hub rows (only rows of hub vertices can be dense: all their targets are < v < kHub)
     g->dense_limit = int32_t(std::min<int64_t>(n, hub_limit));
     {

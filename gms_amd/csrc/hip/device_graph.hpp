@@ -42,6 +42,7 @@ struct gmsx_graph {
     uint32_t *bmpool = nullptr; // bitset containers of the dense hub rows
     int32_t dense_limit = 0;    // rank ids >= this never have a bitset container
     int64_t dense_rows = 0, bmpool_words = 0;
+    bool rows_sorted = false;   // both containers of every row ascending (always, below 2^32 entries)
     int32_t *dplus = nullptr;
     int32_t *order = nullptr;
     int32_t *sorted_dplus = nullptr;

@@ -44,6 +44,7 @@ __device__ __forceinline__ int map_find(const int32_t *keys, const uint16_t *val
 }
 
 // stream both containers of the oriented row of rank id v; every id found in the map sets a bit of `row`
+// (wave-per-pivot kernel: hub and tail members of the pivot live in one small hash map)
 template <class OrFn>
 __device__ __forceinline__ void build_row(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                           const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, int32_t v,
@@ -61,6 +62,69 @@ __device__ __forceinline__ void build_row(const int64_t *__restrict__ hoff, cons
         for (int64_t j = tb + lane; j < te; j += 64) {
             const int idx = map_find(keys, vals, mask, shift, tadj[j]);
             if (idx >= 0) or_bit(idx);
+        }
+    }
+}
+
+// position of w in the ascending list [lst, lst+len), or -1
+__device__ __forceinline__ int sorted_find(const int32_t *__restrict__ lst, int len, int32_t w) {
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (lst[mid] < w) lo = mid + 1; else hi = mid;
+    }
+    return (lo < len && lst[lo] == w) ? lo : -1;
+}
+
+// Local adjacency row of pivot-list member v against a pivot whose hub list (ascending, hc real entries) is
+// hub_list and whose tail list (ascending, tc entries) is tail_list.  Local index = position in [hub list | tail list].
+//  - v has a bitset container (dense hub row): every lane tests "is pivot member j in N+(v)" with one word load; the wave's
+//    ballot IS the row word, written without atomics.  (The stream-and-probe direction is inverted: d lookups instead of
+//    streaming v's row.)
+//  - otherwise v's list containers are streamed; a hub id is found through the pivot bitmap bm + prefix popcounts pre
+//    (rank = local index, because the hub list is sorted), a tail id by binary search in the pivot's tail list.
+__device__ __forceinline__ void build_row_sorted(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                 const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                 const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
+                                                 int32_t dense_limit, int32_t v, const uint16_t *__restrict__ hub_list, int hc,
+                                                 const int32_t *__restrict__ tail_list, int tc, const uint32_t *bm,
+                                                 const unsigned short *pre, uint32_t *row, int lane) {
+    if (v < dense_limit) {
+        const int64_t b0 = bmoff[v];
+        if (bmoff[v + 1] > b0) {
+            const uint32_t *bits = bmpool + b0;
+            for (int j0 = 0; j0 < hc; j0 += 64) {
+                const int j = j0 + lane;
+                bool hit = false;
+                if (j < hc) {
+                    const uint32_t w = hub_list[j];
+                    if (int32_t(w) < v) hit = (bits[w >> 5] >> (w & 31u)) & 1u;
+                }
+                const unsigned long long m = __ballot(hit);
+                if (lane == 0) row[j0 >> 5] = uint32_t(m);
+                if (lane == 1 && j0 + 32 < hc) row[(j0 >> 5) + 1] = uint32_t(m >> 32);
+            }
+            return;  // a hub vertex has no tail neighbours
+        }
+    }
+    const int64_t hb = hoff[v], he = hoff[v + 1];
+    for (int64_t j = hb + lane; j < he; j += 64) {
+        const uint32_t w = hadj[j];
+        if (w == 0xFFFFu) continue;
+        const uint32_t word = bm[w >> 5];
+        if ((word >> (w & 31u)) & 1u) {
+            const int idx = int(pre[w >> 5]) + __popc(word & ((1u << (w & 31u)) - 1u));
+            atomicOr(&row[idx >> 5], 1u << (idx & 31));
+        }
+    }
+    if (tc > 0) {
+        const int64_t tb = toff[v], te = toff[v + 1];
+        for (int64_t j = tb + lane; j < te; j += 64) {
+            const int t = sorted_find(tail_list, tc, tadj[j]);
+            if (t >= 0) {
+                const int idx = hc + t;
+                atomicOr(&row[idx >> 5], 1u << (idx & 31));
+            }
         }
     }
 }
@@ -179,27 +243,27 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
 }
 
 // ---------------------------------------------------------------------------------------------
-// M / L: workgroup per pivot.  W = words per bit row.  GLOBAL_ROWS=false: bit-matrix in dynamic LDS (d <= 1024);
-// true: in a per-workgroup global slab (d up to 64*32*WPL), workgroups walk their pivots with a grid stride.
-// dynamic LDS layout: [rows: dmax*W u32 (LDS variant only)] [keys: 2^log i32] [vals: 2^log u16]
+// M / L: workgroup per pivot.  W = words per bit row, WS = row stride.  GLOBAL_ROWS=false: bit-matrix in dynamic LDS
+// (d <= 1024); true: in a per-workgroup global slab (d up to 64*32*WPL), workgroups walk their pivots with a grid stride.
+// dynamic LDS layout: [rows: dmax*WS u32 (LDS variant only)] [bm: 2048 u32] [pre: 2048 u16]
 // ---------------------------------------------------------------------------------------------
 template <int LV, int WPL, bool GLOBAL_ROWS>
 __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                  const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
-                                                  const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
-                                                  int part, int dmax, int W, int WS, int log_map, uint32_t *__restrict__ slabs,
-                                                  unsigned long long *__restrict__ acc) {
-    extern __shared__ uint32_t smem[];
+                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                   const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
+                                                   int32_t dense_limit, const int32_t *__restrict__ order, int64_t first, int64_t end,
+                                                   int nparts, int part, int dmax, int W, int WS, uint32_t *__restrict__ slabs,
+                                                   unsigned long long *__restrict__ acc) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ unsigned long long red[16];
+    __shared__ int wave_tot[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = int(blockDim.x), nwaves = nthreads >> 6;  // 256 … 1024 threads: big LDS bit-matrices leave one workgroup per CU
-    const int map_size = 1 << log_map, shift = 32 - log_map;
-    const uint32_t mask = uint32_t(map_size - 1);
     // WS = row stride in words: W for the wave-cooperative recursion (lane = word index), W + 1 for the lane-per-pair
     // k = 4 count (random rows per lane: an odd stride spreads them over the LDS banks)
     uint32_t *rows = GLOBAL_ROWS ? slabs + size_t(blockIdx.x) * size_t(dmax) * size_t(WS) : smem;
-    int32_t *keys = reinterpret_cast<int32_t *>(GLOBAL_ROWS ? smem : smem + size_t(dmax) * WS);
-    uint16_t *vals = reinterpret_cast<uint16_t *>(keys + map_size);
+    uint32_t *bm = GLOBAL_ROWS ? smem : smem + size_t(dmax) * WS;
+    unsigned short *pre = reinterpret_cast<unsigned short *>(bm + kBitmapWords);
 
     unsigned long long cnt = 0;
     for (int64_t q = blockIdx.x;; q += gridDim.x) {
@@ -211,21 +275,44 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         const int tc = int(toff[u + 1] - tb);
         if (hc > 0 && hadj[hb + hc - 1] == 0xFFFFu) --hc;
         const int d = hc + tc;
+        const uint16_t *hub_list = hadj + hb;
+        const int32_t *tail_list = tadj + tb;
         __syncthreads();  // previous pivot's counting is done
-        for (int i = tid; i < map_size; i += nthreads) keys[i] = -1;
+        for (int i = tid; i < kBitmapWords; i += nthreads) bm[i] = 0;
         for (int i = tid; i < d * WS; i += nthreads) rows[i] = 0;
         __syncthreads();
-        for (int i = tid; i < d; i += nthreads) {
-            const int32_t v = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
-            map_insert(keys, vals, mask, shift, v, i);
+        for (int i = tid; i < hc; i += nthreads) {
+            const uint32_t w = hub_list[i];
+            atomicOr(&bm[w >> 5], 1u << (w & 31u));
+        }
+        __syncthreads();
+        // prefix popcounts of the bitmap words (exclusive): 8 words per thread over the first 256 threads
+        {
+            int local = 0;
+            if (tid < 256)
+                for (int k = 0; k < 8; ++k) local += __popc(bm[tid * 8 + k]);
+            int incl = local;
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const int o = __shfl_up(incl, sft);
+                if (lane >= sft) incl += o;
+            }
+            if (lane == 63 && wave < 4) wave_tot[wave] = incl;
+            __syncthreads();
+            if (tid < 256) {
+                int base = incl - local;
+                for (int w2 = 0; w2 < wave; ++w2) base += wave_tot[w2];
+                for (int k = 0; k < 8; ++k) {
+                    pre[tid * 8 + k] = (unsigned short)base;
+                    base += __popc(bm[tid * 8 + k]);
+                }
+            }
         }
         if (GLOBAL_ROWS) __threadfence();
         __syncthreads();
         for (int i = wave; i < d; i += nwaves) {
-            const int32_t v = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
-            uint32_t *row = rows + size_t(i) * WS;
-            build_row(hoff, hadj, toff, tadj, v, keys, vals, mask, shift, lane,
-                      [&](int idx) { atomicOr(&row[idx >> 5], 1u << (idx & 31)); });
+            const int32_t v = i < hc ? int32_t(hub_list[i]) : tail_list[i - hc];
+            build_row_sorted(hoff, hadj, toff, tadj, bmoff, bmpool, dense_limit, v, hub_list, hc, tail_list, tc, bm, pre,
+                             rows + size_t(i) * WS, lane);
         }
         if (GLOBAL_ROWS) {
             __threadfence();
@@ -288,6 +375,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     int64_t n_min = 0;
     if (int rc = count_dplus_ge(g, std::max(k - 1, 1), &n_min)) return rc;
     if (ge[0] > 0) return GMSX_ERR_UNSUPPORTED;  // d+ > 4096: beyond the widest bit rows of this build
+    if (!g->rows_sorted) return GMSX_ERR_UNSUPPORTED;  // > 2^32 container entries: rows were not sorted at upload
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
 
     // L: 1024 < d+ <= 4096, bit-matrix in a global slab per workgroup
@@ -296,19 +384,19 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (cnt > 0) {
             const bool wide = ge[1] > 0;  // some d+ > 2048
-            const int dmax = wide ? 4096 : 2048, W = dmax / 32, log_map = wide ? 13 : 12;
+            const int dmax = wide ? 4096 : 2048, W = dmax / 32;
             const int WS = LV == 2 ? W + 1 : W;
             const int64_t blocks = std::min<int64_t>(cnt, cu * 2);
             uint32_t *slabs = nullptr;
             GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(blocks) * dmax * WS * sizeof(uint32_t)));
             *slab_out = slabs;
-            const size_t lds = (size_t(4) << log_map) + (size_t(2) << log_map);
+            const size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2;
             if (wide)
                 hipLaunchKernelGGL((k_kc_block<LV, 2, true>), dim3(unsigned(blocks)), dim3(512), lds, s, g->hoff, g->hadj, g->toff,
-                                   g->tadj, g->order, lo, hi, nparts, part, dmax, W, WS, log_map, slabs, acc);
+                                   g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, slabs, acc);
             else
                 hipLaunchKernelGGL((k_kc_block<LV, 1, true>), dim3(unsigned(blocks)), dim3(512), lds, s, g->hoff, g->hadj, g->toff,
-                                   g->tadj, g->order, lo, hi, nparts, part, dmax, W, WS, log_map, slabs, acc);
+                                   g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, slabs, acc);
             ++*launches;
         }
     }
@@ -323,15 +411,13 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         const int64_t lo = ge[2 + b], hi = std::min(ge[3 + b], n_min);
         const int dmax = 1024 >> b, W = dmax / 32;
         const int WS = LV == 2 ? W + 1 : W;
-        int log_map = 1;
-        while ((1 << log_map) < 2 * dmax) ++log_map;
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (cnt > 0) {
-            const size_t lds = size_t(dmax) * WS * 4 + (size_t(4) << log_map) + (size_t(2) << log_map);
+            const size_t lds = size_t(dmax) * WS * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2;
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
             const int threads = dmax >= 1024 ? 1024 : dmax >= 512 ? 512 : 256;
             hipLaunchKernelGGL((k_kc_block<LV, 1, false>), dim3(unsigned(blocks)), dim3(threads), lds, s, g->hoff, g->hadj, g->toff,
-                               g->tadj, g->order, lo, hi, nparts, part, dmax, W, WS, log_map, static_cast<uint32_t *>(nullptr), acc);
+                               g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, static_cast<uint32_t *>(nullptr), acc);
             ++*launches;
         }
     }
