@@ -259,41 +259,69 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
         const int64_t hb = hoff[u], tb = toff[u];
         const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);  // hl <= 64 (padded), tl < 64
         __builtin_amdgcn_wave_barrier();
-        // hub part of the pivot list: set bits, fetch row extents
+        // hub part of the pivot list: lane j holds member w_j and the extent of its row
         uint32_t hv = 0xFFFFu;
         int64_t rb = 0;
         int rl = 0;
         if (lane < hl) {
             hv = hadj[hb + lane];
-            if (hv != 0xFFFFu) {
-                atomicOr(&bm[hv >> 5], 1u << (hv & 31u));
-                hub_row_extent(int32_t(hv), hoff, bmoff, dense_limit, rb, rl);
-            }
+            if (hv != 0xFFFFu) hub_row_extent(int32_t(hv), hoff, bmoff, dense_limit, rb, rl);
         }
-        // tail part: hash set + extents of both containers of every tail row
-        int64_t trb = 0, thb = 0;
-        int trl = 0, thl = 0;
-        if (tl > 0) {
-            for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
+        uint32_t c = 0;
+        // (1) DENSE rows (bitset containers): the probe direction is inverted — every lane asks "is my member w_j in
+        //     N+(v_i)?" with one word load from v_i's bitset; no LDS, one gather per row instead of streaming the row.
+        //     (A dense row belongs to a hub vertex, whose targets are all hub ids, so tail members never hit.)
+        unsigned long long dense_rows = __ballot(rl < 0);
+        while (dense_rows) {  // four rows per trip: four independent gathers in flight
+            int32_t vi[4];
+            const uint32_t *bits[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                vi[k] = 0;
+                bits[k] = bmpool;
+                if (dense_rows) {
+                    const int i = __ffsll((long long)dense_rows) - 1;
+                    dense_rows &= dense_rows - 1;
+                    vi[k] = int32_t(__builtin_amdgcn_readlane(hv, i));
+                    bits[k] = bmpool + readlane64(rb, i);
+                }
+            }
+            uint32_t wd[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wd[k] = hv < uint32_t(vi[k]) ? bits[k][hv >> 5] : 0u;  // hv == 0xFFFF never passes
+#pragma unroll
+            for (int k = 0; k < 4; ++k) c += (wd[k] >> (hv & 31u)) & 1u;  // per-lane partial count, like the scanners
+        }
+        // (2) LIST rows (of hub members that are not dense, and of tail members): stream them against the pivot bitmap
+        const bool any_list = __ballot(lane < hl && hv != 0xFFFFu && rl > 0) != 0;
+        if (rl < 0) rl = 0;  // dense rows are done
+        if (any_list || tl > 0) {
+            if (hv != 0xFFFFu) atomicOr(&bm[hv >> 5], 1u << (hv & 31u));
+            // tail part: hash set + extents of both containers of every tail row
+            int64_t trb = 0, thb = 0;
+            int trl = 0, thl = 0;
+            if (tl > 0) {
+                for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < tl) {
+                    const int32_t v = tadj[tb + lane];
+                    set_insert(tbl, MASK, SHIFT, v);
+                    thb = hoff[v];
+                    thl = int(hoff[v + 1] - thb);
+                    trb = toff[v];
+                    trl = int(toff[v + 1] - trb);
+                }
+            }
             __builtin_amdgcn_wave_barrier();
-            if (lane < tl) {
-                const int32_t v = tadj[tb + lane];
-                set_insert(tbl, MASK, SHIFT, v);
-                thb = hoff[v];
-                thl = int(hoff[v + 1] - thb);
-                trb = toff[v];
-                trl = int(toff[v + 1] - trb);
+            if (any_list) c += scan_hub_rows(bm, hadj, bmpool, rb, rl, hl, lane);
+            if (tl > 0) {
+                c += scan_hub_rows(bm, hadj, bmpool, thb, thl, tl, lane);
+                c += scan_tail_rows(tbl, MASK, SHIFT, tadj, trb, trl, tl, lane);
             }
-        }
-        __builtin_amdgcn_wave_barrier();
-        uint32_t c = scan_hub_rows(bm, hadj, bmpool, rb, rl, hl, lane);
-        if (tl > 0) {
-            c += scan_hub_rows(bm, hadj, bmpool, thb, thl, tl, lane);
-            c += scan_tail_rows(tbl, MASK, SHIFT, tadj, trb, trl, tl, lane);
+            __builtin_amdgcn_wave_barrier();
+            if (hv != 0xFFFFu) bm[hv >> 5] = 0;  // every bit in this wave's bitmap belongs to this pivot
         }
         cnt += c;
-        __builtin_amdgcn_wave_barrier();
-        if (hv != 0xFFFFu) bm[hv >> 5] = 0;  // every bit in this wave's bitmap belongs to this pivot
     }
     for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
     if (lane == 0) red[wave] = cnt;
