@@ -188,6 +188,33 @@ __device__ __forceinline__ unsigned long long wave_cliques(const uint32_t *rows,
     }
 }
 
+// Per-LANE enumeration for bit-matrices of any width: the path so far is a list of row pointers, the candidate set of a
+// level is never materialised — its words are recomputed as the AND of the path's rows, so a level costs two registers
+// (word index, remaining bits).  R = vertices still to choose.  Returns the number of R-cliques inside ∧ path rows.
+struct KcPath {
+    const uint32_t *row[10];
+};
+template <int R, int P>
+__device__ __forceinline__ unsigned long long lane_enum(const uint32_t *rows, int WS, int W, KcPath &path) {
+    unsigned long long s = 0;
+    for (int t = 0; t < W; ++t) {
+        uint32_t c = path.row[0][t];
+#pragma unroll
+        for (int q = 1; q < P; ++q) c &= path.row[q][t];
+        if constexpr (R == 1) {
+            s += (unsigned long long)__popc(c);
+        } else {
+            while (c) {
+                const int l = (t << 5) + __ffs(c) - 1;
+                c &= c - 1;
+                path.row[P] = rows + size_t(l) * WS;
+                s += lane_enum<R - 1, P + 1>(rows, WS, W, path);
+            }
+        }
+    }
+    return s;
+}
+
 // ---------------------------------------------------------------------------------------------
 // S: wave per pivot, 1 <= d+ <= 32.
 // ---------------------------------------------------------------------------------------------
@@ -321,29 +348,34 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         } else {
             __syncthreads();
         }
-        if constexpr (LV == 2) {
-            // k = 4: Σ_i Σ_{j ∈ rows[i]} popc(rows[i] & rows[j]) with one LANE per matrix word: the lane walks the set
-            // bits j of its word and ANDs the two rows word by word (the reference's isect.intersect(N(vi)) at depth 2)
-            const int words = d * W;
-            for (int cell = tid; cell < words; cell += nthreads) {
-                const int i = cell / W, w = cell - i * W;
-                uint32_t bits = rows[size_t(i) * WS + w];
-                const uint32_t *ri = rows + size_t(i) * WS;
-                while (bits) {
-                    const int j = (w << 5) + __ffs(bits) - 1;
-                    bits &= bits - 1;
-                    const uint32_t *rj = rows + size_t(j) * WS;
-                    uint32_t sum = 0;
-                    for (int t = 0; t < W; ++t) sum += __popc(ri[t] & rj[t]);
-                    cnt += sum;
-                }
-            }
-        } else {
+        if constexpr (LV == 1) {
+            // k = 3: Σ_i popc(rows[i]) — one lane per matrix word
+            for (int cell = tid; cell < d * W; cell += nthreads) cnt += (unsigned long long)__popc(rows[size_t(cell / W) * WS + cell % W]);
+        } else if (LV >= 3 && W > 8) {
+            // deep recursion on wide rows: wave-cooperative (one word per lane, the candidate set of every level is kept),
+            // which reads each row word once per visited node instead of re-ANDing the whole path
             for (int i = wave; i < d; i += nwaves) {
                 uint32_t cand[WPL];
                 cand[0] = lane < W ? rows[size_t(i) * WS + lane] : 0u;
                 if constexpr (WPL > 1) cand[1] = 64 + lane < W ? rows[size_t(i) * WS + 64 + lane] : 0u;
                 cnt += wave_cliques<LV, WPL>(rows, WS, cand, lane);
+            }
+        } else {
+            // k = 4, or narrow rows: one LANE per matrix word (i, w): it walks the set bits j of its word and enumerates the cliques below
+            // the path (i, j) by ANDing the path's rows word by word — the reference's isect.intersect(N(vi)) recursion
+            // (k = 4: Σ_i Σ_{j ∈ rows[i]} popc(rows[i] & rows[j])).  Odd row stride: no LDS bank conflicts.
+            const int words = d * W;
+            for (int cell = tid; cell < words; cell += nthreads) {
+                const int i = cell / W, w = cell - i * W;
+                uint32_t bits = rows[size_t(i) * WS + w];
+                KcPath path;
+                path.row[0] = rows + size_t(i) * WS;
+                while (bits) {
+                    const int j = (w << 5) + __ffs(bits) - 1;
+                    bits &= bits - 1;
+                    path.row[1] = rows + size_t(j) * WS;
+                    cnt += lane_enum<LV - 1, 2>(rows, WS, W, path);
+                }
             }
         }
     }
@@ -385,7 +417,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         if (cnt > 0) {
             const bool wide = ge[1] > 0;  // some d+ > 2048
             const int dmax = wide ? 4096 : 2048, W = dmax / 32;
-            const int WS = LV == 2 ? W + 1 : W;
+            const int WS = W + 1;
             const int64_t blocks = std::min<int64_t>(cnt, cu * 2);
             uint32_t *slabs = nullptr;
             GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(blocks) * dmax * WS * sizeof(uint32_t)));
@@ -410,7 +442,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     for (int b = 0; b < 5; ++b) {
         const int64_t lo = ge[2 + b], hi = std::min(ge[3 + b], n_min);
         const int dmax = 1024 >> b, W = dmax / 32;
-        const int WS = LV == 2 ? W + 1 : W;
+        const int WS = W + 1;
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (cnt > 0) {
             const size_t lds = size_t(dmax) * WS * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2;
