@@ -27,11 +27,6 @@ namespace gmsx {
 static constexpr int kLdsSlabWords = 4096;  // 16 KB per wave
 static constexpr unsigned long long kEmptySlot = ~0ull;
 
-struct BkTask {
-    int32_t v;        // rank id of the start vertex
-    uint32_t words;   // slab words it needs
-};
-
 __host__ __device__ inline uint32_t bk_map_size(int c) {
     uint32_t s = 64;
     while (s < 2u * uint32_t(c)) s <<= 1;

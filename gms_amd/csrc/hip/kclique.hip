@@ -20,12 +20,6 @@ static constexpr int kAccSlots = 64;
 static constexpr int kAccStride = 16;
 static constexpr int kMaxK = 10;
 
-__device__ __forceinline__ int64_t kc_readlane64(int64_t x, int l) {
-    const uint32_t lo = __builtin_amdgcn_readlane(uint32_t(uint64_t(x)), l);
-    const uint32_t hi = __builtin_amdgcn_readlane(uint32_t(uint64_t(x) >> 32), l);
-    return int64_t((uint64_t(hi) << 32) | lo);
-}
-
 // ---- id -> local index map (open addressing, keys -1 = empty) ---------------------------------------------
 __device__ __forceinline__ uint32_t kc_hash(int32_t w, int shift) { return (uint32_t(w) * 0x9E3779B1u) >> shift; }
 __device__ __forceinline__ void map_insert(int32_t *keys, uint16_t *vals, uint32_t mask, int shift, int32_t w, int idx) {
