@@ -149,13 +149,10 @@ __global__ __launch_bounds__(256) void k_fill_parts(int64_t n, const int64_t *__
 
 // ---- bitset containers of dense hub rows -------------------------------------------------------------------
 // words of the bitset of rank id v (covers ids [0, v)), rounded to 16 bytes; 0 if the list form is smaller
-__device__ __forceinline__ int64_t dense_words(int32_t v, int32_t dp) {
-    const int64_t nw = ((int64_t(v) + 31) / 32 + 3) & ~int64_t(3);
-    return (nw * 4 + 32 < int64_t(dp) * 2) ? nw : 0;
-}
 __global__ void k_dense_sizes(int32_t limit, const int32_t *__restrict__ dplus, int64_t *__restrict__ sizes) {
     const int32_t v = int32_t(blockIdx.x * blockDim.x + threadIdx.x);
-    if (v < limit) sizes[v] = dense_words(v, dplus[v]);
+    // every hub vertex with out-neighbours gets a bitset (<= 268 MB in total); the kernels pick bitset or list per use
+    if (v < limit) sizes[v] = bitset_words(v);  // also for d+ = 0: an all-zero bitset answers every gather with "no"
     if (v == limit) sizes[v] = 0;
 }
 __global__ __launch_bounds__(256) void k_dense_fill(int32_t limit, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,

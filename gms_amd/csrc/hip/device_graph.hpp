@@ -20,10 +20,11 @@
 //                                                     is padded to an even count with 0xFFFF (never a valid target)
 //     tail part  toff int64[n+1], tadj int32[...]    targets with rank id >= kHub, 4 bytes each
 //   On power-law graphs >85 % of all entries and >95 % of the streamed ids are hub entries.
-//     bitset part bmoff int64[K+1], bmpool uint32[...]  DENSE hub rows (2*d+ bytes > v/8 bytes) additionally as a bitmap
-//                                                     over [0, v) (Roaring's bitset container): intersecting such a row with
-//                                                     the pivot bitmap is a word-wise AND + popcount, 32 ids per word.  These
-//                                                     few thousand rows carry >70 % of the streamed ids and fit the L2.
+//     bitset part bmoff int64[K+1], bmpool uint32[...]  every hub row additionally as a bitmap over [0, v) (Roaring's bitset
+//                                                     container, <= 268 MB in total).  Heavy pivots stream it instead of the
+//                                                     list when it is the smaller form (2*d+ bytes > v/8 bytes: a few thousand
+//                                                     rows that carry >70 % of the streamed ids; AND + popcount, 32 ids per word);
+//                                                     light pivots gather single words from it ("is my member in N+(v)").
 //
 //   dplus int32[n]                     true out-degree (hub + tail) per rank id
 //   order int32[n]                     rank ids by decreasing d+ (work-sorted launch order, heavy first);
@@ -64,6 +65,9 @@ namespace gmsx {
 
 static constexpr int kHub = 65535;         // rank ids below this live in the 16-bit hub containers
 static constexpr int kBitmapWords = 2048;  // 65536-bit LDS bitmap over the hub id range
+
+// words of the bitset container of hub rank id v (covers ids [0, v)), rounded to 16 bytes
+__host__ __device__ inline int64_t bitset_words(int32_t v) { return ((int64_t(v) + 31) / 32 + 3) & ~int64_t(3); }
 
 struct Ctx {
     int device = -1;

@@ -102,16 +102,15 @@ __device__ __forceinline__ uint32_t scan_hub_rows(const uint32_t *bm, const uint
 // extent of the hub container of rank id v as the scanner wants it: the bitset form when v has one, else the list
 __device__ __forceinline__ void hub_row_extent(int32_t v, const int64_t *__restrict__ hoff, const int64_t *__restrict__ bmoff,
                                                int32_t dense_limit, int64_t &rb, int &rl) {
+    rb = hoff[v];
+    rl = int(hoff[v + 1] - rb);  // list form: 2 bytes per (padded) entry
     if (v < dense_limit) {
-        const int64_t b0 = bmoff[v], b1 = bmoff[v + 1];
-        if (b1 > b0) {
-            rb = b0;
-            rl = -int(b1 - b0);
-            return;
+        const int nw = int(bitset_words(v));
+        if (nw * 4 + 32 < rl * 2) {  // the bitset is the smaller form: stream it instead
+            rb = bmoff[v];
+            rl = -nw;
         }
     }
-    rb = hoff[v];
-    rl = int(hoff[v + 1] - rb);
 }
 
 // ---- tail side: open-addressing hash set in LDS (keys are rank ids >= kHub; -1 = empty) ------------------------
@@ -265,12 +264,15 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
         int rl = 0;
         if (lane < hl) {
             hv = hadj[hb + lane];
-            if (hv != 0xFFFFu) hub_row_extent(int32_t(hv), hoff, bmoff, dense_limit, rb, rl);
+            if (hv != 0xFFFFu && int32_t(hv) < dense_limit) {
+                rb = bmoff[hv];
+                rl = -1;  // every hub member has a bitset container
+            }
         }
         uint32_t c = 0;
-        // (1) DENSE rows (bitset containers): the probe direction is inverted — every lane asks "is my member w_j in
-        //     N+(v_i)?" with one word load from v_i's bitset; no LDS, one gather per row instead of streaming the row.
-        //     (A dense row belongs to a hub vertex, whose targets are all hub ids, so tail members never hit.)
+        // (1) rows of the HUB members: the probe direction is inverted — every lane asks "is my member w_j in N+(v_i)?"
+        //     with one word gather from v_i's bitset container; no LDS, no row streaming, four rows in flight.
+        //     (A hub vertex's targets are all hub ids, so tail members never hit.)
         unsigned long long dense_rows = __ballot(rl < 0);
         while (dense_rows) {  // four rows per trip: four independent gathers in flight
             int32_t vi[4];
@@ -292,9 +294,14 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
 #pragma unroll
             for (int k = 0; k < 4; ++k) c += (wd[k] >> (hv & 31u)) & 1u;  // per-lane partial count, like the scanners
         }
-        // (2) LIST rows (of hub members that are not dense, and of tail members): stream them against the pivot bitmap
-        const bool any_list = __ballot(lane < hl && hv != 0xFFFFu && rl > 0) != 0;
-        if (rl < 0) rl = 0;  // dense rows are done
+        // (2) rows of the TAIL members (and of hub members without a bitset: only with the hub-limit test hook): stream them
+        //     against the pivot bitmap
+        if (rl == 0 && lane < hl && hv != 0xFFFFu) {
+            rb = hoff[hv];
+            rl = int(hoff[hv + 1] - rb);
+        }
+        const bool any_list = __ballot(rl > 0) != 0;
+        if (rl < 0) rl = 0;  // bitset rows are done
         if (any_list || tl > 0) {
             if (hv != 0xFFFFu) atomicOr(&bm[hv >> 5], 1u << (hv & 31u));
             // tail part: hash set + extents of both containers of every tail row
