@@ -231,12 +231,99 @@ __global__ __launch_bounds__(256) void k_tc_block(const int64_t *__restrict__ ho
 }
 
 // ---------------------------------------------------------------------------------------------
-// Wave per pivot (2 <= d+ < 64).  Each of the 4 waves of a workgroup owns a private bitmap (8 KB) and a 256-entry
-// tail set and walks its pivots with a grid stride.  The bitmap is cleared once; each pivot sets its bits and
-// clears exactly those words again afterwards.  One atomic per workgroup at the end.
+// Light pivots (2 <= d+ < 64), part 1 of 2: the rows of the HUB members.  No LDS at all (full occupancy): lane j holds
+// member w_j; for every hub member v_i the lanes gather one word of v_i's bitset container ("is w_j in N+(v_i)?").
+// Eight rows are in flight per trip.  Part 2 (k_tc_wave) adds the rows of the tail members.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tc_wave_hub(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                     const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
+                                                     int32_t dense_limit, const int32_t *__restrict__ order, int64_t first, int64_t end,
+                                                     int nparts, int part, unsigned long long *__restrict__ acc) {
+    __shared__ unsigned long long red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t step = int64_t(gridDim.x) * 4 * nparts;
+    unsigned long long cnt = 0;
+    // two-stage software pipeline over the pivots of this wave (see k_tc_wave): C = current, B = next, A = after next
+    int64_t posC = first + (int64_t(blockIdx.x) * 4 + wave) * nparts + part;
+    int64_t hbC = 0, hbB = 0;
+    int hlC = 0, hlB = 0;
+    int32_t uA = -1;
+    if (posC < end) {
+        const int32_t u = order[posC];
+        hbC = hoff[u];
+        hlC = int(hoff[u + 1] - hbC);
+    }
+    if (posC + step < end) {
+        const int32_t u = order[posC + step];
+        hbB = hoff[u];
+        hlB = int(hoff[u + 1] - hbB);
+    }
+    if (posC + 2 * step < end) uA = order[posC + 2 * step];
+    for (; posC < end; posC += step) {  // uniform per wave
+        int64_t hbN = 0;
+        int hlN = 0;
+        if (uA >= 0) {
+            hbN = hoff[uA];
+            hlN = int(hoff[uA + 1] - hbN);
+        }
+        const int32_t uN = (posC + 3 * step < end) ? order[posC + 3 * step] : -1;
+        const int64_t hb = hbC;
+        const int hl = hlC;  // <= 64 (padded)
+        hbC = hbB; hlC = hlB;
+        hbB = hbN; hlB = hlN;
+        uA = uN;
+        uint32_t hv = 0xFFFFu;
+        int64_t rb = 0;
+        bool has = false;
+        if (lane < hl) {
+            hv = hadj[hb + lane];
+            if (hv != 0xFFFFu && int32_t(hv) < dense_limit) {
+                rb = bmoff[hv];
+                has = true;
+            }
+        }
+        uint32_t c = 0;
+        unsigned long long todo = __ballot(has);
+        while (todo) {
+            int32_t vi[8];
+            const uint32_t *bits[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                vi[k] = 0;
+                bits[k] = bmpool;
+                if (todo) {
+                    const int i = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    vi[k] = int32_t(__builtin_amdgcn_readlane(hv, i));
+                    bits[k] = bmpool + readlane64(rb, i);
+                }
+            }
+            uint32_t wd[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wd[k] = hv < uint32_t(vi[k]) ? bits[k][hv >> 5] : 0u;  // hv == 0xFFFF never passes
+#pragma unroll
+            for (int k = 0; k < 8; ++k) c += (wd[k] >> (hv & 31u)) & 1u;
+        }
+        cnt += c;
+    }
+    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
+    if (lane == 0) red[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long t = red[0] + red[1] + red[2] + red[3];
+        if (t) atomicAdd(&acc[(blockIdx.x & (kAccSlots - 1)) * kAccStride], t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Light pivots (2 <= d+ < 64), part 2 of 2: the rows of the TAIL members (rank ids >= kHub).  Each of the 4 waves of a
+// workgroup owns a private bitmap (8 KB) and a 256-entry tail set and walks its pivots with a grid stride; pivots
+// without tail members are skipped.  The bitmap is cleared once; each pivot sets its bits and clears exactly those
+// words again.  The order[] -> offsets dependent loads of the NEXT TWO pivots are issued before the current one is
+// processed (two-stage software pipeline), so skipping and processing do not pay that latency chain per pivot.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                  const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool, int32_t dense_limit,
+                                                 const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool, int32_t dense_limit,
                                                  const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                  const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
                                                  int part, unsigned long long *__restrict__ acc) {
@@ -249,86 +336,72 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
     uint32_t *bm = bm_all + wave * kBitmapWords;
     int32_t *tbl = tbl_all + wave * SIZE;
     for (int i = lane; i < kBitmapWords; i += 64) bm[i] = 0;
-    const int64_t nwaves = int64_t(gridDim.x) * 4;
+    const int64_t step = int64_t(gridDim.x) * 4 * nparts;
     unsigned long long cnt = 0;
-    for (int64_t q = int64_t(blockIdx.x) * 4 + wave;; q += nwaves) {
-        const int64_t pos = first + q * nparts + part;
-        if (pos >= end) break;  // uniform per wave
-        const int32_t u = order[pos];
-        const int64_t hb = hoff[u], tb = toff[u];
-        const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);  // hl <= 64 (padded), tl < 64
-        __builtin_amdgcn_wave_barrier();
-        // hub part of the pivot list: lane j holds member w_j and the extent of its row
-        uint32_t hv = 0xFFFFu;
-        int64_t rb = 0;
-        int rl = 0;
-        if (lane < hl) {
-            hv = hadj[hb + lane];
-            if (hv != 0xFFFFu && int32_t(hv) < dense_limit) {
-                rb = bmoff[hv];
-                rl = -1;  // every hub member has a bitset container
+    // pipeline registers: C = pivot being processed (offsets known), B = next (offsets in flight), A = after next (id in flight)
+    int64_t posC = first + (int64_t(blockIdx.x) * 4 + wave) * nparts + part;
+    int64_t hbC = 0, tbC = 0, hbB = 0, tbB = 0;
+    int hlC = 0, tlC = 0, hlB = 0, tlB = 0;
+    int32_t uA = -1;
+    if (posC < end) {
+        const int32_t u = order[posC];
+        hbC = hoff[u];
+        hlC = int(hoff[u + 1] - hbC);
+        tbC = toff[u];
+        tlC = int(toff[u + 1] - tbC);
+    }
+    if (posC + step < end) {
+        const int32_t u = order[posC + step];
+        hbB = hoff[u];
+        hlB = int(hoff[u + 1] - hbB);
+        tbB = toff[u];
+        tlB = int(toff[u + 1] - tbB);
+    }
+    if (posC + 2 * step < end) uA = order[posC + 2 * step];
+    for (; posC < end; posC += step) {  // uniform per wave
+        // issue the loads of the two later pivots first; they complete while this one is processed
+        int64_t hbN = 0, tbN = 0;
+        int hlN = 0, tlN = 0;
+        if (uA >= 0) {
+            hbN = hoff[uA];
+            hlN = int(hoff[uA + 1] - hbN);
+            tbN = toff[uA];
+            tlN = int(toff[uA + 1] - tbN);
+        }
+        const int32_t uN = (posC + 3 * step < end) ? order[posC + 3 * step] : -1;
+        const int64_t hb = hbC, tb = tbC;
+        const int hl = hlC, tl = tlC;
+        if (tl > 0) {
+            __builtin_amdgcn_wave_barrier();
+            // hub members: only their bits are needed here (their rows were counted by k_tc_wave_hub)
+            uint32_t hv = 0xFFFFu;
+            if (lane < hl) {
+                hv = hadj[hb + lane];
+                if (hv != 0xFFFFu) atomicOr(&bm[hv >> 5], 1u << (hv & 31u));
             }
-        }
-        uint32_t c = 0;
-        // (1) rows of the HUB members: the probe direction is inverted — every lane asks "is my member w_j in N+(v_i)?"
-        //     with one word gather from v_i's bitset container; no LDS, no row streaming, four rows in flight.
-        //     (A hub vertex's targets are all hub ids, so tail members never hit.)
-        unsigned long long dense_rows = __ballot(rl < 0);
-        while (dense_rows) {  // four rows per trip: four independent gathers in flight
-            int32_t vi[4];
-            const uint32_t *bits[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                vi[k] = 0;
-                bits[k] = bmpool;
-                if (dense_rows) {
-                    const int i = __ffsll((long long)dense_rows) - 1;
-                    dense_rows &= dense_rows - 1;
-                    vi[k] = int32_t(__builtin_amdgcn_readlane(hv, i));
-                    bits[k] = bmpool + readlane64(rb, i);
-                }
-            }
-            uint32_t wd[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wd[k] = hv < uint32_t(vi[k]) ? bits[k][hv >> 5] : 0u;  // hv == 0xFFFF never passes
-#pragma unroll
-            for (int k = 0; k < 4; ++k) c += (wd[k] >> (hv & 31u)) & 1u;  // per-lane partial count, like the scanners
-        }
-        // (2) rows of the TAIL members (and of hub members without a bitset: only with the hub-limit test hook): stream them
-        //     against the pivot bitmap
-        if (rl == 0 && lane < hl && hv != 0xFFFFu) {
-            rb = hoff[hv];
-            rl = int(hoff[hv + 1] - rb);
-        }
-        const bool any_list = __ballot(rl > 0) != 0;
-        if (rl < 0) rl = 0;  // bitset rows are done
-        if (any_list || tl > 0) {
-            if (hv != 0xFFFFu) atomicOr(&bm[hv >> 5], 1u << (hv & 31u));
-            // tail part: hash set + extents of both containers of every tail row
+            // tail members: hash set + extents of both containers of every tail row
             int64_t trb = 0, thb = 0;
             int trl = 0, thl = 0;
-            if (tl > 0) {
-                for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
-                __builtin_amdgcn_wave_barrier();
-                if (lane < tl) {
-                    const int32_t v = tadj[tb + lane];
-                    set_insert(tbl, MASK, SHIFT, v);
-                    thb = hoff[v];
-                    thl = int(hoff[v + 1] - thb);
-                    trb = toff[v];
-                    trl = int(toff[v + 1] - trb);
-                }
+            for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
+            __builtin_amdgcn_wave_barrier();
+            if (lane < tl) {
+                const int32_t v = tadj[tb + lane];
+                set_insert(tbl, MASK, SHIFT, v);
+                thb = hoff[v];
+                thl = int(hoff[v + 1] - thb);
+                trb = toff[v];
+                trl = int(toff[v + 1] - trb);
             }
             __builtin_amdgcn_wave_barrier();
-            if (any_list) c += scan_hub_rows(bm, hadj, bmpool, rb, rl, hl, lane);
-            if (tl > 0) {
-                c += scan_hub_rows(bm, hadj, bmpool, thb, thl, tl, lane);
-                c += scan_tail_rows(tbl, MASK, SHIFT, tadj, trb, trl, tl, lane);
-            }
+            uint32_t c = scan_hub_rows(bm, hadj, bmpool, thb, thl, tl, lane);
+            c += scan_tail_rows(tbl, MASK, SHIFT, tadj, trb, trl, tl, lane);
+            cnt += c;
             __builtin_amdgcn_wave_barrier();
             if (hv != 0xFFFFu) bm[hv >> 5] = 0;  // every bit in this wave's bitmap belongs to this pivot
         }
-        cnt += c;
+        hbC = hbB; hlC = hlB; tbC = tbB; tlC = tlB;
+        hbB = hbN; hlB = hlN; tbB = tbN; tlB = tlN;
+        uA = uN;
     }
     for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
     if (lane == 0) red[wave] = cnt;
@@ -402,8 +475,11 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
         const int64_t cnt = part_count(n_block, n_work, nparts, part);
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
-            hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit, g->toff, g->tadj, g->order,
-                               n_block, n_work, nparts, part, acc);
+            hipLaunchKernelGGL(k_tc_wave_hub, dim3(unsigned(std::min<int64_t>((cnt + 3) / 4, cap_blocks * 2))), dim3(256), 0, s, g->hoff,
+                               g->hadj, g->bmoff, g->bmpool, g->dense_limit, g->order, n_block, n_work, nparts, part, acc);
+            hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit,
+                               g->toff, g->tadj, g->order, n_block, n_work, nparts, part, acc);
+            ++launches;
             ++launches;
         }
     }
