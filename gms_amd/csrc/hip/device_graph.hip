@@ -228,6 +228,7 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->order);
     (void)hipFree(g->sorted_dplus);
     (void)hipFree(g->scratch);
+    (void)hipFree(g->acc);
     delete g;
 }
 
@@ -246,6 +247,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     hipStream_t s = ctx().stream;
     const int64_t n = g->n;
     if (int rc = dmalloc(&g->scratch, 16, g)) return rc;
+    if (int rc = dmalloc(&g->acc, kAccWords, g)) return rc;
     GMSX_HIP(hipMemsetAsync(g->scratch, 0, 16 * sizeof(unsigned long long), s));
 
     // 1. invariant check + Σ(d_u+d_v) + max degree

@@ -51,6 +51,7 @@ struct gmsx_graph {
     int32_t max_dplus = 0;
     int32_t max_deg = 0;
     unsigned long long *scratch = nullptr;  // device: a few u64 accumulators
+    unsigned long long *acc = nullptr;      // device: 64 spread u64 accumulators (128 B apart) + a few control words, reused by every call
     // host-side memo of read-only facts about the immutable graph (filled lazily; handles are single-threaded)
     mutable int32_t ge_thr[16] = {0};
     mutable int64_t ge_cnt[16] = {0};
@@ -65,6 +66,7 @@ namespace gmsx {
 
 static constexpr int kHub = 65535;         // rank ids below this live in the 16-bit hub containers
 static constexpr int kBitmapWords = 2048;  // 65536-bit LDS bitmap over the hub id range
+static constexpr int kAccWords = 64 * 16 + 16;  // size of gmsx_graph::acc in u64
 
 // words of the bitset container of hub rank id v (covers ids [0, v)), rounded to 16 bytes
 __host__ __device__ inline int64_t bitset_words(int32_t v) { return ((int64_t(v) + 31) / 32 + 3) & ~int64_t(3); }

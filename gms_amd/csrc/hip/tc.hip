@@ -454,9 +454,8 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     int64_t n_block = 0, n_work = 0;  // pivots with d+ >= 64, d+ >= 2
     if (int rc = count_dplus_ge(g, 64, &n_block)) return rc;
     if (int rc = count_dplus_ge(g, 2, &n_work)) return rc;
-    unsigned long long *acc = nullptr;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), sizeof(unsigned long long) * (kAccSlots * kAccStride + 2)));
-    struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{acc};
+    unsigned long long *acc = g->acc;  // persistent per-graph accumulators: no allocation on the call path
+    static_assert(kAccSlots * kAccStride + 2 <= kAccWords, "gmsx_graph::acc too small");
     GMSX_HIP(hipEventRecord(c.ev[0], s));
     GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * (kAccSlots * kAccStride + 2), s));
     GMSX_HIP(hipEventRecord(c.ev[1], s));

@@ -109,7 +109,7 @@ typedef struct gmsx_stats {
     double setup_ms;           /* HIP-event time of per-call setup kernels (memsets, bin prep), not in kernel_ms */
     uint64_t units;            /* work units processed: intersect_count calls (edges) / root vertices */
     uint64_t alg_elements;     /* Σ(d_u+d_v) over the units of this call, 0 if n/a */
-    uint64_t probes;           /* set-membership probes the kernels actually issued (work-efficiency numerator) */
+    uint64_t probes;           /* TC: ids the oriented kernels stream (work-efficiency numerator); BK: resume rounds; else 0 */
     int32_t launches;          /* number of kernel launches inside kernel_ms */
     int32_t reserved;
 } gmsx_stats;
