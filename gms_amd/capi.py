@@ -34,7 +34,7 @@ SYMBOLS = [
     "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
     "gmsx_graph_device_bytes", "gmsx_graph_max_out_degree",
     "gmsx_tc_total", "gmsx_tc_partial", "gmsx_tc_divisor", "gmsx_tc_vertex_count2",
-    "gmsx_intersect_count_batch", "gmsx_kclique_count", "gmsx_kclique_partial", "gmsx_bk_count", "gmsx_bk_partial",
+    "gmsx_intersect_count_batch", "gmsx_vertex_similarity_batch", "gmsx_kclique_count", "gmsx_kclique_partial", "gmsx_bk_count", "gmsx_bk_partial",
 ]
 
 
@@ -104,6 +104,7 @@ def lib():
     L.gmsx_tc_divisor.argtypes = [C.c_int]
     L.gmsx_tc_vertex_count2.argtypes = [vp, _i64p, sp]
     L.gmsx_intersect_count_batch.argtypes = [vp, C.c_int64, _i32p, _i32p, _u32p, sp]
+    L.gmsx_vertex_similarity_batch.argtypes = [vp, C.c_int, C.c_int64, _i32p, _i32p, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), sp]
     L.gmsx_kclique_count.argtypes = [vp, C.c_int, u64p, u64p, sp]
     L.gmsx_kclique_partial.argtypes = [vp, C.c_int, C.c_int, C.c_int, u64p, sp]
     L.gmsx_bk_count.argtypes = [vp, C.c_void_p, u64p, sp]
@@ -268,6 +269,18 @@ class DeviceGraph:
         _check(lib().gmsx_intersect_count_batch(self._h, u.size, u if u.size else np.zeros(1, np.int32),
                                                 v if v.size else np.zeros(1, np.int32), out, C.byref(st)),
                "gmsx_intersect_count_batch")
+        out = out[:u.size]
+        return (out, st.as_dict()) if stats else out
+
+    SIM = {"jaccard": 0, "overlap": 1, "adamic_adar": 2, "resource": 3, "common_neighbors": 4, "total_neighbors": 5, "pref_attachment": 6}
+
+    def vertex_similarity_batch(self, metric, u, v, stats=False):
+        u = np.ascontiguousarray(u, dtype=np.int32)
+        v = np.ascontiguousarray(v, dtype=np.int32)
+        out, st = np.zeros(max(u.size, 1), dtype=np.float64), Stats()
+        m = self.SIM[metric] if isinstance(metric, str) else int(metric)
+        _check(lib().gmsx_vertex_similarity_batch(self._h, m, u.size, u if u.size else np.zeros(1, np.int32),
+                                                  v if v.size else np.zeros(1, np.int32), out, C.byref(st)), "gmsx_vertex_similarity_batch")
         out = out[:u.size]
         return (out, st.as_dict()) if stats else out
 

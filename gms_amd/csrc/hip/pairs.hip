@@ -61,6 +61,65 @@ __global__ __launch_bounds__(256) void k_pair_batch(const int64_t *__restrict__ 
     }
 }
 
+// Vertex similarity (vertex_similarity/vertex_similarity.h:30-222): one wave per pair.  Count-based metrics reuse
+// wave_intersect_count; Adamic-Adar / resource allocation add a per-common-neighbour term while intersecting.
+__global__ __launch_bounds__(256) void k_pair_similarity(const int64_t *__restrict__ off, const int32_t *__restrict__ adj, int64_t n,
+                                                         int metric, int64_t n_pairs, const int32_t *__restrict__ pu,
+                                                         const int32_t *__restrict__ pv, double *__restrict__ out,
+                                                         unsigned long long *__restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t p = wave0; p < n_pairs; p += nwaves) {
+        const int32_t u = pu[p], v = pv[p];
+        if (u < 0 || v < 0 || u >= n || v >= n) {
+            if (lane == 0) {
+                out[p] = 0.0;
+                atomicOr(&flags[0], 1ull);
+            }
+            continue;
+        }
+        const int32_t *a = adj + off[u], *b = adj + off[v];
+        int64_t la = off[u + 1] - off[u], lb = off[v + 1] - off[v];
+        const double ca = double(la), cb = double(lb);
+        double r;
+        if (metric == GMSX_SIM_ADAMIC_ADAR || metric == GMSX_SIM_RESOURCE) {
+            if (la > lb) {
+                const int32_t *t = a; a = b; b = t;
+                const int64_t tl = la; la = lb; lb = tl;
+            }
+            double sum = 0.0;
+            for (int64_t base = 0; base < la; base += 64) {
+                const int64_t i = base + lane;
+                if (i < la) {
+                    const int32_t x = a[i];
+                    int64_t lo = 0, hi = lb;
+                    while (lo < hi) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (b[mid] < x) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo < lb && b[lo] == x) {
+                        const double deg = double(off[x + 1] - off[x]);
+                        sum += metric == GMSX_SIM_ADAMIC_ADAR ? 1.0 / log(deg) : 1.0 / deg;
+                    }
+                }
+            }
+            for (int s = 32; s > 0; s >>= 1) sum += __shfl_xor(sum, s);
+            r = sum;
+        } else {
+            const double cnt = double(wave_intersect_count(a, la, b, lb, lane));
+            switch (metric) {
+                case GMSX_SIM_JACCARD: r = (la == 0 && lb == 0) ? 1.0 : cnt / (ca + cb + cnt); break;   // sic, vertex_similarity.h:31-36
+                case GMSX_SIM_OVERLAP: r = cnt / (ca < cb ? ca : cb); break;                              // :66-68
+                case GMSX_SIM_COMMON_NEIGHBORS: r = cnt; break;                                           // :139-143
+                case GMSX_SIM_TOTAL_NEIGHBORS: r = ca + cb - cnt; break;                                  // union_count, :155-159
+                default: r = ca * cb; break;                                                              // :171-174
+            }
+        }
+        if (lane == 0) out[p] = r;
+    }
+}
+
 // One wave per CSR entry e = (u -> v).  MODE 0: u < v only, Σ into acc (the reference's count_total sum, /3 on the host).
 // MODE 1: every entry, counts[u] += |N(u) ∩ N(v)| (vertex_count2).  Entries [first, end) of the shard.
 template <int MODE>
@@ -159,6 +218,45 @@ int gmsx_tc_vertex_count2(const gmsx_graph *g, int64_t *counts, gmsx_stats *stat
     if (int rc = run_edge_pairs(g, 1, 0, 1, nullptr, d_counts, stats)) return rc;
     if (g->n > 0) GMSX_HIP(hipMemcpy(counts, d_counts, sizeof(int64_t) * size_t(g->n), hipMemcpyDeviceToHost));
     return GMSX_OK;
+}
+
+int gmsx_vertex_similarity_batch(const gmsx_graph *g, int metric, int64_t n_pairs, const int32_t *u, const int32_t *v, double *out,
+                                 gmsx_stats *stats) {
+    if (!g || n_pairs < 0 || metric < GMSX_SIM_JACCARD || metric > GMSX_SIM_PREF_ATTACHMENT || (n_pairs > 0 && (!u || !v || !out)))
+        return GMSX_ERR_INVALID;
+    if (int rc = ensure_init()) return rc;
+    if (n_pairs == 0) {
+        if (stats) *stats = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
+        return GMSX_OK;
+    }
+    Ctx &c = ctx();
+    hipStream_t s = c.stream;
+    int32_t *du = nullptr, *dv = nullptr;
+    double *dout = nullptr;
+    unsigned long long *flags = nullptr;
+    struct Guard { void *p = nullptr; ~Guard() { (void)hipFree(p); } } g1, g2, g3, g4;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&du), size_t(n_pairs) * 4)); g1.p = du;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dv), size_t(n_pairs) * 4)); g2.p = dv;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dout), size_t(n_pairs) * 8)); g3.p = dout;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&flags), 8)); g4.p = flags;
+    GMSX_HIP(hipMemcpyAsync(du, u, size_t(n_pairs) * 4, hipMemcpyHostToDevice, s));
+    GMSX_HIP(hipMemcpyAsync(dv, v, size_t(n_pairs) * 4, hipMemcpyHostToDevice, s));
+    GMSX_HIP(hipMemsetAsync(flags, 0, 8, s));
+    GMSX_HIP(hipEventRecord(c.ev[0], s));
+    const int64_t blocks = std::min<int64_t>((n_pairs + 3) / 4, int64_t(c.compute_units > 0 ? c.compute_units : 256) * 32);
+    hipLaunchKernelGGL(k_pair_similarity, dim3(unsigned(blocks)), dim3(256), 0, s, g->off, g->adj, g->n, metric, n_pairs, du, dv, dout, flags);
+    GMSX_HIP(hipEventRecord(c.ev[1], s));
+    GMSX_HIP(hipGetLastError());
+    unsigned long long bad = 0;
+    GMSX_HIP(hipMemcpyAsync(out, dout, size_t(n_pairs) * 8, hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipMemcpyAsync(&bad, flags, 8, hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipStreamSynchronize(s));
+    if (stats) {
+        float ms = 0.f;
+        GMSX_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+        *stats = gmsx_stats{double(ms), 0.0, uint64_t(n_pairs), 0, 0, 1, 0};
+    }
+    return bad ? GMSX_ERR_INVALID : GMSX_OK;
 }
 
 int gmsx_intersect_count_batch(const gmsx_graph *g, int64_t n_pairs, const int32_t *u, const int32_t *v, uint32_t *out,

@@ -161,6 +161,18 @@ int gmsx_tc_vertex_count2(const gmsx_graph *g, int64_t *counts /* n, host */, gm
 int gmsx_intersect_count_batch(const gmsx_graph *g, int64_t n_pairs, const int32_t *u, const int32_t *v,
                                uint32_t *out, gmsx_stats *stats);
 
+/* ---- vertex similarity over graph rows: GMS::VertexSim::vertex_similarity<Metric> (gms/algorithms/set_based/vertex_similarity/
+ * vertex_similarity.h:30-222), the scores behind the reference's link-prediction driver.  out[i] = metric(N(u[i]), N(v[i])) in
+ * double precision, formulas as the reference writes them (its Jaccard divides by |A|+|B|+|A∩B|, :34-35).  The count-based
+ * metrics are bit-identical to the reference; Adamic-Adar / resource-allocation sum their terms in a different order and use
+ * the device log(): |rel. error| <= 1e-12. */
+enum {
+    GMSX_SIM_JACCARD = 0, GMSX_SIM_OVERLAP = 1, GMSX_SIM_ADAMIC_ADAR = 2, GMSX_SIM_RESOURCE = 3,
+    GMSX_SIM_COMMON_NEIGHBORS = 4, GMSX_SIM_TOTAL_NEIGHBORS = 5, GMSX_SIM_PREF_ATTACHMENT = 6
+};
+int gmsx_vertex_similarity_batch(const gmsx_graph *g, int metric, int64_t n_pairs, const int32_t *u, const int32_t *v,
+                                 double *out, gmsx_stats *stats);
+
 /* ---- k-clique counting: CliqueCount (k_clique_count/k_clique_count_set_based.h:19-31).
  * *ordered_count = the reference's return value k!·C_k (mod 2^64, like size_t); *cliques = C_k (may be NULL). */
 int gmsx_kclique_count(const gmsx_graph *g, int k, uint64_t *ordered_count, uint64_t *cliques, gmsx_stats *stats);

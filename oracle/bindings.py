@@ -52,6 +52,8 @@ class Oracle:
         L.gmso_tc_elements.restype = C.c_uint64
         L.gmso_tc_elements.argtypes = [C.c_int64, _i64p, _i32p]
         L.gmso_max_threads.restype = C.c_int
+        L.gmso_vertex_similarity.restype = C.c_double
+        L.gmso_vertex_similarity.argtypes = [C.c_int, C.c_int64, _i64p, _i32p, C.c_int32, C.c_int32]
 
     # -- sets ---------------------------------------------------------------
     @staticmethod
@@ -116,6 +118,9 @@ class Oracle:
             rank = self.degree_rank(off)
         return int(self.L.gmso_bk_count(off.size - 1, off, neigh, np.ascontiguousarray(rank, dtype=np.int32), threads))
 
+    def vertex_similarity(self, metric, off, neigh, u, v):
+        return np.array([self.L.gmso_vertex_similarity(metric, off.size - 1, off, neigh, int(a), int(b)) for a, b in zip(u, v)], dtype=np.float64)
+
     def tc_elements(self, off, neigh):
         return int(self.L.gmso_tc_elements(off.size - 1, off, neigh))
 
@@ -160,6 +165,7 @@ class Reference:
         L.ref_set_op.restype = C.c_int64
         L.ref_set_op.argtypes = [C.c_int, C.c_int, _i32p, C.c_int64, _i32p, C.c_int64, _i32p]
         L.ref_omp_threads.restype = C.c_int
+        L.ref_vertex_similarity.argtypes = [vp, C.c_int, C.c_int, C.c_int64, _i32p, _i32p, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
 
     def generate(self, kind, scale, deg=16, relabel=True, threads=0):
         return self.L.ref_graph_generate(1 if kind == "uniform" else 0, scale, deg, int(relabel), threads)
@@ -195,6 +201,13 @@ class Reference:
         r = np.empty(self.L.ref_num_nodes(g), dtype=np.int32)
         self.L.ref_rank(g, order, r)
         return r
+
+    def vertex_similarity(self, g, metric, u, v, set_kind=0):
+        u = np.ascontiguousarray(u, dtype=np.int32)
+        v = np.ascontiguousarray(v, dtype=np.int32)
+        out = np.zeros(u.size, dtype=np.float64)
+        self.L.ref_vertex_similarity(g, metric, set_kind, u.size, u, v, out)
+        return out
 
     def set_op(self, set_kind, op, a, b):
         a = np.ascontiguousarray(a, dtype=np.int32)

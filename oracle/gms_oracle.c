@@ -2,6 +2,7 @@
  * Plain C11 + OpenMP restatement of the reference's algorithms; written from the behaviour of the
  * cited reference functions, sharing no code with them.  Parity: PINNED (tests/test_oracle.py). */
 #include "gms_oracle.h"
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -311,4 +312,35 @@ void gmso_degree_rank(int64_t n, const int64_t *off, int32_t *rank) {
     qsort(t, (size_t)n, sizeof(deg_id), cmp_deg_id);
     for (int64_t i = 0; i < n; i++) rank[t[i].id] = (int32_t)i;
     free(t);
+}
+
+/* ------------------------------------------------------------------ vertex similarity */
+
+/* vertex_similarity.h:30-222 */
+double gmso_vertex_similarity(int metric, int64_t n, const int64_t *off, const int32_t *neigh, int32_t a, int32_t b) {
+    (void)n;
+    const int32_t *ra = neigh + off[a], *rb = neigh + off[b];
+    const size_t la = (size_t)(off[a + 1] - off[a]), lb = (size_t)(off[b + 1] - off[b]);
+    if (metric == 2 || metric == 3) { /* iterate the intersection in ascending order, as the reference's range-for does */
+        double sum = 0;
+        size_t i = 0, j = 0;
+        while (i < la && j < lb) {
+            if (ra[i] < rb[j]) i++;
+            else if (rb[j] < ra[i]) j++;
+            else {
+                double count = (double)(off[ra[i] + 1] - off[ra[i]]);
+                sum += metric == 2 ? 1. / log(count) : 1.0 / count;
+                i++; j++;
+            }
+        }
+        return sum;
+    }
+    double count = (double)gmso_intersect_count(ra, la, rb, lb);
+    switch (metric) {
+        case 0: return (la == 0 && lb == 0) ? 1.0 : count / ((double)(la + lb) + count);
+        case 1: return count / (double)(la < lb ? la : lb);
+        case 4: return count;
+        case 5: return (double)gmso_union_count(ra, la, rb, lb);
+        default: return (double)(la * lb);
+    }
 }

@@ -58,6 +58,11 @@ uint64_t gmso_bk_count(int64_t n, const int64_t *off, const int32_t *neigh, cons
  * rank = position in ascending (degree, id) order. */
 void gmso_degree_rank(int64_t n, const int64_t *off, int32_t *rank);
 
+/* ---- vertex similarity (gms/algorithms/set_based/vertex_similarity/vertex_similarity.h:30-222) ----
+ * metric: 0 Jaccard (sic: count/(|A|+|B|+count), :31-36), 1 Overlap (:66-68), 2 Adamic-Adar (:96-108), 3 Resource (:120-128),
+ * 4 CommNeigh (:139-143), 5 TotalNeigh (:155-159), 6 PrefAtt (:171-174).  Double precision, reference evaluation order. */
+double gmso_vertex_similarity(int metric, int64_t n, const int64_t *off, const int32_t *neigh, int32_t a, int32_t b);
+
 /* Σ_{(u,v), u<v} (d_u + d_v): the element count behind SURVEY §8(d)'s B_alg. */
 uint64_t gmso_tc_elements(int64_t n, const int64_t *off, const int32_t *neigh);
 int gmso_max_threads(void);

@@ -20,6 +20,7 @@
 #include <gms/algorithms/set_based/triangle_count/triangle_count.h>
 #include <gms/algorithms/set_based/k_clique_count/k_clique_count_set_based.h>
 #include <gms/algorithms/set_based/maximal_clique_enum/bron_kerbosch.h>
+#include <gms/algorithms/set_based/vertex_similarity/vertex_similarity.h>
 
 #include <fcntl.h>
 #include <unistd.h>
@@ -180,6 +181,27 @@ void ref_rank(void *h, int order, int32_t *out) {
 // op codes: see set_op above.  `out` must hold na+nb elements.  Returns count / cardinality.
 int64_t ref_set_op(int set_kind, int op, const int32_t *a, int64_t na, const int32_t *b, int64_t nb, int32_t *out) {
     return set_kind == 0 ? set_op<SortedSet>(op, a, na, b, nb, out) : set_op<RoaringSet>(op, a, na, b, nb, out);
+}
+// metric: index into GMS::VertexSim::Metric {Jaccard, Overlap, AdamicAdar, Resource, CommNeigh, TotalNeigh, PrefAtt}
+void ref_vertex_similarity(void *h, int metric, int set_kind, int64_t n_pairs, const int32_t *u, const int32_t *v, double *out) {
+    Quiet q;
+    const CSRGraph &g = static_cast<RefGraph *>(h)->g;
+    auto run = [&](const auto &sg) {
+        using namespace GMS::VertexSim;
+        for (int64_t i = 0; i < n_pairs; i++) {
+            switch (metric) {
+                case 0: out[i] = vertex_similarity<Metric::Jaccard>(u[i], v[i], sg); break;
+                case 1: out[i] = vertex_similarity<Metric::Overlap>(u[i], v[i], sg); break;
+                case 2: out[i] = vertex_similarity<Metric::AdamicAdar>(u[i], v[i], sg); break;
+                case 3: out[i] = vertex_similarity<Metric::Resource>(u[i], v[i], sg); break;
+                case 4: out[i] = vertex_similarity<Metric::CommNeigh>(u[i], v[i], sg); break;
+                case 5: out[i] = vertex_similarity<Metric::TotalNeigh>(u[i], v[i], sg); break;
+                default: out[i] = vertex_similarity<Metric::PrefAtt>(u[i], v[i], sg); break;
+            }
+        }
+    };
+    if (set_kind == 0) { auto sg = SortedSetGraph::FromCGraph(g); run(sg); }
+    else { auto sg = RoaringGraph::FromCGraph(g); run(sg); }
 }
 int ref_omp_threads(void) { return omp_get_max_threads(); }
 }

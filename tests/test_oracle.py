@@ -148,3 +148,17 @@ def test_set_ops_against_compiled_reference(oracle, reference):
             assert np.array_equal(oracle.difference(sa, sb), np.sort(reference.set_op(kind, "difference", a, b)))
             assert np.array_equal(oracle.union(sa, sb), np.sort(reference.set_op(kind, "union", a, b)))
             assert oracle.union_count(sa, sb) == reference.set_op(kind, "union_count", a, b)
+
+
+SIM = ["jaccard", "overlap", "adamic_adar", "resource", "common_neighbors", "total_neighbors", "pref_attachment"]
+
+
+def test_vertex_similarity_goldens(oracle, capi):
+    """GMS::VertexSim::vertex_similarity (vertex_similarity.h:205-222): bit-identical doubles, NaN/inf positions included."""
+    z = np.load(os.path.join(GOLDEN, "vertex_similarity.npz"))
+    csr = host_graph(capi, "kronecker", 10)
+    off, ng = csr.offsets(), csr.neighbors()
+    for m, name in enumerate(SIM):
+        got = oracle.vertex_similarity(m, off, ng, z["u"], z["v"])
+        assert np.array_equal(got, z[name], equal_nan=True), name
+    assert np.isnan(z["overlap"]).any() and (z["jaccard"] == 1.0).any()  # the empty-set edge cases are in the vectors

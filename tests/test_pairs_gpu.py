@@ -77,3 +77,32 @@ def test_vertex_count2_vs_goldens_and_oracle(gpu, oracle):
     e = gpu.DeviceGraph.from_csr(edges_to_csr(gpu, [(0, 1), (1, 2), (2, 0), (2, 3)]))
     assert e.tc_vertex_count2().tolist() == [2, 2, 2, 0]
     e.free()
+
+
+def test_vertex_similarity_batch(gpu, oracle):
+    """gmsx_vertex_similarity_batch vs the reference goldens: count-based metrics bit-identical (NaN positions included);
+    Adamic-Adar / resource allocation within 1e-12 relative (different summation order, device log())."""
+    z = np.load(os.path.join(GOLDEN, "vertex_similarity.npz"))
+    g = gpu.DeviceGraph.from_csr(host_graph(gpu, "kronecker", 10))
+    for name in ("jaccard", "overlap", "common_neighbors", "total_neighbors", "pref_attachment"):
+        got, st = g.vertex_similarity_batch(name, z["u"], z["v"], stats=True)
+        assert np.array_equal(got, z[name], equal_nan=True), name
+        assert st["units"] == z["u"].size
+    for name in ("adamic_adar", "resource"):
+        got, want = g.vertex_similarity_batch(name, z["u"], z["v"]), z[name]
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin) and np.array_equal(got[~fin], want[~fin], equal_nan=True)
+        assert np.allclose(got[fin], want[fin], rtol=1e-12, atol=0.0), name
+    with pytest.raises(gpu.GmsxError) as ei:
+        g.vertex_similarity_batch(7, [0], [1])
+    assert ei.value.status == gpu.ERR_INVALID
+    g.free()
+    csr = host_graph(gpu, "uniform", 12, 24, True)
+    g = gpu.DeviceGraph.from_csr(csr)
+    rng = np.random.default_rng(3)
+    u, v = rng.integers(0, 4096, 500), rng.integers(0, 4096, 500)
+    for m, name in enumerate(["jaccard", "overlap", "adamic_adar", "resource", "common_neighbors", "total_neighbors", "pref_attachment"]):
+        want = oracle.vertex_similarity(m, csr.offsets(), csr.neighbors(), u, v)
+        got = g.vertex_similarity_batch(name, u, v)
+        assert np.allclose(got, want, rtol=1e-12, atol=0.0, equal_nan=True), name
+    g.free()

@@ -46,6 +46,25 @@ def graph_record(g, tc=True, kc=(3, 4), bk=True, fingerprint=True):
     return rec, off, ng
 
 
+def similarity_goldens():
+    """GMS::VertexSim::vertex_similarity<Metric> (vertex_similarity/vertex_similarity.h:205-222) for 7 metrics on random and
+    edge-case pairs of the scale-10 Kronecker graph; SortedSetGraph and RoaringGraph agree bit for bit."""
+    g = R.generate("kronecker", 10, 16, True)
+    off, ng = R.csr(g)
+    deg = np.diff(off)
+    rng = np.random.default_rng(77)
+    iso = np.flatnonzero(deg == 0)[:4]
+    u = np.concatenate([rng.integers(0, 1024, 400), np.arange(8), iso, iso[::-1], [0, 1, 2]]).astype(np.int32)
+    v = np.concatenate([rng.integers(0, 1024, 400), np.arange(8), iso, np.arange(iso.size), [1023, 1022, 1021]]).astype(np.int32)
+    arrays = {"u": u, "v": v}
+    for m, name in enumerate(["jaccard", "overlap", "adamic_adar", "resource", "common_neighbors", "total_neighbors", "pref_attachment"]):
+        a, b = R.vertex_similarity(g, m, u, v, S), R.vertex_similarity(g, m, u, v, RO)
+        assert np.array_equal(a, b, equal_nan=True), name
+        arrays[name] = a
+    R.free(g)
+    np.savez_compressed(os.path.join(OUT, "vertex_similarity.npz"), **arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
 
@@ -95,6 +114,9 @@ def main():
         arrays["counts%d" % i] = np.array([r["intersect_count"], r["union_count"], r["cardinality"]], dtype=np.int64)
     np.savez_compressed(os.path.join(OUT, "set_ops_random.npz"), **arrays)
     if len(sys.argv) > 1 and sys.argv[1] == "--only-sets":
+        return
+    similarity_goldens()
+    if len(sys.argv) > 1 and sys.argv[1] == "--only-similarity":
         return
 
     # ---- 2. generated graphs: fingerprints + counts ---------------------------------------------------
