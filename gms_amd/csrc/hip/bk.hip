@@ -91,6 +91,30 @@ __device__ __forceinline__ void bk_scan_row(const int64_t *__restrict__ hoff, co
     }
 }
 
+// per-LANE sequential scan of the oriented row of rank id a (the rows of the in-neighbours are short): four hub ids per
+// 8-byte load, so the dependent load chain of a lane is a quarter as long
+struct __attribute__((packed, aligned(4))) bk_u2 { uint32_t x, y; };
+template <class F>
+__device__ __forceinline__ void bk_scan_row_lane(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                 const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, int32_t a,
+                                                 const unsigned long long *map, uint32_t mask, F f) {
+    const int64_t hb = hoff[a], he = hoff[a + 1];  // even count, 4-byte aligned start
+    for (int64_t j = hb; j < he; j += 4) {
+        const bk_u2 p = *reinterpret_cast<const bk_u2 *>(hadj + j);  // may run 2 ids past the row: masked below
+        const uint32_t w0 = p.x & 0xffffu, w1 = p.x >> 16, w2 = p.y & 0xffffu, w3 = p.y >> 16;
+        const bool more = j + 2 < he;
+        if (w0 != 0xFFFFu) { const int k = bk_find(map, mask, int32_t(w0)); if (k >= 0) f(k); }
+        if (w1 != 0xFFFFu) { const int k = bk_find(map, mask, int32_t(w1)); if (k >= 0) f(k); }
+        if (more && w2 != 0xFFFFu) { const int k = bk_find(map, mask, int32_t(w2)); if (k >= 0) f(k); }
+        if (more && w3 != 0xFFFFu) { const int k = bk_find(map, mask, int32_t(w3)); if (k >= 0) f(k); }
+    }
+    const int64_t tb = toff[a], te = toff[a + 1];
+    for (int64_t j = tb; j < te; ++j) {
+        const int k = bk_find(map, mask, tadj[j]);
+        if (k >= 0) f(k);
+    }
+}
+
 __device__ __forceinline__ int wave_sum(int x) {
     for (int s = 32; s > 0; s >>= 1) x += __shfl_xor(x, s);
     return x;
@@ -114,6 +138,9 @@ struct BkShared {
     unsigned long long *dir_count;
     unsigned long long *max_stack;      // max (c+1)*lvl over the dumped records
     unsigned budget;                    // nodes per task before it is split
+    const int64_t *bmoff;               // bitset containers of the hub rows (device_graph.hpp)
+    const uint32_t *bmpool;
+    int32_t dense_limit;
 };
 static constexpr int kRecHeader = 8;  // v, c, x, xf_ne, arena offset (2 words), 2 spare
 static constexpr unsigned long long kNoArena = ~0ull;
@@ -124,9 +151,8 @@ static constexpr unsigned long long kNoArena = ~0ull;
 __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *XT, uint32_t *stack, unsigned char *xfne_stack,
                                           int32_t v, int c, int x, uint32_t P, uint32_t Xc, uint32_t ext, int xf_ne, bool entering,
                                           int lane, unsigned long long &cnt, const BkShared &sh, unsigned long long arena_off,
-                                          bool global_structs) {
-    __shared__ uint32_t piv_P[64];             // the current P, readable by every lane (one wave per workgroup)
-    __shared__ unsigned short piv_list[2048];  // members of P ∪ Xc
+                                          bool global_structs, uint32_t *piv_P /* LDS, 64 words: the current P for all lanes */,
+                                          unsigned short *piv_list /* LDS, 2048 entries: members of P ∪ Xc */) {
     const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
     const int lvl = 3 * cw + xw + 1;
     unsigned budget = sh.budget, nodes = 0;
@@ -327,6 +353,14 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
                                                 unsigned long long slab_words, unsigned long long *__restrict__ acc, BkShared sh) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_slab[LDS_SLAB ? kLdsSlabWords : 4];
     __shared__ unsigned char xfne_stack[2052];  // per level: is Xf non-empty (written by one lane, read by all)
+    // global-slab variant: the id -> index map of the build phase lives in LDS whenever it fits (c <= 512); the probes
+    // of the in-neighbour rows are the long dependent chains of the build
+    constexpr uint32_t kLdsMapSlots = 1024;
+    // one 8.25 KB LDS work area: the build's id -> index map (global-slab variant), then the search's pivot scratch
+    __shared__ __attribute__((aligned(16))) uint32_t lds_work[(LDS_SLAB ? 1024 : 2 * kLdsMapSlots) + 64];
+    unsigned long long *lds_map = reinterpret_cast<unsigned long long *>(lds_work);
+    uint32_t *piv_P = lds_work + (LDS_SLAB ? 1024 : 2 * kLdsMapSlots);
+    unsigned short *piv_list = reinterpret_cast<unsigned short *>(lds_work);
     const int lane = threadIdx.x;
     uint32_t *slab = LDS_SLAB ? lds_slab : slabs + size_t(blockIdx.x) * slab_words;
     unsigned long long cnt = 0;
@@ -343,7 +377,7 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
         const int x = int(oe - ob) - c;
         const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
         const uint32_t msize = bk_map_size(c), mmask = msize - 1;
-        unsigned long long *map = reinterpret_cast<unsigned long long *>(slab);
+        unsigned long long *map = (!LDS_SLAB && msize <= kLdsMapSlots) ? lds_map : reinterpret_cast<unsigned long long *>(slab);
         uint32_t *Cadj = slab + 2 * size_t(msize);
         uint32_t *XT = Cadj + size_t(c) * cw;
         uint32_t *stack = XT + size_t(c) * xw;
@@ -364,12 +398,30 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
         }
         if (!LDS_SLAB) __threadfence();
         __builtin_amdgcn_wave_barrier();
-        for (int i = 0; i < c; ++i) {  // rows of the candidates: all lanes stream one row
+        for (int i = 0; i < c; ++i) {  // rows of the candidates
             const int32_t a = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
-            bk_scan_row(hoff, hadj, toff, tadj, a, map, mmask, lane, 64, [&](int k) {
-                atomicOr(&Cadj[size_t(i) * cw + (k >> 5)], 1u << (k & 31));
-                atomicOr(&Cadj[size_t(k) * cw + (i >> 5)], 1u << (i & 31));
-            });
+            if (a < sh.dense_limit) {
+                // a hub candidate has a bitset container: lane k asks "is candidate k in N+(a)?" with one word gather
+                // (its targets are hub ids < a, so only hub candidates can hit)
+                const uint32_t *bits = sh.bmpool + sh.bmoff[a];
+                for (int k0 = 0; k0 < hc; k0 += 64) {
+                    const int k = k0 + lane;
+                    bool hit = false;
+                    if (k < hc) {
+                        const uint32_t w = hadj[hb + k];
+                        if (int32_t(w) < a) hit = (bits[w >> 5] >> (w & 31u)) & 1u;
+                    }
+                    if (hit) {
+                        atomicOr(&Cadj[size_t(i) * cw + (k >> 5)], 1u << (k & 31));
+                        atomicOr(&Cadj[size_t(k) * cw + (i >> 5)], 1u << (i & 31));
+                    }
+                }
+            } else {  // tail candidate: stream its containers through the map
+                bk_scan_row(hoff, hadj, toff, tadj, a, map, mmask, lane, 64, [&](int k) {
+                    atomicOr(&Cadj[size_t(i) * cw + (k >> 5)], 1u << (k & 31));
+                    atomicOr(&Cadj[size_t(k) * cw + (i >> 5)], 1u << (i & 31));
+                });
+            }
         }
         // rows of the in-neighbours: one lane per row (they are short); t = index of the in-neighbour in X0
         int xbase = 0;
@@ -384,8 +436,8 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
             const unsigned long long m = __ballot(keep);
             if (keep) {
                 const int t = xbase + __popcll(m & ((1ull << lane) - 1ull));
-                bk_scan_row(hoff, hadj, toff, tadj, nw, map, mmask, 0, 1,
-                            [&](int k) { atomicOr(&XT[size_t(k) * xw + (t >> 5)], 1u << (t & 31)); });
+                bk_scan_row_lane(hoff, hadj, toff, tadj, nw, map, mmask,
+                                 [&](int k) { atomicOr(&XT[size_t(k) * xw + (t >> 5)], 1u << (t & 31)); });
             }
             xbase += __popcll(m);
         }
@@ -406,7 +458,7 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
             stack[3 * cw + w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
         }
         __builtin_amdgcn_wave_barrier();
-        bk_search(Cadj, XT, stack, xfne_stack, v, c, x, P, 0u, 0u, x > 0 ? 1 : 0, true, lane, cnt, sh, kNoArena, !LDS_SLAB);
+        bk_search(Cadj, XT, stack, xfne_stack, v, c, x, P, 0u, 0u, x > 0 ? 1 : 0, true, lane, cnt, sh, kNoArena, !LDS_SLAB, piv_P, piv_list);
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
@@ -418,6 +470,8 @@ __global__ __launch_bounds__(64) void k_bk_resume(const uint32_t *__restrict__ p
                                                   uint32_t *__restrict__ slabs, unsigned long long slab_words,
                                                   unsigned long long *__restrict__ acc, BkShared sh) {
     __shared__ unsigned char xfne_stack[2052];
+    __shared__ uint32_t piv_P[64];
+    __shared__ unsigned short piv_list[2048];
     const int lane = threadIdx.x;
     uint32_t *stack = slabs + size_t(blockIdx.x) * slab_words;
     unsigned long long cnt = 0;
@@ -440,7 +494,7 @@ __global__ __launch_bounds__(64) void k_bk_resume(const uint32_t *__restrict__ p
         const uint32_t ext = lane < cw ? rec[kRecHeader + 2 * cw + lane] : 0u;
         for (int w = lane; w < xw; w += 64) stack[3 * cw + w] = rec[kRecHeader + 3 * cw + w];
         __builtin_amdgcn_wave_barrier();
-        bk_search(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, xf_ne, false, lane, cnt, sh, aoff, true);
+        bk_search(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, xf_ne, false, lane, cnt, sh, aoff, true, piv_P, piv_list);
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
@@ -511,10 +565,20 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     sh.dir_count = acc + kCtl + 5;
     sh.max_stack = acc + kCtl + 6;
     sh.budget = 2048;
+    sh.bmoff = g->bmoff;
+    sh.bmpool = g->bmpool;
+    sh.dense_limit = g->dense_limit;
     if (const char *e = std::getenv("GMSX_BK_BUDGET")) {  // tuning knob: nodes a search may visit before it is re-split
         const long v = std::atol(e);
         if (v >= 16 && v <= (1l << 30)) sh.budget = unsigned(v);
     }
+    unsigned budget0 = sh.budget;  // round 0 (start vertices: build + first stretch of the search)
+    if (const char *e = std::getenv("GMSX_BK_BUDGET0")) {
+        const long v = std::atol(e);
+        if (v >= 16 && v <= (1l << 30)) budget0 = unsigned(v);
+    }
+    const unsigned budget_resume = sh.budget;
+    sh.budget = budget0;
     int cur = 0;
     sh.pool = pools[cur];
     sh.dir = dirs[cur];
@@ -557,6 +621,8 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     }
     // ---- rounds >= 1: resume the split searches until no record is left
     int rounds = 0;
+    Guard g_rslab;
+    size_t resume_cap = 0;
     while (true) {
         unsigned long long ctl[4] = {0, 0, 0, 0};  // pool_head, dir_count, max_stack
         GMSX_HIP(hipMemcpyAsync(ctl, sh.pool_head, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -575,12 +641,18 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         GMSX_HIP(hipMemsetAsync(sh.dir, 0xff, sh.dir_cap * 8, s));
         const unsigned long long slab_bytes = std::max<unsigned long long>(stack_w * 4ull, 16);
         if (slab_bytes > budget_bytes) return GMSX_ERR_DEVICE_MEM;
-        const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({int64_t(n_rec), int64_t(cu) * 16, int64_t(budget_bytes / slab_bytes)}));
-        uint32_t *slabs = nullptr;
-        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(waves) * slab_bytes));
-        hipLaunchKernelGGL(k_bk_resume, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, slabs, stack_w, acc, sh);
-        GMSX_HIP(hipStreamSynchronize(s));
-        GMSX_HIP(hipFree(slabs));
+        const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({int64_t(n_rec), int64_t(cu) * 24, int64_t(budget_bytes / slab_bytes)}));
+        // few records left: split sooner so that the idle waves get work (the tail rounds are latency-, not throughput-bound)
+        const int64_t full = int64_t(cu) * 24 * 2;
+        sh.budget = int64_t(n_rec) >= full ? budget_resume : unsigned(std::max<int64_t>(128, int64_t(budget_resume) * int64_t(n_rec) / full));
+        if (size_t(waves) * slab_bytes > resume_cap) {  // grow-only stack slabs, reused by every round
+            (void)hipFree(g_rslab.p);
+            g_rslab.p = nullptr;
+            resume_cap = size_t(waves) * slab_bytes;
+            GMSX_HIP(hipMalloc(&g_rslab.p, resume_cap));
+        }
+        hipLaunchKernelGGL(k_bk_resume, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue,
+                           static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
         ++launches;
         if (++rounds > 100000) return GMSX_ERR_KERNEL;
     }
