@@ -100,9 +100,13 @@ def main():
     import torch
     from gms_amd import capi, dist
 
-    rank, local_rank, world = dist.init_process_group()
+    # test hook for 1-GPU boxes: GMSX_SHARE_GPU=1 lets several ranks share cuda:0 (then over gloo, RCCL refuses duplicates)
+    share = os.environ.get("GMSX_SHARE_GPU") == "1"
+    rank, local_rank, world = dist.init_process_group(backend="gloo" if share else None)
     if world != args.gpus:
         log(rank, f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
+    if share:
+        local_rank %= max(torch.cuda.device_count(), 1)
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank}: cuda:{local_rank} does not exist ({torch.cuda.device_count()} devices visible)")
     torch.cuda.set_device(local_rank)
@@ -137,7 +141,7 @@ def main():
 
     def step():
         partial, st = g.tc_partial(rank, world, algo, stats=True)
-        total = dist.allreduce_count(partial, dev)
+        total = dist.allreduce_count(partial, None if share else dev)
         return total, st
 
     for _ in range(args.warmup):
@@ -152,7 +156,7 @@ def main():
         totals.append(total)
     dist.barrier()
     torch.cuda.synchronize()
-    elapsed = dist.allreduce_max(time.perf_counter() - t0, dev)
+    elapsed = dist.allreduce_max(time.perf_counter() - t0, None if share else dev)
 
     assert len(set(totals)) == 1 and totals[0] % divisor == 0, totals
     triangles = totals[0] // divisor
@@ -168,7 +172,7 @@ def main():
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = m * args.steps / elapsed
-    avg_kernel_ms = dist.allreduce_max(sum(kernel_ms) / len(kernel_ms), dev)
+    avg_kernel_ms = dist.allreduce_max(sum(kernel_ms) / len(kernel_ms), None if share else dev)
     b_alg = 4 * elems + 8 * (n + 1) + 4 * nnz           # bytes the reference operator streams per pass
     per_launch_bytes = b_alg / world                     # one rank's launch covers 1/world of the cost-balanced work
     achieved = per_launch_bytes / (avg_kernel_ms * 1e-3) / 1e9
