@@ -28,6 +28,7 @@
 #include <memory>
 #include <new>
 #include <random>
+#include <sstream>
 #include <string>
 #include <utility>
 #include <vector>
@@ -374,6 +375,117 @@ static int read_el(const std::string &path, EdgeList &el) {
     return GMSX_OK;
 }
 
+// ---- the other text formats of the reference's Reader (gapbs/reader.h:58-218); weights are parsed and dropped, the
+// hot path is unweighted.  Every reader yields a 0-based edge list; symmetrisation / dedup happen in the builder.
+static int push_edge(std::vector<int32_t> &us, std::vector<int32_t> &vs, long long a, long long b) {
+    if (a < 0 || b < 0 || a > std::numeric_limits<int32_t>::max() || b > std::numeric_limits<int32_t>::max()) return GMSX_ERR_OVERFLOW;
+    us.push_back(int32_t(a));
+    vs.push_back(int32_t(b));
+    return GMSX_OK;
+}
+static int finish_el(std::vector<int32_t> &us, std::vector<int32_t> &vs, EdgeList &el) {
+    if (int rc = el.alloc(int64_t(us.size()))) return rc;
+    std::copy(us.begin(), us.end(), el.u.get());
+    std::copy(vs.begin(), vs.end(), el.v.get());
+    return GMSX_OK;
+}
+// .wel: "u v w" per line (reader.h:58-66)
+static int read_wel(const std::string &path, EdgeList &el) {
+    std::ifstream in(path);
+    if (!in.is_open()) return GMSX_ERR_IO;
+    std::vector<int32_t> us, vs;
+    long long a, b;
+    double w;
+    while (in >> a >> b >> w)
+        if (int rc = push_edge(us, vs, a, b)) return rc;
+    return finish_el(us, vs, el);
+}
+// .gr: DIMACS shortest-path format, lines "a u v w" with 1-based ids, everything else ignored (reader.h:68-84)
+static int read_gr(const std::string &path, EdgeList &el) {
+    std::ifstream in(path);
+    if (!in.is_open()) return GMSX_ERR_IO;
+    std::vector<int32_t> us, vs;
+    std::string line;
+    while (std::getline(in, line)) {
+        if (line.empty() || line[0] != 'a') continue;
+        long long a, b;
+        double w;
+        char tag;
+        std::istringstream ls(line);
+        if (!(ls >> tag >> a >> b >> w)) return GMSX_ERR_FORMAT;
+        if (int rc = push_edge(us, vs, a - 1, b - 1)) return rc;
+    }
+    return finish_el(us, vs, el);
+}
+// .graph: METIS — '%' comments, header "n m [fmt]", then one line per vertex listing its 1-based neighbours
+// (fmt 1: neighbour/weight pairs; fmt 0 or 100: plain) (reader.h:86-142)
+static int read_metis(const std::string &path, EdgeList &el) {
+    std::ifstream in(path);
+    if (!in.is_open()) return GMSX_ERR_IO;
+    std::string line;
+    long long n = -1, m = 0, fmt = 0;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line[0] == '%') continue;
+        std::istringstream hs(line);
+        if (!(hs >> n >> m)) return GMSX_ERR_FORMAT;
+        if (hs >> fmt) {
+            if (fmt != 0 && fmt != 1 && fmt != 100) return GMSX_ERR_FORMAT;  // reference: exit(-20)
+        }
+        break;
+    }
+    if (n < 0) return GMSX_ERR_FORMAT;
+    std::vector<int32_t> us, vs;
+    long long u = 0;
+    while (u < n && std::getline(in, line)) {
+        if (!line.empty() && line[0] == '%') continue;
+        std::istringstream ls(line);
+        long long v, w;
+        // Reference behaviour kept on purpose (reader.h:127-136 extract "v >> std::ws" as the loop condition): a
+        // neighbour that is the very last character of its line sets eofbit, the following ws extraction then fails,
+        // and that neighbour is NOT added.  Lines that end in whitespace load completely.  tests/test_loader.py pins
+        // both cases against the compiled reference.
+        if (fmt == 1) {
+            while (ls >> v >> w >> std::ws)
+                if (int rc = push_edge(us, vs, u, v - 1)) return rc;
+        } else {
+            while (ls >> v >> std::ws)
+                if (int rc = push_edge(us, vs, u, v - 1)) return rc;
+        }
+        ++u;
+    }
+    return finish_el(us, vs, el);
+}
+// .mtx: Matrix Market "matrix coordinate", pattern / real / double / integer, square; 1-based (reader.h:146-218)
+static int read_mtx(const std::string &path, EdgeList &el) {
+    std::ifstream in(path);
+    if (!in.is_open()) return GMSX_ERR_IO;
+    std::string start, object, format, field, symmetry, line;
+    if (!(in >> start >> object >> format >> field >> symmetry)) return GMSX_ERR_FORMAT;
+    if (start != "%%MatrixMarket" || object != "matrix" || format != "coordinate" || field == "complex") return GMSX_ERR_FORMAT;
+    const bool weights = field == "real" || field == "double" || field == "integer";
+    if (!weights && field != "pattern") return GMSX_ERR_FORMAT;
+    if (symmetry != "symmetric" && symmetry != "general" && symmetry != "skew-symmetric") return GMSX_ERR_FORMAT;
+    std::getline(in, line);  // rest of the banner line
+    long long rows = -1, cols = -1, nz = -1;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line[0] == '%') continue;
+        std::istringstream hs(line);
+        if (!(hs >> rows >> cols >> nz)) return GMSX_ERR_FORMAT;
+        break;
+    }
+    if (rows < 0 || rows != cols) return GMSX_ERR_FORMAT;  // reference: exit(-26)
+    std::vector<int32_t> us, vs;
+    while (std::getline(in, line)) {
+        std::istringstream ls(line);
+        long long a, b;
+        if (!(ls >> a >> b)) continue;
+        if (int rc = push_edge(us, vs, a - 1, b - 1)) return rc;
+        if (symmetry == "symmetric")  // mirrored even for a directed build, as the reference does
+            if (int rc = push_edge(us, vs, b - 1, a - 1)) return rc;
+    }
+    return finish_el(us, vs, el);
+}
+
 // .sg layout (writer.h:39-69): bool directed; int64 nnz; int64 n; int64 offsets[n+1]; int32 neigh[nnz]
 static int read_sg(const std::string &path, Csr &g) {
     std::FILE *f = std::fopen(path.c_str(), "rb");
@@ -473,10 +585,12 @@ int gmsx_csr_load(const char *path, int symmetrize, int relabel, gmsx_csr **out)
     Csr g;
     if (suf == ".sg") {
         if (int rc = read_sg(p, g)) return rc;
-    } else if (suf == ".el") {
+    } else if (suf == ".el" || suf == ".wel" || suf == ".gr" || suf == ".graph" || suf == ".mtx") {
         EdgeList el;
-        if (int rc = read_el(p, el)) return rc;
-        if (int rc = build_from_el(el, -1, symmetrize != 0, g)) return rc;
+        const int rc = suf == ".el" ? read_el(p, el) : suf == ".wel" ? read_wel(p, el) : suf == ".gr" ? read_gr(p, el)
+                     : suf == ".graph" ? read_metis(p, el) : read_mtx(p, el);
+        if (rc) return rc;
+        if (int rc2 = build_from_el(el, -1, symmetrize != 0, g)) return rc2;
     } else {
         return GMSX_ERR_FORMAT;
     }

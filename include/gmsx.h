@@ -77,8 +77,9 @@ int gmsx_csr_generate_rmat(int scale, int degree, double a, double b, double c, 
 int gmsx_csr_from_edges(int64_t num_nodes, int64_t num_edges, const int32_t *src, const int32_t *dst,
                         int symmetrize, int relabel, gmsx_csr **out);
 
-/* Reader::ReadFile / ReadSerializedGraph by suffix: ".el" (text pairs, reader.h:49-56) and ".sg"
- * (binary CSR, reader.h:252-305).  Other suffixes → GMSX_ERR_FORMAT. */
+/* Reader::ReadFile / ReadSerializedGraph by suffix (reader.h:220-250): ".el" text pairs (:49-56), ".wel" weighted pairs
+ * (:58-66, weights dropped), ".gr" DIMACS (:68-84), ".graph" METIS (:86-142), ".mtx" Matrix Market coordinate (:146-218),
+ * ".sg" binary CSR (:252-305).  Other suffixes → GMSX_ERR_FORMAT. */
 int gmsx_csr_load(const char *path, int symmetrize, int relabel, gmsx_csr **out);
 /* Writer::WriteSerializedGraph (writer.h:39-69). */
 int gmsx_csr_save_sg(const gmsx_csr *g, const char *path);

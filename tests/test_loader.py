@@ -132,3 +132,44 @@ def test_custom_rmat_skew(capi, tmp_path):
         O = bindings.Oracle()
         assert R.bk_count(g, 1, 0) == O.bk_count(off, ng) and R.tc_total(g, 0) == O.tc_total(off, ng)
         R.free(g)
+
+
+def test_other_text_formats(capi, tmp_path):
+    """The same small graph through every text format of the reference's Reader (gapbs/reader.h:49-218): identical CSR,
+    and identical to what the compiled reference loads from the same files (when present)."""
+    edges = [(0, 1), (1, 2), (2, 0), (2, 3), (5, 3), (4, 4)]
+    (tmp_path / "g.el").write_text("".join(f"{a} {b}\n" for a, b in edges))
+    (tmp_path / "g.wel").write_text("".join(f"{a} {b} {7 + i}\n" for i, (a, b) in enumerate(edges)))
+    (tmp_path / "g.gr").write_text("c comment\np sp 6 6\n" + "".join(f"a {a + 1} {b + 1} 3\n" for a, b in edges))
+    adj = {i: [] for i in range(6)}
+    for a, b in edges:
+        adj[a].append(b + 1)
+    # METIS rows end in a blank here; "q.graph" has none, which the reference's reader answers by dropping the last
+    # neighbour of every row (reader.h:127-136) -- kept, see loader.cpp
+    (tmp_path / "g.graph").write_text("% metis\n6 6\n" + "".join("".join(f"{v} " for v in adj[i]) + "\n" for i in range(6)))
+    (tmp_path / "q.graph").write_text("% metis\n6 6\n" + "".join(" ".join(map(str, adj[i])) + "\n" for i in range(6)))
+    (tmp_path / "g.mtx").write_text("%%MatrixMarket matrix coordinate pattern general\n% c\n6 6 6\n" + "".join(f"{a + 1} {b + 1}\n" for a, b in edges))
+    (tmp_path / "w.mtx").write_text("%%MatrixMarket matrix coordinate real symmetric\n6 6 6\n" + "".join(f"{a + 1} {b + 1} 0.5\n" for a, b in edges))
+    base = capi.HostCSR.load(str(tmp_path / "g.el"), relabel=capi.RELABEL_NEVER)
+    assert base.num_nodes == 6 and base.num_edges == 5  # the self loop 4-4 is dropped, vertex 4 stays isolated
+    for name in ("g.wel", "g.gr", "g.graph", "g.mtx", "w.mtx"):
+        got = capi.HostCSR.load(str(tmp_path / name), relabel=capi.RELABEL_NEVER)
+        assert got.fingerprint() == base.fingerprint(), name
+    quirk = capi.HostCSR.load(str(tmp_path / "q.graph"), relabel=capi.RELABEL_NEVER)
+    assert quirk.offsets().tolist() == [0, 1, 1, 2] and quirk.neighbors().tolist() == [2, 0]
+    (tmp_path / "bad.mtx").write_text("%%MatrixMarket matrix array real general\n2 2\n1\n")
+    with pytest.raises(capi.GmsxError) as ei:
+        capi.HostCSR.load(str(tmp_path / "bad.mtx"))
+    assert ei.value.status == capi.ERR_FORMAT
+    from oracle import bindings
+    if bindings.have_ref():
+        R = bindings.Reference()
+        for name in ("g.el", "g.gr", "g.graph", "g.mtx"):
+            g = R.load_file(str(tmp_path / name), relabel=False)
+            off, ng = R.csr(g)
+            assert np.array_equal(off, base.offsets()) and np.array_equal(ng, base.neighbors()), name
+            R.free(g)
+        g = R.load_file(str(tmp_path / "q.graph"), relabel=False)
+        off, ng = R.csr(g)
+        assert np.array_equal(off, quirk.offsets()) and np.array_equal(ng, quirk.neighbors())
+        R.free(g)
