@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 namespace gmsx {
 
@@ -39,7 +40,7 @@ __device__ __forceinline__ int64_t readlane64(int64_t x, int l) {
 // ---- hub side: 65536-bit bitmap in LDS ---------------------------------------------------------------
 __device__ __forceinline__ uint32_t bit_lo(const uint32_t *bm, uint32_t p) {  // id = p & 0xffff
     const uint32_t word = bm[(p >> 5) & 0x7ffu];
-    return __builtin_amdgcn_ubfe(word, p & 31u, 1u);
+    return __builtin_amdgcn_ubfe(word, p, 1u);  // v_bfe_u32 uses offset[4:0] only: no "& 31" needed
 }
 __device__ __forceinline__ uint32_t bit_hi(const uint32_t *bm, uint32_t p) {  // id = p >> 16
     const uint32_t q = p >> 16;
@@ -54,8 +55,14 @@ __device__ __forceinline__ uint32_t hub_hits8(const uint32_t *bm, u4u p) {
 // Streams the hub containers of `rows` rows against the LDS bitmap.  Lane l holds the extent (rb, rl) of row l
 // (rl = padded, even entry count, or -(words) with rb = word offset into bmpool for a dense row; lanes >= rows hold 0).  The wave works as four 16-lane groups, each streaming
 // its own row: 16 lanes x 8 ids per step, two steps (two 16-byte loads per lane) in flight.
+__device__ int g_dbg;
+__device__ __forceinline__ uint32_t hub_hits4(const uint32_t *bm, u4u p) {
+    return bit_lo(bm, p.x) + bit_hi(bm, p.x) + bit_lo(bm, p.y) + bit_hi(bm, p.y);
+}
 __device__ __forceinline__ uint32_t scan_hub_rows(const uint32_t *bm, const uint16_t *__restrict__ hadj,
                                                   const uint32_t *__restrict__ bmpool, int64_t rb, int rl, int rows, int lane) {
+    const int dbg = g_dbg;
+    if (dbg & 2) rb &= 0x3FFFF;
     const int grp = lane >> 4, sub8 = (lane & 15) * 8;
     uint32_t cnt = 0;
     for (int r0 = 0; r0 < rows; r0 += 4) {
@@ -82,8 +89,9 @@ __device__ __forceinline__ uint32_t scan_hub_rows(const uint32_t *bm, const uint
         for (; j + 128 + 8 <= l; j += 256) {  // two full 128-id group steps
             const u4u p = *reinterpret_cast<const u4u *>(row + j);
             const u4u q = *reinterpret_cast<const u4u *>(row + j + 128);
+            if (dbg & 1) { cnt += hub_hits4(bm, p); cnt += hub_hits4(bm, q); } else {
             cnt += hub_hits8(bm, p);
-            cnt += hub_hits8(bm, q);
+            cnt += hub_hits8(bm, q); }
         }
         for (; j < l; j += 128) {  // remaining steps; the last may be partial (l - j in {2,4,6}: whole dwords)
             u4u p = *reinterpret_cast<const u4u *>(row + j);
@@ -130,7 +138,7 @@ __device__ __forceinline__ uint32_t set_contains(const int32_t *tbl, uint32_t ma
     }
 }
 // tail containers are a few percent of the streamed ids: plain 64-lane row streaming
-__device__ __forceinline__ uint32_t scan_tail_rows(const int32_t *tbl, uint32_t mask, int shift, const int32_t *__restrict__ tadj,
+__device__ __forceinline__ uint32_t scan_tail_rows_serial(const int32_t *tbl, uint32_t mask, int shift, const int32_t *__restrict__ tadj,
                                                    int64_t rb, int rl, int rows, int lane) {
     uint32_t cnt = 0;
     for (int r = 0; r < rows; ++r) {
@@ -138,6 +146,86 @@ __device__ __forceinline__ uint32_t scan_tail_rows(const int32_t *tbl, uint32_t 
         if (l == 0) continue;
         const int64_t b = readlane64(rb, r);
         for (int j = lane; j < l; j += 64) cnt += set_contains(tbl, mask, shift, tadj[b + j]);
+    }
+    return cnt;
+}
+// Tail containers (32-bit ids) against the LDS hash set.  Same shape as scan_hub_rows: four 16-lane groups, each on
+// its own row, four ids per lane per 16-byte load, two loads in flight -- so a trip costs one memory round trip for
+// four rows instead of one per row (tail rows are short: ~50 ids).
+__device__ __forceinline__ uint32_t tail_hits4(const int32_t *tbl, uint32_t mask, int shift, u4u p) {
+    return set_contains(tbl, mask, shift, int32_t(p.x)) + set_contains(tbl, mask, shift, int32_t(p.y)) +
+           set_contains(tbl, mask, shift, int32_t(p.z)) + set_contains(tbl, mask, shift, int32_t(p.w));
+}
+__device__ __forceinline__ u4u tail_load4(const int32_t *row, int j, int l) {
+    u4u p = *reinterpret_cast<const u4u *>(row + j);
+    const int valid = l - j;  // >= 1; ids beyond the row become -2: never a key, never the empty marker
+    if (valid < 4) {
+        p.w = 0xfffffffeu;
+        if (valid < 3) p.z = 0xfffffffeu;
+        if (valid < 2) p.y = 0xfffffffeu;
+    }
+    return p;
+}
+__device__ __forceinline__ uint32_t scan_tail_rows(const int32_t *tbl, uint32_t mask, int shift, const int32_t *__restrict__ tadj,
+                                                   int64_t rb, int rl, int rows, int lane) {
+    if (g_dbg & 16) return scan_tail_rows_serial(tbl, mask, shift, tadj, rb, rl, rows, lane);
+    const int grp = lane >> 4, sub4 = (lane & 15) * 4;
+    uint32_t cnt = 0;
+    for (int r0 = 0; r0 < rows; r0 += 4) {
+        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
+        const int l0 = __builtin_amdgcn_readlane(rl, m0), l1 = __builtin_amdgcn_readlane(rl, m1),
+                  l2 = __builtin_amdgcn_readlane(rl, m2), l3 = __builtin_amdgcn_readlane(rl, m3);
+        if ((l0 | l1 | l2 | l3) == 0) continue;  // wave-uniform
+        const int64_t b0 = readlane64(rb, m0), b1 = readlane64(rb, m1), b2 = readlane64(rb, m2), b3 = readlane64(rb, m3);
+        const int64_t b = grp == 0 ? b0 : grp == 1 ? b1 : grp == 2 ? b2 : b3;
+        const int l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
+        const int32_t *row = tadj + b;
+        int j = sub4;
+        for (; j + 64 < l; j += 128) {  // both loads have at least one valid id
+            const u4u p = tail_load4(row, j, l);
+            const u4u q = tail_load4(row, j + 64, l);
+            cnt += tail_hits4(tbl, mask, shift, p);
+            cnt += tail_hits4(tbl, mask, shift, q);
+        }
+        if (j < l) cnt += tail_hits4(tbl, mask, shift, tail_load4(row, j, l));
+    }
+    return cnt;
+}
+
+// Bucketed tail set for the light-pivot kernel (<= 63 keys): 64 buckets x 4 slots, 16-byte aligned, so a probe is ONE
+// ds_read_b128 and four compares -- no probe loop, no divergence, and the four probes of a 16-byte load are
+// independent.  A pivot whose keys overflow a bucket (five keys with the same hash) falls back to the open-addressing
+// table above, built in the same 1 KB.
+__device__ __forceinline__ uint32_t bucket_of(int32_t w) { return (uint32_t(w) ^ (uint32_t(w) >> 6)) & 63u; }
+__device__ __forceinline__ uint32_t bucket_contains(const int32_t *tbl, int32_t w) {
+    const int4 b = *reinterpret_cast<const int4 *>(tbl + bucket_of(w) * 4);
+    return uint32_t((b.x == w) | (b.y == w) | (b.z == w) | (b.w == w));
+}
+__device__ __forceinline__ uint32_t bucket_hits4(const int32_t *tbl, u4u p) {
+    return bucket_contains(tbl, int32_t(p.x)) + bucket_contains(tbl, int32_t(p.y)) + bucket_contains(tbl, int32_t(p.z)) +
+           bucket_contains(tbl, int32_t(p.w));
+}
+__device__ __forceinline__ uint32_t scan_tail_rows_bucket(const int32_t *tbl, const int32_t *__restrict__ tadj, int64_t rb, int rl, int rows,
+                                                          int lane) {
+    const int grp = lane >> 4, sub4 = (lane & 15) * 4;
+    uint32_t cnt = 0;
+    for (int r0 = 0; r0 < rows; r0 += 4) {
+        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
+        const int l0 = __builtin_amdgcn_readlane(rl, m0), l1 = __builtin_amdgcn_readlane(rl, m1),
+                  l2 = __builtin_amdgcn_readlane(rl, m2), l3 = __builtin_amdgcn_readlane(rl, m3);
+        if ((l0 | l1 | l2 | l3) == 0) continue;  // wave-uniform
+        const int64_t b0 = readlane64(rb, m0), b1 = readlane64(rb, m1), b2 = readlane64(rb, m2), b3 = readlane64(rb, m3);
+        const int64_t b = grp == 0 ? b0 : grp == 1 ? b1 : grp == 2 ? b2 : b3;
+        const int l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
+        const int32_t *row = tadj + b;
+        int j = sub4;
+        for (; j + 64 < l; j += 128) {
+            const u4u p = tail_load4(row, j, l);
+            const u4u q = tail_load4(row, j + 64, l);
+            cnt += bucket_hits4(tbl, p);
+            cnt += bucket_hits4(tbl, q);
+        }
+        if (j < l) cnt += bucket_hits4(tbl, tail_load4(row, j, l));
     }
     return cnt;
 }
@@ -330,11 +418,13 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
     constexpr int LOG = 8, SIZE = 1 << LOG, SHIFT = 32 - LOG;
     constexpr uint32_t MASK = SIZE - 1;
     __shared__ __attribute__((aligned(16))) uint32_t bm_all[4 * kBitmapWords];
-    __shared__ int32_t tbl_all[4 * SIZE];
+    __shared__ __attribute__((aligned(16))) int32_t tbl_all[4 * SIZE];
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ uint32_t fill_all[4 * 64];
     uint32_t *bm = bm_all + wave * kBitmapWords;
     int32_t *tbl = tbl_all + wave * SIZE;
+    uint32_t *fill = fill_all + wave * 64;
     for (int i = lane; i < kBitmapWords; i += 64) bm[i] = 0;
     const int64_t step = int64_t(gridDim.x) * 4 * nparts;
     unsigned long long cnt = 0;
@@ -383,18 +473,36 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
             int64_t trb = 0, thb = 0;
             int trl = 0, thl = 0;
             for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
+            fill[lane] = 0;
             __builtin_amdgcn_wave_barrier();
+            int32_t v = -1;
+            uint32_t slot = 0;
             if (lane < tl) {
-                const int32_t v = tadj[tb + lane];
-                set_insert(tbl, MASK, SHIFT, v);
+                v = tadj[tb + lane];
+                slot = atomicAdd(&fill[bucket_of(v)], 1u);
+                if (slot < 4) tbl[bucket_of(v) * 4 + slot] = v;
+            }
+            const bool bucketed = (g_dbg & 16) ? false : __ballot(slot >= 4) == 0;
+            if (!bucketed) {  // rare: some bucket took a fifth key; rebuild as an open-addressing table
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < tl) set_insert(tbl, MASK, SHIFT, v);
+            }
+            if (lane < tl) {
                 thb = hoff[v];
                 thl = int(hoff[v + 1] - thb);
-                trb = toff[v];
-                trl = int(toff[v + 1] - trb);
+                if (lane > 0 || (g_dbg & 4096)) {  // the first tail member's tail ids are all below every tail id of the pivot: no match possible
+                    trb = toff[v];
+                    trl = int(toff[v + 1] - trb);
+                }
             }
             __builtin_amdgcn_wave_barrier();
             uint32_t c = scan_hub_rows(bm, hadj, bmpool, thb, thl, tl, lane);
-            c += scan_tail_rows(tbl, MASK, SHIFT, tadj, trb, trl, tl, lane);
+            if (bucketed)
+                c += scan_tail_rows_bucket(tbl, tadj, trb, trl, tl, lane);
+            else
+                c += scan_tail_rows(tbl, MASK, SHIFT, tadj, trb, trl, tl, lane);
             cnt += c;
             __builtin_amdgcn_wave_barrier();
             if (hv != 0xFFFFu) bm[hv >> 5] = 0;  // every bit in this wave's bitmap belongs to this pivot
@@ -461,10 +569,12 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     GMSX_HIP(hipEventRecord(c.ev[1], s));
 
     int launches = 0;
+    const int dbg = getenv("GMSX_DBG") ? atoi(getenv("GMSX_DBG")) : 0;
+    GMSX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &dbg, sizeof(int)));
     const int64_t cap_blocks = int64_t(c.compute_units > 0 ? c.compute_units : 256) * 16;
     {
         const int64_t cnt = part_count(0, n_block, nparts, part);
-        if (cnt > 0) {
+        if (cnt > 0 && !(dbg & 256)) {
             hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit, g->toff, g->tadj, g->order,
                                int64_t(0), n_block, nparts, part, acc);
             ++launches;
@@ -472,9 +582,9 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     }
     {
         const int64_t cnt = part_count(n_block, n_work, nparts, part);
-        if (cnt > 0) {
+        if (cnt > 0 && !(dbg & 8)) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
-            hipLaunchKernelGGL(k_tc_wave_hub, dim3(unsigned(std::min<int64_t>((cnt + 3) / 4, cap_blocks * 2))), dim3(256), 0, s, g->hoff,
+            if (!(dbg & 256)) hipLaunchKernelGGL(k_tc_wave_hub, dim3(unsigned(std::min<int64_t>((cnt + 3) / 4, cap_blocks * 2))), dim3(256), 0, s, g->hoff,
                                g->hadj, g->bmoff, g->bmpool, g->dense_limit, g->order, n_block, n_work, nparts, part, acc);
             hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit,
                                g->toff, g->tadj, g->order, n_block, n_work, nparts, part, acc);
