@@ -21,7 +21,6 @@
 
 #include <algorithm>
 #include <cstdio>
-#include <cstdlib>
 
 namespace gmsx {
 
@@ -55,14 +54,9 @@ __device__ __forceinline__ uint32_t hub_hits8(const uint32_t *bm, u4u p) {
 // Streams the hub containers of `rows` rows against the LDS bitmap.  Lane l holds the extent (rb, rl) of row l
 // (rl = padded, even entry count, or -(words) with rb = word offset into bmpool for a dense row; lanes >= rows hold 0).  The wave works as four 16-lane groups, each streaming
 // its own row: 16 lanes x 8 ids per step, two steps (two 16-byte loads per lane) in flight.
-__device__ int g_dbg;
-__device__ __forceinline__ uint32_t hub_hits4(const uint32_t *bm, u4u p) {
-    return bit_lo(bm, p.x) + bit_hi(bm, p.x) + bit_lo(bm, p.y) + bit_hi(bm, p.y);
-}
 __device__ __forceinline__ uint32_t scan_hub_rows(const uint32_t *bm, const uint16_t *__restrict__ hadj,
                                                   const uint32_t *__restrict__ bmpool, int64_t rb, int rl, int rows, int lane) {
-    const int dbg = g_dbg;
-    if (dbg & 2) rb &= 0x3FFFF;
+
     const int grp = lane >> 4, sub8 = (lane & 15) * 8;
     uint32_t cnt = 0;
     for (int r0 = 0; r0 < rows; r0 += 4) {
@@ -89,9 +83,8 @@ __device__ __forceinline__ uint32_t scan_hub_rows(const uint32_t *bm, const uint
         for (; j + 128 + 8 <= l; j += 256) {  // two full 128-id group steps
             const u4u p = *reinterpret_cast<const u4u *>(row + j);
             const u4u q = *reinterpret_cast<const u4u *>(row + j + 128);
-            if (dbg & 1) { cnt += hub_hits4(bm, p); cnt += hub_hits4(bm, q); } else {
             cnt += hub_hits8(bm, p);
-            cnt += hub_hits8(bm, q); }
+            cnt += hub_hits8(bm, q);
         }
         for (; j < l; j += 128) {  // remaining steps; the last may be partial (l - j in {2,4,6}: whole dwords)
             u4u p = *reinterpret_cast<const u4u *>(row + j);
@@ -137,18 +130,6 @@ __device__ __forceinline__ uint32_t set_contains(const int32_t *tbl, uint32_t ma
         h = (h + 1) & mask;
     }
 }
-// tail containers are a few percent of the streamed ids: plain 64-lane row streaming
-__device__ __forceinline__ uint32_t scan_tail_rows_serial(const int32_t *tbl, uint32_t mask, int shift, const int32_t *__restrict__ tadj,
-                                                   int64_t rb, int rl, int rows, int lane) {
-    uint32_t cnt = 0;
-    for (int r = 0; r < rows; ++r) {
-        const int l = __builtin_amdgcn_readlane(rl, r);
-        if (l == 0) continue;
-        const int64_t b = readlane64(rb, r);
-        for (int j = lane; j < l; j += 64) cnt += set_contains(tbl, mask, shift, tadj[b + j]);
-    }
-    return cnt;
-}
 // Tail containers (32-bit ids) against the LDS hash set.  Same shape as scan_hub_rows: four 16-lane groups, each on
 // its own row, four ids per lane per 16-byte load, two loads in flight -- so a trip costs one memory round trip for
 // four rows instead of one per row (tail rows are short: ~50 ids).
@@ -168,7 +149,6 @@ __device__ __forceinline__ u4u tail_load4(const int32_t *row, int j, int l) {
 }
 __device__ __forceinline__ uint32_t scan_tail_rows(const int32_t *tbl, uint32_t mask, int shift, const int32_t *__restrict__ tadj,
                                                    int64_t rb, int rl, int rows, int lane) {
-    if (g_dbg & 16) return scan_tail_rows_serial(tbl, mask, shift, tadj, rb, rl, rows, lane);
     const int grp = lane >> 4, sub4 = (lane & 15) * 4;
     uint32_t cnt = 0;
     for (int r0 = 0; r0 < rows; r0 += 4) {
@@ -196,15 +176,21 @@ __device__ __forceinline__ uint32_t scan_tail_rows(const int32_t *tbl, uint32_t 
 // ds_read_b128 and four compares -- no probe loop, no divergence, and the four probes of a 16-byte load are
 // independent.  A pivot whose keys overflow a bucket (five keys with the same hash) falls back to the open-addressing
 // table above, built in the same 1 KB.
-__device__ __forceinline__ uint32_t bucket_of(int32_t w) { return (uint32_t(w) ^ (uint32_t(w) >> 6)) & 63u; }
+template <int NB>
+__device__ __forceinline__ uint32_t bucket_of(int32_t w) {  // NB buckets (power of two)
+    return NB == 64 ? (uint32_t(w) ^ (uint32_t(w) >> 6)) & 63u : (uint32_t(w) ^ (uint32_t(w) >> 9)) & uint32_t(NB - 1);
+}
+template <int NB>
 __device__ __forceinline__ uint32_t bucket_contains(const int32_t *tbl, int32_t w) {
-    const int4 b = *reinterpret_cast<const int4 *>(tbl + bucket_of(w) * 4);
+    const int4 b = *reinterpret_cast<const int4 *>(tbl + bucket_of<NB>(w) * 4);
     return uint32_t((b.x == w) | (b.y == w) | (b.z == w) | (b.w == w));
 }
+template <int NB>
 __device__ __forceinline__ uint32_t bucket_hits4(const int32_t *tbl, u4u p) {
-    return bucket_contains(tbl, int32_t(p.x)) + bucket_contains(tbl, int32_t(p.y)) + bucket_contains(tbl, int32_t(p.z)) +
-           bucket_contains(tbl, int32_t(p.w));
+    return bucket_contains<NB>(tbl, int32_t(p.x)) + bucket_contains<NB>(tbl, int32_t(p.y)) + bucket_contains<NB>(tbl, int32_t(p.z)) +
+           bucket_contains<NB>(tbl, int32_t(p.w));
 }
+template <int NB>
 __device__ __forceinline__ uint32_t scan_tail_rows_bucket(const int32_t *tbl, const int32_t *__restrict__ tadj, int64_t rb, int rl, int rows,
                                                           int lane) {
     const int grp = lane >> 4, sub4 = (lane & 15) * 4;
@@ -222,10 +208,10 @@ __device__ __forceinline__ uint32_t scan_tail_rows_bucket(const int32_t *tbl, co
         for (; j + 64 < l; j += 128) {
             const u4u p = tail_load4(row, j, l);
             const u4u q = tail_load4(row, j + 64, l);
-            cnt += bucket_hits4(tbl, p);
-            cnt += bucket_hits4(tbl, q);
+            cnt += bucket_hits4<NB>(tbl, p);
+            cnt += bucket_hits4<NB>(tbl, q);
         }
-        if (j < l) cnt += bucket_hits4(tbl, tail_load4(row, j, l));
+        if (j < l) cnt += bucket_hits4<NB>(tbl, tail_load4(row, j, l));
     }
     return cnt;
 }
@@ -243,7 +229,7 @@ __global__ __launch_bounds__(256) void k_tc_block(const int64_t *__restrict__ ho
                                                   const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
                                                   int part, unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords];
-    __shared__ int32_t tbl[1 << kBlockLog];
+    __shared__ __attribute__((aligned(16))) int32_t tbl[1 << kBlockLog];
     __shared__ unsigned long long red[4];
     constexpr int SIZE = 1 << kBlockLog, SHIFT = 32 - kBlockLog, TILE = SIZE / 2;
     constexpr uint32_t MASK = SIZE - 1;
@@ -300,7 +286,7 @@ __global__ __launch_bounds__(256) void k_tc_block(const int64_t *__restrict__ ho
             const int idx = base + lane * 4 + wave;
             int64_t rb = 0;
             int rl = 0;
-            if (idx < tl) {
+            if (idx > 0 && idx < tl) {  // idx 0: the first tail member's tail ids lie below every tail id of the pivot
                 const int32_t v = tadj[tb + idx];
                 rb = toff[v];
                 rl = int(toff[v + 1] - rb);
@@ -405,10 +391,12 @@ __global__ __launch_bounds__(256) void k_tc_wave_hub(const int64_t *__restrict__
 
 // ---------------------------------------------------------------------------------------------
 // Light pivots (2 <= d+ < 64), part 2 of 2: the rows of the TAIL members (rank ids >= kHub).  Each of the 4 waves of a
-// workgroup owns a private bitmap (8 KB) and a 256-entry tail set and walks its pivots with a grid stride; pivots
-// without tail members are skipped.  The bitmap is cleared once; each pivot sets its bits and clears exactly those
-// words again.  The order[] -> offsets dependent loads of the NEXT TWO pivots are issued before the current one is
-// processed (two-stage software pipeline), so skipping and processing do not pay that latency chain per pivot.
+// workgroup owns a private bitmap (8 KB) and a 64 x 4 bucket set for the tail part and walks its pivots with a grid
+// stride; pivots without tail members are skipped.  The bitmap is cleared once; each pivot sets its bits and clears
+// exactly those words again.
+// The dependent loads  order[] -> offsets -> member ids -> row extents  form a four-deep software pipeline over the
+// pivots of the wave: while pivot D is scanned, the members and row extents of pivot C, the offsets of B and the id
+// of A are in flight, so a pivot pays only the round trips of its own row scans.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                  const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool, int32_t dense_limit,
@@ -419,37 +407,67 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
     constexpr uint32_t MASK = SIZE - 1;
     __shared__ __attribute__((aligned(16))) uint32_t bm_all[4 * kBitmapWords];
     __shared__ __attribute__((aligned(16))) int32_t tbl_all[4 * SIZE];
+    __shared__ uint32_t fill_all[4 * 64];
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ uint32_t fill_all[4 * 64];
     uint32_t *bm = bm_all + wave * kBitmapWords;
     int32_t *tbl = tbl_all + wave * SIZE;
     uint32_t *fill = fill_all + wave * 64;
     for (int i = lane; i < kBitmapWords; i += 64) bm[i] = 0;
     const int64_t step = int64_t(gridDim.x) * 4 * nparts;
+    const int64_t pos0 = first + (int64_t(blockIdx.x) * 4 + wave) * nparts + part;
     unsigned long long cnt = 0;
-    // pipeline registers: C = pivot being processed (offsets known), B = next (offsets in flight), A = after next (id in flight)
-    int64_t posC = first + (int64_t(blockIdx.x) * 4 + wave) * nparts + part;
+
+    // stage B/C: offsets of the pivots one and two steps ahead of C; stage A: the id three steps ahead
     int64_t hbC = 0, tbC = 0, hbB = 0, tbB = 0;
     int hlC = 0, tlC = 0, hlB = 0, tlB = 0;
     int32_t uA = -1;
-    if (posC < end) {
-        const int32_t u = order[posC];
-        hbC = hoff[u];
-        hlC = int(hoff[u + 1] - hbC);
-        tbC = toff[u];
-        tlC = int(toff[u + 1] - tbC);
+    // stage D: the pivot being scanned -- member ids and the extents of both containers of every tail member
+    int tlD = 0;
+    uint32_t hvD = 0xFFFFu;
+    int32_t vD = -1;
+    int64_t thbD = 0, trbD = 0;
+    int thlD = 0, trlD = 0;
+    {  // prologue
+        int64_t hb0 = 0, tb0 = 0;
+        int hl0 = 0;
+        if (pos0 < end) {
+            const int32_t u = order[pos0];
+            hb0 = hoff[u];
+            hl0 = int(hoff[u + 1] - hb0);
+            tb0 = toff[u];
+            tlD = int(toff[u + 1] - tb0);
+        }
+        if (pos0 + step < end) {
+            const int32_t u = order[pos0 + step];
+            hbC = hoff[u];
+            hlC = int(hoff[u + 1] - hbC);
+            tbC = toff[u];
+            tlC = int(toff[u + 1] - tbC);
+        }
+        if (pos0 + 2 * step < end) {
+            const int32_t u = order[pos0 + 2 * step];
+            hbB = hoff[u];
+            hlB = int(hoff[u + 1] - hbB);
+            tbB = toff[u];
+            tlB = int(toff[u + 1] - tbB);
+        }
+        if (pos0 + 3 * step < end) uA = order[pos0 + 3 * step];
+        if (tlD > 0) {
+            if (lane < hl0) hvD = hadj[hb0 + lane];
+            if (lane < tlD) {
+                vD = tadj[tb0 + lane];
+                thbD = hoff[vD];
+                thlD = int(hoff[vD + 1] - thbD);
+                if (lane > 0) {
+                    trbD = toff[vD];
+                    trlD = int(toff[vD + 1] - trbD);
+                }
+            }
+        }
     }
-    if (posC + step < end) {
-        const int32_t u = order[posC + step];
-        hbB = hoff[u];
-        hlB = int(hoff[u + 1] - hbB);
-        tbB = toff[u];
-        tlB = int(toff[u + 1] - tbB);
-    }
-    if (posC + 2 * step < end) uA = order[posC + 2 * step];
-    for (; posC < end; posC += step) {  // uniform per wave
-        // issue the loads of the two later pivots first; they complete while this one is processed
+    for (int64_t pos = pos0; pos < end; pos += step) {  // uniform per wave
+        // loads of the later stages first; they complete while D is scanned
         int64_t hbN = 0, tbN = 0;
         int hlN = 0, tlN = 0;
         if (uA >= 0) {
@@ -458,55 +476,59 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
             tbN = toff[uA];
             tlN = int(toff[uA + 1] - tbN);
         }
-        const int32_t uN = (posC + 3 * step < end) ? order[posC + 3 * step] : -1;
-        const int64_t hb = hbC, tb = tbC;
-        const int hl = hlC, tl = tlC;
-        if (tl > 0) {
+        const int32_t uN = (pos + 4 * step < end) ? order[pos + 4 * step] : -1;
+        uint32_t hvC = 0xFFFFu;
+        int32_t vC = -1;
+        if (tlC > 0) {
+            if (lane < hlC) hvC = hadj[hbC + lane];
+            if (lane < tlC) vC = tadj[tbC + lane];
+        }
+        uint32_t c = 0;
+        bool bucketed = true;
+        if (tlD > 0) {
             __builtin_amdgcn_wave_barrier();
             // hub members: only their bits are needed here (their rows were counted by k_tc_wave_hub)
-            uint32_t hv = 0xFFFFu;
-            if (lane < hl) {
-                hv = hadj[hb + lane];
-                if (hv != 0xFFFFu) atomicOr(&bm[hv >> 5], 1u << (hv & 31u));
-            }
-            // tail members: hash set + extents of both containers of every tail row
-            int64_t trb = 0, thb = 0;
-            int trl = 0, thl = 0;
+            if (hvD != 0xFFFFu) atomicOr(&bm[hvD >> 5], 1u << (hvD & 31u));
             for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
             fill[lane] = 0;
             __builtin_amdgcn_wave_barrier();
-            int32_t v = -1;
             uint32_t slot = 0;
-            if (lane < tl) {
-                v = tadj[tb + lane];
-                slot = atomicAdd(&fill[bucket_of(v)], 1u);
-                if (slot < 4) tbl[bucket_of(v) * 4 + slot] = v;
+            if (vD >= 0) {
+                slot = atomicAdd(&fill[bucket_of<64>(vD)], 1u);
+                if (slot < 4) tbl[bucket_of<64>(vD) * 4 + slot] = vD;
             }
-            const bool bucketed = (g_dbg & 16) ? false : __ballot(slot >= 4) == 0;
+            bucketed = __ballot(slot >= 4) == 0;
             if (!bucketed) {  // rare: some bucket took a fifth key; rebuild as an open-addressing table
                 __builtin_amdgcn_wave_barrier();
                 for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
                 __builtin_amdgcn_wave_barrier();
-                if (lane < tl) set_insert(tbl, MASK, SHIFT, v);
-            }
-            if (lane < tl) {
-                thb = hoff[v];
-                thl = int(hoff[v + 1] - thb);
-                if (lane > 0 || (g_dbg & 4096)) {  // the first tail member's tail ids are all below every tail id of the pivot: no match possible
-                    trb = toff[v];
-                    trl = int(toff[v + 1] - trb);
-                }
+                if (vD >= 0) set_insert(tbl, MASK, SHIFT, vD);
             }
             __builtin_amdgcn_wave_barrier();
-            uint32_t c = scan_hub_rows(bm, hadj, bmpool, thb, thl, tl, lane);
+            c = scan_hub_rows(bm, hadj, bmpool, thbD, thlD, tlD, lane);
+        }
+        // stage C's member ids have arrived by now: issue the loads of its row extents
+        int64_t thbC = 0, trbC = 0;
+        int thlC = 0, trlC = 0;
+        if (vC >= 0) {
+            thbC = hoff[vC];
+            thlC = int(hoff[vC + 1] - thbC);
+            if (lane > 0) {  // the first tail member's tail ids are all below every tail id of the pivot: no match possible
+                trbC = toff[vC];
+                trlC = int(toff[vC + 1] - trbC);
+            }
+        }
+        if (tlD > 0) {
             if (bucketed)
-                c += scan_tail_rows_bucket(tbl, tadj, trb, trl, tl, lane);
+                c += scan_tail_rows_bucket<64>(tbl, tadj, trbD, trlD, tlD, lane);
             else
-                c += scan_tail_rows(tbl, MASK, SHIFT, tadj, trb, trl, tl, lane);
+                c += scan_tail_rows(tbl, MASK, SHIFT, tadj, trbD, trlD, tlD, lane);
             cnt += c;
             __builtin_amdgcn_wave_barrier();
-            if (hv != 0xFFFFu) bm[hv >> 5] = 0;  // every bit in this wave's bitmap belongs to this pivot
+            if (hvD != 0xFFFFu) bm[hvD >> 5] = 0;  // every bit in this wave's bitmap belongs to this pivot
         }
+        tlD = tlC; hvD = hvC; vD = vC;
+        thbD = thbC; thlD = thlC; trbD = trbC; trlD = trlC;
         hbC = hbB; hlC = hlB; tbC = tbB; tlC = tlB;
         hbB = hbN; hlB = hlN; tbB = tbN; tlB = tlN;
         uA = uN;
@@ -569,12 +591,10 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     GMSX_HIP(hipEventRecord(c.ev[1], s));
 
     int launches = 0;
-    const int dbg = getenv("GMSX_DBG") ? atoi(getenv("GMSX_DBG")) : 0;
-    GMSX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &dbg, sizeof(int)));
     const int64_t cap_blocks = int64_t(c.compute_units > 0 ? c.compute_units : 256) * 16;
     {
         const int64_t cnt = part_count(0, n_block, nparts, part);
-        if (cnt > 0 && !(dbg & 256)) {
+        if (cnt > 0) {
             hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit, g->toff, g->tadj, g->order,
                                int64_t(0), n_block, nparts, part, acc);
             ++launches;
@@ -582,9 +602,9 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     }
     {
         const int64_t cnt = part_count(n_block, n_work, nparts, part);
-        if (cnt > 0 && !(dbg & 8)) {
+        if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
-            if (!(dbg & 256)) hipLaunchKernelGGL(k_tc_wave_hub, dim3(unsigned(std::min<int64_t>((cnt + 3) / 4, cap_blocks * 2))), dim3(256), 0, s, g->hoff,
+            hipLaunchKernelGGL(k_tc_wave_hub, dim3(unsigned(std::min<int64_t>((cnt + 3) / 4, cap_blocks * 2))), dim3(256), 0, s, g->hoff,
                                g->hadj, g->bmoff, g->bmpool, g->dense_limit, g->order, n_block, n_work, nparts, part, acc);
             hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit,
                                g->toff, g->tadj, g->order, n_block, n_work, nparts, part, acc);

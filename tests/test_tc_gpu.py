@@ -160,3 +160,21 @@ def test_tail_containers_and_tiling(gpu, oracle, hub_limit):
     g = gpu.DeviceGraph.from_csr(dense, flags=flags)
     assert g.tc_total() == k * (k - 1) * (k - 2) // 6
     g.free()
+
+
+def test_tail_bucket_overflow(gpu, oracle):
+    """Light pivots whose tail members all hash to one bucket of the 64 x 4 bucket set (ids 4096 apart): the kernel must
+    fall back to the open-addressing table and still count exactly.  A circulant graph keeps every degree equal, so
+    rank ids follow vertex ids and the collisions are by construction."""
+    n = 40000
+    offs = [4096 * j for j in range(1, 7)] + [1, 4097]
+    u = np.concatenate([np.arange(n, dtype=np.int64) for _ in offs])
+    v = np.concatenate([(np.arange(n, dtype=np.int64) + d) % n for d in offs])
+    csr = gpu.HostCSR.from_edges(u.astype(np.int32), v.astype(np.int32))
+    want = oracle.tc_total(csr.offsets(), csr.neighbors())
+    assert want > 0
+    for hub_limit in (1, 0):
+        g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_DEFAULT | (hub_limit << 8))
+        assert g.tc_total() == want, hub_limit
+        assert sum(g.tc_partial(p, 3) for p in range(3)) == want
+        g.free()
