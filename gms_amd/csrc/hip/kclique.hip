@@ -60,6 +60,80 @@ __device__ __forceinline__ void build_row(const int64_t *__restrict__ hoff, cons
     }
 }
 
+// ---- streamed build (workgroup kernels) ------------------------------------------------------------------------
+// Same row streaming as the triangle kernels (tc.hip): a wave works as four 16-lane groups, each on the row of one
+// pivot member, 16-byte loads, two in flight.  A streamed hub id is tested against the pivot bitmap `bm`; a hit becomes
+// the local index  pre[word] + popcount(bits below)  (the hub list is sorted, so rank = position) and sets one bit of
+// the member's adjacency row `orow` (LDS).  Hits are ~5-10 % of the stream: per load they are collected in a mask and
+// resolved in a short loop, so the probe path stays branch-free.
+struct __attribute__((packed, aligned(4))) kc_u4u { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ uint32_t kc_bit(const uint32_t *bm, uint32_t id) { return (bm[id >> 5] >> (id & 31u)) & 1u; }
+
+__device__ __forceinline__ void kc_set_hub_hit(const uint32_t *bm, const unsigned short *pre, uint32_t *orow, uint32_t id) {
+    const uint32_t word = bm[id >> 5];
+    const int idx = int(pre[id >> 5]) + __popc(word & ((1u << (id & 31u)) - 1u));
+    atomicOr(&orow[idx >> 5], 1u << (idx & 31));
+}
+
+__device__ __forceinline__ void kc_probe8(const uint32_t *bm, const unsigned short *pre, uint32_t *orow, kc_u4u p) {
+    uint32_t mask = kc_bit(bm, p.x & 0xffffu) | (kc_bit(bm, p.x >> 16) << 1) | (kc_bit(bm, p.y & 0xffffu) << 2) | (kc_bit(bm, p.y >> 16) << 3) |
+                    (kc_bit(bm, p.z & 0xffffu) << 4) | (kc_bit(bm, p.z >> 16) << 5) | (kc_bit(bm, p.w & 0xffffu) << 6) | (kc_bit(bm, p.w >> 16) << 7);
+    const unsigned long long lo = (unsigned long long)p.x | ((unsigned long long)p.y << 32), hi = (unsigned long long)p.z | ((unsigned long long)p.w << 32);
+    while (mask) {
+        const int s = __ffs(mask) - 1;
+        mask &= mask - 1;
+        const uint32_t id = uint32_t(((s & 4) ? hi : lo) >> ((s & 3) * 16)) & 0xffffu;
+        kc_set_hub_hit(bm, pre, orow, id);
+    }
+}
+
+__device__ __forceinline__ kc_u4u kc_load8(const uint16_t *row, int j, int l) {
+    kc_u4u p = *reinterpret_cast<const kc_u4u *>(row + j);
+    const int valid = l - j;  // even, >= 2; ids beyond the row become 0xFFFF, which is never in the bitmap
+    if (valid < 8) {
+        if (valid < 6) p.z = 0xffffffffu;
+        if (valid < 4) p.y = 0xffffffffu;
+        p.w = 0xffffffffu;
+    }
+    return p;
+}
+
+// 16-bit list container [row, row + l) (l even, padded with 0xFFFF) of one member; sub = lane within the 16-lane group
+__device__ __forceinline__ void kc_stream_list(const uint16_t *__restrict__ row, int l, int sub, const uint32_t *bm, const unsigned short *pre,
+                                               uint32_t *orow) {
+    int j = sub * 8;
+    for (; j + 128 < l; j += 256) {
+        const kc_u4u p = kc_load8(row, j, l);
+        const kc_u4u q = kc_load8(row, j + 128, l);
+        kc_probe8(bm, pre, orow, p);
+        kc_probe8(bm, pre, orow, q);
+    }
+    if (j < l) kc_probe8(bm, pre, orow, kc_load8(row, j, l));
+}
+
+__device__ __forceinline__ void kc_and_word(uint32_t x, uint32_t pivot_word, int k, const unsigned short *pre, uint32_t *orow) {
+    while (x) {
+        const int b = __ffs(x) - 1;
+        x &= x - 1;
+        const int idx = int(pre[k]) + __popc(pivot_word & ((1u << b) - 1u));
+        atomicOr(&orow[idx >> 5], 1u << (idx & 31));
+    }
+}
+
+// bitset container (nw words, multiple of 4) of one hub member: AND with the pivot bitmap, every surviving bit is a hit
+__device__ __forceinline__ void kc_stream_bitset(const uint32_t *__restrict__ brow, int nw, int sub, const uint32_t *bm, const unsigned short *pre,
+                                                 uint32_t *orow) {
+    for (int j = sub * 4; j < nw; j += 64) {
+        const uint4 p = *reinterpret_cast<const uint4 *>(brow + j);
+        const uint4 q = *reinterpret_cast<const uint4 *>(bm + j);
+        kc_and_word(p.x & q.x, q.x, j, pre, orow);
+        kc_and_word(p.y & q.y, q.y, j + 1, pre, orow);
+        kc_and_word(p.z & q.z, q.z, j + 2, pre, orow);
+        kc_and_word(p.w & q.w, q.w, j + 3, pre, orow);
+    }
+}
+
 // position of w in the ascending list [lst, lst+len), or -1
 __device__ __forceinline__ int sorted_find(const int32_t *__restrict__ lst, int len, int32_t w) {
     int lo = 0, hi = len;
@@ -70,56 +144,38 @@ __device__ __forceinline__ int sorted_find(const int32_t *__restrict__ lst, int 
     return (lo < len && lst[lo] == w) ? lo : -1;
 }
 
-// Local adjacency row of pivot-list member v against a pivot whose hub list (ascending, hc real entries) is
-// hub_list and whose tail list (ascending, tc entries) is tail_list.  Local index = position in [hub list | tail list].
-//  - v has a bitset container (dense hub row): every lane tests "is pivot member j in N+(v)" with one word load; the wave's
-//    ballot IS the row word, written without atomics.  (The stream-and-probe direction is inverted: d lookups instead of
-//    streaming v's row.)
-//  - otherwise v's list containers are streamed; a hub id is found through the pivot bitmap bm + prefix popcounts pre
-//    (rank = local index, because the hub list is sorted), a tail id by binary search in the pivot's tail list.
-__device__ __forceinline__ void build_row_sorted(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                 const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
-                                                 const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
-                                                 int32_t dense_limit, int32_t v, const uint16_t *__restrict__ hub_list, int hc,
-                                                 const int32_t *__restrict__ tail_list, int tc, const uint32_t *bm,
-                                                 const unsigned short *pre, uint32_t *row, int lane) {
-    if (v < dense_limit) {
-        const int64_t b0 = bmoff[v];
-        if (bmoff[v + 1] > b0) {
-            const uint32_t *bits = bmpool + b0;
-            for (int j0 = 0; j0 < hc; j0 += 64) {
-                const int j = j0 + lane;
-                bool hit = false;
-                if (j < hc) {
-                    const uint32_t w = hub_list[j];
-                    if (int32_t(w) < v) hit = (bits[w >> 5] >> (w & 31u)) & 1u;
-                }
-                const unsigned long long m = __ballot(hit);
-                if (lane == 0) row[j0 >> 5] = uint32_t(m);
-                if (lane == 1 && j0 + 32 < hc) row[(j0 >> 5) + 1] = uint32_t(m >> 32);
-            }
-            return;  // a hub vertex has no tail neighbours
+// 32-bit tail container [row, row + l) of one tail member against the pivot's ascending tail list (local index hc + position)
+__device__ __forceinline__ void kc_stream_tail(const int32_t *__restrict__ row, int l, int sub, const int32_t *__restrict__ tail_list, int tc, int hc,
+                                               uint32_t *orow) {
+    for (int j = sub; j < l; j += 16) {
+        const int t = sorted_find(tail_list, tc, row[j]);
+        if (t >= 0) {
+            const int idx = hc + t;
+            atomicOr(&orow[idx >> 5], 1u << (idx & 31));
         }
     }
-    const int64_t hb = hoff[v], he = hoff[v + 1];
-    for (int64_t j = hb + lane; j < he; j += 64) {
-        const uint32_t w = hadj[j];
-        if (w == 0xFFFFu) continue;
-        const uint32_t word = bm[w >> 5];
-        if ((word >> (w & 31u)) & 1u) {
-            const int idx = int(pre[w >> 5]) + __popc(word & ((1u << (w & 31u)) - 1u));
-            atomicOr(&row[idx >> 5], 1u << (idx & 31));
+}
+
+// Adjacency row of pivot member i (rank id v) into orow: the smaller of v's bitset / list hub containers, plus the tail
+// container when v is a tail vertex and the pivot has tail members.
+__device__ __forceinline__ void kc_build_member(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool, int32_t dense_limit,
+                                                int32_t v, bool is_hub, int hc, const int32_t *__restrict__ tail_list, int tc,
+                                                const uint32_t *bm, const unsigned short *pre, uint32_t *orow, int sub) {
+    const int64_t hb = hoff[v];
+    const int hl = int(hoff[v + 1] - hb);
+    if (is_hub && v < dense_limit) {
+        const int nw = int(bitset_words(v));
+        if (nw * 4 + 32 < hl * 2) {
+            kc_stream_bitset(bmpool + bmoff[v], nw, sub, bm, pre, orow);
+            return;
         }
     }
-    if (tc > 0) {
-        const int64_t tb = toff[v], te = toff[v + 1];
-        for (int64_t j = tb + lane; j < te; j += 64) {
-            const int t = sorted_find(tail_list, tc, tadj[j]);
-            if (t >= 0) {
-                const int idx = hc + t;
-                atomicOr(&row[idx >> 5], 1u << (idx & 31));
-            }
-        }
+    if (hc > 0) kc_stream_list(hadj + hb, hl, sub, bm, pre, orow);
+    if (!is_hub && tc > 0) {
+        const int64_t tb = toff[v];
+        kc_stream_tail(tadj + tb, int(toff[v + 1] - tb), sub, tail_list, tc, hc, orow);
     }
 }
 
@@ -202,7 +258,7 @@ __device__ __forceinline__ unsigned long long lane_enum(const uint32_t *rows, in
                 const int l = (t << 5) + __ffs(c) - 1;
                 c &= c - 1;
                 path.row[P] = rows + size_t(l) * WS;
-                s += lane_enum<R - 1, P + 1>(rows, WS, W, path);
+                s += lane_enum<R - 1, P + 1>(rows, WS, t + 1, path);  // the matrix is strictly lower triangular
             }
         }
     }
@@ -266,7 +322,7 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
 // ---------------------------------------------------------------------------------------------
 // M / L: workgroup per pivot.  W = words per bit row, WS = row stride.  GLOBAL_ROWS=false: bit-matrix in dynamic LDS
 // (d <= 1024); true: in a per-workgroup global slab (d up to 64*32*WPL), workgroups walk their pivots with a grid stride.
-// dynamic LDS layout: [rows: dmax*WS u32 (LDS variant only)] [bm: 2048 u32] [pre: 2048 u16]
+// dynamic LDS layout: [rows: dmax*WS u32 (LDS variant only)] [bm: 2048 u32] [pre: 2048 u16] [row stage: nwaves*4*W u32 (slab variant only)]
 // ---------------------------------------------------------------------------------------------
 template <int LV, int WPL, bool GLOBAL_ROWS>
 __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
@@ -300,7 +356,8 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         const int32_t *tail_list = tadj + tb;
         __syncthreads();  // previous pivot's counting is done
         for (int i = tid; i < kBitmapWords; i += nthreads) bm[i] = 0;
-        for (int i = tid; i < d * WS; i += nthreads) rows[i] = 0;
+        if (!GLOBAL_ROWS)
+            for (int i = tid; i < d * WS; i += nthreads) rows[i] = 0;  // the slab variant writes every row word at its flush
         __syncthreads();
         for (int i = tid; i < hc; i += nthreads) {
             const uint32_t w = hub_list[i];
@@ -328,12 +385,31 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                 }
             }
         }
-        if (GLOBAL_ROWS) __threadfence();
         __syncthreads();
-        for (int i = wave; i < d; i += nwaves) {
-            const int32_t v = i < hc ? int32_t(hub_list[i]) : tail_list[i - hc];
-            build_row_sorted(hoff, hadj, toff, tadj, bmoff, bmpool, dense_limit, v, hub_list, hc, tail_list, tc, bm, pre,
-                             rows + size_t(i) * WS, lane);
+        // four rows per wave and trip, one per 16-lane group; the global-slab variant builds them in an LDS stage and
+        // writes finished rows out with coalesced stores (no global atomics)
+        {
+            const int grp = lane >> 4, sub = lane & 15;
+            uint32_t *stage = GLOBAL_ROWS ? reinterpret_cast<uint32_t *>(pre + kBitmapWords) + size_t(wave) * 4 * W : nullptr;
+            for (int i0 = wave * 4; i0 < d; i0 += nwaves * 4) {
+                const int i = i0 + grp;
+                if (GLOBAL_ROWS) {
+                    for (int t = lane; t < 4 * W; t += 64) stage[t] = 0;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (i < d) {
+                    const bool is_hub = i < hc;
+                    const int32_t v = is_hub ? int32_t(hub_list[i]) : tail_list[i - hc];
+                    uint32_t *orow = GLOBAL_ROWS ? stage + grp * W : rows + size_t(i) * WS;
+                    kc_build_member(hoff, hadj, toff, tadj, bmoff, bmpool, dense_limit, v, is_hub, hc, tail_list, tc, bm, pre, orow, sub);
+                }
+                if (GLOBAL_ROWS) {
+                    __builtin_amdgcn_wave_barrier();
+                    const int nr = min(4, d - i0);
+                    for (int t = lane; t < nr * W; t += 64) rows[size_t(i0 + t / W) * WS + t % W] = stage[t];
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         }
         if (GLOBAL_ROWS) {
             __threadfence();
@@ -368,7 +444,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                     const int j = (w << 5) + __ffs(bits) - 1;
                     bits &= bits - 1;
                     path.row[1] = rows + size_t(j) * WS;
-                    cnt += lane_enum<LV - 1, 2>(rows, WS, W, path);
+                    cnt += lane_enum<LV - 1, 2>(rows, WS, w + 1, path);  // row j has no bits at or above j: words 0..w only
                 }
             }
         }
@@ -416,7 +492,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             uint32_t *slabs = nullptr;
             GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(blocks) * dmax * WS * sizeof(uint32_t)));
             *slab_out = slabs;
-            const size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2;
+            const size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(512 / 64) * 4 * W * 4;  // + row stage
             if (wide)
                 hipLaunchKernelGGL((k_kc_block<LV, 2, true>), dim3(unsigned(blocks)), dim3(512), lds, s, g->hoff, g->hadj, g->toff,
                                    g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, slabs, acc);
