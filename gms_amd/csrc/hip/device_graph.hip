@@ -409,7 +409,7 @@ int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out) {
     hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, g->n, g->sorted_dplus, threshold, reinterpret_cast<int64_t *>(g->scratch + 8));
     GMSX_HIP(hipMemcpyAsync(out, g->scratch + 8, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
-    if (g->ge_used < 16) {
+    if (g->ge_used < 40) {
         g->ge_thr[g->ge_used] = threshold;
         g->ge_cnt[g->ge_used] = *out;
         ++g->ge_used;

@@ -53,8 +53,8 @@ struct gmsx_graph {
     unsigned long long *scratch = nullptr;  // device: a few u64 accumulators
     unsigned long long *acc = nullptr;      // device: 64 spread u64 accumulators (128 B apart) + a few control words, reused by every call
     // host-side memo of read-only facts about the immutable graph (filled lazily; handles are single-threaded)
-    mutable int32_t ge_thr[16] = {0};
-    mutable int64_t ge_cnt[16] = {0};
+    mutable int32_t ge_thr[40] = {0};
+    mutable int64_t ge_cnt[40] = {0};
     mutable int ge_used = 0;
     mutable int stats_part = -1, stats_nparts = -1;  // shard whose TC bookkeeping (units, probes) is cached below
     mutable uint64_t stats_units = 0, stats_probes = 0;

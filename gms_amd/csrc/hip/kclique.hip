@@ -329,7 +329,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                                                    const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                    const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
                                                    int32_t dense_limit, const int32_t *__restrict__ order, int64_t first, int64_t end,
-                                                   int nparts, int part, int dmax, int W, int WS, uint32_t *__restrict__ slabs,
+                                                   int nparts, int part, int dmax, int W, int WS, int WT, uint32_t *__restrict__ slabs,
                                                    unsigned long long *__restrict__ acc) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ unsigned long long red[16];
@@ -418,7 +418,46 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         } else {
             __syncthreads();
         }
-        if constexpr (LV == 1) {
+        if constexpr (LV == 2 && GLOBAL_ROWS) {
+            // k = 4 on a slab matrix: Σ_i Σ_{j ∈ rows[i]} popc(rows[i] & rows[j]) by COLUMN TILES of WT words staged in LDS
+            // (d x (WT+1) words, over the dead bitmap / stage area): the pair bits (i, j) are read from the slab once
+            // per tile, the row words being ANDed come from LDS.  Row j has bits below j only, so the cell (i, w) —
+            // whose members j have j >> 5 == w — meets tile [t0, t0+WT) on words t0 .. min(t0+WT, w+1) - 1.
+            uint32_t *tile = smem;
+            const int TS = WT + 1;
+            const int Wd = (d + 31) >> 5;
+            const int qd = nthreads / Wd, rm = nthreads - qd * Wd;
+            for (int t0 = 0; t0 < Wd; t0 += WT) {
+                __syncthreads();
+                for (int x = tid; x < d * WT; x += nthreads) {
+                    const int i = x / WT, cw = x - i * WT;  // WT is a power of two
+                    tile[i * TS + cw] = t0 + cw < W ? rows[size_t(i) * WS + t0 + cw] : 0u;
+                }
+                __syncthreads();
+                int i = tid / Wd, w = tid - (tid / Wd) * Wd;
+                while (i < d) {
+                    if (w >= t0 && w <= (i >> 5)) {
+                        uint32_t bits = rows[size_t(i) * WS + w];
+                        const uint32_t *ti = tile + i * TS;
+                        const int nw = min(WT, w + 1 - t0);
+                        while (bits) {
+                            const int j = (w << 5) + __ffs(bits) - 1;
+                            bits &= bits - 1;
+                            const uint32_t *tj = tile + j * TS;
+                            uint32_t c = 0;
+                            for (int q = 0; q < nw; ++q) c += uint32_t(__popc(ti[q] & tj[q]));
+                            cnt += c;
+                        }
+                    }
+                    w += rm;
+                    i += qd;
+                    if (w >= Wd) {
+                        w -= Wd;
+                        ++i;
+                    }
+                }
+            }
+        } else if constexpr (LV == 1) {
             // k = 3: Σ_i popc(rows[i]) — one lane per matrix word
             for (int cell = tid; cell < d * W; cell += nthreads) cnt += (unsigned long long)__popc(rows[size_t(cell / W) * WS + cell % W]);
         } else if (LV >= 3 && W > 8) {
@@ -469,63 +508,82 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     const int k = LV + 2;
-    // positions in the d+-sorted order
-    int64_t ge[8];
-    const int32_t thr[8] = {4097, 2049, 1025, 513, 257, 129, 65, 33};
-    for (int i = 0; i < 8; ++i)
-        if (int rc = count_dplus_ge(g, thr[i], &ge[i])) return rc;
-    int64_t n_min = 0;
-    if (int rc = count_dplus_ge(g, std::max(k - 1, 1), &n_min)) return rc;
-    if (ge[0] > 0) return GMSX_ERR_UNSUPPORTED;  // d+ > 4096: beyond the widest bit rows of this build
+    int64_t over = 0, n_min = 0;
+    if (int rc = count_dplus_ge(g, 4097, &over)) return rc;
+    if (over > 0) return GMSX_ERR_UNSUPPORTED;  // d+ > 4096: beyond the widest bit rows of this build
     if (!g->rows_sorted) return GMSX_ERR_UNSUPPORTED;  // > 2^32 container entries: rows were not sorted at upload
+    if (int rc = count_dplus_ge(g, std::max(k - 1, 1), &n_min)) return rc;
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
+    // positions [lo, hi) in the d+-sorted order of the pivots with a < d+ <= b, cut at the smallest useful d+
+    auto range = [&](int a, int b, int64_t *lo, int64_t *hi) -> int {
+        if (int rc = count_dplus_ge(g, b + 1, lo)) return rc;
+        if (int rc = count_dplus_ge(g, a + 1, hi)) return rc;
+        *hi = std::min(*hi, n_min);
+        return GMSX_OK;
+    };
 
-    // L: 1024 < d+ <= 4096, bit-matrix in a global slab per workgroup
-    {
-        const int64_t lo = 0, hi = ge[2];
-        const int64_t cnt = part_count(lo, hi, nparts, part);
-        if (cnt > 0) {
-            const bool wide = ge[1] > 0;  // some d+ > 2048
-            const int dmax = wide ? 4096 : 2048, W = dmax / 32;
-            const int WS = W + 1;
-            const int64_t blocks = std::min<int64_t>(cnt, cu * 2);
-            uint32_t *slabs = nullptr;
-            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(blocks) * dmax * WS * sizeof(uint32_t)));
-            *slab_out = slabs;
-            const size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(512 / 64) * 4 * W * 4;  // + row stage
-            if (wide)
-                hipLaunchKernelGGL((k_kc_block<LV, 2, true>), dim3(unsigned(blocks)), dim3(512), lds, s, g->hoff, g->hadj, g->toff,
-                                   g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, slabs, acc);
+    // L: 1024 < d+ <= 4096, bit-matrix in a global slab per workgroup; two launches (one / two words per lane)
+    size_t slab_bytes[2] = {0, 0};
+    int64_t l_lo[2], l_hi[2], l_cnt[2], l_blocks[2];
+    const int l_dmax[2] = {4096, 2048};
+    for (int b = 0; b < 2; ++b) {
+        if (int rc = range(l_dmax[b] / 2, l_dmax[b], &l_lo[b], &l_hi[b])) return rc;
+        l_cnt[b] = part_count(l_lo[b], l_hi[b], nparts, part);
+        l_blocks[b] = std::min<int64_t>(l_cnt[b], cu);  // one workgroup per CU: the LDS tile / stage fills it
+        if (l_cnt[b] > 0) slab_bytes[b] = size_t(l_blocks[b]) * l_dmax[b] * (l_dmax[b] / 32 + 1) * sizeof(uint32_t);
+    }
+    if (slab_bytes[0] + slab_bytes[1] > 0) {
+        uint32_t *slabs = nullptr;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), std::max(slab_bytes[0], slab_bytes[1])));  // the launches run back to back
+        *slab_out = slabs;
+        static bool l_attr[kMaxK] = {false};
+        if (!l_attr[LV]) {
+            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            l_attr[LV] = true;
+        }
+        for (int b = 0; b < 2; ++b) {
+            if (l_cnt[b] <= 0) continue;
+            const int dmax = l_dmax[b], W = dmax / 32, WS = W + 1;
+            const int threads = LV == 2 ? 1024 : 512;
+            const int WT = dmax == 4096 ? 8 : 16;  // k = 4 column tile: dmax x (WT+1) words of LDS
+            size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(threads / 64) * 4 * W * 4;  // bitmap + prefix + row stage
+            if (LV == 2) lds = std::max(lds, size_t(dmax) * (WT + 1) * 4);
+            if (b == 0)
+                hipLaunchKernelGGL((k_kc_block<LV, 2, true>), dim3(unsigned(l_blocks[b])), dim3(threads), lds, s, g->hoff, g->hadj, g->toff, g->tadj,
+                                   g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc);
             else
-                hipLaunchKernelGGL((k_kc_block<LV, 1, true>), dim3(unsigned(blocks)), dim3(512), lds, s, g->hoff, g->hadj, g->toff,
-                                   g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, slabs, acc);
+                hipLaunchKernelGGL((k_kc_block<LV, 1, true>), dim3(unsigned(l_blocks[b])), dim3(threads), lds, s, g->hoff, g->hadj, g->toff, g->tadj,
+                                   g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc);
             ++*launches;
         }
     }
-    // M: 32 < d+ <= 1024, bit-matrix in LDS; one launch per power-of-two bin
+    // M: 32 < d+ <= 1024, bit-matrix in LDS; one launch per bin — the bins are cut where another workgroup fits a CU
     static bool attr_set[kMaxK] = {false};
     if (!attr_set[LV]) {
         GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr_set[LV] = true;
     }
-    for (int b = 0; b < 5; ++b) {
-        const int64_t lo = ge[2 + b], hi = std::min(ge[3 + b], n_min);
-        const int dmax = 1024 >> b, W = dmax / 32;
-        const int WS = W + 1;
+    const int m_dmax[] = {1024, 704, 512, 384, 256, 192, 128, 96, 64, 32};  // last entry = lower end of the last bin
+    for (int b = 0; b + 1 < int(sizeof(m_dmax) / sizeof(int)); ++b) {
+        const int dmax = m_dmax[b], W = dmax / 32, WS = W | 1;  // odd stride: rows of one column spread over the LDS banks
+        int64_t lo = 0, hi = 0;
+        if (int rc = range(m_dmax[b + 1], dmax, &lo, &hi)) return rc;
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (cnt > 0) {
             const size_t lds = size_t(dmax) * WS * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2;
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
-            const int threads = dmax >= 1024 ? 1024 : dmax >= 512 ? 512 : 256;
+            const int threads = dmax >= 704 ? 1024 : dmax >= 384 ? 512 : 256;
             hipLaunchKernelGGL((k_kc_block<LV, 1, false>), dim3(unsigned(blocks)), dim3(threads), lds, s, g->hoff, g->hadj, g->toff,
-                               g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, static_cast<uint32_t *>(nullptr), acc);
+                               g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc);
             ++*launches;
         }
     }
     // S: k-1 <= d+ <= 32
     {
-        const int64_t lo = ge[7], hi = n_min;
+        int64_t lo = 0, hi = 0;
+        if (int rc = range(0, 32, &lo, &hi)) return rc;
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, int64_t(cu) * 32);

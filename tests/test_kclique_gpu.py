@@ -70,7 +70,7 @@ def test_partials_sum_to_total(gpu):
 def test_complete_graphs_exercise_every_bin(gpu):
     # K_n: C_k = C(n,k); d+ runs 0..n-1, so n = 40 / 300 / 1100 / 2300 cover the wave kernel, the LDS bit-matrix bins,
     # the global-slab kernel and its two-words-per-lane variant.  k! * C_k wraps mod 2^64 like the reference's size_t.
-    for n, ks in [(5, (3, 4, 5, 6)), (40, (3, 4, 5, 8, 10)), (300, (3, 4, 5)), (1100, (3, 4)), (2300, (3,))]:
+    for n, ks in [(5, (3, 4, 5, 6)), (40, (3, 4, 5, 8, 10)), (300, (3, 4, 5)), (1100, (3, 4)), (2300, (3, 4))]:
         iu = np.triu_indices(n, 1)
         g = gpu.DeviceGraph.from_csr(gpu.HostCSR.from_edges(iu[0].astype(np.int32), iu[1].astype(np.int32)))
         for k in ks:
@@ -93,3 +93,34 @@ def test_edge_cases_and_errors(gpu):
     e = gpu.DeviceGraph.from_csr(edges_to_csr(gpu, []))
     assert e.kclique_count(4) == (0, 0)
     e.free()
+
+
+def test_dense_random_graph_large_out_degrees(gpu):
+    """G(n, p) with p = 0.85: out-degrees up to ~n, so pivots fall into the widest LDS bins and the global-slab kernel with
+    rows that are NOT all-ones (complete graphs cannot catch a wrong bit position).  k = 3 must equal the triangle
+    kernels (an independent code path); k = 4 is checked against a dense-matrix count: a 4-clique is its smallest vertex a
+    plus a triangle among the later neighbours of a (trace-style count on the 0/1 sub-matrix)."""
+    n, p = 1500, 0.85
+    rng = np.random.default_rng(5)
+    A = np.triu(rng.random((n, n)) < p, 1)
+    A = (A | A.T)
+    iu = np.nonzero(np.triu(A, 1))
+    csr = gpu.HostCSR.from_edges(iu[0].astype(np.int32), iu[1].astype(np.int32))
+    Af = A.astype(np.float32)
+    tri = int(round(float(np.einsum("ij,ij->", Af @ Af, Af, dtype=np.float64)))) // 6
+    k4 = 0
+    for a in range(n):
+        nb = np.nonzero(A[a])[0]
+        nb = nb[nb > a]
+        if len(nb) < 3:
+            continue
+        S = Af[np.ix_(nb, nb)]
+        k4 += int(round(float(np.einsum("ij,ij->", S @ S, S, dtype=np.float64)))) // 6  # triangles among the later neighbours of a
+    for hub_limit in (0, 900):
+        g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_DEFAULT | (hub_limit << 8))
+        assert g.max_out_degree > 1024
+        assert g.tc_total() == tri
+        assert g.kclique_count(3)[1] == tri
+        assert g.kclique_count(4)[1] == k4
+        assert sum(g.kclique_partial(4, q, 3) for q in range(3)) == k4
+        g.free()
