@@ -13,9 +13,11 @@
 #include "device_graph.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace gmsx {
 
+__device__ int g_kdbg;
 static constexpr int kAccSlots = 64;
 static constexpr int kAccStride = 16;
 static constexpr int kMaxK = 10;
@@ -265,6 +267,73 @@ __device__ __forceinline__ unsigned long long lane_enum(const uint32_t *rows, in
     return s;
 }
 
+// Σ_{q < nq} popc(word q of the row held one-word-per-lane in `wl`  &  rj[q]); nq is wave-uniform, four LDS reads in flight
+__device__ __forceinline__ uint32_t kc4_and_popc(uint32_t wl, const uint32_t *rj, int nq) {
+    uint32_t acc = 0;
+    int q = 0;
+    for (; q + 4 <= nq; q += 4) {
+        const uint32_t b0 = rj[q], b1 = rj[q + 1], b2 = rj[q + 2], b3 = rj[q + 3];
+        const uint32_t a0 = uint32_t(__builtin_amdgcn_readlane(int(wl), q)), a1 = uint32_t(__builtin_amdgcn_readlane(int(wl), q + 1)),
+                       a2 = uint32_t(__builtin_amdgcn_readlane(int(wl), q + 2)), a3 = uint32_t(__builtin_amdgcn_readlane(int(wl), q + 3));
+        acc += uint32_t(__popc(a0 & b0) + __popc(a1 & b1)) + uint32_t(__popc(a2 & b2) + __popc(a3 & b3));
+    }
+    for (; q < nq; ++q) acc += uint32_t(__popc(uint32_t(__builtin_amdgcn_readlane(int(wl), q)) & rj[q]));
+    return acc;
+}
+
+// k = 4 count of one matrix row i, wave-cooperative:  Σ_{j ∈ rows[i], j in the band} popc(rows[i] & rows[j]).
+// The lanes take the SET BITS j of row i (64 neighbours per chunk, found through a popcount prefix over the row's
+// words: lane t holds word t), so every lane walks words 0..j>>5 of its own row j — neighbouring lanes have
+// neighbouring j, i.e. the same trip count, and rows[i][q] is a wave-uniform v_readlane (no LDS read).  `band` holds
+// the rows of the vertices j0, j0+1, … (stride BS words, zero above the diagonal) in LDS; only the words [jw0, jw1)
+// of row i (the band's columns) are enumerated.
+template <int WPL>
+__device__ __forceinline__ unsigned long long kc4_row(const uint32_t (&wt)[WPL], const uint32_t *band, int BS, int j0, int jw0, int jw1, int lane) {
+    unsigned long long total = 0;
+#pragma unroll
+    for (int h = 0; h < WPL; ++h) {
+        const int t_me = lane + 64 * h;
+        const uint32_t w = (t_me >= jw0 && t_me < jw1) ? wt[h] : 0u;
+        const int pc = __popc(w);
+        int P = pc;  // inclusive prefix over the lanes
+        for (int sft = 1; sft < 64; sft <<= 1) {
+            const int o = __shfl_up(P, sft);
+            if (lane >= sft) P += o;
+        }
+        const int nb = __builtin_amdgcn_readlane(P, 63);
+        const int ex_me = P - pc;
+        for (int c0 = 0; c0 < nb; c0 += 64) {
+            const bool act = c0 + lane < nb;
+            const int rr = act ? c0 + lane : nb - 1;
+            int L = 0;  // number of lanes whose prefix is <= rr = the lane holding my neighbour's word
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1)
+                if (__shfl(P, L + sft - 1) <= rr) L += sft;
+            uint32_t word = uint32_t(__shfl(int(w), L));
+            int k = rr - __shfl(ex_me, L);  // k-th set bit of word (0-based)
+            int pos = 0;
+#pragma unroll
+            for (int sft = 16; sft > 0; sft >>= 1) {
+                const int c = __popc((word >> pos) & ((1u << sft) - 1u));
+                if (k >= c) {
+                    k -= c;
+                    pos += sft;
+                }
+            }
+            const int tj = L + 64 * h;
+            const int j = (tj << 5) + pos;
+            const int tmax = __builtin_amdgcn_readlane(tj, min(63, nb - c0 - 1));  // ranks ascend with the lane: the last active lane has the largest word index
+            const uint32_t *rj = band + size_t(j - j0) * BS;
+            uint32_t acc = kc4_and_popc(wt[0], rj, min(tmax, 63) + 1);
+            if constexpr (WPL > 1) {
+                if (tmax >= 64) acc += kc4_and_popc(wt[1], rj + 64, tmax - 63);
+            }
+            if (act) total += acc;
+        }
+    }
+    return total;
+}
+
 // ---------------------------------------------------------------------------------------------
 // S: wave per pivot, 1 <= d+ <= 32.
 // ---------------------------------------------------------------------------------------------
@@ -391,7 +460,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         {
             const int grp = lane >> 4, sub = lane & 15;
             uint32_t *stage = GLOBAL_ROWS ? reinterpret_cast<uint32_t *>(pre + kBitmapWords) + size_t(wave) * 4 * W : nullptr;
-            for (int i0 = wave * 4; i0 < d; i0 += nwaves * 4) {
+            for (int i0 = wave * 4; i0 < ((g_kdbg & 2) ? 0 : d); i0 += nwaves * 4) {
                 const int i = i0 + grp;
                 if (GLOBAL_ROWS) {
                     for (int t = lane; t < 4 * W; t += 64) stage[t] = 0;
@@ -418,43 +487,27 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         } else {
             __syncthreads();
         }
+        if (g_kdbg & 1) continue;
         if constexpr (LV == 2 && GLOBAL_ROWS) {
-            // k = 4 on a slab matrix: Σ_i Σ_{j ∈ rows[i]} popc(rows[i] & rows[j]) by COLUMN TILES of WT words staged in LDS
-            // (d x (WT+1) words, over the dead bitmap / stage area): the pair bits (i, j) are read from the slab once
-            // per tile, the row words being ANDed come from LDS.  Row j has bits below j only, so the cell (i, w) —
-            // whose members j have j >> 5 == w — meets tile [t0, t0+WT) on words t0 .. min(t0+WT, w+1) - 1.
-            uint32_t *tile = smem;
-            const int TS = WT + 1;
-            const int Wd = (d + 31) >> 5;
-            const int qd = nthreads / Wd, rm = nthreads - qd * Wd;
-            for (int t0 = 0; t0 < Wd; t0 += WT) {
+            // k = 4 on a slab matrix, by ROW BANDS: the rows j0 .. j0+JB-1 are staged in LDS (over the dead bitmap / stage
+            // area), then every later row i (one per wave, its words in registers straight from the slab) meets its
+            // neighbours inside the band.  JB = WT here (host-chosen so that JB x (W+1) words fit the LDS).
+            uint32_t *band = smem;
+            const int JB = WT, BS = W + 1;
+            for (int j0 = 0; j0 + 1 < d; j0 += JB) {
+                const int j1 = min(j0 + JB, d);
                 __syncthreads();
-                for (int x = tid; x < d * WT; x += nthreads) {
-                    const int i = x / WT, cw = x - i * WT;  // WT is a power of two
-                    tile[i * TS + cw] = t0 + cw < W ? rows[size_t(i) * WS + t0 + cw] : 0u;
+                const int bw = (j1 + 31) >> 5;  // rows below j1 have no bits at or above j1
+                for (int x = tid; x < (j1 - j0) * bw; x += nthreads) {
+                    const int r = x / bw, cw = x - r * bw;
+                    band[r * BS + cw] = rows[size_t(j0 + r) * WS + cw];
                 }
                 __syncthreads();
-                int i = tid / Wd, w = tid - (tid / Wd) * Wd;
-                while (i < d) {
-                    if (w >= t0 && w <= (i >> 5)) {
-                        uint32_t bits = rows[size_t(i) * WS + w];
-                        const uint32_t *ti = tile + i * TS;
-                        const int nw = min(WT, w + 1 - t0);
-                        while (bits) {
-                            const int j = (w << 5) + __ffs(bits) - 1;
-                            bits &= bits - 1;
-                            const uint32_t *tj = tile + j * TS;
-                            uint32_t c = 0;
-                            for (int q = 0; q < nw; ++q) c += uint32_t(__popc(ti[q] & tj[q]));
-                            cnt += c;
-                        }
-                    }
-                    w += rm;
-                    i += qd;
-                    if (w >= Wd) {
-                        w -= Wd;
-                        ++i;
-                    }
+                for (int i = j0 + 1 + wave; i < d; i += nwaves) {
+                    uint32_t wt[WPL];
+                    wt[0] = lane < W ? rows[size_t(i) * WS + lane] : 0u;
+                    if constexpr (WPL > 1) wt[1] = 64 + lane < W ? rows[size_t(i) * WS + 64 + lane] : 0u;
+                    cnt += kc4_row<WPL>(wt, band, BS, j0, j0 >> 5, (j1 + 31) >> 5, lane);
                 }
             }
         } else if constexpr (LV == 1) {
@@ -469,8 +522,16 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                 if constexpr (WPL > 1) cand[1] = 64 + lane < W ? rows[size_t(i) * WS + 64 + lane] : 0u;
                 cnt += wave_cliques<LV, WPL>(rows, WS, cand, lane);
             }
+        } else if (LV == 2 && W >= 22) {
+            // k = 4, wide matrix in LDS: a single band (the whole matrix), one row per wave and trip.  (Below ~700 vertices
+            // the per-row prefix / select overhead of kc4_row exceeds what its divergence-free inner loop saves.)
+            for (int i = 1 + wave; i < d; i += nwaves) {
+                uint32_t wt[1];
+                wt[0] = lane < W ? rows[size_t(i) * WS + lane] : 0u;
+                cnt += kc4_row<1>(wt, rows, WS, 0, 0, W, lane);
+            }
         } else {
-            // k = 4, or narrow rows: one LANE per matrix word (i, w): it walks the set bits j of its word and enumerates the cliques below
+            // k = 4 on narrower matrices, and narrow rows at k >= 5: one LANE per matrix word (i, w): it walks the set bits j of its word and enumerates the cliques below
             // the path (i, j) by ANDing the path's rows word by word — the reference's isect.intersect(N(vi)) recursion
             // (k = 4: Σ_i Σ_{j ∈ rows[i]} popc(rows[i] & rows[j])).  Odd row stride: no LDS bank conflicts.
             const int words = d * W;
@@ -546,9 +607,9 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             if (l_cnt[b] <= 0) continue;
             const int dmax = l_dmax[b], W = dmax / 32, WS = W + 1;
             const int threads = LV == 2 ? 1024 : 512;
-            const int WT = dmax == 4096 ? 8 : 16;  // k = 4 column tile: dmax x (WT+1) words of LDS
+            const int WT = dmax == 4096 ? 288 : 576;  // k = 4 row band: WT rows x (W+1) words of LDS (multiple of 32)
             size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(threads / 64) * 4 * W * 4;  // bitmap + prefix + row stage
-            if (LV == 2) lds = std::max(lds, size_t(dmax) * (WT + 1) * 4);
+            if (LV == 2) lds = std::max(lds, size_t(WT) * (W + 1) * 4);
             if (b == 0)
                 hipLaunchKernelGGL((k_kc_block<LV, 2, true>), dim3(unsigned(l_blocks[b])), dim3(threads), lds, s, g->hoff, g->hadj, g->toff, g->tadj,
                                    g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc);
@@ -611,6 +672,7 @@ static int kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uin
     GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * kAccSlots * kAccStride, s));
     GMSX_HIP(hipEventRecord(c.ev[0], s));
     int launches = 0, rc = GMSX_OK;
+    { const int dbg = getenv("GMSX_DBG") ? atoi(getenv("GMSX_DBG")) : 0; GMSX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_kdbg), &dbg, sizeof(int))); }
     switch (k) {
         case 3: rc = launch_all<1>(g, part, nparts, acc, &launches, &slabs); break;
         case 4: rc = launch_all<2>(g, part, nparts, acc, &launches, &slabs); break;
