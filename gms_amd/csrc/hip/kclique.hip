@@ -5,11 +5,15 @@
 // The reference recurses over the SYMMETRIC graph and returns k! * C_k (every clique once per vertex order).  Here
 // each clique is met once, on the degree-oriented DAG, and the result is multiplied by k! (mod 2^64, the reference's
 // size_t arithmetic) at the ABI.  Per pivot u (one workgroup, or one wave for d+ <= 32):
-//   1. BUILD ("LDS-staged intersect"): the pivot row N+(u) is staged into LDS as a hash map id -> local index; the
-//      rows N+(v), v in N+(u), are streamed from HBM and every id found in the map sets one bit of the local
-//      adjacency bit-matrix  rows[i] = N+(v_i) ∩ N+(u)  (d x d bits, in LDS up to d = 1024, else a global slab);
+//   1. BUILD ("LDS-staged intersect"): the pivot row N+(u) is staged into LDS — as the 65536-bit hub bitmap with
+//      prefix popcounts (workgroup kernels: rank in the bitmap = local index) or as a 64 x 4 bucket set id -> local
+//      index (wave kernel); the rows N+(v), v in N+(u), are streamed from HBM exactly like the triangle kernels do
+//      (16-lane groups, 16-byte loads, bitset AND or list probes) and every hit sets one bit of the local adjacency
+//      bit-matrix  rows[i] = N+(v_i) ∩ N+(u)  (d x d bits, strictly lower triangular; in LDS up to d = 1024, else in a
+//      global slab built through an LDS row stage);
 //   2. COUNT: recursive set intersection on bit rows: cand' = cand & rows[j] (bitmap AND), popcount at the last
-//      level — the reference's `isect.intersect(N(vi))` recursion with sets as d-bit vectors, one 32-bit word per lane.
+//      level — the reference's `isect.intersect(N(vi))` recursion with sets as d-bit vectors.  k = 4 on wide matrices
+//      runs wave-cooperatively with one neighbour j per lane (kc4_row), slab matrices band by band through LDS.
 #include "device_graph.hpp"
 
 #include <algorithm>
@@ -22,45 +26,8 @@ static constexpr int kAccSlots = 64;
 static constexpr int kAccStride = 16;
 static constexpr int kMaxK = 10;
 
-// ---- id -> local index map (open addressing, keys -1 = empty) ---------------------------------------------
+// ---- id -> local index map of the wave kernel (open-addressing fallback of its bucket set; keys -1 = empty) ----
 __device__ __forceinline__ uint32_t kc_hash(int32_t w, int shift) { return (uint32_t(w) * 0x9E3779B1u) >> shift; }
-__device__ __forceinline__ void map_insert(int32_t *keys, uint16_t *vals, uint32_t mask, int shift, int32_t w, int idx) {
-    uint32_t h = kc_hash(w, shift);
-    while (atomicCAS(&keys[h], -1, w) != -1) h = (h + 1) & mask;
-    vals[h] = uint16_t(idx);
-}
-__device__ __forceinline__ int map_find(const int32_t *keys, const uint16_t *vals, uint32_t mask, int shift, int32_t w) {
-    uint32_t h = kc_hash(w, shift);
-    while (true) {
-        const int32_t x = keys[h];
-        if (x == w) return int(vals[h]);
-        if (x == -1) return -1;
-        h = (h + 1) & mask;
-    }
-}
-
-// stream both containers of the oriented row of rank id v; every id found in the map sets a bit of `row`
-// (wave-per-pivot kernel: hub and tail members of the pivot live in one small hash map)
-template <class OrFn>
-__device__ __forceinline__ void build_row(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                          const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, int32_t v,
-                                          const int32_t *keys, const uint16_t *vals, uint32_t mask, int shift, int lane, OrFn or_bit) {
-    const int64_t hb = hoff[v], he = hoff[v + 1];
-    for (int64_t j = hb + lane; j < he; j += 64) {
-        const uint32_t w = hadj[j];
-        if (w != 0xFFFFu) {
-            const int idx = map_find(keys, vals, mask, shift, int32_t(w));
-            if (idx >= 0) or_bit(idx);
-        }
-    }
-    {   // hub vertices simply have an empty tail container
-        const int64_t tb = toff[v], te = toff[v + 1];
-        for (int64_t j = tb + lane; j < te; j += 64) {
-            const int idx = map_find(keys, vals, mask, shift, tadj[j]);
-            if (idx >= 0) or_bit(idx);
-        }
-    }
-}
 
 // ---- streamed build (workgroup kernels) ------------------------------------------------------------------------
 // Same row streaming as the triangle kernels (tc.hip): a wave works as four 16-lane groups, each on the row of one
@@ -335,24 +302,101 @@ __device__ __forceinline__ unsigned long long kc4_row(const uint32_t (&wt)[WPL],
 }
 
 // ---------------------------------------------------------------------------------------------
-// S: wave per pivot, 1 <= d+ <= 32.
+// S: wave per pivot, 1 <= d+ <= 32.  The 32 x 32 adjacency matrix is one word per member:
+//   * rows of HUB members come from inverted gathers into their bitset containers (as k_tc_wave_hub): lane j asks
+//     "is member w_j in N+(v_i)", two rows per gather (one per half-wave), eight gathers in flight, and the ballot IS
+//     the pair of row words — no atomics, no LDS;
+//   * rows of TAIL members are streamed (four 16-lane groups, 16-byte loads) and every id — hub or tail — is probed in
+//     one 64 x 4 bucket set of the pivot's members (id -> local index; one ds_read_b128 + four compares).  A pivot
+//     with five members in one bucket uses the open-addressing map instead.
+// No bitmap: 1.4 KB of LDS per wave, full occupancy.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t readlane64(int64_t x, int l) {
+    const uint32_t lo = __builtin_amdgcn_readlane(uint32_t(uint64_t(x)), l);
+    const uint32_t hi = __builtin_amdgcn_readlane(uint32_t(uint64_t(x) >> 32), l);
+    return int64_t((uint64_t(hi) << 32) | lo);
+}
+__device__ __forceinline__ uint32_t kcs_bucket(int32_t w) { return (uint32_t(w) ^ (uint32_t(w) >> 6)) & 63u; }
+
+template <bool BUCKET>
+__device__ __forceinline__ int kcs_find(const int32_t *keys, const unsigned char *vals, int32_t w) {
+    if (BUCKET) {
+        const uint32_t b = kcs_bucket(w) * 4;
+        const int4 k4 = *reinterpret_cast<const int4 *>(keys + b);
+        const uint32_t m = uint32_t(k4.x == w) | (uint32_t(k4.y == w) << 1) | (uint32_t(k4.z == w) << 2) | (uint32_t(k4.w == w) << 3);
+        if (!m) return -1;
+        return int(vals[b + (__ffs(m) - 1)]);
+    } else {
+        uint32_t h = kc_hash(w, 24);
+        while (true) {
+            const int32_t x = keys[h];
+            if (x == w) return int(vals[h]);
+            if (x == -1) return -1;
+            h = (h + 1) & 255u;
+        }
+    }
+}
+
+// both containers of the rows of the tail members i0 .. i0+3 (one per 16-lane group); hits set bits of rows[i]
+template <bool BUCKET>
+__device__ __forceinline__ void kcs_tail_rows(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff,
+                                              const int32_t *__restrict__ tadj, const int32_t *keys, const unsigned char *vals, uint32_t *rows,
+                                              int32_t my, int hc, int d, int lane) {
+    const int grp = lane >> 4, sub = lane & 15;
+    for (int i0 = hc; i0 < d; i0 += 4) {
+        const int32_t v0 = __builtin_amdgcn_readlane(my, i0 & 63), v1 = __builtin_amdgcn_readlane(my, (i0 + 1) & 63),
+                      v2 = __builtin_amdgcn_readlane(my, (i0 + 2) & 63), v3 = __builtin_amdgcn_readlane(my, (i0 + 3) & 63);
+        const int i = i0 + grp;
+        if (i >= d) continue;  // per group
+        const int32_t v = grp == 0 ? v0 : grp == 1 ? v1 : grp == 2 ? v2 : v3;
+        uint32_t bits = 0;
+        {
+            const int64_t hb = hoff[v];
+            const int hl = int(hoff[v + 1] - hb);
+            const uint16_t *row = hadj + hb;
+            for (int j = sub * 8; j < hl; j += 128) {
+                const kc_u4u p = kc_load8(row, j, hl);
+                const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint32_t lo = pw[q] & 0xffffu, hi = pw[q] >> 16;
+                    const int a = lo != 0xffffu ? kcs_find<BUCKET>(keys, vals, int32_t(lo)) : -1;  // 0xFFFF = pad, also a possible tail id
+                    const int c = hi != 0xffffu ? kcs_find<BUCKET>(keys, vals, int32_t(hi)) : -1;
+                    if (a >= 0) bits |= 1u << a;
+                    if (c >= 0) bits |= 1u << c;
+                }
+            }
+        }
+        if (d > hc) {
+            const int64_t tb = toff[v];
+            const int tl = int(toff[v + 1] - tb);
+            const int32_t *row = tadj + tb;
+            for (int j = sub; j < tl; j += 16) {
+                const int a = kcs_find<BUCKET>(keys, vals, row[j]);
+                if (a >= 0) bits |= 1u << a;
+            }
+        }
+        if (bits) atomicOr(&rows[i], bits);
+    }
+}
+
 template <int LV>
 __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                  const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
                                                   const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
                                                   int part, unsigned long long *__restrict__ acc) {
-    constexpr int LOG = 7, SIZE = 1 << LOG, SHIFT = 32 - LOG;
-    constexpr uint32_t MASK = SIZE - 1;
-    __shared__ int32_t keys_all[4 * SIZE];
-    __shared__ uint16_t vals_all[4 * SIZE];
+    constexpr int SIZE = 256;
+    __shared__ __attribute__((aligned(16))) int32_t keys_all[4 * SIZE];
+    __shared__ __attribute__((aligned(4))) unsigned char vals_all[4 * SIZE];
     __shared__ uint32_t rows_all[4 * 32];
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int32_t *keys = keys_all + wave * SIZE;
-    uint16_t *vals = vals_all + wave * SIZE;
+    unsigned char *vals = vals_all + wave * SIZE;
     uint32_t *rows = rows_all + wave * 32;
     const int64_t nwaves = int64_t(gridDim.x) * 4;
+    const int half = lane >> 5, jl = lane & 31;
     unsigned long long cnt = 0;
     for (int64_t q = int64_t(blockIdx.x) * 4 + wave;; q += nwaves) {
         const int64_t pos = first + q * nparts + part;
@@ -367,13 +411,66 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
         if (lane < 32) rows[lane] = 0;
         __builtin_amdgcn_wave_barrier();
         int32_t my = -1;
-        if (lane < hc) my = int32_t(hadj[hb + lane]);
-        else if (lane < d) my = tadj[tb + (lane - hc)];
-        if (lane < d) map_insert(keys, vals, MASK, SHIFT, my, lane);
+        int64_t rbm = 0;
+        if (lane < hc) {
+            my = int32_t(hadj[hb + lane]);
+            rbm = bmoff[my];
+        } else if (lane < d) {
+            my = tadj[tb + (lane - hc)];
+        }
+        bool bucketed = true;
+        if (tc > 0) {  // the member set is only probed by the streamed rows of tail members
+            bool ovf = false;
+            if (lane < d) {
+                int32_t *b = keys + kcs_bucket(my) * 4;
+                int s = 0;
+                for (; s < 4; ++s)
+                    if (atomicCAS(b + s, -1, my) == -1) break;
+                if (s < 4) vals[(b - keys) + s] = (unsigned char)lane;
+                else ovf = true;
+            }
+            bucketed = __ballot(ovf) == 0;
+            if (!bucketed) {  // rare: rebuild as an open-addressing map in the same table
+                __builtin_amdgcn_wave_barrier();
+                for (int i = lane; i < SIZE; i += 64) keys[i] = -1;
+                __builtin_amdgcn_wave_barrier();
+                if (lane < d) {
+                    uint32_t h = kc_hash(my, 24);
+                    while (atomicCAS(&keys[h], -1, my) != -1) h = (h + 1) & 255u;
+                    vals[h] = (unsigned char)lane;
+                }
+            }
+        }
         __builtin_amdgcn_wave_barrier();
-        for (int i = 0; i < d; ++i) {
-            const int32_t v = __builtin_amdgcn_readlane(my, i);
-            build_row(hoff, hadj, toff, tadj, v, keys, vals, MASK, SHIFT, lane, [&](int idx) { atomicOr(&rows[i], 1u << idx); });
+        // rows of the hub members 1 .. hc-1 (member 0 has no smaller member): two rows per gather, eight gathers in flight
+        if (hc > 1) {
+            const int32_t wj = __shfl(my, jl);
+            const bool jv = jl < hc;
+            for (int p0 = 0; p0 * 2 < hc; p0 += 8) {
+                uint32_t wd[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int ia = 2 * (p0 + k), ib = ia + 1;  // <= 31 + 16: masked below
+                    const int32_t va = ia < hc ? __builtin_amdgcn_readlane(my, ia & 63) : 0, vb = ib < hc ? __builtin_amdgcn_readlane(my, ib & 63) : 0;
+                    const int64_t ba = readlane64(rbm, ia & 63), bb = readlane64(rbm, ib & 63);
+                    const int32_t vi = half ? vb : va;
+                    const int64_t rb = half ? bb : ba;
+                    wd[k] = (jv && wj < vi) ? bmpool[rb + (uint32_t(wj) >> 5)] : 0u;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int ia = 2 * (p0 + k), ib = ia + 1;
+                    const unsigned long long m = __ballot((wd[k] >> (uint32_t(wj) & 31u)) & 1u);
+                    if (lane == 0 && ia < hc) rows[ia] = uint32_t(m);
+                    if (lane == 32 && ib < hc) rows[ib] = uint32_t(m >> 32);
+                }
+            }
+        }
+        if (tc > 0) {
+            if (bucketed)
+                kcs_tail_rows<true>(hoff, hadj, toff, tadj, keys, vals, rows, my, hc, d, lane);
+            else
+                kcs_tail_rows<false>(hoff, hadj, toff, tadj, keys, vals, rows, my, hc, d, lane);
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < d) cnt += lane_cliques<LV>(rows, rows[lane]);
@@ -648,8 +745,8 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, int64_t(cu) * 32);
-            hipLaunchKernelGGL(k_kc_small<LV>, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->order,
-                               lo, hi, nparts, part, acc);
+            hipLaunchKernelGGL(k_kc_small<LV>, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                               g->order, lo, hi, nparts, part, acc);
             ++*launches;
         }
     }
