@@ -17,11 +17,9 @@
 #include "device_graph.hpp"
 
 #include <algorithm>
-#include <cstdlib>
 
 namespace gmsx {
 
-__device__ int g_kdbg;
 static constexpr int kAccSlots = 64;
 static constexpr int kAccStride = 16;
 static constexpr int kMaxK = 10;
@@ -91,15 +89,29 @@ __device__ __forceinline__ void kc_and_word(uint32_t x, uint32_t pivot_word, int
 }
 
 // bitset container (nw words, multiple of 4) of one hub member: AND with the pivot bitmap, every surviving bit is a hit
+__device__ __forceinline__ void kc_and4(uint4 p, uint4 q, int j, const unsigned short *pre, uint32_t *orow) {
+    kc_and_word(p.x & q.x, q.x, j, pre, orow);
+    kc_and_word(p.y & q.y, q.y, j + 1, pre, orow);
+    kc_and_word(p.z & q.z, q.z, j + 2, pre, orow);
+    kc_and_word(p.w & q.w, q.w, j + 3, pre, orow);
+}
 __device__ __forceinline__ void kc_stream_bitset(const uint32_t *__restrict__ brow, int nw, int sub, const uint32_t *bm, const unsigned short *pre,
                                                  uint32_t *orow) {
-    for (int j = sub * 4; j < nw; j += 64) {
+    int j = sub * 4;
+    for (; j + 192 < nw; j += 256) {  // four 16-byte loads in flight (the hit loops below keep the compiler from overlapping them itself)
+        const uint4 p0 = *reinterpret_cast<const uint4 *>(brow + j), p1 = *reinterpret_cast<const uint4 *>(brow + j + 64),
+                    p2 = *reinterpret_cast<const uint4 *>(brow + j + 128), p3 = *reinterpret_cast<const uint4 *>(brow + j + 192);
+        const uint4 q0 = *reinterpret_cast<const uint4 *>(bm + j), q1 = *reinterpret_cast<const uint4 *>(bm + j + 64),
+                    q2 = *reinterpret_cast<const uint4 *>(bm + j + 128), q3 = *reinterpret_cast<const uint4 *>(bm + j + 192);
+        kc_and4(p0, q0, j, pre, orow);
+        kc_and4(p1, q1, j + 64, pre, orow);
+        kc_and4(p2, q2, j + 128, pre, orow);
+        kc_and4(p3, q3, j + 192, pre, orow);
+    }
+    for (; j < nw; j += 64) {
         const uint4 p = *reinterpret_cast<const uint4 *>(brow + j);
         const uint4 q = *reinterpret_cast<const uint4 *>(bm + j);
-        kc_and_word(p.x & q.x, q.x, j, pre, orow);
-        kc_and_word(p.y & q.y, q.y, j + 1, pre, orow);
-        kc_and_word(p.z & q.z, q.z, j + 2, pre, orow);
-        kc_and_word(p.w & q.w, q.w, j + 3, pre, orow);
+        kc_and4(p, q, j, pre, orow);
     }
 }
 
@@ -557,7 +569,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         {
             const int grp = lane >> 4, sub = lane & 15;
             uint32_t *stage = GLOBAL_ROWS ? reinterpret_cast<uint32_t *>(pre + kBitmapWords) + size_t(wave) * 4 * W : nullptr;
-            for (int i0 = wave * 4; i0 < ((g_kdbg & 2) ? 0 : d); i0 += nwaves * 4) {
+            for (int i0 = wave * 4; i0 < d; i0 += nwaves * 4) {
                 const int i = i0 + grp;
                 if (GLOBAL_ROWS) {
                     for (int t = lane; t < 4 * W; t += 64) stage[t] = 0;
@@ -584,7 +596,6 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         } else {
             __syncthreads();
         }
-        if (g_kdbg & 1) continue;
         if constexpr (LV == 2 && GLOBAL_ROWS) {
             // k = 4 on a slab matrix, by ROW BANDS: the rows j0 .. j0+JB-1 are staged in LDS (over the dead bitmap / stage
             // area), then every later row i (one per wave, its words in registers straight from the slab) meets its
@@ -769,7 +780,6 @@ static int kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uin
     GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * kAccSlots * kAccStride, s));
     GMSX_HIP(hipEventRecord(c.ev[0], s));
     int launches = 0, rc = GMSX_OK;
-    { const int dbg = getenv("GMSX_DBG") ? atoi(getenv("GMSX_DBG")) : 0; GMSX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_kdbg), &dbg, sizeof(int))); }
     switch (k) {
         case 3: rc = launch_all<1>(g, part, nparts, acc, &launches, &slabs); break;
         case 4: rc = launch_all<2>(g, part, nparts, acc, &launches, &slabs); break;
