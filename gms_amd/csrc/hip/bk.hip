@@ -59,6 +59,11 @@ __global__ void k_bk_tasks(int64_t n, const int64_t *__restrict__ off, const int
     vals[v] = int32_t(v);
 }
 
+__device__ __forceinline__ int64_t bk_readlane64(int64_t x, int l) {
+    const uint32_t lo = __builtin_amdgcn_readlane(uint32_t(uint64_t(x)), l);
+    const uint32_t hi = __builtin_amdgcn_readlane(uint32_t(uint64_t(x) >> 32), l);
+    return int64_t((uint64_t(hi) << 32) | lo);
+}
 __device__ __forceinline__ uint32_t bk_hash(int32_t w, uint32_t mask) { return (uint32_t(w) * 0x9E3779B1u >> 7) & mask; }
 
 __device__ __forceinline__ int bk_find(const unsigned long long *map, uint32_t mask, int32_t w) {
@@ -91,25 +96,57 @@ __device__ __forceinline__ void bk_scan_row(const int64_t *__restrict__ hoff, co
     }
 }
 
-// per-LANE sequential scan of the oriented row of rank id a (the rows of the in-neighbours are short): four hub ids per
-// 8-byte load, so the dependent load chain of a lane is a quarter as long
-struct __attribute__((packed, aligned(4))) bk_u2 { uint32_t x, y; };
+// per-LANE sequential scan of the oriented row of rank id a (the rows of the in-neighbours are short): eight hub ids per
+// 16-byte load, and the next load is issued before the current ids are probed, so the dependent chain of a lane is
+// one load round trip per 8 ids with the probes hidden behind it
+struct __attribute__((packed, aligned(4))) bk_u4 { uint32_t x, y, z, w; };
+template <class F>
+__device__ __forceinline__ void bk_probe2(const unsigned long long *map, uint32_t mask, uint32_t pair, bool valid, F &f) {
+    const uint32_t w0 = pair & 0xffffu, w1 = pair >> 16;
+    if (valid && w0 != 0xFFFFu) { const int k = bk_find(map, mask, int32_t(w0)); if (k >= 0) f(k); }
+    if (valid && w1 != 0xFFFFu) { const int k = bk_find(map, mask, int32_t(w1)); if (k >= 0) f(k); }
+}
 template <class F>
 __device__ __forceinline__ void bk_scan_row_lane(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                  const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, int32_t a,
                                                  const unsigned long long *map, uint32_t mask, F f) {
     const int64_t hb = hoff[a], he = hoff[a + 1];  // even count, 4-byte aligned start
-    for (int64_t j = hb; j < he; j += 4) {
-        const bk_u2 p = *reinterpret_cast<const bk_u2 *>(hadj + j);  // may run 2 ids past the row: masked below
-        const uint32_t w0 = p.x & 0xffffu, w1 = p.x >> 16, w2 = p.y & 0xffffu, w3 = p.y >> 16;
-        const bool more = j + 2 < he;
-        if (w0 != 0xFFFFu) { const int k = bk_find(map, mask, int32_t(w0)); if (k >= 0) f(k); }
-        if (w1 != 0xFFFFu) { const int k = bk_find(map, mask, int32_t(w1)); if (k >= 0) f(k); }
-        if (more && w2 != 0xFFFFu) { const int k = bk_find(map, mask, int32_t(w2)); if (k >= 0) f(k); }
-        if (more && w3 != 0xFFFFu) { const int k = bk_find(map, mask, int32_t(w3)); if (k >= 0) f(k); }
-    }
     const int64_t tb = toff[a], te = toff[a + 1];
+    if (hb < he) {
+        bk_u4 p = *reinterpret_cast<const bk_u4 *>(hadj + hb);  // may run up to 6 ids past the row (hadj is padded): masked below
+        for (int64_t j = hb; j < he; j += 8) {
+            const bk_u4 cur = p;
+            if (j + 8 < he) p = *reinterpret_cast<const bk_u4 *>(hadj + j + 8);
+            const int64_t left = he - j;  // even, >= 2
+            bk_probe2(map, mask, cur.x, true, f);
+            bk_probe2(map, mask, cur.y, left > 2, f);
+            bk_probe2(map, mask, cur.z, left > 4, f);
+            bk_probe2(map, mask, cur.w, left > 6, f);
+        }
+    }
     for (int64_t j = tb; j < te; ++j) {
+        const int k = bk_find(map, mask, tadj[j]);
+        if (k >= 0) f(k);
+    }
+}
+
+// 16-lane-group scan of the oriented row of rank id a: 16-byte loads of the hub container (8 ids per lane), the tail
+// container with a stride of 16
+template <class F>
+__device__ __forceinline__ void bk_scan_row_group(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                  const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, int32_t a,
+                                                  const unsigned long long *map, uint32_t mask, int sub, F f) {
+    const int64_t hb = hoff[a], he = hoff[a + 1];
+    const int64_t tb = toff[a], te = toff[a + 1];
+    for (int64_t j = hb + sub * 8; j < he; j += 128) {
+        const bk_u4 cur = *reinterpret_cast<const bk_u4 *>(hadj + j);
+        const int64_t left = he - j;  // even, >= 2
+        bk_probe2(map, mask, cur.x, true, f);
+        bk_probe2(map, mask, cur.y, left > 2, f);
+        bk_probe2(map, mask, cur.z, left > 4, f);
+        bk_probe2(map, mask, cur.w, left > 6, f);
+    }
+    for (int64_t j = tb + sub; j < te; j += 16) {
         const int k = bk_find(map, mask, tadj[j]);
         if (k >= 0) f(k);
     }
@@ -384,7 +421,16 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
 
         // ---- build: map, Cadj (symmetric closure of the DAG rows inside C), XT (C x X0 adjacency) -------------------
         for (uint32_t i = lane; i < msize; i += 64) map[i] = kEmptySlot;
-        for (size_t i = lane; i < size_t(c) * cw + size_t(c) * xw; i += 64) Cadj[i] = 0;
+        {
+            const size_t nz = size_t(c) * cw + size_t(c) * xw;
+            size_t head = (16 - (reinterpret_cast<uintptr_t>(Cadj) & 15)) & 15;  // bytes to the next 16-byte boundary
+            head = min(nz, head / 4);
+            for (size_t i = lane; i < head; i += 64) Cadj[i] = 0;
+            uint4 *z4 = reinterpret_cast<uint4 *>(Cadj + head);
+            const size_t n4 = (nz - head) / 4;
+            for (size_t i = lane; i < n4; i += 64) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (size_t i = head + n4 * 4 + lane; i < nz; i += 64) Cadj[i] = 0;
+        }
         if (!LDS_SLAB) __threadfence();
         __builtin_amdgcn_wave_barrier();
         const int64_t hb = hoff[v], tb = toff[v];
@@ -398,29 +444,50 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
         }
         if (!LDS_SLAB) __threadfence();
         __builtin_amdgcn_wave_barrier();
-        for (int i = 0; i < c; ++i) {  // rows of the candidates
-            const int32_t a = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
-            if (a < sh.dense_limit) {
-                // a hub candidate has a bitset container: lane k asks "is candidate k in N+(a)?" with one word gather
-                // (its targets are hub ids < a, so only hub candidates can hit)
-                const uint32_t *bits = sh.bmpool + sh.bmoff[a];
-                for (int k0 = 0; k0 < hc; k0 += 64) {
-                    const int k = k0 + lane;
-                    bool hit = false;
-                    if (k < hc) {
-                        const uint32_t w = hadj[hb + k];
-                        if (int32_t(w) < a) hit = (bits[w >> 5] >> (w & 31u)) & 1u;
+        // rows of the hub candidates (all of them have a bitset container): lane k asks "is candidate k in N+(a_i)?" with
+        // one word gather; the candidate ids of a 64-chunk are loaded once, the rows go eight at a time (eight gathers
+        // in flight).  Candidates ascend with their index, so only rows i > k can hit.
+        {
+            for (int k0 = 0; k0 < hc; k0 += 64) {
+                const int k = k0 + lane;
+                const uint32_t w = k < hc ? uint32_t(hadj[hb + k]) : 0xFFFFFFFFu;
+                for (int i0 = k0; i0 < hc; i0 += 64) {  // 64 rows: ids and bitset offsets lane-parallel, then by readlane
+                    int32_t ai = 0;
+                    int64_t rbi = 0;
+                    if (i0 + lane < hc) {
+                        ai = int32_t(hadj[hb + i0 + lane]);
+                        rbi = sh.bmoff[ai];
                     }
-                    if (hit) {
-                        atomicOr(&Cadj[size_t(i) * cw + (k >> 5)], 1u << (k & 31));
-                        atomicOr(&Cadj[size_t(k) * cw + (i >> 5)], 1u << (i & 31));
+                    const int nrow = min(64, hc - i0);
+                    for (int r0 = 0; r0 < nrow; r0 += 8) {
+                        uint32_t wd[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const int32_t a = __builtin_amdgcn_readlane(ai, (r0 + r) & 63);  // 0 beyond the last row: never > w
+                            const int64_t rb = bk_readlane64(rbi, (r0 + r) & 63);
+                            wd[r] = (w < uint32_t(a)) ? sh.bmpool[rb + (w >> 5)] : 0u;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            if ((wd[r] >> (w & 31u)) & 1u) {
+                                const int i = i0 + r0 + r;
+                                atomicOr(&Cadj[size_t(i) * cw + (k >> 5)], 1u << (k & 31));
+                                atomicOr(&Cadj[size_t(k) * cw + (i >> 5)], 1u << (i & 31));
+                            }
+                        }
                     }
                 }
-            } else {  // tail candidate: stream its containers through the map
-                bk_scan_row(hoff, hadj, toff, tadj, a, map, mmask, lane, 64, [&](int k) {
-                    atomicOr(&Cadj[size_t(i) * cw + (k >> 5)], 1u << (k & 31));
-                    atomicOr(&Cadj[size_t(k) * cw + (i >> 5)], 1u << (i & 31));
-                });
+            }
+            // tail candidates: stream their containers through the map, four rows per trip (one per 16-lane group)
+            for (int i0 = hc; i0 < c; i0 += 4) {
+                const int i = i0 + (lane >> 4);
+                if (i < c) {
+                    const int32_t a = tadj[tb + (i - hc)];
+                    bk_scan_row_group(hoff, hadj, toff, tadj, a, map, mmask, lane & 15, [&](int k) {
+                        atomicOr(&Cadj[size_t(i) * cw + (k >> 5)], 1u << (k & 31));
+                        atomicOr(&Cadj[size_t(k) * cw + (i >> 5)], 1u << (i & 31));
+                    });
+                }
             }
         }
         // rows of the in-neighbours: one lane per row (they are short); t = index of the in-neighbour in X0
