@@ -81,6 +81,7 @@ struct Ctx {
 Ctx &ctx();
 int ensure_init();
 // number of vertices with d+ >= threshold (= position in `order` where d+ drops below it)
+int kclique_vertex_counts(const gmsx_graph *g, unsigned long long *d_counts, gmsx_stats *st);  // kclique.hip
 int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out);
 // GMSX_TC_FULL: every edge u<v intersects the FULL rows (pairs.hip); returns the un-divided sum of the shard
 int tc_full_partial(const gmsx_graph *g, int part, int nparts, uint64_t *partial, gmsx_stats *st);

@@ -392,12 +392,13 @@ __device__ __forceinline__ void kcs_tail_rows(const int64_t *__restrict__ hoff, 
     }
 }
 
-template <int LV>
+template <int LV, bool VTX>
 __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
                                                   const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
-                                                  int part, unsigned long long *__restrict__ acc) {
+                                                  int part, unsigned long long *__restrict__ acc, const int32_t *__restrict__ oldid,
+                                                  unsigned long long *__restrict__ vcounts) {
     constexpr int SIZE = 256;
     __shared__ __attribute__((aligned(16))) int32_t keys_all[4 * SIZE];
     __shared__ __attribute__((aligned(4))) unsigned char vals_all[4 * SIZE];
@@ -485,7 +486,20 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
                 kcs_tail_rows<false>(hoff, hadj, toff, tadj, keys, vals, rows, my, hc, d, lane);
         }
         __builtin_amdgcn_wave_barrier();
-        if (lane < d) cnt += lane_cliques<LV>(rows, rows[lane]);
+        if constexpr (VTX) {
+            // per-vertex triangle counts (vertex_count2 = 2 x triangles at the vertex): a set bit (i, j) is the triangle
+            // (u, v_i, v_j); member t collects its row popcount and its column sum, the pivot the number of bits
+            uint32_t rp = 0, cs = 0;
+            if (lane < d) rp = uint32_t(__popc(rows[lane]));
+            for (int i = 0; i < d; ++i) cs += (rows[i] >> lane) & 1u;  // rows[i] is a broadcast read; lanes >= d see zeros
+            if (lane < d && rp + cs) atomicAdd(&vcounts[oldid[my]], 2ull * (rp + cs));
+            uint32_t ps = rp;
+            for (int sft = 32; sft > 0; sft >>= 1) ps += __shfl_xor(ps, sft);
+            if (lane == 0 && ps) atomicAdd(&vcounts[oldid[u]], 2ull * ps);
+            cnt += rp;
+        } else {
+            if (lane < d) cnt += lane_cliques<LV>(rows, rows[lane]);
+        }
         __builtin_amdgcn_wave_barrier();
     }
     for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
@@ -502,13 +516,14 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
 // (d <= 1024); true: in a per-workgroup global slab (d up to 64*32*WPL), workgroups walk their pivots with a grid stride.
 // dynamic LDS layout: [rows: dmax*WS u32 (LDS variant only)] [bm: 2048 u32] [pre: 2048 u16] [row stage: nwaves*4*W u32 (slab variant only)]
 // ---------------------------------------------------------------------------------------------
-template <int LV, int WPL, bool GLOBAL_ROWS>
+template <int LV, int WPL, bool GLOBAL_ROWS, bool VTX>
 __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                    const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                    const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
                                                    int32_t dense_limit, const int32_t *__restrict__ order, int64_t first, int64_t end,
                                                    int nparts, int part, int dmax, int W, int WS, int WT, uint32_t *__restrict__ slabs,
-                                                   unsigned long long *__restrict__ acc) {
+                                                   unsigned long long *__restrict__ acc, const int32_t *__restrict__ oldid,
+                                                   unsigned long long *__restrict__ vcounts) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ unsigned long long red[16];
     __shared__ int wave_tot[16];
@@ -596,7 +611,54 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         } else {
             __syncthreads();
         }
-        if constexpr (LV == 2 && GLOBAL_ROWS) {
+        if constexpr (VTX) {
+            // per-vertex triangle counts (vertex_count2 = 2 x triangles at the vertex): a set bit (i, j) is the triangle
+            // (u, v_i, v_j).  Column sums with byte-sliced counters: lane = word (32 columns), eight registers of four 8-bit
+            // counters each, the rows split over the waves, flushed to LDS counters every 255 rows; then member t adds
+            // its row popcount and its column sum to counts[v_t] (one global atomic), the pivot gets the number of bits.
+            uint32_t *col = GLOBAL_ROWS ? reinterpret_cast<uint32_t *>(pre + kBitmapWords) + size_t(nwaves) * 4 * W
+                                        : reinterpret_cast<uint32_t *>(pre + kBitmapWords);
+            __shared__ uint32_t piv_sum;
+            for (int t = tid; t < d; t += nthreads) col[t] = 0;
+            if (tid == 0) piv_sum = 0;
+            __syncthreads();
+            const int Wd = (d + 31) >> 5;
+            for (int w0 = 0; w0 < Wd; w0 += 64) {
+                const int w = w0 + lane;
+                uint32_t r[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+                int since = 0;
+                for (int i = wave; i < d; i += nwaves) {
+                    const uint32_t x = w < Wd ? rows[size_t(i) * WS + w] : 0u;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) r[q] += (x >> q) & 0x01010101u;
+                    if (++since == 255 || i + nwaves >= d) {
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const uint32_t c = (r[q] >> (8 * b)) & 0xffu;
+                                if (c) atomicAdd(&col[(w << 5) + q + 8 * b], c);
+                            }
+                            r[q] = 0;
+                        }
+                        since = 0;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int t = tid; t < d; t += nthreads) {
+                uint32_t rp = 0;
+                const int nw = (t + 31) >> 5;  // row t has no bits at or above t
+                for (int w = 0; w < nw; ++w) rp += uint32_t(__popc(rows[size_t(t) * WS + w]));
+                const int32_t v = t < hc ? int32_t(hub_list[t]) : tail_list[t - hc];
+                const unsigned long long tot = (unsigned long long)rp + col[t];
+                if (tot) atomicAdd(&vcounts[oldid[v]], 2ull * tot);
+                if (rp) atomicAdd(&piv_sum, rp);
+                cnt += rp;
+            }
+            __syncthreads();
+            if (tid == 0 && piv_sum) atomicAdd(&vcounts[oldid[u]], 2ull * piv_sum);
+        } else if constexpr (LV == 2 && GLOBAL_ROWS) {
             // k = 4 on a slab matrix, by ROW BANDS: the rows j0 .. j0+JB-1 are staged in LDS (over the dead bitmap / stage
             // area), then every later row i (one per wave, its words in registers straight from the slab) meets its
             // neighbours inside the band.  JB = WT here (host-chosen so that JB x (W+1) words fit the LDS).
@@ -672,8 +734,9 @@ static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
     return span <= 0 ? 0 : (span + nparts - 1) / nparts;
 }
 
-template <int LV>
-static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long long *acc, int *launches, uint32_t **slab_out) {
+template <int LV, bool VTX = false>
+static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long long *acc, int *launches, uint32_t **slab_out,
+                      unsigned long long *vcounts = nullptr) {
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     const int k = LV + 2;
@@ -705,11 +768,11 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         uint32_t *slabs = nullptr;
         GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), std::max(slab_bytes[0], slab_bytes[1])));  // the launches run back to back
         *slab_out = slabs;
-        static bool l_attr[kMaxK] = {false};
-        if (!l_attr[LV]) {
-            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-            l_attr[LV] = true;
+        static bool l_attr[kMaxK + 1] = {false};
+        if (!l_attr[VTX ? kMaxK : LV]) {
+            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, true, VTX>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 2, true, VTX>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            l_attr[VTX ? kMaxK : LV] = true;
         }
         for (int b = 0; b < 2; ++b) {
             if (l_cnt[b] <= 0) continue;
@@ -718,21 +781,22 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             const int WT = dmax == 4096 ? 288 : 576;  // k = 4 row band: WT rows x (W+1) words of LDS (multiple of 32)
             size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(threads / 64) * 4 * W * 4;  // bitmap + prefix + row stage
             if (LV == 2) lds = std::max(lds, size_t(WT) * (W + 1) * 4);
+            if (VTX) lds += size_t(dmax) * 4;  // column counters
             if (b == 0)
-                hipLaunchKernelGGL((k_kc_block<LV, 2, true>), dim3(unsigned(l_blocks[b])), dim3(threads), lds, s, g->hoff, g->hadj, g->toff, g->tadj,
-                                   g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc);
+                hipLaunchKernelGGL((k_kc_block<LV, 2, true, VTX>), dim3(unsigned(l_blocks[b])), dim3(threads), lds, s, g->hoff, g->hadj, g->toff, g->tadj,
+                                   g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc, g->oldid, vcounts);
             else
-                hipLaunchKernelGGL((k_kc_block<LV, 1, true>), dim3(unsigned(l_blocks[b])), dim3(threads), lds, s, g->hoff, g->hadj, g->toff, g->tadj,
-                                   g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc);
+                hipLaunchKernelGGL((k_kc_block<LV, 1, true, VTX>), dim3(unsigned(l_blocks[b])), dim3(threads), lds, s, g->hoff, g->hadj, g->toff, g->tadj,
+                                   g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc, g->oldid, vcounts);
             ++*launches;
         }
     }
     // M: 32 < d+ <= 1024, bit-matrix in LDS; one launch per bin — the bins are cut where another workgroup fits a CU
-    static bool attr_set[kMaxK] = {false};
-    if (!attr_set[LV]) {
-        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false>),
+    static bool attr_set[kMaxK + 1] = {false};
+    if (!attr_set[VTX ? kMaxK : LV]) {
+        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        attr_set[LV] = true;
+        attr_set[VTX ? kMaxK : LV] = true;
     }
     const int m_dmax[] = {1024, 704, 512, 384, 256, 192, 128, 96, 64, 32};  // last entry = lower end of the last bin
     for (int b = 0; b + 1 < int(sizeof(m_dmax) / sizeof(int)); ++b) {
@@ -741,11 +805,11 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         if (int rc = range(m_dmax[b + 1], dmax, &lo, &hi)) return rc;
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (cnt > 0) {
-            const size_t lds = size_t(dmax) * WS * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2;
+            const size_t lds = size_t(dmax) * WS * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + (VTX ? size_t(dmax) * 4 : 0);
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
             const int threads = dmax >= 704 ? 1024 : dmax >= 384 ? 512 : 256;
-            hipLaunchKernelGGL((k_kc_block<LV, 1, false>), dim3(unsigned(blocks)), dim3(threads), lds, s, g->hoff, g->hadj, g->toff,
-                               g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc);
+            hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX>), dim3(unsigned(blocks)), dim3(threads), lds, s, g->hoff, g->hadj, g->toff,
+                               g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts);
             ++*launches;
         }
     }
@@ -756,8 +820,8 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, int64_t(cu) * 32);
-            hipLaunchKernelGGL(k_kc_small<LV>, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
-                               g->order, lo, hi, nparts, part, acc);
+            hipLaunchKernelGGL((k_kc_small<LV, VTX>), dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                               g->order, lo, hi, nparts, part, acc, g->oldid, vcounts);
             ++*launches;
         }
     }
@@ -805,6 +869,35 @@ static int kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uin
         float ms = 0.f;
         GMSX_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
         *st = gmsx_stats{double(ms), 0.0, uint64_t(part_count(0, g->n, nparts, part)), 0, 0, launches, 0};
+    }
+    return GMSX_OK;
+}
+
+// per-vertex counts through the k = 3 machinery (used by gmsx_tc_vertex_count2): vcounts is indexed by ORIGINAL vertex id
+int kclique_vertex_counts(const gmsx_graph *g, unsigned long long *d_counts, gmsx_stats *st) {
+    Ctx &c = ctx();
+    hipStream_t s = c.stream;
+    unsigned long long *acc = nullptr;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), sizeof(unsigned long long) * kAccSlots * kAccStride));
+    struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{acc};
+    uint32_t *slabs = nullptr;
+    GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * kAccSlots * kAccStride, s));
+    GMSX_HIP(hipEventRecord(c.ev[0], s));
+    int launches = 0;
+    const int rc = launch_all<1, true>(g, 0, 1, acc, &launches, &slabs, d_counts);
+    Guard slab_guard{slabs};
+    if (rc) return rc;
+    GMSX_HIP(hipEventRecord(c.ev[1], s));
+    GMSX_HIP(hipGetLastError());
+    unsigned long long host[kAccSlots * kAccStride];
+    GMSX_HIP(hipMemcpyAsync(host, acc, sizeof(host), hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipStreamSynchronize(s));
+    if (st) {
+        unsigned long long total = 0;
+        for (int i = 0; i < kAccSlots; ++i) total += host[i * kAccStride];
+        float ms = 0.f;
+        GMSX_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+        *st = gmsx_stats{double(ms), 0.0, uint64_t(g->n), total, 0, launches, 0};  // probes = triangles met
     }
     return GMSX_OK;
 }

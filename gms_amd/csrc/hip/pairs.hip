@@ -215,7 +215,13 @@ int gmsx_tc_vertex_count2(const gmsx_graph *g, int64_t *counts, gmsx_stats *stat
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_counts), sizeof(unsigned long long) * size_t(std::max<int64_t>(g->n, 1))));
     struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{d_counts};
     GMSX_HIP(hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * size_t(std::max<int64_t>(g->n, 1)), s));
-    if (int rc = run_edge_pairs(g, 1, 0, 1, nullptr, d_counts, stats)) return rc;
+    // oriented bit-matrix kernels (kclique.hip) when the graph fits them, else one full-row intersect_count per CSR entry
+    int rc = kclique_vertex_counts(g, d_counts, stats);
+    if (rc == GMSX_ERR_UNSUPPORTED) {
+        GMSX_HIP(hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * size_t(std::max<int64_t>(g->n, 1)), s));
+        rc = run_edge_pairs(g, 1, 0, 1, nullptr, d_counts, stats);
+    }
+    if (rc) return rc;
     if (g->n > 0) GMSX_HIP(hipMemcpy(counts, d_counts, sizeof(int64_t) * size_t(g->n), hipMemcpyDeviceToHost));
     return GMSX_OK;
 }
