@@ -96,9 +96,7 @@ __device__ __forceinline__ void bk_scan_row(const int64_t *__restrict__ hoff, co
     }
 }
 
-// per-LANE sequential scan of the oriented row of rank id a (the rows of the in-neighbours are short): eight hub ids per
-// 16-byte load, and the next load is issued before the current ids are probed, so the dependent chain of a lane is
-// one load round trip per 8 ids with the probes hidden behind it
+// two packed 16-bit ids of a 16-byte hub-container load
 struct __attribute__((packed, aligned(4))) bk_u4 { uint32_t x, y, z, w; };
 template <class F>
 __device__ __forceinline__ void bk_probe2(const unsigned long long *map, uint32_t mask, uint32_t pair, bool valid, F &f) {
@@ -106,30 +104,6 @@ __device__ __forceinline__ void bk_probe2(const unsigned long long *map, uint32_
     if (valid && w0 != 0xFFFFu) { const int k = bk_find(map, mask, int32_t(w0)); if (k >= 0) f(k); }
     if (valid && w1 != 0xFFFFu) { const int k = bk_find(map, mask, int32_t(w1)); if (k >= 0) f(k); }
 }
-template <class F>
-__device__ __forceinline__ void bk_scan_row_lane(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                 const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, int32_t a,
-                                                 const unsigned long long *map, uint32_t mask, F f) {
-    const int64_t hb = hoff[a], he = hoff[a + 1];  // even count, 4-byte aligned start
-    const int64_t tb = toff[a], te = toff[a + 1];
-    if (hb < he) {
-        bk_u4 p = *reinterpret_cast<const bk_u4 *>(hadj + hb);  // may run up to 6 ids past the row (hadj is padded): masked below
-        for (int64_t j = hb; j < he; j += 8) {
-            const bk_u4 cur = p;
-            if (j + 8 < he) p = *reinterpret_cast<const bk_u4 *>(hadj + j + 8);
-            const int64_t left = he - j;  // even, >= 2
-            bk_probe2(map, mask, cur.x, true, f);
-            bk_probe2(map, mask, cur.y, left > 2, f);
-            bk_probe2(map, mask, cur.z, left > 4, f);
-            bk_probe2(map, mask, cur.w, left > 6, f);
-        }
-    }
-    for (int64_t j = tb; j < te; ++j) {
-        const int k = bk_find(map, mask, tadj[j]);
-        if (k >= 0) f(k);
-    }
-}
-
 // 16-lane-group scan of the oriented row of rank id a: 16-byte loads of the hub container (8 ids per lane), the tail
 // container with a stride of 16
 template <class F>
@@ -149,6 +123,33 @@ __device__ __forceinline__ void bk_scan_row_group(const int64_t *__restrict__ ho
     for (int64_t j = tb + sub; j < te; j += 16) {
         const int k = bk_find(map, mask, tadj[j]);
         if (k >= 0) f(k);
+    }
+}
+
+// 8-lane-group scan of the oriented row of rank id a (rows of in-neighbours: ~d+avg ids): 16-byte loads of both
+// containers — 8 hub ids / 4 tail ids per lane and step — so the lanes of a group share one row instead of each
+// walking its own (a wave of single-row lanes idles behind its longest row)
+template <class F>
+__device__ __forceinline__ void bk_scan_row_group8(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, int32_t a,
+                                                   const unsigned long long *map, uint32_t mask, int sub, F f) {
+    const int64_t hb = hoff[a], he = hoff[a + 1];
+    const int64_t tb = toff[a], te = toff[a + 1];
+    for (int64_t j = hb + sub * 8; j < he; j += 64) {
+        const bk_u4 cur = *reinterpret_cast<const bk_u4 *>(hadj + j);
+        const int64_t left = he - j;  // even, >= 2
+        bk_probe2(map, mask, cur.x, true, f);
+        bk_probe2(map, mask, cur.y, left > 2, f);
+        bk_probe2(map, mask, cur.z, left > 4, f);
+        bk_probe2(map, mask, cur.w, left > 6, f);
+    }
+    for (int64_t j = tb + sub * 4; j < te; j += 32) {
+        const bk_u4 cur = *reinterpret_cast<const bk_u4 *>(tadj + j);  // tadj is padded by four ids
+        const int64_t left = te - j;  // >= 1
+        { const int k = bk_find(map, mask, int32_t(cur.x)); if (k >= 0) f(k); }
+        if (left > 1) { const int k = bk_find(map, mask, int32_t(cur.y)); if (k >= 0) f(k); }
+        if (left > 2) { const int k = bk_find(map, mask, int32_t(cur.z)); if (k >= 0) f(k); }
+        if (left > 3) { const int k = bk_find(map, mask, int32_t(cur.w)); if (k >= 0) f(k); }
     }
 }
 
@@ -390,6 +391,7 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
                                                 unsigned long long slab_words, unsigned long long *__restrict__ acc, BkShared sh) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_slab[LDS_SLAB ? kLdsSlabWords : 4];
     __shared__ unsigned char xfne_stack[2052];  // per level: is Xf non-empty (written by one lane, read by all)
+    __shared__ int32_t in_stage[64];             // build: the kept in-neighbours of one 64-entry batch, compacted
     // global-slab variant: the id -> index map of the build phase lives in LDS whenever it fits (c <= 512); the probes
     // of the in-neighbour rows are the long dependent chains of the build
     constexpr uint32_t kLdsMapSlots = 1024;
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
                 }
             }
         }
-        // rows of the in-neighbours: one lane per row (they are short); t = index of the in-neighbour in X0
+        // rows of the in-neighbours, 64 CSR entries per batch; t = index of the in-neighbour in X0
         int xbase = 0;
         for (int64_t e0 = ob; e0 < oe; e0 += 64) {
             const int64_t e = e0 + lane;
@@ -501,12 +503,20 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
                 keep = nw > v;
             }
             const unsigned long long m = __ballot(keep);
-            if (keep) {
-                const int t = xbase + __popcll(m & ((1ull << lane) - 1ull));
-                bk_scan_row_lane(hoff, hadj, toff, tadj, nw, map, mmask,
-                                 [&](int k) { atomicOr(&XT[size_t(k) * xw + (t >> 5)], 1u << (t & 31)); });
+            const int kept = __popcll(m);
+            // compact the kept in-neighbours of this batch, then eight rows per step, one per 8-lane group
+            __builtin_amdgcn_wave_barrier();
+            if (keep) in_stage[__popcll(m & ((1ull << lane) - 1ull))] = nw;
+            __builtin_amdgcn_wave_barrier();
+            for (int r0 = 0; r0 < kept; r0 += 8) {
+                const int r = r0 + (lane >> 3);
+                if (r < kept) {
+                    const int t = xbase + r;
+                    bk_scan_row_group8(hoff, hadj, toff, tadj, in_stage[r], map, mmask, lane & 7,
+                                       [&](int k) { atomicOr(&XT[size_t(k) * xw + (t >> 5)], 1u << (t & 31)); });
+                }
             }
-            xbase += __popcll(m);
+            xbase += kept;
         }
         if (!LDS_SLAB) {
             __threadfence();
