@@ -303,10 +303,10 @@ __device__ __forceinline__ unsigned long long kc4_row(const uint32_t (&wt)[WPL],
             const int j = (tj << 5) + pos;
             const int tmax = __builtin_amdgcn_readlane(tj, min(63, nb - c0 - 1));  // ranks ascend with the lane: the last active lane has the largest word index
             const uint32_t *rj = band + size_t(j - j0) * BS;
-            uint32_t acc = kc4_and_popc(wt[0], rj, min(tmax, 63) + 1);
-            if constexpr (WPL > 1) {
-                if (tmax >= 64) acc += kc4_and_popc(wt[1], rj + 64, tmax - 63);
-            }
+            uint32_t acc = 0;
+#pragma unroll
+            for (int g = 0; g < WPL; ++g)
+                if (tmax >= 64 * g) acc += kc4_and_popc(wt[g], rj + 64 * g, min(tmax - 64 * g, 63) + 1);
             if (act) total += acc;
         }
     }
@@ -673,16 +673,22 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                     band[r * BS + cw] = rows[size_t(j0 + r) * WS + cw];
                 }
                 __syncthreads();
+                const int jw0 = j0 >> 5, jwn = ((j1 + 31) >> 5) - jw0;  // the band's columns: at most JB / 32 <= 18 words
                 for (int i = j0 + 1 + wave; i < d; i += nwaves) {
+                    // a row without a neighbour inside the band is skipped after one short load (sparse matrices of large d)
+                    const uint32_t probe = lane < jwn ? rows[size_t(i) * WS + jw0 + lane] : 0u;
+                    if (__ballot(probe != 0) == 0) continue;
                     uint32_t wt[WPL];
-                    wt[0] = lane < W ? rows[size_t(i) * WS + lane] : 0u;
-                    if constexpr (WPL > 1) wt[1] = 64 + lane < W ? rows[size_t(i) * WS + 64 + lane] : 0u;
+#pragma unroll
+                    for (int h = 0; h < WPL; ++h) wt[h] = 64 * h + lane < W ? rows[size_t(i) * WS + 64 * h + lane] : 0u;
                     cnt += kc4_row<WPL>(wt, band, BS, j0, j0 >> 5, (j1 + 31) >> 5, lane);
                 }
             }
         } else if constexpr (LV == 1) {
             // k = 3: Σ_i popc(rows[i]) — one lane per matrix word
             for (int cell = tid; cell < d * W; cell += nthreads) cnt += (unsigned long long)__popc(rows[size_t(cell / W) * WS + cell % W]);
+        } else if constexpr (LV >= 3 && WPL > 2) {
+            // not instantiated by the host (k >= 5 stops at d+ = 4096)
         } else if (LV >= 3 && W > 8) {
             // deep recursion on wide rows: wave-cooperative (one word per lane, the candidate set of every level is kept),
             // which reads each row word once per visited node instead of re-ANDing the whole path
@@ -741,8 +747,9 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     hipStream_t s = c.stream;
     const int k = LV + 2;
     int64_t over = 0, n_min = 0;
-    if (int rc = count_dplus_ge(g, 4097, &over)) return rc;
-    if (over > 0) return GMSX_ERR_UNSUPPORTED;  // d+ > 4096: beyond the widest bit rows of this build
+    constexpr int kMaxD = (LV <= 2) ? 8192 : 4096;  // widest bit rows: four words per lane for k = 3, 4 and the per-vertex counts, two for k >= 5
+    if (int rc = count_dplus_ge(g, kMaxD + 1, &over)) return rc;
+    if (over > 0) return GMSX_ERR_UNSUPPORTED;
     if (!g->rows_sorted) return GMSX_ERR_UNSUPPORTED;  // > 2^32 container entries: rows were not sorted at upload
     if (int rc = count_dplus_ge(g, std::max(k - 1, 1), &n_min)) return rc;
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
@@ -754,35 +761,42 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         return GMSX_OK;
     };
 
-    // L: 1024 < d+ <= 4096, bit-matrix in a global slab per workgroup; two launches (one / two words per lane)
-    size_t slab_bytes[2] = {0, 0};
-    int64_t l_lo[2], l_hi[2], l_cnt[2], l_blocks[2];
-    const int l_dmax[2] = {4096, 2048};
-    for (int b = 0; b < 2; ++b) {
+    // L: 1024 < d+ <= 4096 (8192 for k <= 4), bit-matrix in a global slab per workgroup; one launch per row width (one / two / four words per lane)
+    constexpr int NL = (LV <= 2) ? 3 : 2;
+    size_t slab_bytes[3] = {0, 0, 0};
+    int64_t l_lo[3], l_hi[3], l_cnt[3] = {0, 0, 0}, l_blocks[3];
+    const int l_dmax[3] = {4096, 2048, 8192};
+    for (int b = 0; b < NL; ++b) {
         if (int rc = range(l_dmax[b] / 2, l_dmax[b], &l_lo[b], &l_hi[b])) return rc;
         l_cnt[b] = part_count(l_lo[b], l_hi[b], nparts, part);
         l_blocks[b] = std::min<int64_t>(l_cnt[b], cu);  // one workgroup per CU: the LDS tile / stage fills it
         if (l_cnt[b] > 0) slab_bytes[b] = size_t(l_blocks[b]) * l_dmax[b] * (l_dmax[b] / 32 + 1) * sizeof(uint32_t);
     }
-    if (slab_bytes[0] + slab_bytes[1] > 0) {
+    if (slab_bytes[0] + slab_bytes[1] + slab_bytes[2] > 0) {
         uint32_t *slabs = nullptr;
-        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), std::max(slab_bytes[0], slab_bytes[1])));  // the launches run back to back
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), std::max({slab_bytes[0], slab_bytes[1], slab_bytes[2]})));  // the launches run back to back
         *slab_out = slabs;
         static bool l_attr[kMaxK + 1] = {false};
         if (!l_attr[VTX ? kMaxK : LV]) {
             GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, true, VTX>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
             GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 2, true, VTX>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            if constexpr (LV <= 2)
+                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 4, true, VTX>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
             l_attr[VTX ? kMaxK : LV] = true;
         }
-        for (int b = 0; b < 2; ++b) {
+        for (int b = 0; b < NL; ++b) {
             if (l_cnt[b] <= 0) continue;
             const int dmax = l_dmax[b], W = dmax / 32, WS = W + 1;
             const int threads = LV == 2 ? 1024 : 512;
-            const int WT = dmax == 4096 ? 288 : 576;  // k = 4 row band: WT rows x (W+1) words of LDS (multiple of 32)
+            const int WT = dmax == 8192 ? 128 : dmax == 4096 ? 288 : 576;  // k = 4 row band: WT rows x (W+1) words of LDS (multiple of 32)
             size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(threads / 64) * 4 * W * 4;  // bitmap + prefix + row stage
             if (LV == 2) lds = std::max(lds, size_t(WT) * (W + 1) * 4);
             if (VTX) lds += size_t(dmax) * 4;  // column counters
-            if (b == 0)
+            if (b == 2) {
+                if constexpr (LV <= 2)
+                    hipLaunchKernelGGL((k_kc_block<LV, 4, true, VTX>), dim3(unsigned(l_blocks[b])), dim3(threads), lds, s, g->hoff, g->hadj, g->toff, g->tadj,
+                                       g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc, g->oldid, vcounts);
+            } else if (b == 0)
                 hipLaunchKernelGGL((k_kc_block<LV, 2, true, VTX>), dim3(unsigned(l_blocks[b])), dim3(threads), lds, s, g->hoff, g->hadj, g->toff, g->tadj,
                                    g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc, g->oldid, vcounts);
             else

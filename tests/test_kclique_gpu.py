@@ -107,7 +107,9 @@ def test_dense_random_graph_large_out_degrees(gpu):
     iu = np.nonzero(np.triu(A, 1))
     csr = gpu.HostCSR.from_edges(iu[0].astype(np.int32), iu[1].astype(np.int32))
     Af = A.astype(np.float32)
-    tri = int(round(float(np.einsum("ij,ij->", Af @ Af, Af, dtype=np.float64)))) // 6
+    A2A = (Af @ Af) * Af
+    tri = int(round(float(A2A.sum(dtype=np.float64)))) // 6
+    per_vertex = np.rint(A2A.sum(axis=1, dtype=np.float64)).astype(np.int64)  # vertex ids survive from_edges (no relabelling there)
     k4 = 0
     for a in range(n):
         nb = np.nonzero(A[a])[0]
@@ -123,4 +125,48 @@ def test_dense_random_graph_large_out_degrees(gpu):
         assert g.kclique_count(3)[1] == tri
         assert g.kclique_count(4)[1] == k4
         assert sum(g.kclique_partial(4, q, 3) for q in range(3)) == k4
+        # per-vertex counts run on the same bit-matrices (row popcounts + column sums): counts[u] = Σ_v A²[u,v]·A[u,v]
+        assert np.array_equal(g.tc_vertex_count2(), per_vertex)
         g.free()
+
+
+def test_out_degrees_above_4096(gpu):
+    """Pivots with 4096 < d+ <= 8192 (four-words-per-lane slab kernel, k <= 4 and the per-vertex counts).  K_{a,b} plus a sparse
+    random graph H inside side A: every B vertex sees all of A as higher-ranked neighbours (d+ = a > 4096), triangles are
+    T(H) + b·|E(H)|, 4-cliques K4(H) + b·T(H); k = 5 is beyond the two-word rows of the deeper recursion: UNSUPPORTED."""
+    a, b, eh = 4200, 4300, 20000
+    rng = np.random.default_rng(11)
+    hu, hv = rng.integers(0, a, eh), rng.integers(0, a, eh)
+    keep = hu != hv
+    H = np.zeros((a, a), dtype=bool)
+    H[hu[keep], hv[keep]] = True
+    H = H | H.T
+    hi = np.nonzero(np.triu(H, 1))
+    Hf = H.astype(np.float32)
+    H2 = (Hf @ Hf) * Hf
+    th = int(round(float(H2.sum(dtype=np.float64)))) // 6
+    k4h = 0
+    for x in np.nonzero(H.any(axis=1))[0]:
+        nb = np.nonzero(H[x])[0]
+        nb = nb[nb > x]
+        if len(nb) >= 3:
+            S = Hf[np.ix_(nb, nb)]
+            k4h += int(round(float(((S @ S) * S).sum(dtype=np.float64)))) // 6
+    bu, bv = np.meshgrid(np.arange(a, dtype=np.int32), np.arange(a, a + b, dtype=np.int32), indexing="ij")
+    src = np.concatenate([bu.ravel(), hi[0].astype(np.int32)])
+    dst = np.concatenate([bv.ravel(), hi[1].astype(np.int32)])
+    g = gpu.DeviceGraph.from_csr(gpu.HostCSR.from_edges(src, dst))
+    assert 4096 < g.max_out_degree <= 8192
+    eh_real = len(hi[0])
+    tri = th + b * eh_real
+    assert g.tc_total() == tri
+    assert g.kclique_count(3)[1] == tri
+    assert g.kclique_count(4)[1] == k4h + b * th
+    per_vertex = np.zeros(a + b, dtype=np.int64)
+    per_vertex[:a] = np.rint(H2.sum(axis=1, dtype=np.float64)).astype(np.int64) + 2 * b * H.sum(axis=1)  # 2 x (triangles in H + b per H-edge at the vertex)
+    per_vertex[a:] = 2 * eh_real
+    assert np.array_equal(g.tc_vertex_count2(), per_vertex)
+    with pytest.raises(gpu.GmsxError) as ei:
+        g.kclique_count(5)
+    assert ei.value.status == gpu.ERR_UNSUPPORTED
+    g.free()
