@@ -761,6 +761,19 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         return GMSX_OK;
     };
 
+    // Two streams: the wide bins (slab, 1024, 704: one or two workgroups per CU, LDS-bound occupancy) on the caller's
+    // stream, the narrow bins and the wave kernel on a side stream — their small workgroups fill the wave slots and the
+    // LDS the wide ones leave free.  All kernels add into the same accumulators; the side stream is joined below.
+    static hipStream_t side = nullptr;
+    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    if (!side) {
+        GMSX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        GMSX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        GMSX_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    GMSX_HIP(hipEventRecord(ev_fork, s));
+    GMSX_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+
     // L: 1024 < d+ <= 4096 (8192 for k <= 4), bit-matrix in a global slab per workgroup; one launch per row width (one / two / four words per lane)
     constexpr int NL = (LV <= 2) ? 3 : 2;
     size_t slab_bytes[3] = {0, 0, 0};
@@ -822,7 +835,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             const size_t lds = size_t(dmax) * WS * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + (VTX ? size_t(dmax) * 4 : 0);
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
             const int threads = dmax >= 704 ? 1024 : dmax >= 384 ? 512 : 256;
-            hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX>), dim3(unsigned(blocks)), dim3(threads), lds, s, g->hoff, g->hadj, g->toff,
+            hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX>), dim3(unsigned(blocks)), dim3(threads), lds, dmax >= 704 ? s : side, g->hoff, g->hadj, g->toff,
                                g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts);
             ++*launches;
         }
@@ -834,11 +847,13 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, int64_t(cu) * 32);
-            hipLaunchKernelGGL((k_kc_small<LV, VTX>), dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+            hipLaunchKernelGGL((k_kc_small<LV, VTX>), dim3(unsigned(blocks)), dim3(256), 0, side, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
                                g->order, lo, hi, nparts, part, acc, g->oldid, vcounts);
             ++*launches;
         }
     }
+    GMSX_HIP(hipEventRecord(ev_join, side));
+    GMSX_HIP(hipStreamWaitEvent(s, ev_join, 0));
     return GMSX_OK;
 }
 
