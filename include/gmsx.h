@@ -154,7 +154,9 @@ int gmsx_tc_total(const gmsx_graph *g, int algo, uint64_t *triangles, gmsx_stats
  * all-reduce of SURVEY §8(e) (the OpenMP reduction(+:total) of parallel/total.h:12). */
 int gmsx_tc_partial(const gmsx_graph *g, int algo, int part, int nparts, uint64_t *partial, gmsx_stats *stats);
 int gmsx_tc_divisor(int algo); /* 1 for ORIENTED/AUTO, 3 for FULL */
-/* Par::vertex_count2 / vertex_count2_once (parallel/vertex.h:14-49): counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| (= 2·triangles at u). */
+/* Par::vertex_count2 / vertex_count2_once (parallel/vertex.h:14-49): counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| (= 2·triangles at u),
+ * indexed by the vertex ids of the uploaded CSR.  Runs on the k = 3 bit-matrix kernels (one atomic per pivot member); graphs
+ * with d+ > 8192 fall back to one full-row intersect_count per CSR entry. */
 int gmsx_tc_vertex_count2(const gmsx_graph *g, int64_t *counts /* n, host */, gmsx_stats *stats);
 
 /* ---- generic batched Set::intersect_count (sorted_set.h:176-182 / roaring_set.h:144-152) over graph rows:
@@ -175,14 +177,17 @@ int gmsx_vertex_similarity_batch(const gmsx_graph *g, int metric, int64_t n_pair
                                  double *out, gmsx_stats *stats);
 
 /* ---- k-clique counting: CliqueCount (k_clique_count/k_clique_count_set_based.h:19-31).
- * *ordered_count = the reference's return value k!·C_k (mod 2^64, like size_t); *cliques = C_k (may be NULL). */
+ * *ordered_count = the reference's return value k!·C_k (mod 2^64, like size_t); *cliques = C_k (may be NULL).
+ * k = 2 … 10.  Limits of the bit-matrix kernels: oriented out-degree d+ <= 8192 for k <= 4, <= 4096 for k >= 5; beyond them
+ * (and for k > 10) the call returns GMSX_ERR_UNSUPPORTED and computes nothing.  (RMAT scale 26: max d+ = 3004.) */
 int gmsx_kclique_count(const gmsx_graph *g, int k, uint64_t *ordered_count, uint64_t *cliques, gmsx_stats *stats);
 int gmsx_kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint64_t *cliques_partial, gmsx_stats *stats);
 
 /* ---- Bron–Kerbosch maximal-clique count: BkEppsteinPar::mceBench with -DBK_COUNT
  * (maximal_clique_enum/parallel/eppsteinPAR.h:18-53 over sequential/tomita.h:12-86).
  * rank: n entries in rank format, or NULL → degree rank (preprocessing/parallel/degree.h:26-62).
- * The count does not depend on the rank. */
+ * The count does not depend on the rank.  Limit: a start vertex may have at most 2048 candidates (d+ <= 2048 in the device's
+ * degree rank), else GMSX_ERR_UNSUPPORTED. */
 int gmsx_bk_count(const gmsx_graph *g, const int32_t *rank, uint64_t *maximal_cliques, gmsx_stats *stats);
 int gmsx_bk_partial(const gmsx_graph *g, const int32_t *rank, int part, int nparts, uint64_t *partial, gmsx_stats *stats);
 
