@@ -26,6 +26,7 @@ namespace gmsx {
 
 static constexpr int kLdsSlabWords = 4096;  // 16 KB per wave
 static constexpr unsigned long long kEmptySlot = ~0ull;
+static constexpr unsigned long long kWideTask = 1ull << 62;  // task key flag: more than 2048 candidates
 
 __host__ __device__ inline uint32_t bk_map_size(int c) {
     uint32_t s = 64;
@@ -41,7 +42,7 @@ __host__ __device__ inline unsigned long long bk_slab_words(int c, long long x) 
 // per start vertex: slab requirement (0 = no search needed); isolated vertices are counted right here
 __global__ void k_bk_tasks(int64_t n, const int64_t *__restrict__ off, const int32_t *__restrict__ oldid,
                            const int32_t *__restrict__ dplus, unsigned long long *__restrict__ keys, int32_t *__restrict__ vals,
-                           unsigned long long *__restrict__ acc /* [0] isolated count, [1] too-wide flag */) {
+                           unsigned long long *__restrict__ acc /* [0] isolated count, [1] too-wide flag, [7] tasks with > 2048 candidates */) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v >= n) return;
     const int32_t o = oldid[v];
@@ -53,7 +54,11 @@ __global__ void k_bk_tasks(int64_t n, const int64_t *__restrict__ off, const int
         if (deg == 0) atomicAdd(&acc[0], 1ull);  // an isolated vertex is a maximal clique (eppsteinPAR.h:32-47, tomita.h:73-78)
     } else {
         w = bk_slab_words(c, x);
-        if (c > 2048) atomicOr(&acc[1], 1ull);
+        if (c > 4096) atomicOr(&acc[1], 1ull);
+        if (c > 2048) {  // two words per lane: these tasks sort first and run on the WPL = 2 kernels
+            w |= kWideTask;
+            atomicAdd(&acc[7], 1ull);
+        }
     }
     keys[v] = w;
     vals[v] = int32_t(v);
@@ -183,51 +188,73 @@ struct BkShared {
 static constexpr int kRecHeader = 8;  // v, c, x, xf_ne, arena offset (2 words), 2 spare
 static constexpr unsigned long long kNoArena = ~0ull;
 
-// Iterative Tomita recursion on bitmaps, resumable.  Registers: this lane's word of P / Xc / ext (lanes >= cw hold 0);
-// Xf levels and the saved words of the ancestors live in `stack` (level l at stack + l*lvl: P, Xc, ext, Xf).
+// Iterative Tomita recursion on bitmaps, resumable.  Registers: this lane's WPL words of P / Xc / ext (word lane + 64 h;
+// words >= cw hold 0; WPL = 1 up to 2048 candidates, 2 up to 4096); Xf levels and the saved words of the ancestors live in
+// `stack` (level l at stack + l*lvl: P, Xc, ext, Xf).
 // `structs`/`struct_words`: where Cadj|XT currently live (for the copy to the arena); arena_off: kNoArena until copied.
+template <int WPL>
 __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *XT, uint32_t *stack, unsigned char *xfne_stack,
-                                          int32_t v, int c, int x, uint32_t P, uint32_t Xc, uint32_t ext, int xf_ne, bool entering,
-                                          int lane, unsigned long long &cnt, const BkShared &sh, unsigned long long arena_off,
-                                          bool global_structs, uint32_t *piv_P /* LDS, 64 words: the current P for all lanes */,
-                                          unsigned short *piv_list /* LDS, 2048 entries: members of P ∪ Xc */) {
+                                          int32_t v, int c, int x, uint32_t (&P)[WPL], uint32_t (&Xc)[WPL], uint32_t (&ext)[WPL], int xf_ne,
+                                          bool entering, int lane, unsigned long long &cnt, const BkShared &sh, unsigned long long arena_off,
+                                          bool global_structs, uint32_t *piv_P /* LDS, 64*WPL words: the current P for all lanes */,
+                                          unsigned short *piv_list /* LDS, 2048*WPL entries: members of P ∪ Xc */) {
     const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
     const int lvl = 3 * cw + xw + 1;
     unsigned budget = sh.budget, nodes = 0;
     int depth = 0;
+    auto any_of = [](const uint32_t (&a)[WPL]) {
+        uint32_t r = a[0];
+#pragma unroll
+        for (int h = 1; h < WPL; ++h) r |= a[h];
+        return r;
+    };
+    auto pop_level = [&](const uint32_t *lv) {
+#pragma unroll
+        for (int h = 0; h < WPL; ++h) {
+            const int w = lane + 64 * h;
+            P[h] = w < cw ? lv[w] : 0u;
+            Xc[h] = w < cw ? lv[cw + w] : 0u;
+            ext[h] = w < cw ? lv[2 * cw + w] : 0u;
+        }
+    };
     while (true) {
         if (entering) {
             ++nodes;
-            if (__ballot(P != 0) == 0) {
-                if (__ballot(Xc != 0) == 0 && !xf_ne) cnt++;
+            if (__ballot(any_of(P) != 0) == 0) {
+                if (__ballot(any_of(Xc) != 0) == 0 && !xf_ne) cnt++;
                 entering = false;
                 if (depth == 0) break;
                 --depth;  // pop
-                uint32_t *lv = stack + size_t(depth) * lvl;
-                P = lane < cw ? lv[lane] : 0u;
-                Xc = lane < cw ? lv[cw + lane] : 0u;
-                ext = lane < cw ? lv[2 * cw + lane] : 0u;
+                pop_level(stack + size_t(depth) * lvl);
                 xf_ne = int(xfne_stack[depth]);
                 continue;
             }
             // pivot: argmax over u in P ∪ Xc of |P ∩ N(u)|.  One LANE per candidate: P is parked in LDS, the members of
             // P ∪ Xc are expanded into an LDS list (wave prefix sum of the per-word popcounts), then every lane scores its
             // own candidates with independent row loads (64 rows in flight instead of one dependent load per candidate).
-            const uint32_t U = P | Xc;
-            if (lane < cw) piv_P[lane] = P;
-            int pre = __popc(U);
-            const int mine = pre;
+            uint32_t U[WPL];
+            int mine = 0;
+#pragma unroll
+            for (int h = 0; h < WPL; ++h) {
+                U[h] = P[h] | Xc[h];
+                mine += __popc(U[h]);
+                if (lane + 64 * h < cw) piv_P[lane + 64 * h] = P[h];
+            }
+            int pre = mine;
             for (int sft = 1; sft < 64; sft <<= 1) {
                 const int o = __shfl_up(pre, sft);
                 if (lane >= sft) pre += o;
             }
-            const int ncand = __shfl(pre, 63);
+            const int ncand = __builtin_amdgcn_readlane(pre, 63);
             {
                 int at = pre - mine;
-                uint32_t bits = U;
-                while (bits) {
-                    piv_list[at++] = (unsigned short)((lane << 5) + __ffs(bits) - 1);
-                    bits &= bits - 1;
+#pragma unroll
+                for (int h = 0; h < WPL; ++h) {
+                    uint32_t bits = U[h];
+                    while (bits) {
+                        piv_list[at++] = (unsigned short)(((lane + 64 * h) << 5) + __ffs(bits) - 1);
+                        bits &= bits - 1;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -250,19 +277,27 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            const uint32_t prow = lane < cw ? Cadj[size_t(best) * cw + lane] : 0u;
-            ext = P & ~prow;
+            best = uni32(best);  // every lane holds the same winner
+#pragma unroll
+            for (int h = 0; h < WPL; ++h) {
+                const int w = lane + 64 * h;
+                const uint32_t prow = w < cw ? Cadj[size_t(best) * cw + w] : 0u;
+                ext[h] = P[h] & ~prow;
+            }
             entering = false;
         }
         // next branch vertex q of this node
-        const unsigned long long nz = __ballot(ext != 0);
-        if (!nz) {
+        unsigned long long nzh[WPL];
+        unsigned long long nz_any = 0;
+#pragma unroll
+        for (int h = 0; h < WPL; ++h) {
+            nzh[h] = __ballot(ext[h] != 0);
+            nz_any |= nzh[h];
+        }
+        if (!nz_any) {
             if (depth == 0) break;
             --depth;  // pop
-            uint32_t *lv = stack + size_t(depth) * lvl;
-            P = lane < cw ? lv[lane] : 0u;
-            Xc = lane < cw ? lv[cw + lane] : 0u;
-            ext = lane < cw ? lv[2 * cw + lane] : 0u;
+            pop_level(stack + size_t(depth) * lvl);
             xf_ne = int(xfne_stack[depth]);
             continue;
         }
@@ -273,7 +308,7 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                 const unsigned long long need = ((unsigned long long)c * cw + (unsigned long long)c * xw + 3ull) & ~3ull;
                 unsigned long long off0 = 0;
                 if (lane == 0) off0 = atomicAdd(sh.arena_head, need);
-                off0 = (unsigned long long)__shfl((long long)off0, 0);
+                off0 = uni64(off0);
                 if (off0 + need > sh.arena_cap) ok = false;
                 else {
                     for (unsigned long long i = lane; i < (unsigned long long)c * cw + (unsigned long long)c * xw; i += 64)
@@ -285,16 +320,21 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
             if (ok) {
                 // levels 0..depth-1 are in the stack, level `depth` is in registers: spill it so all look alike
                 uint32_t *cur = stack + size_t(depth) * lvl;
-                if (lane < cw) {
-                    cur[lane] = P;
-                    cur[cw + lane] = Xc;
-                    cur[2 * cw + lane] = ext;
+#pragma unroll
+                for (int h = 0; h < WPL; ++h) {
+                    const int w = lane + 64 * h;
+                    if (w < cw) {
+                        cur[w] = P[h];
+                        cur[cw + w] = Xc[h];
+                        cur[2 * cw + w] = ext[h];
+                    }
                 }
                 if (lane == 0) xfne_stack[depth] = (unsigned char)xf_ne;
                 if (global_structs) __threadfence();
                 __builtin_amdgcn_wave_barrier();
                 for (int l = 0; l <= depth; ++l) {
-                    const uint32_t e = lane < cw ? stack[size_t(l) * lvl + 2 * cw + lane] : 0u;
+                    uint32_t e = 0;
+                    for (int w = lane; w < cw; w += 64) e |= stack[size_t(l) * lvl + 2 * cw + w];
                     if (__ballot(e != 0)) ++nrec;
                 }
                 const unsigned long long rec_words = (unsigned long long)(kRecHeader + 3 * cw + xw);
@@ -303,15 +343,16 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                     p0 = atomicAdd(sh.pool_head, rec_words * nrec);
                     if (p0 + rec_words * nrec <= sh.pool_cap) d0 = atomicAdd(sh.dir_count, (unsigned long long)nrec);
                 }
-                p0 = (unsigned long long)__shfl((long long)p0, 0);
-                d0 = (unsigned long long)__shfl((long long)d0, 0);
+                p0 = uni64(p0);
+                d0 = uni64(d0);
                 if (p0 + rec_words * nrec > sh.pool_cap || d0 + nrec > sh.dir_cap) {
                     ok = false;  // directory slots that were claimed but not written keep their ~0 fill and are skipped
                 } else {
                     int r = 0;
                     for (int l = 0; l <= depth; ++l) {
                         const uint32_t *lv = stack + size_t(l) * lvl;
-                        const uint32_t e = lane < cw ? lv[2 * cw + lane] : 0u;
+                        uint32_t e = 0;
+                        for (int w = lane; w < cw; w += 64) e |= lv[2 * cw + w];
                         if (!__ballot(e != 0)) continue;
                         uint32_t *rec = sh.pool + p0 + rec_words * r;
                         if (lane == 0) {
@@ -324,11 +365,7 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                             rec[6] = rec[7] = 0;
                             sh.dir[d0 + r] = p0 + rec_words * r;
                         }
-                        if (lane < cw) {
-                            rec[kRecHeader + lane] = lv[lane];
-                            rec[kRecHeader + cw + lane] = lv[cw + lane];
-                            rec[kRecHeader + 2 * cw + lane] = e;
-                        }
+                        for (int w = lane; w < 3 * cw; w += 64) rec[kRecHeader + w] = lv[w];  // P | Xc | ext
                         for (int w = lane; w < xw; w += 64) rec[kRecHeader + 3 * cw + w] = lv[3 * cw + w];
                         ++r;
                     }
@@ -338,12 +375,25 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
             if (ok) return;          // the rest of this search belongs to the next round
             budget = 0xffffffffu;    // no room: finish it here
         }
-        const int L = __ffsll((long long)nz) - 1;
-        const uint32_t word = __builtin_amdgcn_readlane(ext, L);
+        int hsel = 0;
+#pragma unroll
+        for (int h = WPL - 1; h >= 0; --h)
+            if (nzh[h]) hsel = h;  // wave-uniform: the first word group with a branch vertex
+        const int L = __ffsll((long long)nzh[hsel]) - 1;
+        uint32_t word = 0;
+#pragma unroll
+        for (int h = 0; h < WPL; ++h)
+            if (h == hsel) word = __builtin_amdgcn_readlane(ext[h], L);
         const int bit = __ffs(word) - 1;
-        const int q = (L << 5) + bit;
-        const uint32_t qrow = lane < cw ? Cadj[size_t(q) * cw + lane] : 0u;
-        const uint32_t Pn = P & qrow, Xcn = Xc & qrow;
+        const int q = ((L + 64 * hsel) << 5) + bit;
+        uint32_t Pn[WPL], Xcn[WPL];
+#pragma unroll
+        for (int h = 0; h < WPL; ++h) {
+            const int w = lane + 64 * h;
+            const uint32_t qrow = w < cw ? Cadj[size_t(q) * cw + w] : 0u;
+            Pn[h] = P[h] & qrow;
+            Xcn[h] = Xc[h] & qrow;
+        }
         uint32_t *lv = stack + size_t(depth) * lvl;
         uint32_t *nx = lv + lvl;
         int child_ne = 0;
@@ -358,21 +408,28 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
             child_ne = __ballot(any != 0) != 0 ? 1 : 0;
         }
         // this node continues with q moved from cand to fini (tomita.h:68-70)
-        if (lane == L) {
-            ext &= ~(1u << bit);
-            P &= ~(1u << bit);
-            Xc |= 1u << bit;
-        }
-        if (lane < cw) {
-            lv[lane] = P;
-            lv[cw + lane] = Xc;
-            lv[2 * cw + lane] = ext;
+#pragma unroll
+        for (int h = 0; h < WPL; ++h) {
+            if (h == hsel && lane == L) {
+                ext[h] &= ~(1u << bit);
+                P[h] &= ~(1u << bit);
+                Xc[h] |= 1u << bit;
+            }
+            const int w = lane + 64 * h;
+            if (w < cw) {
+                lv[w] = P[h];
+                lv[cw + w] = Xc[h];
+                lv[2 * cw + w] = ext[h];
+            }
         }
         if (lane == 0) xfne_stack[depth] = (unsigned char)xf_ne;
         __builtin_amdgcn_wave_barrier();
         ++depth;
-        P = Pn;
-        Xc = Xcn;
+#pragma unroll
+        for (int h = 0; h < WPL; ++h) {
+            P[h] = Pn[h];
+            Xc[h] = Xcn[h];
+        }
         xf_ne = child_ne;
         entering = true;
     }
@@ -380,7 +437,7 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
 
 // Round 0: one wave per start vertex.  LDS_SLAB: every structure of the search lives in this wave's LDS slab (tasks of
 // at most kLdsSlabWords words); otherwise in slabs[block * slab_words].
-template <bool LDS_SLAB>
+template <bool LDS_SLAB, int WPL>
 __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                 const int32_t *__restrict__ newid, const int32_t *__restrict__ oldid,
                                                 const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
@@ -390,13 +447,14 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
                                                 unsigned long long *__restrict__ queue, uint32_t *__restrict__ slabs,
                                                 unsigned long long slab_words, unsigned long long *__restrict__ acc, BkShared sh) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_slab[LDS_SLAB ? kLdsSlabWords : 4];
-    __shared__ unsigned char xfne_stack[2052];  // per level: is Xf non-empty (written by one lane, read by all)
+    __shared__ unsigned char xfne_stack[2052 * WPL];  // per level: is Xf non-empty (written by one lane, read by all)
     __shared__ int32_t in_stage[64];             // build: the kept in-neighbours of one 64-entry batch, compacted
     // global-slab variant: the id -> index map of the build phase lives in LDS whenever it fits (c <= 512); the probes
     // of the in-neighbour rows are the long dependent chains of the build
     constexpr uint32_t kLdsMapSlots = 1024;
     // one 8.25 KB LDS work area: the build's id -> index map (global-slab variant), then the search's pivot scratch
-    __shared__ __attribute__((aligned(16))) uint32_t lds_work[(LDS_SLAB ? 1024 : 2 * kLdsMapSlots) + 64];
+    static_assert(!LDS_SLAB || WPL == 1, "LDS-slab tasks are tiny");
+    __shared__ __attribute__((aligned(16))) uint32_t lds_work[(LDS_SLAB ? 1024 : 2 * kLdsMapSlots) + 64 * WPL];  // piv_list: 2048*WPL u16 fit the map area
     unsigned long long *lds_map = reinterpret_cast<unsigned long long *>(lds_work);
     uint32_t *piv_P = lds_work + (LDS_SLAB ? 1024 : 2 * kLdsMapSlots);
     unsigned short *piv_list = reinterpret_cast<unsigned short *>(lds_work);
@@ -406,13 +464,13 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
     while (true) {
         unsigned long long q0 = 0;
         if (lane == 0) q0 = atomicAdd(queue, 1ull);
-        const int64_t qi = int64_t(__shfl(q0, 0));
+        const int64_t qi = int64_t(uni64(q0));
         const int64_t pos = first + qi * nparts + part;
         if (pos >= end) break;
-        const int32_t v = task_v[pos];
-        const int32_t vo = oldid[v];
-        const int c = dplus[v];
-        const int64_t ob = off[vo], oe = off[vo + 1];
+        const int32_t v = uni32(task_v[pos]);
+        const int32_t vo = uni32(oldid[v]);
+        const int c = uni32(dplus[v]);
+        const int64_t ob = uni64(off[vo]), oe = uni64(off[vo + 1]);
         const int x = int(oe - ob) - c;
         const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
         const uint32_t msize = bk_map_size(c), mmask = msize - 1;
@@ -435,9 +493,9 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
         }
         if (!LDS_SLAB) __threadfence();
         __builtin_amdgcn_wave_barrier();
-        const int64_t hb = hoff[v], tb = toff[v];
-        int hc = int(hoff[v + 1] - hb);
-        if (hc > 0 && hadj[hb + hc - 1] == 0xFFFFu) --hc;
+        const int64_t hb = uni64(hoff[v]), tb = uni64(toff[v]);
+        int hc = int(uni64(hoff[v + 1]) - hb);
+        if (hc > 0 && uni32(uint32_t(hadj[hb + hc - 1])) == 0xFFFFu) --hc;
         for (int i = lane; i < c; i += 64) {
             const int32_t a = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
             uint32_t h = bk_hash(a, mmask);
@@ -525,53 +583,64 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
         __builtin_amdgcn_wave_barrier();
 
         // ---- search from the root: P = C, Xc = {}, Xf = X0 ------------------------------------------------------
-        uint32_t P = 0;
-        if (lane < cw) {
-            const int bits = c - lane * 32;
-            P = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+        uint32_t P[WPL], Xc[WPL], ext[WPL];
+#pragma unroll
+        for (int h = 0; h < WPL; ++h) {
+            const int w = lane + 64 * h;
+            P[h] = Xc[h] = ext[h] = 0u;
+            if (w < cw) {
+                const int bits = c - w * 32;
+                P[h] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+            }
         }
         for (int w = lane; w < xw; w += 64) {
             const int bits = x - w * 32;
             stack[3 * cw + w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
         }
         __builtin_amdgcn_wave_barrier();
-        bk_search(Cadj, XT, stack, xfne_stack, v, c, x, P, 0u, 0u, x > 0 ? 1 : 0, true, lane, cnt, sh, kNoArena, !LDS_SLAB, piv_P, piv_list);
+        bk_search<WPL>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, x > 0 ? 1 : 0, true, lane, cnt, sh, kNoArena, !LDS_SLAB, piv_P, piv_list);
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
 }
 
 // Rounds >= 1: one wave per resumable record; Cadj | XT are read from the arena, the stack lives in this wave's slab.
+template <int WPL>
 __global__ __launch_bounds__(64) void k_bk_resume(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in,
                                                   unsigned long long n_records, unsigned long long *__restrict__ queue,
                                                   uint32_t *__restrict__ slabs, unsigned long long slab_words,
                                                   unsigned long long *__restrict__ acc, BkShared sh) {
-    __shared__ unsigned char xfne_stack[2052];
-    __shared__ uint32_t piv_P[64];
-    __shared__ unsigned short piv_list[2048];
+    __shared__ unsigned char xfne_stack[2052 * WPL];
+    __shared__ uint32_t piv_P[64 * WPL];
+    __shared__ unsigned short piv_list[2048 * WPL];
     const int lane = threadIdx.x;
     uint32_t *stack = slabs + size_t(blockIdx.x) * slab_words;
     unsigned long long cnt = 0;
     while (true) {
         unsigned long long q0 = 0;
         if (lane == 0) q0 = atomicAdd(queue, 1ull);
-        q0 = (unsigned long long)__shfl((long long)q0, 0);
+        q0 = uni64(q0);
         if (q0 >= n_records) break;
-        const unsigned long long roff = dir_in[q0];
+        const unsigned long long roff = uni64(dir_in[q0]);
         if (roff == ~0ull) continue;  // a claimed-but-unwritten directory slot (its wave kept the search)
         const uint32_t *rec = pool_in + roff;
-        const int32_t v = int32_t(rec[0]);
-        const int c = int(rec[1]), x = int(rec[2]), xf_ne = int(rec[3]);
-        const unsigned long long aoff = (unsigned long long)rec[4] | ((unsigned long long)rec[5] << 32);
+        const int32_t v = uni32(int32_t(rec[0]));
+        const int c = uni32(int(rec[1])), x = uni32(int(rec[2])), xf_ne = uni32(int(rec[3]));
+        const unsigned long long aoff = (unsigned long long)uni32(rec[4]) | ((unsigned long long)uni32(rec[5]) << 32);
         const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
         const uint32_t *Cadj = sh.arena + aoff;
         const uint32_t *XT = Cadj + size_t(c) * cw;
-        const uint32_t P = lane < cw ? rec[kRecHeader + lane] : 0u;
-        const uint32_t Xc = lane < cw ? rec[kRecHeader + cw + lane] : 0u;
-        const uint32_t ext = lane < cw ? rec[kRecHeader + 2 * cw + lane] : 0u;
+        uint32_t P[WPL], Xc[WPL], ext[WPL];
+#pragma unroll
+        for (int h = 0; h < WPL; ++h) {
+            const int w = lane + 64 * h;
+            P[h] = w < cw ? rec[kRecHeader + w] : 0u;
+            Xc[h] = w < cw ? rec[kRecHeader + cw + w] : 0u;
+            ext[h] = w < cw ? rec[kRecHeader + 2 * cw + w] : 0u;
+        }
         for (int w = lane; w < xw; w += 64) stack[3 * cw + w] = rec[kRecHeader + 3 * cw + w];
         __builtin_amdgcn_wave_barrier();
-        bk_search(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, xf_ne, false, lane, cnt, sh, aoff, true, piv_P, piv_list);
+        bk_search<WPL>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, xf_ne, false, lane, cnt, sh, aoff, true, piv_P, piv_list);
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
@@ -614,11 +683,13 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     g_tmp.p = tmp;
     GMSX_HIP(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, k_in, k_out, v_in, v_out, size_t(n), 0, 64, s));
     std::vector<unsigned long long> words(static_cast<size_t>(n));
-    unsigned long long head[2] = {0, 0};
+    unsigned long long head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     GMSX_HIP(hipMemcpyAsync(words.data(), k_out, size_t(n) * 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipMemcpyAsync(head, acc + kCtl, sizeof(head), hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
-    if (head[1]) return GMSX_ERR_UNSUPPORTED;  // a start vertex with more than 2048 candidates (one word per lane)
+    if (head[1]) return GMSX_ERR_UNSUPPORTED;  // a start vertex with more than 4096 candidates (two words per lane)
+    const int64_t n_wide = int64_t(head[7]);     // tasks with 2049..4096 candidates: sorted first (kWideTask), WPL = 2 kernels
+    for (int64_t i = 0; i < n_wide; ++i) words[size_t(i)] &= ~kWideTask;
 
     // ---- arena + record pools of the load balancer
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
@@ -668,16 +739,18 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     int launches = 0;
     int64_t lo = 0;
     while (lo < n_tasks) {
+        const bool wide = lo < n_wide;
+        const int64_t bin_end = wide ? n_wide : n_tasks;  // the wide tasks form their own bins
         const unsigned long long top = words[size_t(lo)];
-        const bool lds = top <= (unsigned long long)kLdsSlabWords;
+        const bool lds = !wide && top <= (unsigned long long)kLdsSlabWords;
         int64_t hi = lo;
-        while (hi < n_tasks && (lds || words[size_t(hi)] * 4 > top)) ++hi;
+        while (hi < bin_end && (lds || words[size_t(hi)] * 4 > top)) ++hi;
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (cnt > 0) {
             GMSX_HIP(hipMemsetAsync(queue, 0, 8, s));
             if (lds) {
                 const int64_t waves = std::min<int64_t>(cnt, int64_t(cu) * 10);
-                hipLaunchKernelGGL(k_bk_wave<true>, dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff,
+                hipLaunchKernelGGL((k_bk_wave<true, 1>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff,
                                    g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue,
                                    static_cast<uint32_t *>(nullptr), 0ull, acc, sh);
             } else {
@@ -687,8 +760,12 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({cnt, int64_t(cu) * 16, int64_t(budget_bytes / slab_bytes)}));
                 uint32_t *slabs = nullptr;
                 GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(waves) * slab_bytes));
-                hipLaunchKernelGGL(k_bk_wave<false>, dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
-                                   g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
+                if (wide)
+                    hipLaunchKernelGGL((k_bk_wave<false, 2>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
+                                       g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
+                else
+                    hipLaunchKernelGGL((k_bk_wave<false, 1>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
+                                       g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
                 GMSX_HIP(hipStreamSynchronize(s));
                 GMSX_HIP(hipFree(slabs));
             }
@@ -728,8 +805,12 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
             resume_cap = size_t(waves) * slab_bytes;
             GMSX_HIP(hipMalloc(&g_rslab.p, resume_cap));
         }
-        hipLaunchKernelGGL(k_bk_resume, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue,
-                           static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
+        if (n_wide > 0)  // records of wide tasks may be anywhere in the pool
+            hipLaunchKernelGGL(k_bk_resume<2>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue,
+                               static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
+        else
+            hipLaunchKernelGGL(k_bk_resume<1>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue,
+                               static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
         ++launches;
         if (++rounds > 100000) return GMSX_ERR_KERNEL;
     }

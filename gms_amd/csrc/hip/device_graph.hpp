@@ -86,6 +86,17 @@ int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out);
 // GMSX_TC_FULL: every edge u<v intersects the FULL rows (pairs.hip); returns the un-divided sum of the shard
 int tc_full_partial(const gmsx_graph *g, int part, int nparts, uint64_t *partial, gmsx_stats *st);
 
+// A value every lane of the wave loaded from the same address is uniform, but the compiler cannot know: pinning it with
+// v_readfirstlane moves it (and every offset / pointer derived from it) from vector to scalar registers.
+__device__ __forceinline__ int uni32(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ uint32_t uni32(uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(int(x))); }
+__device__ __forceinline__ int64_t uni64(int64_t x) {
+    const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uint64_t(x)))));
+    const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(uint64_t(x) >> 32))));
+    return int64_t((uint64_t(hi) << 32) | lo);
+}
+__device__ __forceinline__ unsigned long long uni64(unsigned long long x) { return (unsigned long long)uni64(int64_t(x)); }
+
 #define GMSX_HIP(call)                                                    \
     do {                                                                  \
         hipError_t e_ = (call);                                           \

@@ -94,3 +94,25 @@ def test_bk_edge_cases(gpu):
     g = gpu.DeviceGraph.from_csr(edges_to_csr(gpu, edges))
     assert g.bk_count() == 27
     g.free()
+
+
+def test_bk_more_than_2048_candidates(gpu, oracle):
+    """Start vertices with 2049..4096 candidates run on the two-words-per-lane kernels.  K_{a,b} plus a sparse random graph H
+    inside side A: B is independent and sees all of A, so every maximal clique is (a maximal clique of H, isolated vertices
+    included) + one B vertex: b · MC(H), with MC(H) from the oracle on H alone.  Also the partial counts and the wide +
+    narrow mix of resumable records (the B searches exceed the node budget)."""
+    a, b, eh = 2200, 2300, 9000
+    rng = np.random.default_rng(21)
+    hu, hv = rng.integers(0, a, eh), rng.integers(0, a, eh)
+    keep = hu != hv
+    hcsr = gpu.HostCSR.from_edges(hu[keep].astype(np.int32), hv[keep].astype(np.int32), num_nodes=a)
+    mc_h = oracle.bk_count(hcsr.offsets(), hcsr.neighbors())
+    bu, bv = np.meshgrid(np.arange(a, dtype=np.int32), np.arange(a, a + b, dtype=np.int32), indexing="ij")
+    src = np.concatenate([bu.ravel(), hu[keep].astype(np.int32)])
+    dst = np.concatenate([bv.ravel(), hv[keep].astype(np.int32)])
+    g = gpu.DeviceGraph.from_csr(gpu.HostCSR.from_edges(src, dst))
+    assert 2048 < g.max_out_degree <= 4096
+    want = b * mc_h
+    assert g.bk_count() == want
+    assert sum(g.bk_partial(p, 3) for p in range(3)) == want
+    g.free()
