@@ -186,7 +186,7 @@ int gmsx_kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint6
 /* ---- Bron–Kerbosch maximal-clique count: BkEppsteinPar::mceBench with -DBK_COUNT
  * (maximal_clique_enum/parallel/eppsteinPAR.h:18-53 over sequential/tomita.h:12-86).
  * rank: n entries in rank format, or NULL → degree rank (preprocessing/parallel/degree.h:26-62).
- * The count does not depend on the rank.  Limit: a start vertex may have at most 2048 candidates (d+ <= 2048 in the device's
+ * The count does not depend on the rank.  Limit: a start vertex may have at most 4096 candidates (d+ <= 4096 in the device's
  * degree rank), else GMSX_ERR_UNSUPPORTED. */
 int gmsx_bk_count(const gmsx_graph *g, const int32_t *rank, uint64_t *maximal_cliques, gmsx_stats *stats);
 int gmsx_bk_partial(const gmsx_graph *g, const int32_t *rank, int part, int nparts, uint64_t *partial, gmsx_stats *stats);
