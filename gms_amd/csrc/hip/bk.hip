@@ -24,7 +24,7 @@
 
 namespace gmsx {
 
-static constexpr int kLdsSlabWords = 4096;  // 16 KB per wave
+static constexpr int kLdsSlabWords = 2048;  // 8 KB per wave: tasks of at most ~90 candidates; with the trimmed scratch below 17 waves fit a CU
 static constexpr unsigned long long kEmptySlot = ~0ull;
 static constexpr unsigned long long kWideTask = 1ull << 62;  // task key flag: more than 2048 candidates
 
@@ -447,16 +447,17 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
                                                 unsigned long long *__restrict__ queue, uint32_t *__restrict__ slabs,
                                                 unsigned long long slab_words, unsigned long long *__restrict__ acc, BkShared sh) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_slab[LDS_SLAB ? kLdsSlabWords : 4];
-    __shared__ unsigned char xfne_stack[2052 * WPL];  // per level: is Xf non-empty (written by one lane, read by all)
+    // per level: is Xf non-empty (written by one lane, read by all); an LDS-slab task has < 256 candidates (its slab would not fit otherwise)
+    __shared__ unsigned char xfne_stack[LDS_SLAB ? 256 : 2052 * WPL];
     __shared__ int32_t in_stage[64];             // build: the kept in-neighbours of one 64-entry batch, compacted
     // global-slab variant: the id -> index map of the build phase lives in LDS whenever it fits (c <= 512); the probes
     // of the in-neighbour rows are the long dependent chains of the build
     constexpr uint32_t kLdsMapSlots = 1024;
     // one 8.25 KB LDS work area: the build's id -> index map (global-slab variant), then the search's pivot scratch
     static_assert(!LDS_SLAB || WPL == 1, "LDS-slab tasks are tiny");
-    __shared__ __attribute__((aligned(16))) uint32_t lds_work[(LDS_SLAB ? 1024 : 2 * kLdsMapSlots) + 64 * WPL];  // piv_list: 2048*WPL u16 fit the map area
+    __shared__ __attribute__((aligned(16))) uint32_t lds_work[(LDS_SLAB ? 128 : 2 * kLdsMapSlots) + 64 * WPL];  // piv_list: 2048*WPL u16 fit the map area (256 u16 for an LDS-slab task)
     unsigned long long *lds_map = reinterpret_cast<unsigned long long *>(lds_work);
-    uint32_t *piv_P = lds_work + (LDS_SLAB ? 1024 : 2 * kLdsMapSlots);
+    uint32_t *piv_P = lds_work + (LDS_SLAB ? 128 : 2 * kLdsMapSlots);
     unsigned short *piv_list = reinterpret_cast<unsigned short *>(lds_work);
     const int lane = threadIdx.x;
     uint32_t *slab = LDS_SLAB ? lds_slab : slabs + size_t(blockIdx.x) * slab_words;
@@ -749,7 +750,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         if (cnt > 0) {
             GMSX_HIP(hipMemsetAsync(queue, 0, 8, s));
             if (lds) {
-                const int64_t waves = std::min<int64_t>(cnt, int64_t(cu) * 10);
+                const int64_t waves = std::min<int64_t>(cnt, int64_t(cu) * 16);
                 hipLaunchKernelGGL((k_bk_wave<true, 1>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff,
                                    g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue,
                                    static_cast<uint32_t *>(nullptr), 0ull, acc, sh);
