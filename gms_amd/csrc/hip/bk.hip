@@ -713,7 +713,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     sh.pool_head = acc + kCtl + 4;
     sh.dir_count = acc + kCtl + 5;
     sh.max_stack = acc + kCtl + 6;
-    sh.budget = 2048;
+    sh.budget = 512;  // nodes before a search is re-split: swept 128 … 8192 on the config-4 graph and Kronecker scale 14 after the occupancy work
     sh.bmoff = g->bmoff;
     sh.bmpool = g->bmpool;
     sh.dense_limit = g->dense_limit;
