@@ -607,7 +607,7 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
 
 // Rounds >= 1: one wave per resumable record; Cadj | XT are read from the arena, the stack lives in this wave's slab.
 template <int WPL>
-__global__ __launch_bounds__(64) void k_bk_resume(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? 6 : 3))) void k_bk_resume(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in,
                                                   unsigned long long n_records, unsigned long long *__restrict__ queue,
                                                   uint32_t *__restrict__ slabs, unsigned long long slab_words,
                                                   unsigned long long *__restrict__ acc, BkShared sh) {
