@@ -2,7 +2,9 @@
 """bench.py — the headline benchmark of BASELINE.json: edges-intersected/s (+ algorithmic-bytes roofline) of the
 triangle count on a synthetic RMAT graph, through the gmsx C-ABI on N GPUs of one node.
 
-  python bench.py                       # N=1, RMAT scale-24 ef-16 (BASELINE.json configs[1]), 5 steps, 2 warm-ups
+  python bench.py                       # N=1, RMAT scale-26 ef-16 (the graph BASELINE.json's metric is quoted on), 5 steps,
+                                        # 2 warm-ups; plus a parity record on scale 24 (configs[1], reference golden)
+  python bench.py --scale 24            # configs[1] as the timed workload
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -83,12 +85,41 @@ def reference_baseline(scale, degree):
         return {"error": repr(e)}
 
 
+METRIC = "edges-intersected/sec + achieved HBM GB/s, RMAT-26 triangle count @1/2/4/8 GPU"  # BASELINE.json "metric", verbatim
+# device counts without a reference golden, each cross-checked three ways; key = generator-scale-degree
+CROSS_CHECKED = {"kronecker-26-16": 49175273487, "kronecker-27-16": 106873365648}
+
+
+def config1_check(capi, generator, scale, degree, algo, divisor):
+    """BASELINE.json configs[1] (RMAT scale 24 on one GPU) as a parity record next to the headline: a few passes on that
+    graph, the count asserted against the reference's golden (tests/golden/graphs.json, from the compiled reference)."""
+    csr = capi.HostCSR.generate(generator, scale, degree, capi.RELABEL_AUTO)
+    g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_TRUSTED)
+    ms = []
+    for _ in range(4):
+        partial, st = g.tc_partial(0, 1, algo, stats=True)
+        ms.append(st["kernel_ms"])
+    m = csr.num_edges
+    g.free()
+    tri = partial // divisor
+    with open(os.path.join(ROOT, "tests", "golden", "graphs.json")) as f:
+        rec = json.load(f).get(f"{generator}-{scale}-{degree}-relabel")
+    golden = rec.get("triangles") if rec else None
+    if golden is not None:
+        assert tri == golden, f"PARITY FAILURE (configs[1]): {tri} != reference golden {golden}"
+    best = min(ms[1:])
+    return {"workload": f"triangle count, RMAT scale-{scale} ef={degree} (BASELINE.json configs[1])", "m": int(m), "triangles": int(tri),
+            "parity": "== reference golden" if golden is not None else "no golden", "kernel_ms": best, "edges_per_s": m / (best * 1e-3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--scale", type=int, default=24, help="RMAT scale (BASELINE.json configs[1] = 24)")
+    ap.add_argument("--scale", type=int, default=26, help="RMAT scale: 26 = the graph BASELINE.json's metric is quoted on; 24 = configs[1]")
+    ap.add_argument("--check-scale", type=int, default=24, help="N=1 only: extra untimed-setup pass on this scale, asserted against the "
+                                                               "reference golden (configs[1]); 0 disables")
     ap.add_argument("--degree", type=int, default=16)
     ap.add_argument("--generator", default="kronecker")
     ap.add_argument("--algo", default="auto", choices=["auto", "oriented", "full"])
@@ -120,10 +151,19 @@ def main():
     # ---- synthetic input: the reference loader's "-g kronecker <scale> --deg <degree>" graph, bit-identical ------
     t0 = time.perf_counter()
     sg = os.path.join(args.cache_dir, f"{args.generator}-{args.scale}-{args.degree}.sg")
-    if world == 1:
+    if world == 1 and os.path.exists(sg):  # a cache left by an earlier run (profiling passes, multi-rank runs)
+        csr = capi.HostCSR.load(sg, relabel=capi.RELABEL_NEVER)
+    elif world == 1:
         csr = capi.HostCSR.generate(args.generator, args.scale, args.degree, capi.RELABEL_AUTO)
+        if os.environ.get("GMSX_SAVE_CACHE") == "1":
+            os.makedirs(args.cache_dir, exist_ok=True)
+            csr.save_sg(sg + ".tmp")
+            os.replace(sg + ".tmp", sg)
     else:
         if rank == 0 and not os.path.exists(sg):  # one rank generates, the others read the .sg cache
+            # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers: the generating rank takes the host's cores back
+            # (scale 26: 65 s instead of 400 s); the other ranks only read the .sg cache
+            capi.set_host_threads(0)
             os.makedirs(args.cache_dir, exist_ok=True)
             capi.HostCSR.generate(args.generator, args.scale, args.degree, capi.RELABEL_AUTO).save_sg(sg + ".tmp")
             os.replace(sg + ".tmp", sg)
@@ -169,6 +209,12 @@ def main():
         pass
     if golden is not None:
         assert triangles == golden, f"PARITY FAILURE: {triangles} != reference golden {golden}"
+    parity = "== reference golden" if golden is not None else "no golden at this size"
+    crosschecked = CROSS_CHECKED.get(f"{args.generator}-{args.scale}-{args.degree}")
+    if golden is None and crosschecked is not None:
+        assert triangles == crosschecked, f"PARITY FAILURE: {triangles} != cross-checked count {crosschecked}"
+        parity = ("== count cross-checked three ways on the device (bitmap kernels, 8 shards, bit-matrix kernels at k=3; "
+                  "profiles/r01/probe_s26_v8.log); the reference has no golden at this size — its scale-24 golden is asserted in config1_check")
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = m * args.steps / elapsed
@@ -184,14 +230,14 @@ def main():
         pass
 
     out = {
-        "metric": "edges-intersected/sec + achieved HBM GB/s, RMAT triangle count", "value": value, "unit": "edges/s",
+        "metric": METRIC, "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32 ids / uint64 counts",
         "data": "synthetic",
         "config": {"workload": f"triangle count, RMAT scale-{args.scale} ef={args.degree} ({args.generator}, GAPBS generator "
                                f"seed 27491095, symmetrised, de-duplicated, relabelled by degree)",
                    "n": n, "m": m, "nnz": nnz, "algo": args.algo, "parallelism": f"edge-shard x{world} + 1 all-reduce(u64)",
-                   "triangles": triangles, "parity": ("== reference golden" if golden is not None else "no golden at this size"),
+                   "triangles": triangles, "parity": parity,
                    "device": info["name"]},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
@@ -203,8 +249,13 @@ def main():
                      "probes_per_launch": st["probes"]},
         "setup_s": {"generate_or_load": t_gen, "upload_and_build": t_upload},
     }
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+    if rank == 0 and world == 1 and args.check_scale > 0 and args.check_scale != args.scale:
         g.free()
+        g = None
+        out["config1_check"] = config1_check(capi, args.generator, args.check_scale, args.degree, algo, divisor)
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        if g is not None:
+            g.free()
         out["cpu_baseline"] = cpu_baseline(csr, args.cpu_seconds)
         if args.ref_scale > 0:
             out["cpu_reference"] = reference_baseline(args.ref_scale, args.degree)

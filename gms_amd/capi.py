@@ -29,7 +29,7 @@ SYMBOLS = [
     "gmsx_csr_generate", "gmsx_csr_generate_rmat", "gmsx_csr_from_edges", "gmsx_csr_load", "gmsx_csr_save_sg", "gmsx_csr_from_arrays",
     "gmsx_csr_worth_relabelling", "gmsx_csr_relabel_by_degree", "gmsx_csr_num_nodes", "gmsx_csr_num_edges",
     "gmsx_csr_num_edges_directed", "gmsx_csr_offsets", "gmsx_csr_neighbors", "gmsx_csr_merge_elements",
-    "gmsx_csr_fingerprint", "gmsx_csr_free",
+    "gmsx_csr_fingerprint", "gmsx_csr_free", "gmsx_set_host_threads",
     "gmsx_init", "gmsx_set_stream", "gmsx_device_info",
     "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
     "gmsx_graph_device_bytes", "gmsx_graph_max_out_degree",
@@ -204,6 +204,11 @@ class HostCSR:
         if getattr(self, "_h", None):
             lib().gmsx_csr_free(self._h)
             self._h = None
+
+
+def set_host_threads(n=0):
+    """Threads of the host substrate (OpenMP); n <= 0 = all processors.  Returns the previous maximum."""
+    return int(lib().gmsx_set_host_threads(int(n)))
 
 
 def init(device=-1):

@@ -641,6 +641,17 @@ int gmsx_csr_relabel_by_degree(const gmsx_csr *h, gmsx_csr **out) {
 }
 
 int64_t gmsx_csr_num_nodes(const gmsx_csr *h) { return h ? h->g.n : int64_t(GMSX_ERR_INVALID); }
+int gmsx_set_host_threads(int n) {
+#ifdef _OPENMP
+    const int before = omp_get_max_threads();
+    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+    return before;
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 int64_t gmsx_csr_num_edges(const gmsx_csr *h) { return h ? (h->g.directed ? h->g.nnz : h->g.nnz / 2) : int64_t(GMSX_ERR_INVALID); }
 int64_t gmsx_csr_num_edges_directed(const gmsx_csr *h) { return h ? h->g.nnz : int64_t(GMSX_ERR_INVALID); }
 const int64_t *gmsx_csr_offsets(const gmsx_csr *h) { return h ? h->g.off.get() : nullptr; }

@@ -100,6 +100,11 @@ uint64_t gmsx_csr_merge_elements(const gmsx_csr *g);
 uint64_t gmsx_csr_fingerprint(const gmsx_csr *g, int which /*0 offsets, 1 neighbours*/);
 void gmsx_csr_free(gmsx_csr *g);
 
+/* Threads of the host substrate (generator, builder, relabelling: OpenMP, like the reference's loader).  n <= 0 restores
+ * the runtime default.  Returns the previous maximum.  Launchers that export OMP_NUM_THREADS=1 to their workers
+ * (torch.distributed.run does) would otherwise serialise graph generation: the rank that builds the graph calls this. */
+int gmsx_set_host_threads(int n);
+
 /* =====================================================================================
  * Device side
  * ===================================================================================== */
