@@ -168,6 +168,8 @@ def main():
             capi.HostCSR.generate(args.generator, args.scale, args.degree, capi.RELABEL_AUTO).save_sg(sg + ".tmp")
             os.replace(sg + ".tmp", sg)
         dist.barrier()
+        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        capi.set_host_threads(max(1, ncores // world))  # every rank: its share of the cores for the host-side bookkeeping
         csr = capi.HostCSR.load(sg, relabel=capi.RELABEL_NEVER)
     t_gen = time.perf_counter() - t0
     n, m, nnz = csr.num_nodes, csr.num_edges, csr.nnz
