@@ -173,3 +173,16 @@ def test_other_text_formats(capi, tmp_path):
         off, ng = R.csr(g)
         assert np.array_equal(off, quirk.offsets()) and np.array_equal(ng, quirk.neighbors())
         R.free(g)
+
+
+def test_host_threads_do_not_change_the_graph(capi):
+    """gmsx_set_host_threads only changes how many OpenMP threads the generator / builder use: same CSR bit for bit."""
+    base = capi.HostCSR.generate("kronecker", 12, 16).fingerprint()
+    prev = capi.set_host_threads(1)
+    assert prev >= 1
+    try:
+        assert capi.HostCSR.generate("kronecker", 12, 16).fingerprint() == base
+        assert capi.set_host_threads(3) == 1
+        assert capi.HostCSR.generate("kronecker", 12, 16).fingerprint() == base
+    finally:
+        capi.set_host_threads(prev)
