@@ -22,7 +22,9 @@
 #include <cerrno>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <limits>
 #include <memory>
@@ -178,6 +180,25 @@ static int make_uniform(int scale, int degree, EdgeList &el) {
     return GMSX_OK;
 }
 
+// phase timings of the host substrate on stderr when GMSX_TIMING=1 (the reference prints "Generate Time" / "Build Time")
+struct PhaseTimer {
+    const bool on = std::getenv("GMSX_TIMING") != nullptr;
+    double t0 = now();
+    static double now() {
+#ifdef _OPENMP
+        return omp_get_wtime();
+#else
+        return double(std::clock()) / CLOCKS_PER_SEC;
+#endif
+    }
+    void lap(const char *what) {
+        if (!on) return;
+        const double t1 = now();
+        std::fprintf(stderr, "[gmsx host] %-28s %8.3f s\n", what, t1 - t0);
+        t0 = t1;
+    }
+};
+
 // ---- CSR construction --------------------------------------------------------------------------
 
 static int alloc_csr(Csr &g, int64_t n, int64_t nnz) {
@@ -229,10 +250,12 @@ static int build_from_el(const EdgeList &el, int64_t num_nodes, bool symmetrize,
         for (int64_t e = 0; e < m; ++e) mx = std::max(mx, std::max(eu[e], ev[e]));
         num_nodes = int64_t(mx) + 1;
     }
+    PhaseTimer pt;
     const int64_t n = num_nodes;
     for (int64_t e = 0; e < m; ++e)  // cheap guard; the generators never trip it
         if (eu[e] < 0 || ev[e] < 0 || eu[e] >= n || ev[e] >= n) return GMSX_ERR_INVALID;
 
+    pt.lap("build: max id + guard");
     // pass 1: raw row sizes (self-loops dropped here already; duplicates later)
     std::unique_ptr<std::atomic<int64_t>[]> cnt(new (std::nothrow) std::atomic<int64_t>[size_t(n + 1)]);
     std::unique_ptr<int64_t[]> raw_off(new (std::nothrow) int64_t[size_t(n + 1)]);
@@ -245,6 +268,7 @@ static int build_from_el(const EdgeList &el, int64_t num_nodes, bool symmetrize,
         cnt[eu[e]].fetch_add(1, std::memory_order_relaxed);
         if (symmetrize) cnt[ev[e]].fetch_add(1, std::memory_order_relaxed);
     }
+    pt.lap("build: count degrees");
     prefix_sum(reinterpret_cast<int64_t *>(cnt.get()), n, raw_off.get());
     const int64_t raw_nnz = raw_off[n];
     std::unique_ptr<int32_t[]> raw(new (std::nothrow) int32_t[size_t(std::max<int64_t>(raw_nnz, 1))]);
@@ -258,6 +282,7 @@ static int build_from_el(const EdgeList &el, int64_t num_nodes, bool symmetrize,
         raw[cnt[eu[e]].fetch_add(1, std::memory_order_relaxed)] = ev[e];
         if (symmetrize) raw[cnt[ev[e]].fetch_add(1, std::memory_order_relaxed)] = eu[e];
     }
+    pt.lap("build: prefix + scatter");
     // pass 3: sort + unique each row, record the surviving length
     std::unique_ptr<int64_t[]> len(new (std::nothrow) int64_t[size_t(n + 1)]);
     if (!len) return GMSX_ERR_NOMEM;
@@ -267,6 +292,7 @@ static int build_from_el(const EdgeList &el, int64_t num_nodes, bool symmetrize,
         std::sort(b, e);
         len[u] = std::unique(b, e) - b;
     }
+    pt.lap("build: sort + unique rows");
     cnt.reset();
     // pass 4: compact
     std::unique_ptr<int64_t[]> off(new (std::nothrow) int64_t[size_t(n + 1)]);
@@ -527,11 +553,15 @@ int gmsx_csr_generate(int generator, int scale, int degree, int relabel, int thr
     {
         Csr g;
         {
+            PhaseTimer pt;
             EdgeList el;
             rc = generator == GMSX_GEN_UNIFORM ? make_uniform(scale, degree, el) : make_rmat(scale, degree, el);
+            pt.lap("generate edge list");
             if (!rc) rc = build_from_el(el, -1, true, g);
         }
+        PhaseTimer pf;
         if (!rc) rc = finish(std::move(g), relabel, out);
+        pf.lap("relabel decision + relabel");
     }
 #ifdef _OPENMP
     if (threads > 0) omp_set_num_threads(saved);
