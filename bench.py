@@ -155,10 +155,13 @@ def main():
         csr = capi.HostCSR.load(sg, relabel=capi.RELABEL_NEVER)
     elif world == 1:
         csr = capi.HostCSR.generate(args.generator, args.scale, args.degree, capi.RELABEL_AUTO)
-        if os.environ.get("GMSX_SAVE_CACHE") == "1":
-            os.makedirs(args.cache_dir, exist_ok=True)
-            csr.save_sg(sg + ".tmp")
-            os.replace(sg + ".tmp", sg)
+        if os.environ.get("GMSX_NO_CACHE") != "1":  # later runs on this box (N = 1 again, N = 2, 4, 8) load it in seconds
+            try:
+                os.makedirs(args.cache_dir, exist_ok=True)
+                csr.save_sg(sg + ".tmp")
+                os.replace(sg + ".tmp", sg)
+            except (OSError, capi.GmsxError) as e:  # a full or read-only cache directory is not an error of the benchmark
+                log(rank, f"cache not written: {e}")
     else:
         if rank == 0 and not os.path.exists(sg):  # one rank generates, the others read the .sg cache
             # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers: the generating rank takes the host's cores back
