@@ -18,6 +18,9 @@
 #include "gmsx_internal.hpp"
 
 #include <algorithm>
+#ifdef _OPENMP
+#include <parallel/algorithm>
+#endif
 #include <atomic>
 #include <cerrno>
 #include <cmath>
@@ -94,7 +97,20 @@ static void shuffle_ids(int32_t *a, int64_t n, std::mt19937 &rng) {
         }
         return;
     }
-    for (int64_t i = 1; i < n; ++i) std::swap(a[i], a[uniform_closed(rng, uint32_t(i))]);
+    // general path: one draw per swap.  The targets do not depend on the array, so they are drawn a chunk ahead (same
+    // engine sequence) and prefetched: the swaps themselves stay sequential, but no longer wait for a cache miss each
+    // (n = 2^26: the array is 256 MB, every target a miss).
+    constexpr int64_t kChunk = 4096, kAhead = 32;
+    std::unique_ptr<uint32_t[]> tgt(new uint32_t[size_t(kChunk)]);
+    for (int64_t base = 1; base < n; base += kChunk) {
+        const int64_t cnt = std::min<int64_t>(kChunk, n - base);
+        for (int64_t k = 0; k < cnt; ++k) tgt[k] = uniform_closed(rng, uint32_t(base + k));
+        for (int64_t k = 0; k < std::min<int64_t>(kAhead, cnt); ++k) __builtin_prefetch(a + tgt[k], 1, 0);
+        for (int64_t k = 0; k < cnt; ++k) {
+            if (k + kAhead < cnt) __builtin_prefetch(a + tgt[k + kAhead], 1, 0);
+            std::swap(a[base + k], a[tgt[k]]);
+        }
+    }
 }
 
 // ---- edge lists ------------------------------------------------------------------------------
@@ -115,10 +131,20 @@ static int make_rmat(int scale, int degree, EdgeList &el, float A = 0.57f, float
     if (int rc = el.alloc(m)) return rc;
     const float AB = A + B, ABC = A + B + C;  // float sums, as the reference compares against
     int32_t *eu = el.u.get(), *ev = el.v.get();
+    // id permutation (generator.h:52-62): identity shuffled once with mt19937(kSeed).  The shuffle is inherently serial;
+    // one thread runs it while the others generate the edges (it then joins them).
+    std::unique_ptr<int32_t[]> perm(new (std::nothrow) int32_t[size_t(n)]);
+    if (!perm) return GMSX_ERR_NOMEM;
 #pragma omp parallel
     {
+#pragma omp single nowait
+        {
+            for (int64_t i = 0; i < n; ++i) perm[i] = int32_t(i);
+            std::mt19937 prng(kSeed);
+            shuffle_ids(perm.get(), n, prng);
+        }
         std::mt19937 rng;
-#pragma omp for schedule(dynamic, 4)
+#pragma omp for schedule(dynamic, 1)
         for (int64_t block = 0; block < m; block += kGenBlock) {
             rng.seed(uint32_t(kSeed + block / kGenBlock));
             const int64_t end = std::min(block + kGenBlock, m);
@@ -140,12 +166,7 @@ static int make_rmat(int scale, int degree, EdgeList &el, float A = 0.57f, float
             }
         }
     }
-    // id permutation (generator.h:52-62): identity shuffled once with mt19937(kSeed), applied to both ends
-    std::unique_ptr<int32_t[]> perm(new (std::nothrow) int32_t[size_t(n)]);
-    if (!perm) return GMSX_ERR_NOMEM;
-    for (int64_t i = 0; i < n; ++i) perm[i] = int32_t(i);
-    std::mt19937 prng(kSeed);
-    shuffle_ids(perm.get(), n, prng);
+    // the permutation is applied to both ends
 #pragma omp parallel for schedule(static)
     for (int64_t e = 0; e < m; ++e) {
         eu[e] = perm[eu[e]];
@@ -252,36 +273,107 @@ static int build_from_el(const EdgeList &el, int64_t num_nodes, bool symmetrize,
     }
     PhaseTimer pt;
     const int64_t n = num_nodes;
-    for (int64_t e = 0; e < m; ++e)  // cheap guard; the generators never trip it
-        if (eu[e] < 0 || ev[e] < 0 || eu[e] >= n || ev[e] >= n) return GMSX_ERR_INVALID;
+    int bad = 0;  // cheap guard; the generators never trip it
+#pragma omp parallel for reduction(| : bad) schedule(static)
+    for (int64_t e = 0; e < m; ++e) bad |= int(eu[e] < 0 || ev[e] < 0 || eu[e] >= n || ev[e] >= n);
+    if (bad) return GMSX_ERR_INVALID;
 
     pt.lap("build: max id + guard");
-    // pass 1: raw row sizes (self-loops dropped here already; duplicates later)
-    std::unique_ptr<std::atomic<int64_t>[]> cnt(new (std::nothrow) std::atomic<int64_t>[size_t(n + 1)]);
+    // passes 1-2 without atomics (hub rows made the fetch_add counters the hot spot of a 256-thread host): the directed
+    // pairs are first partitioned by the high bits of their row vertex into buckets — every thread counts and then writes
+    // its own slice of the edge list through private cursors — and each bucket, which owns a contiguous vertex range, is
+    // then counted and scattered by one thread.  Placement inside a row differs from run to run; the per-row sort below
+    // makes the result deterministic, as before.
+    int nthreads = 1;
+#ifdef _OPENMP
+    nthreads = omp_get_max_threads();
+#endif
+    int shift = 0;
+    while (((n - 1) >> shift) >= 4096) ++shift;  // at most 4096 buckets
+    const int64_t nb = ((n - 1) >> shift) + 1;
+    std::unique_ptr<int64_t[]> hist(new (std::nothrow) int64_t[size_t(nb) * size_t(nthreads) + 1]);
     std::unique_ptr<int64_t[]> raw_off(new (std::nothrow) int64_t[size_t(n + 1)]);
-    if (!cnt || !raw_off) return GMSX_ERR_NOMEM;
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i <= n; ++i) cnt[i].store(0, std::memory_order_relaxed);
-#pragma omp parallel for schedule(static)
-    for (int64_t e = 0; e < m; ++e) {
-        if (eu[e] == ev[e]) continue;
-        cnt[eu[e]].fetch_add(1, std::memory_order_relaxed);
-        if (symmetrize) cnt[ev[e]].fetch_add(1, std::memory_order_relaxed);
+    std::unique_ptr<int64_t[]> cnt(new (std::nothrow) int64_t[size_t(n + 1)]);
+    if (!hist || !raw_off || !cnt) return GMSX_ERR_NOMEM;
+    std::fill(hist.get(), hist.get() + size_t(nb) * size_t(nthreads) + 1, int64_t(0));
+    auto slice = [&](int t, int64_t &lo, int64_t &hi) {
+        lo = m * int64_t(t) / nthreads;
+        hi = m * int64_t(t + 1) / nthreads;
+    };
+#pragma omp parallel num_threads(nthreads)
+    {
+        int t = 0;
+#ifdef _OPENMP
+        t = omp_get_thread_num();
+#endif
+        int64_t lo, hi;
+        slice(t, lo, hi);
+        int64_t *h = hist.get() + size_t(t) * size_t(nb);  // layout [thread][bucket] while counting
+        for (int64_t e = lo; e < hi; ++e) {
+            if (eu[e] == ev[e]) continue;
+            ++h[eu[e] >> shift];
+            if (symmetrize) ++h[ev[e] >> shift];
+        }
     }
-    pt.lap("build: count degrees");
-    prefix_sum(reinterpret_cast<int64_t *>(cnt.get()), n, raw_off.get());
-    const int64_t raw_nnz = raw_off[n];
+    // exclusive prefix in (bucket, thread) order -> private write cursors; bucket_off[b] = start of bucket b
+    std::unique_ptr<int64_t[]> bucket_off(new (std::nothrow) int64_t[size_t(nb + 1)]);
+    if (!bucket_off) return GMSX_ERR_NOMEM;
+    int64_t run = 0;
+    for (int64_t bkt = 0; bkt < nb; ++bkt) {
+        bucket_off[bkt] = run;
+        for (int t = 0; t < nthreads; ++t) {
+            int64_t &slot = hist[size_t(t) * size_t(nb) + size_t(bkt)];
+            const int64_t c = slot;
+            slot = run;
+            run += c;
+        }
+    }
+    bucket_off[nb] = run;
+    const int64_t raw_nnz = run;
+    std::unique_ptr<int32_t[]> prow(new (std::nothrow) int32_t[size_t(std::max<int64_t>(raw_nnz, 1))]);
+    std::unique_ptr<int32_t[]> pnbr(new (std::nothrow) int32_t[size_t(std::max<int64_t>(raw_nnz, 1))]);
     std::unique_ptr<int32_t[]> raw(new (std::nothrow) int32_t[size_t(std::max<int64_t>(raw_nnz, 1))]);
-    if (!raw) return GMSX_ERR_NOMEM;
-    // pass 2: scatter (placement inside a row is racy, the per-row sort below makes the result deterministic)
-#pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; ++i) cnt[i].store(raw_off[i], std::memory_order_relaxed);
-#pragma omp parallel for schedule(static)
-    for (int64_t e = 0; e < m; ++e) {
-        if (eu[e] == ev[e]) continue;
-        raw[cnt[eu[e]].fetch_add(1, std::memory_order_relaxed)] = ev[e];
-        if (symmetrize) raw[cnt[ev[e]].fetch_add(1, std::memory_order_relaxed)] = eu[e];
+    if (!prow || !pnbr || !raw) return GMSX_ERR_NOMEM;
+#pragma omp parallel num_threads(nthreads)
+    {
+        int t = 0;
+#ifdef _OPENMP
+        t = omp_get_thread_num();
+#endif
+        int64_t lo, hi;
+        slice(t, lo, hi);
+        int64_t *cur = hist.get() + size_t(t) * size_t(nb);
+        for (int64_t e = lo; e < hi; ++e) {
+            const int32_t a = eu[e], c = ev[e];
+            if (a == c) continue;
+            int64_t p = cur[a >> shift]++;
+            prow[p] = a;
+            pnbr[p] = c;
+            if (symmetrize) {
+                p = cur[c >> shift]++;
+                prow[p] = c;
+                pnbr[p] = a;
+            }
+        }
     }
+    pt.lap("build: bucket partition");
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t bkt = 0; bkt < nb; ++bkt) {  // raw row sizes of the bucket's vertices (self-loops dropped already; duplicates later)
+        const int64_t v0 = bkt << shift, v1 = std::min<int64_t>(n, (bkt + 1) << shift);
+        for (int64_t v = v0; v < v1; ++v) cnt[v] = 0;
+        for (int64_t p = bucket_off[bkt]; p < bucket_off[bkt + 1]; ++p) ++cnt[prow[p]];
+    }
+    cnt[n] = 0;
+    pt.lap("build: count degrees");
+    prefix_sum(cnt.get(), n, raw_off.get());
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t bkt = 0; bkt < nb; ++bkt) {
+        const int64_t v0 = bkt << shift, v1 = std::min<int64_t>(n, (bkt + 1) << shift);
+        for (int64_t v = v0; v < v1; ++v) cnt[v] = raw_off[v];
+        for (int64_t p = bucket_off[bkt]; p < bucket_off[bkt + 1]; ++p) raw[cnt[prow[p]]++] = pnbr[p];
+    }
+    prow.reset();
+    pnbr.reset();
     pt.lap("build: prefix + scatter");
     // pass 3: sort + unique each row, record the surviving length
     std::unique_ptr<int64_t[]> len(new (std::nothrow) int64_t[size_t(n + 1)]);
@@ -340,7 +432,12 @@ int relabel_by_degree(const Csr &g, Csr &out) {
     std::vector<std::pair<int64_t, int32_t>> key(static_cast<size_t>(n));
 #pragma omp parallel for schedule(static)
     for (int64_t v = 0; v < n; ++v) key[size_t(v)] = {g.off[v + 1] - g.off[v], int32_t(v)};
+    // a total order (ids are unique), so the parallel multiway merge sort gives the same permutation as std::sort
+#ifdef _OPENMP
+    __gnu_parallel::sort(key.begin(), key.end(), std::greater<std::pair<int64_t, int32_t>>());
+#else
     std::sort(key.begin(), key.end(), std::greater<std::pair<int64_t, int32_t>>());
+#endif
     std::unique_ptr<int32_t[]> new_id(new (std::nothrow) int32_t[size_t(std::max<int64_t>(n, 1))]);
     std::unique_ptr<int64_t[]> deg(new (std::nothrow) int64_t[size_t(n + 1)]);
     if (!new_id || !deg) return GMSX_ERR_NOMEM;
