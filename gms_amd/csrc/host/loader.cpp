@@ -17,6 +17,8 @@
 // std::mt19937 itself is fully specified by the C++ standard and is used as is.
 #include "gmsx_internal.hpp"
 
+#include <sys/mman.h>
+
 #include <algorithm>
 #ifdef _OPENMP
 #include <parallel/algorithm>
@@ -46,6 +48,25 @@ namespace gmsx {
 
 static constexpr uint32_t kSeed = 27491095u;         // gapbs/util.h:25
 static constexpr int64_t kGenBlock = int64_t(1) << 18;  // generator.h:152: rng reseeded per 2^18-edge block
+
+// phase timings of the host substrate on stderr when GMSX_TIMING=1 (the reference prints "Generate Time" / "Build Time")
+struct PhaseTimer {
+    const bool on = std::getenv("GMSX_TIMING") != nullptr;
+    double t0 = now();
+    static double now() {
+#ifdef _OPENMP
+        return omp_get_wtime();
+#else
+        return double(std::clock()) / CLOCKS_PER_SEC;
+#endif
+    }
+    void lap(const char *what) {
+        if (!on) return;
+        const double t1 = now();
+        std::fprintf(stderr, "[gmsx host] %-28s %8.3f s\n", what, t1 - t0);
+        t0 = t1;
+    }
+};
 
 // ---- restated libstdc++ distributions ------------------------------------------------------
 
@@ -128,20 +149,34 @@ struct EdgeList {
 
 static int make_rmat(int scale, int degree, EdgeList &el, float A = 0.57f, float B = 0.19f, float C = 0.19f) {
     const int64_t n = int64_t(1) << scale, m = n * degree;
+    PhaseTimer pt;
     if (int rc = el.alloc(m)) return rc;
     const float AB = A + B, ABC = A + B + C;  // float sums, as the reference compares against
     int32_t *eu = el.u.get(), *ev = el.v.get();
     // id permutation (generator.h:52-62): identity shuffled once with mt19937(kSeed).  The shuffle is inherently serial;
     // one thread runs it while the others generate the edges (it then joins them).
-    std::unique_ptr<int32_t[]> perm(new (std::nothrow) int32_t[size_t(n)]);
-    if (!perm) return GMSX_ERR_NOMEM;
+    // (2 MB-aligned and advised as huge pages where the host allows it: the shuffle touches the array at random, and with
+    // 4 KB pages every swap is a TLB miss first)
+    struct FreeDeleter { void operator()(int32_t *p) const { std::free(p); } };
+    std::unique_ptr<int32_t[], FreeDeleter> perm;
+    {
+        void *mem = nullptr;
+        const size_t bytes = ((size_t(n) * sizeof(int32_t) + (size_t(2) << 20) - 1) >> 21) << 21;
+        if (posix_memalign(&mem, size_t(2) << 20, bytes) != 0) return GMSX_ERR_NOMEM;
+#ifdef MADV_HUGEPAGE
+        (void)madvise(mem, bytes, MADV_HUGEPAGE);
+#endif
+        perm.reset(static_cast<int32_t *>(mem));
+    }
 #pragma omp parallel
     {
 #pragma omp single nowait
         {
             for (int64_t i = 0; i < n; ++i) perm[i] = int32_t(i);
             std::mt19937 prng(kSeed);
+            PhaseTimer ps;
             shuffle_ids(perm.get(), n, prng);
+            ps.lap("  rmat: shuffle alone");
         }
         std::mt19937 rng;
 #pragma omp for schedule(dynamic, 1)
@@ -166,12 +201,14 @@ static int make_rmat(int scale, int degree, EdgeList &el, float A = 0.57f, float
             }
         }
     }
+    pt.lap("  rmat: draws || shuffle");
     // the permutation is applied to both ends
 #pragma omp parallel for schedule(static)
     for (int64_t e = 0; e < m; ++e) {
         eu[e] = perm[eu[e]];
         ev[e] = perm[ev[e]];
     }
+    pt.lap("  rmat: apply permutation");
     return GMSX_OK;
 }
 
@@ -200,25 +237,6 @@ static int make_uniform(int scale, int degree, EdgeList &el) {
     }
     return GMSX_OK;
 }
-
-// phase timings of the host substrate on stderr when GMSX_TIMING=1 (the reference prints "Generate Time" / "Build Time")
-struct PhaseTimer {
-    const bool on = std::getenv("GMSX_TIMING") != nullptr;
-    double t0 = now();
-    static double now() {
-#ifdef _OPENMP
-        return omp_get_wtime();
-#else
-        return double(std::clock()) / CLOCKS_PER_SEC;
-#endif
-    }
-    void lap(const char *what) {
-        if (!on) return;
-        const double t1 = now();
-        std::fprintf(stderr, "[gmsx host] %-28s %8.3f s\n", what, t1 - t0);
-        t0 = t1;
-    }
-};
 
 // ---- CSR construction --------------------------------------------------------------------------
 
