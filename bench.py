@@ -31,6 +31,25 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def cpu_quota_cores():
+    """CPU bandwidth limit of this container in cores (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited/unknown:
+    the host may show 256 hardware threads while the container is throttled to a fraction of them."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        return None if quota == "max" else round(int(quota) / int(period), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            quota = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            period = int(f.read())
+        return None if quota <= 0 else round(quota / period, 2)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(csr, seconds):
     """The oracle's OpenMP restatement of Par::count_total timed on a bounded, strided sample of the same graph."""
     from oracle.bindings import Oracle
@@ -59,6 +78,7 @@ def cpu_baseline(csr, seconds):
                    f"{elems} merged ids in {dt:.2f} s; value = m / (total merged ids / sampled ids-per-second)"),
         "sample_seconds": dt, "sample_edges": edges, "sample_elements": elems,
         "algorithmic_GBps": 4.0 * elems_per_s / 1e9,
+        "cpu_quota_cores": cpu_quota_cores(), "host_threads_visible": os.cpu_count(),
     }
 
 
