@@ -50,8 +50,24 @@ def cpu_quota_cores():
         return None
 
 
+def set_gomp_threads(n):
+    os.environ["OMP_NUM_THREADS"] = str(n)  # for a libgomp that is not loaded yet
+    try:
+        import ctypes
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(n))
+    except OSError:
+        pass
+
+
 def cpu_baseline(csr, seconds):
     """The oracle's OpenMP restatement of Par::count_total timed on a bounded, strided sample of the same graph."""
+    quota = cpu_quota_cores()
+    if quota and quota < (os.cpu_count() or 1) and "GMSX_CPU_THREADS" not in os.environ:
+        # a throttled container: one thread per core of quota beats hundreds of threads sharing it (the OpenMP runtime of
+        # the oracle and the compiled reference is libgomp, usually loaded long before by numpy / torch: set it at run time)
+        set_gomp_threads(max(1, int(quota + 0.999)))
+    elif "GMSX_CPU_THREADS" in os.environ:
+        set_gomp_threads(int(os.environ["GMSX_CPU_THREADS"]))
     from oracle.bindings import Oracle
     O = Oracle()
     off, ng = csr.offsets(), csr.neighbors()
