@@ -185,6 +185,13 @@ def main():
     divisor = capi.lib().gmsx_tc_divisor(algo)
 
     # ---- synthetic input: the reference loader's "-g kronecker <scale> --deg <degree>" graph, bit-identical ------
+    # host threads: the cores this container may really use (cgroup quota, else the affinity mask) — hundreds of OpenMP
+    # threads on a 16-core quota make the generator 2x slower, and torch.distributed.run hands its workers OMP_NUM_THREADS=1
+    quota = cpu_quota_cores()
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if quota:
+        ncores = max(1, min(ncores, int(quota + 0.999)))
+    capi.set_host_threads(ncores)
     t0 = time.perf_counter()
     sg = os.path.join(args.cache_dir, f"{args.generator}-{args.scale}-{args.degree}.sg")
     if world == 1 and os.path.exists(sg):  # a cache left by an earlier run (profiling passes, multi-rank runs)
@@ -200,14 +207,10 @@ def main():
                 log(rank, f"cache not written: {e}")
     else:
         if rank == 0 and not os.path.exists(sg):  # one rank generates, the others read the .sg cache
-            # torch.distributed.run exports OMP_NUM_THREADS=1 to its workers: the generating rank takes the host's cores back
-            # (scale 26: 65 s instead of 400 s); the other ranks only read the .sg cache
-            capi.set_host_threads(0)
             os.makedirs(args.cache_dir, exist_ok=True)
             capi.HostCSR.generate(args.generator, args.scale, args.degree, capi.RELABEL_AUTO).save_sg(sg + ".tmp")
             os.replace(sg + ".tmp", sg)
         dist.barrier()
-        ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         capi.set_host_threads(max(1, ncores // world))  # every rank: its share of the cores for the host-side bookkeeping
         csr = capi.HostCSR.load(sg, relabel=capi.RELABEL_NEVER)
     t_gen = time.perf_counter() - t0
@@ -271,7 +274,7 @@ def main():
         pass
 
     out = {
-        "metric": METRIC, "value": value, "unit": "edges/s",
+        "metric": METRIC if args.scale == 26 else METRIC.replace("RMAT-26", f"RMAT-{args.scale}"), "value": value, "unit": "edges/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "int32 ids / uint64 counts",
         "data": "synthetic",
