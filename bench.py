@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""bench.py — the headline benchmark of BASELINE.json: edges-intersected/s (+ algorithmic-bytes roofline) of the
-triangle count on a synthetic RMAT graph, through the gmsx C-ABI on N GPUs of one node.
+"""bench.py — the headline benchmark of BASELINE.json: edges-intersected/s (+ HBM roofline) of the triangle count on a
+synthetic RMAT graph, through the gmsx C-ABI on N GPUs of one node.
 
   python bench.py                       # N=1, RMAT scale-26 ef-16 (the graph BASELINE.json's metric is quoted on), 5 steps,
                                         # 2 warm-ups; plus a parity record on scale 24 (configs[1], reference golden)
@@ -8,15 +8,31 @@ triangle count on a synthetic RMAT graph, through the gmsx C-ABI on N GPUs of on
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A step = one full pass of the hot path over the graph: every rank counts its cost-balanced shard of the m
-undirected edges (one intersect_count per edge) with the HIP kernels, then ONE 8-byte all-reduce (RCCL) combines
-the partial counts — the device replacement of Par::count_total (triangle_count/parallel/total.h:7-24).  The graph
-is resident in HBM before the timed region starts.  Rank 0 prints ONE JSON line.
+A step = one full pass of the hot path over the graph: every rank counts its cost-balanced shard of the m undirected edges
+(one intersect_count per edge) with the HIP kernels, then ONE 8-byte all-reduce over RCCL (native: gmsx_comm_allreduce_u64;
+torch.distributed is only the launcher and the control plane) combines the partial counts — the device replacement of
+Par::count_total (triangle_count/parallel/total.h:7-24).  The graph is resident in HBM before the timed region starts.
+Rank 0 prints ONE JSON line.
+
+Roofline record (all per launch = one rank's pass):
+  achieved / frac   MEASURED traffic beyond the L2 (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes, collected in
+                    this very run by short child processes BEFORE the parent touches the GPU) / kernel time / 8 TB/s.
+                    FETCH_SIZE counts L2 misses including Infinity-Cache hits, so this is beyond-L2 (MALL + HBM) bandwidth.
+  algorithmic_bytes device-computed bytes of THIS formulation (oriented rows in the container form the kernels read, no
+                    on-chip reuse assumed: gmsx_stats.stream_bytes); work_efficiency = traffic / algorithmic_bytes.
+  reference_equivalent_GBps   B_alg / t with SURVEY §8(d)'s B_alg = 4*Σ(d_u+d_v) + 8(n+1) + 4*nnz — what the reference's
+                    full-row merges would stream; NOT a hardware utilisation (the oriented kernels do ~20x less work).
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -24,11 +40,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, "Chip-level parameters")
+METRIC = "edges-intersected/sec + achieved HBM GB/s, RMAT-26 triangle count @1/2/4/8 GPU"  # BASELINE.json "metric", verbatim
+KERNEL_SOURCES = ["gms_amd/csrc/hip/tc.hip", "gms_amd/csrc/hip/device_graph.hip", "gms_amd/csrc/hip/device_graph.hpp"]
+SHARD_COUNTS = (1, 2, 4, 8)
 
 
 def log(rank, *a):
     if rank == 0:
         print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def kernel_hash():
+    """Identity of the triangle-count kernels + containers: PMC numbers are only valid for the build they were measured on."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def cpu_quota_cores():
@@ -48,6 +76,14 @@ def cpu_quota_cores():
         return None if quota <= 0 else round(quota / period, 2)
     except (OSError, ValueError):
         return None
+
+
+def host_cores():
+    quota = cpu_quota_cores()
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if quota:
+        ncores = max(1, min(ncores, int(quota + 0.999)))
+    return ncores
 
 
 def set_gomp_threads(n):
@@ -112,7 +148,7 @@ def reference_baseline(scale, degree):
         out = {"graph": f"RMAT scale-{scale} ef={degree} (reference loader)", "m": int(m), "threads": int(R.L.ref_omp_threads())}
         for name, kind in (("RoaringGraph", 1), ("SortedSetGraph", 0)):
             t0 = time.perf_counter()
-            tri = R.tc_total(g, kind)  # includes SetGraph::FromCGraph, reported separately below is not possible through the shim
+            tri = R.tc_total(g, kind)  # includes SetGraph::FromCGraph (the shim cannot time it separately)
             dt = time.perf_counter() - t0
             out[name] = {"seconds_incl_setgraph_build": dt, "edges_per_s": m / dt, "triangles": int(tri)}
         R.free(g)
@@ -121,9 +157,13 @@ def reference_baseline(scale, degree):
         return {"error": repr(e)}
 
 
-METRIC = "edges-intersected/sec + achieved HBM GB/s, RMAT-26 triangle count @1/2/4/8 GPU"  # BASELINE.json "metric", verbatim
-# device counts without a reference golden, each cross-checked three ways; key = generator-scale-degree
-CROSS_CHECKED = {"kronecker-26-16": 49175273487, "kronecker-27-16": 106873365648}
+def golden_triangles(generator, scale, degree):
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "graphs.json")) as f:
+            rec = json.load(f).get(f"{generator}-{scale}-{degree}-relabel")
+        return (rec.get("triangles"), (rec.get("sources") or {}).get("triangles") or rec.get("source")) if rec else (None, None)
+    except OSError:
+        return None, None
 
 
 def config1_check(capi, generator, scale, degree, algo, divisor):
@@ -138,14 +178,119 @@ def config1_check(capi, generator, scale, degree, algo, divisor):
     m = csr.num_edges
     g.free()
     tri = partial // divisor
-    with open(os.path.join(ROOT, "tests", "golden", "graphs.json")) as f:
-        rec = json.load(f).get(f"{generator}-{scale}-{degree}-relabel")
-    golden = rec.get("triangles") if rec else None
+    golden, _ = golden_triangles(generator, scale, degree)
     if golden is not None:
         assert tri == golden, f"PARITY FAILURE (configs[1]): {tri} != reference golden {golden}"
     best = min(ms[1:])
     return {"workload": f"triangle count, RMAT scale-{scale} ef={degree} (BASELINE.json configs[1])", "m": int(m), "triangles": int(tri),
             "parity": "== reference golden" if golden is not None else "no golden", "kernel_ms": best, "edges_per_s": m / (best * 1e-3)}
+
+
+# ---- rocprofv3 PMC passes, live --------------------------------------------------------------------------------------
+
+def sg_cache_path(args):
+    return os.path.join(args.cache_dir, f"{args.generator}-{args.scale}-{args.degree}.sg")
+
+
+def pmc_child(args):
+    """Runs under `rocprofv3 --pmc …` (spawned by the parent below): loads the cached graph, uploads it and executes one
+    pass per shard count — full graph, then shard 0 of 2, 4, 8 — printing which dispatches belong to which."""
+    from gms_amd import capi
+    capi.init(0)
+    capi.set_host_threads(host_cores())
+    csr = capi.HostCSR.load(sg_cache_path(args), relabel=capi.RELABEL_NEVER)
+    g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_DEFAULT)  # a cache file is not trusted: validated on the device
+    algo = {"auto": capi.TC_AUTO, "oriented": capi.TC_ORIENTED, "full": capi.TC_FULL}[args.algo]
+    seq = []
+    for nparts in SHARD_COUNTS:
+        partial, st = g.tc_partial(0, nparts, algo, stats=True)
+        seq.append({"nparts": nparts, "launches": st["launches"], "kernel_ms": st["kernel_ms"], "partial": partial,
+                    "stream_bytes": st["stream_bytes"]})
+    print("PMC_CHILD " + json.dumps(seq), flush=True)
+    g.free()
+
+
+def run_pmc_pass(args, counters, timeout):
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="gmsx_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    cmd = [rocprof, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", "pmc", "--",
+                                            sys.executable, os.path.abspath(__file__), "--pmc-child", "--scale", str(args.scale), "--degree", str(args.degree),
+                                            "--generator", args.generator, "--algo", args.algo, "--cache-dir", args.cache_dir]
+    try:
+        env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
+        r = subprocess.run(cmd, cwd=out, env=env, capture_output=True, text=True, timeout=timeout)
+        line = next((l for l in r.stdout.splitlines() if l.startswith("PMC_CHILD ")), None)
+        if r.returncode != 0 or line is None:
+            return None, f"rc={r.returncode}: {(r.stderr or r.stdout)[-400:]}"
+        seq = json.loads(line[len("PMC_CHILD "):])
+        rows = []
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                rows += [x for x in csv.DictReader(fh) if "k_tc_" in x["Kernel_Name"] and "k_tc_stats" not in x["Kernel_Name"]]
+        # dispatches in issue order -> passes (each pass = st["launches"] dispatches)
+        by_dispatch = {}
+        for x in rows:
+            d = by_dispatch.setdefault(int(x["Dispatch_Id"]), {"kernel": x["Kernel_Name"].split("(")[0].replace("gmsx::", "")})
+            d[x["Counter_Name"]] = d.get(x["Counter_Name"], 0.0) + float(x["Counter_Value"])
+        order = [by_dispatch[k] for k in sorted(by_dispatch)]
+        if len(order) != sum(s["launches"] for s in seq):
+            return None, f"dispatch count mismatch: {len(order)} PMC rows for {seq}"
+        res, pos = {}, 0
+        for s in seq:
+            mine = order[pos:pos + s["launches"]]
+            pos += s["launches"]
+            res[f"n{s['nparts']}"] = {"counters": {c: sum(d.get(c, 0.0) for d in mine) for c in counters},
+                                      "kernels": {d["kernel"]: {c: d.get(c, 0.0) for c in counters} for d in mine},
+                                      "kernel_ms_under_pmc": s["kernel_ms"], "stream_bytes": s["stream_bytes"]}
+        return res, None
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as e:
+        return None, repr(e)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def measure_traffic(args, rank):
+    """Separate PMC passes (FETCH_SIZE needs 3 of the 4 TCC slots, WRITE_SIZE 2: never in one pass; never combined with tracing).
+    Returns {"n1": {...}, "n2": …} or (None, reason)."""
+    table, notes = {}, []
+    for counters in (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]):
+        t0 = time.perf_counter()
+        res, err = run_pmc_pass(args, counters, timeout=args.pmc_timeout)
+        log(rank, f"PMC pass {counters}: {'ok' if res else 'FAILED ' + str(err)} in {time.perf_counter() - t0:.1f}s")
+        if res is None:
+            notes.append(f"{counters}: {err}")
+            if counters[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                return None, "; ".join(notes)
+            continue
+        for key, rec in res.items():
+            t = table.setdefault(key, {"kernels": {}, "stream_bytes": rec["stream_bytes"]})
+            t.update(rec["counters"])
+            for k, c in rec["kernels"].items():
+                t["kernels"].setdefault(k, {}).update(c)
+    for key, t in table.items():
+        # FETCH_SIZE / WRITE_SIZE are reported in KB; gfx950 tallies the 128-B requests of 16-B-per-lane streaming loads at 64 B
+        # (MI355X_MICROARCH.md "HBM"): double the fetch figure.  The 4-byte gathers of k_tc_wave_hub are outside that calibration,
+        # so its (small) share is an upper bound.
+        t["bytes"] = (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0
+        for k in t["kernels"].values():
+            if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+                k["bytes"] = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+        if "TCC_HIT_sum" in t and t["TCC_HIT_sum"] + t.get("TCC_MISS_sum", 0) > 0:
+            t["l2_hit_rate"] = t["TCC_HIT_sum"] / (t["TCC_HIT_sum"] + t["TCC_MISS_sum"])
+    return table, "; ".join(notes) if notes else None
+
+
+def committed_traffic(khash, key, world):
+    """profiles/hbm_traffic.json holds the last profiled numbers, keyed by the kernel hash they were measured on: stale entries are refused."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            doc = json.load(f)
+        rec = doc.get("by_kernel_hash", {}).get(khash, {}).get(key, {}).get(f"n{world}")
+        return rec
+    except (OSError, ValueError):
+        return None
 
 
 def main():
@@ -161,12 +306,58 @@ def main():
     ap.add_argument("--algo", default="auto", choices=["auto", "oriented", "full"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="size of the CPU-baseline sample; 0 disables it")
     ap.add_argument("--ref-scale", type=int, default=20, help="scale of the graph the compiled reference is timed on; 0 disables")
-    ap.add_argument("--cache-dir", default=os.environ.get("GMSX_CACHE", "/tmp/gmsx_cache"))
+    ap.add_argument("--cache-dir", default=os.environ.get("GMSX_CACHE") or os.path.join(tempfile.gettempdir(), f"gmsx_cache_{os.getuid()}"))
+    ap.add_argument("--pmc", type=int, default=1, help="N=1: collect HBM traffic with rocprofv3 PMC child passes in this run (0 = use profiles/hbm_traffic.json)")
+    ap.add_argument("--pmc-timeout", type=float, default=420.0)
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        return pmc_child(args)
+
+    from gms_amd import capi, dist
+    rank, local_rank, world = dist.env_rank_world()
+    khash = kernel_hash()
+    gkey = f"{args.generator}-{args.scale}-{args.degree}/{args.algo}"
+
+    # ---- synthetic input: the reference loader's "-g kronecker <scale> --deg <degree>" graph, bit-identical ------
+    # host threads: the cores this container may really use (cgroup quota, else the affinity mask) — hundreds of OpenMP
+    # threads on a 16-core quota make the generator 2x slower, and torch.distributed.run hands its workers OMP_NUM_THREADS=1
+    ncores = host_cores()
+    capi.set_host_threads(ncores)
+    t0 = time.perf_counter()
+    sg = sg_cache_path(args)
+    csr = None
+    if rank == 0:
+        os.makedirs(args.cache_dir, mode=0o700, exist_ok=True)
+        if os.path.exists(sg):  # a cache left by an earlier run on this box (N = 1, 2, 4, 8 back to back)
+            try:
+                csr = capi.HostCSR.load(sg, relabel=capi.RELABEL_NEVER)  # offsets / id range validated by the reader
+            except capi.GmsxError as e:
+                log(rank, f"cache {sg} unusable ({e}); regenerating")
+        if csr is None:
+            csr = capi.HostCSR.generate(args.generator, args.scale, args.degree, capi.RELABEL_AUTO)
+            if os.environ.get("GMSX_NO_CACHE") != "1" or world > 1:
+                try:
+                    fd, tmp = tempfile.mkstemp(prefix=".sg_", dir=args.cache_dir)
+                    os.close(fd)
+                    csr.save_sg(tmp)
+                    os.replace(tmp, sg)
+                except (OSError, capi.GmsxError) as e:  # a full or read-only cache directory is not an error of the benchmark
+                    log(rank, f"cache not written: {e}")
+
+    # ---- HBM traffic: PMC passes in child processes, before this process touches the GPU (N = 1) ----------------------------
+    traffic_table, traffic_note, traffic_source = None, None, None
+    if rank == 0 and world == 1 and args.pmc and os.path.exists(sg):
+        traffic_table, traffic_note = measure_traffic(args, rank)
+        if traffic_table:
+            traffic_source = "rocprofv3 --pmc child passes of this run (2*FETCH_SIZE + WRITE_SIZE, separate passes)"
+            try:  # the shard figures serve the N = 2, 4, 8 runs that follow on this box
+                with open(os.path.join(args.cache_dir, f"traffic_{khash}_{gkey.replace('/', '_')}.json"), "w") as f:
+                    json.dump(traffic_table, f)
+            except OSError:
+                pass
 
     import torch
-    from gms_amd import capi, dist
-
     # test hook for 1-GPU boxes: GMSX_SHARE_GPU=1 lets several ranks share cuda:0 (then over gloo, RCCL refuses duplicates)
     share = os.environ.get("GMSX_SHARE_GPU") == "1"
     rank, local_rank, world = dist.init_process_group(backend="gloo" if share else None)
@@ -184,48 +375,41 @@ def main():
     algo = {"auto": capi.TC_AUTO, "oriented": capi.TC_ORIENTED, "full": capi.TC_FULL}[args.algo]
     divisor = capi.lib().gmsx_tc_divisor(algo)
 
-    # ---- synthetic input: the reference loader's "-g kronecker <scale> --deg <degree>" graph, bit-identical ------
-    # host threads: the cores this container may really use (cgroup quota, else the affinity mask) — hundreds of OpenMP
-    # threads on a 16-core quota make the generator 2x slower, and torch.distributed.run hands its workers OMP_NUM_THREADS=1
-    quota = cpu_quota_cores()
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    if quota:
-        ncores = max(1, min(ncores, int(quota + 0.999)))
-    capi.set_host_threads(ncores)
-    t0 = time.perf_counter()
-    sg = os.path.join(args.cache_dir, f"{args.generator}-{args.scale}-{args.degree}.sg")
-    if world == 1 and os.path.exists(sg):  # a cache left by an earlier run (profiling passes, multi-rank runs)
-        csr = capi.HostCSR.load(sg, relabel=capi.RELABEL_NEVER)
-    elif world == 1:
-        csr = capi.HostCSR.generate(args.generator, args.scale, args.degree, capi.RELABEL_AUTO)
-        if os.environ.get("GMSX_NO_CACHE") != "1":  # later runs on this box (N = 1 again, N = 2, 4, 8) load it in seconds
-            try:
-                os.makedirs(args.cache_dir, exist_ok=True)
-                csr.save_sg(sg + ".tmp")
-                os.replace(sg + ".tmp", sg)
-            except (OSError, capi.GmsxError) as e:  # a full or read-only cache directory is not an error of the benchmark
-                log(rank, f"cache not written: {e}")
-    else:
-        if rank == 0 and not os.path.exists(sg):  # one rank generates, the others read the .sg cache
-            os.makedirs(args.cache_dir, exist_ok=True)
-            capi.HostCSR.generate(args.generator, args.scale, args.degree, capi.RELABEL_AUTO).save_sg(sg + ".tmp")
-            os.replace(sg + ".tmp", sg)
-        dist.barrier()
-        capi.set_host_threads(max(1, ncores // world))  # every rank: its share of the cores for the host-side bookkeeping
-        csr = capi.HostCSR.load(sg, relabel=capi.RELABEL_NEVER)
+    if world > 1:
+        dist.barrier()  # rank 0 has written the cache
+        if csr is None:
+            capi.set_host_threads(max(1, ncores // world))  # every rank: its share of the cores for the host-side bookkeeping
+            csr = capi.HostCSR.load(sg, relabel=capi.RELABEL_NEVER)
     t_gen = time.perf_counter() - t0
     n, m, nnz = csr.num_nodes, csr.num_edges, csr.nnz
     elems = csr.merge_elements()
     t0 = time.perf_counter()
-    g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_TRUSTED)
+    g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_DEFAULT)  # validated on the device (sorted, loop-free, symmetric)
     torch.cuda.synchronize()
     t_upload = time.perf_counter() - t0
-    log(rank, f"{info['name']}: graph n={n} m={m} Σ(du+dv)={elems} generate/load {t_gen:.1f}s upload+build {t_upload:.2f}s "
+    log(rank, f"{info['name']}: graph n={n} m={m} Σ(du+dv)={elems} generate/load(+PMC passes) {t_gen:.1f}s upload+build {t_upload:.2f}s "
               f"max d+={g.max_out_degree} device bytes={g.device_bytes}")
+
+    # ---- the one collective: native RCCL communicator under the C-ABI; torch.distributed only carries the 128-byte id ------
+    comm = None
+    if world > 1 and not share:
+        idt = torch.zeros(capi.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8))
+        torch.distributed.broadcast(idt, 0)
+        comm = capi.Comm.init(rank, world, bytes(idt.cpu().numpy().tobytes()))
+        collective = "gmsx_comm_allreduce_u64 = ncclAllReduce(count=1, ncclUint64, ncclSum) over RCCL (native, librccl)"
+    elif world > 1:
+        collective = "torch.distributed gloo all-reduce (GMSX_SHARE_GPU test hook: ranks share one GPU, RCCL refuses duplicates)"
+    else:
+        collective = "none (single rank)"
 
     def step():
         partial, st = g.tc_partial(rank, world, algo, stats=True)
-        total = dist.allreduce_count(partial, None if share else dev)
+        if comm is not None:
+            total = comm.allreduce_u64(partial)
+        else:
+            total = dist.allreduce_count(partial, None if share else dev)
         return total, st
 
     for _ in range(args.warmup):
@@ -244,34 +428,55 @@ def main():
 
     assert len(set(totals)) == 1 and totals[0] % divisor == 0, totals
     triangles = totals[0] // divisor
-    golden = None
-    try:
-        with open(os.path.join(ROOT, "tests", "golden", "graphs.json")) as f:
-            rec = json.load(f).get(f"{args.generator}-{args.scale}-{args.degree}-relabel")
-        golden = rec.get("triangles") if rec else None
-    except OSError:
-        pass
+    golden, golden_src = golden_triangles(args.generator, args.scale, args.degree)
     if golden is not None:
         assert triangles == golden, f"PARITY FAILURE: {triangles} != reference golden {golden}"
-    parity = "== reference golden" if golden is not None else "no golden at this size"
-    crosschecked = CROSS_CHECKED.get(f"{args.generator}-{args.scale}-{args.degree}")
-    if golden is None and crosschecked is not None:
-        assert triangles == crosschecked, f"PARITY FAILURE: {triangles} != cross-checked count {crosschecked}"
-        parity = ("== count cross-checked three ways on the device (bitmap kernels, 8 shards, bit-matrix kernels at k=3; "
-                  "profiles/r01/probe_s26_v8.log); the reference has no golden at this size — its scale-24 golden is asserted in config1_check")
+        parity = f"== reference golden ({golden_src or 'tests/golden/graphs.json'})"
+    else:
+        parity = "no reference golden at this size (self-consistency only: every step returned the same count)"
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = m * args.steps / elapsed
     avg_kernel_ms = dist.allreduce_max(sum(kernel_ms) / len(kernel_ms), None if share else dev)
+    t_kernel = avg_kernel_ms * 1e-3
     b_alg = 4 * elems + 8 * (n + 1) + 4 * nnz           # bytes the reference operator streams per pass
-    per_launch_bytes = b_alg / world                     # one rank's launch covers 1/world of the cost-balanced work
-    achieved = per_launch_bytes / (avg_kernel_ms * 1e-3) / 1e9
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            traffic = json.load(f).get(f"{args.generator}-{args.scale}-{args.degree}/{args.algo}/n{world}")
-    except OSError:
-        pass
+    stream_bytes = int(st["stream_bytes"])               # this rank's launch, oriented formulation, no reuse assumed
+
+    trec = None
+    if traffic_table and f"n{world}" in traffic_table:
+        trec = traffic_table[f"n{world}"]
+    else:
+        for path in (os.path.join(args.cache_dir, f"traffic_{khash}_{gkey.replace('/', '_')}.json"),):
+            try:
+                with open(path) as f:
+                    trec = json.load(f).get(f"n{world}")
+                traffic_source = "rocprofv3 --pmc passes of the N=1 run on this box, same kernel build (shard 0 of %d on one GPU)" % world
+            except (OSError, ValueError):
+                pass
+        if trec is None:
+            trec = committed_traffic(khash, gkey, world)
+            if trec is not None:
+                traffic_source = "profiles/hbm_traffic.json (measured on this kernel build: hash %s)" % khash
+    traffic = trec["bytes"] if trec else None
+    if traffic is not None:
+        achieved, achieved_src = traffic / t_kernel / 1e9, "measured traffic / kernel time"
+    else:
+        achieved, achieved_src = stream_bytes / t_kernel / 1e9, ("ALGORITHMIC bytes of the oriented formulation / kernel time (no PMC measurement "
+                                                                 "for this kernel build: " + str(traffic_note or "none available") + ")")
+    roofline = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "achieved_is": achieved_src, "traffic_source": traffic_source,
+        "memory_level": "beyond-L2 (Infinity Cache + HBM): FETCH_SIZE counts L2 misses, MALL hits included; no DRAM-side counter separates them",
+        "kernel_ms": avg_kernel_ms, "kernel_hash": khash,
+        "algorithmic_bytes": stream_bytes, "algorithmic_GBps": stream_bytes / t_kernel / 1e9,
+        "work_efficiency_traffic_over_algorithmic": (traffic / stream_bytes) if (traffic and stream_bytes) else None,
+        "l2_hit_rate": trec.get("l2_hit_rate") if trec else None,
+        "per_kernel_traffic_bytes": {k: v.get("bytes") for k, v in trec["kernels"].items()} if trec else None,
+        "reference_equivalent_bytes": b_alg / world, "reference_equivalent_GBps": b_alg / world / t_kernel / 1e9,
+        "reference_equivalent_note": "B_alg = 4*sum_{u<v}(d_u+d_v) + 8(n+1) + 4*nnz (SURVEY 8(d)): what the reference's full-row merges stream; "
+                                     "not a hardware utilisation — the oriented kernels probe far fewer ids",
+        "probes_per_launch": st["probes"], "graph_device_bytes": g.device_bytes,
+    }
 
     out = {
         "metric": METRIC if args.scale == 26 else METRIC.replace("RMAT-26", f"RMAT-{args.scale}"), "value": value, "unit": "edges/s",
@@ -281,18 +486,12 @@ def main():
         "config": {"workload": f"triangle count, RMAT scale-{args.scale} ef={args.degree} ({args.generator}, GAPBS generator "
                                f"seed 27491095, symmetrised, de-duplicated, relabelled by degree)",
                    "n": n, "m": m, "nnz": nnz, "algo": args.algo, "parallelism": f"edge-shard x{world} + 1 all-reduce(u64)",
-                   "triangles": triangles, "parity": parity,
-                   "device": info["name"]},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic,
-                     "kernel_ms": avg_kernel_ms, "algorithmic_bytes_per_launch": per_launch_bytes,
-                     "note": "achieved = B_alg/t with B_alg = 4*sum_{u<v}(d_u+d_v) + 8(n+1) + 4*nnz (SURVEY 8(d)): the bytes the "
-                             "reference's full-row merges stream; the oriented kernel probes far fewer ids, so frac can exceed 1",
-                     "traffic_GBps": (traffic / (avg_kernel_ms * 1e-3) / 1e9) if traffic else None,
-                     "traffic_frac_of_peak": (traffic / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "probes_per_launch": st["probes"]},
-        "setup_s": {"generate_or_load": t_gen, "upload_and_build": t_upload},
+                   "collective": collective, "triangles": triangles, "parity": parity, "device": info["name"]},
+        "roofline": roofline,
+        "setup_s": {"generate_or_load_incl_pmc_passes": t_gen, "upload_and_build": t_upload},
     }
+    if comm is not None:
+        comm.finalize()
     if rank == 0 and world == 1 and args.check_scale > 0 and args.check_scale != args.scale:
         g.free()
         g = None

@@ -21,7 +21,8 @@ RELABEL_NEVER, RELABEL_AUTO, RELABEL_ALWAYS = 0, 1, 2
 TC_AUTO, TC_ORIENTED, TC_FULL = 0, 1, 2
 UPLOAD_DEFAULT, UPLOAD_TRUSTED = 0, 1
 OK, ERR_INVALID, ERR_NOMEM, ERR_IO, ERR_FORMAT, ERR_DIRECTED, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
-ERR_DEVICE_MEM, ERR_NOT_CANONICAL, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_KERNEL = -7, -8, -9, -10, -11
+ERR_DEVICE_MEM, ERR_NOT_CANONICAL, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_KERNEL, ERR_COMM = -7, -8, -9, -10, -11, -12
+COMM_ID_BYTES = 128
 
 # every symbol include/gmsx.h declares (tests/test_capi_symbols.py checks the header against this list)
 SYMBOLS = [
@@ -35,12 +36,15 @@ SYMBOLS = [
     "gmsx_graph_device_bytes", "gmsx_graph_max_out_degree",
     "gmsx_tc_total", "gmsx_tc_partial", "gmsx_tc_divisor", "gmsx_tc_vertex_count2",
     "gmsx_intersect_count_batch", "gmsx_vertex_similarity_batch", "gmsx_kclique_count", "gmsx_kclique_partial", "gmsx_bk_count", "gmsx_bk_partial",
+    "gmsx_adg_rank", "gmsx_tc_ordering",
+    "gmsx_comm_unique_id", "gmsx_comm_init", "gmsx_comm_allreduce_u64", "gmsx_comm_rank", "gmsx_comm_size", "gmsx_comm_finalize",
 ]
 
 
 class Stats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("setup_ms", C.c_double), ("units", C.c_uint64),
-                ("alg_elements", C.c_uint64), ("probes", C.c_uint64), ("launches", C.c_int32), ("reserved", C.c_int32)]
+                ("alg_elements", C.c_uint64), ("probes", C.c_uint64), ("launches", C.c_int32), ("reserved", C.c_int32),
+                ("stream_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -109,6 +113,14 @@ def lib():
     L.gmsx_kclique_partial.argtypes = [vp, C.c_int, C.c_int, C.c_int, u64p, sp]
     L.gmsx_bk_count.argtypes = [vp, C.c_void_p, u64p, sp]
     L.gmsx_bk_partial.argtypes = [vp, C.c_void_p, C.c_int, C.c_int, u64p, sp]
+    L.gmsx_adg_rank.argtypes = [vp, C.c_double, C.c_int, _i32p, C.POINTER(C.c_int32), sp]
+    L.gmsx_tc_ordering.argtypes = [vp, _i32p, sp]
+    L.gmsx_comm_unique_id.argtypes = [C.c_char_p]
+    L.gmsx_comm_init.argtypes = [C.c_int, C.c_int, C.c_char_p, vpp]
+    L.gmsx_comm_allreduce_u64.argtypes = [vp, u64p]
+    L.gmsx_comm_rank.argtypes = [vp]
+    L.gmsx_comm_size.argtypes = [vp]
+    L.gmsx_comm_finalize.argtypes = [vp]
     _LIB = L
     return L
 
@@ -318,6 +330,19 @@ class DeviceGraph:
         _check(lib().gmsx_bk_partial(self._h, rp, part, nparts, C.byref(out), C.byref(st)), "gmsx_bk_partial")
         return (int(out.value), st.as_dict()) if stats else int(out.value)
 
+    def adg_rank(self, epsilon=0.001, rank_format=True, stats=False):
+        """gmsx_adg_rank: (rank or order vector, number of peeling rounds)"""
+        out, rounds, st = np.zeros(max(self.num_nodes, 1), dtype=np.int32), C.c_int32(0), Stats()
+        _check(lib().gmsx_adg_rank(self._h, float(epsilon), int(bool(rank_format)), out, C.byref(rounds), C.byref(st)), "gmsx_adg_rank")
+        r = (out[:self.num_nodes], int(rounds.value))
+        return (r + (st.as_dict(),)) if stats else r
+
+    def tc_ordering(self, stats=False):
+        out, st = np.zeros(max(self.num_nodes, 1), dtype=np.int32), Stats()
+        _check(lib().gmsx_tc_ordering(self._h, out, C.byref(st)), "gmsx_tc_ordering")
+        out = out[:self.num_nodes]
+        return (out, st.as_dict()) if stats else out
+
     def free(self):
         if getattr(self, "_h", None):
             lib().gmsx_graph_free(self._h)
@@ -325,3 +350,36 @@ class DeviceGraph:
 
     def __del__(self):
         self.free()
+
+
+class Comm:
+    """gmsx_comm*: the native RCCL communicator of the path's single collective (one u64 all-reduce)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(lib().gmsx_comm_unique_id(buf), "gmsx_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def init(cls, rank, nranks, uid):
+        assert len(uid) == COMM_ID_BYTES
+        h = C.c_void_p()
+        _check(lib().gmsx_comm_init(rank, nranks, uid, C.byref(h)), "gmsx_comm_init")
+        return cls(h)
+
+    rank = property(lambda self: lib().gmsx_comm_rank(self._h))
+    size = property(lambda self: lib().gmsx_comm_size(self._h))
+
+    def allreduce_u64(self, value):
+        v = C.c_uint64(value & 0xFFFFFFFFFFFFFFFF)
+        _check(lib().gmsx_comm_allreduce_u64(self._h, C.byref(v)), "gmsx_comm_allreduce_u64")
+        return int(v.value)
+
+    def finalize(self):
+        if getattr(self, "_h", None):
+            _check(lib().gmsx_comm_finalize(self._h), "gmsx_comm_finalize")
+            self._h = None

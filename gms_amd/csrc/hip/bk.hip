@@ -761,6 +761,8 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({cnt, int64_t(cu) * 16, int64_t(budget_bytes / slab_bytes)}));
                 uint32_t *slabs = nullptr;
                 GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(waves) * slab_bytes));
+                Guard g_slabs;  // freed on every path out of this bin, error returns included
+                g_slabs.p = slabs;
                 if (wide)
                     hipLaunchKernelGGL((k_bk_wave<false, 2>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
                                        g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
@@ -768,7 +770,6 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                     hipLaunchKernelGGL((k_bk_wave<false, 1>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
                                        g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
                 GMSX_HIP(hipStreamSynchronize(s));
-                GMSX_HIP(hipFree(slabs));
             }
             ++launches;
         }
@@ -840,10 +841,22 @@ using namespace gmsx;
 extern "C" {
 
 int gmsx_bk_partial(const gmsx_graph *g, const int32_t *rank, int part, int nparts, uint64_t *partial, gmsx_stats *stats) {
-    // `rank` is accepted for interface parity with mceBench(graph, ordering); the number of maximal cliques does not
-    // depend on it, and the device always uses its own degree rank.
-    (void)rank;
     if (!g || !partial || nparts < 1 || part < 0 || part >= nparts) return GMSX_ERR_INVALID;
+    // `rank` is what the reference's drivers hand from the preprocessing step to mceBench(graph, ordering).  The number of
+    // maximal cliques does not depend on it and the device splits by its own degree rank, so it is validated
+    // (a permutation of 0..n-1, as every rank-format ordering is) and otherwise not needed.
+    if (rank) {
+        const int64_t n = g->n;
+        std::vector<uint64_t> seen(size_t((n + 63) / 64 + 1), 0);
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t r = rank[i];
+            if (r < 0 || r >= n) return GMSX_ERR_INVALID;
+            uint64_t &w = seen[size_t(r >> 6)];
+            const uint64_t bit = 1ull << (r & 63);
+            if (w & bit) return GMSX_ERR_INVALID;
+            w |= bit;
+        }
+    }
     if (int rc = ensure_init()) return rc;
     return bk_partial(g, part, nparts, partial, stats);
 }

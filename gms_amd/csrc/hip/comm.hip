@@ -1,0 +1,118 @@
+// The one collective of the path: partial counts of the ranks -> ONE all-reduce of a single uint64 over
+// RCCL / xGMI.  It replaces the OpenMP reduction(+:total) of gms/algorithms/set_based/triangle_count/parallel/total.h:12 and
+// k_clique_count/k_clique_count_set_based.h:25, and the `#pragma omp atomic BK_CLIQUE_COUNTER++` of
+// maximal_clique_enum/sequential/tomita.h:76-77, across processes (one process per GPU).
+//
+// librccl is loaded on first use (dlopen), so libgmsx.so itself has no link-time dependency on it: single-GPU users and the
+// CPU-side loader tests never touch it.  The message is 8 bytes — latency-bound, ring/tree choice and link bandwidth are
+// irrelevant; the call is issued on the library's stream right behind the counting kernels.
+#include "device_graph.hpp"
+
+#include <dlfcn.h>
+
+#include <cstring>
+#include <new>
+
+namespace {
+
+// the slice of <rccl/rccl.h> this file needs (ABI-stable NCCL types)
+typedef struct ncclComm *ncclComm_t;
+struct ncclUniqueId { char internal[128]; };
+static_assert(sizeof(ncclUniqueId) == GMSX_COMM_ID_BYTES, "GMSX_COMM_ID_BYTES must be NCCL_UNIQUE_ID_BYTES");
+constexpr int kNcclSuccess = 0, kNcclSum = 0, kNcclUint64 = 5;
+
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl() {
+    static Rccl r = [] {
+        Rccl x;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (x.handle) break;
+        }
+        if (!x.handle) return x;
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.handle, "ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.handle, "ncclCommInitRank"));
+        x.AllReduce = reinterpret_cast<decltype(x.AllReduce)>(dlsym(x.handle, "ncclAllReduce"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.handle, "ncclCommDestroy"));
+        x.ok = x.GetUniqueId && x.CommInitRank && x.AllReduce && x.CommDestroy;
+        return x;
+    }();
+    return r;
+}
+
+}  // namespace
+
+struct gmsx_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    unsigned long long *buf = nullptr;  // device: the value being reduced
+};
+
+using namespace gmsx;
+
+extern "C" {
+
+int gmsx_comm_unique_id(void *id) {
+    if (!id) return GMSX_ERR_INVALID;
+    if (!rccl().ok) return GMSX_ERR_COMM;
+    ncclUniqueId u;
+    if (rccl().GetUniqueId(&u) != kNcclSuccess) return GMSX_ERR_COMM;
+    std::memcpy(id, &u, sizeof(u));
+    return GMSX_OK;
+}
+
+int gmsx_comm_init(int rank, int nranks, const void *id, gmsx_comm **out) {
+    if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) return GMSX_ERR_INVALID;
+    if (int rc = ensure_init()) return rc;  // the communicator lives on the device this process is bound to (gmsx_init)
+    if (!rccl().ok) return GMSX_ERR_COMM;
+    gmsx_comm *c = new (std::nothrow) gmsx_comm;
+    if (!c) return GMSX_ERR_NOMEM;
+    c->rank = rank;
+    c->nranks = nranks;
+    if (hipMalloc(reinterpret_cast<void **>(&c->buf), 16) != hipSuccess) {
+        (void)hipGetLastError();
+        delete c;
+        return GMSX_ERR_DEVICE_MEM;
+    }
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    if (rccl().CommInitRank(&c->comm, nranks, u, rank) != kNcclSuccess) {
+        (void)hipFree(c->buf);
+        delete c;
+        return GMSX_ERR_COMM;
+    }
+    *out = c;
+    return GMSX_OK;
+}
+
+int gmsx_comm_allreduce_u64(gmsx_comm *c, uint64_t *value) {
+    if (!c || !value) return GMSX_ERR_INVALID;
+    hipStream_t s = ctx().stream;
+    GMSX_HIP(hipMemcpyAsync(c->buf, value, sizeof(uint64_t), hipMemcpyHostToDevice, s));
+    if (rccl().AllReduce(c->buf, c->buf, 1, kNcclUint64, kNcclSum, c->comm, s) != kNcclSuccess) return GMSX_ERR_COMM;
+    GMSX_HIP(hipMemcpyAsync(value, c->buf, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipStreamSynchronize(s));
+    return GMSX_OK;
+}
+
+int gmsx_comm_rank(const gmsx_comm *c) { return c ? c->rank : GMSX_ERR_INVALID; }
+int gmsx_comm_size(const gmsx_comm *c) { return c ? c->nranks : GMSX_ERR_INVALID; }
+
+int gmsx_comm_finalize(gmsx_comm *c) {
+    if (!c) return GMSX_OK;
+    int rc = GMSX_OK;
+    if (c->comm && rccl().ok && rccl().CommDestroy(c->comm) != kNcclSuccess) rc = GMSX_ERR_COMM;
+    (void)hipFree(c->buf);
+    delete c;
+    return rc;
+}
+
+}  // extern "C"

@@ -434,8 +434,11 @@ int gmsx_init(int device) {
         if (hipGetDevice(&device) != hipSuccess) return GMSX_ERR_NO_DEVICE;
     }
     if (device >= count) return GMSX_ERR_INVALID;
+    // one device per process (one process per GPU): the library's stream, events and every graph handle live on the first
+    // device bound; re-binding to another one is refused rather than silently launching on a foreign stream
+    if (c.device >= 0 && c.device != device) return GMSX_ERR_UNSUPPORTED;
+    if (hipSetDevice(device) != hipSuccess) return GMSX_ERR_NO_DEVICE;  // also makes the device current for a new host thread
     if (c.device == device) return GMSX_OK;
-    if (hipSetDevice(device) != hipSuccess) return GMSX_ERR_NO_DEVICE;
     if (!c.own_stream) {
         if (hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking) != hipSuccess) return GMSX_ERR_NO_DEVICE;
         for (auto &e : c.ev)
@@ -532,6 +535,7 @@ const char *gmsx_strerror(int status) {
         case GMSX_ERR_OVERFLOW: return "vertex ids do not fit int32";
         case GMSX_ERR_UNSUPPORTED: return "request not supported by this build";
         case GMSX_ERR_KERNEL: return "HIP kernel launch or synchronisation failed";
+        case GMSX_ERR_COMM: return "librccl could not be loaded or an RCCL call failed";
         default: return "unknown gmsx status";
     }
 }

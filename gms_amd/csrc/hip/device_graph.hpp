@@ -57,7 +57,7 @@ struct gmsx_graph {
     mutable int64_t ge_cnt[40] = {0};
     mutable int ge_used = 0;
     mutable int stats_part = -1, stats_nparts = -1;  // shard whose TC bookkeeping (units, probes) is cached below
-    mutable uint64_t stats_units = 0, stats_probes = 0;
+    mutable uint64_t stats_units = 0, stats_probes = 0, stats_bytes = 0;
     uint64_t alg_elements = 0;              // Σ_{u<v}(d_u+d_v), computed on the device at upload
     int64_t device_bytes = 0;
 };
@@ -83,6 +83,8 @@ int ensure_init();
 // number of vertices with d+ >= threshold (= position in `order` where d+ drops below it)
 int kclique_vertex_counts(const gmsx_graph *g, unsigned long long *d_counts, gmsx_stats *st);  // kclique.hip
 int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out);
+// counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| into a zeroed device array (pairs.hip); shared by the per-vertex count and the TC ordering
+int tc_vertex_counts_device(const gmsx_graph *g, unsigned long long *d_counts, gmsx_stats *st);
 // GMSX_TC_FULL: every edge u<v intersects the FULL rows (pairs.hip); returns the un-divided sum of the shard
 int tc_full_partial(const gmsx_graph *g, int part, int nparts, uint64_t *partial, gmsx_stats *st);
 

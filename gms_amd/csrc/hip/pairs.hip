@@ -201,6 +201,19 @@ int tc_full_partial(const gmsx_graph *g, int part, int nparts, uint64_t *partial
     return run_edge_pairs(g, 0, part, nparts, partial, nullptr, st);
 }
 
+// counts[u] = Σ_{v∈N(u)} |N(u) ∩ N(v)| into a zeroed device array indexed by caller vertex id: the oriented bit-matrix kernels
+// (kclique.hip) when the graph fits them, else one full-row intersect_count per CSR entry.  Shared by gmsx_tc_vertex_count2 and
+// gmsx_tc_ordering (ordering.hip).
+int tc_vertex_counts_device(const gmsx_graph *g, unsigned long long *d_counts, gmsx_stats *stats) {
+    hipStream_t s = ctx().stream;
+    int rc = kclique_vertex_counts(g, d_counts, stats);
+    if (rc == GMSX_ERR_UNSUPPORTED) {
+        GMSX_HIP(hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * size_t(std::max<int64_t>(g->n, 1)), s));
+        rc = run_edge_pairs(g, 1, 0, 1, nullptr, d_counts, stats);
+    }
+    return rc;
+}
+
 }  // namespace gmsx
 
 using namespace gmsx;
@@ -215,13 +228,7 @@ int gmsx_tc_vertex_count2(const gmsx_graph *g, int64_t *counts, gmsx_stats *stat
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_counts), sizeof(unsigned long long) * size_t(std::max<int64_t>(g->n, 1))));
     struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{d_counts};
     GMSX_HIP(hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * size_t(std::max<int64_t>(g->n, 1)), s));
-    // oriented bit-matrix kernels (kclique.hip) when the graph fits them, else one full-row intersect_count per CSR entry
-    int rc = kclique_vertex_counts(g, d_counts, stats);
-    if (rc == GMSX_ERR_UNSUPPORTED) {
-        GMSX_HIP(hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * size_t(std::max<int64_t>(g->n, 1)), s));
-        rc = run_edge_pairs(g, 1, 0, 1, nullptr, d_counts, stats);
-    }
-    if (rc) return rc;
+    if (int rc = tc_vertex_counts_device(g, d_counts, stats)) return rc;
     if (g->n > 0) GMSX_HIP(hipMemcpy(counts, d_counts, sizeof(int64_t) * size_t(g->n), hipMemcpyDeviceToHost));
     return GMSX_OK;
 }

@@ -542,34 +542,62 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
     }
 }
 
-// units / probes of a partition (untimed bookkeeping for gmsx_stats): wave per pivot position
+// units / probes / algorithmic stream bytes of a partition (untimed bookkeeping for gmsx_stats): wave per pivot position.
+// out[2] follows what the three count kernels read, byte for byte, assuming no on-chip reuse:
+//   pivot u (d+ >= 2): its own hub + tail containers once;
+//   heavy pivot (d+ >= 64, k_tc_block): every hub member's row in the form hub_row_extent() picks (bitset words or 16-bit list),
+//       every tail member's 16-bit list and (except the first) its 32-bit list;
+//   light pivot (k_tc_wave_hub + k_tc_wave): one 4-byte word gathered per (hub member with a bitset, lane) pair; tail members as above.
 __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
-                                                  int64_t first, int64_t end, int nparts, int part,
+                                                  int32_t dense_limit, int64_t first, int64_t end, int nparts, int part,
                                                   unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
-    unsigned long long units = 0, probes = 0;
+    unsigned long long units = 0, probes = 0, bytes = 0;
     for (int64_t q = wave0;; q += nwaves) {
         const int64_t pos = first + q * nparts + part;
         if (pos >= end) break;
         const int32_t u = order[pos];
-        if (lane == 0) units += (unsigned long long)dplus[u];
+        const int du = dplus[u];
+        const int hl = int(hoff[u + 1] - hoff[u]), tl = int(toff[u + 1] - toff[u]);
+        if (lane == 0) {
+            units += (unsigned long long)du;
+            if (du >= 2) bytes += 2ull * hl + 4ull * tl;
+        }
+        const bool heavy = du >= 64, work = du >= 2;
         for (int64_t j = hoff[u] + lane; j < hoff[u + 1]; j += 64) {
             const uint32_t v = hadj[j];
-            if (v != 0xFFFFu) probes += (unsigned long long)dplus[v];
+            if (v == 0xFFFFu) continue;
+            probes += (unsigned long long)dplus[v];
+            if (!work) continue;
+            if (heavy) {
+                const unsigned long long list = 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
+                const unsigned long long bits = 4ull * (unsigned long long)bitset_words(int32_t(v));
+                bytes += (int32_t(v) < dense_limit && bits + 32 < list) ? bits : list;
+            } else if (int32_t(v) < dense_limit) {
+                bytes += 4ull * (unsigned long long)hl;  // one word per lane that holds a member
+            }
         }
-        for (int64_t j = toff[u] + lane; j < toff[u + 1]; j += 64) probes += (unsigned long long)dplus[tadj[j]];
+        for (int64_t j = toff[u] + lane; j < toff[u + 1]; j += 64) {
+            const int32_t v = tadj[j];
+            probes += (unsigned long long)dplus[v];
+            if (!work) continue;
+            bytes += 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
+            if (j > toff[u]) bytes += 4ull * (unsigned long long)(toff[v + 1] - toff[v]);
+        }
     }
     for (int s = 32; s > 0; s >>= 1) {
         units += __shfl_down(units, s);
         probes += __shfl_down(probes, s);
+        bytes += __shfl_down(bytes, s);
     }
     if (lane == 0) {
         if (units) atomicAdd(&out[0], units);
         if (probes) atomicAdd(&out[1], probes);
+        if (bytes) atomicAdd(&out[2], bytes);
     }
 }
 
@@ -585,9 +613,9 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     if (int rc = count_dplus_ge(g, 64, &n_block)) return rc;
     if (int rc = count_dplus_ge(g, 2, &n_work)) return rc;
     unsigned long long *acc = g->acc;  // persistent per-graph accumulators: no allocation on the call path
-    static_assert(kAccSlots * kAccStride + 2 <= kAccWords, "gmsx_graph::acc too small");
+    static_assert(kAccSlots * kAccStride + 3 <= kAccWords, "gmsx_graph::acc too small");
     GMSX_HIP(hipEventRecord(c.ev[0], s));
-    GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * (kAccSlots * kAccStride + 2), s));
+    GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * (kAccSlots * kAccStride + 3), s));
     GMSX_HIP(hipEventRecord(c.ev[1], s));
 
     int launches = 0;
@@ -621,10 +649,10 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
             hipLaunchKernelGGL(k_tc_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus,
-                               g->order, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
+                               g->order, g->dense_limit, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
         }
     }
-    unsigned long long host[kAccSlots * kAccStride + 2];
+    unsigned long long host[kAccSlots * kAccStride + 3];
     GMSX_HIP(hipMemcpyAsync(host, acc, sizeof(host), hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     unsigned long long total = 0;
@@ -641,12 +669,14 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
             g->stats_nparts = nparts;
             g->stats_units = host[kAccSlots * kAccStride];
             g->stats_probes = host[kAccSlots * kAccStride + 1];
+            g->stats_bytes = host[kAccSlots * kAccStride + 2];
         }
         st->units = g->stats_units;
         st->probes = g->stats_probes;
         st->alg_elements = nparts == 1 ? g->alg_elements : 0;
         st->launches = launches;
         st->reserved = 0;
+        st->stream_bytes = g->stats_bytes;
     }
     return GMSX_OK;
 }

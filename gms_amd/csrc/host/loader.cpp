@@ -256,23 +256,27 @@ static void prefix_sum(const int64_t *cnt, int64_t n, int64_t *off) {
 #endif
     std::vector<int64_t> part(size_t(nt) + 1, 0);
     const int64_t chunk = (n + nt - 1) / std::max(nt, 1);
+    // slices are walked by slice index, not by thread id: the team may be smaller than `nt` (OMP_THREAD_LIMIT, OMP_DYNAMIC,
+    // a nested region) and every slice must still be summed and written
 #pragma omp parallel num_threads(nt)
     {
-        int t = 0;
-#ifdef _OPENMP
-        t = omp_get_thread_num();
-#endif
-        const int64_t lo = std::min<int64_t>(n, t * chunk), hi = std::min<int64_t>(n, lo + chunk);
-        int64_t s = 0;
-        for (int64_t i = lo; i < hi; ++i) s += cnt[i];
-        part[size_t(t) + 1] = s;
-#pragma omp barrier
+#pragma omp for schedule(static, 1)
+        for (int t = 0; t < nt; ++t) {
+            const int64_t lo = std::min<int64_t>(n, t * chunk), hi = std::min<int64_t>(n, lo + chunk);
+            int64_t s = 0;
+            for (int64_t i = lo; i < hi; ++i) s += cnt[i];
+            part[size_t(t) + 1] = s;
+        }
 #pragma omp single
         for (int i = 0; i < nt; ++i) part[size_t(i) + 1] += part[size_t(i)];
-        s = part[size_t(t)];
-        for (int64_t i = lo; i < hi; ++i) {
-            off[i] = s;
-            s += cnt[i];
+#pragma omp for schedule(static, 1)
+        for (int t = 0; t < nt; ++t) {
+            const int64_t lo = std::min<int64_t>(n, t * chunk), hi = std::min<int64_t>(n, lo + chunk);
+            int64_t s = part[size_t(t)];
+            for (int64_t i = lo; i < hi; ++i) {
+                off[i] = s;
+                s += cnt[i];
+            }
         }
     }
     off[n] = part[size_t(nt)];
@@ -318,15 +322,12 @@ static int build_from_el(const EdgeList &el, int64_t num_nodes, bool symmetrize,
         lo = m * int64_t(t) / nthreads;
         hi = m * int64_t(t + 1) / nthreads;
     };
-#pragma omp parallel num_threads(nthreads)
-    {
-        int t = 0;
-#ifdef _OPENMP
-        t = omp_get_thread_num();
-#endif
+    // (slices are handed out by index with schedule(static,1): correct for any team size the runtime actually delivers)
+#pragma omp parallel for schedule(static, 1) num_threads(nthreads)
+    for (int t = 0; t < nthreads; ++t) {
         int64_t lo, hi;
         slice(t, lo, hi);
-        int64_t *h = hist.get() + size_t(t) * size_t(nb);  // layout [thread][bucket] while counting
+        int64_t *h = hist.get() + size_t(t) * size_t(nb);  // layout [slice][bucket] while counting
         for (int64_t e = lo; e < hi; ++e) {
             if (eu[e] == ev[e]) continue;
             ++h[eu[e] >> shift];
@@ -352,12 +353,8 @@ static int build_from_el(const EdgeList &el, int64_t num_nodes, bool symmetrize,
     std::unique_ptr<int32_t[]> pnbr(new (std::nothrow) int32_t[size_t(std::max<int64_t>(raw_nnz, 1))]);
     std::unique_ptr<int32_t[]> raw(new (std::nothrow) int32_t[size_t(std::max<int64_t>(raw_nnz, 1))]);
     if (!prow || !pnbr || !raw) return GMSX_ERR_NOMEM;
-#pragma omp parallel num_threads(nthreads)
-    {
-        int t = 0;
-#ifdef _OPENMP
-        t = omp_get_thread_num();
-#endif
+#pragma omp parallel for schedule(static, 1) num_threads(nthreads)
+    for (int t = 0; t < nthreads; ++t) {
         int64_t lo, hi;
         slice(t, lo, hi);
         int64_t *cur = hist.get() + size_t(t) * size_t(nb);
@@ -641,6 +638,16 @@ static int read_sg(const std::string &path, Csr &g) {
     if (std::fread(g.off.get(), 8, size_t(n + 1), f) != size_t(n + 1)) return GMSX_ERR_FORMAT;
     if (nnz && std::fread(g.neigh.get(), 4, size_t(nnz), f) != size_t(nnz)) return GMSX_ERR_FORMAT;
     if (g.off[0] != 0 || g.off[n] != nnz) return GMSX_ERR_FORMAT;
+    // a stale / truncated / planted cache file must not lead to out-of-bounds row walks later: offsets monotone, ids in range
+    int bad = 0;
+    const int64_t *off = g.off.get();
+    const int32_t *ng = g.neigh.get();
+#pragma omp parallel for reduction(| : bad) schedule(static)
+    for (int64_t u = 0; u < n; ++u) bad |= int(off[u + 1] < off[u]);
+    if (bad) return GMSX_ERR_FORMAT;
+#pragma omp parallel for reduction(| : bad) schedule(static)
+    for (int64_t j = 0; j < nnz; ++j) bad |= int(ng[j] < 0 || int64_t(ng[j]) >= n);
+    if (bad) return GMSX_ERR_FORMAT;
     g.directed = directed != 0;
     return GMSX_OK;
 }

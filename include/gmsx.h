@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GMSX_VERSION 100
+#define GMSX_VERSION 200
 
 /* ---- status codes ---- */
 enum {
@@ -44,7 +44,8 @@ enum {
     GMSX_ERR_NOT_CANONICAL = -8,/* CSR rows not sorted / not loop-free / not symmetric where required */
     GMSX_ERR_OVERFLOW = -9,     /* ids do not fit int32 (reference: exit(-31), generator.h:41-48) */
     GMSX_ERR_UNSUPPORTED = -10, /* valid request outside what this build implements */
-    GMSX_ERR_KERNEL = -11       /* a kernel launch or device synchronisation failed */
+    GMSX_ERR_KERNEL = -11,      /* a kernel launch or device synchronisation failed */
+    GMSX_ERR_COMM = -12         /* librccl missing or an RCCL call failed */
 };
 const char *gmsx_strerror(int status);
 int gmsx_version(void);
@@ -118,9 +119,14 @@ typedef struct gmsx_stats {
     uint64_t probes;           /* TC: ids the oriented kernels stream (work-efficiency numerator); BK: resume rounds; else 0 */
     int32_t launches;          /* number of kernel launches inside kernel_ms */
     int32_t reserved;
+    uint64_t stream_bytes;     /* TC (oriented): algorithmic bytes of THIS formulation per call — every pivot's own containers once, plus
+                                  for every oriented edge (u,v) the bytes of N+(v) in the container form the kernels read (bitset words,
+                                  16-bit list, 32-bit list; 4 bytes per inverted gather).  No cache is assumed: the traffic a pass would
+                                  cause if nothing were ever re-used on chip.  0 for the other entry points. */
 } gmsx_stats;
 
-/* Bind this process to one HIP device.  device<0 → current device. */
+/* Bind this process to one HIP device.  device<0 → current device.  Calling it again with the same device is a no-op (and makes
+ * the device current for the calling host thread); a different device → GMSX_ERR_UNSUPPORTED (one device per process). */
 int gmsx_init(int device);
 /* Use a caller-owned HIP stream (hipStream_t passed as void*) for all subsequent launches; NULL → library stream. */
 int gmsx_set_stream(void *hip_stream);
@@ -190,11 +196,40 @@ int gmsx_kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint6
 
 /* ---- Bron–Kerbosch maximal-clique count: BkEppsteinPar::mceBench with -DBK_COUNT
  * (maximal_clique_enum/parallel/eppsteinPAR.h:18-53 over sequential/tomita.h:12-86).
- * rank: n entries in rank format, or NULL → degree rank (preprocessing/parallel/degree.h:26-62).
- * The count does not depend on the rank.  Limit: a start vertex may have at most 4096 candidates (d+ <= 4096 in the device's
- * degree rank), else GMSX_ERR_UNSUPPORTED. */
+ * rank: n entries in rank format (host), or NULL.  The number of maximal cliques does not depend on the order the start
+ * vertices split their neighbourhoods by (eppsteinPAR.h:39-45), so the device always splits by its own degree rank (the
+ * order its containers are built for); a non-NULL `rank` is only VALIDATED — it must be a permutation of 0..n-1, else
+ * GMSX_ERR_INVALID — the way the reference's drivers hand a rank vector from the preprocessing step to mceBench
+ * (maximal_clique_enum_bron_kerbosch.cc:36-56).  gmsx_adg_rank() below is that preprocessing step on the device. */
 int gmsx_bk_count(const gmsx_graph *g, const int32_t *rank, uint64_t *maximal_cliques, gmsx_stats *stats);
 int gmsx_bk_partial(const gmsx_graph *g, const int32_t *rank, int part, int nparts, uint64_t *partial, gmsx_stats *stats);
+
+/* ---- vertex orderings that consume the path's operators ----
+ * PpParallel::getDegeneracyOrderingApproxSGraph<boundary_function::averageDegree> (preprocessing/parallel/
+ * degeneracy_approx_set.h:14-86, boundary_function.h:14-23): peel in rounds — every remaining vertex whose remaining degree is
+ * <= (unsigned)((1+epsilon) * average remaining degree) leaves in this round; the degrees of the others drop by
+ * |N(v) ∩ X| (the intersect_count of :77).  out[n] (host): rank_format != 0 → out[v] = position of v (what BK consumes,
+ * eppsteinPAR.h:41), else out[i] = i-th vertex.  *rounds (may be NULL) = number of peeling rounds.
+ * Ties: inside a round the vertices are ordered by (remaining degree, vertex id).  The reference leaves ties to
+ * __gnu_parallel::partition / sort (:41-59), i.e. to the thread count; every order it can produce has the same rounds and the
+ * same remaining-degree sequence as this one. */
+int gmsx_adg_rank(const gmsx_graph *g, double epsilon, int rank_format, int32_t *out, int32_t *rounds, gmsx_stats *stats);
+/* PpParallel::triangleCountOrdering (preprocessing/parallel/triangle_count.h:11-30): ordering[i] = i-th vertex by increasing
+ * per-vertex count (the counts of gmsx_tc_vertex_count2); ties by vertex id (the reference's std::sort leaves them open). */
+int gmsx_tc_ordering(const gmsx_graph *g, int32_t *ordering /* n, host */, gmsx_stats *stats);
+
+/* ---- the one collective of the path: the OpenMP reduction(+:total) of parallel/total.h:12,
+ * k_clique_count_set_based.h:25 and the BK_CLIQUE_COUNTER atomic (tomita.h:76-77) across GPUs = ONE all-reduce of a u64 over
+ * RCCL/xGMI.  One process per GPU; the 128-byte id is created on one rank (gmsx_comm_unique_id) and handed to the others by the
+ * launcher (file, environment, MPI, torch.distributed store — the library does not care).  librccl is loaded on first use. */
+typedef struct gmsx_comm gmsx_comm;
+#define GMSX_COMM_ID_BYTES 128
+int gmsx_comm_unique_id(void *id /* GMSX_COMM_ID_BYTES, out */);
+int gmsx_comm_init(int rank, int nranks, const void *id /* GMSX_COMM_ID_BYTES */, gmsx_comm **out); /* ncclCommInitRank on the bound device */
+int gmsx_comm_allreduce_u64(gmsx_comm *c, uint64_t *value /* in: this rank's partial, out: the sum */); /* ncclAllReduce(count=1, ncclUint64, ncclSum) */
+int gmsx_comm_rank(const gmsx_comm *c);
+int gmsx_comm_size(const gmsx_comm *c);
+int gmsx_comm_finalize(gmsx_comm *c);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,9 @@ class Oracle:
         L.gmso_bk_count.restype = C.c_uint64
         L.gmso_bk_count.argtypes = [C.c_int64, _i64p, _i32p, _i32p, C.c_int]
         L.gmso_degree_rank.argtypes = [C.c_int64, _i64p, _i32p]
+        L.gmso_adg_rank.restype = C.c_int32
+        L.gmso_adg_rank.argtypes = [C.c_int64, _i64p, _i32p, C.c_double, _i32p, _i32p, _i32p]
+        L.gmso_tc_ordering.argtypes = [C.c_int64, _i64p, _i32p, C.c_int, _i32p]
         L.gmso_tc_elements.restype = C.c_uint64
         L.gmso_tc_elements.argtypes = [C.c_int64, _i64p, _i32p]
         L.gmso_max_threads.restype = C.c_int
@@ -118,6 +121,18 @@ class Oracle:
             rank = self.degree_rank(off)
         return int(self.L.gmso_bk_count(off.size - 1, off, neigh, np.ascontiguousarray(rank, dtype=np.int32), threads))
 
+    def adg_rank(self, off, neigh, epsilon=0.001):
+        """(rank, round_of, degree_at_removal, rounds)"""
+        n = off.size - 1
+        rank, rnd, deg = (np.zeros(max(n, 1), dtype=np.int32) for _ in range(3))
+        rounds = int(self.L.gmso_adg_rank(n, off, neigh, float(epsilon), rank, rnd, deg))
+        return rank[:n], rnd[:n], deg[:n], rounds
+
+    def tc_ordering(self, off, neigh, threads=0):
+        o = np.zeros(max(off.size - 1, 1), dtype=np.int32)
+        self.L.gmso_tc_ordering(off.size - 1, off, neigh, threads, o)
+        return o[:off.size - 1]
+
     def vertex_similarity(self, metric, off, neigh, u, v):
         return np.array([self.L.gmso_vertex_similarity(metric, off.size - 1, off, neigh, int(a), int(b)) for a, b in zip(u, v)], dtype=np.float64)
 
@@ -162,6 +177,8 @@ class Reference:
         L.ref_bk_count.restype = C.c_uint64
         L.ref_bk_count.argtypes = [vp, C.c_int, C.c_int]
         L.ref_rank.argtypes = [vp, C.c_int, _i32p]
+        if hasattr(L, "ref_tc_ordering"):
+            L.ref_tc_ordering.argtypes = [vp, C.c_int, _i32p]
         L.ref_set_op.restype = C.c_int64
         L.ref_set_op.argtypes = [C.c_int, C.c_int, _i32p, C.c_int64, _i32p, C.c_int64, _i32p]
         L.ref_omp_threads.restype = C.c_int
@@ -175,6 +192,15 @@ class Reference:
 
     def free(self, g):
         self.L.ref_graph_free(g)
+
+    def num_nodes(self, g):
+        return int(self.L.ref_num_nodes(g))
+
+    def nnz(self, g):
+        return int(self.L.ref_nnz(g))
+
+    def omp_threads(self):
+        return int(self.L.ref_omp_threads())
 
     def csr(self, g):
         n, nnz = self.L.ref_num_nodes(g), self.L.ref_nnz(g)
@@ -201,6 +227,11 @@ class Reference:
         r = np.empty(self.L.ref_num_nodes(g), dtype=np.int32)
         self.L.ref_rank(g, order, r)
         return r
+
+    def tc_ordering(self, g, set_kind=0):
+        o = np.empty(self.L.ref_num_nodes(g), dtype=np.int32)
+        self.L.ref_tc_ordering(g, set_kind, o)
+        return o
 
     def vertex_similarity(self, g, metric, u, v, set_kind=0):
         u = np.ascontiguousarray(u, dtype=np.int32)

@@ -344,3 +344,76 @@ double gmso_vertex_similarity(int metric, int64_t n, const int64_t *off, const i
         default: return (double)(la * lb);
     }
 }
+
+/* ------------------------------------------------------------------ orderings that consume intersect_count */
+
+typedef struct { int32_t deg; int32_t id; } adg_key;
+static int cmp_degid_asc(const void *p, const void *q) {
+    const adg_key *a = (const adg_key *)p, *b = (const adg_key *)q;
+    if (a->deg != b->deg) return a->deg < b->deg ? -1 : 1;
+    return a->id < b->id ? -1 : (a->id > b->id);
+}
+
+/* degeneracy_approx_set.h:14-86 with boundary_function::averageDegree (boundary_function.h:14-23). */
+int32_t gmso_adg_rank(int64_t n, const int64_t *off, const int32_t *neigh, double epsilon, int32_t *rank, int32_t *round_of,
+                      int32_t *deg_at) {
+    int32_t *deg = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));   /* degreeCounter (:22) */
+    int32_t *work = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));  /* vArray (:23), [start, n) = remaining */
+    adg_key *batch = (adg_key *)malloc(sizeof(adg_key) * (size_t)(n > 0 ? n : 1));
+    int32_t *x = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));     /* the batch as a sorted set X (:62) */
+    for (int64_t i = 0; i < n; i++) { deg[i] = (int32_t)(off[i + 1] - off[i]); work[i] = (int32_t)i; }
+    int64_t start = 0, counter = 0;
+    int32_t rounds = 0;
+    while (counter < n) {
+        const int64_t remaining = n - start;
+        double res = 0;  /* boundary_function.h:16-22: sum in double, (1+eps)*(res/size), truncated to unsigned (:39) */
+        for (int64_t i = start; i < n; i++) res += deg[work[i]];
+        const unsigned border = (unsigned)((1 + epsilon) * (res / (double)remaining));
+        /* partition (:41-51): vertices with degree <= border to the front, then sort them by degree (:55-59); ties by id here */
+        int64_t mid = 0;
+        int64_t keep = n;  /* stable two-way split into batch[] and the tail of work[] */
+        for (int64_t i = n - 1; i >= start; i--) {
+            const int32_t v = work[i];
+            if ((unsigned)deg[v] <= border) { batch[mid].deg = deg[v]; batch[mid].id = v; mid++; }
+            else work[--keep] = v;
+        }
+        qsort(batch, (size_t)mid, sizeof(adg_key), cmp_degid_asc);
+        for (int64_t i = 0; i < mid; i++) {
+            const int32_t v = batch[i].id;
+            rank[v] = (int32_t)(counter + i);  /* rank format (:68-69) */
+            if (round_of) round_of[v] = rounds;
+            if (deg_at) deg_at[v] = batch[i].deg;
+            x[i] = v;
+        }
+        qsort(x, (size_t)mid, sizeof(int32_t), cmp_i32);  /* Set X(start_index, mid) (:62) */
+        /* PULL update (:74-79): every remaining vertex loses |N(v) ∩ X| */
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int64_t i = keep; i < n; i++) {
+            const int32_t v = work[i];
+            deg[v] -= (int32_t)gmso_intersect_count(neigh + off[v], (size_t)(off[v + 1] - off[v]), x, (size_t)mid);
+        }
+        start = keep;
+        counter += mid;
+        rounds++;
+        (void)remaining;
+    }
+    free(deg); free(work); free(batch); free(x);
+    return rounds;
+}
+
+typedef struct { int64_t cnt; int32_t id; } cnt_id;
+static int cmp_cntid_asc(const void *p, const void *q) {
+    const cnt_id *a = (const cnt_id *)p, *b = (const cnt_id *)q;
+    if (a->cnt != b->cnt) return a->cnt < b->cnt ? -1 : 1;
+    return a->id < b->id ? -1 : (a->id > b->id);
+}
+/* preprocessing/parallel/triangle_count.h:11-30 */
+void gmso_tc_ordering(int64_t n, const int64_t *off, const int32_t *neigh, int threads, int32_t *ordering) {
+    int64_t *counts = (int64_t *)calloc((size_t)(n > 0 ? n : 1), sizeof(int64_t));
+    cnt_id *keys = (cnt_id *)malloc(sizeof(cnt_id) * (size_t)(n > 0 ? n : 1));
+    gmso_tc_vertex_count2_once(n, off, neigh, threads, counts);  /* CountFn default (:14) */
+    for (int64_t u = 0; u < n; u++) { keys[u].cnt = counts[u]; keys[u].id = (int32_t)u; }
+    qsort(keys, (size_t)n, sizeof(cnt_id), cmp_cntid_asc);
+    for (int64_t i = 0; i < n; i++) ordering[i] = keys[i].id;
+    free(counts); free(keys);
+}

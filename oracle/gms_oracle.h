@@ -58,6 +58,19 @@ uint64_t gmso_bk_count(int64_t n, const int64_t *off, const int32_t *neigh, cons
  * rank = position in ascending (degree, id) order. */
 void gmso_degree_rank(int64_t n, const int64_t *off, int32_t *rank);
 
+/* PpParallel::getDegeneracyOrderingApproxSGraph<boundary_function::averageDegree, useRankFormat=true>
+ * (gms/algorithms/preprocessing/parallel/degeneracy_approx_set.h:14-86, boundary_function.h:14-23): rounds of
+ * "remove every remaining vertex with remaining degree <= (unsigned)((1+eps) * mean remaining degree)", the others'
+ * degrees drop by |N(v) ∩ X| (PULL style, :74-79).  rank[v] = position.  round_of / deg_at (may be NULL) receive the round a
+ * vertex left in and its remaining degree at that moment.  Ties inside a round: (degree, id) — the reference leaves them to
+ * __gnu_parallel::partition/sort; tests check its output is one of the orders this function's (round, degree) keys allow.
+ * Returns the number of rounds. */
+int32_t gmso_adg_rank(int64_t n, const int64_t *off, const int32_t *neigh, double epsilon, int32_t *rank, int32_t *round_of,
+                      int32_t *deg_at);
+/* PpParallel::triangleCountOrdering (preprocessing/parallel/triangle_count.h:11-30) over Par::vertex_count2_once:
+ * ordering[i] = i-th vertex by increasing count, ties by id (std::sort leaves them unspecified). */
+void gmso_tc_ordering(int64_t n, const int64_t *off, const int32_t *neigh, int threads, int32_t *ordering);
+
 /* ---- vertex similarity (gms/algorithms/set_based/vertex_similarity/vertex_similarity.h:30-222) ----
  * metric: 0 Jaccard (sic: count/(|A|+|B|+count), :31-36), 1 Overlap (:66-68), 2 Adamic-Adar (:96-108), 3 Resource (:120-128),
  * 4 CommNeigh (:139-143), 5 TotalNeigh (:155-159), 6 PrefAtt (:171-174).  Double precision, reference evaluation order. */

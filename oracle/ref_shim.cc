@@ -12,6 +12,7 @@
 //   k-clique    gms/algorithms/set_based/k_clique_count/k_clique_count_set_based.h:5-31
 //   BK          gms/algorithms/set_based/maximal_clique_enum/parallel/eppsteinPAR.h:18-53 (+ sequential/tomita.h:12-86)
 //   set algebra gms/representations/sets/sorted_set.h:21-272, roaring_set.h:15-229
+//   orderings   gms/algorithms/preprocessing/parallel/degeneracy_approx_set.h:14-86, degree.h:26-62, triangle_count.h:11-30
 #include "gms/third_party/gapbs/benchmark.h"
 #include <gms/common/cli/cli.h>
 #include <gms/common/types.h>
@@ -21,6 +22,7 @@
 #include <gms/algorithms/set_based/k_clique_count/k_clique_count_set_based.h>
 #include <gms/algorithms/set_based/maximal_clique_enum/bron_kerbosch.h>
 #include <gms/algorithms/set_based/vertex_similarity/vertex_similarity.h>
+#include <gms/algorithms/preprocessing/parallel/triangle_count.h>
 
 #include <fcntl.h>
 #include <unistd.h>
@@ -177,6 +179,15 @@ void ref_rank(void *h, int order, int32_t *out) {
         PpParallel::getDegeneracyOrderingApproxSGraph<PpParallel::boundary_function::averageDegree, true, SortedSetGraph, pvector<NodeId>>(sg, rank, 0.001);
     else PpSequential::getDegeneracyOrderingMatula<SortedSetGraph, true, pvector<NodeId>>(sg, rank);
     for (int64_t i = 0; i < sg.num_nodes(); i++) out[i] = rank[i];
+}
+// PpParallel::triangleCountOrdering (preprocessing/parallel/triangle_count.h:11-30), order format
+void ref_tc_ordering(void *h, int set_kind, int32_t *out) {
+    Quiet q;
+    const CSRGraph &g = static_cast<RefGraph *>(h)->g;
+    std::vector<NodeId> ord;
+    if (set_kind == 0) { auto sg = SortedSetGraph::FromCGraph(g); PpParallel::triangleCountOrdering<SortedSetGraph>(sg, ord); }
+    else { auto sg = RoaringGraph::FromCGraph(g); PpParallel::triangleCountOrdering<RoaringGraph>(sg, ord); }
+    for (size_t i = 0; i < ord.size(); i++) out[i] = ord[i];
 }
 // op codes: see set_op above.  `out` must hold na+nb elements.  Returns count / cardinality.
 int64_t ref_set_op(int set_kind, int op, const int32_t *a, int64_t na, const int32_t *b, int64_t nb, int32_t *out) {

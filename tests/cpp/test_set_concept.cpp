@@ -1,9 +1,10 @@
-// CPU test of the C++ adaptor (include/gmsx_set_graph.hpp): gmsx::SortedSpanSet must behave like the reference's
+// CPU test of the C++ adaptor (include/gmsx_set_graph.hpp): gmsx::SortedSpanSet / RoaringSpanSet / SortedSpanRef must behave like the reference's
 // Set concept on the literal cases of testing/sets.cpp (values restated from SURVEY §8b), and gmsx::HipSetGraph must
 // expose the SGraph surface.  With -DWITH_REFERENCE the reference's own generic algorithm templates are instantiated
 // over HipSetGraph on the host (no device call) and compared with the reference's SortedSetGraph.
 #include <cassert>
 #include <cstdio>
+#include <type_traits>
 #include <vector>
 
 #ifdef WITH_REFERENCE
@@ -18,12 +19,13 @@
 
 #include "gmsx_set_graph.hpp"
 
-using S = gmsx::SortedSpanSet;
 #define CHECK(x) do { if (!(x)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #x); return 1; } } while (0)
 
-static std::vector<int> vec(const S &s) { return std::vector<int>(s.begin(), s.end()); }
+template <class Set> static std::vector<int> vec(const Set &s) { return std::vector<int>(s.begin(), s.end()); }
 
-int main() {
+// the literal cases of testing/sets.cpp, for one set flavour (the reference runs them as a typed test over its set types, sets.cpp:15-24)
+template <class S>
+static int set_cases() {
     // construction is order-insensitive and from unsorted input (sets.cpp:39,80-94)
     CHECK(S({2, 4, 8}) == S({4, 2, 8}));
     const int raw[] = {1, 5, 2, 7, 9, 0, 3};
@@ -76,13 +78,68 @@ int main() {
     }
     CHECK(c != d && !(c == d));
 
+    // ---- views (the zero-copy row form): read-only ops work in place, the first mutation detaches a private copy ----
+    {
+        const int32_t row[] = {1, 3, 5, 7, 9};
+        S v = S::borrow(row, 5);
+        CHECK(v.borrowed() && v.data() == row && v.cardinality() == 5 && v.contains(7) && !v.contains(8));
+        CHECK(v.intersect_count(c) == 3 && vec(v.intersect(c)) == (std::vector<int>{1, 3, 5}) && vec(v.difference(c)) == (std::vector<int>{7, 9}));
+        S w = v.clone();
+        CHECK(!w.borrowed() && w == v && w.data() != row);
+        v.union_inplace(4);  // detaches
+        CHECK(!v.borrowed() && vec(v) == (std::vector<int>{1, 3, 4, 5, 7, 9}) && row[2] == 5);
+        S x = S::borrow(row, 5);
+        x.remove(3);
+        CHECK(vec(x) == (std::vector<int>{1, 5, 7, 9}) && row[1] == 3);
+        S y = S::borrow(row, 5);
+        y.intersect_inplace(c);
+        CHECK(vec(y) == (std::vector<int>{1, 3, 5}) && row[3] == 7);
+        S z = S::borrow(row, 5);
+        z.difference_inplace(c);
+        CHECK(vec(z) == (std::vector<int>{7, 9}));
+        S m = std::move(z);
+        CHECK(vec(m) == (std::vector<int>{7, 9}) && z.cardinality() == 0);
+        for (int i = 0; i < 100; ++i) m.add(100 - i);  // growth path
+        CHECK(m.cardinality() == 100 && m.contains(1) && m.contains(100) && m.contains(7));
+    }
+    return 0;
+}
+
+int main() {
+    if (set_cases<gmsx::SortedSpanSet>()) return 1;
+    if (set_cases<gmsx::RoaringSpanSet>()) return 1;
+    using S = gmsx::SortedSpanSet;
+    static_assert(sizeof(S) == 16 && sizeof(gmsx::SortedSpanRef) == 16, "a row view is pointer + count");
+    static_assert(std::is_same_v<decltype(*gmsx::RoaringSpanSet().begin()), const uint32_t &>, "Roaring flavour iterates uint32 (roaring_set.h:82-105)");
+    static_assert(std::is_same_v<decltype(*S().begin()), const int32_t &>, "SortedSet flavour iterates SetElement");
+    {   // SortedSetRef surface (sorted_set_ref.h:9-78): borrowed, operators return owning sets
+        const int32_t row[] = {1, 2, 3, 4, 5}, other[] = {3, 4, 5, 6, 8};
+        gmsx::SortedSpanRef r(row, 5), o(other, 5);
+        CHECK(r.cardinality() == 5 && r.begin() == row && r.intersect_count(o) == 3);
+        CHECK(vec(r.intersect(o)) == (std::vector<int>{3, 4, 5}) && vec(r.difference(o)) == (std::vector<int>{1, 2}));
+        CHECK(vec(r.union_with(o)).size() == 7 && r.contains(5) && !r.contains(6));
+        CHECK(vec(r.intersect(S{2, 3, 9})) == (std::vector<int>{2, 3}));
+    }
+
     // SGraph surface on a tiny CSR through the C-ABI host substrate (no device call)
     const int32_t src[] = {0, 1, 2, 2}, dst[] = {1, 2, 0, 3};
     gmsx_csr *csr = nullptr;
     CHECK(gmsx_csr_from_edges(-1, 4, src, dst, 1, GMSX_RELABEL_NEVER, &csr) == GMSX_OK);
-    gmsx::HipSetGraph hg = gmsx::HipSetGraph::FromCsr(csr);
-    CHECK(hg.num_nodes() == 4 && hg.out_degree(2) == 3 && vec(hg.out_neigh(2)) == (std::vector<int>{0, 1, 3}));
-    CHECK(hg.out_neigh(0).intersect_count(hg.out_neigh(1)) == 1);
+    {
+        gmsx::HipSetGraph hg = gmsx::HipSetGraph::FromCsr(csr);
+        CHECK(hg.num_nodes() == 4 && hg.out_degree(2) == 3 && vec(hg.out_neigh(2)) == (std::vector<int>{0, 1, 3}));
+        CHECK(hg.out_neigh(0).intersect_count(hg.out_neigh(1)) == 1);
+        // zero-copy: the rows are views into the gmsx_csr arrays, no second adjacency
+        CHECK(hg.borrows_adjacency() && hg.neighbors() == gmsx_csr_neighbors(csr) && hg.out_neigh(2).data() == gmsx_csr_neighbors(csr) + gmsx_csr_offsets(csr)[2]);
+        gmsx::HipSetGraph deep = hg.clone();
+        CHECK(!deep.borrows_adjacency() && deep.num_nodes() == 4 && deep.out_neigh(2) == hg.out_neigh(2));
+        gmsx::HipRoaringGraph rg = gmsx::HipRoaringGraph::FromCsr(csr);
+        unsigned sum = 0;
+        for (auto v : rg.out_neigh(2)) sum += v;  // uint32 iteration
+        CHECK(sum == 4 && rg.out_neigh(2).intersect_count(rg.out_neigh(0)) == 1);
+        gmsx::HipSetRefGraph fg = gmsx::HipSetRefGraph::FromCsr(csr);
+        CHECK(fg.out_neigh(2).cardinality() == 3 && fg.out_neigh(2).intersect_count(fg.out_neigh(0)) == 1);
+    }
     gmsx_csr_free(csr);
 
 #ifdef WITH_REFERENCE
@@ -94,6 +151,8 @@ int main() {
         auto ref = SortedSetGraph::FromCGraph(cg);
         auto mine = gmsx::HipSetGraph::FromCGraph(cg);
         CHECK(mine.num_nodes() == ref.num_nodes());
+        // zero-copy from the reference's CSRGraph: rows are views into ITS neighbour array (gapbs/graph.h:361-364)
+        CHECK(mine.borrows_adjacency() && mine.out_neigh(0).data() == cg.out_neigh(0).begin());
         CHECK(GMS::TriangleCount::Seq::count_total(mine) == GMS::TriangleCount::Seq::count_total(ref));
         CHECK(GMS::TriangleCount::Par::count_total(mine) == 10479);  // tests/golden/graphs.json kronecker-8
         std::vector<int64_t> c1, c2;
@@ -106,6 +165,21 @@ int main() {
         BK_CLIQUE_COUNTER = 0;
         BkEppsteinPar::mceBench<gmsx::HipSetGraph>(mine, rank);
         CHECK(BK_CLIQUE_COUNTER == 1808);  // tests/golden/graphs.json kronecker-8 bk
+        // the Roaring flavour through the same generic templates (the BK driver instantiates RoaringGraph, …bron_kerbosch.cc:84-91)
+        auto rmine = gmsx::HipRoaringGraph::FromCGraph(cg);
+        CHECK(GMS::TriangleCount::Par::count_total(rmine) == 10479);
+        BK_CLIQUE_COUNTER = 0;
+        BkEppsteinPar::mceBench<gmsx::HipRoaringGraph>(rmine, rank);
+        CHECK(BK_CLIQUE_COUNTER == 1808);
+        // ADG on the host through the generic template over our sets == over the reference's (1 thread: deterministic ties)
+        omp_set_num_threads(1);
+        pvector<NodeId> r1(mine.num_nodes()), r2(mine.num_nodes());
+        PpParallel::getDegeneracyOrderingApproxSGraph<PpParallel::boundary_function::averageDegree, true, gmsx::HipSetGraph, pvector<NodeId>>(mine, r1, 0.001);
+        PpParallel::getDegeneracyOrderingApproxSGraph<PpParallel::boundary_function::averageDegree, true, SortedSetGraph, pvector<NodeId>>(ref, r2, 0.001);
+        for (int64_t i = 0; i < mine.num_nodes(); ++i) CHECK(r1[i] == r2[i]);
+        // SetGraph<SortedSetRef> flavour in the k-clique recursion (k_clique_count_set_based.cc:38)
+        auto fmine = gmsx::HipSetRefGraph::FromCGraph(cg);
+        CHECK(RecursiveStepCliqueCount(fmine, 3, fmine.out_neigh(0)) == RecursiveStepCliqueCount(ref, 3, ref.out_neigh(0)));
     }
 #endif
     std::printf("set concept ok\n");

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 GRAPHS = load_golden("graphs.json")
 
 
-@pytest.mark.parametrize("key", [k for k, v in GRAPHS.items() if "bk" in v and v["scale"] <= 12])
+@pytest.mark.parametrize("key", [k for k, v in GRAPHS.items() if "bk" in v and v["scale"] <= 14])
 def test_bk_equals_reference_golden(gpu, key):
     rec = GRAPHS[key]
     g = gpu.DeviceGraph.from_csr(host_graph(gpu, rec["generator"], rec["scale"], rec["degree"], rec["relabel"]))
@@ -38,7 +38,12 @@ def test_bk_reference_test_graphs_and_random_instances(gpu, oracle):
     for c in ka["bk_random"]:  # concrete instances of testing/bron_kerbosch.cpp:256-268
         g = gpu.DeviceGraph.from_csr(edges_to_csr(gpu, c["edges"], n=c["n"]))
         assert g.bk_count() == c["bk"]
-        assert g.bk_count(rank=np.arange(c["n"], dtype=np.int32)) == c["bk"]  # rank-independent
+        # a rank vector is validated (it must be a permutation, like every rank-format ordering) and does not change the count
+        assert g.bk_count(rank=np.arange(c["n"], dtype=np.int32)[::-1].copy()) == c["bk"]
+        for bad in (np.zeros(c["n"], dtype=np.int32), np.arange(1, c["n"] + 1, dtype=np.int32)):
+            with pytest.raises(gpu.GmsxError) as ei:
+                g.bk_count(rank=bad)
+            assert ei.value.status == gpu.ERR_INVALID
         g.free()
     for c in ka["kclique"]:
         g = gpu.DeviceGraph.from_csr(edges_to_csr(gpu, c["edges"]))

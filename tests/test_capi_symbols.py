@@ -23,7 +23,7 @@ def test_header_and_library_agree(capi):
     for name in names:
         assert hasattr(L, name), f"{name} declared in include/gmsx.h but not exported by libgmsx.so"
     assert sorted(capi.SYMBOLS) == names
-    assert capi.lib().gmsx_version() == 100
+    assert capi.lib().gmsx_version() == 200
     assert capi.lib().gmsx_strerror(-6).decode().startswith("no HIP device")
 
 
@@ -54,3 +54,11 @@ def test_device_calls_fail_loudly_without_gpu(capi):
     with pytest.raises(capi.GmsxError) as ei:
         capi.DeviceGraph.upload(np.array([0, 1, 2], dtype=np.int64), np.array([1, 0], dtype=np.int32))
     assert ei.value.status == capi.ERR_NO_DEVICE
+
+
+@pytest.mark.skipif(_have_gpu(), reason="only meaningful on a GPU-less host")
+def test_new_entry_points_fail_loudly_without_gpu(capi):
+    """The RCCL communicator and the ordering kernels have no host path either."""
+    with pytest.raises(capi.GmsxError) as ei:  # (creating an id is host-side bootstrap and may succeed; binding a rank needs the device)
+        capi.Comm.init(0, 1, bytes(capi.COMM_ID_BYTES))
+    assert ei.value.status in (capi.ERR_COMM, capi.ERR_NO_DEVICE)

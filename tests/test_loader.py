@@ -186,3 +186,53 @@ def test_host_threads_do_not_change_the_graph(capi):
         assert capi.HostCSR.generate("kronecker", 12, 16).fingerprint() == base
     finally:
         capi.set_host_threads(prev)
+
+
+def test_smaller_omp_team_than_requested_builds_the_same_graph(capi):
+    """the builder slices the edge list by omp_get_max_threads(); under OMP_THREAD_LIMIT the team is smaller than
+    that.  Every slice must still be counted and written: same fingerprint as the golden."""
+    import subprocess
+    import sys
+    from conftest import ROOT, load_golden
+    rec = load_golden("graphs.json")["kronecker-12-16-relabel"]
+    code = ("import sys; sys.path.insert(0, %r); from gms_amd import capi; capi.set_host_threads(8); "
+            "c = capi.HostCSR.generate('kronecker', 12, 16, capi.RELABEL_AUTO, 8); f = c.fingerprint(); "
+            "print('%%016x %%016x %%d %%d' %% (f[0], f[1], c.num_nodes, c.num_edges))" % ROOT)
+    for limit in ("1", "2", "3"):
+        env = dict(os.environ, OMP_THREAD_LIMIT=limit, OMP_DYNAMIC="true")
+        out = subprocess.run([sys.executable, "-c", code], env=env, check=True, capture_output=True, text=True).stdout.split()
+        assert out == [rec["offsets_fnv64"], rec["neigh_fnv64"], str(rec["n"]), str(rec["m"])], (limit, out)
+
+
+def test_sg_reader_rejects_corrupt_files(capi, tmp_path):
+    """a stale / truncated / planted .sg cache must be refused by the reader, not walked out of bounds later."""
+    import struct
+    csr = capi.HostCSR.generate("kronecker", 8, 16)
+    good = str(tmp_path / "g.sg")
+    csr.save_sg(good)
+    raw = bytearray(open(good, "rb").read())
+    n, nnz = csr.num_nodes, csr.nnz
+    assert struct.unpack_from("<qq", raw, 1) == (nnz, n)
+    off0 = 1 + 16
+    adj0 = off0 + 8 * (n + 1)
+
+    def variant(name, mutate):
+        b = bytearray(raw)
+        mutate(b)
+        p = str(tmp_path / name)
+        open(p, "wb").write(b)
+        return p
+
+    cases = {
+        "nonmono.sg": lambda b: struct.pack_into("<q", b, off0 + 8 * 5, nnz + 7),          # offsets[5] beyond offsets[6]
+        "negid.sg": lambda b: struct.pack_into("<i", b, adj0 + 4 * 3, -1),
+        "bigid.sg": lambda b: struct.pack_into("<i", b, adj0 + 4 * 3, n),
+        "trunc.sg": lambda b: b.__delitem__(slice(len(b) - 10, len(b))),
+        "badend.sg": lambda b: struct.pack_into("<q", b, off0 + 8 * n, nnz - 1),
+    }
+    for name, mut in cases.items():
+        with pytest.raises(capi.GmsxError) as ei:
+            capi.HostCSR.load(variant(name, mut), relabel=capi.RELABEL_NEVER)
+        assert ei.value.status == capi.ERR_FORMAT, name
+    again = capi.HostCSR.load(good, relabel=capi.RELABEL_NEVER)
+    assert again.fingerprint() == csr.fingerprint()

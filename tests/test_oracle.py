@@ -162,3 +162,58 @@ def test_vertex_similarity_goldens(oracle, capi):
         got = oracle.vertex_similarity(m, off, ng, z["u"], z["v"])
         assert np.array_equal(got, z[name], equal_nan=True), name
     assert np.isnan(z["overlap"]).any() and (z["jaccard"] == 1.0).any()  # the empty-set edge cases are in the vectors
+
+
+# ---- orderings -------------------------------------------------------------------------------
+
+def _adg_consistent(ref_rank, rnd, deg):
+    """The reference leaves ties inside a round to its partition/sort: its output must walk the oracle's (round, degree) staircase."""
+    by_ref = np.argsort(ref_rank)
+    keys = rnd[by_ref].astype(np.int64) * (1 << 32) + deg[by_ref]
+    return bool(np.all(np.diff(keys) >= 0))
+
+
+def test_orderings_match_reference_goldens(oracle, capi):
+    path = os.path.join(GOLDEN, "orderings.npz")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/orderings.npz not generated (tools/make_golden_orderings.py)")
+    G = np.load(path)
+    seen = 0
+    for key in G.files:
+        if not key.startswith("adg_") or key.startswith("adg_file_"):
+            continue
+        kind, scale, deg = key[4:].rsplit("_", 2)
+        csr = capi.HostCSR.generate(kind, int(scale), int(deg))
+        off, ng = csr.offsets(), csr.neighbors()
+        rank, rnd, dat, rounds = oracle.adg_rank(off, ng, 0.001)
+        assert np.array_equal(np.sort(rank), np.arange(csr.num_nodes)) and rounds == rnd.max() + 1
+        assert _adg_consistent(G[key], rnd, dat), key
+        # inside a round the oracle orders by (degree, id): ranks strictly follow that key
+        by_rank = np.argsort(rank)
+        assert np.all(np.diff((rnd[by_rank].astype(np.int64) << 52) + (dat[by_rank].astype(np.int64) << 28) + by_rank) > 0)
+        counts = oracle.tc_vertex_count2(off, ng)
+        mine = oracle.tc_ordering(off, ng)
+        assert np.array_equal(counts[G["tco_" + key[4:]]], counts[mine]), key     # same count sequence as the reference's order
+        assert np.all(np.diff(counts[mine]) >= 0)
+        seen += 1
+    for name in sorted(os.listdir(os.path.join(GOLDEN, "testGraphs"))):
+        key = "adg_file_" + name[:-3]
+        if key in G.files:
+            csr = capi.HostCSR.load(os.path.join(GOLDEN, "testGraphs", name))
+            rank, rnd, dat, _ = oracle.adg_rank(csr.offsets(), csr.neighbors(), 0.001)
+            assert _adg_consistent(G[key], rnd, dat), key
+            seen += 1
+    assert seen >= 6
+
+
+@pytest.mark.parametrize("spec", [("kronecker", 9, 8), ("kronecker", 11, 16), ("uniform", 11, 12)])
+def test_orderings_against_compiled_reference(oracle, reference, spec):
+    kind, scale, deg = spec
+    g = reference.generate(kind, scale, deg, True, threads=1)
+    off, ng = reference.csr(g)
+    rank, rnd, dat, _ = oracle.adg_rank(off, ng, 0.001)
+    assert _adg_consistent(reference.rank(g, 1), rnd, dat)
+    if hasattr(reference.L, "ref_tc_ordering"):
+        counts = oracle.tc_vertex_count2(off, ng)
+        assert np.array_equal(counts[reference.tc_ordering(g, 0)], counts[oracle.tc_ordering(off, ng)])
+    reference.free(g)

@@ -129,18 +129,6 @@ def test_relabel_invariance_and_golden_scale20(gpu):
     g.free()
 
 
-@pytest.mark.skipif(os.environ.get("GMSX_FULL_SIZE", "0") != "1", reason="set GMSX_FULL_SIZE=1: generates RMAT scale 24 (~1 min, ~12 GB host)")
-def test_config2_scale24_golden(gpu):
-    rec = GRAPHS["kronecker-24-16-relabel"]
-    csr = gpu.HostCSR.generate("kronecker", 24)
-    assert (csr.num_nodes, csr.num_edges) == (rec["n"], rec["m"]) and csr.merge_elements() == rec["merge_elements"]
-    g = upload(gpu, csr, flags=gpu.UPLOAD_DEFAULT)
-    assert g.tc_total() == rec["triangles"]
-    parts = [g.tc_partial(p, 8) for p in range(8)]
-    assert sum(parts) == rec["triangles"]
-    g.free()
-
-
 @pytest.mark.parametrize("hub_limit", [1, 16, 300, 5000])
 def test_tail_containers_and_tiling(gpu, oracle, hub_limit):
     """Shrinking the hub id range (upload test hook) pushes ids into the 32-bit tail containers: same counts.

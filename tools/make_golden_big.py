@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Reference-produced goldens at the sizes BASELINE.json / north_star name (run in the BUILD CONTAINER only).
+
+    make -C oracle ref
+    python tools/make_golden_big.py tc 26          # Par::count_total<RoaringGraph>, ~35 min on 8 threads, ~45 GB
+    python tools/make_golden_big.py kc4 16|18|20   # CliqueCount<RoaringSet,RoaringGraph,RoaringSet>(g, 4)
+    python tools/make_golden_big.py bk 14          # BkEppsteinPar::mceBench<RoaringGraph>, degree rank
+
+Every value is computed by the COMPILED REFERENCE (oracle/_ref/libgms_ref.so = spcl/gms headers + vendored
+CRoaring, see oracle/ref_shim.cc) on the graph its own loader generates (`-g kronecker <scale> --deg 16`,
+parse_and_load incl. relabel-by-degree), and merged into tests/golden/graphs.json under the key
+`kronecker-<scale>-16-relabel` together with n, m and the wall time of the reference call.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.bindings import Reference  # noqa: E402
+
+PATH = os.path.join(ROOT, "tests", "golden", "graphs.json")
+
+
+def main():
+    what, scale = sys.argv[1], int(sys.argv[2])
+    deg = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    R = Reference()
+    t0 = time.time()
+    g = R.generate("kronecker", scale, deg, True)
+    n, m = R.num_nodes(g), R.nnz(g) // 2
+    t_load = time.time() - t0
+    print("loaded scale %d: n=%d m=%d in %.1f s" % (scale, n, m, t_load), flush=True)
+    t0 = time.time()
+    if what == "tc":
+        field, val, how = "triangles", R.tc_total(g, Reference.ROARING), "Par::count_total<RoaringGraph>"
+    elif what == "kc4":
+        field, val, how = "kc4", R.kclique(g, 4, Reference.ROARING), "CliqueCount<RoaringSet,RoaringGraph,RoaringSet>(g,4)"
+    elif what == "bk":
+        field, val, how = "bk", R.bk_count(g, Reference.ROARING, 0), "BkEppsteinPar::mceBench<RoaringGraph>, degree rank"
+    else:
+        raise SystemExit("what = tc | kc4 | bk")
+    dt = time.time() - t0
+    R.free(g)
+    key = "kronecker-%d-%d-relabel" % (scale, deg)
+    with open(PATH) as f:
+        graphs = json.load(f)
+    rec = graphs.setdefault(key, dict(generator="kronecker", scale=scale, degree=deg, relabel=True))
+    assert rec.get("n", n) == n and rec.get("m", m) == m, (rec, n, m)
+    if field in rec:
+        assert rec[field] == val, "existing golden %s=%d disagrees with the reference run: %d" % (field, rec[field], val)
+    rec.update(n=n, m=m)
+    rec[field] = val
+    rec.setdefault("sources", {})[field] = "oracle/_ref %s, %d threads, %.0f s (tools/make_golden_big.py)" % (how, R.omp_threads(), dt)
+    with open(PATH, "w") as f:
+        json.dump(graphs, f, indent=1)
+    print(json.dumps({key: {field: val, "n": n, "m": m, "load_s": round(t_load, 1), "run_s": round(dt, 1)}}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
