@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>  // before rocprim: its texture iterator calls the host memset
 #include <new>
 
@@ -156,6 +157,7 @@ __global__ void k_dense_sizes(int32_t limit, const int32_t *__restrict__ dplus, 
     if (v == limit) sizes[v] = 0;
 }
 __global__ __launch_bounds__(256) void k_dense_fill(int32_t limit, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                    const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                     const int64_t *__restrict__ bmoff, uint32_t *__restrict__ pool) {
     const int lane = threadIdx.x & 63;
     const int32_t wave0 = int32_t((int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6);
@@ -167,6 +169,24 @@ __global__ __launch_bounds__(256) void k_dense_fill(int32_t limit, const int64_t
             const uint32_t id = hadj[j];
             if (id != 0xFFFFu) atomicOr(&pool[b + (id >> 5)], 1u << (id & 31u));
         }
+        for (int64_t j = toff[v] + lane; j < toff[v + 1]; j += 64) {  // near-tail rows: their tail targets are < v too
+            const uint32_t id = uint32_t(tadj[j]);
+            atomicOr(&pool[b + (id >> 5)], 1u << (id & 31u));
+        }
+    }
+}
+// tsplit[u] = number of tail targets of u below `limit` (tail rows are ascending when rows_sorted; otherwise a plain count,
+// which the kernels then do not use as a position)
+__global__ __launch_bounds__(256) void k_tail_split(int64_t n, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, int32_t limit,
+                                                    int32_t *__restrict__ tsplit) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t u = wave0; u < n; u += nwaves) {
+        int c = 0;
+        for (int64_t j = toff[u] + lane; j < toff[u + 1]; j += 64) c += tadj[j] < limit;
+        for (int s = 32; s > 0; s >>= 1) c += __shfl_down(c, s);
+        if (lane == 0) tsplit[u] = c;
     }
 }
 
@@ -224,6 +244,7 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->tadj);
     (void)hipFree(g->bmoff);
     (void)hipFree(g->bmpool);
+    (void)hipFree(g->tsplit);
     (void)hipFree(g->dplus);
     (void)hipFree(g->order);
     (void)hipFree(g->sorted_dplus);
@@ -352,10 +373,25 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     if (g->hub_entries >= (int64_t(1) << 32) || n >= (int64_t(1) << 32)) g->rows_sorted = false;
     if (g->tail_entries == 0 && g->hub_entries < (int64_t(1) << 32) && n < (int64_t(1) << 32)) g->rows_sorted = true;
 
-    // 4b. bitset containers for dense hub rows (only rows of hub vertices can be dense: all their targets are < v < kHub)
+    // 4b. bitset containers: every row of rank id < R as a bitmap over [0, v).  The hub rows (v < hub_limit) use them as the dense
+    //     streaming form and as gather targets; the near-tail rows (hub_limit <= v < R) only as gather targets of the light pivots.
+    //     R^2/16 bytes: 268 MB for the hub range, 4.3 GB for R = 262144 — HBM is what this box has plenty of (288 GB).
     g->dense_limit = int32_t(std::min<int64_t>(n, hub_limit));
     {
-        const int32_t K = g->dense_limit;
+        // measured on MI355X (tools/tc_bitset_sweep.py): scale 26 (n = 67 M) 277 ms at R = 65535, 264 at 262144, 262 at 524288;
+        // scale 24 (n = 17 M) is fastest with the hub range only — the near tail pays once rows are long and pivots many
+        int64_t want = std::min<int64_t>(524288, n / 256);
+        if (const char *e = std::getenv("GMSX_BITSET_LIMIT")) {
+            const long long v = std::atoll(e);
+            if (v >= 0 && v <= (1ll << 22)) want = v;
+        }
+        if ((flags >> 8) & 0xffffu) want = std::min<int64_t>(want, int64_t(4) * hub_limit);  // test hook: keep a far tail on small graphs
+        if (!g->rows_sorted) want = 0;                                                       // positions in tail rows need sorted rows
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)  // never more than a quarter of what is free right now
+            while (want > hub_limit && uint64_t(want) * uint64_t(want) / 16u > free_b / 4u) want /= 2;
+        g->bitset_limit = int32_t(std::min<int64_t>(n, std::max<int64_t>(want, g->dense_limit)));
+        const int32_t K = g->bitset_limit;
         int64_t *sizes = nullptr;
         if (int rc = dmalloc(&sizes, int64_t(K) + 1, nullptr)) return rc;
         DevGuard g_sz{sizes};
@@ -366,7 +402,9 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         if (int rc = dmalloc(&g->bmpool, g->bmpool_words + 4, g)) return rc;
         GMSX_HIP(hipMemsetAsync(g->bmpool, 0, size_t(g->bmpool_words + 4) * sizeof(uint32_t), s));
         if (K > 0 && g->bmpool_words > 0)
-            hipLaunchKernelGGL(k_dense_fill, dim3(grid_for_waves(K)), dim3(256), 0, s, K, g->hoff, g->hadj, g->bmoff, g->bmpool);
+            hipLaunchKernelGGL(k_dense_fill, dim3(grid_for_waves(K)), dim3(256), 0, s, K, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool);
+        if (int rc = dmalloc(&g->tsplit, n, g)) return rc;
+        if (n > 0) hipLaunchKernelGGL(k_tail_split, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->toff, g->tadj, K, g->tsplit);
     }
 
     // 5. work-sorted launch order: rank ids by decreasing d+

@@ -20,7 +20,8 @@
 //                                                     is padded to an even count with 0xFFFF (never a valid target)
 //     tail part  toff int64[n+1], tadj int32[...]    targets with rank id >= kHub, 4 bytes each
 //   On power-law graphs >85 % of all entries and >95 % of the streamed ids are hub entries.
-//     bitset part bmoff int64[K+1], bmpool uint32[...]  every hub row additionally as a bitmap over [0, v) (Roaring's bitset
+//     bitset part bmoff int64[R+1], bmpool uint32[...]  every row of rank id < R (R = bitset_limit >= the hub range; sized by the HBM
+//                                                     budget: R^2/16 bytes, 4.3 GB for R = 262144) additionally as a bitmap over [0, v) (Roaring's bitset
 //                                                     container, <= 268 MB in total).  Heavy pivots stream it instead of the
 //                                                     list when it is the smaller form (2*d+ bytes > v/8 bytes: a few thousand
 //                                                     rows that carry >70 % of the streamed ids; AND + popcount, 32 ids per word);
@@ -41,7 +42,11 @@ struct gmsx_graph {
     int32_t *tadj = nullptr;
     int64_t *bmoff = nullptr;   // [dense_limit + 1] word offsets into bmpool (multiples of 4); equal neighbours = not dense
     uint32_t *bmpool = nullptr; // bitset containers of the dense hub rows
-    int32_t dense_limit = 0;    // rank ids >= this never have a bitset container
+    int32_t dense_limit = 0;    // = min(n, hub limit): hub rank ids; their rows have a bitset AND only hub entries
+    int32_t bitset_limit = 0;   // >= dense_limit: every rank id below it has a bitset container over [0, v) in bmpool (hub AND tail
+                                // targets); ids in [dense_limit, bitset_limit) are the "near tail": light pivots resolve their rows by
+                                // inverted gathers too instead of streaming them (tc.hip), the other kernels ignore them
+    int32_t *tsplit = nullptr;  // int32[n]: position in the tail row of the first target >= bitset_limit (= tail length if none)
     int64_t dense_rows = 0, bmpool_words = 0;
     bool rows_sorted = false;   // both containers of every row ascending (always, below 2^32 entries)
     int32_t *dplus = nullptr;

@@ -63,9 +63,10 @@ __device__ __forceinline__ uint32_t scan_hub_rows(const uint32_t *bm, const uint
         // extents of rows r0..r0+3 through wave-uniform readlanes, then a per-group select (a per-lane __shfl here
         // gets sunk under the row-count predicate by the compiler and then reads inactive lanes)
         const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
-        const int64_t b0 = readlane64(rb, m0), b1 = readlane64(rb, m1), b2 = readlane64(rb, m2), b3 = readlane64(rb, m3);
         const int l0 = __builtin_amdgcn_readlane(rl, m0), l1 = __builtin_amdgcn_readlane(rl, m1),
                   l2 = __builtin_amdgcn_readlane(rl, m2), l3 = __builtin_amdgcn_readlane(rl, m3);
+        if ((l0 | l1 | l2 | l3) == 0) continue;  // wave-uniform: four empty rows (e.g. members whose rows another kernel resolves)
+        const int64_t b0 = readlane64(rb, m0), b1 = readlane64(rb, m1), b2 = readlane64(rb, m2), b3 = readlane64(rb, m3);
         const int64_t b = grp == 0 ? b0 : grp == 1 ? b1 : grp == 2 ? b2 : b3;
         const int l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
         if (l < 0) {
@@ -305,13 +306,16 @@ __global__ __launch_bounds__(256) void k_tc_block(const int64_t *__restrict__ ho
 }
 
 // ---------------------------------------------------------------------------------------------
-// Light pivots (2 <= d+ < 64), part 1 of 2: the rows of the HUB members.  No LDS at all (full occupancy): lane j holds
-// member w_j; for every hub member v_i the lanes gather one word of v_i's bitset container ("is w_j in N+(v_i)?").
-// Eight rows are in flight per trip.  Part 2 (k_tc_wave) adds the rows of the tail members.
+// Light pivots (2 <= d+ < 64), part 1 of 2: the rows of every member that has a BITSET container (rank id < bitset_limit: the
+// hub range and the near tail).  No LDS at all (full occupancy): lane j holds member w_j — the hub part of the pivot list in
+// the low lanes, the tail part behind it, ascending — and for every member v_i with a bitset the lanes gather one word of
+// v_i's container ("is w_j in N+(v_i)?").  Eight rows are in flight per trip; nothing is streamed.  Part 2 (k_tc_wave) adds
+// the rows of the members beyond bitset_limit.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tc_wave_hub(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                     const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                      const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
-                                                     int32_t dense_limit, const int32_t *__restrict__ order, int64_t first, int64_t end,
+                                                     int32_t bitset_limit, const int32_t *__restrict__ order, int64_t first, int64_t end,
                                                      int nparts, int part, unsigned long long *__restrict__ acc) {
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -319,45 +323,52 @@ __global__ __launch_bounds__(256) void k_tc_wave_hub(const int64_t *__restrict__
     unsigned long long cnt = 0;
     // two-stage software pipeline over the pivots of this wave (see k_tc_wave): C = current, B = next, A = after next
     int64_t posC = first + (int64_t(blockIdx.x) * 4 + wave) * nparts + part;
-    int64_t hbC = 0, hbB = 0;
-    int hlC = 0, hlB = 0;
+    int64_t hbC = 0, hbB = 0, tbC = 0, tbB = 0;
+    int hlC = 0, hlB = 0, tlC = 0, tlB = 0;
     int32_t uA = -1;
     if (posC < end) {
         const int32_t u = order[posC];
         hbC = hoff[u];
         hlC = int(hoff[u + 1] - hbC);
+        tbC = toff[u];
+        tlC = int(toff[u + 1] - tbC);
     }
     if (posC + step < end) {
         const int32_t u = order[posC + step];
         hbB = hoff[u];
         hlB = int(hoff[u + 1] - hbB);
+        tbB = toff[u];
+        tlB = int(toff[u + 1] - tbB);
     }
     if (posC + 2 * step < end) uA = order[posC + 2 * step];
     for (; posC < end; posC += step) {  // uniform per wave
-        int64_t hbN = 0;
-        int hlN = 0;
+        int64_t hbN = 0, tbN = 0;
+        int hlN = 0, tlN = 0;
         if (uA >= 0) {
             hbN = hoff[uA];
             hlN = int(hoff[uA + 1] - hbN);
+            tbN = toff[uA];
+            tlN = int(toff[uA + 1] - tbN);
         }
         const int32_t uN = (posC + 3 * step < end) ? order[posC + 3 * step] : -1;
-        const int64_t hb = hbC;
-        const int hl = hlC;  // <= 64 (padded)
-        hbC = hbB; hlC = hlB;
-        hbB = hbN; hlB = hlN;
+        const int64_t hb = hbC, tb = tbC;
+        const int hl = hlC, tl = tlC;  // hl (padded) + tl <= 64
+        hbC = hbB; hlC = hlB; tbC = tbB; tlC = tlB;
+        hbB = hbN; hlB = hlN; tbB = tbN; tlB = tlN;
         uA = uN;
-        uint32_t hv = 0xFFFFu;
-        int64_t rb = 0;
-        bool has = false;
+        int32_t mv = 0x7fffffff;  // this lane's member (rank id); the pad and empty lanes never pass "mv < v_i"
         if (lane < hl) {
-            hv = hadj[hb + lane];
-            if (hv != 0xFFFFu && int32_t(hv) < dense_limit) {
-                rb = bmoff[hv];
-                has = true;
-            }
+            const uint32_t h = hadj[hb + lane];
+            if (h != 0xFFFFu) mv = int32_t(h);
+        } else if (lane - hl < tl) {
+            mv = tadj[tb + (lane - hl)];
         }
+        int64_t rb = 0;
+        const bool has = mv < bitset_limit;
+        if (has) rb = bmoff[mv];
         uint32_t c = 0;
         unsigned long long todo = __ballot(has);
+        todo &= todo - 1;  // the smallest member has no member below it
         while (todo) {
             int32_t vi[8];
             const uint32_t *bits[8];
@@ -368,15 +379,15 @@ __global__ __launch_bounds__(256) void k_tc_wave_hub(const int64_t *__restrict__
                 if (todo) {
                     const int i = __ffsll((long long)todo) - 1;
                     todo &= todo - 1;
-                    vi[k] = int32_t(__builtin_amdgcn_readlane(hv, i));
+                    vi[k] = __builtin_amdgcn_readlane(mv, i);
                     bits[k] = bmpool + readlane64(rb, i);
                 }
             }
             uint32_t wd[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) wd[k] = hv < uint32_t(vi[k]) ? bits[k][hv >> 5] : 0u;  // hv == 0xFFFF never passes
+            for (int k = 0; k < 8; ++k) wd[k] = mv < vi[k] ? bits[k][uint32_t(mv) >> 5] : 0u;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) c += (wd[k] >> (hv & 31u)) & 1u;
+            for (int k = 0; k < 8; ++k) c += (wd[k] >> (uint32_t(mv) & 31u)) & 1u;
         }
         cnt += c;
     }
@@ -390,7 +401,7 @@ __global__ __launch_bounds__(256) void k_tc_wave_hub(const int64_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// Light pivots (2 <= d+ < 64), part 2 of 2: the rows of the TAIL members (rank ids >= kHub).  Each of the 4 waves of a
+// Light pivots (2 <= d+ < 64), part 2 of 2: the rows of the FAR members (rank ids >= bitset_limit; k_tc_wave_hub resolved the others).  Each of the 4 waves of a
 // workgroup owns a private bitmap (8 KB) and a 64 x 4 bucket set for the tail part and walks its pivots with a grid
 // stride; pivots without tail members are skipped.  The bitmap is cleared once; each pivot sets its bits and clears
 // exactly those words again.
@@ -401,7 +412,7 @@ __global__ __launch_bounds__(256) void k_tc_wave_hub(const int64_t *__restrict__
 __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                  const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool, int32_t dense_limit,
                                                  const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
-                                                 const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
+                                                 const int32_t *__restrict__ tsplit, const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
                                                  int part, unsigned long long *__restrict__ acc) {
     constexpr int LOG = 8, SIZE = 1 << LOG, SHIFT = 32 - LOG;
     constexpr uint32_t MASK = SIZE - 1;
@@ -421,6 +432,7 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
     // stage B/C: offsets of the pivots one and two steps ahead of C; stage A: the id three steps ahead
     int64_t hbC = 0, tbC = 0, hbB = 0, tbB = 0;
     int hlC = 0, tlC = 0, hlB = 0, tlB = 0;
+    int tsC = 0, tsB = 0, tsD = 0;  // members below bitset_limit come first in a tail row: k_tc_wave_hub resolved their rows
     int32_t uA = -1;
     // stage D: the pivot being scanned -- member ids and the extents of both containers of every tail member
     int tlD = 0;
@@ -437,6 +449,8 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
             hl0 = int(hoff[u + 1] - hb0);
             tb0 = toff[u];
             tlD = int(toff[u + 1] - tb0);
+            tsD = tsplit[u];
+            if (tlD <= tsD) tlD = 0;  // no member beyond bitset_limit: nothing to stream for this pivot
         }
         if (pos0 + step < end) {
             const int32_t u = order[pos0 + step];
@@ -444,6 +458,8 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
             hlC = int(hoff[u + 1] - hbC);
             tbC = toff[u];
             tlC = int(toff[u + 1] - tbC);
+            tsC = tsplit[u];
+            if (tlC <= tsC) tlC = 0;
         }
         if (pos0 + 2 * step < end) {
             const int32_t u = order[pos0 + 2 * step];
@@ -451,17 +467,21 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
             hlB = int(hoff[u + 1] - hbB);
             tbB = toff[u];
             tlB = int(toff[u + 1] - tbB);
+            tsB = tsplit[u];
+            if (tlB <= tsB) tlB = 0;
         }
         if (pos0 + 3 * step < end) uA = order[pos0 + 3 * step];
         if (tlD > 0) {
             if (lane < hl0) hvD = hadj[hb0 + lane];
             if (lane < tlD) {
                 vD = tadj[tb0 + lane];
-                thbD = hoff[vD];
-                thlD = int(hoff[vD + 1] - thbD);
-                if (lane > 0) {
-                    trbD = toff[vD];
-                    trlD = int(toff[vD + 1] - trbD);
+                if (lane >= tsD) {
+                    thbD = hoff[vD];
+                    thlD = int(hoff[vD + 1] - thbD);
+                    if (lane > 0) {
+                        trbD = toff[vD];
+                        trlD = int(toff[vD + 1] - trbD);
+                    }
                 }
             }
         }
@@ -469,12 +489,14 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
     for (int64_t pos = pos0; pos < end; pos += step) {  // uniform per wave
         // loads of the later stages first; they complete while D is scanned
         int64_t hbN = 0, tbN = 0;
-        int hlN = 0, tlN = 0;
+        int hlN = 0, tlN = 0, tsN = 0;
         if (uA >= 0) {
             hbN = hoff[uA];
             hlN = int(hoff[uA + 1] - hbN);
             tbN = toff[uA];
             tlN = int(toff[uA + 1] - tbN);
+            tsN = tsplit[uA];
+            if (tlN <= tsN) tlN = 0;
         }
         const int32_t uN = (pos + 4 * step < end) ? order[pos + 4 * step] : -1;
         uint32_t hvC = 0xFFFFu;
@@ -510,7 +532,7 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
         // stage C's member ids have arrived by now: issue the loads of its row extents
         int64_t thbC = 0, trbC = 0;
         int thlC = 0, trlC = 0;
-        if (vC >= 0) {
+        if (vC >= 0 && lane >= tsC) {
             thbC = hoff[vC];
             thlC = int(hoff[vC + 1] - thbC);
             if (lane > 0) {  // the first tail member's tail ids are all below every tail id of the pivot: no match possible
@@ -527,10 +549,10 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
             __builtin_amdgcn_wave_barrier();
             if (hvD != 0xFFFFu) bm[hvD >> 5] = 0;  // every bit in this wave's bitmap belongs to this pivot
         }
-        tlD = tlC; hvD = hvC; vD = vC;
+        tlD = tlC; tsD = tsC; hvD = hvC; vD = vC;
         thbD = thbC; thlD = thlC; trbD = trbC; trlD = trlC;
-        hbC = hbB; hlC = hlB; tbC = tbB; tlC = tlB;
-        hbB = hbN; hlB = hlN; tbB = tbN; tlB = tlN;
+        hbC = hbB; hlC = hlB; tbC = tbB; tlC = tlB; tsC = tsB;
+        hbB = hbN; hlB = hlN; tbB = tbN; tlB = tlN; tsB = tsN;
         uA = uN;
     }
     for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
@@ -547,11 +569,12 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
 //   pivot u (d+ >= 2): its own hub + tail containers once;
 //   heavy pivot (d+ >= 64, k_tc_block): every hub member's row in the form hub_row_extent() picks (bitset words or 16-bit list),
 //       every tail member's 16-bit list and (except the first) its 32-bit list;
-//   light pivot (k_tc_wave_hub + k_tc_wave): one 4-byte word gathered per (hub member with a bitset, lane) pair; tail members as above.
+//   light pivot (k_tc_wave_hub + k_tc_wave): one 4-byte word gathered per (member with a bitset, smaller member) pair; members beyond
+//       bitset_limit streamed as above.
 __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
-                                                  int32_t dense_limit, int64_t first, int64_t end, int nparts, int part,
+                                                  int32_t dense_limit, int32_t bitset_limit, int64_t first, int64_t end, int nparts, int part,
                                                   unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -577,14 +600,18 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
                 const unsigned long long list = 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
                 const unsigned long long bits = 4ull * (unsigned long long)bitset_words(int32_t(v));
                 bytes += (int32_t(v) < dense_limit && bits + 32 < list) ? bits : list;
-            } else if (int32_t(v) < dense_limit) {
-                bytes += 4ull * (unsigned long long)hl;  // one word per lane that holds a member
+            } else if (int32_t(v) < bitset_limit) {
+                bytes += 4ull * (unsigned long long)(j - hoff[u]);  // one gathered word per member below v
             }
         }
         for (int64_t j = toff[u] + lane; j < toff[u + 1]; j += 64) {
             const int32_t v = tadj[j];
             probes += (unsigned long long)dplus[v];
             if (!work) continue;
+            if (!heavy && v < bitset_limit) {  // near-tail member of a light pivot: gathers, nothing streamed
+                bytes += 4ull * (unsigned long long)(du - tl + (j - toff[u]));
+                continue;
+            }
             bytes += 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
             if (j > toff[u]) bytes += 4ull * (unsigned long long)(toff[v + 1] - toff[v]);
         }
@@ -633,9 +660,9 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
             hipLaunchKernelGGL(k_tc_wave_hub, dim3(unsigned(std::min<int64_t>((cnt + 3) / 4, cap_blocks * 2))), dim3(256), 0, s, g->hoff,
-                               g->hadj, g->bmoff, g->bmpool, g->dense_limit, g->order, n_block, n_work, nparts, part, acc);
+                               g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool, g->bitset_limit, g->order, n_block, n_work, nparts, part, acc);
             hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit,
-                               g->toff, g->tadj, g->order, n_block, n_work, nparts, part, acc);
+                               g->toff, g->tadj, g->tsplit, g->order, n_block, n_work, nparts, part, acc);
             ++launches;
             ++launches;
         }
@@ -649,7 +676,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
             hipLaunchKernelGGL(k_tc_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus,
-                               g->order, g->dense_limit, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
+                               g->order, g->dense_limit, g->bitset_limit, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
         }
     }
     unsigned long long host[kAccSlots * kAccStride + 3];

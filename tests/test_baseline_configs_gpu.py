@@ -135,10 +135,10 @@ def test_north_star_scale26_reference_golden(gpu):
 
 def test_config5_scale27_eight_shards_on_one_gpu(gpu):
     """configs[4]: triangle count, RMAT scale-27 ef=16, edge-range shards for 8 GPUs — the eight shards, computed one after the
-    other on the one GPU of this box, add up to the un-sharded count; nnz > 2^32 exercises the 64-bit offsets."""
+    other on the one GPU of this box, add up to the un-sharded count; nnz = 4.2e9 > 2^31 exercises the 64-bit offsets."""
     threads(gpu)
     csr = gpu.HostCSR.generate("kronecker", 27)
-    assert csr.nnz > 2 ** 32 and csr.num_nodes == 134217728
+    assert csr.nnz > 2 ** 31 and csr.nnz == 2 * 2111632322 and csr.num_nodes == 134217728
     g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_TRUSTED)
     del csr
     total = g.tc_total()
