@@ -381,11 +381,12 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         // measured on MI355X (tools/tc_bitset_sweep.py): scale 26 (n = 67 M) 277 ms at R = 65535, 264 at 262144, 262 at 524288;
         // scale 24 (n = 17 M) is fastest with the hub range only — the near tail pays once rows are long and pivots many
         int64_t want = std::min<int64_t>(524288, n / 256);
-        if (const char *e = std::getenv("GMSX_BITSET_LIMIT")) {
+        bool forced = false;
+        if (const char *e = std::getenv("GMSX_BITSET_LIMIT")) {  // tuning / test knob
             const long long v = std::atoll(e);
-            if (v >= 0 && v <= (1ll << 22)) want = v;
+            if (v >= 0 && v <= (1ll << 22)) { want = v; forced = true; }
         }
-        if ((flags >> 8) & 0xffffu) want = std::min<int64_t>(want, int64_t(4) * hub_limit);  // test hook: keep a far tail on small graphs
+        if (!forced && ((flags >> 8) & 0xffffu)) want = int64_t(4) * hub_limit;  // hub-limit test hook: near AND far tail on small graphs
         if (!g->rows_sorted) want = 0;                                                       // positions in tail rows need sorted rows
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)  // never more than a quarter of what is free right now

@@ -215,7 +215,10 @@ int gmsx_bk_partial(const gmsx_graph *g, const int32_t *rank, int part, int npar
  * same remaining-degree sequence as this one. */
 int gmsx_adg_rank(const gmsx_graph *g, double epsilon, int rank_format, int32_t *out, int32_t *rounds, gmsx_stats *stats);
 /* PpParallel::triangleCountOrdering (preprocessing/parallel/triangle_count.h:11-30): ordering[i] = i-th vertex by increasing
- * per-vertex count (the counts of gmsx_tc_vertex_count2); ties by vertex id (the reference's std::sort leaves them open). */
+ * per-vertex count (the counts of gmsx_tc_vertex_count2); ties by vertex id (the reference's std::sort leaves them open).
+ * (As shipped, the reference's default CountFn vertex_count2_once adds into an uninitialised pvector, triangle_count.h:19 +
+ * parallel/vertex.h:42-46, so its own output depends on heap contents; this is the ordering by the well-defined counts, which
+ * the reference produces with CountFn = Par::vertex_count2 — that instantiation is what the goldens were generated with.) */
 int gmsx_tc_ordering(const gmsx_graph *g, int32_t *ordering /* n, host */, gmsx_stats *stats);
 
 /* ---- the one collective of the path: the OpenMP reduction(+:total) of parallel/total.h:12,

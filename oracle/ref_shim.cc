@@ -180,13 +180,22 @@ void ref_rank(void *h, int order, int32_t *out) {
     else PpSequential::getDegeneracyOrderingMatula<SortedSetGraph, true, pvector<NodeId>>(sg, rank);
     for (int64_t i = 0; i < sg.num_nodes(); i++) out[i] = rank[i];
 }
-// PpParallel::triangleCountOrdering (preprocessing/parallel/triangle_count.h:11-30), order format
+// PpParallel::triangleCountOrdering (preprocessing/parallel/triangle_count.h:11-30), order format.  Instantiated with
+// CountFn = Par::vertex_count2 instead of the default Par::vertex_count2_once: the default ACCUMULATES (`counts[v] += c`,
+// parallel/vertex.h:42-46) into a pvector<int64_t> that triangle_count.h:19 leaves uninitialised (pvector does not zero,
+// gapbs/pvector.h:17), so its output depends on stale heap contents; vertex_count2 assigns every element and yields the
+// counts the function is documented to sort by.
 void ref_tc_ordering(void *h, int set_kind, int32_t *out) {
     Quiet q;
     const CSRGraph &g = static_cast<RefGraph *>(h)->g;
     std::vector<NodeId> ord;
-    if (set_kind == 0) { auto sg = SortedSetGraph::FromCGraph(g); PpParallel::triangleCountOrdering<SortedSetGraph>(sg, ord); }
-    else { auto sg = RoaringGraph::FromCGraph(g); PpParallel::triangleCountOrdering<RoaringGraph>(sg, ord); }
+    if (set_kind == 0) {
+        auto sg = SortedSetGraph::FromCGraph(g);
+        PpParallel::triangleCountOrdering<SortedSetGraph, GMS::TriangleCount::Par::vertex_count2<SortedSetGraph, pvector<int64_t>>>(sg, ord);
+    } else {
+        auto sg = RoaringGraph::FromCGraph(g);
+        PpParallel::triangleCountOrdering<RoaringGraph, GMS::TriangleCount::Par::vertex_count2<RoaringGraph, pvector<int64_t>>>(sg, ord);
+    }
     for (size_t i = 0; i < ord.size(); i++) out[i] = ord[i];
 }
 // op codes: see set_op above.  `out` must hold na+nb elements.  Returns count / cardinality.

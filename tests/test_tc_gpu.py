@@ -166,3 +166,28 @@ def test_tail_bucket_overflow(gpu, oracle):
         assert g.tc_total() == want, hub_limit
         assert sum(g.tc_partial(p, 3) for p in range(3)) == want
         g.free()
+
+
+@pytest.mark.parametrize("hub_limit,bitset_limit", [(16, 0), (16, 40), (16, 700), (16, 10 ** 6), (300, 301), (300, 4000), (0, 3000)])
+def test_near_tail_bitsets(gpu, oracle, hub_limit, bitset_limit):
+    """Rows of rank id < bitset_limit have a bitset container; light pivots resolve those members by inverted gathers
+    (k_tc_wave_hub), the others stream (k_tc_wave).  Any split of the tail into near and far parts gives the same counts —
+    for the triangle kernels and for the k-clique / Bron–Kerbosch kernels that share the containers."""
+    old = os.environ.get("GMSX_BITSET_LIMIT")
+    os.environ["GMSX_BITSET_LIMIT"] = str(bitset_limit)
+    try:
+        for kind, scale, deg in (("kronecker", 13, 16), ("uniform", 12, 20)):
+            csr = host_graph(gpu, kind, scale, deg, True)
+            want = oracle.tc_total(csr.offsets(), csr.neighbors())
+            g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_DEFAULT | (hub_limit << 8))
+            assert g.tc_total() == want
+            assert sum(g.tc_partial(p, 3) for p in range(3)) == want
+            assert g.kclique_count(3)[1] == want
+            if scale == 12:
+                assert g.bk_count() == oracle.bk_count(csr.offsets(), csr.neighbors())
+            g.free()
+    finally:
+        if old is None:
+            os.environ.pop("GMSX_BITSET_LIMIT", None)
+        else:
+            os.environ["GMSX_BITSET_LIMIT"] = old
