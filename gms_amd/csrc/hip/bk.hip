@@ -27,6 +27,7 @@ namespace gmsx {
 static constexpr int kLdsSlabWords = 2048;  // 8 KB per wave: tasks of at most ~90 candidates; with the trimmed scratch below 17 waves fit a CU
 static constexpr unsigned long long kEmptySlot = ~0ull;
 static constexpr unsigned long long kWideTask = 1ull << 62;  // task key flag: more than 2048 candidates
+static constexpr int kBkMaxCand = 16384;  // widest bit rows of the search kernels: eight words per lane
 
 __host__ __device__ inline uint32_t bk_map_size(int c) {
     uint32_t s = 64;
@@ -54,8 +55,8 @@ __global__ void k_bk_tasks(int64_t n, const int64_t *__restrict__ off, const int
         if (deg == 0) atomicAdd(&acc[0], 1ull);  // an isolated vertex is a maximal clique (eppsteinPAR.h:32-47, tomita.h:73-78)
     } else {
         w = bk_slab_words(c, x);
-        if (c > 4096) atomicOr(&acc[1], 1ull);
-        if (c > 2048) {  // two words per lane: these tasks sort first and run on the WPL = 2 kernels
+        if (c > kBkMaxCand) atomicOr(&acc[1], 1ull);
+        if (c > 2048) {  // more than one word per lane: these tasks sort first and run on the WPL = 2 / 4 / 8 kernels
             w |= kWideTask;
             atomicAdd(&acc[7], 1ull);
         }
@@ -455,9 +456,10 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
     constexpr uint32_t kLdsMapSlots = 1024;
     // one 8.25 KB LDS work area: the build's id -> index map (global-slab variant), then the search's pivot scratch
     static_assert(!LDS_SLAB || WPL == 1, "LDS-slab tasks are tiny");
-    __shared__ __attribute__((aligned(16))) uint32_t lds_work[(LDS_SLAB ? 128 : 2 * kLdsMapSlots) + 64 * WPL];  // piv_list: 2048*WPL u16 fit the map area (256 u16 for an LDS-slab task)
+    constexpr uint32_t kWorkWords = LDS_SLAB ? 128 : (2 * kLdsMapSlots > 1024u * WPL ? 2 * kLdsMapSlots : 1024u * WPL);  // map area, or piv_list: 2048*WPL u16 (256 u16 for an LDS-slab task)
+    __shared__ __attribute__((aligned(16))) uint32_t lds_work[kWorkWords + 64 * WPL];
     unsigned long long *lds_map = reinterpret_cast<unsigned long long *>(lds_work);
-    uint32_t *piv_P = lds_work + (LDS_SLAB ? 128 : 2 * kLdsMapSlots);
+    uint32_t *piv_P = lds_work + kWorkWords;
     unsigned short *piv_list = reinterpret_cast<unsigned short *>(lds_work);
     const int lane = threadIdx.x;
     uint32_t *slab = LDS_SLAB ? lds_slab : slabs + size_t(blockIdx.x) * slab_words;
@@ -607,7 +609,7 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
 
 // Rounds >= 1: one wave per resumable record; Cadj | XT are read from the arena, the stack lives in this wave's slab.
 template <int WPL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? 6 : 3))) void k_bk_resume(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? 6 : WPL == 2 ? 3 : 1))) void k_bk_resume(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in,
                                                   unsigned long long n_records, unsigned long long *__restrict__ queue,
                                                   uint32_t *__restrict__ slabs, unsigned long long slab_words,
                                                   unsigned long long *__restrict__ acc, BkShared sh) {
@@ -688,8 +690,9 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipMemcpyAsync(words.data(), k_out, size_t(n) * 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipMemcpyAsync(head, acc + kCtl, sizeof(head), hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
-    if (head[1]) return GMSX_ERR_UNSUPPORTED;  // a start vertex with more than 4096 candidates (two words per lane)
-    const int64_t n_wide = int64_t(head[7]);     // tasks with 2049..4096 candidates: sorted first (kWideTask), WPL = 2 kernels
+    if (head[1]) return GMSX_ERR_UNSUPPORTED;  // a start vertex with more than 16384 candidates (eight words per lane)
+    const int64_t n_wide = int64_t(head[7]);     // tasks with more than 2048 candidates: sorted first (kWideTask), WPL = 2 / 4 / 8 kernels
+    const int wpl_wide = g->max_dplus <= 4096 ? 2 : g->max_dplus <= 8192 ? 4 : 8;  // candidates of a start vertex = its d+
     for (int64_t i = 0; i < n_wide; ++i) words[size_t(i)] &= ~kWideTask;
 
     // ---- arena + record pools of the load balancer
@@ -763,8 +766,14 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(waves) * slab_bytes));
                 Guard g_slabs;  // freed on every path out of this bin, error returns included
                 g_slabs.p = slabs;
-                if (wide)
+                if (wide && wpl_wide == 2)
                     hipLaunchKernelGGL((k_bk_wave<false, 2>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
+                                       g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
+                else if (wide && wpl_wide == 4)
+                    hipLaunchKernelGGL((k_bk_wave<false, 4>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
+                                       g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
+                else if (wide)
+                    hipLaunchKernelGGL((k_bk_wave<false, 8>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
                                        g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
                 else
                     hipLaunchKernelGGL((k_bk_wave<false, 1>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
@@ -807,8 +816,14 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
             resume_cap = size_t(waves) * slab_bytes;
             GMSX_HIP(hipMalloc(&g_rslab.p, resume_cap));
         }
-        if (n_wide > 0)  // records of wide tasks may be anywhere in the pool
+        if (n_wide > 0 && wpl_wide == 2)  // records of wide tasks may be anywhere in the pool
             hipLaunchKernelGGL(k_bk_resume<2>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue,
+                               static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
+        else if (n_wide > 0 && wpl_wide == 4)
+            hipLaunchKernelGGL(k_bk_resume<4>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue,
+                               static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
+        else if (n_wide > 0)
+            hipLaunchKernelGGL(k_bk_resume<8>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue,
                                static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
         else
             hipLaunchKernelGGL(k_bk_resume<1>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue,

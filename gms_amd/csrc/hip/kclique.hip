@@ -17,6 +17,7 @@
 #include "device_graph.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace gmsx {
 
@@ -735,22 +736,178 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Generic path — no limit on d+ or k (k <= kMaxGenericK): the reference's recursion (k_clique_count_set_based.h:5-17) with
+// sets as sorted id lists in a per-wave global slab instead of bit rows.  One wave per (pivot u, first member v_i) task;
+// below that an iterative depth-first search: level sets  S' = { w in S[0..t) : w in N+(S[t]) }  are filtered 64 candidates
+// at a time (ballot compaction), membership = one bit of a bitset container (rank id < bitset_limit) or a binary search
+// in the member's sorted 16-bit / 32-bit list.  Slower than the bit-matrix kernels by an order of magnitude; it serves the
+// pivots they cannot hold (d+ > 8192 for k <= 4, > 4096 beyond) and k > kMaxK, so that no request fails for its size.
+// ---------------------------------------------------------------------------------------------
+static constexpr int kMaxGenericK = 64;
+
+__device__ __forceinline__ bool kc_has_edge(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff,
+                                            const int32_t *__restrict__ tadj, const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
+                                            int32_t bitset_limit, int32_t hub_limit, int32_t v, int32_t w) {  // w < v: is w in N+(v)?
+    if (v < bitset_limit) return (bmpool[bmoff[v] + (uint32_t(w) >> 5)] >> (uint32_t(w) & 31u)) & 1u;
+    if (w < hub_limit) {
+        int64_t lo = hoff[v], hi = hoff[v + 1];
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (int32_t(hadj[mid]) < w) lo = mid + 1; else hi = mid;  // the 0xFFFF pad sorts last
+        }
+        return lo < hoff[v + 1] && int32_t(hadj[lo]) == w;
+    }
+    int64_t lo = toff[v], hi = toff[v + 1];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (tadj[mid] < w) lo = mid + 1; else hi = mid;
+    }
+    return lo < toff[v + 1] && tadj[lo] == w;
+}
+
+__global__ __launch_bounds__(256) void k_kc_generic(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                    const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                    const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool, int32_t bitset_limit,
+                                                    int32_t hub_limit, const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
+                                                    int64_t first, int64_t end, int nparts, int part, int k, int32_t *__restrict__ slab,
+                                                    int64_t level_stride, unsigned long long *__restrict__ acc) {
+    __shared__ int s_idx[4][kMaxGenericK], s_len[4][kMaxGenericK];
+    __shared__ unsigned long long red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t pos = first + int64_t(blockIdx.y) * nparts + part;
+    unsigned long long cnt = 0;
+    if (pos < end) {
+        const int32_t u = order[pos];
+        const int d = dplus[u];
+        const int64_t hb = hoff[u], tb = toff[u];
+        const int tl = int(toff[u + 1] - tb), hreal = d - tl;  // members: hreal hub ids (ascending), then tl tail ids (ascending)
+        auto member = [&](int p) -> int32_t { return p < hreal ? int32_t(hadj[hb + p]) : tadj[tb + (p - hreal)]; };
+        const int64_t wave_id = int64_t(blockIdx.x) * 4 + wave, nwaves = int64_t(gridDim.x) * 4;
+        int32_t *base = slab + (int64_t(blockIdx.y) * nwaves + wave_id) * level_stride * int64_t(k > 3 ? k - 3 : 1);
+        int *idx = s_idx[wave], *len = s_len[wave];
+        for (int64_t i = wave_id + (k - 2); i < d; i += nwaves) {  // v_i needs k-2 members below it
+            const int32_t v = member(int(i));
+            // level 0: S = { w = member(p), p < i : w in N+(v) } — counted for k = 3, materialised otherwise
+            int n0 = 0;
+            for (int p0 = 0; p0 < int(i); p0 += 64) {
+                const int p = p0 + lane;
+                int32_t w = 0;
+                bool hit = false;
+                if (p < int(i)) {
+                    w = member(p);
+                    hit = kc_has_edge(hoff, hadj, toff, tadj, bmoff, bmpool, bitset_limit, hub_limit, v, w);
+                }
+                const unsigned long long m = __ballot(hit);
+                if (k > 3 && hit) base[n0 + __popcll(m & ((1ull << lane) - 1ull))] = w;
+                n0 += __popcll(m);
+            }
+            if (k == 3) { cnt += (lane == 0) ? (unsigned long long)n0 : 0ull; continue; }
+            if (n0 < k - 2) continue;  // the clique still needs k-2 vertices from this set
+            // depth-first over the levels: level L holds a set of len[L] ids from which `need` = k-2-L pairwise adjacent vertices
+            // are still to be chosen — R(need, S) of the reference recursion; R(1, S) = |S|
+            __builtin_amdgcn_wave_barrier();
+            int L = 0;
+            if (lane == 0) { len[0] = n0; idx[0] = n0; }
+            __builtin_amdgcn_wave_barrier();
+            while (L >= 0) {
+                const int need = k - 2 - L;  // vertices to pick from level L (>= 1)
+                const int n = len[L];
+                if (need == 1) {  // R(1, S) = |S|
+                    cnt += (lane == 0) ? (unsigned long long)n : 0ull;
+                    --L;
+                    continue;
+                }
+                int t = idx[L] - 1;  // next member of this level to branch on (descending)
+                if (t < need - 1) { --L; continue; }  // fewer than need-1 candidates below it
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) idx[L] = t;
+                const int32_t *cur = base + int64_t(L) * level_stride;
+                int32_t *nxt = base + int64_t(L + 1) * level_stride;
+                const int32_t x = cur[t];
+                int nn = 0;
+                for (int p0 = 0; p0 < t; p0 += 64) {
+                    const int p = p0 + lane;
+                    int32_t w = 0;
+                    bool hit = false;
+                    if (p < t) {
+                        w = cur[p];
+                        hit = kc_has_edge(hoff, hadj, toff, tadj, bmoff, bmpool, bitset_limit, hub_limit, x, w);
+                    }
+                    const unsigned long long m = __ballot(hit);
+                    if (need > 2 && hit) nxt[nn + __popcll(m & ((1ull << lane) - 1ull))] = w;
+                    nn += __popcll(m);
+                }
+                if (need == 2) {  // the next level would only be counted
+                    cnt += (lane == 0) ? (unsigned long long)nn : 0ull;
+                } else if (nn >= need - 1) {
+                    ++L;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane == 0) { len[L] = nn; idx[L] = nn; }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
+    if (lane == 0) red[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long t = red[0] + red[1] + red[2] + red[3];
+        if (t) atomicAdd(&acc[((blockIdx.x + blockIdx.y) & (kAccSlots - 1)) * kAccStride], t);
+    }
+}
+
 static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
     const int64_t span = end - first - part;
     return span <= 0 ? 0 : (span + nparts - 1) / nparts;
 }
 
+// generic list recursion for the pivots at positions [first, end) of the d+ order; *slab_out is freed by the caller after the sync
+static int launch_generic(const gmsx_graph *g, int k, int64_t first, int64_t end, int part, int nparts, unsigned long long *acc, int *launches,
+                          int32_t **slab_out) {
+    Ctx &c = ctx();
+    hipStream_t s = c.stream;
+    const int64_t pivots = part_count(first, end, nparts, part);
+    if (pivots <= 0) return GMSX_OK;
+    if (pivots > 65535) return GMSX_ERR_UNSUPPORTED;  // grid.y; tens of thousands of pivots beyond the bit-matrix limits do not occur
+    const int cu = c.compute_units > 0 ? c.compute_units : 256;
+    const int64_t dmax = std::max<int64_t>(g->max_dplus, 1);
+    const int64_t levels = k > 3 ? k - 3 : 1, stride = (dmax + 63) & ~int64_t(63);
+    // waves per pivot: enough to fill the chip a few times over, bounded by a 2 GB slab
+    int64_t blocks_x = std::max<int64_t>(1, std::min<int64_t>((dmax + 3) / 4, std::max<int64_t>(1, int64_t(cu) * 8 / pivots)));
+    while (blocks_x > 1 && pivots * blocks_x * 4 * levels * stride * 4 > (int64_t(2) << 30)) blocks_x /= 2;
+    const int64_t slab_ints = pivots * blocks_x * 4 * levels * stride;
+    if (slab_ints * 4 > (int64_t(8) << 30)) return GMSX_ERR_DEVICE_MEM;
+    int32_t *slab = nullptr;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slab), size_t(slab_ints) * 4));
+    *slab_out = slab;
+    hipLaunchKernelGGL(k_kc_generic, dim3(unsigned(blocks_x), unsigned(pivots)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                       g->bitset_limit, g->dense_limit, g->dplus, g->order, first, end, nparts, part, k, slab, stride, acc);
+    ++*launches;
+    return GMSX_OK;
+}
+
 template <int LV, bool VTX = false>
 static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long long *acc, int *launches, uint32_t **slab_out,
-                      unsigned long long *vcounts = nullptr) {
+                      unsigned long long *vcounts = nullptr, int32_t **generic_slab = nullptr) {
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     const int k = LV + 2;
     int64_t over = 0, n_min = 0;
     constexpr int kMaxD = (LV <= 2) ? 8192 : 4096;  // widest bit rows: four words per lane for k = 3, 4 and the per-vertex counts, two for k >= 5
-    if (int rc = count_dplus_ge(g, kMaxD + 1, &over)) return rc;
-    if (over > 0) return GMSX_ERR_UNSUPPORTED;
+    int max_d = kMaxD;
+    if (const char *e = std::getenv("GMSX_KC_MAXD")) {  // test hook: a lower limit sends more pivots through the generic path
+        const int v = std::atoi(e);
+        if (v >= 1 && v < kMaxD) max_d = v;
+    }
+    if (int rc = count_dplus_ge(g, max_d + 1, &over)) return rc;
     if (!g->rows_sorted) return GMSX_ERR_UNSUPPORTED;  // > 2^32 container entries: rows were not sorted at upload
+    if (over > 0) {
+        if (VTX) return GMSX_ERR_UNSUPPORTED;  // the per-vertex counts have their own full-row fallback (pairs.hip)
+        // pivots wider than the bit-matrix kernels hold: the generic list recursion takes positions [0, over) of the d+ order
+        if (int rc = launch_generic(g, k, 0, over, part, nparts, acc, launches, generic_slab)) return rc;
+    }
     if (int rc = count_dplus_ge(g, std::max(k - 1, 1), &n_min)) return rc;
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
     // positions [lo, hi) in the d+-sorted order of the pivots with a < d+ <= b, cut at the smallest useful d+
@@ -758,6 +915,8 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         if (int rc = count_dplus_ge(g, b + 1, lo)) return rc;
         if (int rc = count_dplus_ge(g, a + 1, hi)) return rc;
         *hi = std::min(*hi, n_min);
+        *lo = std::max(*lo, over);  // positions [0, over) went through the generic path
+        *hi = std::max(*hi, *lo);
         return GMSX_OK;
     };
 
@@ -870,21 +1029,34 @@ static int kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uin
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), sizeof(unsigned long long) * kAccSlots * kAccStride));
     struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{acc};
     uint32_t *slabs = nullptr;
+    int32_t *gslab = nullptr;
     GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * kAccSlots * kAccStride, s));
     GMSX_HIP(hipEventRecord(c.ev[0], s));
     int launches = 0, rc = GMSX_OK;
     switch (k) {
-        case 3: rc = launch_all<1>(g, part, nparts, acc, &launches, &slabs); break;
-        case 4: rc = launch_all<2>(g, part, nparts, acc, &launches, &slabs); break;
-        case 5: rc = launch_all<3>(g, part, nparts, acc, &launches, &slabs); break;
-        case 6: rc = launch_all<4>(g, part, nparts, acc, &launches, &slabs); break;
-        case 7: rc = launch_all<5>(g, part, nparts, acc, &launches, &slabs); break;
-        case 8: rc = launch_all<6>(g, part, nparts, acc, &launches, &slabs); break;
-        case 9: rc = launch_all<7>(g, part, nparts, acc, &launches, &slabs); break;
-        case 10: rc = launch_all<8>(g, part, nparts, acc, &launches, &slabs); break;
-        default: rc = GMSX_ERR_UNSUPPORTED;
+        case 3: rc = launch_all<1>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
+        case 4: rc = launch_all<2>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
+        case 5: rc = launch_all<3>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
+        case 6: rc = launch_all<4>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
+        case 7: rc = launch_all<5>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
+        case 8: rc = launch_all<6>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
+        case 9: rc = launch_all<7>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
+        case 10: rc = launch_all<8>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
+        default: {  // k > kMaxK: every pivot that can head a k-clique (d+ >= k-1) through the generic list recursion
+            int64_t n_min = 0;
+            rc = g->rows_sorted ? count_dplus_ge(g, k - 1, &n_min) : GMSX_ERR_UNSUPPORTED;
+            for (int64_t lo = 0; !rc && lo < n_min; lo += int64_t(60000) * nparts) {  // grid.y chunks
+                int32_t *chunk = nullptr;
+                rc = launch_generic(g, k, lo, std::min<int64_t>(n_min, lo + int64_t(60000) * nparts), part, nparts, acc, &launches, &chunk);
+                if (!rc && chunk) {
+                    GMSX_HIP(hipStreamSynchronize(s));
+                    (void)hipFree(chunk);
+                }
+            }
+        }
     }
     Guard slab_guard{slabs};
+    Guard gslab_guard{gslab};
     if (rc) return rc;
     GMSX_HIP(hipEventRecord(c.ev[1], s));
     GMSX_HIP(hipGetLastError());
@@ -939,7 +1111,7 @@ extern "C" {
 
 int gmsx_kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint64_t *cliques_partial, gmsx_stats *stats) {
     if (!g || !cliques_partial || nparts < 1 || part < 0 || part >= nparts || k < 2) return GMSX_ERR_INVALID;
-    if (k > kMaxK) return GMSX_ERR_UNSUPPORTED;
+    if (k > kMaxGenericK) return GMSX_ERR_UNSUPPORTED;  // the generic recursion keeps its per-level cursors in LDS: k <= 64
     if (int rc = ensure_init()) return rc;
     return kclique_partial(g, k, part, nparts, cliques_partial, stats);
 }

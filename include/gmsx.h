@@ -189,8 +189,9 @@ int gmsx_vertex_similarity_batch(const gmsx_graph *g, int metric, int64_t n_pair
 
 /* ---- k-clique counting: CliqueCount (k_clique_count/k_clique_count_set_based.h:19-31).
  * *ordered_count = the reference's return value k!·C_k (mod 2^64, like size_t); *cliques = C_k (may be NULL).
- * k = 2 … 10.  Limits of the bit-matrix kernels: oriented out-degree d+ <= 8192 for k <= 4, <= 4096 for k >= 5; beyond them
- * (and for k > 10) the call returns GMSX_ERR_UNSUPPORTED and computes nothing.  (RMAT scale 26: max d+ = 3004.) */
+ * k = 2 … 64.  The fast path — one bit-matrix per pivot — holds oriented out-degrees d+ <= 8192 for k <= 4, <= 4096 for
+ * 5 <= k <= 10 (RMAT scale 26: max d+ = 3004); wider pivots and k > 10 run on a generic list recursion on the device (an order of
+ * magnitude slower per pivot, same result), so no request fails for its size.  k > 64 → GMSX_ERR_UNSUPPORTED. */
 int gmsx_kclique_count(const gmsx_graph *g, int k, uint64_t *ordered_count, uint64_t *cliques, gmsx_stats *stats);
 int gmsx_kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint64_t *cliques_partial, gmsx_stats *stats);
 
@@ -200,7 +201,9 @@ int gmsx_kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint6
  * vertices split their neighbourhoods by (eppsteinPAR.h:39-45), so the device always splits by its own degree rank (the
  * order its containers are built for); a non-NULL `rank` is only VALIDATED — it must be a permutation of 0..n-1, else
  * GMSX_ERR_INVALID — the way the reference's drivers hand a rank vector from the preprocessing step to mceBench
- * (maximal_clique_enum_bron_kerbosch.cc:36-56).  gmsx_adg_rank() below is that preprocessing step on the device. */
+ * (maximal_clique_enum_bron_kerbosch.cc:36-56).  gmsx_adg_rank() below is that preprocessing step on the device.
+ * Width: a start vertex may have up to 16384 candidates (d+ in the device's degree rank; the search kernels run with 1, 2, 4 or 8
+ * words per lane; RMAT scale 27: max d+ = 3855); beyond that GMSX_ERR_UNSUPPORTED — the one size limit left in this header. */
 int gmsx_bk_count(const gmsx_graph *g, const int32_t *rank, uint64_t *maximal_cliques, gmsx_stats *stats);
 int gmsx_bk_partial(const gmsx_graph *g, const int32_t *rank, int part, int nparts, uint64_t *partial, gmsx_stats *stats);
 

@@ -86,8 +86,9 @@ def test_edge_cases_and_errors(gpu):
     with pytest.raises(gpu.GmsxError) as ei:
         g.kclique_count(1)
     assert ei.value.status == gpu.ERR_INVALID
+    assert g.kclique_count(11) == (0, 0)  # k > 10 runs on the generic list recursion (tests/test_no_cliffs_gpu.py)
     with pytest.raises(gpu.GmsxError) as ei:
-        g.kclique_count(11)
+        g.kclique_count(65)
     assert ei.value.status == gpu.ERR_UNSUPPORTED
     g.free()
     e = gpu.DeviceGraph.from_csr(edges_to_csr(gpu, []))
@@ -130,10 +131,10 @@ def test_dense_random_graph_large_out_degrees(gpu):
         g.free()
 
 
-def test_out_degrees_above_4096(gpu):
+def test_out_degrees_above_4096(gpu, oracle):
     """Pivots with 4096 < d+ <= 8192 (four-words-per-lane slab kernel, k <= 4 and the per-vertex counts).  K_{a,b} plus a sparse
     random graph H inside side A: every B vertex sees all of A as higher-ranked neighbours (d+ = a > 4096), triangles are
-    T(H) + b·|E(H)|, 4-cliques K4(H) + b·T(H); k = 5 is beyond the two-word rows of the deeper recursion: UNSUPPORTED."""
+    T(H) + b·|E(H)|, 4-cliques K4(H) + b·T(H); k = 5 is beyond the two-word rows of the deeper recursion: the generic list recursion takes it."""
     a, b, eh = 4200, 4300, 20000
     rng = np.random.default_rng(11)
     hu, hv = rng.integers(0, a, eh), rng.integers(0, a, eh)
@@ -166,7 +167,9 @@ def test_out_degrees_above_4096(gpu):
     per_vertex[:a] = np.rint(H2.sum(axis=1, dtype=np.float64)).astype(np.int64) + 2 * b * H.sum(axis=1)  # 2 x (triangles in H + b per H-edge at the vertex)
     per_vertex[a:] = 2 * eh_real
     assert np.array_equal(g.tc_vertex_count2(), per_vertex)
-    with pytest.raises(gpu.GmsxError) as ei:
-        g.kclique_count(5)
-    assert ei.value.status == gpu.ERR_UNSUPPORTED
+    # k = 5 is past the 4096-wide bit rows of the k >= 5 kernels: the B pivots go through the generic list recursion
+    # (every 5-clique has at most one B vertex: b * C_4(H) + C_5(H))
+    hcsr = gpu.HostCSR.from_edges(hi[0].astype(np.int32), hi[1].astype(np.int32), num_nodes=a)
+    k5h = oracle.kclique(hcsr.offsets(), hcsr.neighbors(), 5) // 120
+    assert g.kclique_count(5)[1] == b * k4h + k5h
     g.free()

@@ -1,0 +1,127 @@
+"""GPU: no request fails for its SIZE.  The bit-matrix kernels hold pivots up to d+ = 8192 (k <= 4) /
+4096 (k >= 5) and k <= 10, the Bron–Kerbosch search kernels grow to eight words per lane (16384 candidates); wider pivots
+and larger k fall back to the generic list recursion (kclique.hip, k_kc_generic) instead of GMSX_ERR_UNSUPPORTED.
+
+Shapes: K_{a,b} plus a sparse random graph H inside side A, b = a + 1.  Every B vertex has all of A as its oriented row
+(d+ = a), B is independent, so every clique has at most one B vertex:
+    C_k(G) = b * C_{k-1}(H) + C_k(H),      maximal cliques(G) = b * MC(H)    (isolated vertices of H count)
+with the H terms from the oracle on H alone."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from conftest import host_graph
+
+pytestmark = pytest.mark.gpu
+
+
+def kab_plus_h(gpu, oracle, a, b, eh, seed):
+    rng = np.random.default_rng(seed)
+    hu, hv = rng.integers(0, a, eh), rng.integers(0, a, eh)
+    keep = hu != hv
+    hu, hv = hu[keep].astype(np.int32), hv[keep].astype(np.int32)
+    hcsr = gpu.HostCSR.from_edges(hu, hv, num_nodes=a)
+    bu, bv = np.meshgrid(np.arange(a, dtype=np.int32), np.arange(a, a + b, dtype=np.int32), indexing="ij")
+    csr = gpu.HostCSR.from_edges(np.concatenate([bu.ravel(), hu]), np.concatenate([bv.ravel(), hv]))
+    return csr, hcsr
+
+
+def cliques_of(oracle, csr, k):
+    if k == 1:
+        return csr.num_nodes
+    if k == 2:
+        return csr.num_edges
+    ordered = oracle.kclique(csr.offsets(), csr.neighbors(), k)
+    assert ordered % math.factorial(k) == 0
+    return ordered // math.factorial(k)
+
+
+@pytest.mark.parametrize("a,ks", [(4200, (5, 6)), (8300, (3, 4))])
+def test_kclique_beyond_the_bit_matrix_width(gpu, oracle, a, ks):
+    b = a + 1
+    csr, hcsr = kab_plus_h(gpu, oracle, a, b, 3 * a, seed=a)
+    g = gpu.DeviceGraph.from_csr(csr)
+    assert g.max_out_degree >= a
+    for k in ks:
+        want = b * cliques_of(oracle, hcsr, k - 1) + cliques_of(oracle, hcsr, k)
+        ordered, cliques = g.kclique_count(k)
+        assert cliques == want and ordered == (want * math.factorial(k)) & ((1 << 64) - 1), (a, k)
+        assert sum(g.kclique_partial(k, p, 3) for p in range(3)) == want
+    g.free()
+
+
+_WANT = {}
+
+
+def _want(oracle, csr, key, k):
+    if (key, k) not in _WANT:
+        _WANT[(key, k)] = oracle.kclique(csr.offsets(), csr.neighbors(), k)
+    return _WANT[(key, k)]
+
+
+@pytest.mark.parametrize("maxd", [1, 8, 40, 300])
+def test_generic_path_equals_bit_matrix_path(gpu, oracle, maxd):
+    """GMSX_KC_MAXD (test hook) lowers the width limit, so ordinary graphs go through the generic recursion: same counts."""
+    old = os.environ.get("GMSX_KC_MAXD")
+    os.environ["GMSX_KC_MAXD"] = str(maxd)
+    try:
+        for kind, scale, deg, ks in (("kronecker", 10, 16, (3, 4, 5, 6)), ("uniform", 10, 30, (3, 4)), ("kronecker", 12, 8, (3, 4, 5))):
+            csr = host_graph(gpu, kind, scale, deg, True)
+            g = gpu.DeviceGraph.from_csr(csr)
+            for k in ks:
+                assert g.kclique_count(k)[0] == _want(oracle, csr, (kind, scale, deg), k), (kind, scale, k, maxd)
+            g.free()
+    finally:
+        if old is None:
+            os.environ.pop("GMSX_KC_MAXD", None)
+        else:
+            os.environ["GMSX_KC_MAXD"] = old
+
+
+def test_k_beyond_ten(gpu):
+    """k = 11 … 14 (the unrolled bit-matrix recursions stop at 10): K_n has C(n, k) k-cliques; a dense random graph against
+    a plain Python recursion on the same DAG orientation."""
+    for n in (12, 16, 20):
+        iu = np.triu_indices(n, 1)
+        g = gpu.DeviceGraph.from_csr(gpu.HostCSR.from_edges(iu[0].astype(np.int32), iu[1].astype(np.int32)))
+        for k in (11, 12, 14):
+            assert g.kclique_count(k)[1] == math.comb(n, k), (n, k)
+        g.free()
+    rng = np.random.default_rng(5)
+    n = 36
+    adj = np.triu(rng.random((n, n)) < 0.85, 1)
+    adj = adj | adj.T
+    nbrs = [set(np.flatnonzero(adj[i])) for i in range(n)]
+
+    def count(k, cand):
+        if k == 0:
+            return 1
+        total = 0
+        for v in sorted(cand):
+            total += count(k - 1, {w for w in cand & nbrs[v] if w > v})
+        return total
+    iu = np.nonzero(np.triu(adj, 1))
+    g = gpu.DeviceGraph.from_csr(gpu.HostCSR.from_edges(iu[0].astype(np.int32), iu[1].astype(np.int32), num_nodes=n))
+    for k in (11, 13):
+        assert g.kclique_count(k)[1] == count(k, set(range(n))), k
+    with pytest.raises(gpu.GmsxError) as ei:
+        g.kclique_count(65)
+    assert ei.value.status == gpu.ERR_UNSUPPORTED  # the one remaining bound: per-level cursors of the generic recursion
+    g.free()
+
+
+@pytest.mark.parametrize("a", [4200, 8200])
+def test_bk_beyond_4096_candidates(gpu, oracle, a):
+    """Start vertices with 4097..8192 / 8193..16384 candidates: four / eight words per lane in the search kernels."""
+    b = a + 1
+    csr, hcsr = kab_plus_h(gpu, oracle, a, b, 4 * a, seed=a + 1)
+    mc_h = oracle.bk_count(hcsr.offsets(), hcsr.neighbors())
+    g = gpu.DeviceGraph.from_csr(csr)
+    assert g.max_out_degree >= a
+    want = b * mc_h
+    got, st = g.bk_count(stats=True)
+    assert got == want
+    assert sum(g.bk_partial(p, 2) for p in range(2)) == want
+    g.free()
