@@ -219,6 +219,9 @@ int launch_ranks(int argc, char **argv, int gpus) {
             setenv("GMSX_DRIVER_RANK", std::to_string(r).c_str(), 1);
             setenv("GMSX_DRIVER_NRANKS", std::to_string(gpus).c_str(), 1);
             setenv("GMSX_DRIVER_ID_FILE", idfile, 1);
+            // one node by construction: keep RCCL's bootstrap off the (possibly absent) external network unless the user chose otherwise
+            setenv("NCCL_SOCKET_IFNAME", "lo", 0);
+            setenv("NCCL_IB_DISABLE", "1", 0);
             execv("/proc/self/exe", argv);
             std::perror("execv");
             _exit(127);

@@ -33,7 +33,7 @@ def test_kclique_vs_oracle_k3_to_k7(gpu, oracle, spec):
     csr = host_graph(gpu, kind, scale, deg, True)
     g = gpu.DeviceGraph.from_csr(csr)
     for k in (3, 4, 5, 6, 7):
-        if k >= 6 and (scale, deg) == (10, 30):
+        if (k >= 6 and (scale, deg) == (10, 30)) or (k >= 7 and (scale, deg) == (12, 8)):
             continue  # the oracle's k! * C recursion takes minutes there
         want = oracle.kclique(csr.offsets(), csr.neighbors(), k)
         assert g.kclique_count(k)[0] == want, (spec, k)
