@@ -482,6 +482,11 @@ int gmsx_init(int device) {
         if (hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking) != hipSuccess) return GMSX_ERR_NO_DEVICE;
         for (auto &e : c.ev)
             if (hipEventCreate(&e) != hipSuccess) return GMSX_ERR_NO_DEVICE;
+        for (auto &st : c.side)
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return GMSX_ERR_NO_DEVICE;
+        if (hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess) return GMSX_ERR_NO_DEVICE;
+        for (auto &e : c.ev_join)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return GMSX_ERR_NO_DEVICE;
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GMSX_ERR_NO_DEVICE;

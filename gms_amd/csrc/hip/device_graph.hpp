@@ -81,6 +81,8 @@ struct Ctx {
     hipStream_t stream = nullptr;       // stream all launches go to
     hipStream_t own_stream = nullptr;   // created by gmsx_init
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side[2] = {nullptr, nullptr};  // co-scheduling: the latency-bound light-pivot kernels run beside the bandwidth-bound one
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     int compute_units = 0;
 };
 Ctx &ctx();

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 
 namespace gmsx {
 
@@ -646,26 +647,52 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     GMSX_HIP(hipEventRecord(c.ev[1], s));
 
     int launches = 0;
-    const int64_t cap_blocks = int64_t(c.compute_units > 0 ? c.compute_units : 256) * 16;
-    {
-        const int64_t cnt = part_count(0, n_block, nparts, part);
-        if (cnt > 0) {
-            hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit, g->toff, g->tadj, g->order,
-                               int64_t(0), n_block, nparts, part, acc);
-            ++launches;
-        }
+    const int cus = c.compute_units > 0 ? c.compute_units : 256;
+    const int64_t cap_blocks = int64_t(cus) * 16;
+    const int64_t cnt_heavy = part_count(0, n_block, nparts, part), cnt_light = part_count(n_block, n_work, nparts, part);
+    // CO-SCHEDULING.  The heavy-pivot kernel is bound by beyond-L2 bandwidth, the two light-pivot kernels by memory latency
+    // (k_tc_wave) and by the gather rate of the texture addressers (k_tc_wave_hub): run back to back, each leaves the resource the
+    // others need idle.  So the light kernels go to two side streams FIRST, with grids of only a few workgroups per CU (they are
+    // persistent grid-stride kernels: 1 + 2 workgroups = 12 waves and 77 KB of LDS per CU), and the heavy kernel fills the
+    // remaining wave slots and LDS of every CU (5 workgroups, growing to 8 as the light kernels retire).  One pass then costs
+    // about max(heavy, light) instead of their sum.  GMSX_TC_OVERLAP=0 restores the serial order (full-width light grids).
+    static const int overlap = [] { const char *e = std::getenv("GMSX_TC_OVERLAP"); return e ? std::atoi(e) : 1; }();
+    static const int hub_wgs = [] { const char *e = std::getenv("GMSX_TC_HUB_WGS"); return e ? std::max(1, std::atoi(e)) : 1; }();
+    static const int wave_wgs = [] { const char *e = std::getenv("GMSX_TC_WAVE_WGS"); return e ? std::max(1, std::atoi(e)) : 2; }();
+    // measured (tools/tc_overlap_sweep.py, MI355X): scale 26 268 -> 254 ms — 1.80 TB of beyond-L2 traffic at 7.1 TB/s, i.e. the pass then
+    // sits on the aggregate bandwidth roof and only fewer bytes can make it faster; scale 24 37.8 -> 36…46 ms (noisy: the light kernels are
+    // 12 ms there and the heavy kernel loses more to the sharing than they hide).  So: only in the large-graph regime, which is also
+    // where the near-tail bitsets are on.
+    const bool co = overlap && cnt_heavy > 0 && cnt_light > 0 && c.side[0] && c.side[1] && (overlap > 1 || g->bitset_limit > g->dense_limit);
+    hipStream_t s_hub = co ? c.side[0] : s, s_wave = co ? c.side[1] : s;
+    if (co) {
+        GMSX_HIP(hipEventRecord(c.ev_fork, s));
+        GMSX_HIP(hipStreamWaitEvent(c.side[0], c.ev_fork, 0));
+        GMSX_HIP(hipStreamWaitEvent(c.side[1], c.ev_fork, 0));
     }
-    {
-        const int64_t cnt = part_count(n_block, n_work, nparts, part);
-        if (cnt > 0) {
-            const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
-            hipLaunchKernelGGL(k_tc_wave_hub, dim3(unsigned(std::min<int64_t>((cnt + 3) / 4, cap_blocks * 2))), dim3(256), 0, s, g->hoff,
-                               g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool, g->bitset_limit, g->order, n_block, n_work, nparts, part, acc);
-            hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit,
-                               g->toff, g->tadj, g->tsplit, g->order, n_block, n_work, nparts, part, acc);
-            ++launches;
-            ++launches;
-        }
+    auto launch_light = [&]() {
+        if (cnt_light <= 0) return;
+        const int64_t want = (cnt_light + 3) / 4;
+        const int64_t b_hub = std::min<int64_t>(want, co ? int64_t(cus) * hub_wgs : cap_blocks * 2);
+        const int64_t b_wave = std::min<int64_t>(want, co ? int64_t(cus) * wave_wgs : cap_blocks);
+        hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(b_wave)), dim3(256), 0, s_wave, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit,
+                           g->toff, g->tadj, g->tsplit, g->order, n_block, n_work, nparts, part, acc);
+        hipLaunchKernelGGL(k_tc_wave_hub, dim3(unsigned(b_hub)), dim3(256), 0, s_hub, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                           g->bitset_limit, g->order, n_block, n_work, nparts, part, acc);
+        launches += 2;
+    };
+    if (co) launch_light();
+    if (cnt_heavy > 0) {
+        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt_heavy)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit, g->toff, g->tadj,
+                           g->order, int64_t(0), n_block, nparts, part, acc);
+        ++launches;
+    }
+    if (!co) launch_light();
+    if (co) {
+        GMSX_HIP(hipEventRecord(c.ev_join[0], c.side[0]));
+        GMSX_HIP(hipEventRecord(c.ev_join[1], c.side[1]));
+        GMSX_HIP(hipStreamWaitEvent(s, c.ev_join[0], 0));
+        GMSX_HIP(hipStreamWaitEvent(s, c.ev_join[1], 0));
     }
     GMSX_HIP(hipEventRecord(c.ev[2], s));
     GMSX_HIP(hipGetLastError());
