@@ -34,7 +34,7 @@ SYMBOLS = [
     "gmsx_init", "gmsx_set_stream", "gmsx_device_info",
     "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
     "gmsx_graph_device_bytes", "gmsx_graph_max_out_degree",
-    "gmsx_tc_total", "gmsx_tc_partial", "gmsx_tc_divisor", "gmsx_tc_vertex_count2",
+    "gmsx_tc_total", "gmsx_tc_partial", "gmsx_tc_divisor", "gmsx_tc_stream_breakdown", "gmsx_tc_vertex_count2",
     "gmsx_intersect_count_batch", "gmsx_vertex_similarity_batch", "gmsx_kclique_count", "gmsx_kclique_partial", "gmsx_bk_count", "gmsx_bk_partial",
     "gmsx_adg_rank", "gmsx_tc_ordering",
     "gmsx_comm_unique_id", "gmsx_comm_init", "gmsx_comm_allreduce_u64", "gmsx_comm_rank", "gmsx_comm_size", "gmsx_comm_finalize",
@@ -106,6 +106,7 @@ def lib():
     L.gmsx_tc_total.argtypes = [vp, C.c_int, u64p, sp]
     L.gmsx_tc_partial.argtypes = [vp, C.c_int, C.c_int, C.c_int, u64p, sp]
     L.gmsx_tc_divisor.argtypes = [C.c_int]
+    L.gmsx_tc_stream_breakdown.argtypes = [vp, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
     L.gmsx_tc_vertex_count2.argtypes = [vp, _i64p, sp]
     L.gmsx_intersect_count_batch.argtypes = [vp, C.c_int64, _i32p, _i32p, _u32p, sp]
     L.gmsx_vertex_similarity_batch.argtypes = [vp, C.c_int, C.c_int64, _i32p, _i32p, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), sp]
@@ -273,6 +274,15 @@ class DeviceGraph:
         out, st = C.c_uint64(0), Stats()
         _check(lib().gmsx_tc_partial(self._h, algo, part, nparts, C.byref(out), C.byref(st)), "gmsx_tc_partial")
         return (int(out.value), st.as_dict()) if stats else int(out.value)
+
+    BREAKDOWN = ["heavy_bitset_rows", "heavy_list_rows", "heavy_tailmember_hub_parts", "heavy_tailmember_tail_parts", "light_gathers",
+                 "light_streamed_hub_parts", "light_streamed_tail_parts", "pivot_containers", "heavy_list_rows_delta", "heavy_tailmember_hub_parts_delta",
+                 "light_streamed_hub_parts_delta", "row_fetches_heavy", "row_fetches_light_streamed"]
+
+    def tc_stream_breakdown(self):
+        out = np.zeros(13, dtype=np.uint64)
+        _check(lib().gmsx_tc_stream_breakdown(self._h, out), "gmsx_tc_stream_breakdown")
+        return dict(zip(self.BREAKDOWN, (int(x) for x in out)))
 
     def tc_vertex_count2(self, stats=False):
         c, st = np.zeros(self.num_nodes, dtype=np.int64), Stats()

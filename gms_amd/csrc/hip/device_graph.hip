@@ -148,6 +148,80 @@ __global__ __launch_bounds__(256) void k_fill_parts(int64_t n, const int64_t *__
     }
 }
 
+// ---- stream rows: per row the cheapest of list / bitset / byte-delta, in whole 16-byte units ------------------------------------
+// units of the byte-delta form of one sorted 16-bit list: unit = 16-bit base id, one count byte, 13 gap bytes; a gap above 255
+// ends the unit (the next unit's base is free), unused gap bytes stay 0 and are cut off by the count.  `emit` != nullptr writes
+// the units.  One THREAD per row: the encoding is sequential.
+__device__ inline uint32_t delta_encode(const uint16_t *__restrict__ row, int len, uint32_t *__restrict__ emit) {
+    uint32_t units = 0;
+    int i = 0;
+    while (i < len && row[i] != 0xFFFFu) {
+        uint32_t w[4] = {row[i], 0u, 0u, 0u};  // base id in the low half of word 0
+        uint32_t cur = row[i];
+        int slot = 3;  // byte position of the next gap (3 … 15); byte 2 holds the number of ids of the unit
+        ++i;
+        while (i < len && row[i] != 0xFFFFu && slot < 16) {
+            const uint32_t gap = uint32_t(row[i]) - cur;  // >= 1: rows are strictly ascending
+            if (gap > 255u) break;                         // does not fit a byte: the next unit starts at this id (its base is free)
+            w[slot >> 2] |= gap << ((slot & 3) * 8);
+            ++slot;
+            cur = row[i];
+            ++i;
+        }
+        w[0] |= uint32_t(slot - 2) << 16;  // ids in this unit: 1 … 14
+        if (emit) {
+            emit[units * 4 + 0] = w[0]; emit[units * 4 + 1] = w[1]; emit[units * 4 + 2] = w[2]; emit[units * 4 + 3] = w[3];
+        }
+        ++units;
+    }
+    return units;
+}
+// delta_mode: 0 = never, 1 = when it is at least 15 % smaller than the list, 2 = whenever possible (test hook)
+__global__ void k_srow_sizes(int64_t n, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, int32_t dense_limit, int delta_mode,
+                             int delta_pct, int64_t *__restrict__ units_out, unsigned char *__restrict__ form_out) {
+    const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (v > n) return;
+    if (v == n) { units_out[n] = 0; return; }
+    const int64_t b = hoff[v];
+    const int len = int(hoff[v + 1] - b);
+    uint32_t best = uint32_t((len + 7) / 8);  // list: 8 ids per unit
+    int form = kFormList;
+    if (len > 0 && v < dense_limit) {
+        const uint32_t bits = uint32_t(bitset_words(int32_t(v)) / 4);
+        if (bits * 16u + 32u < uint32_t(len) * 2u) { best = bits; form = kFormBitset; }  // same rule as the kernels always used
+    }
+    if (len > 0 && form == kFormList && delta_mode > 0 && (delta_mode == 2 || len >= 24)) {
+        const uint32_t d = delta_encode(hadj + b, len, nullptr);
+        if (delta_mode == 2 || d * 100u <= best * uint32_t(delta_pct)) { best = d; form = kFormDelta; }
+    }
+    units_out[v] = int64_t(best);
+    form_out[v] = (unsigned char)form;
+}
+__global__ void k_srow_fill(int64_t n, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, const int64_t *__restrict__ bmoff,
+                            const uint32_t *__restrict__ bmpool, const int64_t *__restrict__ uoff, const unsigned char *__restrict__ form,
+                            unsigned long long *__restrict__ srow, uint32_t *__restrict__ spool) {
+    const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const int64_t u0 = uoff[v], units = uoff[v + 1] - u0;
+    srow[v] = ((unsigned long long)u0 << 24) | ((unsigned long long)form[v] << 22) | (unsigned long long)units;
+    if (units == 0) return;
+    uint32_t *dst = spool + u0 * 4;
+    const int64_t b = hoff[v];
+    const int len = int(hoff[v + 1] - b);
+    if (form[v] == kFormDelta) {
+        delta_encode(hadj + b, len, dst);
+    } else if (form[v] == kFormBitset) {
+        const uint32_t *src = bmpool + bmoff[v];  // bitset_words(v) is a multiple of 4 words = whole units
+        for (int64_t w = 0; w < units * 4; ++w) dst[w] = src[w];
+    } else {
+        for (int64_t w = 0; w < units * 4; ++w) {
+            const int i = int(w) * 2;
+            const uint32_t lo = i < len ? hadj[b + i] : 0xFFFFu, hi = i + 1 < len ? hadj[b + i + 1] : 0xFFFFu;
+            dst[w] = lo | (hi << 16);
+        }
+    }
+}
+
 // ---- bitset containers of dense hub rows -------------------------------------------------------------------
 // words of the bitset of rank id v (covers ids [0, v)), rounded to 16 bytes; 0 if the list form is smaller
 __global__ void k_dense_sizes(int32_t limit, const int32_t *__restrict__ dplus, int64_t *__restrict__ sizes) {
@@ -245,6 +319,8 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->bmoff);
     (void)hipFree(g->bmpool);
     (void)hipFree(g->tsplit);
+    (void)hipFree(g->srow);
+    (void)hipFree(g->spool);
     (void)hipFree(g->dplus);
     (void)hipFree(g->order);
     (void)hipFree(g->sorted_dplus);
@@ -406,6 +482,38 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
             hipLaunchKernelGGL(k_dense_fill, dim3(grid_for_waves(K)), dim3(256), 0, s, K, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool);
         if (int rc = dmalloc(&g->tsplit, n, g)) return rc;
         if (n > 0) hipLaunchKernelGGL(k_tail_split, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->toff, g->tadj, K, g->tsplit);
+    }
+
+    // 4d. stream rows of the heavy-pivot triangle kernel (needs the hub rows sorted: the delta form encodes ascending ids)
+    {
+        int delta_mode = g->rows_sorted ? 1 : 0;
+        if (const char *e = std::getenv("GMSX_TC_DELTA")) {  // 0 = lists and bitsets only, 2 = delta wherever possible (test hook)
+            const int v = std::atoi(e);
+            if (v >= 0 && v <= 2 && g->rows_sorted) delta_mode = v;
+        }
+        int delta_pct = 85;  // take the delta form when it is at most this percentage of the list form (its decode costs ~30 % more VALU per id)
+        if (const char *e = std::getenv("GMSX_TC_DELTA_PCT")) {
+            const int v = std::atoi(e);
+            if (v >= 10 && v <= 100) delta_pct = v;
+        }
+        int64_t *units = nullptr, *uoff = nullptr;
+        unsigned char *form = nullptr;
+        if (int rc = dmalloc(&units, n + 1, nullptr)) return rc;
+        DevGuard g_u{units};
+        if (int rc = dmalloc(&uoff, n + 1, nullptr)) return rc;
+        DevGuard g_o{uoff};
+        if (int rc = dmalloc(&form, n + 1, nullptr)) return rc;
+        DevGuard g_f{form};
+        hipLaunchKernelGGL(k_srow_sizes, dim3(unsigned(n / 256 + 1)), dim3(256), 0, s, n, g->hoff, g->hadj, g->dense_limit, delta_mode, delta_pct, units, form);
+        if (int rc = exclusive_scan_i64(units, uoff, n + 1, s)) return rc;
+        GMSX_HIP(hipMemcpy(&g->spool_units, uoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (g->spool_units >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;  // 40 offset bits in a srow entry (16 TB)
+        if (int rc = dmalloc(&g->srow, n, g)) return rc;
+        if (int rc = dmalloc(&g->spool, g->spool_units * 4 + 4, g)) return rc;
+        if (n > 0)
+            hipLaunchKernelGGL(k_srow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->hoff, g->hadj, g->bmoff, g->bmpool, uoff, form, g->srow,
+                               g->spool);
+        GMSX_HIP(hipStreamSynchronize(s));
     }
 
     // 5. work-sorted launch order: rank ids by decreasing d+

@@ -46,6 +46,16 @@ struct gmsx_graph {
     int32_t bitset_limit = 0;   // >= dense_limit: every rank id below it has a bitset container over [0, v) in bmpool (hub AND tail
                                 // targets); ids in [dense_limit, bitset_limit) are the "near tail": light pivots resolve their rows by
                                 // inverted gathers too instead of streaming them (tc.hip), the other kernels ignore them
+    // STREAM ROWS (heavy-pivot triangle kernel): the hub part of every row once more, in the form that is cheapest to stream,
+    // every row a whole number of 16-byte units (padded with neutral fillers, so the scanners need no tail handling) at a 16-byte
+    // aligned offset of ONE pool; srow[v] packs (offset / 16) << 24 | form << 22 | units into 8 bytes = one load per row fetch.
+    //   form 0  16-bit list      8 ids per unit, filler 0xFFFF (never in a pivot bitmap)
+    //   form 1  bitset           128 ids per unit over [0, v), filler 0 (hub rows only, when smaller than the list)
+    //   form 2  byte-delta       unit = 16-bit base id + count byte + 13 gap bytes; a gap above 255 ends the unit early.
+    //                            14 ids per unit when gaps < 256: 1.14 B/id against 2 B/id
+    unsigned long long *srow = nullptr;  // [n]
+    uint32_t *spool = nullptr;           // 16-byte units
+    int64_t spool_units = 0;
     int32_t *tsplit = nullptr;  // int32[n]: position in the tail row of the first target >= bitset_limit (= tail length if none)
     int64_t dense_rows = 0, bmpool_words = 0;
     bool rows_sorted = false;   // both containers of every row ascending (always, below 2^32 entries)
@@ -71,7 +81,9 @@ namespace gmsx {
 
 static constexpr int kHub = 65535;         // rank ids below this live in the 16-bit hub containers
 static constexpr int kBitmapWords = 2048;  // 65536-bit LDS bitmap over the hub id range
-static constexpr int kAccWords = 64 * 16 + 16;  // size of gmsx_graph::acc in u64
+static constexpr int kAccWords = 64 * 16 + 16;
+static constexpr int kFormList = 0, kFormBitset = 1, kFormDelta = 2;
+static constexpr int kDeltaIds = 14;  // ids per full 16-byte delta unit  // size of gmsx_graph::acc in u64
 
 // words of the bitset container of hub rank id v (covers ids [0, v)), rounded to 16 bytes
 __host__ __device__ inline int64_t bitset_words(int32_t v) { return ((int64_t(v) + 31) / 32 + 3) & ~int64_t(3); }

@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace gmsx {
 
@@ -114,6 +115,89 @@ __device__ __forceinline__ void hub_row_extent(int32_t v, const int64_t *__restr
             rl = -nw;
         }
     }
+}
+
+// ---- stream rows (device_graph.hpp): whole 16-byte units at 16-byte aligned offsets, three forms, no tail handling -------------
+// one unit of the byte-delta form: 16-bit base id, count byte (1 … 14 ids), 13 gap bytes.  All fourteen running ids first (a chain
+// of byte adds), THEN the fourteen LDS probes back to back — written the other way round the compiler waits for every probe before
+// it issues the next — and the count cuts the unused slots off.  A running id never exceeds 65535 + 13*255: the probe of an unused
+// slot may read past the 8 KB bitmap into the workgroup's next LDS array, which is harmless (its bit is masked out).
+__device__ __forceinline__ uint32_t delta_unit_hits(const uint32_t *bm, uint4 p) {
+    uint32_t id[14];
+    id[0] = p.x & 0xffffu;
+    id[1] = id[0] + (p.x >> 24);
+    id[2] = id[1] + (p.y & 0xffu);
+    id[3] = id[2] + ((p.y >> 8) & 0xffu);
+    id[4] = id[3] + ((p.y >> 16) & 0xffu);
+    id[5] = id[4] + (p.y >> 24);
+    id[6] = id[5] + (p.z & 0xffu);
+    id[7] = id[6] + ((p.z >> 8) & 0xffu);
+    id[8] = id[7] + ((p.z >> 16) & 0xffu);
+    id[9] = id[8] + (p.z >> 24);
+    id[10] = id[9] + (p.w & 0xffu);
+    id[11] = id[10] + ((p.w >> 8) & 0xffu);
+    id[12] = id[11] + ((p.w >> 16) & 0xffu);
+    id[13] = id[12] + (p.w >> 24);
+    uint32_t w[14];
+#pragma unroll
+    for (int k = 0; k < 14; ++k) w[k] = bm[id[k] >> 5];
+    uint32_t hits = 0;
+#pragma unroll
+    for (int k = 0; k < 14; ++k) hits |= __builtin_amdgcn_ubfe(w[k], id[k], 1u) << k;
+    const uint32_t n = (p.x >> 16) & 0xffu;
+    return uint32_t(__popc(hits & ((1u << n) - 1u)));
+}
+
+// Streams `rows` stream rows against the LDS bitmap.  Lane l holds the packed descriptor of row l (srow[v]; 0 = no row).
+// Same shape as scan_hub_rows: four 16-lane groups, each on its own row, one 16-byte unit per lane per step, two steps in flight.
+__device__ __forceinline__ uint32_t scan_srows(const uint32_t *bm, const uint32_t *__restrict__ spool, unsigned long long desc, int rows, int lane) {
+    const int grp = lane >> 4, sub = lane & 15;
+    uint32_t cnt = 0;
+    for (int r0 = 0; r0 < rows; r0 += 4) {
+        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
+        const uint32_t lo0 = __builtin_amdgcn_readlane(uint32_t(desc), m0), lo1 = __builtin_amdgcn_readlane(uint32_t(desc), m1),
+                       lo2 = __builtin_amdgcn_readlane(uint32_t(desc), m2), lo3 = __builtin_amdgcn_readlane(uint32_t(desc), m3);
+        if (((lo0 | lo1 | lo2 | lo3) & 0x3fffffu) == 0) continue;  // wave-uniform: four empty rows
+        const uint32_t hi0 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m0), hi1 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m1),
+                       hi2 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m2), hi3 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m3);
+        const uint32_t lo = grp == 0 ? lo0 : grp == 1 ? lo1 : grp == 2 ? lo2 : lo3;
+        const uint32_t hi = grp == 0 ? hi0 : grp == 1 ? hi1 : grp == 2 ? hi2 : hi3;
+        const int units = int(lo & 0x3fffffu), form = int((lo >> 22) & 3u);
+        const uint4 *row = reinterpret_cast<const uint4 *>(spool) + ((uint64_t(hi) << 8) | (lo >> 24));
+        if (form == kFormBitset) {  // AND the bitset with the pivot bitmap, 128 ids per unit
+            for (int j = sub; j < units; j += 32) {
+                const uint4 p = row[j];
+                const uint4 q = *reinterpret_cast<const uint4 *>(bm + 4 * j);
+                uint32_t c = uint32_t(__popc(p.x & q.x) + __popc(p.y & q.y) + __popc(p.z & q.z) + __popc(p.w & q.w));
+                if (j + 16 < units) {
+                    const uint4 p2 = row[j + 16];
+                    const uint4 q2 = *reinterpret_cast<const uint4 *>(bm + 4 * (j + 16));
+                    c += uint32_t(__popc(p2.x & q2.x) + __popc(p2.y & q2.y) + __popc(p2.z & q2.z) + __popc(p2.w & q2.w));
+                }
+                cnt += c;
+            }
+        } else if (form == kFormDelta) {
+            int j = sub;
+            for (; j + 16 < units; j += 32) {
+                const uint4 p = row[j], q = row[j + 16];
+                cnt += delta_unit_hits(bm, p);
+                cnt += delta_unit_hits(bm, q);
+            }
+            if (j < units) cnt += delta_unit_hits(bm, row[j]);
+        } else {  // 16-bit list, 8 ids per unit, filler 0xFFFF
+            int j = sub;
+            for (; j + 16 < units; j += 32) {
+                const uint4 p = row[j], q = row[j + 16];
+                cnt += hub_hits8(bm, u4u{p.x, p.y, p.z, p.w});
+                cnt += hub_hits8(bm, u4u{q.x, q.y, q.z, q.w});
+            }
+            if (j < units) {
+                const uint4 p = row[j];
+                cnt += hub_hits8(bm, u4u{p.x, p.y, p.z, p.w});
+            }
+        }
+    }
+    return cnt;
 }
 
 // ---- tail side: open-addressing hash set in LDS (keys are rank ids >= kHub; -1 = empty) ------------------------
@@ -225,8 +309,8 @@ __device__ __forceinline__ uint32_t scan_tail_rows_bucket(const int32_t *tbl, co
 // ---------------------------------------------------------------------------------------------
 static constexpr int kBlockLog = 11;
 
-__global__ __launch_bounds__(256) void k_tc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                  const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool, int32_t dense_limit,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                  const unsigned long long *__restrict__ srow, const uint32_t *__restrict__ spool,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
                                                   int part, unsigned long long *__restrict__ acc) {
@@ -251,30 +335,25 @@ __global__ __launch_bounds__(256) void k_tc_block(const int64_t *__restrict__ ho
     __syncthreads();
 
     unsigned long long cnt = 0;
-    // (a) rows of the hub part of the pivot list: pure hub containers (a hub vertex has no tail container)
+    // (a) rows of the hub part of the pivot list: pure hub containers (a hub vertex has no tail container), each in its stream
+    //     form — bitset, 16-bit list or byte-delta — described by ONE 8-byte srow entry
     for (int base = 0; base < hl; base += 256) {
         const int idx = base + lane * 4 + wave;
-        int64_t rb = 0;
-        int rl = 0;
+        unsigned long long desc = 0;
         if (idx < hl) {
             const uint32_t v = hadj[hb + idx];
-            if (v != 0xFFFFu) hub_row_extent(int32_t(v), hoff, bmoff, dense_limit, rb, rl);
+            if (v != 0xFFFFu) desc = srow[v];
         }
         const int rows = min(64, (hl - base - wave + 3) >> 2);
-        cnt += scan_hub_rows(bm, hadj, bmpool, rb, rl, rows, lane);
+        cnt += scan_srows(bm, spool, desc, rows, lane);
     }
     // (b) rows of the tail part of the pivot list: their hub containers against the bitmap …
     for (int base = 0; base < tl; base += 256) {
         const int idx = base + lane * 4 + wave;
-        int64_t rb = 0;
-        int rl = 0;
-        if (idx < tl) {
-            const int32_t v = tadj[tb + idx];
-            rb = hoff[v];
-            rl = int(hoff[v + 1] - rb);
-        }
+        unsigned long long desc = 0;
+        if (idx < tl) desc = srow[tadj[tb + idx]];
         const int rows = min(64, (tl - base - wave + 3) >> 2);
-        cnt += scan_hub_rows(bm, hadj, bmpool, rb, rl, rows, lane);
+        cnt += scan_srows(bm, spool, desc, rows, lane);
     }
     // (c) … and their tail containers against the hash set of the pivot's tail part
     for (int t0 = 0; t0 < tl; t0 += TILE) {
@@ -568,15 +647,15 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
 // units / probes / algorithmic stream bytes of a partition (untimed bookkeeping for gmsx_stats): wave per pivot position.
 // out[2] follows what the three count kernels read, byte for byte, assuming no on-chip reuse:
 //   pivot u (d+ >= 2): its own hub + tail containers once;
-//   heavy pivot (d+ >= 64, k_tc_block): every hub member's row in the form hub_row_extent() picks (bitset words or 16-bit list),
-//       every tail member's 16-bit list and (except the first) its 32-bit list;
+//   heavy pivot (d+ >= 64, k_tc_block): the stream row (whole 16-byte units of the cheapest of bitset / 16-bit list / byte-delta) of
+//       every member, and (except for the first tail member) the 32-bit tail list of every tail member;
 //   light pivot (k_tc_wave_hub + k_tc_wave): one 4-byte word gathered per (member with a bitset, smaller member) pair; members beyond
 //       bitset_limit streamed as above.
 __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
-                                                  int32_t dense_limit, int32_t bitset_limit, int64_t first, int64_t end, int nparts, int part,
-                                                  unsigned long long *__restrict__ out) {
+                                                  const unsigned long long *__restrict__ srow, int32_t bitset_limit, int64_t first, int64_t end,
+                                                  int nparts, int part, unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -598,9 +677,7 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
             probes += (unsigned long long)dplus[v];
             if (!work) continue;
             if (heavy) {
-                const unsigned long long list = 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
-                const unsigned long long bits = 4ull * (unsigned long long)bitset_words(int32_t(v));
-                bytes += (int32_t(v) < dense_limit && bits + 32 < list) ? bits : list;
+                bytes += 16ull * (srow[v] & 0x3fffffull);  // the stream row: whole 16-byte units in its chosen form
             } else if (int32_t(v) < bitset_limit) {
                 bytes += 4ull * (unsigned long long)(j - hoff[u]);  // one gathered word per member below v
             }
@@ -613,7 +690,7 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
                 bytes += 4ull * (unsigned long long)(du - tl + (j - toff[u]));
                 continue;
             }
-            bytes += 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
+            bytes += heavy ? 16ull * (srow[v] & 0x3fffffull) : 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
             if (j > toff[u]) bytes += 4ull * (unsigned long long)(toff[v + 1] - toff[v]);
         }
     }
@@ -626,6 +703,73 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
         if (units) atomicAdd(&out[0], units);
         if (probes) atomicAdd(&out[1], probes);
         if (bytes) atomicAdd(&out[2], bytes);
+    }
+}
+
+// Diagnostics (gmsx_tc_stream_breakdown): algorithmic stream bytes of one pass by category, plus what the 16-bit list rows
+// would cost in the byte-delta form of the stream rows (16-byte units: 16-bit base + count + 13 one-byte gaps; estimate).
+//   out[0] heavy pivots: bitset-form hub rows      out[1] heavy: list-form hub rows        out[2] heavy: hub parts of tail-member rows
+//   out[3] heavy: tail parts of tail-member rows   out[4] light: gathered words            out[5] light: hub parts of streamed rows
+//   out[6] light: tail parts of streamed rows      out[7] pivot containers
+//   out[8] = out[1] with min(list, delta) per row  out[9] = out[2] likewise                out[10] = out[5] likewise
+//   out[11] row fetches (heavy)                    out[12] row fetches (light, streamed)
+__global__ __launch_bounds__(256) void k_row_delta_bytes(int64_t n, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                         uint32_t *__restrict__ dbytes) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t v = wave0; v < n; v += nwaves) {
+        const int64_t b = hoff[v], e = hoff[v + 1];
+        unsigned slots = 0;
+        for (int64_t j = b + lane; j < e; j += 64) {
+            const uint32_t id = hadj[j];
+            if (id == 0xFFFFu) continue;
+            const uint32_t prev = j > b ? hadj[j - 1] : id;
+            slots += 1u + ((id - prev) > 255u ? 7u : 0u);  // a gap above a byte ends a unit: on average half a unit is lost (approximation)
+        }
+        for (int s = 32; s > 0; s >>= 1) slots += __shfl_down(slots, s);
+        if (lane == 0) dbytes[v] = ((slots + 13u) / 14u) * 16u;
+    }
+}
+__global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                      const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                      const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
+                                                      const uint32_t *__restrict__ dbytes, int32_t dense_limit, int32_t bitset_limit, int64_t end,
+                                                      unsigned long long *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    unsigned long long c[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t pos = wave0; pos < end; pos += nwaves) {
+        const int32_t u = order[pos];
+        const int du = dplus[u];
+        if (du < 2) continue;
+        const bool heavy = du >= 64;
+        const int hl = int(hoff[u + 1] - hoff[u]), tl = int(toff[u + 1] - toff[u]);
+        if (lane == 0) c[7] += 2ull * hl + 4ull * tl;
+        for (int64_t j = hoff[u] + lane; j < hoff[u + 1]; j += 64) {
+            const uint32_t v = hadj[j];
+            if (v == 0xFFFFu) continue;
+            const unsigned long long list = 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]), bits = 4ull * (unsigned long long)bitset_words(int32_t(v));
+            if (heavy) {
+                c[11]++;
+                if (int32_t(v) < dense_limit && bits + 32 < list) c[0] += bits;
+                else { c[1] += list; c[8] += min(list, (unsigned long long)dbytes[v]); }
+            } else c[4] += 4ull * (unsigned long long)(j - hoff[u]);
+        }
+        for (int64_t j = toff[u] + lane; j < toff[u + 1]; j += 64) {
+            const int32_t v = tadj[j];
+            const unsigned long long list = 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
+            const unsigned long long tail = j > toff[u] ? 4ull * (unsigned long long)(toff[v + 1] - toff[v]) : 0ull;
+            if (heavy) { c[11]++; c[2] += list; c[9] += min(list, (unsigned long long)dbytes[v]); c[3] += tail; }
+            else if (v < bitset_limit) c[4] += 4ull * (unsigned long long)(du - tl + (j - toff[u]));
+            else { c[12]++; c[5] += list; c[10] += min(list, (unsigned long long)dbytes[v]); c[6] += tail; }
+        }
+    }
+    for (int k = 0; k < 13; ++k) {
+        unsigned long long x = c[k];
+        for (int s = 32; s > 0; s >>= 1) x += __shfl_down(x, s);
+        if (lane == 0 && x) atomicAdd(&out[k], x);
     }
 }
 
@@ -683,7 +827,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     };
     if (co) launch_light();
     if (cnt_heavy > 0) {
-        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt_heavy)), dim3(256), 0, s, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit, g->toff, g->tadj,
+        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt_heavy)), dim3(256), 0, s, g->hoff, g->hadj, g->srow, g->spool, g->toff, g->tadj,
                            g->order, int64_t(0), n_block, nparts, part, acc);
         ++launches;
     }
@@ -703,7 +847,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
             hipLaunchKernelGGL(k_tc_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus,
-                               g->order, g->dense_limit, g->bitset_limit, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
+                               g->order, g->srow, g->bitset_limit, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
         }
     }
     unsigned long long host[kAccSlots * kAccStride + 3];
@@ -742,6 +886,29 @@ using namespace gmsx;
 extern "C" {
 
 int gmsx_tc_divisor(int algo) { return algo == GMSX_TC_FULL ? 3 : 1; }
+
+int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out13) {
+    if (!g || !out13) return GMSX_ERR_INVALID;
+    if (int rc = ensure_init()) return rc;
+    hipStream_t s = ctx().stream;
+    std::memset(out13, 0, 13 * sizeof(uint64_t));
+    if (g->n == 0) return GMSX_OK;
+    uint32_t *dbytes = nullptr;
+    unsigned long long *acc = nullptr;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dbytes), size_t(g->n) * 4));
+    struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g1{dbytes};
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), 13 * 8));
+    Guard g2{acc};
+    GMSX_HIP(hipMemsetAsync(acc, 0, 13 * 8, s));
+    const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
+    hipLaunchKernelGGL(k_row_delta_bytes, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->n, g->hoff, g->hadj, dbytes);
+    hipLaunchKernelGGL(k_tc_breakdown, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, dbytes,
+                       g->dense_limit, g->bitset_limit, g->n, acc);
+    GMSX_HIP(hipMemcpyAsync(out13, acc, 13 * 8, hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipStreamSynchronize(s));
+    GMSX_HIP(hipGetLastError());
+    return GMSX_OK;
+}
 
 int gmsx_tc_partial(const gmsx_graph *g, int algo, int part, int nparts, uint64_t *partial, gmsx_stats *stats) {
     if (!g || !partial || nparts < 1 || part < 0 || part >= nparts) return GMSX_ERR_INVALID;

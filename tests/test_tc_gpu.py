@@ -191,3 +191,34 @@ def test_near_tail_bitsets(gpu, oracle, hub_limit, bitset_limit):
             os.environ.pop("GMSX_BITSET_LIMIT", None)
         else:
             os.environ["GMSX_BITSET_LIMIT"] = old
+
+
+@pytest.mark.parametrize("delta", ["0", "1", "2"])
+def test_stream_row_forms(gpu, oracle, delta):
+    """The heavy-pivot kernel reads every member's hub part as a 'stream row' in the cheapest of three forms (16-bit list, bitset,
+    byte-delta with 255-escapes).  GMSX_TC_DELTA = 0 / 1 / 2 = never / when smaller / wherever possible: same counts, on graphs
+    whose rows have small gaps (dense block), huge gaps (sparse uniform: escapes and one-id units) and both (RMAT)."""
+    old = os.environ.get("GMSX_TC_DELTA")
+    os.environ["GMSX_TC_DELTA"] = delta
+    try:
+        for kind, scale, deg in (("kronecker", 14, 16), ("uniform", 13, 150), ("kronecker", 12, 64)):
+            csr = host_graph(gpu, kind, scale, deg, True)
+            want = oracle.tc_total(csr.offsets(), csr.neighbors())
+            for hub_limit in (0, 2000):
+                g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_DEFAULT | (hub_limit << 8))
+                assert g.tc_total() == want, (kind, scale, hub_limit)
+                assert sum(g.tc_partial(p, 3) for p in range(3)) == want
+                g.free()
+        k = 1500  # a dense random block: d+ up to ~500, gaps of 2-3 -> full delta units
+        rng = np.random.default_rng(9)
+        iu = np.triu_indices(k, 1)
+        sel = rng.random(iu[0].size) < 0.4
+        csr = gpu.HostCSR.from_edges(iu[0][sel].astype(np.int32), iu[1][sel].astype(np.int32))
+        g = gpu.DeviceGraph.from_csr(csr)
+        assert g.tc_total() == oracle.tc_total(csr.offsets(), csr.neighbors())
+        g.free()
+    finally:
+        if old is None:
+            os.environ.pop("GMSX_TC_DELTA", None)
+        else:
+            os.environ["GMSX_TC_DELTA"] = old
