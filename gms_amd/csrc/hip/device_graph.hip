@@ -178,10 +178,11 @@ __device__ inline uint32_t delta_encode(const uint16_t *__restrict__ row, int le
 }
 // delta_mode: 0 = never, 1 = when it is at least 15 % smaller than the list, 2 = whenever possible (test hook)
 __global__ void k_srow_sizes(int64_t n, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, int32_t dense_limit, int delta_mode,
-                             int delta_pct, int64_t *__restrict__ units_out, unsigned char *__restrict__ form_out) {
+                             int delta_pct, int64_t *__restrict__ units_out, int64_t *__restrict__ small_out, uint32_t *__restrict__ real_out,
+                             unsigned char *__restrict__ form_out) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v > n) return;
-    if (v == n) { units_out[n] = 0; return; }
+    if (v == n) { units_out[n] = 0; small_out[n] = 0; return; }
     const int64_t b = hoff[v];
     const int len = int(hoff[v + 1] - b);
     uint32_t best = uint32_t((len + 7) / 8);  // list: 8 ids per unit
@@ -194,15 +195,22 @@ __global__ void k_srow_sizes(int64_t n, const int64_t *__restrict__ hoff, const 
         const uint32_t d = delta_encode(hadj + b, len, nullptr);
         if (delta_mode == 2 || d * 100u <= best * uint32_t(delta_pct)) { best = d; form = kFormDelta; }
     }
-    units_out[v] = int64_t(best);
+    // rows of 8 units (128 bytes) or more start on 128-byte boundaries of their own region of the pool: a row fetch then touches
+    // ceil(L/128) lines instead of L/128 + 1 (≈5 % of the heavy-pivot traffic); the small rows are packed behind them
+    const bool big = best >= 8u;
+    units_out[v] = big ? int64_t((best + 7u) & ~7u) : 0;
+    small_out[v] = big ? 0 : int64_t(best);
+    real_out[v] = best;
     form_out[v] = (unsigned char)form;
 }
 __global__ void k_srow_fill(int64_t n, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, const int64_t *__restrict__ bmoff,
-                            const uint32_t *__restrict__ bmpool, const int64_t *__restrict__ uoff, const unsigned char *__restrict__ form,
-                            unsigned long long *__restrict__ srow, uint32_t *__restrict__ spool) {
+                            const uint32_t *__restrict__ bmpool, const int64_t *__restrict__ uoff, const int64_t *__restrict__ soff,
+                            const uint32_t *__restrict__ real, const unsigned char *__restrict__ form, unsigned long long *__restrict__ srow,
+                            uint32_t *__restrict__ spool) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v >= n) return;
-    const int64_t u0 = uoff[v], units = uoff[v + 1] - u0;
+    const int64_t units = int64_t(real[v]);
+    const int64_t u0 = units >= 8 ? uoff[v] : uoff[n] + soff[v];  // big rows: 128-byte aligned region first; small rows behind it
     srow[v] = ((unsigned long long)u0 << 24) | ((unsigned long long)form[v] << 22) | (unsigned long long)units;
     if (units == 0) return;
     uint32_t *dst = spool + u0 * 4;
@@ -220,6 +228,25 @@ __global__ void k_srow_fill(int64_t n, const int64_t *__restrict__ hoff, const u
             dst[w] = lo | (hi << 16);
         }
     }
+}
+
+// ---- stream rows of the tail parts: 32-bit ids in whole 16-byte units (a 16-bit delta form was built and measured: 66 GB fewer
+//      bytes at scale 26 but +3 ms — the tail phase is bound by its set probes, not by bytes — and removed) ------------------------
+__global__ void k_trow_sizes(int64_t n, const int64_t *__restrict__ toff, int64_t *__restrict__ units_out) {
+    const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (v > n) return;
+    units_out[v] = v == n ? 0 : (toff[v + 1] - toff[v] + 3) / 4;  // 4 ids per unit
+}
+__global__ void k_trow_fill(int64_t n, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, const int64_t *__restrict__ uoff,
+                            unsigned long long *__restrict__ trow, uint32_t *__restrict__ tpool) {
+    const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const int64_t u0 = uoff[v], units = uoff[v + 1] - u0;
+    trow[v] = ((unsigned long long)u0 << 24) | (unsigned long long)units;
+    uint32_t *dst = tpool + u0 * 4;
+    const int64_t b = toff[v];
+    const int64_t len = toff[v + 1] - b;
+    for (int64_t w = 0; w < units * 4; ++w) dst[w] = w < len ? uint32_t(tadj[b + w]) : 0xfffffffeu;
 }
 
 // ---- bitset containers of dense hub rows -------------------------------------------------------------------
@@ -321,6 +348,8 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->tsplit);
     (void)hipFree(g->srow);
     (void)hipFree(g->spool);
+    (void)hipFree(g->trow);
+    (void)hipFree(g->tpool);
     (void)hipFree(g->dplus);
     (void)hipFree(g->order);
     (void)hipFree(g->sorted_dplus);
@@ -496,23 +525,53 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
             const int v = std::atoi(e);
             if (v >= 10 && v <= 100) delta_pct = v;
         }
-        int64_t *units = nullptr, *uoff = nullptr;
+        int64_t *units = nullptr, *uoff = nullptr, *small = nullptr, *soff = nullptr;
+        uint32_t *real = nullptr;
         unsigned char *form = nullptr;
         if (int rc = dmalloc(&units, n + 1, nullptr)) return rc;
         DevGuard g_u{units};
         if (int rc = dmalloc(&uoff, n + 1, nullptr)) return rc;
         DevGuard g_o{uoff};
+        if (int rc = dmalloc(&small, n + 1, nullptr)) return rc;
+        DevGuard g_s{small};
+        if (int rc = dmalloc(&soff, n + 1, nullptr)) return rc;
+        DevGuard g_so{soff};
+        if (int rc = dmalloc(&real, n + 1, nullptr)) return rc;
+        DevGuard g_r{real};
         if (int rc = dmalloc(&form, n + 1, nullptr)) return rc;
         DevGuard g_f{form};
-        hipLaunchKernelGGL(k_srow_sizes, dim3(unsigned(n / 256 + 1)), dim3(256), 0, s, n, g->hoff, g->hadj, g->dense_limit, delta_mode, delta_pct, units, form);
+        hipLaunchKernelGGL(k_srow_sizes, dim3(unsigned(n / 256 + 1)), dim3(256), 0, s, n, g->hoff, g->hadj, g->dense_limit, delta_mode, delta_pct, units, small,
+                           real, form);
         if (int rc = exclusive_scan_i64(units, uoff, n + 1, s)) return rc;
-        GMSX_HIP(hipMemcpy(&g->spool_units, uoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (int rc = exclusive_scan_i64(small, soff, n + 1, s)) return rc;
+        int64_t big_units = 0, small_units = 0;
+        GMSX_HIP(hipMemcpy(&big_units, uoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        GMSX_HIP(hipMemcpy(&small_units, soff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        g->spool_units = big_units + small_units;
         if (g->spool_units >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;  // 40 offset bits in a srow entry (16 TB)
         if (int rc = dmalloc(&g->srow, n, g)) return rc;
         if (int rc = dmalloc(&g->spool, g->spool_units * 4 + 4, g)) return rc;
+        GMSX_HIP(hipMemsetAsync(g->spool, 0, size_t(g->spool_units * 4 + 4) * sizeof(uint32_t), s));  // the alignment gaps are never read, but keep them defined
         if (n > 0)
-            hipLaunchKernelGGL(k_srow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->hoff, g->hadj, g->bmoff, g->bmpool, uoff, form, g->srow,
-                               g->spool);
+            hipLaunchKernelGGL(k_srow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->hoff, g->hadj, g->bmoff, g->bmpool, uoff, soff, real, form,
+                               g->srow, g->spool);
+        GMSX_HIP(hipStreamSynchronize(s));
+    }
+    // 4e. … and of the tail parts
+    {
+        int64_t *units = nullptr, *uoff = nullptr;
+        if (int rc = dmalloc(&units, n + 1, nullptr)) return rc;
+        DevGuard g_u{units};
+        if (int rc = dmalloc(&uoff, n + 1, nullptr)) return rc;
+        DevGuard g_o{uoff};
+        hipLaunchKernelGGL(k_trow_sizes, dim3(unsigned(n / 256 + 1)), dim3(256), 0, s, n, g->toff, units);
+        if (int rc = exclusive_scan_i64(units, uoff, n + 1, s)) return rc;
+        GMSX_HIP(hipMemcpy(&g->tpool_units, uoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (g->tpool_units >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;
+        if (int rc = dmalloc(&g->trow, n, g)) return rc;
+        if (int rc = dmalloc(&g->tpool, g->tpool_units * 4 + 4, g)) return rc;
+        if (n > 0)
+            hipLaunchKernelGGL(k_trow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->toff, g->tadj, uoff, g->trow, g->tpool);
         GMSX_HIP(hipStreamSynchronize(s));
     }
 

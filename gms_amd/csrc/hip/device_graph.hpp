@@ -56,6 +56,10 @@ struct gmsx_graph {
     unsigned long long *srow = nullptr;  // [n]
     uint32_t *spool = nullptr;           // 16-byte units
     int64_t spool_units = 0;
+    // … and the TAIL part of every row as 32-bit ids in whole 16-byte units (filler -2, never a key of a pivot's tail set):
+    unsigned long long *trow = nullptr;
+    uint32_t *tpool = nullptr;
+    int64_t tpool_units = 0;
     int32_t *tsplit = nullptr;  // int32[n]: position in the tail row of the first target >= bitset_limit (= tail length if none)
     int64_t dense_rows = 0, bmpool_words = 0;
     bool rows_sorted = false;   // both containers of every row ascending (always, below 2^32 entries)

@@ -258,6 +258,49 @@ __device__ __forceinline__ uint32_t scan_tail_rows(const int32_t *tbl, uint32_t 
     return cnt;
 }
 
+// Tail stream rows (trow / tpool: 32-bit ids, 4 per 16-byte unit, filler -2) against the pivot's tail set; same shape as scan_srows.
+// Almost every streamed tail id is a miss (scale 24: 0.7 M of 10.3 G triangles close through a tail id), so the set is fronted by a
+// FILTER: a 32768-bit bitmap of (id & 0x7fff).  One LDS word read + bit test answers "no" for all but tl/32768 of the ids; only
+// the lanes with a positive walk the open-addressing table (whose divergent probe loops were 47 of k_tc_block's 165 ms at scale 26).
+static constexpr int kFilterWords = 1024;
+__device__ __forceinline__ uint32_t flt_bit(const uint32_t *flt, uint32_t id) { return __builtin_amdgcn_ubfe(flt[(id >> 5) & (kFilterWords - 1)], id, 1u); }
+__device__ __forceinline__ uint32_t tail_unit_hits(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, uint4 p) {
+    const uint32_t m = flt_bit(flt, p.x) | (flt_bit(flt, p.y) << 1) | (flt_bit(flt, p.z) << 2) | (flt_bit(flt, p.w) << 3);
+    uint32_t c = 0;
+    if (m) {  // rare: exact membership for the ids the filter let through (the filler -2 may pass the filter, it is never a key)
+        if (m & 1u) c += set_contains(tbl, mask, shift, int32_t(p.x));
+        if (m & 2u) c += set_contains(tbl, mask, shift, int32_t(p.y));
+        if (m & 4u) c += set_contains(tbl, mask, shift, int32_t(p.z));
+        if (m & 8u) c += set_contains(tbl, mask, shift, int32_t(p.w));
+    }
+    return c;
+}
+__device__ __forceinline__ uint32_t scan_trows(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, const uint32_t *__restrict__ tpool,
+                                               unsigned long long desc, int rows, int lane) {
+    const int grp = lane >> 4, sub = lane & 15;
+    uint32_t cnt = 0;
+    for (int r0 = 0; r0 < rows; r0 += 4) {
+        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
+        const uint32_t lo0 = __builtin_amdgcn_readlane(uint32_t(desc), m0), lo1 = __builtin_amdgcn_readlane(uint32_t(desc), m1),
+                       lo2 = __builtin_amdgcn_readlane(uint32_t(desc), m2), lo3 = __builtin_amdgcn_readlane(uint32_t(desc), m3);
+        if (((lo0 | lo1 | lo2 | lo3) & 0x3fffffu) == 0) continue;  // wave-uniform
+        const uint32_t hi0 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m0), hi1 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m1),
+                       hi2 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m2), hi3 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m3);
+        const uint32_t lo = grp == 0 ? lo0 : grp == 1 ? lo1 : grp == 2 ? lo2 : lo3;
+        const uint32_t hi = grp == 0 ? hi0 : grp == 1 ? hi1 : grp == 2 ? hi2 : hi3;
+        const int units = int(lo & 0x3fffffu);
+        const uint4 *row = reinterpret_cast<const uint4 *>(tpool) + ((uint64_t(hi) << 8) | (lo >> 24));
+        int j = sub;
+        for (; j + 16 < units; j += 32) {
+            const uint4 p = row[j], q = row[j + 16];
+            cnt += tail_unit_hits(flt, tbl, mask, shift, p);
+            cnt += tail_unit_hits(flt, tbl, mask, shift, q);
+        }
+        if (j < units) cnt += tail_unit_hits(flt, tbl, mask, shift, row[j]);
+    }
+    return cnt;
+}
+
 // Bucketed tail set for the light-pivot kernel (<= 63 keys): 64 buckets x 4 slots, 16-byte aligned, so a probe is ONE
 // ds_read_b128 and four compares -- no probe loop, no divergence, and the four probes of a 16-byte load are
 // independent.  A pivot whose keys overflow a bucket (five keys with the same hash) falls back to the open-addressing
@@ -304,18 +347,20 @@ __device__ __forceinline__ uint32_t scan_tail_rows_bucket(const int32_t *tbl, co
 
 // ---------------------------------------------------------------------------------------------
 // Workgroup per pivot (d+ >= 64).  256 threads = 4 waves share the pivot's bitmap + tail set; wave w streams the
-// rows of the pivot-list entries w, w+4, ….  LDS: 8 KB bitmap + 2^kBlockLog x 4 B hash; a tail longer than half the
-// table is processed in tiles.
+// rows of the pivot-list entries w, w+4, ….  LDS: 8 KB hub bitmap + 4 KB tail filter + 2^kBlockLog x 4 B hash; a tail longer
+// than half the table is processed in tiles.
 // ---------------------------------------------------------------------------------------------
-static constexpr int kBlockLog = 11;
+static constexpr int kBlockLog = 10;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const unsigned long long *__restrict__ srow, const uint32_t *__restrict__ spool,
+                                                  const unsigned long long *__restrict__ trow, const uint32_t *__restrict__ tpool,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
                                                   int part, unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords];
     __shared__ __attribute__((aligned(16))) int32_t tbl[1 << kBlockLog];
+    __shared__ uint32_t flt[kFilterWords];
     __shared__ unsigned long long red[4];
     constexpr int SIZE = 1 << kBlockLog, SHIFT = 32 - kBlockLog, TILE = SIZE / 2;
     constexpr uint32_t MASK = SIZE - 1;
@@ -360,20 +405,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         const int tn = min(TILE, tl - t0);
         __syncthreads();
         for (int i = tid; i < SIZE; i += 256) tbl[i] = -1;
+        for (int i = tid; i < kFilterWords; i += 256) flt[i] = 0;
         __syncthreads();
-        for (int i = tid; i < tn; i += 256) set_insert(tbl, MASK, SHIFT, tadj[tb + t0 + i]);
+        for (int i = tid; i < tn; i += 256) {
+            const int32_t t = tadj[tb + t0 + i];
+            set_insert(tbl, MASK, SHIFT, t);
+            atomicOr(&flt[(uint32_t(t) >> 5) & (kFilterWords - 1)], 1u << (uint32_t(t) & 31u));
+        }
         __syncthreads();
         for (int base = 0; base < tl; base += 256) {
             const int idx = base + lane * 4 + wave;
-            int64_t rb = 0;
-            int rl = 0;
-            if (idx > 0 && idx < tl) {  // idx 0: the first tail member's tail ids lie below every tail id of the pivot
-                const int32_t v = tadj[tb + idx];
-                rb = toff[v];
-                rl = int(toff[v + 1] - rb);
-            }
+            unsigned long long desc = 0;
+            if (idx > 0 && idx < tl) desc = trow[tadj[tb + idx]];  // idx 0: the first tail member's tail ids lie below every tail id of the pivot
             const int rows = min(64, (tl - base - wave + 3) >> 2);
-            cnt += scan_tail_rows(tbl, MASK, SHIFT, tadj, rb, rl, rows, lane);
+            cnt += scan_trows(flt, tbl, MASK, SHIFT, tpool, desc, rows, lane);
         }
     }
     for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
@@ -654,8 +699,9 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
 __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
-                                                  const unsigned long long *__restrict__ srow, int32_t bitset_limit, int64_t first, int64_t end,
-                                                  int nparts, int part, unsigned long long *__restrict__ out) {
+                                                  const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
+                                                  int32_t bitset_limit, int64_t first, int64_t end, int nparts, int part,
+                                                  unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -691,7 +737,7 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
                 continue;
             }
             bytes += heavy ? 16ull * (srow[v] & 0x3fffffull) : 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
-            if (j > toff[u]) bytes += 4ull * (unsigned long long)(toff[v + 1] - toff[v]);
+            if (j > toff[u]) bytes += heavy ? 16ull * (trow[v] & 0x3fffffull) : 4ull * (unsigned long long)(toff[v + 1] - toff[v]);
         }
     }
     for (int s = 32; s > 0; s >>= 1) {
@@ -827,7 +873,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     };
     if (co) launch_light();
     if (cnt_heavy > 0) {
-        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt_heavy)), dim3(256), 0, s, g->hoff, g->hadj, g->srow, g->spool, g->toff, g->tadj,
+        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt_heavy)), dim3(256), 0, s, g->hoff, g->hadj, g->srow, g->spool, g->trow, g->tpool, g->toff, g->tadj,
                            g->order, int64_t(0), n_block, nparts, part, acc);
         ++launches;
     }
@@ -847,7 +893,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
             hipLaunchKernelGGL(k_tc_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus,
-                               g->order, g->srow, g->bitset_limit, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
+                               g->order, g->srow, g->trow, g->bitset_limit, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
         }
     }
     unsigned long long host[kAccSlots * kAccStride + 3];

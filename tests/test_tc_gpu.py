@@ -199,12 +199,14 @@ def test_stream_row_forms(gpu, oracle, delta):
     byte-delta with 255-escapes).  GMSX_TC_DELTA = 0 / 1 / 2 = never / when smaller / wherever possible: same counts, on graphs
     whose rows have small gaps (dense block), huge gaps (sparse uniform: escapes and one-id units) and both (RMAT)."""
     old = os.environ.get("GMSX_TC_DELTA")
+    old_t = os.environ.get("GMSX_TC_TAIL_DELTA")
     os.environ["GMSX_TC_DELTA"] = delta
+    os.environ["GMSX_TC_TAIL_DELTA"] = delta   # (retired knob: the tail parts are always 32-bit units now)
     try:
         for kind, scale, deg in (("kronecker", 14, 16), ("uniform", 13, 150), ("kronecker", 12, 64)):
             csr = host_graph(gpu, kind, scale, deg, True)
             want = oracle.tc_total(csr.offsets(), csr.neighbors())
-            for hub_limit in (0, 2000):
+            for hub_limit in (0, 2000, 40):  # 40: nearly everything lives in the tail containers
                 g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_DEFAULT | (hub_limit << 8))
                 assert g.tc_total() == want, (kind, scale, hub_limit)
                 assert sum(g.tc_partial(p, 3) for p in range(3)) == want
@@ -218,7 +220,8 @@ def test_stream_row_forms(gpu, oracle, delta):
         assert g.tc_total() == oracle.tc_total(csr.offsets(), csr.neighbors())
         g.free()
     finally:
-        if old is None:
-            os.environ.pop("GMSX_TC_DELTA", None)
-        else:
-            os.environ["GMSX_TC_DELTA"] = old
+        for name, val in (("GMSX_TC_DELTA", old), ("GMSX_TC_TAIL_DELTA", old_t)):
+            if val is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = val

@@ -4,7 +4,7 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gms_amd import capi
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 26
-modes = sys.argv[2:] or ["0", "1", "2"]   # "1:95" = mode 1 with GMSX_TC_DELTA_PCT=95
+modes = sys.argv[2:] or ["0", "1", "2"]   # "1:95" = mode 1 with GMSX_TC_DELTA_PCT=95; "1::0" = hub delta on, tail delta off
 capi.init(0)
 try:
     q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -14,7 +14,8 @@ except (OSError, ValueError):
 csr = capi.HostCSR.generate("kronecker", scale, 16)
 for mode in modes:
     os.environ["GMSX_TC_DELTA"] = mode.split(":")[0]
-    os.environ["GMSX_TC_DELTA_PCT"] = mode.split(":")[1] if ":" in mode else "85"
+    os.environ["GMSX_TC_DELTA_PCT"] = mode.split(":")[1] if ":" in mode and mode.split(":")[1] else "85"
+    os.environ["GMSX_TC_TAIL_DELTA"] = mode.split(":")[2] if mode.count(":") >= 2 else "1"
     t0 = time.time()
     g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_TRUSTED)
     up = time.time() - t0
