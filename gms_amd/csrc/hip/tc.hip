@@ -843,11 +843,11 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     // CO-SCHEDULING.  The heavy-pivot kernel is bound by beyond-L2 bandwidth, the two light-pivot kernels by memory latency
     // (k_tc_wave) and by the gather rate of the texture addressers (k_tc_wave_hub): run back to back, each leaves the resource the
     // others need idle.  So the light kernels go to two side streams FIRST, with grids of only a few workgroups per CU (they are
-    // persistent grid-stride kernels: 1 + 2 workgroups = 12 waves and 77 KB of LDS per CU), and the heavy kernel fills the
-    // remaining wave slots and LDS of every CU (5 workgroups, growing to 8 as the light kernels retire).  One pass then costs
+    // persistent grid-stride kernels: 2 + 2 workgroups = 16 waves and 77 KB of LDS per CU), and the heavy kernel fills the
+    // remaining wave slots and LDS of every CU (4-5 workgroups, growing to 8 as the light kernels retire).  One pass then costs
     // about max(heavy, light) instead of their sum.  GMSX_TC_OVERLAP=0 restores the serial order (full-width light grids).
     static const int overlap = [] { const char *e = std::getenv("GMSX_TC_OVERLAP"); return e ? std::atoi(e) : 1; }();
-    static const int hub_wgs = [] { const char *e = std::getenv("GMSX_TC_HUB_WGS"); return e ? std::max(1, std::atoi(e)) : 1; }();
+    static const int hub_wgs = [] { const char *e = std::getenv("GMSX_TC_HUB_WGS"); return e ? std::max(1, std::atoi(e)) : 2; }();
     static const int wave_wgs = [] { const char *e = std::getenv("GMSX_TC_WAVE_WGS"); return e ? std::max(1, std::atoi(e)) : 2; }();
     // measured (tools/tc_overlap_sweep.py, MI355X): scale 26 268 -> 254 ms — 1.80 TB of beyond-L2 traffic at 7.1 TB/s, i.e. the pass then
     // sits on the aggregate bandwidth roof and only fewer bytes can make it faster; scale 24 37.8 -> 36…46 ms (noisy: the light kernels are
