@@ -230,23 +230,62 @@ __global__ void k_srow_fill(int64_t n, const int64_t *__restrict__ hoff, const u
     }
 }
 
-// ---- stream rows of the tail parts: 32-bit ids in whole 16-byte units (a 16-bit delta form was built and measured: 66 GB fewer
-//      bytes at scale 26 but +3 ms — the tail phase is bound by its set probes, not by bytes — and removed) ------------------------
-__global__ void k_trow_sizes(int64_t n, const int64_t *__restrict__ toff, int64_t *__restrict__ units_out) {
+// ---- stream rows of the tail parts: 32-bit list or 16-bit delta, whole 16-byte units ------------------------------------------
+// 16-bit delta form of a tail row: unit = 32-bit base id, count (1 … 6) in the low half of word 1, five 16-bit gaps; a gap above
+// 65535 ends the unit early.  6 ids per unit: 2.67 B/id against 4 B/id.
+__device__ inline uint32_t tail_delta_encode(const int32_t *__restrict__ row, int len, uint32_t *__restrict__ emit) {
+    uint32_t units = 0;
+    int i = 0;
+    while (i < len) {
+        uint32_t w[4] = {uint32_t(row[i]), 0u, 0u, 0u};
+        uint32_t cur = uint32_t(row[i]);
+        int slot = 1;  // half-word index in words 1..3 (half-word 0 = the count): gap k lives in half-word k
+        ++i;
+        while (i < len && slot < 6) {
+            const uint32_t gap = uint32_t(row[i]) - cur;
+            if (gap > 65535u) break;
+            w[1 + (slot >> 1)] |= gap << ((slot & 1) * 16);
+            ++slot;
+            cur = uint32_t(row[i]);
+            ++i;
+        }
+        w[1] |= uint32_t(slot);  // ids in this unit
+        if (emit) {
+            emit[units * 4 + 0] = w[0]; emit[units * 4 + 1] = w[1]; emit[units * 4 + 2] = w[2]; emit[units * 4 + 3] = w[3];
+        }
+        ++units;
+    }
+    return units;
+}
+__global__ void k_trow_sizes(int64_t n, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, int delta_mode,
+                             int64_t *__restrict__ units_out, unsigned char *__restrict__ form_out) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v > n) return;
-    units_out[v] = v == n ? 0 : (toff[v + 1] - toff[v] + 3) / 4;  // 4 ids per unit
+    if (v == n) { units_out[n] = 0; return; }
+    const int64_t b = toff[v];
+    const int len = int(toff[v + 1] - b);
+    uint32_t best = uint32_t((len + 3) / 4);  // list: 4 ids per unit
+    int form = kFormList;
+    if (len >= 8 && delta_mode > 0) {
+        const uint32_t d = tail_delta_encode(tadj + b, len, nullptr);
+        if (delta_mode == 2 || d * 100u <= best * 85u) { best = d; form = kFormDelta; }
+    }
+    units_out[v] = int64_t(best);
+    form_out[v] = (unsigned char)form;
 }
 __global__ void k_trow_fill(int64_t n, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, const int64_t *__restrict__ uoff,
-                            unsigned long long *__restrict__ trow, uint32_t *__restrict__ tpool) {
+                            const unsigned char *__restrict__ form, unsigned long long *__restrict__ trow, uint32_t *__restrict__ tpool) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v >= n) return;
     const int64_t u0 = uoff[v], units = uoff[v + 1] - u0;
-    trow[v] = ((unsigned long long)u0 << 24) | (unsigned long long)units;
+    trow[v] = ((unsigned long long)u0 << 24) | ((unsigned long long)form[v] << 22) | (unsigned long long)units;
+    if (units == 0) return;
     uint32_t *dst = tpool + u0 * 4;
     const int64_t b = toff[v];
     const int64_t len = toff[v + 1] - b;
-    for (int64_t w = 0; w < units * 4; ++w) dst[w] = w < len ? uint32_t(tadj[b + w]) : 0xfffffffeu;
+    if (form[v] == kFormDelta) tail_delta_encode(tadj + b, int(len), dst);
+    else
+        for (int64_t w = 0; w < units * 4; ++w) dst[w] = w < len ? uint32_t(tadj[b + w]) : 0xfffffffeu;
 }
 
 // ---- bitset containers of dense hub rows -------------------------------------------------------------------
@@ -559,19 +598,27 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     }
     // 4e. … and of the tail parts
     {
+        int delta_mode = g->rows_sorted ? 1 : 0;
+        if (const char *e = std::getenv("GMSX_TC_TAIL_DELTA")) {  // 0 = 32-bit lists only, 2 = delta wherever possible (test hook)
+            const int v = std::atoi(e);
+            if (v >= 0 && v <= 2 && g->rows_sorted) delta_mode = v;
+        }
         int64_t *units = nullptr, *uoff = nullptr;
+        unsigned char *form = nullptr;
         if (int rc = dmalloc(&units, n + 1, nullptr)) return rc;
         DevGuard g_u{units};
         if (int rc = dmalloc(&uoff, n + 1, nullptr)) return rc;
         DevGuard g_o{uoff};
-        hipLaunchKernelGGL(k_trow_sizes, dim3(unsigned(n / 256 + 1)), dim3(256), 0, s, n, g->toff, units);
+        if (int rc = dmalloc(&form, n + 1, nullptr)) return rc;
+        DevGuard g_f{form};
+        hipLaunchKernelGGL(k_trow_sizes, dim3(unsigned(n / 256 + 1)), dim3(256), 0, s, n, g->toff, g->tadj, delta_mode, units, form);
         if (int rc = exclusive_scan_i64(units, uoff, n + 1, s)) return rc;
         GMSX_HIP(hipMemcpy(&g->tpool_units, uoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
         if (g->tpool_units >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;
         if (int rc = dmalloc(&g->trow, n, g)) return rc;
         if (int rc = dmalloc(&g->tpool, g->tpool_units * 4 + 4, g)) return rc;
         if (n > 0)
-            hipLaunchKernelGGL(k_trow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->toff, g->tadj, uoff, g->trow, g->tpool);
+            hipLaunchKernelGGL(k_trow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->toff, g->tadj, uoff, form, g->trow, g->tpool);
         GMSX_HIP(hipStreamSynchronize(s));
     }
 

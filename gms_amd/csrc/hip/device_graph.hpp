@@ -56,7 +56,8 @@ struct gmsx_graph {
     unsigned long long *srow = nullptr;  // [n]
     uint32_t *spool = nullptr;           // 16-byte units
     int64_t spool_units = 0;
-    // … and the TAIL part of every row as 32-bit ids in whole 16-byte units (filler -2, never a key of a pivot's tail set):
+    // … and the TAIL part of every row the same way (trow / tpool): form 0 = 32-bit ids, 4 per unit, filler -2 (never a key of a
+    // pivot's tail set); form 2 = 16-bit delta: 32-bit base, count, five 16-bit gaps — 6 ids per unit, 2.67 B/id against 4 B/id
     unsigned long long *trow = nullptr;
     uint32_t *tpool = nullptr;
     int64_t tpool_units = 0;

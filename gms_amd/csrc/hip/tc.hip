@@ -258,7 +258,8 @@ __device__ __forceinline__ uint32_t scan_tail_rows(const int32_t *tbl, uint32_t 
     return cnt;
 }
 
-// Tail stream rows (trow / tpool: 32-bit ids, 4 per 16-byte unit, filler -2) against the pivot's tail set; same shape as scan_srows.
+// Tail stream rows (trow / tpool: 32-bit ids, 4 per 16-byte unit, filler -2 — or 16-bit delta units, 6 ids each) against the pivot's
+// tail set; same shape as scan_srows.
 // Almost every streamed tail id is a miss (scale 24: 0.7 M of 10.3 G triangles close through a tail id), so the set is fronted by a
 // FILTER: a 32768-bit bitmap of (id & 0x7fff).  One LDS word read + bit test answers "no" for all but tl/32768 of the ids; only
 // the lanes with a positive walk the open-addressing table (whose divergent probe loops were 47 of k_tc_block's 165 ms at scale 26).
@@ -275,6 +276,24 @@ __device__ __forceinline__ uint32_t tail_unit_hits(const uint32_t *flt, const in
     }
     return c;
 }
+// one unit of the 16-bit delta form: 32-bit base, count (low half of word 1), five 16-bit gaps
+__device__ __forceinline__ uint32_t tail_delta_unit_hits(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, uint4 p) {
+    const uint32_t id0 = p.x, id1 = id0 + (p.y >> 16), id2 = id1 + (p.z & 0xffffu), id3 = id2 + (p.z >> 16), id4 = id3 + (p.w & 0xffffu),
+                   id5 = id4 + (p.w >> 16);
+    const uint32_t n = p.y & 0xffu;
+    const uint32_t m = (flt_bit(flt, id0) | (flt_bit(flt, id1) << 1) | (flt_bit(flt, id2) << 2) | (flt_bit(flt, id3) << 3) | (flt_bit(flt, id4) << 4) |
+                        (flt_bit(flt, id5) << 5)) & ((1u << n) - 1u);
+    uint32_t c = 0;
+    if (m) {
+        if (m & 1u) c += set_contains(tbl, mask, shift, int32_t(id0));
+        if (m & 2u) c += set_contains(tbl, mask, shift, int32_t(id1));
+        if (m & 4u) c += set_contains(tbl, mask, shift, int32_t(id2));
+        if (m & 8u) c += set_contains(tbl, mask, shift, int32_t(id3));
+        if (m & 16u) c += set_contains(tbl, mask, shift, int32_t(id4));
+        if (m & 32u) c += set_contains(tbl, mask, shift, int32_t(id5));
+    }
+    return c;
+}
 __device__ __forceinline__ uint32_t scan_trows(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, const uint32_t *__restrict__ tpool,
                                                unsigned long long desc, int rows, int lane) {
     const int grp = lane >> 4, sub = lane & 15;
@@ -288,15 +307,24 @@ __device__ __forceinline__ uint32_t scan_trows(const uint32_t *flt, const int32_
                        hi2 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m2), hi3 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m3);
         const uint32_t lo = grp == 0 ? lo0 : grp == 1 ? lo1 : grp == 2 ? lo2 : lo3;
         const uint32_t hi = grp == 0 ? hi0 : grp == 1 ? hi1 : grp == 2 ? hi2 : hi3;
-        const int units = int(lo & 0x3fffffu);
+        const int units = int(lo & 0x3fffffu), form = int((lo >> 22) & 3u);
         const uint4 *row = reinterpret_cast<const uint4 *>(tpool) + ((uint64_t(hi) << 8) | (lo >> 24));
         int j = sub;
-        for (; j + 16 < units; j += 32) {
-            const uint4 p = row[j], q = row[j + 16];
-            cnt += tail_unit_hits(flt, tbl, mask, shift, p);
-            cnt += tail_unit_hits(flt, tbl, mask, shift, q);
+        if (form == kFormDelta) {
+            for (; j + 16 < units; j += 32) {
+                const uint4 p = row[j], q = row[j + 16];
+                cnt += tail_delta_unit_hits(flt, tbl, mask, shift, p);
+                cnt += tail_delta_unit_hits(flt, tbl, mask, shift, q);
+            }
+            if (j < units) cnt += tail_delta_unit_hits(flt, tbl, mask, shift, row[j]);
+        } else {
+            for (; j + 16 < units; j += 32) {
+                const uint4 p = row[j], q = row[j + 16];
+                cnt += tail_unit_hits(flt, tbl, mask, shift, p);
+                cnt += tail_unit_hits(flt, tbl, mask, shift, q);
+            }
+            if (j < units) cnt += tail_unit_hits(flt, tbl, mask, shift, row[j]);
         }
-        if (j < units) cnt += tail_unit_hits(flt, tbl, mask, shift, row[j]);
     }
     return cnt;
 }

@@ -201,7 +201,7 @@ def test_stream_row_forms(gpu, oracle, delta):
     old = os.environ.get("GMSX_TC_DELTA")
     old_t = os.environ.get("GMSX_TC_TAIL_DELTA")
     os.environ["GMSX_TC_DELTA"] = delta
-    os.environ["GMSX_TC_TAIL_DELTA"] = delta   # (retired knob: the tail parts are always 32-bit units now)
+    os.environ["GMSX_TC_TAIL_DELTA"] = delta   # the tail parts have the same choice: 32-bit list or 16-bit delta units
     try:
         for kind, scale, deg in (("kronecker", 14, 16), ("uniform", 13, 150), ("kronecker", 12, 64)):
             csr = host_graph(gpu, kind, scale, deg, True)
