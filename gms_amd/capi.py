@@ -277,10 +277,12 @@ class DeviceGraph:
 
     BREAKDOWN = ["heavy_bitset_rows", "heavy_list_rows", "heavy_tailmember_hub_parts", "heavy_tailmember_tail_parts", "light_gathers",
                  "light_streamed_hub_parts", "light_streamed_tail_parts", "pivot_containers", "heavy_list_rows_delta", "heavy_tailmember_hub_parts_delta",
-                 "light_streamed_hub_parts_delta", "row_fetches_heavy", "row_fetches_light_streamed"]
+                 "light_streamed_hub_parts_delta", "row_fetches_heavy", "row_fetches_light_streamed",
+                 "actual_hubmember_list", "actual_hubmember_bitset", "actual_hubmember_delta", "actual_tailmember_hub_list", "actual_tailmember_hub_bitset",
+                 "actual_tailmember_hub_delta", "actual_tailmember_tail_list", "actual_tailmember_tail_delta"]
 
     def tc_stream_breakdown(self):
-        out = np.zeros(13, dtype=np.uint64)
+        out = np.zeros(21, dtype=np.uint64)
         _check(lib().gmsx_tc_stream_breakdown(self._h, out), "gmsx_tc_stream_breakdown")
         return dict(zip(self.BREAKDOWN, (int(x) for x in out)))
 

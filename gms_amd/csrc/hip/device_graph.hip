@@ -191,9 +191,9 @@ __global__ void k_srow_sizes(int64_t n, const int64_t *__restrict__ hoff, const 
         const uint32_t bits = uint32_t(bitset_words(int32_t(v)) / 4);
         if (bits * 16u + 32u < uint32_t(len) * 2u) { best = bits; form = kFormBitset; }  // same rule as the kernels always used
     }
-    if (len > 0 && form == kFormList && delta_mode > 0 && (delta_mode == 2 || len >= 24)) {
+    if (len > 0 && delta_mode > 0 && (delta_mode == 2 || len >= 24)) {  // also against the bitset: between 1/16 and 1/9 density delta is smaller
         const uint32_t d = delta_encode(hadj + b, len, nullptr);
-        if (delta_mode == 2 || d * 100u <= best * uint32_t(delta_pct)) { best = d; form = kFormDelta; }
+        if ((delta_mode == 2 && form == kFormList) || d * 100u <= best * uint32_t(delta_pct)) { best = d; form = kFormDelta; }
     }
     // rows of 8 units (128 bytes) or more start on 128-byte boundaries of their own region of the pool: a row fetch then touches
     // ceil(L/128) lines instead of L/128 + 1 (≈5 % of the heavy-pivot traffic); the small rows are packed behind them

@@ -787,6 +787,8 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
 //   out[6] light: tail parts of streamed rows      out[7] pivot containers
 //   out[8] = out[1] with min(list, delta) per row  out[9] = out[2] likewise                out[10] = out[5] likewise
 //   out[11] row fetches (heavy)                    out[12] row fetches (light, streamed)
+//   out[13..15] ACTUAL stream-row bytes of heavy pivots' hub members by form (list, bitset, delta); out[16..18] the same for the hub
+//   parts of their tail members; out[19..20] tail parts of their tail members (32-bit list, 16-bit delta)
 __global__ __launch_bounds__(256) void k_row_delta_bytes(int64_t n, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                          uint32_t *__restrict__ dbytes) {
     const int lane = threadIdx.x & 63;
@@ -808,12 +810,13 @@ __global__ __launch_bounds__(256) void k_row_delta_bytes(int64_t n, const int64_
 __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                       const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                       const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
-                                                      const uint32_t *__restrict__ dbytes, int32_t dense_limit, int32_t bitset_limit, int64_t end,
-                                                      unsigned long long *__restrict__ out) {
+                                                      const uint32_t *__restrict__ dbytes, const unsigned long long *__restrict__ srow,
+                                                      const unsigned long long *__restrict__ trow, int32_t dense_limit, int32_t bitset_limit,
+                                                      int64_t end, unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
-    unsigned long long c[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long c[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t pos = wave0; pos < end; pos += nwaves) {
         const int32_t u = order[pos];
         const int du = dplus[u];
@@ -829,18 +832,25 @@ __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict_
                 c[11]++;
                 if (int32_t(v) < dense_limit && bits + 32 < list) c[0] += bits;
                 else { c[1] += list; c[8] += min(list, (unsigned long long)dbytes[v]); }
+                const unsigned long long d = srow[v];
+                c[13 + ((d >> 22) & 3)] += 16ull * (d & 0x3fffffull);  // actual stream bytes of hub members by form (list, bitset, delta)
             } else c[4] += 4ull * (unsigned long long)(j - hoff[u]);
         }
         for (int64_t j = toff[u] + lane; j < toff[u + 1]; j += 64) {
             const int32_t v = tadj[j];
             const unsigned long long list = 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
             const unsigned long long tail = j > toff[u] ? 4ull * (unsigned long long)(toff[v + 1] - toff[v]) : 0ull;
-            if (heavy) { c[11]++; c[2] += list; c[9] += min(list, (unsigned long long)dbytes[v]); c[3] += tail; }
+            if (heavy) {
+                c[11]++; c[2] += list; c[9] += min(list, (unsigned long long)dbytes[v]); c[3] += tail;
+                const unsigned long long d = srow[v], t = trow[v];
+                c[16 + ((d >> 22) & 3)] += 16ull * (d & 0x3fffffull);           // hub parts of tail members by form
+                if (j > toff[u]) c[19 + (((t >> 22) & 3) ? 1 : 0)] += 16ull * (t & 0x3fffffull);  // their tail parts: list / delta
+            }
             else if (v < bitset_limit) c[4] += 4ull * (unsigned long long)(du - tl + (j - toff[u]));
             else { c[12]++; c[5] += list; c[10] += min(list, (unsigned long long)dbytes[v]); c[6] += tail; }
         }
     }
-    for (int k = 0; k < 13; ++k) {
+    for (int k = 0; k < 21; ++k) {
         unsigned long long x = c[k];
         for (int s = 32; s > 0; s >>= 1) x += __shfl_down(x, s);
         if (lane == 0 && x) atomicAdd(&out[k], x);
@@ -961,24 +971,25 @@ extern "C" {
 
 int gmsx_tc_divisor(int algo) { return algo == GMSX_TC_FULL ? 3 : 1; }
 
-int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out13) {
+int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21) {
+    uint64_t *out13 = out21;
     if (!g || !out13) return GMSX_ERR_INVALID;
     if (int rc = ensure_init()) return rc;
     hipStream_t s = ctx().stream;
-    std::memset(out13, 0, 13 * sizeof(uint64_t));
+    std::memset(out13, 0, 21 * sizeof(uint64_t));
     if (g->n == 0) return GMSX_OK;
     uint32_t *dbytes = nullptr;
     unsigned long long *acc = nullptr;
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dbytes), size_t(g->n) * 4));
     struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g1{dbytes};
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), 13 * 8));
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), 21 * 8));
     Guard g2{acc};
-    GMSX_HIP(hipMemsetAsync(acc, 0, 13 * 8, s));
+    GMSX_HIP(hipMemsetAsync(acc, 0, 21 * 8, s));
     const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
     hipLaunchKernelGGL(k_row_delta_bytes, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->n, g->hoff, g->hadj, dbytes);
     hipLaunchKernelGGL(k_tc_breakdown, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, dbytes,
-                       g->dense_limit, g->bitset_limit, g->n, acc);
-    GMSX_HIP(hipMemcpyAsync(out13, acc, 13 * 8, hipMemcpyDeviceToHost, s));
+                       g->srow, g->trow, g->dense_limit, g->bitset_limit, g->n, acc);
+    GMSX_HIP(hipMemcpyAsync(out13, acc, 21 * 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     GMSX_HIP(hipGetLastError());
     return GMSX_OK;

@@ -168,8 +168,10 @@ int gmsx_tc_divisor(int algo); /* 1 for ORIENTED/AUTO, 3 for FULL */
 /* Diagnostics: the algorithmic stream bytes of one oriented pass (gmsx_stats.stream_bytes) split by what is read — out[0..7]: heavy
  * pivots' bitset-form hub rows, list-form hub rows, hub parts and tail parts of tail-member rows; light pivots' gathered words, hub
  * parts and tail parts of streamed rows; the pivots' own containers — out[8..10]: entries 1, 2, 5 if every 16-bit list row were
- * stored in the smaller of list / byte-delta form; out[11..12]: row fetches of heavy / light pivots.  13 values, host. */
-int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out13);
+ * stored in the smaller of list / byte-delta form (an estimate); out[11..12]: row fetches of heavy / light pivots; out[13..20]: the
+ * ACTUAL stream-row bytes of the heavy pivots by form — hub members (list, bitset, delta), hub parts of tail members (list, bitset,
+ * delta), tail parts of tail members (32-bit list, 16-bit delta).  21 values, host. */
+int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21);
 /* Par::vertex_count2 / vertex_count2_once (parallel/vertex.h:14-49): counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| (= 2·triangles at u),
  * indexed by the vertex ids of the uploaded CSR.  Runs on the k = 3 bit-matrix kernels (one atomic per pivot member); graphs
  * with d+ > 8192 fall back to one full-row intersect_count per CSR entry. */
