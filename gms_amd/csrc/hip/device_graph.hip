@@ -288,6 +288,15 @@ __global__ void k_trow_fill(int64_t n, const int64_t *__restrict__ toff, const i
         for (int64_t w = 0; w < units * 4; ++w) dst[w] = w < len ? uint32_t(tadj[b + w]) : 0xfffffffeu;
 }
 
+__global__ void k_tdesc_fill(int64_t entries, const int32_t *__restrict__ tadj, const unsigned long long *__restrict__ srow,
+                             const unsigned long long *__restrict__ trow, unsigned long long *__restrict__ tdesc) {
+    const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= entries) return;
+    const int32_t v = tadj[e];
+    tdesc[2 * e] = srow[v];
+    tdesc[2 * e + 1] = trow[v];
+}
+
 // ---- bitset containers of dense hub rows -------------------------------------------------------------------
 // words of the bitset of rank id v (covers ids [0, v)), rounded to 16 bytes; 0 if the list form is smaller
 __global__ void k_dense_sizes(int32_t limit, const int32_t *__restrict__ dplus, int64_t *__restrict__ sizes) {
@@ -388,6 +397,7 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->srow);
     (void)hipFree(g->spool);
     (void)hipFree(g->trow);
+    (void)hipFree(g->tdesc);
     (void)hipFree(g->tpool);
     (void)hipFree(g->dplus);
     (void)hipFree(g->order);
@@ -619,6 +629,10 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         if (int rc = dmalloc(&g->tpool, g->tpool_units * 4 + 4, g)) return rc;
         if (n > 0)
             hipLaunchKernelGGL(k_trow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->toff, g->tadj, uoff, form, g->trow, g->tpool);
+        if (int rc = dmalloc(&g->tdesc, 2 * g->tail_entries + 2, g)) return rc;
+        if (g->tail_entries > 0)
+            hipLaunchKernelGGL(k_tdesc_fill, dim3(unsigned((g->tail_entries + 255) / 256)), dim3(256), 0, s, g->tail_entries, g->tadj, g->srow, g->trow,
+                               g->tdesc);
         GMSX_HIP(hipStreamSynchronize(s));
     }
 

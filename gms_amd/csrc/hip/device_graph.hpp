@@ -58,6 +58,11 @@ struct gmsx_graph {
     int64_t spool_units = 0;
     // … and the TAIL part of every row the same way (trow / tpool): form 0 = 32-bit ids, 4 per unit, filler -2 (never a key of a
     // pivot's tail set); form 2 = 16-bit delta: 32-bit base, count, five 16-bit gaps — 6 ids per unit, 2.67 B/id against 4 B/id
+    // both descriptors of every TAIL entry once more, next to the entry: tdesc[2*e] = srow[tadj[e]], tdesc[2*e+1] = trow[tadj[e]].
+    // A heavy pivot then reads the descriptors of its tail members as one coalesced 16-byte load per member instead of two
+    // dependent 8-byte gathers into 0.5 GB tables (≈60 GB of 64-byte lines per pass at scale 26); hub members keep srow[v]
+    // (65535 entries: L2-resident).
+    unsigned long long *tdesc = nullptr;
     unsigned long long *trow = nullptr;
     uint32_t *tpool = nullptr;
     int64_t tpool_units = 0;

@@ -382,7 +382,7 @@ static constexpr int kBlockLog = 10;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const unsigned long long *__restrict__ srow, const uint32_t *__restrict__ spool,
-                                                  const unsigned long long *__restrict__ trow, const uint32_t *__restrict__ tpool,
+                                                  const unsigned long long *__restrict__ tdesc, const uint32_t *__restrict__ tpool,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
                                                   int part, unsigned long long *__restrict__ acc) {
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (int base = 0; base < tl; base += 256) {
         const int idx = base + lane * 4 + wave;
         unsigned long long desc = 0;
-        if (idx < tl) desc = srow[tadj[tb + idx]];
+        if (idx < tl) desc = tdesc[2 * (tb + idx)];  // = srow[tadj[tb + idx]], stored next to the entry
         const int rows = min(64, (tl - base - wave + 3) >> 2);
         cnt += scan_srows(bm, spool, desc, rows, lane);
     }
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         for (int base = 0; base < tl; base += 256) {
             const int idx = base + lane * 4 + wave;
             unsigned long long desc = 0;
-            if (idx > 0 && idx < tl) desc = trow[tadj[tb + idx]];  // idx 0: the first tail member's tail ids lie below every tail id of the pivot
+            if (idx > 0 && idx < tl) desc = tdesc[2 * (tb + idx) + 1];  // = trow[tadj[…]]; idx 0: the first tail member's tail ids lie below every tail id of the pivot
             const int rows = min(64, (tl - base - wave + 3) >> 2);
             cnt += scan_trows(flt, tbl, MASK, SHIFT, tpool, desc, rows, lane);
         }
@@ -911,7 +911,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     };
     if (co) launch_light();
     if (cnt_heavy > 0) {
-        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt_heavy)), dim3(256), 0, s, g->hoff, g->hadj, g->srow, g->spool, g->trow, g->tpool, g->toff, g->tadj,
+        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt_heavy)), dim3(256), 0, s, g->hoff, g->hadj, g->srow, g->spool, g->tdesc, g->tpool, g->toff, g->tadj,
                            g->order, int64_t(0), n_block, nparts, part, acc);
         ++launches;
     }
