@@ -932,6 +932,16 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     }
     GMSX_HIP(hipEventRecord(ev_fork, s));
     GMSX_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+    // every way out of this function joins the side stream again — error returns included, so that no later call on the launch
+    // stream can overtake kernels still running beside it
+    struct Join {
+        hipStream_t main, side;
+        hipEvent_t ev;
+        bool armed = true;
+        ~Join() {
+            if (armed && hipEventRecord(ev, side) == hipSuccess) (void)hipStreamWaitEvent(main, ev, 0);
+        }
+    } join{s, side, ev_join};
 
     // L: 1024 < d+ <= 4096 (8192 for k <= 4), bit-matrix in a global slab per workgroup; one launch per row width (one / two / four words per lane)
     constexpr int NL = (LV <= 2) ? 3 : 2;
@@ -1011,6 +1021,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             ++*launches;
         }
     }
+    join.armed = false;
     GMSX_HIP(hipEventRecord(ev_join, side));
     GMSX_HIP(hipStreamWaitEvent(s, ev_join, 0));
     return GMSX_OK;

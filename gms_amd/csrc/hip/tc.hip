@@ -373,6 +373,44 @@ __device__ __forceinline__ uint32_t scan_tail_rows_bucket(const int32_t *tbl, co
     return cnt;
 }
 
+// Tail stream rows against an arbitrary exact membership probe (the light-pivot kernel: bucket set or open-addressing table, no filter).
+template <class Probe>
+__device__ __forceinline__ uint32_t tail_unit_probe(Probe probe, uint4 p, int form) {
+    if (form == kFormDelta) {
+        const uint32_t id0 = p.x, id1 = id0 + (p.y >> 16), id2 = id1 + (p.z & 0xffffu), id3 = id2 + (p.z >> 16), id4 = id3 + (p.w & 0xffffu),
+                       id5 = id4 + (p.w >> 16);
+        const uint32_t n = p.y & 0xffu;
+        return probe(int32_t(id0)) + (n > 1 ? probe(int32_t(id1)) : 0u) + (n > 2 ? probe(int32_t(id2)) : 0u) + (n > 3 ? probe(int32_t(id3)) : 0u) +
+               (n > 4 ? probe(int32_t(id4)) : 0u) + (n > 5 ? probe(int32_t(id5)) : 0u);
+    }
+    return probe(int32_t(p.x)) + probe(int32_t(p.y)) + probe(int32_t(p.z)) + probe(int32_t(p.w));  // the filler -2 is never a key
+}
+template <class Probe>
+__device__ __forceinline__ uint32_t scan_trows_probe(Probe probe, const uint32_t *__restrict__ tpool, unsigned long long desc, int rows, int lane) {
+    const int grp = lane >> 4, sub = lane & 15;
+    uint32_t cnt = 0;
+    for (int r0 = 0; r0 < rows; r0 += 4) {
+        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
+        const uint32_t lo0 = __builtin_amdgcn_readlane(uint32_t(desc), m0), lo1 = __builtin_amdgcn_readlane(uint32_t(desc), m1),
+                       lo2 = __builtin_amdgcn_readlane(uint32_t(desc), m2), lo3 = __builtin_amdgcn_readlane(uint32_t(desc), m3);
+        if (((lo0 | lo1 | lo2 | lo3) & 0x3fffffu) == 0) continue;  // wave-uniform
+        const uint32_t hi0 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m0), hi1 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m1),
+                       hi2 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m2), hi3 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m3);
+        const uint32_t lo = grp == 0 ? lo0 : grp == 1 ? lo1 : grp == 2 ? lo2 : lo3;
+        const uint32_t hi = grp == 0 ? hi0 : grp == 1 ? hi1 : grp == 2 ? hi2 : hi3;
+        const int units = int(lo & 0x3fffffu), form = int((lo >> 22) & 3u);
+        const uint4 *row = reinterpret_cast<const uint4 *>(tpool) + ((uint64_t(hi) << 8) | (lo >> 24));
+        int j = sub;
+        for (; j + 16 < units; j += 32) {
+            const uint4 p = row[j], q = row[j + 16];
+            cnt += tail_unit_probe(probe, p, form);
+            cnt += tail_unit_probe(probe, q, form);
+        }
+        if (j < units) cnt += tail_unit_probe(probe, row[j], form);
+    }
+    return cnt;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Workgroup per pivot (d+ >= 64).  256 threads = 4 waves share the pivot's bitmap + tail set; wave w streams the
 // rows of the pivot-list entries w, w+4, ….  LDS: 8 KB hub bitmap + 4 KB tail filter + 2^kBlockLog x 4 B hash; a tail longer
@@ -563,13 +601,14 @@ __global__ __launch_bounds__(256) void k_tc_wave_hub(const int64_t *__restrict__
 // of A are in flight, so a pivot pays only the round trips of its own row scans.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                 const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool, int32_t dense_limit,
-                                                 const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
-                                                 const int32_t *__restrict__ tsplit, const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
-                                                 int part, unsigned long long *__restrict__ acc) {
+                                                 const uint32_t *__restrict__ spool, const uint32_t *__restrict__ tpool,
+                                                 const unsigned long long *__restrict__ tdesc, const int64_t *__restrict__ toff,
+                                                 const int32_t *__restrict__ tadj, const int32_t *__restrict__ tsplit,
+                                                 const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts, int part,
+                                                 unsigned long long *__restrict__ acc) {
     constexpr int LOG = 8, SIZE = 1 << LOG, SHIFT = 32 - LOG;
     constexpr uint32_t MASK = SIZE - 1;
-    __shared__ __attribute__((aligned(16))) uint32_t bm_all[4 * kBitmapWords];
+    __shared__ __attribute__((aligned(16))) uint32_t bm_all[4 * kBitmapWords + 128];  // + slack: the delta probes of unused slots read up to 104 words past a bitmap
     __shared__ __attribute__((aligned(16))) int32_t tbl_all[4 * SIZE];
     __shared__ uint32_t fill_all[4 * 64];
     __shared__ unsigned long long red[4];
@@ -582,85 +621,60 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
     const int64_t pos0 = first + (int64_t(blockIdx.x) * 4 + wave) * nparts + part;
     unsigned long long cnt = 0;
 
-    // stage B/C: offsets of the pivots one and two steps ahead of C; stage A: the id three steps ahead
+    // The dependent loads  order[] -> offsets -> (member ids, stream-row descriptors)  form a three-deep software pipeline over the
+    // pivots of the wave.  The descriptors of a pivot's tail members sit next to the members (tdesc), so they no longer wait for the
+    // member ids: stage C loads ids and descriptors together, stage D scans.
     int64_t hbC = 0, tbC = 0, hbB = 0, tbB = 0;
     int hlC = 0, tlC = 0, hlB = 0, tlB = 0;
     int tsC = 0, tsB = 0, tsD = 0;  // members below bitset_limit come first in a tail row: k_tc_wave_hub resolved their rows
     int32_t uA = -1;
-    // stage D: the pivot being scanned -- member ids and the extents of both containers of every tail member
     int tlD = 0;
     uint32_t hvD = 0xFFFFu;
     int32_t vD = -1;
-    int64_t thbD = 0, trbD = 0;
-    int thlD = 0, trlD = 0;
-    {  // prologue
-        int64_t hb0 = 0, tb0 = 0;
-        int hl0 = 0;
-        if (pos0 < end) {
-            const int32_t u = order[pos0];
-            hb0 = hoff[u];
-            hl0 = int(hoff[u + 1] - hb0);
-            tb0 = toff[u];
-            tlD = int(toff[u + 1] - tb0);
-            tsD = tsplit[u];
-            if (tlD <= tsD) tlD = 0;  // no member beyond bitset_limit: nothing to stream for this pivot
-        }
-        if (pos0 + step < end) {
-            const int32_t u = order[pos0 + step];
-            hbC = hoff[u];
-            hlC = int(hoff[u + 1] - hbC);
-            tbC = toff[u];
-            tlC = int(toff[u + 1] - tbC);
-            tsC = tsplit[u];
-            if (tlC <= tsC) tlC = 0;
-        }
-        if (pos0 + 2 * step < end) {
-            const int32_t u = order[pos0 + 2 * step];
-            hbB = hoff[u];
-            hlB = int(hoff[u + 1] - hbB);
-            tbB = toff[u];
-            tlB = int(toff[u + 1] - tbB);
-            tsB = tsplit[u];
-            if (tlB <= tsB) tlB = 0;
-        }
-        if (pos0 + 3 * step < end) uA = order[pos0 + 3 * step];
-        if (tlD > 0) {
-            if (lane < hl0) hvD = hadj[hb0 + lane];
-            if (lane < tlD) {
-                vD = tadj[tb0 + lane];
-                if (lane >= tsD) {
-                    thbD = hoff[vD];
-                    thlD = int(hoff[vD + 1] - thbD);
-                    if (lane > 0) {
-                        trbD = toff[vD];
-                        trlD = int(toff[vD + 1] - trbD);
-                    }
+    unsigned long long dsD = 0, dtD = 0;  // stream-row descriptors (hub part, tail part) of this lane's far member; 0 = nothing to stream
+    auto load_members = [&](int64_t hb, int hl, int64_t tb, int tl, int ts, uint32_t &hv, int32_t &v, unsigned long long &ds, unsigned long long &dt) {
+        hv = 0xFFFFu; v = -1; ds = 0; dt = 0;
+        if (tl > 0) {
+            if (lane < hl) hv = hadj[hb + lane];
+            if (lane < tl) {
+                v = tadj[tb + lane];
+                if (lane >= ts) {
+                    const ulonglong2 d = *reinterpret_cast<const ulonglong2 *>(tdesc + 2 * (tb + lane));
+                    ds = d.x;
+                    if (lane > 0) dt = d.y;  // the first tail member's tail ids are all below every tail id of the pivot: no match possible
                 }
             }
         }
+    };
+    auto load_offsets = [&](int32_t u, int64_t &hb, int &hl, int64_t &tb, int &tl, int &ts) {
+        hb = hoff[u];
+        hl = int(hoff[u + 1] - hb);
+        tb = toff[u];
+        tl = int(toff[u + 1] - tb);
+        ts = tsplit[u];
+        if (tl <= ts) tl = 0;  // no member beyond bitset_limit: nothing to stream for this pivot
+    };
+    {  // prologue
+        int64_t hb0 = 0, tb0 = 0;
+        int hl0 = 0;
+        if (pos0 < end) load_offsets(order[pos0], hb0, hl0, tb0, tlD, tsD);
+        if (pos0 + step < end) load_offsets(order[pos0 + step], hbC, hlC, tbC, tlC, tsC);
+        if (pos0 + 2 * step < end) load_offsets(order[pos0 + 2 * step], hbB, hlB, tbB, tlB, tsB);
+        if (pos0 + 3 * step < end) uA = order[pos0 + 3 * step];
+        load_members(hb0, hl0, tb0, tlD, tsD, hvD, vD, dsD, dtD);
     }
     for (int64_t pos = pos0; pos < end; pos += step) {  // uniform per wave
         // loads of the later stages first; they complete while D is scanned
         int64_t hbN = 0, tbN = 0;
         int hlN = 0, tlN = 0, tsN = 0;
-        if (uA >= 0) {
-            hbN = hoff[uA];
-            hlN = int(hoff[uA + 1] - hbN);
-            tbN = toff[uA];
-            tlN = int(toff[uA + 1] - tbN);
-            tsN = tsplit[uA];
-            if (tlN <= tsN) tlN = 0;
-        }
+        if (uA >= 0) load_offsets(uA, hbN, hlN, tbN, tlN, tsN);
         const int32_t uN = (pos + 4 * step < end) ? order[pos + 4 * step] : -1;
-        uint32_t hvC = 0xFFFFu;
-        int32_t vC = -1;
-        if (tlC > 0) {
-            if (lane < hlC) hvC = hadj[hbC + lane];
-            if (lane < tlC) vC = tadj[tbC + lane];
-        }
-        uint32_t c = 0;
-        bool bucketed = true;
+        uint32_t hvC;
+        int32_t vC;
+        unsigned long long dsC, dtC;
+        load_members(hbC, hlC, tbC, tlC, tsC, hvC, vC, dsC, dtC);
         if (tlD > 0) {
+            uint32_t c = 0;
             __builtin_amdgcn_wave_barrier();
             // hub members: only their bits are needed here (their rows were counted by k_tc_wave_hub)
             if (hvD != 0xFFFFu) atomicOr(&bm[hvD >> 5], 1u << (hvD & 31u));
@@ -672,7 +686,7 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
                 slot = atomicAdd(&fill[bucket_of<64>(vD)], 1u);
                 if (slot < 4) tbl[bucket_of<64>(vD) * 4 + slot] = vD;
             }
-            bucketed = __ballot(slot >= 4) == 0;
+            const bool bucketed = __ballot(slot >= 4) == 0;
             if (!bucketed) {  // rare: some bucket took a fifth key; rebuild as an open-addressing table
                 __builtin_amdgcn_wave_barrier();
                 for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
@@ -680,30 +694,16 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
                 if (vD >= 0) set_insert(tbl, MASK, SHIFT, vD);
             }
             __builtin_amdgcn_wave_barrier();
-            c = scan_hub_rows(bm, hadj, bmpool, thbD, thlD, tlD, lane);
-        }
-        // stage C's member ids have arrived by now: issue the loads of its row extents
-        int64_t thbC = 0, trbC = 0;
-        int thlC = 0, trlC = 0;
-        if (vC >= 0 && lane >= tsC) {
-            thbC = hoff[vC];
-            thlC = int(hoff[vC + 1] - thbC);
-            if (lane > 0) {  // the first tail member's tail ids are all below every tail id of the pivot: no match possible
-                trbC = toff[vC];
-                trlC = int(toff[vC + 1] - trbC);
-            }
-        }
-        if (tlD > 0) {
+            c = scan_srows(bm, spool, dsD, tlD, lane);
             if (bucketed)
-                c += scan_tail_rows_bucket<64>(tbl, tadj, trbD, trlD, tlD, lane);
+                c += scan_trows_probe([tbl](int32_t w) { return bucket_contains<64>(tbl, w); }, tpool, dtD, tlD, lane);
             else
-                c += scan_tail_rows(tbl, MASK, SHIFT, tadj, trbD, trlD, tlD, lane);
+                c += scan_trows_probe([tbl](int32_t w) { return set_contains(tbl, MASK, SHIFT, w); }, tpool, dtD, tlD, lane);
             cnt += c;
             __builtin_amdgcn_wave_barrier();
             if (hvD != 0xFFFFu) bm[hvD >> 5] = 0;  // every bit in this wave's bitmap belongs to this pivot
         }
-        tlD = tlC; tsD = tsC; hvD = hvC; vD = vC;
-        thbD = thbC; thlD = thlC; trbD = trbC; trlD = trlC;
+        tlD = tlC; tsD = tsC; hvD = hvC; vD = vC; dsD = dsC; dtD = dtC;
         hbC = hbB; hlC = hlB; tbC = tbB; tlC = tlB; tsC = tsB;
         hbB = hbN; hlB = hlN; tbB = tbN; tlB = tlN; tsB = tsN;
         uA = uN;
@@ -764,8 +764,8 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
                 bytes += 4ull * (unsigned long long)(du - tl + (j - toff[u]));
                 continue;
             }
-            bytes += heavy ? 16ull * (srow[v] & 0x3fffffull) : 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
-            if (j > toff[u]) bytes += heavy ? 16ull * (trow[v] & 0x3fffffull) : 4ull * (unsigned long long)(toff[v + 1] - toff[v]);
+            bytes += 16ull * (srow[v] & 0x3fffffull);                      // heavy and light pivots stream the same stream rows
+            if (j > toff[u]) bytes += 16ull * (trow[v] & 0x3fffffull);
         }
     }
     for (int s = 32; s > 0; s >>= 1) {
@@ -893,18 +893,29 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     // where the near-tail bitsets are on.
     const bool co = overlap && cnt_heavy > 0 && cnt_light > 0 && c.side[0] && c.side[1] && (overlap > 1 || g->bitset_limit > g->dense_limit);
     hipStream_t s_hub = co ? c.side[0] : s, s_wave = co ? c.side[1] : s;
+    struct Join {  // joins the side streams on every way out once they were forked (error returns included)
+        Ctx &c;
+        hipStream_t s;
+        bool armed = false;
+        ~Join() {
+            if (!armed) return;
+            for (int i = 0; i < 2; ++i)
+                if (hipEventRecord(c.ev_join[i], c.side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, c.ev_join[i], 0);
+        }
+    } join{c, s};
     if (co) {
         GMSX_HIP(hipEventRecord(c.ev_fork, s));
         GMSX_HIP(hipStreamWaitEvent(c.side[0], c.ev_fork, 0));
         GMSX_HIP(hipStreamWaitEvent(c.side[1], c.ev_fork, 0));
+        join.armed = true;
     }
     auto launch_light = [&]() {
         if (cnt_light <= 0) return;
         const int64_t want = (cnt_light + 3) / 4;
         const int64_t b_hub = std::min<int64_t>(want, co ? int64_t(cus) * hub_wgs : cap_blocks * 2);
         const int64_t b_wave = std::min<int64_t>(want, co ? int64_t(cus) * wave_wgs : cap_blocks);
-        hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(b_wave)), dim3(256), 0, s_wave, g->hoff, g->hadj, g->bmoff, g->bmpool, g->dense_limit,
-                           g->toff, g->tadj, g->tsplit, g->order, n_block, n_work, nparts, part, acc);
+        hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(b_wave)), dim3(256), 0, s_wave, g->hoff, g->hadj, g->spool, g->tpool, g->tdesc, g->toff, g->tadj,
+                           g->tsplit, g->order, n_block, n_work, nparts, part, acc);
         hipLaunchKernelGGL(k_tc_wave_hub, dim3(unsigned(b_hub)), dim3(256), 0, s_hub, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
                            g->bitset_limit, g->order, n_block, n_work, nparts, part, acc);
         launches += 2;
@@ -917,6 +928,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     }
     if (!co) launch_light();
     if (co) {
+        join.armed = false;
         GMSX_HIP(hipEventRecord(c.ev_join[0], c.side[0]));
         GMSX_HIP(hipEventRecord(c.ev_join[1], c.side[1]));
         GMSX_HIP(hipStreamWaitEvent(s, c.ev_join[0], 0));
