@@ -8,14 +8,19 @@
 // on the degree-oriented rows:  T = Σ_u Σ_{v∈N+(u)} |N+(u) ∩ N+(v)|, which meets every triangle once, so the
 // returned integer is the same.
 //
-// Kernel shape — one pivot vertex u per workgroup (d+ >= 64) or per wave (2 <= d+ < 64), Roaring-style sets:
-//   1. the pivot row N+(u) is staged into LDS: its hub part (rank ids < 65535) as a 65536-bit BITMAP (8 KB), its
-//      tail part as a small open-addressing hash set;
-//   2. the rows N+(v), v ∈ N+(u), are streamed from HBM/L2 with coalesced 16-byte loads: hub containers carry
-//      eight 16-bit ids per lane per load, tail containers 32-bit ids;
-//   3. every streamed hub id is one LDS word read + bit test (bitmap AND, no collisions, no branches); tail ids
-//      probe the hash set; hits are counted per lane, reduced per workgroup, and added to one of 64 spread u64
-//      accumulators (one atomic per workgroup).
+// Kernel shape — one pivot vertex u per workgroup (d+ >= 64, k_tc_block) or per wave (2 <= d+ < 64), Roaring-style sets:
+//   1. the pivot row N+(u) is staged into LDS: its hub part (rank ids < 65535) as a 65536-bit BITMAP (8 KB), its tail part as
+//      an open-addressing hash set fronted by a 32768-bit filter (heavy pivots) or as a 64 x 4 bucket set (light pivots);
+//   2. the rows N+(v), v ∈ N+(u), are streamed from HBM/MALL with coalesced 16-byte loads as STREAM ROWS (device_graph.hpp):
+//      whole 16-byte units of the cheapest of three forms per row — bitset (AND + popcount, 128 ids per unit), 16-bit list
+//      (8 ids), byte-delta (base + count + 13 gaps: 14 ids) — for the hub part, 32-bit ids or 16-bit delta units (6 ids) for
+//      the tail part; a wave works as four 16-lane groups, each on its own row, two loads in flight;
+//   3. every streamed hub id is one LDS word read + bit test (no collisions, no branches); a tail id is one filter-bit test and,
+//      for the few that pass, a table probe; hits are counted per lane, reduced per workgroup, added to one of 64 spread u64
+//      accumulators (one atomic per workgroup);
+//   4. light pivots resolve the rows of all members that own a bitset container (rank id < bitset_limit) by inverted gathers
+//      (k_tc_wave_hub: "is my member w_j in N+(v_i)?", no LDS) and stream only the members beyond it (k_tc_wave); on large graphs
+//      both run BESIDE k_tc_block on side streams — the pass is bound by beyond-L2 bandwidth, not by any one kernel.
 // No MFMA: integer/indexing work bounded by row streaming (HBM/MALL/L2) and the LDS probe rate.
 #include "device_graph.hpp"
 
@@ -53,70 +58,6 @@ __device__ __forceinline__ uint32_t hub_hits8(const uint32_t *bm, u4u p) {
            bit_lo(bm, p.w) + bit_hi(bm, p.w);
 }
 
-// Streams the hub containers of `rows` rows against the LDS bitmap.  Lane l holds the extent (rb, rl) of row l
-// (rl = padded, even entry count, or -(words) with rb = word offset into bmpool for a dense row; lanes >= rows hold 0).  The wave works as four 16-lane groups, each streaming
-// its own row: 16 lanes x 8 ids per step, two steps (two 16-byte loads per lane) in flight.
-__device__ __forceinline__ uint32_t scan_hub_rows(const uint32_t *bm, const uint16_t *__restrict__ hadj,
-                                                  const uint32_t *__restrict__ bmpool, int64_t rb, int rl, int rows, int lane) {
-
-    const int grp = lane >> 4, sub8 = (lane & 15) * 8;
-    uint32_t cnt = 0;
-    for (int r0 = 0; r0 < rows; r0 += 4) {
-        // extents of rows r0..r0+3 through wave-uniform readlanes, then a per-group select (a per-lane __shfl here
-        // gets sunk under the row-count predicate by the compiler and then reads inactive lanes)
-        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
-        const int l0 = __builtin_amdgcn_readlane(rl, m0), l1 = __builtin_amdgcn_readlane(rl, m1),
-                  l2 = __builtin_amdgcn_readlane(rl, m2), l3 = __builtin_amdgcn_readlane(rl, m3);
-        if ((l0 | l1 | l2 | l3) == 0) continue;  // wave-uniform: four empty rows (e.g. members whose rows another kernel resolves)
-        const int64_t b0 = readlane64(rb, m0), b1 = readlane64(rb, m1), b2 = readlane64(rb, m2), b3 = readlane64(rb, m3);
-        const int64_t b = grp == 0 ? b0 : grp == 1 ? b1 : grp == 2 ? b2 : b3;
-        const int l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
-        if (l < 0) {
-            // dense row: a bitset container over [0, v); AND it word-wise with the pivot bitmap (16 lanes x 4 words per step)
-            const uint32_t *brow = bmpool + b;
-            for (int j = sub8 >> 1; j < -l; j += 64) {
-                const uint4 p = *reinterpret_cast<const uint4 *>(brow + j);
-                const uint4 q = *reinterpret_cast<const uint4 *>(bm + j);
-                cnt += uint32_t(__popc(p.x & q.x) + __popc(p.y & q.y) + __popc(p.z & q.z) + __popc(p.w & q.w));
-            }
-            continue;
-        }
-        const uint16_t *row = hadj + b;
-        int j = sub8;
-        for (; j + 128 + 8 <= l; j += 256) {  // two full 128-id group steps
-            const u4u p = *reinterpret_cast<const u4u *>(row + j);
-            const u4u q = *reinterpret_cast<const u4u *>(row + j + 128);
-            cnt += hub_hits8(bm, p);
-            cnt += hub_hits8(bm, q);
-        }
-        for (; j < l; j += 128) {  // remaining steps; the last may be partial (l - j in {2,4,6}: whole dwords)
-            u4u p = *reinterpret_cast<const u4u *>(row + j);
-            const int valid = l - j;
-            if (valid < 8) {  // ids beyond the row are neutralised to 0xFFFF, which is never set in the bitmap
-                if (valid < 6) p.z = 0xffffffffu;
-                if (valid < 4) p.y = 0xffffffffu;
-                p.w = 0xffffffffu;
-            }
-            cnt += hub_hits8(bm, p);
-        }
-    }
-    return cnt;
-}
-
-// extent of the hub container of rank id v as the scanner wants it: the bitset form when v has one, else the list
-__device__ __forceinline__ void hub_row_extent(int32_t v, const int64_t *__restrict__ hoff, const int64_t *__restrict__ bmoff,
-                                               int32_t dense_limit, int64_t &rb, int &rl) {
-    rb = hoff[v];
-    rl = int(hoff[v + 1] - rb);  // list form: 2 bytes per (padded) entry
-    if (v < dense_limit) {
-        const int nw = int(bitset_words(v));
-        if (nw * 4 + 32 < rl * 2) {  // the bitset is the smaller form: stream it instead
-            rb = bmoff[v];
-            rl = -nw;
-        }
-    }
-}
-
 // ---- stream rows (device_graph.hpp): whole 16-byte units at 16-byte aligned offsets, three forms, no tail handling -------------
 // one unit of the byte-delta form: 16-bit base id, count byte (1 … 14 ids), 13 gap bytes.  All fourteen running ids first (a chain
 // of byte adds), THEN the fourteen LDS probes back to back — written the other way round the compiler waits for every probe before
@@ -149,7 +90,8 @@ __device__ __forceinline__ uint32_t delta_unit_hits(const uint32_t *bm, uint4 p)
 }
 
 // Streams `rows` stream rows against the LDS bitmap.  Lane l holds the packed descriptor of row l (srow[v]; 0 = no row).
-// Same shape as scan_hub_rows: four 16-lane groups, each on its own row, one 16-byte unit per lane per step, two steps in flight.
+// A wave works as four 16-lane groups, each on its own row: one 16-byte unit per lane per step, two steps in flight; the descriptors of
+// four rows are handed out with wave-uniform v_readlane + a per-group select.
 __device__ __forceinline__ uint32_t scan_srows(const uint32_t *bm, const uint32_t *__restrict__ spool, unsigned long long desc, int rows, int lane) {
     const int grp = lane >> 4, sub = lane & 15;
     uint32_t cnt = 0;
@@ -216,48 +158,6 @@ __device__ __forceinline__ uint32_t set_contains(const int32_t *tbl, uint32_t ma
         h = (h + 1) & mask;
     }
 }
-// Tail containers (32-bit ids) against the LDS hash set.  Same shape as scan_hub_rows: four 16-lane groups, each on
-// its own row, four ids per lane per 16-byte load, two loads in flight -- so a trip costs one memory round trip for
-// four rows instead of one per row (tail rows are short: ~50 ids).
-__device__ __forceinline__ uint32_t tail_hits4(const int32_t *tbl, uint32_t mask, int shift, u4u p) {
-    return set_contains(tbl, mask, shift, int32_t(p.x)) + set_contains(tbl, mask, shift, int32_t(p.y)) +
-           set_contains(tbl, mask, shift, int32_t(p.z)) + set_contains(tbl, mask, shift, int32_t(p.w));
-}
-__device__ __forceinline__ u4u tail_load4(const int32_t *row, int j, int l) {
-    u4u p = *reinterpret_cast<const u4u *>(row + j);
-    const int valid = l - j;  // >= 1; ids beyond the row become -2: never a key, never the empty marker
-    if (valid < 4) {
-        p.w = 0xfffffffeu;
-        if (valid < 3) p.z = 0xfffffffeu;
-        if (valid < 2) p.y = 0xfffffffeu;
-    }
-    return p;
-}
-__device__ __forceinline__ uint32_t scan_tail_rows(const int32_t *tbl, uint32_t mask, int shift, const int32_t *__restrict__ tadj,
-                                                   int64_t rb, int rl, int rows, int lane) {
-    const int grp = lane >> 4, sub4 = (lane & 15) * 4;
-    uint32_t cnt = 0;
-    for (int r0 = 0; r0 < rows; r0 += 4) {
-        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
-        const int l0 = __builtin_amdgcn_readlane(rl, m0), l1 = __builtin_amdgcn_readlane(rl, m1),
-                  l2 = __builtin_amdgcn_readlane(rl, m2), l3 = __builtin_amdgcn_readlane(rl, m3);
-        if ((l0 | l1 | l2 | l3) == 0) continue;  // wave-uniform
-        const int64_t b0 = readlane64(rb, m0), b1 = readlane64(rb, m1), b2 = readlane64(rb, m2), b3 = readlane64(rb, m3);
-        const int64_t b = grp == 0 ? b0 : grp == 1 ? b1 : grp == 2 ? b2 : b3;
-        const int l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
-        const int32_t *row = tadj + b;
-        int j = sub4;
-        for (; j + 64 < l; j += 128) {  // both loads have at least one valid id
-            const u4u p = tail_load4(row, j, l);
-            const u4u q = tail_load4(row, j + 64, l);
-            cnt += tail_hits4(tbl, mask, shift, p);
-            cnt += tail_hits4(tbl, mask, shift, q);
-        }
-        if (j < l) cnt += tail_hits4(tbl, mask, shift, tail_load4(row, j, l));
-    }
-    return cnt;
-}
-
 // Tail stream rows (trow / tpool: 32-bit ids, 4 per 16-byte unit, filler -2 — or 16-bit delta units, 6 ids each) against the pivot's
 // tail set; same shape as scan_srows.
 // Almost every streamed tail id is a miss (scale 24: 0.7 M of 10.3 G triangles close through a tail id), so the set is fronted by a
@@ -342,37 +242,6 @@ __device__ __forceinline__ uint32_t bucket_contains(const int32_t *tbl, int32_t 
     const int4 b = *reinterpret_cast<const int4 *>(tbl + bucket_of<NB>(w) * 4);
     return uint32_t((b.x == w) | (b.y == w) | (b.z == w) | (b.w == w));
 }
-template <int NB>
-__device__ __forceinline__ uint32_t bucket_hits4(const int32_t *tbl, u4u p) {
-    return bucket_contains<NB>(tbl, int32_t(p.x)) + bucket_contains<NB>(tbl, int32_t(p.y)) + bucket_contains<NB>(tbl, int32_t(p.z)) +
-           bucket_contains<NB>(tbl, int32_t(p.w));
-}
-template <int NB>
-__device__ __forceinline__ uint32_t scan_tail_rows_bucket(const int32_t *tbl, const int32_t *__restrict__ tadj, int64_t rb, int rl, int rows,
-                                                          int lane) {
-    const int grp = lane >> 4, sub4 = (lane & 15) * 4;
-    uint32_t cnt = 0;
-    for (int r0 = 0; r0 < rows; r0 += 4) {
-        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
-        const int l0 = __builtin_amdgcn_readlane(rl, m0), l1 = __builtin_amdgcn_readlane(rl, m1),
-                  l2 = __builtin_amdgcn_readlane(rl, m2), l3 = __builtin_amdgcn_readlane(rl, m3);
-        if ((l0 | l1 | l2 | l3) == 0) continue;  // wave-uniform
-        const int64_t b0 = readlane64(rb, m0), b1 = readlane64(rb, m1), b2 = readlane64(rb, m2), b3 = readlane64(rb, m3);
-        const int64_t b = grp == 0 ? b0 : grp == 1 ? b1 : grp == 2 ? b2 : b3;
-        const int l = grp == 0 ? l0 : grp == 1 ? l1 : grp == 2 ? l2 : l3;
-        const int32_t *row = tadj + b;
-        int j = sub4;
-        for (; j + 64 < l; j += 128) {
-            const u4u p = tail_load4(row, j, l);
-            const u4u q = tail_load4(row, j + 64, l);
-            cnt += bucket_hits4<NB>(tbl, p);
-            cnt += bucket_hits4<NB>(tbl, q);
-        }
-        if (j < l) cnt += bucket_hits4<NB>(tbl, tail_load4(row, j, l));
-    }
-    return cnt;
-}
-
 // Tail stream rows against an arbitrary exact membership probe (the light-pivot kernel: bucket set or open-addressing table, no filter).
 template <class Probe>
 __device__ __forceinline__ uint32_t tail_unit_probe(Probe probe, uint4 p, int form) {
