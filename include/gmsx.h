@@ -120,9 +120,10 @@ typedef struct gmsx_stats {
     int32_t launches;          /* number of kernel launches inside kernel_ms */
     int32_t reserved;
     uint64_t stream_bytes;     /* TC (oriented): algorithmic bytes of THIS formulation per call — every pivot's own containers once, plus
-                                  for every oriented edge (u,v) the bytes of N+(v) in the container form the kernels read (bitset words,
-                                  16-bit list, 32-bit list; 4 bytes per inverted gather).  No cache is assumed: the traffic a pass would
-                                  cause if nothing were ever re-used on chip.  0 for the other entry points. */
+                                  for every oriented edge (u,v) the bytes of N+(v) in the form the kernels read: its stream rows (whole
+                                  16-byte units of bitset / 16-bit list / byte-delta for the hub part, 32-bit ids / 16-bit delta for the
+                                  tail part) or 4 bytes per inverted gather.  No cache is assumed: the traffic a pass would cause if
+                                  nothing were ever re-used on chip.  0 for the other entry points. */
 } gmsx_stats;
 
 /* Bind this process to one HIP device.  device<0 → current device.  Calling it again with the same device is a no-op (and makes
