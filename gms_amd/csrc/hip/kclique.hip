@@ -863,34 +863,38 @@ static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
     return span <= 0 ? 0 : (span + nparts - 1) / nparts;
 }
 
-// generic list recursion for the pivots at positions [first, end) of the d+ order; *slab_out is freed by the caller after the sync
-static int launch_generic(const gmsx_graph *g, int k, int64_t first, int64_t end, int part, int nparts, unsigned long long *acc, int *launches,
-                          int32_t **slab_out) {
+// generic list recursion for the pivots at positions [first, end) of the d+ order, in chunks of at most 60000 pivots (grid.y); every
+// chunk is synchronised and its slab freed before the next one starts — this is the slow path
+static int launch_generic(const gmsx_graph *g, int k, int64_t first, int64_t end, int part, int nparts, unsigned long long *acc, int *launches) {
     Ctx &c = ctx();
     hipStream_t s = c.stream;
-    const int64_t pivots = part_count(first, end, nparts, part);
-    if (pivots <= 0) return GMSX_OK;
-    if (pivots > 65535) return GMSX_ERR_UNSUPPORTED;  // grid.y; tens of thousands of pivots beyond the bit-matrix limits do not occur
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
     const int64_t dmax = std::max<int64_t>(g->max_dplus, 1);
     const int64_t levels = k > 3 ? k - 3 : 1, stride = (dmax + 63) & ~int64_t(63);
-    // waves per pivot: enough to fill the chip a few times over, bounded by a 2 GB slab
-    int64_t blocks_x = std::max<int64_t>(1, std::min<int64_t>((dmax + 3) / 4, std::max<int64_t>(1, int64_t(cu) * 8 / pivots)));
-    while (blocks_x > 1 && pivots * blocks_x * 4 * levels * stride * 4 > (int64_t(2) << 30)) blocks_x /= 2;
-    const int64_t slab_ints = pivots * blocks_x * 4 * levels * stride;
-    if (slab_ints * 4 > (int64_t(8) << 30)) return GMSX_ERR_DEVICE_MEM;
-    int32_t *slab = nullptr;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slab), size_t(slab_ints) * 4));
-    *slab_out = slab;
-    hipLaunchKernelGGL(k_kc_generic, dim3(unsigned(blocks_x), unsigned(pivots)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
-                       g->bitset_limit, g->dense_limit, g->dplus, g->order, first, end, nparts, part, k, slab, stride, acc);
-    ++*launches;
+    for (int64_t lo = first; lo < end; lo += int64_t(60000) * nparts) {
+        const int64_t hi = std::min<int64_t>(end, lo + int64_t(60000) * nparts);
+        const int64_t pivots = part_count(lo, hi, nparts, part);
+        if (pivots <= 0) continue;
+        // waves per pivot: enough to fill the chip a few times over, bounded by a 2 GB slab
+        int64_t blocks_x = std::max<int64_t>(1, std::min<int64_t>((dmax + 3) / 4, std::max<int64_t>(1, int64_t(cu) * 8 / pivots)));
+        while (blocks_x > 1 && pivots * blocks_x * 4 * levels * stride * 4 > (int64_t(2) << 30)) blocks_x /= 2;
+        const int64_t slab_ints = pivots * blocks_x * 4 * levels * stride;
+        if (slab_ints * 4 > (int64_t(32) << 30)) return GMSX_ERR_DEVICE_MEM;
+        int32_t *slab = nullptr;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slab), size_t(slab_ints) * 4));
+        struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{slab};
+        hipLaunchKernelGGL(k_kc_generic, dim3(unsigned(blocks_x), unsigned(pivots)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff,
+                           g->bmpool, g->bitset_limit, g->dense_limit, g->dplus, g->order, lo, hi, nparts, part, k, slab, stride, acc);
+        ++*launches;
+        GMSX_HIP(hipStreamSynchronize(s));
+        GMSX_HIP(hipGetLastError());
+    }
     return GMSX_OK;
 }
 
 template <int LV, bool VTX = false>
 static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long long *acc, int *launches, uint32_t **slab_out,
-                      unsigned long long *vcounts = nullptr, int32_t **generic_slab = nullptr) {
+                      unsigned long long *vcounts = nullptr) {
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     const int k = LV + 2;
@@ -906,7 +910,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     if (over > 0) {
         if (VTX) return GMSX_ERR_UNSUPPORTED;  // the per-vertex counts have their own full-row fallback (pairs.hip)
         // pivots wider than the bit-matrix kernels hold: the generic list recursion takes positions [0, over) of the d+ order
-        if (int rc = launch_generic(g, k, 0, over, part, nparts, acc, launches, generic_slab)) return rc;
+        if (int rc = launch_generic(g, k, 0, over, part, nparts, acc, launches)) return rc;
     }
     if (int rc = count_dplus_ge(g, std::max(k - 1, 1), &n_min)) return rc;
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
@@ -1040,34 +1044,25 @@ static int kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uin
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), sizeof(unsigned long long) * kAccSlots * kAccStride));
     struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{acc};
     uint32_t *slabs = nullptr;
-    int32_t *gslab = nullptr;
     GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * kAccSlots * kAccStride, s));
     GMSX_HIP(hipEventRecord(c.ev[0], s));
     int launches = 0, rc = GMSX_OK;
     switch (k) {
-        case 3: rc = launch_all<1>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
-        case 4: rc = launch_all<2>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
-        case 5: rc = launch_all<3>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
-        case 6: rc = launch_all<4>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
-        case 7: rc = launch_all<5>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
-        case 8: rc = launch_all<6>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
-        case 9: rc = launch_all<7>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
-        case 10: rc = launch_all<8>(g, part, nparts, acc, &launches, &slabs, nullptr, &gslab); break;
+        case 3: rc = launch_all<1>(g, part, nparts, acc, &launches, &slabs); break;
+        case 4: rc = launch_all<2>(g, part, nparts, acc, &launches, &slabs); break;
+        case 5: rc = launch_all<3>(g, part, nparts, acc, &launches, &slabs); break;
+        case 6: rc = launch_all<4>(g, part, nparts, acc, &launches, &slabs); break;
+        case 7: rc = launch_all<5>(g, part, nparts, acc, &launches, &slabs); break;
+        case 8: rc = launch_all<6>(g, part, nparts, acc, &launches, &slabs); break;
+        case 9: rc = launch_all<7>(g, part, nparts, acc, &launches, &slabs); break;
+        case 10: rc = launch_all<8>(g, part, nparts, acc, &launches, &slabs); break;
         default: {  // k > kMaxK: every pivot that can head a k-clique (d+ >= k-1) through the generic list recursion
             int64_t n_min = 0;
             rc = g->rows_sorted ? count_dplus_ge(g, k - 1, &n_min) : GMSX_ERR_UNSUPPORTED;
-            for (int64_t lo = 0; !rc && lo < n_min; lo += int64_t(60000) * nparts) {  // grid.y chunks
-                int32_t *chunk = nullptr;
-                rc = launch_generic(g, k, lo, std::min<int64_t>(n_min, lo + int64_t(60000) * nparts), part, nparts, acc, &launches, &chunk);
-                if (!rc && chunk) {
-                    GMSX_HIP(hipStreamSynchronize(s));
-                    (void)hipFree(chunk);
-                }
-            }
+            if (!rc) rc = launch_generic(g, k, 0, n_min, part, nparts, acc, &launches);
         }
     }
     Guard slab_guard{slabs};
-    Guard gslab_guard{gslab};
     if (rc) return rc;
     GMSX_HIP(hipEventRecord(c.ev[1], s));
     GMSX_HIP(hipGetLastError());
