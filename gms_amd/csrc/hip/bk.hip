@@ -27,7 +27,8 @@ namespace gmsx {
 static constexpr int kLdsSlabWords = 2048;  // 8 KB per wave: tasks of at most ~90 candidates; with the trimmed scratch below 17 waves fit a CU
 static constexpr unsigned long long kEmptySlot = ~0ull;
 static constexpr unsigned long long kWideTask = 1ull << 62;  // task key flag: more than 2048 candidates
-static constexpr int kBkMaxCand = 16384;  // widest bit rows of the search kernels: eight words per lane
+static constexpr int kBkMaxCand = 16384;  // widest bit rows of the register-resident search kernels: eight words per lane; start
+                                          // vertices with more candidates run on the memory-resident search (k_bk_wave<false, 0>)
 
 __host__ __device__ inline uint32_t bk_map_size(int c) {
     uint32_t s = 64;
@@ -40,10 +41,16 @@ __host__ __device__ inline unsigned long long bk_slab_words(int c, long long x) 
            (unsigned long long)(c + 1) * (3 * cw + xw + 1);
 }
 
+// slab of a memory-resident search: the usual structures + the pivot-candidate list (c words) + one Xf flag byte per level
+__host__ __device__ inline unsigned long long bk_slab_words_mem(int c, long long x) {
+    return bk_slab_words(c, x) + (unsigned long long)c + (unsigned long long)(c + 8) / 4ull + 8ull;
+}
+
 // per start vertex: slab requirement (0 = no search needed); isolated vertices are counted right here
 __global__ void k_bk_tasks(int64_t n, const int64_t *__restrict__ off, const int32_t *__restrict__ oldid,
                            const int32_t *__restrict__ dplus, unsigned long long *__restrict__ keys, int32_t *__restrict__ vals,
-                           unsigned long long *__restrict__ acc /* [0] isolated count, [1] too-wide flag, [7] tasks with > 2048 candidates */) {
+                           int max_c, int32_t *__restrict__ giant, unsigned long long giant_cap,
+                           unsigned long long *__restrict__ acc /* [0] isolated count, [1] giant tasks, [2] their largest slab, [7] tasks with > 2048 candidates */) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v >= n) return;
     const int32_t o = oldid[v];
@@ -55,8 +62,12 @@ __global__ void k_bk_tasks(int64_t n, const int64_t *__restrict__ off, const int
         if (deg == 0) atomicAdd(&acc[0], 1ull);  // an isolated vertex is a maximal clique (eppsteinPAR.h:32-47, tomita.h:73-78)
     } else {
         w = bk_slab_words(c, x);
-        if (c > kBkMaxCand) atomicOr(&acc[1], 1ull);
-        if (c > 2048) {  // more than one word per lane: these tasks sort first and run on the WPL = 2 / 4 / 8 kernels
+        if (c > max_c) {  // too wide for the register-resident search: its own list, run after the rounds by the memory-resident search
+            const unsigned long long at = atomicAdd(&acc[1], 1ull);
+            if (at < giant_cap) giant[at] = int32_t(v);
+            atomicMax(&acc[2], bk_slab_words_mem(c, x));
+            w = 0;
+        } else if (c > 2048) {  // more than one word per lane: these tasks sort first and run on the WPL = 2 / 4 / 8 kernels
             w |= kWideTask;
             atomicAdd(&acc[7], 1ull);
         }
@@ -436,6 +447,132 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
     }
 }
 
+// Memory-resident Tomita search for start vertices with more candidates than the register-resident kernels hold (c > 16384, or
+// whatever GMSX_BK_MAXC says): the same recursion with P / Xc / ext of EVERY level in the slab (level l at stack + l*lvl: P, Xc,
+// ext, Xf), the pivot-candidate list and the per-level Xf flags behind the stack, every set operation a lane-strided loop over the
+// cw words.  No node budget, no re-split: one wave finishes its start vertex.  An order of magnitude slower per node than the
+// register kernels; it exists so that no graph is refused for the width of a neighbourhood.
+__device__ __forceinline__ void bk_search_mem(const uint32_t *Cadj, const uint32_t *XT, uint32_t *stack, int c, int x, int xf_ne, int lane,
+                                              unsigned long long &cnt) {
+    const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
+    const int lvl = 3 * cw + xw + 1;
+    uint32_t *piv_list = stack + size_t(c + 1) * lvl;                                  // c entries
+    unsigned char *xfne = reinterpret_cast<unsigned char *>(piv_list + c);              // c + 1 entries
+    auto wave_or = [&](const uint32_t *a, int nw) {
+        uint32_t r = 0;
+        for (int w = lane; w < nw; w += 64) r |= a[w];
+        return __ballot(r != 0) != 0;
+    };
+    int depth = 0;
+    bool entering = true;
+    while (true) {
+        uint32_t *lv = stack + size_t(depth) * lvl;
+        uint32_t *P = lv, *Xc = lv + cw, *ext = lv + 2 * cw;
+        if (entering) {
+            if (!wave_or(P, cw)) {
+                if (!wave_or(Xc, cw) && !xf_ne) cnt++;
+                if (depth == 0) break;
+                --depth;
+                xf_ne = int(xfne[depth]);
+                entering = false;
+                continue;
+            }
+            // pivot: argmax over u in P ∪ Xc of |P ∩ N(u)| (ties -> smallest index); candidates listed by a wave prefix sum per 64-word chunk
+            int ncand = 0;
+            for (int w0 = 0; w0 < cw; w0 += 64) {
+                const int w = w0 + lane;
+                uint32_t bits = w < cw ? (P[w] | Xc[w]) : 0u;
+                const int mine = __popc(bits);
+                int pre = mine;
+                for (int sft = 1; sft < 64; sft <<= 1) {
+                    const int o = __shfl_up(pre, sft);
+                    if (lane >= sft) pre += o;
+                }
+                int at = ncand + pre - mine;
+                while (bits) {
+                    piv_list[at++] = uint32_t((w << 5) + __ffs(bits) - 1);
+                    bits &= bits - 1;
+                }
+                ncand += __builtin_amdgcn_readlane(pre, 63);
+            }
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            int best = 0x7fffffff, best_score = -1;
+            for (int k = lane; k < ncand; k += 64) {
+                const int u = int(piv_list[k]);
+                const uint32_t *row = Cadj + size_t(u) * cw;
+                int sc = 0;
+                for (int w = 0; w < cw; ++w) sc += __popc(P[w] & row[w]);
+                if (sc > best_score || (sc == best_score && u < best)) {
+                    best_score = sc;
+                    best = u;
+                }
+            }
+            for (int sft = 32; sft > 0; sft >>= 1) {
+                const int os = __shfl_xor(best_score, sft), ob = __shfl_xor(best, sft);
+                if (os > best_score || (os == best_score && ob < best)) {
+                    best_score = os;
+                    best = ob;
+                }
+            }
+            best = uni32(best);
+            const uint32_t *prow = Cadj + size_t(best) * cw;
+            for (int w = lane; w < cw; w += 64) ext[w] = P[w] & ~prow[w];
+            __threadfence_block();
+            __builtin_amdgcn_wave_barrier();
+            entering = false;
+        }
+        // next branch vertex q of this node: the lowest set bit of ext
+        int q = -1;
+        for (int w0 = 0; w0 < cw && q < 0; w0 += 64) {
+            const int w = w0 + lane;
+            const uint32_t e = w < cw ? ext[w] : 0u;
+            const unsigned long long nz = __ballot(e != 0);
+            if (nz) {
+                const int L = __ffsll((long long)nz) - 1;
+                const uint32_t word = __builtin_amdgcn_readlane(e, L);
+                q = ((w0 + L) << 5) + __ffs(word) - 1;
+            }
+        }
+        if (q < 0) {
+            if (depth == 0) break;
+            --depth;
+            xf_ne = int(xfne[depth]);
+            continue;
+        }
+        uint32_t *nx = lv + lvl;
+        const uint32_t *qrow = Cadj + size_t(q) * cw;
+        for (int w = lane; w < cw; w += 64) {
+            nx[w] = P[w] & qrow[w];
+            nx[cw + w] = Xc[w] & qrow[w];
+        }
+        int child_ne = 0;
+        if (xf_ne) {
+            uint32_t any = 0;
+            const uint32_t *xt = XT + size_t(q) * xw;
+            for (int w = lane; w < xw; w += 64) {
+                const uint32_t t = lv[3 * cw + w] & xt[w];
+                nx[3 * cw + w] = t;
+                any |= t;
+            }
+            child_ne = __ballot(any != 0) != 0 ? 1 : 0;
+        }
+        // this node continues with q moved from cand to fini (tomita.h:68-70)
+        if (lane == 0) {
+            const uint32_t bit = 1u << (q & 31);
+            ext[q >> 5] &= ~bit;
+            P[q >> 5] &= ~bit;
+            Xc[q >> 5] |= bit;
+            xfne[depth] = (unsigned char)xf_ne;
+        }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        ++depth;
+        xf_ne = child_ne;
+        entering = true;
+    }
+}
+
 // Round 0: one wave per start vertex.  LDS_SLAB: every structure of the search lives in this wave's LDS slab (tasks of
 // at most kLdsSlabWords words); otherwise in slabs[block * slab_words].
 template <bool LDS_SLAB, int WPL>
@@ -449,15 +586,16 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
                                                 unsigned long long slab_words, unsigned long long *__restrict__ acc, BkShared sh) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_slab[LDS_SLAB ? kLdsSlabWords : 4];
     // per level: is Xf non-empty (written by one lane, read by all); an LDS-slab task has < 256 candidates (its slab would not fit otherwise)
-    __shared__ unsigned char xfne_stack[LDS_SLAB ? 256 : 2052 * WPL];
+    constexpr int WR = WPL > 0 ? WPL : 1;  // WPL = 0: the memory-resident search keeps nothing of the search in LDS
+    __shared__ unsigned char xfne_stack[LDS_SLAB ? 256 : 2052 * WR];
     __shared__ int32_t in_stage[64];             // build: the kept in-neighbours of one 64-entry batch, compacted
     // global-slab variant: the id -> index map of the build phase lives in LDS whenever it fits (c <= 512); the probes
     // of the in-neighbour rows are the long dependent chains of the build
     constexpr uint32_t kLdsMapSlots = 1024;
     // one 8.25 KB LDS work area: the build's id -> index map (global-slab variant), then the search's pivot scratch
     static_assert(!LDS_SLAB || WPL == 1, "LDS-slab tasks are tiny");
-    constexpr uint32_t kWorkWords = LDS_SLAB ? 128 : (2 * kLdsMapSlots > 1024u * WPL ? 2 * kLdsMapSlots : 1024u * WPL);  // map area, or piv_list: 2048*WPL u16 (256 u16 for an LDS-slab task)
-    __shared__ __attribute__((aligned(16))) uint32_t lds_work[kWorkWords + 64 * WPL];
+    constexpr uint32_t kWorkWords = LDS_SLAB ? 128 : (2 * kLdsMapSlots > 1024u * WR ? 2 * kLdsMapSlots : 1024u * WR);  // map area, or piv_list: 2048*WPL u16 (256 u16 for an LDS-slab task)
+    __shared__ __attribute__((aligned(16))) uint32_t lds_work[kWorkWords + 64 * WR];
     unsigned long long *lds_map = reinterpret_cast<unsigned long long *>(lds_work);
     uint32_t *piv_P = lds_work + kWorkWords;
     unsigned short *piv_list = reinterpret_cast<unsigned short *>(lds_work);
@@ -586,22 +724,33 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
         __builtin_amdgcn_wave_barrier();
 
         // ---- search from the root: P = C, Xc = {}, Xf = X0 ------------------------------------------------------
-        uint32_t P[WPL], Xc[WPL], ext[WPL];
-#pragma unroll
-        for (int h = 0; h < WPL; ++h) {
-            const int w = lane + 64 * h;
-            P[h] = Xc[h] = ext[h] = 0u;
-            if (w < cw) {
-                const int bits = c - w * 32;
-                P[h] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
-            }
-        }
         for (int w = lane; w < xw; w += 64) {
             const int bits = x - w * 32;
             stack[3 * cw + w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
         }
-        __builtin_amdgcn_wave_barrier();
-        bk_search<WPL>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, x > 0 ? 1 : 0, true, lane, cnt, sh, kNoArena, !LDS_SLAB, piv_P, piv_list);
+        if constexpr (WPL == 0) {
+            for (int w = lane; w < cw; w += 64) {
+                const int bits = c - w * 32;
+                stack[w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+                stack[cw + w] = 0u;
+            }
+            __threadfence();
+            __builtin_amdgcn_wave_barrier();
+            bk_search_mem(Cadj, XT, stack, c, x, x > 0 ? 1 : 0, lane, cnt);
+        } else {
+            uint32_t P[WR], Xc[WR], ext[WR];
+#pragma unroll
+            for (int h = 0; h < WR; ++h) {
+                const int w = lane + 64 * h;
+                P[h] = Xc[h] = ext[h] = 0u;
+                if (w < cw) {
+                    const int bits = c - w * 32;
+                    P[h] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            bk_search<WR>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, x > 0 ? 1 : 0, true, lane, cnt, sh, kNoArena, !LDS_SLAB, piv_P, piv_list);
+        }
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
@@ -677,7 +826,17 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&v_in), size_t(n) * 4)); g_vi.p = v_in;
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&v_out), size_t(n) * 4)); g_vo.p = v_out;
     GMSX_HIP(hipEventRecord(c.ev[0], s));
-    hipLaunchKernelGGL(k_bk_tasks, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->off, g->oldid, g->dplus, k_in, v_in,
+    int max_c = kBkMaxCand;
+    if (const char *e = std::getenv("GMSX_BK_MAXC")) {  // test hook: a lower width limit sends more start vertices through the memory-resident search
+        const int v = std::atoi(e);
+        if (v >= 1 && v < kBkMaxCand) max_c = v;
+    }
+    const unsigned long long giant_cap = (unsigned long long)std::min<int64_t>(n, int64_t(1) << 20);
+    int32_t *giant = nullptr;
+    Guard g_giant;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&giant), size_t(giant_cap) * 4));
+    g_giant.p = giant;
+    hipLaunchKernelGGL(k_bk_tasks, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->off, g->oldid, g->dplus, k_in, v_in, max_c, giant, giant_cap,
                        acc + kCtl);
     size_t tmp_bytes = 0;
     GMSX_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, k_in, k_out, v_in, v_out, size_t(n), 0, 64, s));
@@ -690,9 +849,12 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipMemcpyAsync(words.data(), k_out, size_t(n) * 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipMemcpyAsync(head, acc + kCtl, sizeof(head), hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
-    if (head[1]) return GMSX_ERR_UNSUPPORTED;  // a start vertex with more than 16384 candidates (eight words per lane)
+    const int64_t n_giant = int64_t(head[1]);    // start vertices beyond the register-resident width: memory-resident search after the rounds
+    const unsigned long long giant_slab_w = (head[2] + 3ull) & ~3ull;
+    if (n_giant > int64_t(giant_cap)) return GMSX_ERR_UNSUPPORTED;  // more than a million of them
     const int64_t n_wide = int64_t(head[7]);     // tasks with more than 2048 candidates: sorted first (kWideTask), WPL = 2 / 4 / 8 kernels
-    const int wpl_wide = g->max_dplus <= 4096 ? 2 : g->max_dplus <= 8192 ? 4 : 8;  // candidates of a start vertex = its d+
+    const int widest = std::min(g->max_dplus, max_c);  // candidates of a start vertex = its d+
+    const int wpl_wide = widest <= 4096 ? 2 : widest <= 8192 ? 4 : 8;
     for (int64_t i = 0; i < n_wide; ++i) words[size_t(i)] &= ~kWideTask;
 
     // ---- arena + record pools of the load balancer
@@ -830,6 +992,39 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                                static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
         ++launches;
         if (++rounds > 100000) return GMSX_ERR_KERNEL;
+    }
+    // ---- start vertices too wide for the register-resident search: one wave each, the whole search in its global slab
+    if (n_giant > 0) {
+        const int64_t cnt = part_count(0, n_giant, nparts, part);
+        if (cnt > 0) {
+            {   // the list was appended with atomics: sort it, so that every rank shards the same sequence
+                int32_t *sorted = nullptr;
+                GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&sorted), size_t(n_giant) * 4));
+                Guard g_sorted;
+                g_sorted.p = sorted;
+                size_t sort_bytes = 0;
+                GMSX_HIP(rocprim::radix_sort_keys(nullptr, sort_bytes, giant, sorted, size_t(n_giant), 0, 32, s));
+                void *sort_tmp = nullptr;
+                GMSX_HIP(hipMalloc(&sort_tmp, sort_bytes ? sort_bytes : 8));
+                Guard g_st;
+                g_st.p = sort_tmp;
+                GMSX_HIP(rocprim::radix_sort_keys(sort_tmp, sort_bytes, giant, sorted, size_t(n_giant), 0, 32, s));
+                GMSX_HIP(hipMemcpyAsync(giant, sorted, size_t(n_giant) * 4, hipMemcpyDeviceToDevice, s));
+                GMSX_HIP(hipStreamSynchronize(s));
+            }
+            const unsigned long long slab_bytes = giant_slab_w * 4ull;
+            if (slab_bytes > budget_bytes) return GMSX_ERR_DEVICE_MEM;
+            const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({cnt, int64_t(cu) * 8, int64_t(budget_bytes / slab_bytes)}));
+            uint32_t *slabs = nullptr;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(waves) * slab_bytes));
+            Guard g_slabs;
+            g_slabs.p = slabs;
+            GMSX_HIP(hipMemsetAsync(queue, 0, 8, s));
+            hipLaunchKernelGGL((k_bk_wave<false, 0>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff, g->hadj,
+                               g->toff, g->tadj, g->dplus, giant, int64_t(0), n_giant, nparts, part, queue, slabs, giant_slab_w, acc, sh);
+            GMSX_HIP(hipStreamSynchronize(s));
+            ++launches;
+        }
     }
     GMSX_HIP(hipEventRecord(c.ev[2], s));
     GMSX_HIP(hipGetLastError());

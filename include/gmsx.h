@@ -210,8 +210,10 @@ int gmsx_kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint6
  * order its containers are built for); a non-NULL `rank` is only VALIDATED — it must be a permutation of 0..n-1, else
  * GMSX_ERR_INVALID — the way the reference's drivers hand a rank vector from the preprocessing step to mceBench
  * (maximal_clique_enum_bron_kerbosch.cc:36-56).  gmsx_adg_rank() below is that preprocessing step on the device.
- * Width: a start vertex may have up to 16384 candidates (d+ in the device's degree rank; the search kernels run with 1, 2, 4 or 8
- * words per lane; RMAT scale 27: max d+ = 3855); beyond that GMSX_ERR_UNSUPPORTED — the one size limit left in this header. */
+ * Width: start vertices with up to 16384 candidates (d+ in the device's degree rank; RMAT scale 27: max d+ = 3855) run on the
+ * register-resident search kernels (1, 2, 4 or 8 words per lane, re-split across waves when a search outgrows its node budget);
+ * wider ones run on a memory-resident search — one wave per start vertex, every level's sets in a global slab, an order of
+ * magnitude slower per node, same count — so no graph is refused for the width of a neighbourhood. */
 int gmsx_bk_count(const gmsx_graph *g, const int32_t *rank, uint64_t *maximal_cliques, gmsx_stats *stats);
 int gmsx_bk_partial(const gmsx_graph *g, const int32_t *rank, int part, int nparts, uint64_t *partial, gmsx_stats *stats);
 

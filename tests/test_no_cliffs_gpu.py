@@ -1,6 +1,7 @@
 """GPU: no request fails for its SIZE.  The bit-matrix kernels hold pivots up to d+ = 8192 (k <= 4) /
-4096 (k >= 5) and k <= 10, the Bron–Kerbosch search kernels grow to eight words per lane (16384 candidates); wider pivots
-and larger k fall back to the generic list recursion (kclique.hip, k_kc_generic) instead of GMSX_ERR_UNSUPPORTED.
+4096 (k >= 5) and k <= 10, the Bron–Kerbosch register-resident search kernels grow to eight words per lane (16384 candidates); wider
+pivots and larger k fall back to the generic list recursion (kclique.hip, k_kc_generic), wider start vertices to the memory-resident
+search (bk.hip, bk_search_mem), instead of GMSX_ERR_UNSUPPORTED.
 
 Shapes: K_{a,b} plus a sparse random graph H inside side A, b = a + 1.  Every B vertex has all of A as its oriented row
 (d+ = a), B is independent, so every clique has at most one B vertex:
@@ -125,3 +126,34 @@ def test_bk_beyond_4096_candidates(gpu, oracle, a):
     assert got == want
     assert sum(g.bk_partial(p, 2) for p in range(2)) == want
     g.free()
+
+
+@pytest.mark.parametrize("maxc", [1, 20, 200])
+def test_bk_memory_resident_search_equals_register_search(gpu, oracle, maxc):
+    """GMSX_BK_MAXC (test hook) lowers the width above which a start vertex runs on the memory-resident search (k_bk_wave<false, 0>:
+    P / Xc / ext of every level in the global slab) — production value 16384.  Same counts as the oracle and as the shard sums."""
+    old = os.environ.get("GMSX_BK_MAXC")
+    os.environ["GMSX_BK_MAXC"] = str(maxc)
+    try:
+        for kind, scale, deg in (("kronecker", 10, 16), ("uniform", 10, 30), ("kronecker", 11, 8)):
+            csr = host_graph(gpu, kind, scale, deg, True)
+            want = _WANT.setdefault(("bk", kind, scale, deg), oracle.bk_count(csr.offsets(), csr.neighbors()))
+            g = gpu.DeviceGraph.from_csr(csr)
+            assert g.bk_count() == want, (kind, scale, maxc)
+            assert sum(g.bk_partial(p, 3) for p in range(3)) == want
+            g.free()
+        # K_n: one maximal clique, search depth n; a complete multipartite graph: 3^4 maximal cliques
+        iu = np.triu_indices(300, 1)
+        g = gpu.DeviceGraph.from_csr(gpu.HostCSR.from_edges(iu[0].astype(np.int32), iu[1].astype(np.int32)))
+        assert g.bk_count() == 1
+        g.free()
+        parts = [range(3 * i, 3 * i + 3) for i in range(4)]
+        edges = [(a, b) for i, pa in enumerate(parts) for pb in parts[i + 1:] for a in pa for b in pb]
+        g = gpu.DeviceGraph.from_csr(gpu.HostCSR.from_edges(np.array([e[0] for e in edges], np.int32), np.array([e[1] for e in edges], np.int32)))
+        assert g.bk_count() == 81
+        g.free()
+    finally:
+        if old is None:
+            os.environ.pop("GMSX_BK_MAXC", None)
+        else:
+            os.environ["GMSX_BK_MAXC"] = old
