@@ -89,54 +89,73 @@ __device__ __forceinline__ uint32_t delta_unit_hits(const uint32_t *bm, uint4 p)
     return uint32_t(__popc(hits & ((1u << n) - 1u)));
 }
 
-// Streams `rows` stream rows against the LDS bitmap.  Lane l holds the packed descriptor of row l (srow[v]; 0 = no row).
-// A wave works as four 16-lane groups, each on its own row: one 16-byte unit per lane per step, two steps in flight; the descriptors of
-// four rows are handed out with wave-uniform v_readlane + a per-group select.
-__device__ __forceinline__ uint32_t scan_srows(const uint32_t *bm, const uint32_t *__restrict__ spool, unsigned long long desc, int rows, int lane) {
+// Streams up to 64 stream rows against the LDS bitmap.  Lane l holds the packed descriptor of one row (srow[v]; 0 = no row).
+// A wave works as four 16-lane groups, each on its own row: one 16-byte unit per lane per step, two steps in flight.  Rows are handed
+// out FORM BY FORM (a ballot per form, then the four lowest lanes of the ballot): the three forms cost 12 / 32 / 81 VALU instructions per
+// unit, and a handout that mixes them executes every branch with a quarter of the lanes (neighbouring members of a pivot list alternate
+// between list and byte-delta rows all the time: VALU lane utilisation of k_tc_block was 63 % with rows handed out in list order).
+struct RowHandout {
+    const uint4 *row;
+    int units;
+};
+__device__ __forceinline__ RowHandout take_rows(unsigned long long &todo, const uint32_t *__restrict__ pool, uint32_t dlo, uint32_t dhi, int grp) {
+    uint32_t lo[4], hi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        lo[k] = 0;
+        hi[k] = 0;
+        if (todo) {  // wave-uniform
+            const int i = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            lo[k] = __builtin_amdgcn_readlane(dlo, i);
+            hi[k] = __builtin_amdgcn_readlane(dhi, i);
+        }
+    }
+    const uint32_t l = grp == 0 ? lo[0] : grp == 1 ? lo[1] : grp == 2 ? lo[2] : lo[3];
+    const uint32_t h = grp == 0 ? hi[0] : grp == 1 ? hi[1] : grp == 2 ? hi[2] : hi[3];
+    return RowHandout{reinterpret_cast<const uint4 *>(pool) + ((uint64_t(h) << 8) | (l >> 24)), int(l & 0x3fffffu)};
+}
+__device__ __forceinline__ uint32_t scan_srows(const uint32_t *bm, const uint32_t *__restrict__ spool, unsigned long long desc, int lane) {
     const int grp = lane >> 4, sub = lane & 15;
+    const uint32_t dlo = uint32_t(desc), dhi = uint32_t(desc >> 32);
+    const bool any = (dlo & 0x3fffffu) != 0;
+    const uint32_t form = (dlo >> 22) & 3u;
     uint32_t cnt = 0;
-    for (int r0 = 0; r0 < rows; r0 += 4) {
-        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
-        const uint32_t lo0 = __builtin_amdgcn_readlane(uint32_t(desc), m0), lo1 = __builtin_amdgcn_readlane(uint32_t(desc), m1),
-                       lo2 = __builtin_amdgcn_readlane(uint32_t(desc), m2), lo3 = __builtin_amdgcn_readlane(uint32_t(desc), m3);
-        if (((lo0 | lo1 | lo2 | lo3) & 0x3fffffu) == 0) continue;  // wave-uniform: four empty rows
-        const uint32_t hi0 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m0), hi1 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m1),
-                       hi2 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m2), hi3 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m3);
-        const uint32_t lo = grp == 0 ? lo0 : grp == 1 ? lo1 : grp == 2 ? lo2 : lo3;
-        const uint32_t hi = grp == 0 ? hi0 : grp == 1 ? hi1 : grp == 2 ? hi2 : hi3;
-        const int units = int(lo & 0x3fffffu), form = int((lo >> 22) & 3u);
-        const uint4 *row = reinterpret_cast<const uint4 *>(spool) + ((uint64_t(hi) << 8) | (lo >> 24));
-        if (form == kFormBitset) {  // AND the bitset with the pivot bitmap, 128 ids per unit
-            for (int j = sub; j < units; j += 32) {
-                const uint4 p = row[j];
-                const uint4 q = *reinterpret_cast<const uint4 *>(bm + 4 * j);
-                uint32_t c = uint32_t(__popc(p.x & q.x) + __popc(p.y & q.y) + __popc(p.z & q.z) + __popc(p.w & q.w));
-                if (j + 16 < units) {
-                    const uint4 p2 = row[j + 16];
-                    const uint4 q2 = *reinterpret_cast<const uint4 *>(bm + 4 * (j + 16));
-                    c += uint32_t(__popc(p2.x & q2.x) + __popc(p2.y & q2.y) + __popc(p2.z & q2.z) + __popc(p2.w & q2.w));
-                }
-                cnt += c;
+    for (unsigned long long todo = __ballot(any && form == kFormBitset); todo;) {  // AND the bitset with the pivot bitmap, 128 ids per unit
+        const RowHandout r = take_rows(todo, spool, dlo, dhi, grp);
+        for (int j = sub; j < r.units; j += 32) {
+            const uint4 p = r.row[j];
+            const uint4 q = *reinterpret_cast<const uint4 *>(bm + 4 * j);
+            uint32_t c = uint32_t(__popc(p.x & q.x) + __popc(p.y & q.y) + __popc(p.z & q.z) + __popc(p.w & q.w));
+            if (j + 16 < r.units) {
+                const uint4 p2 = r.row[j + 16];
+                const uint4 q2 = *reinterpret_cast<const uint4 *>(bm + 4 * (j + 16));
+                c += uint32_t(__popc(p2.x & q2.x) + __popc(p2.y & q2.y) + __popc(p2.z & q2.z) + __popc(p2.w & q2.w));
             }
-        } else if (form == kFormDelta) {
-            int j = sub;
-            for (; j + 16 < units; j += 32) {
-                const uint4 p = row[j], q = row[j + 16];
-                cnt += delta_unit_hits(bm, p);
-                cnt += delta_unit_hits(bm, q);
-            }
-            if (j < units) cnt += delta_unit_hits(bm, row[j]);
-        } else {  // 16-bit list, 8 ids per unit, filler 0xFFFF
-            int j = sub;
-            for (; j + 16 < units; j += 32) {
-                const uint4 p = row[j], q = row[j + 16];
-                cnt += hub_hits8(bm, u4u{p.x, p.y, p.z, p.w});
-                cnt += hub_hits8(bm, u4u{q.x, q.y, q.z, q.w});
-            }
-            if (j < units) {
-                const uint4 p = row[j];
-                cnt += hub_hits8(bm, u4u{p.x, p.y, p.z, p.w});
-            }
+            cnt += c;
+        }
+    }
+    for (unsigned long long todo = __ballot(any && form == kFormDelta); todo;) {
+        const RowHandout r = take_rows(todo, spool, dlo, dhi, grp);
+        int j = sub;
+        for (; j + 16 < r.units; j += 32) {
+            const uint4 p = r.row[j], q = r.row[j + 16];
+            cnt += delta_unit_hits(bm, p);
+            cnt += delta_unit_hits(bm, q);
+        }
+        if (j < r.units) cnt += delta_unit_hits(bm, r.row[j]);
+    }
+    for (unsigned long long todo = __ballot(any && form == kFormList); todo;) {  // 16-bit list, 8 ids per unit, filler 0xFFFF
+        const RowHandout r = take_rows(todo, spool, dlo, dhi, grp);
+        int j = sub;
+        for (; j + 16 < r.units; j += 32) {
+            const uint4 p = r.row[j], q = r.row[j + 16];
+            cnt += hub_hits8(bm, u4u{p.x, p.y, p.z, p.w});
+            cnt += hub_hits8(bm, u4u{q.x, q.y, q.z, q.w});
+        }
+        if (j < r.units) {
+            const uint4 p = r.row[j];
+            cnt += hub_hits8(bm, u4u{p.x, p.y, p.z, p.w});
         }
     }
     return cnt;
@@ -324,16 +343,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const uint32_t v = hadj[hb + idx];
             if (v != 0xFFFFu) desc = srow[v];
         }
-        const int rows = min(64, (hl - base - wave + 3) >> 2);
-        cnt += scan_srows(bm, spool, desc, rows, lane);
+        cnt += scan_srows(bm, spool, desc, lane);
     }
     // (b) rows of the tail part of the pivot list: their hub containers against the bitmap …
     for (int base = 0; base < tl; base += 256) {
         const int idx = base + lane * 4 + wave;
         unsigned long long desc = 0;
         if (idx < tl) desc = tdesc[2 * (tb + idx)];  // = srow[tadj[tb + idx]], stored next to the entry
-        const int rows = min(64, (tl - base - wave + 3) >> 2);
-        cnt += scan_srows(bm, spool, desc, rows, lane);
+        cnt += scan_srows(bm, spool, desc, lane);
     }
     // (c) … and their tail containers against the hash set of the pivot's tail part
     for (int t0 = 0; t0 < tl; t0 += TILE) {
@@ -563,7 +580,7 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
                 if (vD >= 0) set_insert(tbl, MASK, SHIFT, vD);
             }
             __builtin_amdgcn_wave_barrier();
-            c = scan_srows(bm, spool, dsD, tlD, lane);
+            c = scan_srows(bm, spool, dsD, lane);
             if (bucketed)
                 c += scan_trows_probe([tbl](int32_t w) { return bucket_contains<64>(tbl, w); }, tpool, dtD, tlD, lane);
             else
@@ -726,6 +743,80 @@ __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict_
     }
 }
 
+// Diagnostics behind gmsx_tc_row_histogram: how the stream rows the heavy pivots read are distributed over row lengths (a 16-lane
+// group works on one row, so a row of n units keeps min(n,16)/16 of its lanes busy), and what the light pivots' gathers cost against
+// streaming the same member's rows.  out[(cls*24 + bin)*2 + {0,1}] = rows, units; cls: hub rows as list / bitset / byte-delta, tail
+// rows as list / delta; bin: 1…16 units exactly, then 17-32, 33-64, … 1025+.  out[240…]: light pivots — members with a bitset:
+// gathered words, words of those whose rows would be cheaper to stream at 128 B per gathered word, the stream bytes of those.
+__device__ __forceinline__ int hist_bin(unsigned long long units) {
+    if (units <= 16) return int(units) - 1;
+    int b = 16;
+    for (unsigned long long lim = 32; units > lim && b < 23; lim <<= 1) ++b;
+    return b;
+}
+__global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                     const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                     const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
+                                                     const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
+                                                     int32_t bitset_limit, int64_t end, unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long h[248];
+    for (int i = threadIdx.x; i < 248; i += 256) h[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    auto add = [&](int cls, unsigned long long units) {
+        if (units == 0) return;
+        const int b = (cls * 24 + hist_bin(units)) * 2;
+        atomicAdd(&h[b], 1ull);
+        atomicAdd(&h[b + 1], units);
+    };
+    for (int64_t pos = wave0; pos < end; pos += nwaves) {
+        const int32_t u = order[pos];
+        const int du = dplus[u];
+        if (du < 2) continue;
+        const bool heavy = du >= 64;
+        const int64_t hb = hoff[u], tb = toff[u];
+        const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
+        if (heavy) {
+            for (int i = lane; i < hl; i += 64) {
+                const uint32_t v = hadj[hb + i];
+                if (v == 0xFFFFu) continue;
+                const unsigned long long d = srow[v];
+                add(int((d >> 22) & 3), d & 0x3fffffull);
+            }
+            for (int i = lane; i < tl; i += 64) {
+                const int32_t v = tadj[tb + i];
+                const unsigned long long d = srow[v], t = trow[v];
+                add(int((d >> 22) & 3), d & 0x3fffffull);
+                if (i > 0) add(((t >> 22) & 3) ? 4 : 3, t & 0x3fffffull);
+            }
+        } else {  // hl (padded) + tl <= 64: one lane per member, as in k_tc_wave_hub
+            int32_t mv = 0x7fffffff;
+            if (lane < hl) {
+                const uint32_t x = hadj[hb + lane];
+                if (x != 0xFFFFu) mv = int32_t(x);
+            } else if (lane - hl < tl) mv = tadj[tb + (lane - hl)];
+            const unsigned long long valid = __ballot(mv != 0x7fffffff);
+            const unsigned long long below = uint64_t(__popcll(valid & ((1ull << lane) - 1ull)));
+            if (mv < bitset_limit && below > 0) {
+                const unsigned long long d = srow[mv], t = trow[mv];
+                const unsigned long long sb = 16ull * ((d & 0x3fffffull) + (mv >= 65535 ? (t & 0x3fffffull) : 0ull));
+                const int k = mv >= 65535 ? 4 : 0;
+                atomicAdd(&h[240 + k], below);
+                if (sb < 128ull * below) {
+                    atomicAdd(&h[241 + k], below);
+                    atomicAdd(&h[242 + k], sb);
+                }
+                atomicAdd(&h[243 + k], sb);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 248; i += 256)
+        if (h[i]) atomicAdd(&out[i], h[i]);
+}
+
 static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
     const int64_t span = end - first - part;
     return span <= 0 ? 0 : (span + nparts - 1) / nparts;
@@ -871,6 +962,25 @@ int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21) {
     hipLaunchKernelGGL(k_tc_breakdown, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, dbytes,
                        g->srow, g->trow, g->dense_limit, g->bitset_limit, g->n, acc);
     GMSX_HIP(hipMemcpyAsync(out13, acc, 21 * 8, hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipStreamSynchronize(s));
+    GMSX_HIP(hipGetLastError());
+    return GMSX_OK;
+}
+
+int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out248) {
+    if (!g || !out248) return GMSX_ERR_INVALID;
+    if (int rc = ensure_init()) return rc;
+    hipStream_t s = ctx().stream;
+    std::memset(out248, 0, 248 * sizeof(uint64_t));
+    if (g->n == 0) return GMSX_OK;
+    unsigned long long *acc = nullptr;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), 248 * 8));
+    struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g1{acc};
+    GMSX_HIP(hipMemsetAsync(acc, 0, 248 * 8, s));
+    const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
+    hipLaunchKernelGGL(k_tc_row_hist, dim3(unsigned(cus * 8)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow,
+                       g->bitset_limit, g->n, acc);
+    GMSX_HIP(hipMemcpyAsync(out248, acc, 248 * 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     GMSX_HIP(hipGetLastError());
     return GMSX_OK;
