@@ -289,7 +289,7 @@ class DeviceGraph:
 
     def tc_row_histogram(self):
         """(hist[5 classes][24 bins][rows, units], light[8]) — see gmsx_tc_row_histogram."""
-        out = np.zeros(248, dtype=np.uint64)
+        out = np.zeros(256, dtype=np.uint64)
         _check(lib().gmsx_tc_row_histogram(self._h, out), "gmsx_tc_row_histogram")
         return out[:240].reshape(5, 24, 2).astype(np.int64), out[240:].astype(np.int64)
 

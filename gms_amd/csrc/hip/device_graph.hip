@@ -357,6 +357,84 @@ __global__ void k_count_ge(int64_t n, const int32_t *__restrict__ keys, int32_t 
     out[0] = lo;
 }
 
+// ---- task lists of the heavy pivots (device_graph.hpp) -------------------------------------------------------------------------
+// The rule, evaluated once per oriented edge (u,v), u heavy: the edge is handed to v ("reverse") iff v is heavy too and u's rows are
+// strictly fewer 16-byte units than v's; otherwise u keeps it ("forward").
+__device__ __forceinline__ uint32_t row_units(const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow, int32_t x) {
+    return uint32_t(srow[x] & 0x3fffffull) + uint32_t(trow[x] & 0x3fffffull);
+}
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32_t *__restrict__ order, const int64_t *__restrict__ hoff,
+                                                    const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                    const int32_t *__restrict__ dplus, const unsigned long long *__restrict__ srow,
+                                                    const unsigned long long *__restrict__ trow, int two_sided, unsigned long long *__restrict__ cnt,
+                                                    const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ task,
+                                                    unsigned long long *__restrict__ reversed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    unsigned long long rev = 0;
+    for (int64_t pos = wave0; pos < n_heavy; pos += nwaves) {
+        const int32_t u = order[pos];
+        const int64_t hb = hoff[u], tb = toff[u];
+        const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
+        const uint32_t su = row_units(srow, trow, u);
+        const unsigned long long du_s = srow[u], du_t = trow[u];
+        int64_t fwd = FILL ? tbeg[u] : 0;  // next forward slot (wave-uniform)
+        for (int base = 0; base < hl + tl; base += 64) {
+            const int i = base + lane;
+            int32_t v = -1;
+            if (i < hl) {
+                const uint32_t x = hadj[hb + i];
+                if (x != 0xFFFFu) v = int32_t(x);
+            } else if (i < hl + tl) v = tadj[tb + i - hl];
+            bool reverse = false;
+            if (v >= 0 && two_sided && dplus[v] >= kHeavy) reverse = row_units(srow, trow, v) > su;
+            const unsigned long long fmask = __ballot(v >= 0 && !reverse);
+            if (FILL) {
+                if (v >= 0 && !reverse) {
+                    const int64_t slot = fwd + __popcll(fmask & ((1ull << lane) - 1ull));
+                    task[2 * slot] = srow[v];
+                    // the tail ids of the first tail member lie below every tail id of the pivot; a hub member has no tail part
+                    task[2 * slot + 1] = (i > hl) ? trow[v] : 0ull;
+                } else if (v >= 0) {
+                    const int64_t slot = tbeg[v + 1] - 1 - int64_t(atomicAdd(&cnt[v], 1ull));  // reverse entries fill v's list from its end
+                    task[2 * slot] = du_s;
+                    task[2 * slot + 1] = (toff[v + 1] > toff[v]) ? du_t : 0ull;  // a pivot without tail part has nothing to match
+                }
+                fwd += __popcll(fmask);
+            } else {
+                if (v >= 0 && reverse) {
+                    atomicAdd(&cnt[v], 1ull);
+                    ++rev;
+                }
+                fwd += __popcll(fmask);
+            }
+        }
+        if (!FILL && lane == 0 && fwd) atomicAdd(&cnt[u], (unsigned long long)fwd);
+    }
+    if (!FILL) {
+        for (int s = 32; s > 0; s >>= 1) rev += __shfl_down(rev, s);
+        if (lane == 0 && rev) atomicAdd(reversed, rev);
+    }
+}
+__global__ void k_item_counts(int64_t n_heavy, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, int64_t *__restrict__ items) {
+    const int64_t pos = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (pos > n_heavy) return;
+    if (pos == n_heavy) { items[pos] = 0; return; }
+    const int32_t w = order[pos];
+    items[pos] = (tbeg[w + 1] - tbeg[w] + kTaskChunk - 1) / kTaskChunk;
+}
+__global__ void k_item_fill(int64_t n_heavy, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, const int64_t *__restrict__ ioff,
+                            gmsx_task_item *__restrict__ items) {
+    const int64_t pos = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (pos >= n_heavy) return;
+    const int32_t w = order[pos];
+    const int64_t b = tbeg[w], e = tbeg[w + 1];
+    int64_t k = ioff[pos];
+    for (int64_t x = b; x < e; x += kTaskChunk, ++k) items[k] = gmsx_task_item{x, w, int32_t(min(int64_t(kTaskChunk), e - x))};
+}
+
 static int grid_for_waves(int64_t rows) {
     // wave-per-row grid-stride kernels: enough 256-thread blocks to fill the chip a few times over
     const int64_t want = (rows + 3) / 4;
@@ -398,6 +476,9 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->spool);
     (void)hipFree(g->trow);
     (void)hipFree(g->tdesc);
+    (void)hipFree(g->task);
+    (void)hipFree(g->tbeg);
+    (void)hipFree(g->titem);
     (void)hipFree(g->tpool);
     (void)hipFree(g->dplus);
     (void)hipFree(g->order);
@@ -656,6 +737,51 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         GMSX_HIP(hipMemcpyAsync(&top, g->sorted_dplus, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         GMSX_HIP(hipStreamSynchronize(s));
         g->max_dplus = top;
+    }
+
+    // 6. task lists of the heavy pivots: every oriented edge of a heavy pivot goes to the endpoint whose row is the bigger one
+    {
+        int64_t n_heavy = 0;
+        if (n > 0) {
+            int64_t *d_cnt = nullptr;
+            if (int rc = dmalloc(&d_cnt, 1, nullptr)) return rc;
+            DevGuard g_c{d_cnt};
+            hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, n, g->sorted_dplus, int32_t(kHeavy), d_cnt);
+            GMSX_HIP(hipStreamSynchronize(s));
+            GMSX_HIP(hipMemcpy(&n_heavy, d_cnt, sizeof(int64_t), hipMemcpyDeviceToHost));
+        }
+        int two_sided = 1;
+        if (const char *e = std::getenv("GMSX_TC_TWO_SIDED")) two_sided = std::atoi(e) != 0;  // 0 = every pivot keeps all its edges (A/B knob)
+        unsigned long long *cnt = nullptr;
+        if (int rc = dmalloc(&cnt, n + 2, nullptr)) return rc;
+        DevGuard g_cnt{cnt};
+        GMSX_HIP(hipMemsetAsync(cnt, 0, size_t(n + 2) * sizeof(unsigned long long), s));
+        if (int rc = dmalloc(&g->tbeg, n + 1, g)) return rc;
+        const int grid = grid_for_waves(n_heavy);
+        if (n_heavy > 0)
+            hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
+                               g->trow, two_sided, cnt, g->tbeg, static_cast<unsigned long long *>(nullptr), cnt + n + 1);
+        if (int rc = exclusive_scan_i64(reinterpret_cast<const int64_t *>(cnt), g->tbeg, n + 1, s)) return rc;
+        unsigned long long rev = 0;
+        GMSX_HIP(hipMemcpy(&g->task_entries, g->tbeg + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        GMSX_HIP(hipMemcpy(&rev, cnt + n + 1, sizeof(rev), hipMemcpyDeviceToHost));
+        g->task_reverse = int64_t(rev);
+        if (int rc = dmalloc(&g->task, 2 * g->task_entries + 2, g)) return rc;
+        GMSX_HIP(hipMemsetAsync(cnt, 0, size_t(n + 2) * sizeof(unsigned long long), s));  // now the reverse cursors
+        if (n_heavy > 0)
+            hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
+                               g->trow, two_sided, cnt, g->tbeg, g->task, cnt + n + 1);
+        int64_t *icnt = nullptr, *ioff = nullptr;
+        if (int rc = dmalloc(&icnt, n_heavy + 1, nullptr)) return rc;
+        DevGuard g_ic{icnt};
+        if (int rc = dmalloc(&ioff, n_heavy + 1, nullptr)) return rc;
+        DevGuard g_io{ioff};
+        hipLaunchKernelGGL(k_item_counts, dim3(unsigned(n_heavy / 256 + 1)), dim3(256), 0, s, n_heavy, g->order, g->tbeg, icnt);
+        if (int rc = exclusive_scan_i64(icnt, ioff, n_heavy + 1, s)) return rc;
+        GMSX_HIP(hipMemcpy(&g->task_items, ioff + n_heavy, sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (int rc = dmalloc(&g->titem, g->task_items + 1, g)) return rc;
+        if (n_heavy > 0) hipLaunchKernelGGL(k_item_fill, dim3(unsigned(n_heavy / 256 + 1)), dim3(256), 0, s, n_heavy, g->order, g->tbeg, ioff, g->titem);
+        GMSX_HIP(hipStreamSynchronize(s));
     }
     GMSX_HIP(hipStreamSynchronize(s));
     GMSX_HIP(hipGetLastError());

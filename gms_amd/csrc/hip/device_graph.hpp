@@ -30,6 +30,11 @@
 //   dplus int32[n]                     true out-degree (hub + tail) per rank id
 //   order int32[n]                     rank ids by decreasing d+ (work-sorted launch order, heavy first);
 //   sorted_dplus int32[n]              dplus[order[i]] (for bin boundaries)
+struct gmsx_task_item {
+    int64_t begin;  // first entry (index into task / 2)
+    int32_t pivot;  // rank id whose row is staged in LDS
+    int32_t count;  // entries of this chunk
+};
 struct gmsx_graph {
     int64_t n = 0, nnz = 0, m = 0;
     int64_t *off = nullptr;
@@ -63,6 +68,18 @@ struct gmsx_graph {
     // dependent 8-byte gathers into 0.5 GB tables (≈60 GB of 64-byte lines per pass at scale 26); hub members keep srow[v]
     // (65535 entries: L2-resident).
     unsigned long long *tdesc = nullptr;
+    // TASK LISTS of the heavy pivots (d+ >= 64; tc.hip).  |N+(u) ∩ N+(v)| of an oriented edge (u,v) can be counted with either
+    // endpoint as the pivot (its row as bitmap + tail set in LDS) and the other one streamed; the pass streams the SMALLER row
+    // (fewer 16-byte units).  So every vertex w owns a list of (srow, trow) descriptor pairs — one per edge it is the pivot of:
+    // members v of its own row whose rows are the smaller ones ("forward"), and in-neighbours u that hand their edge over because
+    // their own row is smaller than w's ("reverse", only towards heavy w) — and the heavy-pivot kernel walks work items = chunks
+    // of at most kTaskChunk entries of one list.  Light pivots keep all their edges (k_tc_wave_hub / k_tc_wave).
+    unsigned long long *task = nullptr;  // [2 * task_entries]: srow / trow descriptor of the streamed row (trow 0 = no match possible)
+    int64_t task_entries = 0;
+    int64_t *tbeg = nullptr;             // [n + 1] first entry of vertex w's list
+    struct gmsx_task_item *titem = nullptr;
+    int64_t task_items = 0;
+    int64_t task_reverse = 0;            // entries handed over to the other endpoint
     unsigned long long *trow = nullptr;
     uint32_t *tpool = nullptr;
     int64_t tpool_units = 0;
@@ -93,6 +110,8 @@ static constexpr int kHub = 65535;         // rank ids below this live in the 16
 static constexpr int kBitmapWords = 2048;  // 65536-bit LDS bitmap over the hub id range
 static constexpr int kAccWords = 64 * 16 + 16;
 static constexpr int kFormList = 0, kFormBitset = 1, kFormDelta = 2;
+static constexpr int kTaskChunk = 1024;  // entries per work item of the heavy-pivot kernel
+static constexpr int kHeavy = 64;        // d+ from which a pivot runs on the workgroup kernel
 static constexpr int kDeltaIds = 14;  // ids per full 16-byte delta unit  // size of gmsx_graph::acc in u64
 
 // words of the bitset container of hub rank id v (covers ids [0, v)), rounded to 16 bytes

@@ -300,18 +300,20 @@ __device__ __forceinline__ uint32_t scan_trows_probe(Probe probe, const uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// Workgroup per pivot (d+ >= 64).  256 threads = 4 waves share the pivot's bitmap + tail set; wave w streams the
-// rows of the pivot-list entries w, w+4, ….  LDS: 8 KB hub bitmap + 4 KB tail filter + 2^kBlockLog x 4 B hash; a tail longer
-// than half the table is processed in tiles.
+// Heavy pivots (d+ >= 64): one workgroup per WORK ITEM = up to kTaskChunk entries of one pivot's task list (device_graph.hpp).  The
+// 256 threads = 4 waves stage the pivot's row — hub part as the 65536-bit bitmap, tail part as filter + hash set, tiled if longer than
+// half the table — and wave w streams the rows of entries 64w … 64w+63 of every 256: their hub stream rows against the bitmap, then
+// (pivots with a tail part) their tail stream rows against the set.  An entry is either a member of the pivot's own row or an
+// in-neighbour that handed the edge over because its row is the smaller one: the kernel cannot tell and need not.
+// LDS: 8 KB bitmap + 4 KB filter + 2^kBlockLog x 4 B table.
 // ---------------------------------------------------------------------------------------------
 static constexpr int kBlockLog = 10;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                  const unsigned long long *__restrict__ srow, const uint32_t *__restrict__ spool,
-                                                  const unsigned long long *__restrict__ tdesc, const uint32_t *__restrict__ tpool,
+                                                  const uint32_t *__restrict__ spool, const uint32_t *__restrict__ tpool,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
-                                                  const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
-                                                  int part, unsigned long long *__restrict__ acc) {
+                                                  const unsigned long long *__restrict__ task, const gmsx_task_item *__restrict__ items,
+                                                  int64_t n_items, int nparts, int part, unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords];
     __shared__ __attribute__((aligned(16))) int32_t tbl[1 << kBlockLog];
     __shared__ uint32_t flt[kFilterWords];
@@ -319,11 +321,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     constexpr int SIZE = 1 << kBlockLog, SHIFT = 32 - kBlockLog, TILE = SIZE / 2;
     constexpr uint32_t MASK = SIZE - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t pos = first + int64_t(blockIdx.x) * nparts + part;
-    if (pos >= end) return;  // uniform per block
-    const int32_t u = order[pos];
+    const int64_t pos = int64_t(blockIdx.x) * nparts + part;
+    if (pos >= n_items) return;  // uniform per block
+    const gmsx_task_item it = items[pos];
+    const int32_t u = it.pivot;
     const int64_t hb = hoff[u], tb = toff[u];
     const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
+    const int ne = it.count;
+    const unsigned long long *__restrict__ ent = task + 2 * it.begin;
 
     for (int i = tid; i < kBitmapWords; i += 256) bm[i] = 0;
     __syncthreads();
@@ -334,25 +339,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __syncthreads();
 
     unsigned long long cnt = 0;
-    // (a) rows of the hub part of the pivot list: pure hub containers (a hub vertex has no tail container), each in its stream
-    //     form — bitset, 16-bit list or byte-delta — described by ONE 8-byte srow entry
-    for (int base = 0; base < hl; base += 256) {
-        const int idx = base + lane * 4 + wave;
-        unsigned long long desc = 0;
-        if (idx < hl) {
-            const uint32_t v = hadj[hb + idx];
-            if (v != 0xFFFFu) desc = srow[v];
-        }
+    // hub stream rows of the entries against the bitmap
+    for (int base = 0; base < ne; base += 256) {
+        const int idx = base + lane * 4 + wave;  // interleaved: the four waves see the same mix of rows
+        const unsigned long long desc = idx < ne ? ent[2 * idx] : 0ull;
         cnt += scan_srows(bm, spool, desc, lane);
     }
-    // (b) rows of the tail part of the pivot list: their hub containers against the bitmap …
-    for (int base = 0; base < tl; base += 256) {
-        const int idx = base + lane * 4 + wave;
-        unsigned long long desc = 0;
-        if (idx < tl) desc = tdesc[2 * (tb + idx)];  // = srow[tadj[tb + idx]], stored next to the entry
-        cnt += scan_srows(bm, spool, desc, lane);
-    }
-    // (c) … and their tail containers against the hash set of the pivot's tail part
+    // tail stream rows against the hash set of the pivot's tail part
     for (int t0 = 0; t0 < tl; t0 += TILE) {
         const int tn = min(TILE, tl - t0);
         __syncthreads();
@@ -365,12 +358,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             atomicOr(&flt[(uint32_t(t) >> 5) & (kFilterWords - 1)], 1u << (uint32_t(t) & 31u));
         }
         __syncthreads();
-        for (int base = 0; base < tl; base += 256) {
+        for (int base = 0; base < ne; base += 256) {
             const int idx = base + lane * 4 + wave;
-            unsigned long long desc = 0;
-            if (idx > 0 && idx < tl) desc = tdesc[2 * (tb + idx) + 1];  // = trow[tadj[…]]; idx 0: the first tail member's tail ids lie below every tail id of the pivot
-            const int rows = min(64, (tl - base - wave + 3) >> 2);
-            cnt += scan_trows(flt, tbl, MASK, SHIFT, tpool, desc, rows, lane);
+            const unsigned long long desc = idx < ne ? ent[2 * idx + 1] : 0ull;
+            cnt += scan_trows(flt, tbl, MASK, SHIFT, tpool, desc, 64, lane);
         }
     }
     for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
@@ -603,13 +594,14 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
     }
 }
 
-// units / probes / algorithmic stream bytes of a partition (untimed bookkeeping for gmsx_stats): wave per pivot position.
-// out[2] follows what the three count kernels read, byte for byte, assuming no on-chip reuse:
-//   pivot u (d+ >= 2): its own hub + tail containers once;
-//   heavy pivot (d+ >= 64, k_tc_block): the stream row (whole 16-byte units of the cheapest of bitset / 16-bit list / byte-delta) of
-//       every member, and (except for the first tail member) the 32-bit tail list of every tail member;
-//   light pivot (k_tc_wave_hub + k_tc_wave): one 4-byte word gathered per (member with a bitset, smaller member) pair; members beyond
-//       bitset_limit streamed as above.
+// units / probes / algorithmic stream bytes of a shard (untimed bookkeeping for gmsx_stats).  out[2] follows what the count kernels
+// read, byte for byte, assuming no on-chip reuse:
+//   light pivot u (2 <= d+ < 64; k_tc_stats, wave per pivot position): its own containers once; one 4-byte word gathered per (member
+//       with a bitset, smaller member) pair; the stream rows of the members beyond bitset_limit;
+//   work item of a heavy pivot (k_tc_item_stats, wave per item): the pivot's containers once; per entry 16 bytes of descriptors and the
+//       hub + tail stream rows they describe (whole 16-byte units).
+// out[0] = oriented edges counted by the shard (every edge of a light or idle pivot at the pivot, every edge of a heavy pivot where its
+// entry lives); out[1] = id slots probed (per unit: 8 list, 14 byte-delta, 4 bitset words; 4 / 6 tail ids; one per gathered word).
 __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
@@ -620,38 +612,76 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
     unsigned long long units = 0, probes = 0, bytes = 0;
+    auto slots = [](unsigned long long d, bool tail) -> unsigned long long {
+        const unsigned long long n = d & 0x3fffffull, f = (d >> 22) & 3ull;
+        return n * (tail ? (f ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : 4ull));
+    };
     for (int64_t q = wave0;; q += nwaves) {
         const int64_t pos = first + q * nparts + part;
         if (pos >= end) break;
         const int32_t u = order[pos];
         const int du = dplus[u];
+        if (du >= kHeavy) continue;  // counted per work item
         const int hl = int(hoff[u + 1] - hoff[u]), tl = int(toff[u + 1] - toff[u]);
         if (lane == 0) {
             units += (unsigned long long)du;
             if (du >= 2) bytes += 2ull * hl + 4ull * tl;
         }
-        const bool heavy = du >= 64, work = du >= 2;
+        if (du < 2) continue;
         for (int64_t j = hoff[u] + lane; j < hoff[u + 1]; j += 64) {
             const uint32_t v = hadj[j];
             if (v == 0xFFFFu) continue;
-            probes += (unsigned long long)dplus[v];
-            if (!work) continue;
-            if (heavy) {
-                bytes += 16ull * (srow[v] & 0x3fffffull);  // the stream row: whole 16-byte units in its chosen form
-            } else if (int32_t(v) < bitset_limit) {
+            if (int32_t(v) < bitset_limit) {
                 bytes += 4ull * (unsigned long long)(j - hoff[u]);  // one gathered word per member below v
+                probes += (unsigned long long)(j - hoff[u]);
             }
         }
         for (int64_t j = toff[u] + lane; j < toff[u + 1]; j += 64) {
             const int32_t v = tadj[j];
-            probes += (unsigned long long)dplus[v];
-            if (!work) continue;
-            if (!heavy && v < bitset_limit) {  // near-tail member of a light pivot: gathers, nothing streamed
+            if (v < bitset_limit) {  // near-tail member: gathers, nothing streamed
                 bytes += 4ull * (unsigned long long)(du - tl + (j - toff[u]));
+                probes += (unsigned long long)(du - tl + (j - toff[u]));
                 continue;
             }
-            bytes += 16ull * (srow[v] & 0x3fffffull);                      // heavy and light pivots stream the same stream rows
-            if (j > toff[u]) bytes += 16ull * (trow[v] & 0x3fffffull);
+            const unsigned long long d = srow[v], t = j > toff[u] ? trow[v] : 0ull;
+            bytes += 16ull * ((d & 0x3fffffull) + (t & 0x3fffffull));
+            probes += slots(d, false) + slots(t, true);
+        }
+    }
+    for (int s = 32; s > 0; s >>= 1) {
+        units += __shfl_down(units, s);
+        probes += __shfl_down(probes, s);
+        bytes += __shfl_down(bytes, s);
+    }
+    if (lane == 0) {
+        if (units) atomicAdd(&out[0], units);
+        if (probes) atomicAdd(&out[1], probes);
+        if (bytes) atomicAdd(&out[2], bytes);
+    }
+}
+__global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict__ hoff, const int64_t *__restrict__ toff,
+                                                       const unsigned long long *__restrict__ task, const gmsx_task_item *__restrict__ items,
+                                                       int64_t n_items, int nparts, int part, unsigned long long *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    unsigned long long units = 0, probes = 0, bytes = 0;
+    auto slots = [](unsigned long long d, bool tail) -> unsigned long long {
+        const unsigned long long n = d & 0x3fffffull, f = (d >> 22) & 3ull;
+        return n * (tail ? (f ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : 4ull));
+    };
+    for (int64_t q = wave0;; q += nwaves) {
+        const int64_t pos = q * nparts + part;
+        if (pos >= n_items) break;
+        const gmsx_task_item it = items[pos];
+        if (lane == 0) {
+            units += (unsigned long long)it.count;
+            bytes += 2ull * (unsigned long long)(hoff[it.pivot + 1] - hoff[it.pivot]) + 4ull * (unsigned long long)(toff[it.pivot + 1] - toff[it.pivot]);
+        }
+        for (int i = lane; i < it.count; i += 64) {
+            const unsigned long long d = task[2 * (it.begin + i)], t = task[2 * (it.begin + i) + 1];
+            bytes += 16ull + 16ull * ((d & 0x3fffffull) + (t & 0x3fffffull));
+            probes += slots(d, false) + slots(t, true);
         }
     }
     for (int s = 32; s > 0; s >>= 1) {
@@ -747,7 +777,8 @@ __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict_
 // group works on one row, so a row of n units keeps min(n,16)/16 of its lanes busy), and what the light pivots' gathers cost against
 // streaming the same member's rows.  out[(cls*24 + bin)*2 + {0,1}] = rows, units; cls: hub rows as list / bitset / byte-delta, tail
 // rows as list / delta; bin: 1…16 units exactly, then 17-32, 33-64, … 1025+.  out[240…]: light pivots — members with a bitset:
-// gathered words, words of those whose rows would be cheaper to stream at 128 B per gathered word, the stream bytes of those.
+// gathered words, words of those whose rows would be cheaper to stream at 128 B per gathered word, the stream bytes of those;
+// out[248…251]: Σ over oriented edges (u,v) of the stream units of v, and of min(units of u, units of v), heavy then light pivots u.
 __device__ __forceinline__ int hist_bin(unsigned long long units) {
     if (units <= 16) return int(units) - 1;
     int b = 16;
@@ -759,8 +790,8 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
                                                      const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
                                                      const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
                                                      int32_t bitset_limit, int64_t end, unsigned long long *__restrict__ out) {
-    __shared__ unsigned long long h[248];
-    for (int i = threadIdx.x; i < 248; i += 256) h[i] = 0;
+    __shared__ unsigned long long h[256];
+    for (int i = threadIdx.x; i < 256; i += 256) h[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -778,6 +809,23 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
         const bool heavy = du >= 64;
         const int64_t hb = hoff[u], tb = toff[u];
         const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
+        {  // either endpoint of an oriented edge can be the streamed side: Σ s(v) (what the pass does) against Σ min(s(u), s(v))
+            const unsigned long long su = (srow[u] & 0x3fffffull) + (trow[u] & 0x3fffffull);
+            unsigned long long cur = 0, best = 0;
+            for (int i = lane; i < hl + tl; i += 64) {
+                int32_t v;
+                if (i < hl) {
+                    const uint32_t x = hadj[hb + i];
+                    if (x == 0xFFFFu) continue;
+                    v = int32_t(x);
+                } else v = tadj[tb + i - hl];
+                const unsigned long long sv = (srow[v] & 0x3fffffull) + (trow[v] & 0x3fffffull);
+                cur += sv;
+                best += min(su, sv);
+            }
+            atomicAdd(&h[heavy ? 248 : 250], cur);
+            atomicAdd(&h[heavy ? 249 : 251], best);
+        }
         if (heavy) {
             for (int i = lane; i < hl; i += 64) {
                 const uint32_t v = hadj[hb + i];
@@ -813,7 +861,7 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 248; i += 256)
+    for (int i = threadIdx.x; i < 256; i += 256)
         if (h[i]) atomicAdd(&out[i], h[i]);
 }
 
@@ -837,7 +885,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     int launches = 0;
     const int cus = c.compute_units > 0 ? c.compute_units : 256;
     const int64_t cap_blocks = int64_t(cus) * 16;
-    const int64_t cnt_heavy = part_count(0, n_block, nparts, part), cnt_light = part_count(n_block, n_work, nparts, part);
+    const int64_t cnt_heavy = part_count(0, g->task_items, nparts, part), cnt_light = part_count(n_block, n_work, nparts, part);
     // CO-SCHEDULING.  The heavy-pivot kernel is bound by beyond-L2 bandwidth, the two light-pivot kernels by memory latency
     // (k_tc_wave) and by the gather rate of the texture addressers (k_tc_wave_hub): run back to back, each leaves the resource the
     // others need idle.  So the light kernels go to two side streams FIRST, with grids of only a few workgroups per CU (they are
@@ -882,8 +930,8 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     };
     if (co) launch_light();
     if (cnt_heavy > 0) {
-        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt_heavy)), dim3(256), 0, s, g->hoff, g->hadj, g->srow, g->spool, g->tdesc, g->tpool, g->toff, g->tadj,
-                           g->order, int64_t(0), n_block, nparts, part, acc);
+        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt_heavy)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->tpool, g->toff, g->tadj, g->task, g->titem,
+                           g->task_items, nparts, part, acc);
         ++launches;
     }
     if (!co) launch_light();
@@ -904,6 +952,11 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
             hipLaunchKernelGGL(k_tc_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus,
                                g->order, g->srow, g->trow, g->bitset_limit, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
+        }
+        if (cnt_heavy > 0) {
+            const int64_t blocks = std::min<int64_t>((cnt_heavy + 3) / 4, cap_blocks);
+            hipLaunchKernelGGL(k_tc_item_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->toff, g->task, g->titem, g->task_items, nparts, part,
+                               acc + kAccSlots * kAccStride);
         }
     }
     unsigned long long host[kAccSlots * kAccStride + 3];
@@ -967,20 +1020,21 @@ int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21) {
     return GMSX_OK;
 }
 
-int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out248) {
+int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out256) {
+    uint64_t *out248 = out256;
     if (!g || !out248) return GMSX_ERR_INVALID;
     if (int rc = ensure_init()) return rc;
     hipStream_t s = ctx().stream;
-    std::memset(out248, 0, 248 * sizeof(uint64_t));
+    std::memset(out248, 0, 256 * sizeof(uint64_t));
     if (g->n == 0) return GMSX_OK;
     unsigned long long *acc = nullptr;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), 248 * 8));
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), 256 * 8));
     struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g1{acc};
-    GMSX_HIP(hipMemsetAsync(acc, 0, 248 * 8, s));
+    GMSX_HIP(hipMemsetAsync(acc, 0, 256 * 8, s));
     const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
     hipLaunchKernelGGL(k_tc_row_hist, dim3(unsigned(cus * 8)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow,
                        g->bitset_limit, g->n, acc);
-    GMSX_HIP(hipMemcpyAsync(out248, acc, 248 * 8, hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipMemcpyAsync(out248, acc, 256 * 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     GMSX_HIP(hipGetLastError());
     return GMSX_OK;

@@ -176,9 +176,10 @@ int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21);
 /* Diagnostics: the stream rows read by the heavy pivots as a histogram over row length in 16-byte units — out[(cls*24 + bin)*2] rows,
  * [+1] units; cls 0..4 = hub rows as list / bitset / byte-delta, tail rows as list / delta; bin = 1 … 16 units exactly, then 17-32,
  * 33-64, … 1025+ — and, out[240..247], for the light pivots' members with a bitset (hub range, then near tail): gathered words, the
- * words and stream bytes of the members whose rows would be cheaper to stream (at 128 B per gathered word), stream bytes of all.
- * 248 values, host. */
-int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out248);
+ * words and stream bytes of the members whose rows would be cheaper to stream (at 128 B per gathered word), stream bytes of all;
+ * out[248..251]: Σ over oriented edges (u,v) of the stream units of v's rows and of min(units of u's rows, units of v's rows), for
+ * heavy then light pivots u (out[252..255] reserved).  256 values, host. */
+int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out256);
 /* Par::vertex_count2 / vertex_count2_once (parallel/vertex.h:14-49): counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| (= 2·triangles at u),
  * indexed by the vertex ids of the uploaded CSR.  Runs on the k = 3 bit-matrix kernels (one atomic per pivot member); graphs
  * with d+ > 8192 fall back to one full-row intersect_count per CSR entry. */

@@ -30,4 +30,7 @@ for k, lab in ((0, "hub-range members"), (4, "near-tail members")):
     w, cw, cs, sb = (int(x) for x in light[k:k + 4])
     print(f"light pivots, {lab}: gathered words {w/1e9:.3f} G (= {w*128/1e9:.1f} GB at 128 B each); cheaper to stream: {cw/1e9:.3f} G words "
           f"({cw*128/1e9:.1f} GB) -> {cs/1e9:.1f} GB streamed; streaming all would be {sb/1e9:.1f} GB")
+for k, lab in ((8, "heavy pivots"), (10, "light pivots")):
+    cur, best = int(light[k]), int(light[k + 1])
+    print(f"{lab}: streaming the member's rows for every oriented edge = {cur*16/1e9:.1f} GB; streaming the smaller endpoint's rows = {best*16/1e9:.1f} GB")
 print(json.dumps({"scale": scale, "hist": hist.tolist(), "light": light.tolist()}))
