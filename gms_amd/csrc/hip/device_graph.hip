@@ -357,6 +357,95 @@ __global__ void k_count_ge(int64_t n, const int32_t *__restrict__ keys, int32_t 
     out[0] = lo;
 }
 
+// ---- inline rows (build step 4c / 5b) --------------------------------------------------------------------------------------------
+static constexpr int kInlineChunk = 64;  // units of an inline row per task entry
+__device__ __forceinline__ bool takes_inline(int32_t v, int32_t inline_limit, const int32_t *__restrict__ dplus) {
+    return v < inline_limit || dplus[v] >= kHeavy;
+}
+// Wave per light pivot u (positions [first, end) of `order`), one lane per member (hub part — padded at its end — in the low lanes,
+// tail part behind it, both ascending; hl + tl <= 64).  COUNT: ids handed over per receiving member; FILL: copies them (cnt_* are
+// the cursors then) and blanks the tdesc descriptors of the far members that were handed over, so that k_tc_wave skips them.
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_inline_rows(int64_t first, int64_t end, const int32_t *__restrict__ order, const int64_t *__restrict__ hoff,
+                                                     const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                     const int32_t *__restrict__ dplus, int32_t inline_limit, unsigned long long *__restrict__ cnt_h,
+                                                     unsigned long long *__restrict__ cnt_t, const int64_t *__restrict__ ihoff,
+                                                     const int64_t *__restrict__ itoff, int64_t base_h, uint16_t *__restrict__ pool_h, int64_t base_t,
+                                                     int32_t *__restrict__ pool_t, unsigned long long *__restrict__ tdesc) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t pos = first + wave0; pos < end; pos += nwaves) {
+        const int32_t u = order[pos];
+        const int64_t hb = hoff[u], tb = toff[u];
+        const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
+        int32_t mv = 0x7fffffff;
+        if (lane < hl) {
+            const uint32_t x = hadj[hb + lane];
+            if (x != 0xFFFFu) mv = int32_t(x);
+        } else if (lane - hl < tl) {
+            mv = tadj[tb + (lane - hl)];
+        }
+        const bool valid = mv != 0x7fffffff, is_tail = valid && lane >= hl;
+        const unsigned long long vmask = __ballot(valid);
+        const int nhub = __popcll(__ballot(valid && lane < hl));  // the valid hub members are the lanes [0, nhub)
+        const int below = __popcll(vmask & ((1ull << lane) - 1ull));
+        const bool give = valid && below > 0 && takes_inline(mv, inline_limit, dplus);
+        const int nh = give ? (is_tail ? nhub : below) : 0;
+        const int nt = give && is_tail ? lane - hl : 0;
+        if (!FILL) {
+            if (nh) atomicAdd(&cnt_h[mv], (unsigned long long)nh);
+            if (nt) atomicAdd(&cnt_t[mv], (unsigned long long)nt);
+        } else {
+            int64_t at_h = 0, at_t = 0;
+            if (nh) at_h = (base_h + ihoff[mv]) * 8 + int64_t(atomicAdd(&cnt_h[mv], (unsigned long long)nh));
+            if (nt) at_t = (base_t + itoff[mv]) * 4 + int64_t(atomicAdd(&cnt_t[mv], (unsigned long long)nt));
+            for (int k = 0; k < nhub; ++k) {  // wave-uniform trip count
+                const int32_t x = __shfl(mv, k);
+                if (k < nh) pool_h[at_h + k] = uint16_t(x);
+            }
+            for (int k = 0; k < tl; ++k) {
+                const int32_t x = __shfl(mv, hl + k);
+                if (k < nt) pool_t[at_t + k] = x;
+            }
+            if (give && is_tail && mv >= inline_limit) {  // a far member, handed over because it is heavy
+                tdesc[2 * (tb + lane - hl)] = 0ull;
+                tdesc[2 * (tb + lane - hl) + 1] = 0ull;
+            }
+        }
+    }
+}
+__global__ void k_inline_units(int64_t n, const unsigned long long *__restrict__ ids_h, const unsigned long long *__restrict__ ids_t,
+                               int64_t *__restrict__ units_h, int64_t *__restrict__ units_t) {
+    const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (v > n) return;
+    units_h[v] = v < n ? int64_t((ids_h[v] + 7) / 8) : 0;
+    units_t[v] = v < n ? int64_t((ids_t[v] + 3) / 4) : 0;
+}
+__device__ __forceinline__ int64_t inline_chunks(const int64_t *__restrict__ ihoff, const int64_t *__restrict__ itoff, int64_t v) {
+    const int64_t uh = ihoff[v + 1] - ihoff[v], ut = itoff[v + 1] - itoff[v];
+    return (max(uh, ut) + kInlineChunk - 1) / kInlineChunk;
+}
+// the inline entries of every receiver: chunk k of its hub inline row and chunk k of its tail inline row share entry k of its list
+template <bool FILL>
+__global__ void k_inline_entries(int64_t n, const int64_t *__restrict__ ihoff, const int64_t *__restrict__ itoff, int64_t base_h, int64_t base_t,
+                                 unsigned long long *__restrict__ cnt, const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ task) {
+    const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const int64_t c = inline_chunks(ihoff, itoff, v);
+    if (!FILL) {
+        cnt[v] = (unsigned long long)c;
+        return;
+    }
+    const int64_t uh = ihoff[v + 1] - ihoff[v], ut = itoff[v + 1] - itoff[v];
+    for (int64_t k = 0; k < c; ++k) {
+        const int64_t o = k * kInlineChunk;
+        const int64_t nh = min(int64_t(kInlineChunk), uh - o), nt = min(int64_t(kInlineChunk), ut - o);
+        task[2 * (tbeg[v] + k)] = nh > 0 ? ((unsigned long long)(base_h + ihoff[v] + o) << 24) | ((unsigned long long)kFormList << 22) | (unsigned long long)nh : 0ull;
+        task[2 * (tbeg[v] + k) + 1] = nt > 0 ? ((unsigned long long)(base_t + itoff[v] + o) << 24) | (unsigned long long)nt : 0ull;
+    }
+}
+
 // ---- task lists of the heavy pivots (device_graph.hpp) -------------------------------------------------------------------------
 // The rule, evaluated once per oriented edge (u,v), u heavy: the edge is handed to v ("reverse") iff v is heavy too and u's rows are
 // strictly fewer 16-byte units than v's; otherwise u keeps it ("forward").
@@ -369,7 +458,8 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                                                     const int32_t *__restrict__ dplus, const unsigned long long *__restrict__ srow,
                                                     const unsigned long long *__restrict__ trow, int two_sided, unsigned long long *__restrict__ cnt,
                                                     const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ task,
-                                                    unsigned long long *__restrict__ reversed) {
+                                                    unsigned long long *__restrict__ reversed, const int64_t *__restrict__ ihoff,
+                                                    const int64_t *__restrict__ itoff) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -380,7 +470,7 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
         const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
         const uint32_t su = row_units(srow, trow, u);
         const unsigned long long du_s = srow[u], du_t = trow[u];
-        int64_t fwd = FILL ? tbeg[u] : 0;  // next forward slot (wave-uniform)
+        int64_t fwd = FILL ? tbeg[u] + inline_chunks(ihoff, itoff, u) : 0;  // next forward slot (wave-uniform); the inline entries come first
         for (int base = 0; base < hl + tl; base += 64) {
             const int i = base + lane;
             int32_t v = -1;
@@ -418,21 +508,26 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
         if (lane == 0 && rev) atomicAdd(reversed, rev);
     }
 }
-__global__ void k_item_counts(int64_t n_heavy, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, int64_t *__restrict__ items) {
+// work items: per vertex (in launch order) first the chunks of its inline entries (count < 0: they stand for no edge of their own in
+// the bookkeeping), then the chunks of its forward + reverse entries
+__global__ void k_item_counts(int64_t n, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, const int64_t *__restrict__ ihoff,
+                              const int64_t *__restrict__ itoff, int64_t *__restrict__ items) {
     const int64_t pos = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (pos > n_heavy) return;
-    if (pos == n_heavy) { items[pos] = 0; return; }
+    if (pos > n) return;
+    if (pos == n) { items[pos] = 0; return; }
     const int32_t w = order[pos];
-    items[pos] = (tbeg[w + 1] - tbeg[w] + kTaskChunk - 1) / kTaskChunk;
+    const int64_t all = tbeg[w + 1] - tbeg[w], inl = inline_chunks(ihoff, itoff, w);
+    items[pos] = (inl + kTaskChunk - 1) / kTaskChunk + (all - inl + kTaskChunk - 1) / kTaskChunk;
 }
-__global__ void k_item_fill(int64_t n_heavy, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, const int64_t *__restrict__ ioff,
-                            gmsx_task_item *__restrict__ items) {
+__global__ void k_item_fill(int64_t n, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, const int64_t *__restrict__ ihoff,
+                            const int64_t *__restrict__ itoff, const int64_t *__restrict__ ioff, gmsx_task_item *__restrict__ items) {
     const int64_t pos = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (pos >= n_heavy) return;
+    if (pos >= n) return;
     const int32_t w = order[pos];
-    const int64_t b = tbeg[w], e = tbeg[w + 1];
+    const int64_t b = tbeg[w], e = tbeg[w + 1], m = b + inline_chunks(ihoff, itoff, w);
     int64_t k = ioff[pos];
-    for (int64_t x = b; x < e; x += kTaskChunk, ++k) items[k] = gmsx_task_item{x, w, int32_t(min(int64_t(kTaskChunk), e - x))};
+    for (int64_t x = b; x < m; x += kTaskChunk, ++k) items[k] = gmsx_task_item{x, w, -int32_t(min(int64_t(kTaskChunk), m - x))};
+    for (int64_t x = m; x < e; x += kTaskChunk, ++k) items[k] = gmsx_task_item{x, w, int32_t(min(int64_t(kTaskChunk), e - x))};
 }
 
 static int grid_for_waves(int64_t rows) {
@@ -608,25 +703,11 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     if (g->hub_entries >= (int64_t(1) << 32) || n >= (int64_t(1) << 32)) g->rows_sorted = false;
     if (g->tail_entries == 0 && g->hub_entries < (int64_t(1) << 32) && n < (int64_t(1) << 32)) g->rows_sorted = true;
 
-    // 4b. bitset containers: every row of rank id < R as a bitmap over [0, v).  The hub rows (v < hub_limit) use them as the dense
-    //     streaming form and as gather targets; the near-tail rows (hub_limit <= v < R) only as gather targets of the light pivots.
-    //     R^2/16 bytes: 268 MB for the hub range, 4.3 GB for R = 262144 — HBM is what this box has plenty of (288 GB).
+    // 4b. bitset containers: every hub row (rank id < hub_limit) as a bitmap over [0, v) — the dense streaming form of the triangle
+    //     kernel and the edge test of the k-clique recursion.  <= 268 MB.
     g->dense_limit = int32_t(std::min<int64_t>(n, hub_limit));
+    g->bitset_limit = g->dense_limit;
     {
-        // measured on MI355X (tools/tc_bitset_sweep.py): scale 26 (n = 67 M) 277 ms at R = 65535, 264 at 262144, 262 at 524288;
-        // scale 24 (n = 17 M) is fastest with the hub range only — the near tail pays once rows are long and pivots many
-        int64_t want = std::min<int64_t>(524288, n / 256);
-        bool forced = false;
-        if (const char *e = std::getenv("GMSX_BITSET_LIMIT")) {  // tuning / test knob
-            const long long v = std::atoll(e);
-            if (v >= 0 && v <= (1ll << 22)) { want = v; forced = true; }
-        }
-        if (!forced && ((flags >> 8) & 0xffffu)) want = int64_t(4) * hub_limit;  // hub-limit test hook: near AND far tail on small graphs
-        if (!g->rows_sorted) want = 0;                                                       // positions in tail rows need sorted rows
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)  // never more than a quarter of what is free right now
-            while (want > hub_limit && uint64_t(want) * uint64_t(want) / 16u > free_b / 4u) want /= 2;
-        g->bitset_limit = int32_t(std::min<int64_t>(n, std::max<int64_t>(want, g->dense_limit)));
         const int32_t K = g->bitset_limit;
         int64_t *sizes = nullptr;
         if (int rc = dmalloc(&sizes, int64_t(K) + 1, nullptr)) return rc;
@@ -639,11 +720,95 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         GMSX_HIP(hipMemsetAsync(g->bmpool, 0, size_t(g->bmpool_words + 4) * sizeof(uint32_t), s));
         if (K > 0 && g->bmpool_words > 0)
             hipLaunchKernelGGL(k_dense_fill, dim3(grid_for_waves(K)), dim3(256), 0, s, K, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool);
+    }
+    // 4c. INLINE LIMIT.  A light pivot u (2 <= d+ < 64) hands the edge (u,v) over to v whenever v is a pivot of the workgroup kernel
+    //     anyway (d+ >= 64) or a popular target (rank id < inline_limit): the members of u below v — the only ids of N+(u) that can
+    //     be in N+(v) — are copied into v's INLINE ROWS, two more stream rows of v (16-bit hub ids / 32-bit tail ids, list form) that
+    //     v's work items scan against v's own row like any other entry.  A 20-byte row behind a pointer would cost a 128-byte line
+    //     per fetch; inline it is streamed.  Only the far, light members stay with the light-pivot kernel (k_tc_wave).
+    {
+        int64_t want = std::min<int64_t>(524288, n / 256);
+        bool forced = false;
+        if (const char *e = std::getenv("GMSX_INLINE_LIMIT")) {  // tuning / test knob
+            const long long v = std::atoll(e);
+            if (v >= 0 && v <= (1ll << 31) - 1) { want = v; forced = true; }
+        }
+        if (!forced && ((flags >> 8) & 0xffffu)) want = int64_t(4) * hub_limit;  // hub-limit test hook: near AND far tail on small graphs
+        g->inline_limit = int32_t(std::min<int64_t>(n, std::max<int64_t>(want, g->dense_limit)));
         if (int rc = dmalloc(&g->tsplit, n, g)) return rc;
-        if (n > 0) hipLaunchKernelGGL(k_tail_split, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->toff, g->tadj, K, g->tsplit);
+        if (n > 0) hipLaunchKernelGGL(k_tail_split, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->toff, g->tadj, g->inline_limit, g->tsplit);
+    }
+
+    // 5. work-sorted launch order: rank ids by decreasing d+
+    if (int rc = dmalloc(&g->order, n, g)) return rc;
+    if (int rc = dmalloc(&g->sorted_dplus, n, g)) return rc;
+    if (n > 0) {
+        int32_t *keys_in = nullptr, *vals_in = nullptr;
+        if (int rc = dmalloc(&keys_in, n, nullptr)) return rc;
+        DevGuard g_ki{keys_in};
+        if (int rc = dmalloc(&vals_in, n, nullptr)) return rc;
+        DevGuard g_vi{vals_in};
+        hipLaunchKernelGGL(k_order_keys, dim3(tb), dim3(256), 0, s, n, g->dplus, keys_in, vals_in);
+        size_t tmp_bytes = 0;
+        GMSX_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, keys_in, g->sorted_dplus, vals_in, g->order, size_t(n), 0, 32, s));
+        void *tmp = nullptr;
+        GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+        DevGuard g_tmp{tmp};
+        GMSX_HIP(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, g->sorted_dplus, vals_in, g->order, size_t(n), 0, 32, s));
+        int32_t top = 0;
+        GMSX_HIP(hipMemcpyAsync(&top, g->sorted_dplus, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        g->max_dplus = top;
+    }
+
+    // 5b. sizes of the inline rows (4c): ids handed over per receiving vertex
+    int64_t n_heavy = 0, n_work = 0;
+    unsigned long long *inl_h = nullptr, *inl_t = nullptr;  // [n + 1] ids per receiver, later the fill cursors
+    int64_t *ihoff = nullptr, *itoff = nullptr;             // [n + 1] first 16-byte unit of the receiver's inline rows (relative to the inline region)
+    if (int rc = dmalloc(&inl_h, n + 1, nullptr)) return rc;
+    DevGuard g_inl_h{inl_h};
+    if (int rc = dmalloc(&inl_t, n + 1, nullptr)) return rc;
+    DevGuard g_inl_t{inl_t};
+    if (int rc = dmalloc(&ihoff, n + 1, nullptr)) return rc;
+    DevGuard g_ihoff{ihoff};
+    if (int rc = dmalloc(&itoff, n + 1, nullptr)) return rc;
+    DevGuard g_itoff{itoff};
+    int64_t inline_h_units = 0, inline_t_units = 0;
+    {
+        if (n > 0) {
+            int64_t *d_cnt = nullptr;
+            if (int rc = dmalloc(&d_cnt, 2, nullptr)) return rc;
+            DevGuard g_c{d_cnt};
+            hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, n, g->sorted_dplus, int32_t(kHeavy), d_cnt);
+            hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, n, g->sorted_dplus, int32_t(2), d_cnt + 1);
+            GMSX_HIP(hipStreamSynchronize(s));
+            int64_t h[2] = {0, 0};
+            GMSX_HIP(hipMemcpy(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost));
+            n_heavy = h[0];
+            n_work = h[1];
+        }
+        if (!g->rows_sorted && n_work > n_heavy) return GMSX_ERR_UNSUPPORTED;  // "members below v" are the lanes before v: needs ascending rows
+        GMSX_HIP(hipMemsetAsync(inl_h, 0, size_t(n + 1) * sizeof(unsigned long long), s));
+        GMSX_HIP(hipMemsetAsync(inl_t, 0, size_t(n + 1) * sizeof(unsigned long long), s));
+        if (n_work > n_heavy)
+            hipLaunchKernelGGL(k_inline_rows<false>, dim3(grid_for_waves(n_work - n_heavy)), dim3(256), 0, s, n_heavy, n_work, g->order, g->hoff, g->hadj,
+                               g->toff, g->tadj, g->dplus, g->inline_limit, inl_h, inl_t, ihoff, itoff, int64_t(0), static_cast<uint16_t *>(nullptr),
+                               int64_t(0), static_cast<int32_t *>(nullptr), static_cast<unsigned long long *>(nullptr));
+        int64_t *uh = nullptr, *ut = nullptr;
+        if (int rc = dmalloc(&uh, n + 1, nullptr)) return rc;
+        DevGuard g_uh{uh};
+        if (int rc = dmalloc(&ut, n + 1, nullptr)) return rc;
+        DevGuard g_ut{ut};
+        hipLaunchKernelGGL(k_inline_units, dim3(unsigned(n / 256 + 1)), dim3(256), 0, s, n, inl_h, inl_t, uh, ut);
+        if (int rc = exclusive_scan_i64(uh, ihoff, n + 1, s)) return rc;
+        if (int rc = exclusive_scan_i64(ut, itoff, n + 1, s)) return rc;
+        GMSX_HIP(hipMemcpy(&inline_h_units, ihoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        GMSX_HIP(hipMemcpy(&inline_t_units, itoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        g->inline_units = inline_h_units + inline_t_units;
     }
 
     // 4d. stream rows of the heavy-pivot triangle kernel (needs the hub rows sorted: the delta form encodes ascending ids)
+    int64_t inline_h_base = 0, inline_t_base = 0;  // first unit of the inline regions of spool / tpool
     {
         int delta_mode = g->rows_sorted ? 1 : 0;
         if (const char *e = std::getenv("GMSX_TC_DELTA")) {  // 0 = lists and bitsets only, 2 = delta wherever possible (test hook)
@@ -677,11 +842,13 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         int64_t big_units = 0, small_units = 0;
         GMSX_HIP(hipMemcpy(&big_units, uoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
         GMSX_HIP(hipMemcpy(&small_units, soff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
-        g->spool_units = big_units + small_units;
+        g->spool_units = big_units + small_units + inline_h_units;
+        inline_h_base = big_units + small_units;
         if (g->spool_units >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;  // 40 offset bits in a srow entry (16 TB)
         if (int rc = dmalloc(&g->srow, n, g)) return rc;
         if (int rc = dmalloc(&g->spool, g->spool_units * 4 + 4, g)) return rc;
         GMSX_HIP(hipMemsetAsync(g->spool, 0, size_t(g->spool_units * 4 + 4) * sizeof(uint32_t), s));  // the alignment gaps are never read, but keep them defined
+        if (inline_h_units > 0) GMSX_HIP(hipMemsetAsync(g->spool + inline_h_base * 4, 0xff, size_t(inline_h_units) * 16, s));  // list filler 0xFFFF
         if (n > 0)
             hipLaunchKernelGGL(k_srow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->hoff, g->hadj, g->bmoff, g->bmpool, uoff, soff, real, form,
                                g->srow, g->spool);
@@ -705,9 +872,12 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         hipLaunchKernelGGL(k_trow_sizes, dim3(unsigned(n / 256 + 1)), dim3(256), 0, s, n, g->toff, g->tadj, delta_mode, units, form);
         if (int rc = exclusive_scan_i64(units, uoff, n + 1, s)) return rc;
         GMSX_HIP(hipMemcpy(&g->tpool_units, uoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        inline_t_base = g->tpool_units;
+        g->tpool_units += inline_t_units;
         if (g->tpool_units >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;
         if (int rc = dmalloc(&g->trow, n, g)) return rc;
         if (int rc = dmalloc(&g->tpool, g->tpool_units * 4 + 4, g)) return rc;
+        if (inline_t_units > 0) GMSX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g->tpool + inline_t_base * 4), int(0xFFFFFFFEu), size_t(inline_t_units) * 4, s));  // filler -2
         if (n > 0)
             hipLaunchKernelGGL(k_trow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->toff, g->tadj, uoff, form, g->trow, g->tpool);
         if (int rc = dmalloc(&g->tdesc, 2 * g->tail_entries + 2, g)) return rc;
@@ -717,50 +887,31 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         GMSX_HIP(hipStreamSynchronize(s));
     }
 
-    // 5. work-sorted launch order: rank ids by decreasing d+
-    if (int rc = dmalloc(&g->order, n, g)) return rc;
-    if (int rc = dmalloc(&g->sorted_dplus, n, g)) return rc;
-    if (n > 0) {
-        int32_t *keys_in = nullptr, *vals_in = nullptr;
-        if (int rc = dmalloc(&keys_in, n, nullptr)) return rc;
-        DevGuard g_ki{keys_in};
-        if (int rc = dmalloc(&vals_in, n, nullptr)) return rc;
-        DevGuard g_vi{vals_in};
-        hipLaunchKernelGGL(k_order_keys, dim3(tb), dim3(256), 0, s, n, g->dplus, keys_in, vals_in);
-        size_t tmp_bytes = 0;
-        GMSX_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, keys_in, g->sorted_dplus, vals_in, g->order, size_t(n), 0, 32, s));
-        void *tmp = nullptr;
-        GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-        DevGuard g_tmp{tmp};
-        GMSX_HIP(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, g->sorted_dplus, vals_in, g->order, size_t(n), 0, 32, s));
-        int32_t top = 0;
-        GMSX_HIP(hipMemcpyAsync(&top, g->sorted_dplus, sizeof(int32_t), hipMemcpyDeviceToHost, s));
-        GMSX_HIP(hipStreamSynchronize(s));
-        g->max_dplus = top;
+    // 5c. inline rows: copy the handed-over ids (pools exist now), blank the light pivots' descriptors of handed-over far members
+    if (n_work > n_heavy) {
+        GMSX_HIP(hipMemsetAsync(inl_h, 0, size_t(n + 1) * sizeof(unsigned long long), s));  // now the fill cursors
+        GMSX_HIP(hipMemsetAsync(inl_t, 0, size_t(n + 1) * sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(k_inline_rows<true>, dim3(grid_for_waves(n_work - n_heavy)), dim3(256), 0, s, n_heavy, n_work, g->order, g->hoff, g->hadj, g->toff,
+                           g->tadj, g->dplus, g->inline_limit, inl_h, inl_t, ihoff, itoff, inline_h_base, reinterpret_cast<uint16_t *>(g->spool),
+                           inline_t_base, reinterpret_cast<int32_t *>(g->tpool), g->tdesc);
     }
-
-    // 6. task lists of the heavy pivots: every oriented edge of a heavy pivot goes to the endpoint whose row is the bigger one
+    // 6. task lists: inline entries, then every oriented edge of a heavy pivot at the endpoint whose row is the bigger one
     {
-        int64_t n_heavy = 0;
-        if (n > 0) {
-            int64_t *d_cnt = nullptr;
-            if (int rc = dmalloc(&d_cnt, 1, nullptr)) return rc;
-            DevGuard g_c{d_cnt};
-            hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, n, g->sorted_dplus, int32_t(kHeavy), d_cnt);
-            GMSX_HIP(hipStreamSynchronize(s));
-            GMSX_HIP(hipMemcpy(&n_heavy, d_cnt, sizeof(int64_t), hipMemcpyDeviceToHost));
-        }
         int two_sided = 1;
-        if (const char *e = std::getenv("GMSX_TC_TWO_SIDED")) two_sided = std::atoi(e) != 0;  // 0 = every pivot keeps all its edges (A/B knob)
+        if (const char *e = std::getenv("GMSX_TC_TWO_SIDED")) two_sided = std::atoi(e) != 0;  // 0 = every heavy pivot keeps all its edges (A/B knob)
         unsigned long long *cnt = nullptr;
         if (int rc = dmalloc(&cnt, n + 2, nullptr)) return rc;
         DevGuard g_cnt{cnt};
         GMSX_HIP(hipMemsetAsync(cnt, 0, size_t(n + 2) * sizeof(unsigned long long), s));
         if (int rc = dmalloc(&g->tbeg, n + 1, g)) return rc;
+        const unsigned vb = unsigned(n / 256 + 1);
+        if (n > 0)
+            hipLaunchKernelGGL(k_inline_entries<false>, dim3(vb), dim3(256), 0, s, n, ihoff, itoff, inline_h_base, inline_t_base, cnt, g->tbeg,
+                               static_cast<unsigned long long *>(nullptr));
         const int grid = grid_for_waves(n_heavy);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
-                               g->trow, two_sided, cnt, g->tbeg, static_cast<unsigned long long *>(nullptr), cnt + n + 1);
+                               g->trow, two_sided, cnt, g->tbeg, static_cast<unsigned long long *>(nullptr), cnt + n + 1, ihoff, itoff);
         if (int rc = exclusive_scan_i64(reinterpret_cast<const int64_t *>(cnt), g->tbeg, n + 1, s)) return rc;
         unsigned long long rev = 0;
         GMSX_HIP(hipMemcpy(&g->task_entries, g->tbeg + n, sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -768,19 +919,20 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         g->task_reverse = int64_t(rev);
         if (int rc = dmalloc(&g->task, 2 * g->task_entries + 2, g)) return rc;
         GMSX_HIP(hipMemsetAsync(cnt, 0, size_t(n + 2) * sizeof(unsigned long long), s));  // now the reverse cursors
+        if (n > 0) hipLaunchKernelGGL(k_inline_entries<true>, dim3(vb), dim3(256), 0, s, n, ihoff, itoff, inline_h_base, inline_t_base, cnt, g->tbeg, g->task);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
-                               g->trow, two_sided, cnt, g->tbeg, g->task, cnt + n + 1);
+                               g->trow, two_sided, cnt, g->tbeg, g->task, cnt + n + 1, ihoff, itoff);
         int64_t *icnt = nullptr, *ioff = nullptr;
-        if (int rc = dmalloc(&icnt, n_heavy + 1, nullptr)) return rc;
+        if (int rc = dmalloc(&icnt, n + 1, nullptr)) return rc;
         DevGuard g_ic{icnt};
-        if (int rc = dmalloc(&ioff, n_heavy + 1, nullptr)) return rc;
+        if (int rc = dmalloc(&ioff, n + 1, nullptr)) return rc;
         DevGuard g_io{ioff};
-        hipLaunchKernelGGL(k_item_counts, dim3(unsigned(n_heavy / 256 + 1)), dim3(256), 0, s, n_heavy, g->order, g->tbeg, icnt);
-        if (int rc = exclusive_scan_i64(icnt, ioff, n_heavy + 1, s)) return rc;
-        GMSX_HIP(hipMemcpy(&g->task_items, ioff + n_heavy, sizeof(int64_t), hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(k_item_counts, dim3(vb), dim3(256), 0, s, n, g->order, g->tbeg, ihoff, itoff, icnt);
+        if (int rc = exclusive_scan_i64(icnt, ioff, n + 1, s)) return rc;
+        GMSX_HIP(hipMemcpy(&g->task_items, ioff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
         if (int rc = dmalloc(&g->titem, g->task_items + 1, g)) return rc;
-        if (n_heavy > 0) hipLaunchKernelGGL(k_item_fill, dim3(unsigned(n_heavy / 256 + 1)), dim3(256), 0, s, n_heavy, g->order, g->tbeg, ioff, g->titem);
+        if (n > 0) hipLaunchKernelGGL(k_item_fill, dim3(vb), dim3(256), 0, s, n, g->order, g->tbeg, ihoff, itoff, ioff, g->titem);
         GMSX_HIP(hipStreamSynchronize(s));
     }
     GMSX_HIP(hipStreamSynchronize(s));

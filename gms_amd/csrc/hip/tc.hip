@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int32_t u = it.pivot;
     const int64_t hb = hoff[u], tb = toff[u];
     const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
-    const int ne = it.count;
+    const int ne = it.count < 0 ? -it.count : it.count;  // negative: a chunk of inline entries (bookkeeping only)
     const unsigned long long *__restrict__ ent = task + 2 * it.begin;
 
     for (int i = tid; i < kBitmapWords; i += 256) bm[i] = 0;
@@ -374,102 +374,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 }
 
 // ---------------------------------------------------------------------------------------------
-// Light pivots (2 <= d+ < 64), part 1 of 2: the rows of every member that has a BITSET container (rank id < bitset_limit: the
-// hub range and the near tail).  No LDS at all (full occupancy): lane j holds member w_j — the hub part of the pivot list in
-// the low lanes, the tail part behind it, ascending — and for every member v_i with a bitset the lanes gather one word of
-// v_i's container ("is w_j in N+(v_i)?").  Eight rows are in flight per trip; nothing is streamed.  Part 2 (k_tc_wave) adds
-// the rows of the members beyond bitset_limit.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tc_wave_hub(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                     const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
-                                                     const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
-                                                     int32_t bitset_limit, const int32_t *__restrict__ order, int64_t first, int64_t end,
-                                                     int nparts, int part, unsigned long long *__restrict__ acc) {
-    __shared__ unsigned long long red[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t step = int64_t(gridDim.x) * 4 * nparts;
-    unsigned long long cnt = 0;
-    // two-stage software pipeline over the pivots of this wave (see k_tc_wave): C = current, B = next, A = after next
-    int64_t posC = first + (int64_t(blockIdx.x) * 4 + wave) * nparts + part;
-    int64_t hbC = 0, hbB = 0, tbC = 0, tbB = 0;
-    int hlC = 0, hlB = 0, tlC = 0, tlB = 0;
-    int32_t uA = -1;
-    if (posC < end) {
-        const int32_t u = order[posC];
-        hbC = hoff[u];
-        hlC = int(hoff[u + 1] - hbC);
-        tbC = toff[u];
-        tlC = int(toff[u + 1] - tbC);
-    }
-    if (posC + step < end) {
-        const int32_t u = order[posC + step];
-        hbB = hoff[u];
-        hlB = int(hoff[u + 1] - hbB);
-        tbB = toff[u];
-        tlB = int(toff[u + 1] - tbB);
-    }
-    if (posC + 2 * step < end) uA = order[posC + 2 * step];
-    for (; posC < end; posC += step) {  // uniform per wave
-        int64_t hbN = 0, tbN = 0;
-        int hlN = 0, tlN = 0;
-        if (uA >= 0) {
-            hbN = hoff[uA];
-            hlN = int(hoff[uA + 1] - hbN);
-            tbN = toff[uA];
-            tlN = int(toff[uA + 1] - tbN);
-        }
-        const int32_t uN = (posC + 3 * step < end) ? order[posC + 3 * step] : -1;
-        const int64_t hb = hbC, tb = tbC;
-        const int hl = hlC, tl = tlC;  // hl (padded) + tl <= 64
-        hbC = hbB; hlC = hlB; tbC = tbB; tlC = tlB;
-        hbB = hbN; hlB = hlN; tbB = tbN; tlB = tlN;
-        uA = uN;
-        int32_t mv = 0x7fffffff;  // this lane's member (rank id); the pad and empty lanes never pass "mv < v_i"
-        if (lane < hl) {
-            const uint32_t h = hadj[hb + lane];
-            if (h != 0xFFFFu) mv = int32_t(h);
-        } else if (lane - hl < tl) {
-            mv = tadj[tb + (lane - hl)];
-        }
-        int64_t rb = 0;
-        const bool has = mv < bitset_limit;
-        if (has) rb = bmoff[mv];
-        uint32_t c = 0;
-        unsigned long long todo = __ballot(has);
-        todo &= todo - 1;  // the smallest member has no member below it
-        while (todo) {
-            int32_t vi[8];
-            const uint32_t *bits[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                vi[k] = 0;
-                bits[k] = bmpool;
-                if (todo) {
-                    const int i = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    vi[k] = __builtin_amdgcn_readlane(mv, i);
-                    bits[k] = bmpool + readlane64(rb, i);
-                }
-            }
-            uint32_t wd[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) wd[k] = mv < vi[k] ? bits[k][uint32_t(mv) >> 5] : 0u;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) c += (wd[k] >> (uint32_t(mv) & 31u)) & 1u;
-        }
-        cnt += c;
-    }
-    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
-    if (lane == 0) red[wave] = cnt;
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long t = red[0] + red[1] + red[2] + red[3];
-        if (t) atomicAdd(&acc[(blockIdx.x & (kAccSlots - 1)) * kAccStride], t);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Light pivots (2 <= d+ < 64), part 2 of 2: the rows of the FAR members (rank ids >= bitset_limit; k_tc_wave_hub resolved the others).  Each of the 4 waves of a
+// Light pivots (2 <= d+ < 64): the rows of their FAR, LIGHT members (rank id >= inline_limit and d+ < 64).  Every other edge of a light
+// pivot was handed over to the member at upload (inline rows, device_graph.hpp) and is counted by k_tc_block.  Each of the 4 waves of a
 // workgroup owns a private bitmap (8 KB) and a 64 x 4 bucket set for the tail part and walks its pivots with a grid
 // stride; pivots without tail members are skipped.  The bitmap is cleared once; each pivot sets its bits and clears
 // exactly those words again.
@@ -503,7 +409,7 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
     // member ids: stage C loads ids and descriptors together, stage D scans.
     int64_t hbC = 0, tbC = 0, hbB = 0, tbB = 0;
     int hlC = 0, tlC = 0, hlB = 0, tlB = 0;
-    int tsC = 0, tsB = 0, tsD = 0;  // members below bitset_limit come first in a tail row: k_tc_wave_hub resolved their rows
+    int tsC = 0, tsB = 0, tsD = 0;  // members below inline_limit come first in a tail row: handed over
     int32_t uA = -1;
     int tlD = 0;
     uint32_t hvD = 0xFFFFu;
@@ -529,7 +435,7 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
         tb = toff[u];
         tl = int(toff[u + 1] - tb);
         ts = tsplit[u];
-        if (tl <= ts) tl = 0;  // no member beyond bitset_limit: nothing to stream for this pivot
+        if (tl <= ts) tl = 0;  // no member beyond inline_limit: nothing to stream for this pivot
     };
     {  // prologue
         int64_t hb0 = 0, tb0 = 0;
@@ -553,7 +459,7 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
         if (tlD > 0) {
             uint32_t c = 0;
             __builtin_amdgcn_wave_barrier();
-            // hub members: only their bits are needed here (their rows were counted by k_tc_wave_hub)
+            // hub members: only their bits are needed here (their edges were handed over)
             if (hvD != 0xFFFFu) atomicOr(&bm[hvD >> 5], 1u << (hvD & 31u));
             for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
             fill[lane] = 0;
@@ -596,17 +502,17 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
 
 // units / probes / algorithmic stream bytes of a shard (untimed bookkeeping for gmsx_stats).  out[2] follows what the count kernels
 // read, byte for byte, assuming no on-chip reuse:
-//   light pivot u (2 <= d+ < 64; k_tc_stats, wave per pivot position): its own containers once; one 4-byte word gathered per (member
-//       with a bitset, smaller member) pair; the stream rows of the members beyond bitset_limit;
-//   work item of a heavy pivot (k_tc_item_stats, wave per item): the pivot's containers once; per entry 16 bytes of descriptors and the
-//       hub + tail stream rows they describe (whole 16-byte units).
+//   light pivot u (2 <= d+ < 64; k_tc_stats, wave per pivot position): its hub part if it has tail members; per far light member
+//       (rank id >= inline_limit, d+ < 64) the member id, its two descriptors and the stream rows they describe;
+//   work item (k_tc_item_stats, wave per item): the pivot's containers once; per entry 16 bytes of descriptors and the hub + tail
+//       stream rows they describe (whole 16-byte units) — members' rows, handed-over rows and inline rows alike.
 // out[0] = oriented edges counted by the shard (every edge of a light or idle pivot at the pivot, every edge of a heavy pivot where its
-// entry lives); out[1] = id slots probed (per unit: 8 list, 14 byte-delta, 4 bitset words; 4 / 6 tail ids; one per gathered word).
+// entry lives); out[1] = id slots probed (per unit: 8 list, 14 byte-delta, 4 bitset words; 4 / 6 tail ids).
 __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
                                                   const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
-                                                  int32_t bitset_limit, int64_t first, int64_t end, int nparts, int part,
+                                                  int32_t inline_limit, int64_t first, int64_t end, int nparts, int part,
                                                   unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -625,26 +531,14 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
         const int hl = int(hoff[u + 1] - hoff[u]), tl = int(toff[u + 1] - toff[u]);
         if (lane == 0) {
             units += (unsigned long long)du;
-            if (du >= 2) bytes += 2ull * hl + 4ull * tl;
+            if (du >= 2 && tl > 0) bytes += 2ull * hl;  // k_tc_wave reads the hub part of every pivot that has tail members
         }
         if (du < 2) continue;
-        for (int64_t j = hoff[u] + lane; j < hoff[u + 1]; j += 64) {
-            const uint32_t v = hadj[j];
-            if (v == 0xFFFFu) continue;
-            if (int32_t(v) < bitset_limit) {
-                bytes += 4ull * (unsigned long long)(j - hoff[u]);  // one gathered word per member below v
-                probes += (unsigned long long)(j - hoff[u]);
-            }
-        }
         for (int64_t j = toff[u] + lane; j < toff[u + 1]; j += 64) {
             const int32_t v = tadj[j];
-            if (v < bitset_limit) {  // near-tail member: gathers, nothing streamed
-                bytes += 4ull * (unsigned long long)(du - tl + (j - toff[u]));
-                probes += (unsigned long long)(du - tl + (j - toff[u]));
-                continue;
-            }
+            if (v < inline_limit || dplus[v] >= kHeavy) continue;  // handed over: the ids are in v's inline rows, counted with its items
             const unsigned long long d = srow[v], t = j > toff[u] ? trow[v] : 0ull;
-            bytes += 16ull * ((d & 0x3fffffull) + (t & 0x3fffffull));
+            bytes += 16ull * ((d & 0x3fffffull) + (t & 0x3fffffull)) + 20ull;  // the rows + the member id and its descriptors
             probes += slots(d, false) + slots(t, true);
         }
     }
@@ -674,11 +568,12 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
         const int64_t pos = q * nparts + part;
         if (pos >= n_items) break;
         const gmsx_task_item it = items[pos];
+        const int ne = it.count < 0 ? -it.count : it.count;
         if (lane == 0) {
-            units += (unsigned long long)it.count;
+            if (it.count > 0) units += (unsigned long long)it.count;  // inline chunks stand for edges counted at their light pivots
             bytes += 2ull * (unsigned long long)(hoff[it.pivot + 1] - hoff[it.pivot]) + 4ull * (unsigned long long)(toff[it.pivot + 1] - toff[it.pivot]);
         }
-        for (int i = lane; i < it.count; i += 64) {
+        for (int i = lane; i < ne; i += 64) {
             const unsigned long long d = task[2 * (it.begin + i)], t = task[2 * (it.begin + i) + 1];
             bytes += 16ull + 16ull * ((d & 0x3fffffull) + (t & 0x3fffffull));
             probes += slots(d, false) + slots(t, true);
@@ -893,40 +788,34 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     // remaining wave slots and LDS of every CU (4-5 workgroups, growing to 8 as the light kernels retire).  One pass then costs
     // about max(heavy, light) instead of their sum.  GMSX_TC_OVERLAP=0 restores the serial order (full-width light grids).
     static const int overlap = [] { const char *e = std::getenv("GMSX_TC_OVERLAP"); return e ? std::atoi(e) : 1; }();
-    static const int hub_wgs = [] { const char *e = std::getenv("GMSX_TC_HUB_WGS"); return e ? std::max(1, std::atoi(e)) : 2; }();
     static const int wave_wgs = [] { const char *e = std::getenv("GMSX_TC_WAVE_WGS"); return e ? std::max(1, std::atoi(e)) : 2; }();
     // measured (tools/tc_overlap_sweep.py, MI355X): scale 26 268 -> 254 ms — 1.80 TB of beyond-L2 traffic at 7.1 TB/s, i.e. the pass then
     // sits on the aggregate bandwidth roof and only fewer bytes can make it faster; scale 24 37.8 -> 36…46 ms (noisy: the light kernels are
     // 12 ms there and the heavy kernel loses more to the sharing than they hide).  So: only in the large-graph regime, which is also
     // where the near-tail bitsets are on.
-    const bool co = overlap && cnt_heavy > 0 && cnt_light > 0 && c.side[0] && c.side[1] && (overlap > 1 || g->bitset_limit > g->dense_limit);
-    hipStream_t s_hub = co ? c.side[0] : s, s_wave = co ? c.side[1] : s;
+    const bool co = overlap && cnt_heavy > 0 && cnt_light > 0 && c.side[0] && c.side[1] && (overlap > 1 || g->inline_limit > g->dense_limit);
+    hipStream_t s_wave = co ? c.side[1] : s;
     struct Join {  // joins the side streams on every way out once they were forked (error returns included)
         Ctx &c;
         hipStream_t s;
         bool armed = false;
         ~Join() {
             if (!armed) return;
-            for (int i = 0; i < 2; ++i)
-                if (hipEventRecord(c.ev_join[i], c.side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, c.ev_join[i], 0);
+            if (hipEventRecord(c.ev_join[1], c.side[1]) == hipSuccess) (void)hipStreamWaitEvent(s, c.ev_join[1], 0);
         }
     } join{c, s};
     if (co) {
         GMSX_HIP(hipEventRecord(c.ev_fork, s));
-        GMSX_HIP(hipStreamWaitEvent(c.side[0], c.ev_fork, 0));
         GMSX_HIP(hipStreamWaitEvent(c.side[1], c.ev_fork, 0));
         join.armed = true;
     }
     auto launch_light = [&]() {
         if (cnt_light <= 0) return;
         const int64_t want = (cnt_light + 3) / 4;
-        const int64_t b_hub = std::min<int64_t>(want, co ? int64_t(cus) * hub_wgs : cap_blocks * 2);
         const int64_t b_wave = std::min<int64_t>(want, co ? int64_t(cus) * wave_wgs : cap_blocks);
         hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(b_wave)), dim3(256), 0, s_wave, g->hoff, g->hadj, g->spool, g->tpool, g->tdesc, g->toff, g->tadj,
                            g->tsplit, g->order, n_block, n_work, nparts, part, acc);
-        hipLaunchKernelGGL(k_tc_wave_hub, dim3(unsigned(b_hub)), dim3(256), 0, s_hub, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
-                           g->bitset_limit, g->order, n_block, n_work, nparts, part, acc);
-        launches += 2;
+        ++launches;
     };
     if (co) launch_light();
     if (cnt_heavy > 0) {
@@ -937,9 +826,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     if (!co) launch_light();
     if (co) {
         join.armed = false;
-        GMSX_HIP(hipEventRecord(c.ev_join[0], c.side[0]));
         GMSX_HIP(hipEventRecord(c.ev_join[1], c.side[1]));
-        GMSX_HIP(hipStreamWaitEvent(s, c.ev_join[0], 0));
         GMSX_HIP(hipStreamWaitEvent(s, c.ev_join[1], 0));
     }
     GMSX_HIP(hipEventRecord(c.ev[2], s));
@@ -951,7 +838,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
             hipLaunchKernelGGL(k_tc_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus,
-                               g->order, g->srow, g->trow, g->bitset_limit, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
+                               g->order, g->srow, g->trow, g->inline_limit, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
         }
         if (cnt_heavy > 0) {
             const int64_t blocks = std::min<int64_t>((cnt_heavy + 3) / 4, cap_blocks);
