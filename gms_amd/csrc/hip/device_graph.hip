@@ -508,16 +508,14 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
         if (lane == 0 && rev) atomicAdd(reversed, rev);
     }
 }
-// work items: per vertex (in launch order) first the chunks of its inline entries (count < 0: they stand for no edge of their own in
-// the bookkeeping), then the chunks of its forward + reverse entries
-__global__ void k_item_counts(int64_t n, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, const int64_t *__restrict__ ihoff,
-                              const int64_t *__restrict__ itoff, int64_t *__restrict__ items) {
+// work items: the list of every vertex that has one (in launch order) in chunks of kTaskChunk entries; count = entries | inline << 16
+// (the inline entries stand for no edge of their own in the bookkeeping)
+__global__ void k_item_counts(int64_t n, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, int64_t *__restrict__ items) {
     const int64_t pos = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (pos > n) return;
     if (pos == n) { items[pos] = 0; return; }
     const int32_t w = order[pos];
-    const int64_t all = tbeg[w + 1] - tbeg[w], inl = inline_chunks(ihoff, itoff, w);
-    items[pos] = (inl + kTaskChunk - 1) / kTaskChunk + (all - inl + kTaskChunk - 1) / kTaskChunk;
+    items[pos] = (tbeg[w + 1] - tbeg[w] + kTaskChunk - 1) / kTaskChunk;
 }
 __global__ void k_item_fill(int64_t n, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, const int64_t *__restrict__ ihoff,
                             const int64_t *__restrict__ itoff, const int64_t *__restrict__ ioff, gmsx_task_item *__restrict__ items) {
@@ -526,8 +524,10 @@ __global__ void k_item_fill(int64_t n, const int32_t *__restrict__ order, const 
     const int32_t w = order[pos];
     const int64_t b = tbeg[w], e = tbeg[w + 1], m = b + inline_chunks(ihoff, itoff, w);
     int64_t k = ioff[pos];
-    for (int64_t x = b; x < m; x += kTaskChunk, ++k) items[k] = gmsx_task_item{x, w, -int32_t(min(int64_t(kTaskChunk), m - x))};
-    for (int64_t x = m; x < e; x += kTaskChunk, ++k) items[k] = gmsx_task_item{x, w, int32_t(min(int64_t(kTaskChunk), e - x))};
+    for (int64_t x = b; x < e; x += kTaskChunk, ++k) {
+        const int64_t cnt = min(int64_t(kTaskChunk), e - x), inl = max(int64_t(0), min(m, x + cnt) - x);
+        items[k] = gmsx_task_item{x, w, int32_t(cnt | (inl << 16))};
+    }
 }
 
 static int grid_for_waves(int64_t rows) {
@@ -928,7 +928,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         DevGuard g_ic{icnt};
         if (int rc = dmalloc(&ioff, n + 1, nullptr)) return rc;
         DevGuard g_io{ioff};
-        hipLaunchKernelGGL(k_item_counts, dim3(vb), dim3(256), 0, s, n, g->order, g->tbeg, ihoff, itoff, icnt);
+        hipLaunchKernelGGL(k_item_counts, dim3(vb), dim3(256), 0, s, n, g->order, g->tbeg, icnt);
         if (int rc = exclusive_scan_i64(icnt, ioff, n + 1, s)) return rc;
         GMSX_HIP(hipMemcpy(&g->task_items, ioff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
         if (int rc = dmalloc(&g->titem, g->task_items + 1, g)) return rc;

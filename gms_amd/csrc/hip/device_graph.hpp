@@ -33,7 +33,7 @@
 struct gmsx_task_item {
     int64_t begin;  // first entry (index into task / 2)
     int32_t pivot;  // rank id whose row is staged in LDS
-    int32_t count;  // entries of this chunk
+    int32_t count;  // entries of this chunk (<= kTaskChunk) | inline entries among them << 16
 };
 struct gmsx_graph {
     int64_t n = 0, nnz = 0, m = 0;
@@ -73,7 +73,7 @@ struct gmsx_graph {
     // (fewer 16-byte units).  So every vertex w owns a list of (srow, trow) descriptor pairs — one per edge it is the pivot of:
     // members v of its own row whose rows are the smaller ones ("forward"), and in-neighbours u that hand their edge over because
     // their own row is smaller than w's ("reverse", only towards heavy w) — and the heavy-pivot kernel walks work items = chunks
-    // of at most kTaskChunk entries of one list.  Light pivots keep all their edges (k_tc_wave_hub / k_tc_wave).
+    // of at most kTaskChunk entries of one list.  Light pivots hand most of theirs over as INLINE ROWS (inline_limit below).
     unsigned long long *task = nullptr;  // [2 * task_entries]: srow / trow descriptor of the streamed row (trow 0 = no match possible)
     int64_t task_entries = 0;
     int64_t *tbeg = nullptr;             // [n + 1] first entry of vertex w's list
@@ -112,7 +112,7 @@ static constexpr int kHub = 65535;         // rank ids below this live in the 16
 static constexpr int kBitmapWords = 2048;  // 65536-bit LDS bitmap over the hub id range
 static constexpr int kAccWords = 64 * 16 + 16;
 static constexpr int kFormList = 0, kFormBitset = 1, kFormDelta = 2;
-static constexpr int kTaskChunk = 1024;  // entries per work item of the heavy-pivot kernel
+static constexpr int kTaskChunk = 1024;  // entries per work item of the heavy-pivot kernel (< 65536: two counts share gmsx_task_item::count)
 static constexpr int kHeavy = 64;        // d+ from which a pivot runs on the workgroup kernel
 static constexpr int kDeltaIds = 14;  // ids per full 16-byte delta unit  // size of gmsx_graph::acc in u64
 
