@@ -442,7 +442,8 @@ __global__ void k_inline_entries(int64_t n, const int64_t *__restrict__ ihoff, c
         const int64_t o = k * kInlineChunk;
         const int64_t nh = min(int64_t(kInlineChunk), uh - o), nt = min(int64_t(kInlineChunk), ut - o);
         task[2 * (tbeg[v] + k)] = nh > 0 ? ((unsigned long long)(base_h + ihoff[v] + o) << 24) | ((unsigned long long)kFormList << 22) | (unsigned long long)nh : 0ull;
-        task[2 * (tbeg[v] + k) + 1] = nt > 0 ? ((unsigned long long)(base_t + itoff[v] + o) << 24) | (unsigned long long)nt : 0ull;
+        // bit 22 of the tail descriptor (no tail form uses it) marks an inline entry: it stands for no edge of its own in the bookkeeping
+        task[2 * (tbeg[v] + k) + 1] = (nt > 0 ? ((unsigned long long)(base_t + itoff[v] + o) << 24) | (unsigned long long)nt : 0ull) | (1ull << 22);
     }
 }
 
@@ -508,8 +509,11 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
         if (lane == 0 && rev) atomicAdd(reversed, rev);
     }
 }
-// work items: the list of every vertex that has one (in launch order) in chunks of kTaskChunk entries; count = entries | inline << 16
-// (the inline entries stand for no edge of their own in the bookkeeping)
+__global__ void k_task_keys(int64_t entries, const unsigned long long *__restrict__ task, uint32_t *__restrict__ keys) {
+    const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e < entries) keys[e] = uint32_t(task[2 * e]) & 0xffffffu;  // form << 22 | units
+}
+// work items: the list of every vertex that has one (in launch order) in chunks of kTaskChunk entries
 __global__ void k_item_counts(int64_t n, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, int64_t *__restrict__ items) {
     const int64_t pos = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (pos > n) return;
@@ -517,17 +521,14 @@ __global__ void k_item_counts(int64_t n, const int32_t *__restrict__ order, cons
     const int32_t w = order[pos];
     items[pos] = (tbeg[w + 1] - tbeg[w] + kTaskChunk - 1) / kTaskChunk;
 }
-__global__ void k_item_fill(int64_t n, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, const int64_t *__restrict__ ihoff,
-                            const int64_t *__restrict__ itoff, const int64_t *__restrict__ ioff, gmsx_task_item *__restrict__ items) {
+__global__ void k_item_fill(int64_t n, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, const int64_t *__restrict__ ioff,
+                            gmsx_task_item *__restrict__ items) {
     const int64_t pos = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (pos >= n) return;
     const int32_t w = order[pos];
-    const int64_t b = tbeg[w], e = tbeg[w + 1], m = b + inline_chunks(ihoff, itoff, w);
+    const int64_t b = tbeg[w], e = tbeg[w + 1];
     int64_t k = ioff[pos];
-    for (int64_t x = b; x < e; x += kTaskChunk, ++k) {
-        const int64_t cnt = min(int64_t(kTaskChunk), e - x), inl = max(int64_t(0), min(m, x + cnt) - x);
-        items[k] = gmsx_task_item{x, w, int32_t(cnt | (inl << 16))};
-    }
+    for (int64_t x = b; x < e; x += kTaskChunk, ++k) items[k] = gmsx_task_item{x, w, int32_t(min(int64_t(kTaskChunk), e - x))};
 }
 
 static int grid_for_waves(int64_t rows) {
@@ -923,6 +924,38 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
                                g->trow, two_sided, cnt, g->tbeg, g->task, cnt + n + 1, ihoff, itoff);
+        // every list sorted by (form, units) of the hub stream row: the four rows a wave works on at a time are then equally long
+        // (tc.hip, scan_srows).  The order of a list carries no meaning.  GMSX_TC_SORT_TASKS=0 skips it (A/B knob).
+        bool sort_tasks = g->task_entries > 0 && g->task_entries < (int64_t(1) << 32) && n < (int64_t(1) << 32);
+        if (const char *e = std::getenv("GMSX_TC_SORT_TASKS")) sort_tasks = sort_tasks && std::atoi(e) != 0;
+        if (sort_tasks) {
+            struct Entry { unsigned long long x, y; };
+            uint32_t *k_in = nullptr, *k_out = nullptr;
+            unsigned long long *sorted = nullptr;
+            if (int rc = dmalloc(&k_in, g->task_entries, nullptr)) return rc;
+            DevGuard g_ki{k_in};
+            if (int rc = dmalloc(&k_out, g->task_entries, nullptr)) return rc;
+            DevGuard g_ko{k_out};
+            if (int rc = dmalloc(&sorted, 2 * g->task_entries + 2, nullptr)) return rc;
+            hipLaunchKernelGGL(k_task_keys, dim3(unsigned((g->task_entries + 255) / 256)), dim3(256), 0, s, g->task_entries, g->task, k_in);
+            size_t tmp_bytes = 0;
+            hipError_t e1 = rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, reinterpret_cast<Entry *>(g->task), reinterpret_cast<Entry *>(sorted),
+                                                                unsigned(g->task_entries), unsigned(n), g->tbeg, g->tbeg + 1, 0, 24, s);
+            void *tmp = nullptr;
+            if (e1 == hipSuccess) e1 = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8);
+            if (e1 == hipSuccess)
+                e1 = rocprim::segmented_radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, reinterpret_cast<Entry *>(g->task), reinterpret_cast<Entry *>(sorted),
+                                                         unsigned(g->task_entries), unsigned(n), g->tbeg, g->tbeg + 1, 0, 24, s);
+            if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
+            (void)hipFree(tmp);
+            if (e1 != hipSuccess) {
+                (void)hipFree(sorted);
+                (void)hipGetLastError();
+                return e1 == hipErrorOutOfMemory ? GMSX_ERR_DEVICE_MEM : GMSX_ERR_KERNEL;
+            }
+            (void)hipFree(g->task);
+            g->task = sorted;
+        }
         int64_t *icnt = nullptr, *ioff = nullptr;
         if (int rc = dmalloc(&icnt, n + 1, nullptr)) return rc;
         DevGuard g_ic{icnt};
@@ -932,7 +965,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         if (int rc = exclusive_scan_i64(icnt, ioff, n + 1, s)) return rc;
         GMSX_HIP(hipMemcpy(&g->task_items, ioff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
         if (int rc = dmalloc(&g->titem, g->task_items + 1, g)) return rc;
-        if (n > 0) hipLaunchKernelGGL(k_item_fill, dim3(vb), dim3(256), 0, s, n, g->order, g->tbeg, ihoff, itoff, ioff, g->titem);
+        if (n > 0) hipLaunchKernelGGL(k_item_fill, dim3(vb), dim3(256), 0, s, n, g->order, g->tbeg, ioff, g->titem);
         GMSX_HIP(hipStreamSynchronize(s));
     }
     GMSX_HIP(hipStreamSynchronize(s));

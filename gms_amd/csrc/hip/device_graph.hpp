@@ -33,7 +33,7 @@
 struct gmsx_task_item {
     int64_t begin;  // first entry (index into task / 2)
     int32_t pivot;  // rank id whose row is staged in LDS
-    int32_t count;  // entries of this chunk (<= kTaskChunk) | inline entries among them << 16
+    int32_t count;  // entries of this chunk (<= kTaskChunk)
 };
 struct gmsx_graph {
     int64_t n = 0, nnz = 0, m = 0;
@@ -112,7 +112,7 @@ static constexpr int kHub = 65535;         // rank ids below this live in the 16
 static constexpr int kBitmapWords = 2048;  // 65536-bit LDS bitmap over the hub id range
 static constexpr int kAccWords = 64 * 16 + 16;
 static constexpr int kFormList = 0, kFormBitset = 1, kFormDelta = 2;
-static constexpr int kTaskChunk = 1024;  // entries per work item of the heavy-pivot kernel (< 65536: two counts share gmsx_task_item::count)
+static constexpr int kTaskChunk = 1024;  // entries per work item of the heavy-pivot kernel 
 static constexpr int kHeavy = 64;        // d+ from which a pivot runs on the workgroup kernel
 static constexpr int kDeltaIds = 14;  // ids per full 16-byte delta unit  // size of gmsx_graph::acc in u64
 

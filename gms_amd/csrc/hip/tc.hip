@@ -90,51 +90,32 @@ __device__ __forceinline__ uint32_t delta_unit_hits(const uint32_t *bm, uint4 p)
 }
 
 // Streams up to 64 stream rows against the LDS bitmap.  Lane l holds the packed descriptor of one row (srow[v]; 0 = no row).
-// A wave works as four 16-lane groups; a group takes a CHUNK of at most 32 units (two 16-byte loads per lane in flight) of the current
-// row, the next group the next chunk of the same row or the first of the next one.  The hand-out is scalar code (s_ff1 over a ballot,
-// v_readlane into SGPRs, SALU arithmetic — a separate issue port) and costs the vector pipe one select per group and value.
-// Rows go form by form, so every branch is wave-uniform.  Before: one ROW per group, four rows per hand-out — rows of 70, 100, 120 and 90
-// units kept the wave busy for 120 and the lanes 66 % used; with the smaller-endpoint rule rows got shorter and more uneven (VALU lane
-// utilisation 48 %).  The forms cost 12 / 32 / 81 VALU instructions per unit, so mixed hand-outs would run every branch.
-struct Chunk {
-    const uint4 *row;  // first unit of the chunk
-    int n;             // units (0 … 32)
-    int pos;           // index of the first unit within its row (the bitset form indexes the pivot bitmap with it)
+// A wave works as four 16-lane groups, each on its own row: one 16-byte unit per lane per step, two steps in flight.  Rows are handed
+// out FORM BY FORM (a ballot per form, then the four lowest lanes of the ballot): the three forms cost 12 / 32 / 81 VALU instructions per
+// unit, and a hand-out that mixes them executes every branch with a quarter of the lanes.  The four rows of a hand-out should also be
+// equally long — the wave works until the longest is done — which the BUILD takes care of: every task list is sorted by (form, units)
+// (device_graph.hip), so neighbouring lanes hold rows of nearly the same length.  (Tried instead: 32-unit chunks handed out by a scalar
+// cursor — balanced too, but ~45 VALU instructions per hand-out of at most 128 units against ~30 per four whole rows.)
+struct RowHandout {
+    const uint4 *row;
+    int units;
 };
-struct RowCursor {
-    unsigned long long todo;  // lanes whose rows of this form are still to come
-    uint32_t lo = 0, hi = 0;  // descriptor of the current row
-    int units = 0, pos = 0;
-    __device__ __forceinline__ bool more() const { return todo != 0 || pos < units; }
-};
-__device__ __forceinline__ Chunk take_chunks(RowCursor &c, const uint32_t *__restrict__ pool, uint32_t dlo, uint32_t dhi, int grp, int &max_n) {
-    uint32_t olo[4], ohi[4];
-    int nn[4], pp[4];
-    max_n = 0;
+__device__ __forceinline__ RowHandout take_rows(unsigned long long &todo, const uint32_t *__restrict__ pool, uint32_t dlo, uint32_t dhi, int grp) {
+    uint32_t lo[4], hi[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (c.pos >= c.units && c.todo) {  // wave-uniform: next row of this form
-            const int i = __ffsll((long long)c.todo) - 1;
-            c.todo &= c.todo - 1;
-            c.lo = __builtin_amdgcn_readlane(dlo, i);
-            c.hi = __builtin_amdgcn_readlane(dhi, i);
-            c.units = int(c.lo & 0x3fffffu);
-            c.pos = 0;
+        lo[k] = 0;
+        hi[k] = 0;
+        if (todo) {  // wave-uniform
+            const int i = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            lo[k] = __builtin_amdgcn_readlane(dlo, i);
+            hi[k] = __builtin_amdgcn_readlane(dhi, i);
         }
-        const int rem = c.units - c.pos;
-        nn[k] = rem > 0 ? min(rem, 32) : 0;
-        const uint64_t off = ((uint64_t(c.hi) << 8) | (c.lo >> 24)) + uint32_t(c.pos);
-        olo[k] = uint32_t(off);
-        ohi[k] = uint32_t(off >> 32);
-        pp[k] = c.pos;
-        if (rem > 0) c.pos += 32;
-        max_n = max(max_n, nn[k]);
     }
-    const uint32_t l = grp == 0 ? olo[0] : grp == 1 ? olo[1] : grp == 2 ? olo[2] : olo[3];
-    const uint32_t h = grp == 0 ? ohi[0] : grp == 1 ? ohi[1] : grp == 2 ? ohi[2] : ohi[3];
-    const int n = grp == 0 ? nn[0] : grp == 1 ? nn[1] : grp == 2 ? nn[2] : nn[3];
-    const int q = grp == 0 ? pp[0] : grp == 1 ? pp[1] : grp == 2 ? pp[2] : pp[3];
-    return Chunk{reinterpret_cast<const uint4 *>(pool) + ((uint64_t(h) << 32) | l), n, q};
+    const uint32_t l = grp == 0 ? lo[0] : grp == 1 ? lo[1] : grp == 2 ? lo[2] : lo[3];
+    const uint32_t h = grp == 0 ? hi[0] : grp == 1 ? hi[1] : grp == 2 ? hi[2] : hi[3];
+    return RowHandout{reinterpret_cast<const uint4 *>(pool) + ((uint64_t(h) << 8) | (l >> 24)), int(l & 0x3fffffu)};
 }
 __device__ __forceinline__ uint32_t scan_srows(const uint32_t *bm, const uint32_t *__restrict__ spool, unsigned long long desc, int lane) {
     const int grp = lane >> 4, sub = lane & 15;
@@ -142,34 +123,42 @@ __device__ __forceinline__ uint32_t scan_srows(const uint32_t *bm, const uint32_
     const bool any = (dlo & 0x3fffffu) != 0;
     const uint32_t form = (dlo >> 22) & 3u;
     uint32_t cnt = 0;
-    int max_n;
-    for (RowCursor c{__ballot(any && form == kFormBitset)}; c.more();) {  // AND the bitset with the pivot bitmap, 128 ids per unit
-        const Chunk k = take_chunks(c, spool, dlo, dhi, grp, max_n);
-        uint4 p = {0u, 0u, 0u, 0u}, p2 = {0u, 0u, 0u, 0u};
-        if (sub < k.n) p = k.row[sub];
-        if (sub + 16 < k.n) p2 = k.row[sub + 16];
-        const uint4 q = *reinterpret_cast<const uint4 *>(bm + 4 * ((k.pos + sub) & 511));  // a row has at most 512 bitset units
-        cnt += uint32_t(__popc(p.x & q.x) + __popc(p.y & q.y) + __popc(p.z & q.z) + __popc(p.w & q.w));
-        if (max_n > 16) {
-            const uint4 q2 = *reinterpret_cast<const uint4 *>(bm + 4 * ((k.pos + sub + 16) & 511));
-            cnt += uint32_t(__popc(p2.x & q2.x) + __popc(p2.y & q2.y) + __popc(p2.z & q2.z) + __popc(p2.w & q2.w));
+    for (unsigned long long todo = __ballot(any && form == kFormBitset); todo;) {  // AND the bitset with the pivot bitmap, 128 ids per unit
+        const RowHandout r = take_rows(todo, spool, dlo, dhi, grp);
+        for (int j = sub; j < r.units; j += 32) {
+            const uint4 p = r.row[j];
+            const uint4 q = *reinterpret_cast<const uint4 *>(bm + 4 * j);
+            uint32_t c = uint32_t(__popc(p.x & q.x) + __popc(p.y & q.y) + __popc(p.z & q.z) + __popc(p.w & q.w));
+            if (j + 16 < r.units) {
+                const uint4 p2 = r.row[j + 16];
+                const uint4 q2 = *reinterpret_cast<const uint4 *>(bm + 4 * (j + 16));
+                c += uint32_t(__popc(p2.x & q2.x) + __popc(p2.y & q2.y) + __popc(p2.z & q2.z) + __popc(p2.w & q2.w));
+            }
+            cnt += c;
         }
     }
-    for (RowCursor c{__ballot(any && form == kFormDelta)}; c.more();) {
-        const Chunk k = take_chunks(c, spool, dlo, dhi, grp, max_n);
-        uint4 p = {0u, 0u, 0u, 0u}, p2 = {0u, 0u, 0u, 0u};  // count byte 0: no id
-        if (sub < k.n) p = k.row[sub];
-        if (sub + 16 < k.n) p2 = k.row[sub + 16];
-        cnt += delta_unit_hits(bm, p);
-        if (max_n > 16) cnt += delta_unit_hits(bm, p2);
+    for (unsigned long long todo = __ballot(any && form == kFormDelta); todo;) {
+        const RowHandout r = take_rows(todo, spool, dlo, dhi, grp);
+        int j = sub;
+        for (; j + 16 < r.units; j += 32) {
+            const uint4 p = r.row[j], q = r.row[j + 16];
+            cnt += delta_unit_hits(bm, p);
+            cnt += delta_unit_hits(bm, q);
+        }
+        if (j < r.units) cnt += delta_unit_hits(bm, r.row[j]);
     }
-    for (RowCursor c{__ballot(any && form == kFormList)}; c.more();) {  // 16-bit list, 8 ids per unit, filler 0xFFFF
-        const Chunk k = take_chunks(c, spool, dlo, dhi, grp, max_n);
-        uint4 p = {~0u, ~0u, ~0u, ~0u}, p2 = {~0u, ~0u, ~0u, ~0u};
-        if (sub < k.n) p = k.row[sub];
-        if (sub + 16 < k.n) p2 = k.row[sub + 16];
-        cnt += hub_hits8(bm, u4u{p.x, p.y, p.z, p.w});
-        if (max_n > 16) cnt += hub_hits8(bm, u4u{p2.x, p2.y, p2.z, p2.w});
+    for (unsigned long long todo = __ballot(any && form == kFormList); todo;) {  // 16-bit list, 8 ids per unit, filler 0xFFFF
+        const RowHandout r = take_rows(todo, spool, dlo, dhi, grp);
+        int j = sub;
+        for (; j + 16 < r.units; j += 32) {
+            const uint4 p = r.row[j], q = r.row[j + 16];
+            cnt += hub_hits8(bm, u4u{p.x, p.y, p.z, p.w});
+            cnt += hub_hits8(bm, u4u{q.x, q.y, q.z, q.w});
+        }
+        if (j < r.units) {
+            const uint4 p = r.row[j];
+            cnt += hub_hits8(bm, u4u{p.x, p.y, p.z, p.w});
+        }
     }
     return cnt;
 }
@@ -340,7 +329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int32_t u = it.pivot;
     const int64_t hb = hoff[u], tb = toff[u];
     const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
-    const int ne = it.count & 0xffff;  // the high half counts the inline entries among them (bookkeeping only)
+    const int ne = it.count;
     const unsigned long long *__restrict__ ent = task + 2 * it.begin;
 
     for (int i = tid; i < kBitmapWords; i += 256) bm[i] = 0;
@@ -533,7 +522,7 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
     unsigned long long units = 0, probes = 0, bytes = 0;
     auto slots = [](unsigned long long d, bool tail) -> unsigned long long {
         const unsigned long long n = d & 0x3fffffull, f = (d >> 22) & 3ull;
-        return n * (tail ? (f ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : 4ull));
+        return n * (tail ? (f == kFormDelta ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : 4ull));
     };
     for (int64_t q = wave0;; q += nwaves) {
         const int64_t pos = first + q * nparts + part;
@@ -575,21 +564,21 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
     unsigned long long units = 0, probes = 0, bytes = 0;
     auto slots = [](unsigned long long d, bool tail) -> unsigned long long {
         const unsigned long long n = d & 0x3fffffull, f = (d >> 22) & 3ull;
-        return n * (tail ? (f ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : 4ull));
+        return n * (tail ? (f == kFormDelta ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : 4ull));
     };
     for (int64_t q = wave0;; q += nwaves) {
         const int64_t pos = q * nparts + part;
         if (pos >= n_items) break;
         const gmsx_task_item it = items[pos];
-        const int ne = it.count & 0xffff;
+        const int ne = it.count;
         if (lane == 0) {
-            units += (unsigned long long)(ne - (it.count >> 16));  // inline entries stand for edges counted at their light pivots
             bytes += 2ull * (unsigned long long)(hoff[it.pivot + 1] - hoff[it.pivot]) + 4ull * (unsigned long long)(toff[it.pivot + 1] - toff[it.pivot]);
         }
         for (int i = lane; i < ne; i += 64) {
             const unsigned long long d = task[2 * (it.begin + i)], t = task[2 * (it.begin + i) + 1];
             bytes += 16ull + 16ull * ((d & 0x3fffffull) + (t & 0x3fffffull));
             probes += slots(d, false) + slots(t, true);
+            if (!((t >> 22) & 1ull)) ++units;  // bit 22 marks an inline entry: its edges are counted at their light pivots
         }
     }
     for (int s = 32; s > 0; s >>= 1) {
