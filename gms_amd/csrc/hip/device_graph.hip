@@ -448,10 +448,35 @@ __global__ void k_inline_entries(int64_t n, const int64_t *__restrict__ ihoff, c
 }
 
 // ---- task lists of the heavy pivots (device_graph.hpp) -------------------------------------------------------------------------
-// The rule, evaluated once per oriented edge (u,v), u heavy: the edge is handed to v ("reverse") iff v is heavy too and u's rows are
-// strictly fewer 16-byte units than v's; otherwise u keeps it ("forward").
+// The rule, evaluated once per oriented edge (u,v), u heavy: the edge is handed to v ("reverse") iff v is heavy too and the part of u's
+// rows that v has to stream (cut at v's id) is strictly fewer 16-byte units than what u would stream of v's; otherwise u keeps it.
 __device__ __forceinline__ uint32_t row_units(const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow, int32_t x) {
     return uint32_t(srow[x] & 0x3fffffull) + uint32_t(trow[x] & 0x3fffffull);
+}
+// A handed-over row is needed only up to the receiving pivot's id: N+(v) lies below v.  The units of u's hub stream row that can hold
+// ids below hub member v (which has `below` hub members of u in front of it), and of u's tail stream row for tail member v:
+__device__ __forceinline__ uint32_t cut_hub_units(const uint32_t *__restrict__ spool, unsigned long long d, int below, int32_t v) {
+    const uint32_t units = uint32_t(d) & 0x3fffffu, form = (uint32_t(d) >> 22) & 3u;
+    if (form == kFormList) return min(units, uint32_t(below + 7) / 8u);
+    if (form == kFormBitset) return min(units, uint32_t(v + 127) / 128u);
+    const uint4 *row = reinterpret_cast<const uint4 *>(spool) + (d >> 24);  // byte-delta: units ascend by their 16-bit base id
+    uint32_t lo = 0, hi = units;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (int32_t(row[mid].x & 0xffffu) < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ uint32_t cut_tail_units(const uint32_t *__restrict__ tpool, unsigned long long d, int below, int32_t v) {
+    const uint32_t units = uint32_t(d) & 0x3fffffu, form = (uint32_t(d) >> 22) & 3u;
+    if (form != kFormDelta) return min(units, uint32_t(below + 3) / 4u);
+    const uint4 *row = reinterpret_cast<const uint4 *>(tpool) + (d >> 24);  // 16-bit delta: units ascend by their 32-bit base id
+    uint32_t lo = 0, hi = units;
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (int32_t(row[mid].x) < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
 }
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32_t *__restrict__ order, const int64_t *__restrict__ hoff,
@@ -460,7 +485,8 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                                                     const unsigned long long *__restrict__ trow, int two_sided, unsigned long long *__restrict__ cnt,
                                                     const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ task,
                                                     unsigned long long *__restrict__ reversed, const int64_t *__restrict__ ihoff,
-                                                    const int64_t *__restrict__ itoff) {
+                                                    const int64_t *__restrict__ itoff, const uint32_t *__restrict__ spool,
+                                                    const uint32_t *__restrict__ tpool) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -469,7 +495,6 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
         const int32_t u = order[pos];
         const int64_t hb = hoff[u], tb = toff[u];
         const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
-        const uint32_t su = row_units(srow, trow, u);
         const unsigned long long du_s = srow[u], du_t = trow[u];
         int64_t fwd = FILL ? tbeg[u] + inline_chunks(ihoff, itoff, u) : 0;  // next forward slot (wave-uniform); the inline entries come first
         for (int base = 0; base < hl + tl; base += 64) {
@@ -480,7 +505,13 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                 if (x != 0xFFFFu) v = int32_t(x);
             } else if (i < hl + tl) v = tadj[tb + i - hl];
             bool reverse = false;
-            if (v >= 0 && two_sided && dplus[v] >= kHeavy) reverse = row_units(srow, trow, v) > su;
+            uint32_t ch = 0, ct = 0;  // units of u's rows that v would have to stream
+            if (v >= 0 && two_sided && dplus[v] >= kHeavy) {
+                ch = i < hl ? cut_hub_units(spool, du_s, i, v) : uint32_t(du_s) & 0x3fffffu;  // a tail member sees the whole hub part
+                ct = (i < hl || toff[v + 1] == toff[v]) ? 0u : cut_tail_units(tpool, du_t, i - hl, v);  // a pivot without tail part has nothing to match
+                const uint32_t keep = uint32_t(srow[v] & 0x3fffffull) + (i > hl ? uint32_t(trow[v] & 0x3fffffull) : 0u);  // what u would stream
+                reverse = ch + ct < keep;
+            }
             const unsigned long long fmask = __ballot(v >= 0 && !reverse);
             if (FILL) {
                 if (v >= 0 && !reverse) {
@@ -490,8 +521,8 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                     task[2 * slot + 1] = (i > hl) ? trow[v] : 0ull;
                 } else if (v >= 0) {
                     const int64_t slot = tbeg[v + 1] - 1 - int64_t(atomicAdd(&cnt[v], 1ull));  // reverse entries fill v's list from its end
-                    task[2 * slot] = du_s;
-                    task[2 * slot + 1] = (toff[v + 1] > toff[v]) ? du_t : 0ull;  // a pivot without tail part has nothing to match
+                    task[2 * slot] = ch ? (du_s & ~0x3fffffull) | ch : 0ull;
+                    task[2 * slot + 1] = ct ? (du_t & ~0x3fffffull) | ct : 0ull;
                 }
                 fwd += __popcll(fmask);
             } else {
@@ -912,7 +943,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         const int grid = grid_for_waves(n_heavy);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
-                               g->trow, two_sided, cnt, g->tbeg, static_cast<unsigned long long *>(nullptr), cnt + n + 1, ihoff, itoff);
+                               g->trow, two_sided, cnt, g->tbeg, static_cast<unsigned long long *>(nullptr), cnt + n + 1, ihoff, itoff, g->spool, g->tpool);
         if (int rc = exclusive_scan_i64(reinterpret_cast<const int64_t *>(cnt), g->tbeg, n + 1, s)) return rc;
         unsigned long long rev = 0;
         GMSX_HIP(hipMemcpy(&g->task_entries, g->tbeg + n, sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -923,7 +954,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         if (n > 0) hipLaunchKernelGGL(k_inline_entries<true>, dim3(vb), dim3(256), 0, s, n, ihoff, itoff, inline_h_base, inline_t_base, cnt, g->tbeg, g->task);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
-                               g->trow, two_sided, cnt, g->tbeg, g->task, cnt + n + 1, ihoff, itoff);
+                               g->trow, two_sided, cnt, g->tbeg, g->task, cnt + n + 1, ihoff, itoff, g->spool, g->tpool);
         // every list sorted by (form, units) of the hub stream row: the four rows a wave works on at a time are then equally long
         // (tc.hip, scan_srows).  The order of a list carries no meaning.  GMSX_TC_SORT_TASKS=0 skips it (A/B knob).
         bool sort_tasks = g->task_entries > 0 && g->task_entries < (int64_t(1) << 32) && n < (int64_t(1) << 32);

@@ -670,12 +670,11 @@ __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict_
     }
 }
 
-// Diagnostics behind gmsx_tc_row_histogram: how the stream rows the heavy pivots read are distributed over row lengths (a 16-lane
-// group works on one row, so a row of n units keeps min(n,16)/16 of its lanes busy), and what the light pivots' gathers cost against
-// streaming the same member's rows.  out[(cls*24 + bin)*2 + {0,1}] = rows, units; cls: hub rows as list / bitset / byte-delta, tail
-// rows as list / delta; bin: 1…16 units exactly, then 17-32, 33-64, … 1025+.  out[240…]: light pivots — members with a bitset:
-// gathered words, words of those whose rows would be cheaper to stream at 128 B per gathered word, the stream bytes of those;
-// out[248…251]: Σ over oriented edges (u,v) of the stream units of v, and of min(units of u, units of v), heavy then light pivots u.
+// Diagnostics behind gmsx_tc_row_histogram: how the stream rows the work items read are distributed over row lengths (a group of W
+// lanes works on one row, so short rows keep few lanes busy).  out[(cls*24 + bin)*2 + {0,1}] = rows, units; cls: hub rows as list /
+// bitset / byte-delta, tail rows as list / delta; bin: 1…16 units exactly, then 17-32, 33-64, … 1025+.  out[240…243]: entries, inline
+// entries, work items, pivots' own container bytes; out[248…251]: Σ over the oriented edges (u,v) of heavy then light pivots u of the
+// stream units of v's rows and of min(units of u's rows, units of v's rows) — what the smaller-endpoint rule is about.
 __device__ __forceinline__ int hist_bin(unsigned long long units) {
     if (units <= 16) return int(units) - 1;
     int b = 16;
@@ -686,7 +685,8 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
                                                      const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                      const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
                                                      const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
-                                                     int32_t bitset_limit, int64_t end, unsigned long long *__restrict__ out) {
+                                                     const unsigned long long *__restrict__ task, const gmsx_task_item *__restrict__ items,
+                                                     int64_t n_items, int64_t end, unsigned long long *__restrict__ out) {
     __shared__ unsigned long long h[256];
     for (int i = threadIdx.x; i < 256; i += 256) h[i] = 0;
     __syncthreads();
@@ -699,63 +699,44 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
         atomicAdd(&h[b], 1ull);
         atomicAdd(&h[b + 1], units);
     };
+    for (int64_t q = wave0; q < n_items; q += nwaves) {
+        const gmsx_task_item it = items[q];
+        if (lane == 0) {
+            atomicAdd(&h[240], (unsigned long long)it.count);
+            atomicAdd(&h[242], 1ull);
+            atomicAdd(&h[243], 2ull * (unsigned long long)(hoff[it.pivot + 1] - hoff[it.pivot]) + 4ull * (unsigned long long)(toff[it.pivot + 1] - toff[it.pivot]));
+        }
+        for (int i = lane; i < it.count; i += 64) {
+            const unsigned long long d = task[2 * (it.begin + i)], t = task[2 * (it.begin + i) + 1];
+            add(int((d >> 22) & 3), d & 0x3fffffull);
+            add(((t >> 22) & 3) == kFormDelta ? 4 : 3, t & 0x3fffffull);
+            if ((t >> 22) & 1ull) atomicAdd(&h[241], 1ull);
+        }
+    }
     for (int64_t pos = wave0; pos < end; pos += nwaves) {
         const int32_t u = order[pos];
         const int du = dplus[u];
         if (du < 2) continue;
-        const bool heavy = du >= 64;
         const int64_t hb = hoff[u], tb = toff[u];
         const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
-        {  // either endpoint of an oriented edge can be the streamed side: Σ s(v) (what the pass does) against Σ min(s(u), s(v))
-            const unsigned long long su = (srow[u] & 0x3fffffull) + (trow[u] & 0x3fffffull);
-            unsigned long long cur = 0, best = 0;
-            for (int i = lane; i < hl + tl; i += 64) {
-                int32_t v;
-                if (i < hl) {
-                    const uint32_t x = hadj[hb + i];
-                    if (x == 0xFFFFu) continue;
-                    v = int32_t(x);
-                } else v = tadj[tb + i - hl];
-                const unsigned long long sv = (srow[v] & 0x3fffffull) + (trow[v] & 0x3fffffull);
-                cur += sv;
-                best += min(su, sv);
-            }
-            atomicAdd(&h[heavy ? 248 : 250], cur);
-            atomicAdd(&h[heavy ? 249 : 251], best);
+        const unsigned long long su = (srow[u] & 0x3fffffull) + (trow[u] & 0x3fffffull);
+        unsigned long long cur = 0, best = 0, cut = 0;
+        for (int i = lane; i < hl + tl; i += 64) {
+            int32_t v;
+            if (i < hl) {
+                const uint32_t x = hadj[hb + i];
+                if (x == 0xFFFFu) continue;
+                v = int32_t(x);
+            } else v = tadj[tb + i - hl];
+            const unsigned long long sv = (srow[v] & 0x3fffffull) + (trow[v] & 0x3fffffull);
+            cur += sv;
+            best += min(su, sv);
+            // only the ids of u below v can be in N+(v): member i of u has i of them, about the first i/d+ of u's units
+            cut += min(sv, dplus[v] >= kHeavy ? (su * (unsigned long long)i + du - 1) / (unsigned long long)du : ~0ull);
         }
-        if (heavy) {
-            for (int i = lane; i < hl; i += 64) {
-                const uint32_t v = hadj[hb + i];
-                if (v == 0xFFFFu) continue;
-                const unsigned long long d = srow[v];
-                add(int((d >> 22) & 3), d & 0x3fffffull);
-            }
-            for (int i = lane; i < tl; i += 64) {
-                const int32_t v = tadj[tb + i];
-                const unsigned long long d = srow[v], t = trow[v];
-                add(int((d >> 22) & 3), d & 0x3fffffull);
-                if (i > 0) add(((t >> 22) & 3) ? 4 : 3, t & 0x3fffffull);
-            }
-        } else {  // hl (padded) + tl <= 64: one lane per member, as in k_tc_wave_hub
-            int32_t mv = 0x7fffffff;
-            if (lane < hl) {
-                const uint32_t x = hadj[hb + lane];
-                if (x != 0xFFFFu) mv = int32_t(x);
-            } else if (lane - hl < tl) mv = tadj[tb + (lane - hl)];
-            const unsigned long long valid = __ballot(mv != 0x7fffffff);
-            const unsigned long long below = uint64_t(__popcll(valid & ((1ull << lane) - 1ull)));
-            if (mv < bitset_limit && below > 0) {
-                const unsigned long long d = srow[mv], t = trow[mv];
-                const unsigned long long sb = 16ull * ((d & 0x3fffffull) + (mv >= 65535 ? (t & 0x3fffffull) : 0ull));
-                const int k = mv >= 65535 ? 4 : 0;
-                atomicAdd(&h[240 + k], below);
-                if (sb < 128ull * below) {
-                    atomicAdd(&h[241 + k], below);
-                    atomicAdd(&h[242 + k], sb);
-                }
-                atomicAdd(&h[243 + k], sb);
-            }
-        }
+        atomicAdd(&h[du >= kHeavy ? 248 : 250], cur);
+        atomicAdd(&h[du >= kHeavy ? 249 : 251], best);
+        if (du >= kHeavy) atomicAdd(&h[252], cut);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += 256)
@@ -922,7 +903,7 @@ int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out256) {
     GMSX_HIP(hipMemsetAsync(acc, 0, 256 * 8, s));
     const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
     hipLaunchKernelGGL(k_tc_row_hist, dim3(unsigned(cus * 8)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow,
-                       g->bitset_limit, g->n, acc);
+                       g->task, g->titem, g->task_items, g->n, acc);
     GMSX_HIP(hipMemcpyAsync(out248, acc, 256 * 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     GMSX_HIP(hipGetLastError());

@@ -26,11 +26,9 @@ for c, name in enumerate(names):
     print(f"   lane-slot utilisation of the class ≈ {units/max(slots,1):.3f}")
     tot_rows += rows; tot_units += units; tot_slots += slots
 print(f"all classes: rows {tot_rows/1e6:.1f} M, units {tot_units/1e9:.2f} G, lane-slot utilisation ≈ {tot_units/max(tot_slots,1):.3f}")
-for k, lab in ((0, "hub-range members"), (4, "near-tail members")):
-    w, cw, cs, sb = (int(x) for x in light[k:k + 4])
-    print(f"light pivots, {lab}: gathered words {w/1e9:.3f} G (= {w*128/1e9:.1f} GB at 128 B each); cheaper to stream: {cw/1e9:.3f} G words "
-          f"({cw*128/1e9:.1f} GB) -> {cs/1e9:.1f} GB streamed; streaming all would be {sb/1e9:.1f} GB")
+print(f"entries {int(light[0])/1e6:.1f} M (inline {int(light[1])/1e6:.2f} M) in {int(light[2])/1e6:.2f} M work items; pivots' own containers {int(light[3])/1e9:.2f} GB")
 for k, lab in ((8, "heavy pivots"), (10, "light pivots")):
     cur, best = int(light[k]), int(light[k + 1])
     print(f"{lab}: streaming the member's rows for every oriented edge = {cur*16/1e9:.1f} GB; streaming the smaller endpoint's rows = {best*16/1e9:.1f} GB")
+print(f"heavy pivots, handed-over rows cut at the receiving pivot's id (estimate): {int(light[12])*16/1e9:.1f} GB")
 print(json.dumps({"scale": scale, "hist": hist.tolist(), "light": light.tolist()}))
