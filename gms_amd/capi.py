@@ -276,11 +276,12 @@ class DeviceGraph:
         _check(lib().gmsx_tc_partial(self._h, algo, part, nparts, C.byref(out), C.byref(st)), "gmsx_tc_partial")
         return (int(out.value), st.as_dict()) if stats else int(out.value)
 
-    BREAKDOWN = ["heavy_bitset_rows", "heavy_list_rows", "heavy_tailmember_hub_parts", "heavy_tailmember_tail_parts", "light_gathers",
-                 "light_streamed_hub_parts", "light_streamed_tail_parts", "pivot_containers", "heavy_list_rows_delta", "heavy_tailmember_hub_parts_delta",
-                 "light_streamed_hub_parts_delta", "row_fetches_heavy", "row_fetches_light_streamed",
-                 "actual_hubmember_list", "actual_hubmember_bitset", "actual_hubmember_delta", "actual_tailmember_hub_list", "actual_tailmember_hub_bitset",
-                 "actual_tailmember_hub_delta", "actual_tailmember_tail_list", "actual_tailmember_tail_delta"]
+    BREAKDOWN = ["hub_rows_list", "hub_rows_bitset", "hub_rows_delta", "tail_rows_list", "tail_rows_delta", "entries", "pivot_containers",
+                 "of_which_inline_rows", "light_streamed_hub_rows", "light_streamed_tail_rows", "light_pivot_lists_and_descriptors",
+                 "count_entries", "count_inline_entries", "count_work_items", "count_light_streamed_members",
+                 "reserved15", "reserved16", "reserved17", "reserved18", "reserved19", "reserved20"]
+    BREAKDOWN_BYTES = ("hub_rows_list", "hub_rows_bitset", "hub_rows_delta", "tail_rows_list", "tail_rows_delta", "entries", "pivot_containers",
+                       "light_streamed_hub_rows", "light_streamed_tail_rows", "light_pivot_lists_and_descriptors")  # these add up to stats.stream_bytes
 
     def tc_stream_breakdown(self):
         out = np.zeros(21, dtype=np.uint64)

@@ -5,23 +5,31 @@
 //
 // Formulation (GMSX_TC_ORIENTED).  The reference evaluates, for every undirected edge {u,v}, one intersect_count
 // on the full rows and divides the sum by 3.  Here every undirected edge is still exactly one intersect_count, but
-// on the degree-oriented rows:  T = Σ_u Σ_{v∈N+(u)} |N+(u) ∩ N+(v)|, which meets every triangle once, so the
-// returned integer is the same.
+// on the degree-oriented rows:  T = Σ_(u,v) |N+(u) ∩ N+(v)| over the oriented edges (v ∈ N+(u), rank(v) < rank(u)), which meets
+// every triangle once, so the returned integer is the same.
 //
-// Kernel shape — one pivot vertex u per workgroup (d+ >= 64, k_tc_block) or per wave (2 <= d+ < 64), Roaring-style sets:
-//   1. the pivot row N+(u) is staged into LDS: its hub part (rank ids < 65535) as a 65536-bit BITMAP (8 KB), its tail part as
-//      an open-addressing hash set fronted by a 32768-bit filter (heavy pivots) or as a 64 x 4 bucket set (light pivots);
-//   2. the rows N+(v), v ∈ N+(u), are streamed from HBM/MALL with coalesced 16-byte loads as STREAM ROWS (device_graph.hpp):
-//      whole 16-byte units of the cheapest of three forms per row — bitset (AND + popcount, 128 ids per unit), 16-bit list
-//      (8 ids), byte-delta (base + count + 13 gaps: 14 ids) — for the hub part, 32-bit ids or 16-bit delta units (6 ids) for
-//      the tail part; a wave works as four 16-lane groups, each on its own row, two loads in flight;
+// One intersect_count = one row staged in LDS (the PIVOT), the other STREAMED through it.  Either endpoint can be the pivot, and
+// only the ids of N+(u) below v can be in N+(v).  The upload decides per edge (device_graph.hip, task lists):
+//   * u heavy (d+ >= 64): the edge stays with u — v's stream rows are named in u's task list — unless v is heavy too and the
+//     part of u's rows below v is shorter than v's rows: then u's rows, CUT at v, are named in v's list;
+//   * u light: the members of u below v are COPIED into v's inline rows (v heavy or a popular target, rank id < inline_limit) —
+//     a 20-byte row behind a pointer would cost a 128-byte line per fetch, inline it is streamed; only far light members v stay
+//     with u and the light-pivot kernel.
+// Kernel shape, Roaring-style sets:
+//   1. k_tc_block — one workgroup per WORK ITEM (<= 1024 entries of one pivot's task list).  The pivot row is staged into LDS: its
+//      hub part (rank ids < 65535) as a 65536-bit BITMAP (8 KB), its tail part as an open-addressing hash set fronted by a
+//      32768-bit filter;
+//   2. the rows the entries name are streamed from HBM with coalesced 16-byte loads as STREAM ROWS (device_graph.hpp): whole
+//      16-byte units of the cheapest of three forms per row — bitset (AND + popcount, 128 ids per unit), 16-bit list (8 ids),
+//      byte-delta (base + count + 13 gaps: 14 ids) — for the hub part, 32-bit ids or 16-bit delta units (6 ids) for the tail
+//      part; a wave works as four 16-lane groups, each on its own row, two loads in flight; the lists are sorted by (form,
+//      length) so that the four rows are equally long;
 //   3. every streamed hub id is one LDS word read + bit test (no collisions, no branches); a tail id is one filter-bit test and,
 //      for the few that pass, a table probe; hits are counted per lane, reduced per workgroup, added to one of 64 spread u64
 //      accumulators (one atomic per workgroup);
-//   4. light pivots resolve the rows of all members that own a bitset container (rank id < bitset_limit) by inverted gathers
-//      (k_tc_wave_hub: "is my member w_j in N+(v_i)?", no LDS) and stream only the members beyond it (k_tc_wave); on large graphs
-//      both run BESIDE k_tc_block on side streams — the pass is bound by beyond-L2 bandwidth, not by any one kernel.
-// No MFMA: integer/indexing work bounded by row streaming (HBM/MALL/L2) and the LDS probe rate.
+//   4. k_tc_wave — light pivots with far light members: wave per pivot, private bitmap + bucket set, streams those members' rows;
+//      on large graphs it runs BESIDE k_tc_block on a side stream.
+// No MFMA: integer/indexing work bounded by row streaming (HBM) and VALU issue of the decode + probe sequence.
 #include "device_graph.hpp"
 
 #include <algorithm>
@@ -593,77 +601,56 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
     }
 }
 
-// Diagnostics (gmsx_tc_stream_breakdown): algorithmic stream bytes of one pass by category, plus what the 16-bit list rows
-// would cost in the byte-delta form of the stream rows (16-byte units: 16-bit base + count + 13 one-byte gaps; estimate).
-//   out[0] heavy pivots: bitset-form hub rows      out[1] heavy: list-form hub rows        out[2] heavy: hub parts of tail-member rows
-//   out[3] heavy: tail parts of tail-member rows   out[4] light: gathered words            out[5] light: hub parts of streamed rows
-//   out[6] light: tail parts of streamed rows      out[7] pivot containers
-//   out[8] = out[1] with min(list, delta) per row  out[9] = out[2] likewise                out[10] = out[5] likewise
-//   out[11] row fetches (heavy)                    out[12] row fetches (light, streamed)
-//   out[13..15] ACTUAL stream-row bytes of heavy pivots' hub members by form (list, bitset, delta); out[16..18] the same for the hub
-//   parts of their tail members; out[19..20] tail parts of their tail members (32-bit list, 16-bit delta)
-__global__ __launch_bounds__(256) void k_row_delta_bytes(int64_t n, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                         uint32_t *__restrict__ dbytes) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
-    for (int64_t v = wave0; v < n; v += nwaves) {
-        const int64_t b = hoff[v], e = hoff[v + 1];
-        unsigned slots = 0;
-        for (int64_t j = b + lane; j < e; j += 64) {
-            const uint32_t id = hadj[j];
-            if (id == 0xFFFFu) continue;
-            const uint32_t prev = j > b ? hadj[j - 1] : id;
-            slots += 1u + ((id - prev) > 255u ? 7u : 0u);  // a gap above a byte ends a unit: on average half a unit is lost (approximation)
-        }
-        for (int s = 32; s > 0; s >>= 1) slots += __shfl_down(slots, s);
-        if (lane == 0) dbytes[v] = ((slots + 13u) / 14u) * 16u;
-    }
-}
-__global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                      const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+// Diagnostics (gmsx_tc_stream_breakdown): the algorithmic stream bytes of one pass (= gmsx_stats.stream_bytes) by what is read.
+//   out[0..2]  hub stream rows named by the work items' entries, by form (16-bit list, bitset, byte-delta)
+//   out[3..4]  tail stream rows named by the entries (32-bit list, 16-bit delta)
+//   out[5]     the entries themselves (16 bytes each)         out[6]  the pivots' own containers, once per work item
+//   out[7]     of out[0] + out[3]: inline rows (ids handed over by light pivots)
+//   out[8..9]  light pivots: hub / tail stream rows of their far light members (k_tc_wave)
+//   out[10]    light pivots: their own hub parts + member ids + descriptors (k_tc_wave)
+//   out[11..14] counts: entries, inline entries, work items, far light members streamed by k_tc_wave
+//   out[15..20] reserved (0)
+__global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict__ hoff, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                       const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
-                                                      const uint32_t *__restrict__ dbytes, const unsigned long long *__restrict__ srow,
-                                                      const unsigned long long *__restrict__ trow, int32_t dense_limit, int32_t bitset_limit,
-                                                      int64_t end, unsigned long long *__restrict__ out) {
+                                                      const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
+                                                      const unsigned long long *__restrict__ task, const gmsx_task_item *__restrict__ items,
+                                                      int64_t n_items, int32_t inline_limit, int64_t first_light, int64_t end_light,
+                                                      unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
-    unsigned long long c[21] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t pos = wave0; pos < end; pos += nwaves) {
-        const int32_t u = order[pos];
-        const int du = dplus[u];
-        if (du < 2) continue;
-        const bool heavy = du >= 64;
-        const int hl = int(hoff[u + 1] - hoff[u]), tl = int(toff[u + 1] - toff[u]);
-        if (lane == 0) c[7] += 2ull * hl + 4ull * tl;
-        for (int64_t j = hoff[u] + lane; j < hoff[u + 1]; j += 64) {
-            const uint32_t v = hadj[j];
-            if (v == 0xFFFFu) continue;
-            const unsigned long long list = 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]), bits = 4ull * (unsigned long long)bitset_words(int32_t(v));
-            if (heavy) {
-                c[11]++;
-                if (int32_t(v) < dense_limit && bits + 32 < list) c[0] += bits;
-                else { c[1] += list; c[8] += min(list, (unsigned long long)dbytes[v]); }
-                const unsigned long long d = srow[v];
-                c[13 + ((d >> 22) & 3)] += 16ull * (d & 0x3fffffull);  // actual stream bytes of hub members by form (list, bitset, delta)
-            } else c[4] += 4ull * (unsigned long long)(j - hoff[u]);
+    unsigned long long c[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t q = wave0; q < n_items; q += nwaves) {
+        const gmsx_task_item it = items[q];
+        if (lane == 0) {
+            c[6] += 2ull * (unsigned long long)(hoff[it.pivot + 1] - hoff[it.pivot]) + 4ull * (unsigned long long)(toff[it.pivot + 1] - toff[it.pivot]);
+            c[11] += (unsigned long long)it.count;
+            c[13] += 1;
         }
-        for (int64_t j = toff[u] + lane; j < toff[u + 1]; j += 64) {
-            const int32_t v = tadj[j];
-            const unsigned long long list = 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
-            const unsigned long long tail = j > toff[u] ? 4ull * (unsigned long long)(toff[v + 1] - toff[v]) : 0ull;
-            if (heavy) {
-                c[11]++; c[2] += list; c[9] += min(list, (unsigned long long)dbytes[v]); c[3] += tail;
-                const unsigned long long d = srow[v], t = trow[v];
-                c[16 + ((d >> 22) & 3)] += 16ull * (d & 0x3fffffull);           // hub parts of tail members by form
-                if (j > toff[u]) c[19 + (((t >> 22) & 3) ? 1 : 0)] += 16ull * (t & 0x3fffffull);  // their tail parts: list / delta
-            }
-            else if (v < bitset_limit) c[4] += 4ull * (unsigned long long)(du - tl + (j - toff[u]));
-            else { c[12]++; c[5] += list; c[10] += min(list, (unsigned long long)dbytes[v]); c[6] += tail; }
+        for (int i = lane; i < it.count; i += 64) {
+            const unsigned long long d = task[2 * (it.begin + i)], t = task[2 * (it.begin + i) + 1];
+            const unsigned long long db = 16ull * (d & 0x3fffffull), tb = 16ull * (t & 0x3fffffull);
+            const int fd = int((d >> 22) & 3);
+            c[fd == kFormList ? 0 : fd == kFormBitset ? 1 : 2] += db;
+            c[((t >> 22) & 3) == kFormDelta ? 4 : 3] += tb;
+            c[5] += 16;
+            if ((t >> 22) & 1ull) { c[7] += db + tb; c[12] += 1; }
         }
     }
-    for (int k = 0; k < 21; ++k) {
+    for (int64_t pos = first_light + wave0; pos < end_light; pos += nwaves) {
+        const int32_t u = order[pos];
+        const int64_t tb0 = toff[u], te = toff[u + 1];
+        if (lane == 0 && te > tb0) c[10] += 2ull * (unsigned long long)(hoff[u + 1] - hoff[u]);
+        for (int64_t j = tb0 + lane; j < te; j += 64) {
+            const int32_t v = tadj[j];
+            if (v < inline_limit || dplus[v] >= kHeavy) continue;
+            c[8] += 16ull * (srow[v] & 0x3fffffull);
+            if (j > tb0) c[9] += 16ull * (trow[v] & 0x3fffffull);
+            c[10] += 20;
+            c[14] += 1;
+        }
+    }
+    for (int k = 0; k < 15; ++k) {
         unsigned long long x = c[k];
         for (int s = 32; s > 0; s >>= 1) x += __shfl_down(x, s);
         if (lane == 0 && x) atomicAdd(&out[k], x);
@@ -764,18 +751,14 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     const int cus = c.compute_units > 0 ? c.compute_units : 256;
     const int64_t cap_blocks = int64_t(cus) * 16;
     const int64_t cnt_heavy = part_count(0, g->task_items, nparts, part), cnt_light = part_count(n_block, n_work, nparts, part);
-    // CO-SCHEDULING.  The heavy-pivot kernel is bound by beyond-L2 bandwidth, the two light-pivot kernels by memory latency
-    // (k_tc_wave) and by the gather rate of the texture addressers (k_tc_wave_hub): run back to back, each leaves the resource the
-    // others need idle.  So the light kernels go to two side streams FIRST, with grids of only a few workgroups per CU (they are
-    // persistent grid-stride kernels: 2 + 2 workgroups = 16 waves and 77 KB of LDS per CU), and the heavy kernel fills the
-    // remaining wave slots and LDS of every CU (4-5 workgroups, growing to 8 as the light kernels retire).  One pass then costs
-    // about max(heavy, light) instead of their sum.  GMSX_TC_OVERLAP=0 restores the serial order (full-width light grids).
-    static const int overlap = [] { const char *e = std::getenv("GMSX_TC_OVERLAP"); return e ? std::atoi(e) : 1; }();
-    static const int wave_wgs = [] { const char *e = std::getenv("GMSX_TC_WAVE_WGS"); return e ? std::max(1, std::atoi(e)) : 2; }();
-    // measured (tools/tc_overlap_sweep.py, MI355X): scale 26 268 -> 254 ms — 1.80 TB of beyond-L2 traffic at 7.1 TB/s, i.e. the pass then
-    // sits on the aggregate bandwidth roof and only fewer bytes can make it faster; scale 24 37.8 -> 36…46 ms (noisy: the light kernels are
-    // 12 ms there and the heavy kernel loses more to the sharing than they hide).  So: only in the large-graph regime, which is also
-    // where the near-tail bitsets are on.
+    // CO-SCHEDULING.  The work-item kernel is bound by HBM bandwidth and VALU issue, the light-pivot kernel (short rows behind
+    // dependent loads) by memory latency: back to back each leaves what the other needs idle.  So the light kernel goes to a side
+    // stream FIRST, as a persistent grid of a few workgroups per CU, and the work items fill the remaining wave slots and LDS of
+    // every CU.  GMSX_TC_OVERLAP=0 restores the serial order (full-width light grid), 2 forces co-scheduling on small graphs.
+    const int overlap = [] { const char *e = std::getenv("GMSX_TC_OVERLAP"); return e ? std::atoi(e) : 1; }();
+    const int wave_wgs = [] { const char *e = std::getenv("GMSX_TC_WAVE_WGS"); return e ? std::max(1, std::atoi(e)) : 2; }();
+    // measured (MI355X, scale 26): serial 95 ms, co-scheduled 93 ms (the light kernel is 15 ms of it); at scale 24 the light kernel is too
+    // short to be worth the shared CUs.  So: only in the large-graph regime (inline_limit beyond the hub range).
     const bool co = overlap && cnt_heavy > 0 && cnt_light > 0 && c.side[0] && c.side[1] && (overlap > 1 || g->inline_limit > g->dense_limit);
     hipStream_t s_wave = co ? c.side[1] : s;
     struct Join {  // joins the side streams on every way out once they were forked (error returns included)
@@ -867,24 +850,22 @@ extern "C" {
 int gmsx_tc_divisor(int algo) { return algo == GMSX_TC_FULL ? 3 : 1; }
 
 int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21) {
-    uint64_t *out13 = out21;
-    if (!g || !out13) return GMSX_ERR_INVALID;
+    if (!g || !out21) return GMSX_ERR_INVALID;
     if (int rc = ensure_init()) return rc;
     hipStream_t s = ctx().stream;
-    std::memset(out13, 0, 21 * sizeof(uint64_t));
+    std::memset(out21, 0, 21 * sizeof(uint64_t));
     if (g->n == 0) return GMSX_OK;
-    uint32_t *dbytes = nullptr;
+    int64_t n_block = 0, n_work = 0;
+    if (int rc = count_dplus_ge(g, kHeavy, &n_block)) return rc;
+    if (int rc = count_dplus_ge(g, 2, &n_work)) return rc;
     unsigned long long *acc = nullptr;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dbytes), size_t(g->n) * 4));
-    struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g1{dbytes};
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), 21 * 8));
-    Guard g2{acc};
+    struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g1{acc};
     GMSX_HIP(hipMemsetAsync(acc, 0, 21 * 8, s));
     const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
-    hipLaunchKernelGGL(k_row_delta_bytes, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->n, g->hoff, g->hadj, dbytes);
-    hipLaunchKernelGGL(k_tc_breakdown, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, dbytes,
-                       g->srow, g->trow, g->dense_limit, g->bitset_limit, g->n, acc);
-    GMSX_HIP(hipMemcpyAsync(out13, acc, 21 * 8, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_tc_breakdown, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->hoff, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow, g->task,
+                       g->titem, g->task_items, g->inline_limit, n_block, n_work, acc);
+    GMSX_HIP(hipMemcpyAsync(out21, acc, 21 * 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     GMSX_HIP(hipGetLastError());
     return GMSX_OK;

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GMSX_VERSION 200
+#define GMSX_VERSION 210
 
 /* ---- status codes ---- */
 enum {
@@ -116,7 +116,8 @@ typedef struct gmsx_stats {
     double setup_ms;           /* HIP-event time of per-call setup kernels (memsets, bin prep), not in kernel_ms */
     uint64_t units;            /* work units processed: intersect_count calls (edges) / root vertices */
     uint64_t alg_elements;     /* Σ(d_u+d_v) over the units of this call, 0 if n/a */
-    uint64_t probes;           /* TC: ids the oriented kernels stream (work-efficiency numerator); BK: resume rounds; else 0 */
+    uint64_t probes;           /* TC: id slots the oriented kernels probe (8 per list unit, 14 per byte-delta unit, 4 words per bitset
+                                * unit, 4 / 6 per tail unit); BK: resume rounds; else 0 */
     int32_t launches;          /* number of kernel launches inside kernel_ms */
     int32_t reserved;
     uint64_t stream_bytes;     /* TC (oriented): algorithmic bytes of THIS formulation per call — every pivot's own containers once, plus
@@ -166,19 +167,18 @@ int gmsx_tc_total(const gmsx_graph *g, int algo, uint64_t *triangles, gmsx_stats
  * all-reduce of SURVEY §8(e) (the OpenMP reduction(+:total) of parallel/total.h:12). */
 int gmsx_tc_partial(const gmsx_graph *g, int algo, int part, int nparts, uint64_t *partial, gmsx_stats *stats);
 int gmsx_tc_divisor(int algo); /* 1 for ORIENTED/AUTO, 3 for FULL */
-/* Diagnostics: the algorithmic stream bytes of one oriented pass (gmsx_stats.stream_bytes) split by what is read — out[0..7]: heavy
- * pivots' bitset-form hub rows, list-form hub rows, hub parts and tail parts of tail-member rows; light pivots' gathered words, hub
- * parts and tail parts of streamed rows; the pivots' own containers — out[8..10]: entries 1, 2, 5 if every 16-bit list row were
- * stored in the smaller of list / byte-delta form (an estimate); out[11..12]: row fetches of heavy / light pivots; out[13..20]: the
- * ACTUAL stream-row bytes of the heavy pivots by form — hub members (list, bitset, delta), hub parts of tail members (list, bitset,
- * delta), tail parts of tail members (32-bit list, 16-bit delta).  21 values, host. */
+/* Diagnostics: the algorithmic stream bytes of one oriented pass (gmsx_stats.stream_bytes) split by what is read — out[0..2]: the hub
+ * stream rows named by the work items' entries, by form (16-bit list, bitset, byte-delta); out[3..4]: the tail stream rows (32-bit
+ * list, 16-bit delta); out[5]: the entries themselves; out[6]: the pivots' own containers, once per work item; out[7]: the part of
+ * out[0] + out[3] that is inline rows (ids handed over by light pivots); out[8..10]: the light-pivot kernel — hub rows, tail rows of
+ * the far light members it streams, and its own lists + descriptors; out[11..14]: counts — entries, inline entries, work items,
+ * members streamed by the light-pivot kernel; out[15..20]: 0.  out[0..6] + out[8..10] = stream_bytes.  21 values, host. */
 int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21);
-/* Diagnostics: the stream rows read by the heavy pivots as a histogram over row length in 16-byte units — out[(cls*24 + bin)*2] rows,
- * [+1] units; cls 0..4 = hub rows as list / bitset / byte-delta, tail rows as list / delta; bin = 1 … 16 units exactly, then 17-32,
- * 33-64, … 1025+ — and, out[240..247], for the light pivots' members with a bitset (hub range, then near tail): gathered words, the
- * words and stream bytes of the members whose rows would be cheaper to stream (at 128 B per gathered word), stream bytes of all;
- * out[248..251]: Σ over oriented edges (u,v) of the stream units of v's rows and of min(units of u's rows, units of v's rows), for
- * heavy then light pivots u (out[252..255] reserved).  256 values, host. */
+/* Diagnostics: the stream rows named by the work items' entries as a histogram over row length in 16-byte units — out[(cls*24 +
+ * bin)*2] rows, [+1] units; cls 0..4 = hub rows as list / bitset / byte-delta, tail rows as list / delta; bin = 1 … 16 units exactly,
+ * then 17-32, 33-64, … 1025+; out[240..243]: entries, inline entries, work items, bytes of the pivots' own containers;
+ * out[248..251]: Σ over the oriented edges (u,v) of heavy then light pivots u of the stream units of v's rows and of min(units of
+ * u's rows, units of v's rows); out[252]: the same sum for heavy u with u's rows cut at v's id (estimate).  256 values, host. */
 int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out256);
 /* Par::vertex_count2 / vertex_count2_once (parallel/vertex.h:14-49): counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| (= 2·triangles at u),
  * indexed by the vertex ids of the uploaded CSR.  Runs on the k = 3 bit-matrix kernels (one atomic per pivot member); graphs

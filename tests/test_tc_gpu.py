@@ -168,29 +168,63 @@ def test_tail_bucket_overflow(gpu, oracle):
         g.free()
 
 
-@pytest.mark.parametrize("hub_limit,bitset_limit", [(16, 0), (16, 40), (16, 700), (16, 10 ** 6), (300, 301), (300, 4000), (0, 3000)])
-def test_near_tail_bitsets(gpu, oracle, hub_limit, bitset_limit):
-    """Rows of rank id < bitset_limit have a bitset container; light pivots resolve those members by inverted gathers
-    (k_tc_wave_hub), the others stream (k_tc_wave).  Any split of the tail into near and far parts gives the same counts —
-    for the triangle kernels and for the k-clique / Bron–Kerbosch kernels that share the containers."""
-    old = os.environ.get("GMSX_BITSET_LIMIT")
-    os.environ["GMSX_BITSET_LIMIT"] = str(bitset_limit)
+@pytest.mark.parametrize("hub_limit,inline_limit", [(16, 0), (16, 40), (16, 700), (16, 10 ** 6), (300, 301), (300, 4000), (0, 3000)])
+def test_inline_limit(gpu, oracle, hub_limit, inline_limit):
+    """Light pivots hand the edges to their heavy members and to members of rank id < inline_limit over as inline rows (the members
+    below v copied next to v, scanned by v's work items); only far light members stay with k_tc_wave.  Any limit gives the same
+    counts — for the triangle kernels and for the k-clique / Bron–Kerbosch kernels that share the containers."""
+    old = os.environ.get("GMSX_INLINE_LIMIT")
+    os.environ["GMSX_INLINE_LIMIT"] = str(inline_limit)
     try:
         for kind, scale, deg in (("kronecker", 13, 16), ("uniform", 12, 20)):
             csr = host_graph(gpu, kind, scale, deg, True)
             want = oracle.tc_total(csr.offsets(), csr.neighbors())
             g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_DEFAULT | (hub_limit << 8))
-            assert g.tc_total() == want
-            assert sum(g.tc_partial(p, 3) for p in range(3)) == want
+            t, st = g.tc_total(stats=True)
+            assert t == want and st["units"] == csr.num_edges
+            parts = [g.tc_partial(p, 3, stats=True) for p in range(3)]
+            assert sum(p[0] for p in parts) == want and sum(p[1]["units"] for p in parts) == csr.num_edges
             assert g.kclique_count(3)[1] == want
             if scale == 12:
                 assert g.bk_count() == oracle.bk_count(csr.offsets(), csr.neighbors())
             g.free()
     finally:
         if old is None:
-            os.environ.pop("GMSX_BITSET_LIMIT", None)
+            os.environ.pop("GMSX_INLINE_LIMIT", None)
         else:
-            os.environ["GMSX_BITSET_LIMIT"] = old
+            os.environ["GMSX_INLINE_LIMIT"] = old
+
+
+@pytest.mark.parametrize("knobs", [{"GMSX_TC_TWO_SIDED": "0"}, {"GMSX_TC_SORT_TASKS": "0"}, {"GMSX_TC_TWO_SIDED": "0", "GMSX_INLINE_LIMIT": "0"},
+                                   {"GMSX_TC_OVERLAP": "0"}, {"GMSX_TC_OVERLAP": "2"}])
+def test_task_list_knobs(gpu, oracle, knobs):
+    """Every oriented edge is counted at exactly one endpoint: at the pivot that keeps it (forward entry), at the member it was handed
+    to because the member's row is the bigger one (reverse entry, cut at the member's id), or inside the member's inline rows.  With
+    the hand-over off, the task lists unsorted, or the kernels serial / always co-scheduled, the count and the bookkeeping stay."""
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        for kind, scale, deg, hub_limit in (("kronecker", 14, 16, 0), ("kronecker", 13, 40, 64), ("uniform", 12, 120, 0), ("uniform", 12, 120, 500)):
+            csr = host_graph(gpu, kind, scale, deg, True)
+            want = oracle.tc_total(csr.offsets(), csr.neighbors())
+            g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_DEFAULT | (hub_limit << 8))
+            t, st = g.tc_total(stats=True)
+            assert t == want and st["units"] == csr.num_edges, (kind, scale, hub_limit)
+            b = g.tc_stream_breakdown()
+            assert sum(b[k] for k in gpu.DeviceGraph.BREAKDOWN_BYTES) == st["stream_bytes"]
+            assert b["count_entries"] >= b["count_inline_entries"] and b["of_which_inline_rows"] <= b["hub_rows_list"] + b["tail_rows_list"]
+            hist, extra = g.tc_row_histogram()
+            assert int(extra[0]) == b["count_entries"] and int(extra[2]) == b["count_work_items"]
+            assert 16 * int(hist[:3, :, 1].sum()) == b["hub_rows_list"] + b["hub_rows_bitset"] + b["hub_rows_delta"]
+            parts = [g.tc_partial(p, 5, stats=True) for p in range(5)]
+            assert sum(p[0] for p in parts) == want and sum(p[1]["units"] for p in parts) == csr.num_edges
+            g.free()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 @pytest.mark.parametrize("delta", ["0", "1", "2"])

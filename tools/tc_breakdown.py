@@ -13,7 +13,9 @@ csr = capi.HostCSR.generate("kronecker", scale, 16)
 g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_TRUSTED)
 tri, st = g.tc_total(stats=True)
 b = g.tc_stream_breakdown()
-total = sum(b[k] for k in capi.DeviceGraph.BREAKDOWN[:8])
+total = sum(b[k] for k in capi.DeviceGraph.BREAKDOWN_BYTES)
 print(json.dumps({"scale": scale, "triangles": tri, "kernel_ms": st["kernel_ms"], "stream_bytes": st["stream_bytes"], "sum_of_categories": total}))
 for k, v in b.items():
-    print("%-40s %12.3f GB" % (k, v / 1e9) if not k.startswith("row_") else "%-40s %12.3f M" % (k, v / 1e6))
+    if k.startswith("reserved"):
+        continue
+    print("%-40s %12.3f GB" % (k, v / 1e9) if not k.startswith("count_") else "%-40s %12.3f M" % (k, v / 1e6))
