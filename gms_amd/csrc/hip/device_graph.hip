@@ -359,11 +359,13 @@ __global__ void k_count_ge(int64_t n, const int32_t *__restrict__ keys, int32_t 
 
 // ---- inline rows (build step 4c / 5b) --------------------------------------------------------------------------------------------
 static constexpr int kInlineChunk = 64;  // units of an inline row per task entry
+static constexpr int kInlineFirst = 64;  // a heavy pivot hands the edges to its first kInlineFirst members over inline too: their cut rows are 1-8 units,
+                                         // 2 bytes per id inline against 16 bytes of entry + a 128-byte line behind a pointer
 __device__ __forceinline__ bool takes_inline(int32_t v, int32_t inline_limit, const int32_t *__restrict__ dplus) {
     return v < inline_limit || dplus[v] >= kHeavy;
 }
-// Wave per light pivot u (positions [first, end) of `order`), one lane per member (hub part — padded at its end — in the low lanes,
-// tail part behind it, both ascending; hl + tl <= 64).  COUNT: ids handed over per receiving member; FILL: copies them (cnt_* are
+// Wave per pivot u (positions [first, end) of `order`: every pivot with d+ >= 2), one lane per member (hub part — padded at its end — in
+// the low lanes, tail part behind it, both ascending; a light pivot has hl + tl <= 64, a heavy one takes part with its first 64).  COUNT: ids handed over per receiving member; FILL: copies them (cnt_* are
 // the cursors then) and blanks the tdesc descriptors of the far members that were handed over, so that k_tc_wave skips them.
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_inline_rows(int64_t first, int64_t end, const int32_t *__restrict__ order, const int64_t *__restrict__ hoff,
@@ -378,7 +380,8 @@ __global__ __launch_bounds__(256) void k_inline_rows(int64_t first, int64_t end,
     for (int64_t pos = first + wave0; pos < end; pos += nwaves) {
         const int32_t u = order[pos];
         const int64_t hb = hoff[u], tb = toff[u];
-        const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
+        // a heavy pivot takes part with its first kInlineFirst members only (the low lanes of its combined list)
+        const int hl = min(int(hoff[u + 1] - hb), kInlineFirst), tl = min(int(toff[u + 1] - tb), kInlineFirst - hl);
         int32_t mv = 0x7fffffff;
         if (lane < hl) {
             const uint32_t x = hadj[hb + lane];
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                                                     const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ task,
                                                     unsigned long long *__restrict__ reversed, const int64_t *__restrict__ ihoff,
                                                     const int64_t *__restrict__ itoff, const uint32_t *__restrict__ spool,
-                                                    const uint32_t *__restrict__ tpool) {
+                                                    const uint32_t *__restrict__ tpool, int32_t inline_limit) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -504,9 +507,10 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                 const uint32_t x = hadj[hb + i];
                 if (x != 0xFFFFu) v = int32_t(x);
             } else if (i < hl + tl) v = tadj[tb + i - hl];
+            if (v >= 0 && i > 0 && i < kInlineFirst && takes_inline(v, inline_limit, dplus)) v = -1;  // handed over inline (k_inline_rows): no entry
             bool reverse = false;
             uint32_t ch = 0, ct = 0;  // units of u's rows that v would have to stream
-            if (v >= 0 && two_sided && dplus[v] >= kHeavy) {
+            if (v >= 0 && i > 0 && two_sided && dplus[v] >= kHeavy) {
                 ch = i < hl ? cut_hub_units(spool, du_s, i, v) : uint32_t(du_s) & 0x3fffffu;  // a tail member sees the whole hub part
                 ct = (i < hl || toff[v + 1] == toff[v]) ? 0u : cut_tail_units(tpool, du_t, i - hl, v);  // a pivot without tail part has nothing to match
                 const uint32_t keep = uint32_t(srow[v] & 0x3fffffull) + (i > hl ? uint32_t(trow[v] & 0x3fffffull) : 0u);  // what u would stream
@@ -516,7 +520,7 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
             if (FILL) {
                 if (v >= 0 && !reverse) {
                     const int64_t slot = fwd + __popcll(fmask & ((1ull << lane) - 1ull));
-                    task[2 * slot] = srow[v];
+                    task[2 * slot] = i > 0 ? srow[v] : 0ull;  // the first member has no member below it: the edge closes no triangle
                     // the tail ids of the first tail member lie below every tail id of the pivot; a hub member has no tail part
                     task[2 * slot + 1] = (i > hl) ? trow[v] : 0ull;
                 } else if (v >= 0) {
@@ -819,11 +823,11 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
             n_heavy = h[0];
             n_work = h[1];
         }
-        if (!g->rows_sorted && n_work > n_heavy) return GMSX_ERR_UNSUPPORTED;  // "members below v" are the lanes before v: needs ascending rows
+        if (!g->rows_sorted && n_work > 0) return GMSX_ERR_UNSUPPORTED;  // "members below v" are the lanes before v: needs ascending rows
         GMSX_HIP(hipMemsetAsync(inl_h, 0, size_t(n + 1) * sizeof(unsigned long long), s));
         GMSX_HIP(hipMemsetAsync(inl_t, 0, size_t(n + 1) * sizeof(unsigned long long), s));
-        if (n_work > n_heavy)
-            hipLaunchKernelGGL(k_inline_rows<false>, dim3(grid_for_waves(n_work - n_heavy)), dim3(256), 0, s, n_heavy, n_work, g->order, g->hoff, g->hadj,
+        if (n_work > 0)
+            hipLaunchKernelGGL(k_inline_rows<false>, dim3(grid_for_waves(n_work)), dim3(256), 0, s, int64_t(0), n_work, g->order, g->hoff, g->hadj,
                                g->toff, g->tadj, g->dplus, g->inline_limit, inl_h, inl_t, ihoff, itoff, int64_t(0), static_cast<uint16_t *>(nullptr),
                                int64_t(0), static_cast<int32_t *>(nullptr), static_cast<unsigned long long *>(nullptr));
         int64_t *uh = nullptr, *ut = nullptr;
@@ -920,10 +924,10 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     }
 
     // 5c. inline rows: copy the handed-over ids (pools exist now), blank the light pivots' descriptors of handed-over far members
-    if (n_work > n_heavy) {
+    if (n_work > 0) {
         GMSX_HIP(hipMemsetAsync(inl_h, 0, size_t(n + 1) * sizeof(unsigned long long), s));  // now the fill cursors
         GMSX_HIP(hipMemsetAsync(inl_t, 0, size_t(n + 1) * sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(k_inline_rows<true>, dim3(grid_for_waves(n_work - n_heavy)), dim3(256), 0, s, n_heavy, n_work, g->order, g->hoff, g->hadj, g->toff,
+        hipLaunchKernelGGL(k_inline_rows<true>, dim3(grid_for_waves(n_work)), dim3(256), 0, s, int64_t(0), n_work, g->order, g->hoff, g->hadj, g->toff,
                            g->tadj, g->dplus, g->inline_limit, inl_h, inl_t, ihoff, itoff, inline_h_base, reinterpret_cast<uint16_t *>(g->spool),
                            inline_t_base, reinterpret_cast<int32_t *>(g->tpool), g->tdesc);
     }
@@ -943,7 +947,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         const int grid = grid_for_waves(n_heavy);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
-                               g->trow, two_sided, cnt, g->tbeg, static_cast<unsigned long long *>(nullptr), cnt + n + 1, ihoff, itoff, g->spool, g->tpool);
+                               g->trow, two_sided, cnt, g->tbeg, static_cast<unsigned long long *>(nullptr), cnt + n + 1, ihoff, itoff, g->spool, g->tpool, g->inline_limit);
         if (int rc = exclusive_scan_i64(reinterpret_cast<const int64_t *>(cnt), g->tbeg, n + 1, s)) return rc;
         unsigned long long rev = 0;
         GMSX_HIP(hipMemcpy(&g->task_entries, g->tbeg + n, sizeof(int64_t), hipMemcpyDeviceToHost));
@@ -954,7 +958,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         if (n > 0) hipLaunchKernelGGL(k_inline_entries<true>, dim3(vb), dim3(256), 0, s, n, ihoff, itoff, inline_h_base, inline_t_base, cnt, g->tbeg, g->task);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
-                               g->trow, two_sided, cnt, g->tbeg, g->task, cnt + n + 1, ihoff, itoff, g->spool, g->tpool);
+                               g->trow, two_sided, cnt, g->tbeg, g->task, cnt + n + 1, ihoff, itoff, g->spool, g->tpool, g->inline_limit);
         // every list sorted by (form, units) of the hub stream row: the four rows a wave works on at a time are then equally long
         // (tc.hip, scan_srows).  The order of a list carries no meaning.  GMSX_TC_SORT_TASKS=0 skips it (A/B knob).
         bool sort_tasks = g->task_entries > 0 && g->task_entries < (int64_t(1) << 32) && n < (int64_t(1) << 32);

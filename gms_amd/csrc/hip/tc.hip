@@ -537,7 +537,16 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
         if (pos >= end) break;
         const int32_t u = order[pos];
         const int du = dplus[u];
-        if (du >= kHeavy) continue;  // counted per work item
+        if (du >= kHeavy) {  // counted per work item, except the edges to its first members that went inline (no entry)
+            const int hl = min(int(hoff[u + 1] - hoff[u]), 64), tl = min(int(toff[u + 1] - toff[u]), 64 - hl);
+            int32_t v = -1;
+            if (lane < hl) {
+                const uint32_t x = hadj[hoff[u] + lane];
+                if (x != 0xFFFFu) v = int32_t(x);
+            } else if (lane - hl < tl) v = tadj[toff[u] + lane - hl];
+            if (v >= 0 && lane > 0 && (v < inline_limit || dplus[v] >= kHeavy)) ++units;
+            continue;
+        }
         const int hl = int(hoff[u + 1] - hoff[u]), tl = int(toff[u + 1] - toff[u]);
         if (lane == 0) {
             units += (unsigned long long)du;
