@@ -12,6 +12,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 
 #include "../host/gmsx_internal.hpp"
 
@@ -630,6 +631,65 @@ static int exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t count, hi
     return GMSX_OK;
 }
 
+// ---- rows ascending: segmented radix sort in vertex ranges of < 2^31 entries ---------------------------------------------------------
+struct OffsetMinus {
+    int64_t base;
+    __host__ __device__ int64_t operator()(int64_t x) const { return x - base; }
+};
+__global__ void k_lower_bound_i64(int64_t count, const int64_t *__restrict__ a, int64_t target, int64_t *__restrict__ out) {
+    int64_t lo = 0, hi = count;  // first index with a[i] >= target (a ascending)
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (a[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    out[0] = lo;
+}
+template <class K>
+static int sort_rows(K *keys, int64_t entries, int64_t n, const int64_t *d_off, int end_bit, hipStream_t s) {
+    if (n <= 0 || entries <= 0) return GMSX_OK;
+    int64_t chunk = int64_t(1) << 31;
+    if (const char *e = std::getenv("GMSX_SORT_CHUNK")) {  // test hook: force several ranges on a small graph
+        const long long v = std::atoll(e);
+        if (v > 0) chunk = v;
+    }
+    int64_t *d_v = nullptr;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_v), sizeof(int64_t)));
+    DevGuard g_v{d_v};
+    int64_t v0 = 0, base = 0;
+    while (v0 < n) {
+        // the range [v0, v1): as many whole rows as fit below base + chunk, at least one
+        int64_t v1 = n;
+        if (entries - base > chunk) {
+            hipLaunchKernelGGL(k_lower_bound_i64, dim3(1), dim3(1), 0, s, n + 1, d_off, base + chunk + 1, d_v);
+            GMSX_HIP(hipStreamSynchronize(s));
+            GMSX_HIP(hipMemcpy(&v1, d_v, sizeof(int64_t), hipMemcpyDeviceToHost));
+            v1 = std::max(v0 + 1, std::min(n, v1 - 1));  // off[v1] <= base + chunk
+        }
+        int64_t end = 0;
+        GMSX_HIP(hipMemcpy(&end, d_off + v1, sizeof(int64_t), hipMemcpyDeviceToHost));
+        const int64_t cnt = end - base;
+        if (cnt >= (int64_t(1) << 32)) return GMSX_ERR_UNSUPPORTED;  // one row of 2^32 entries: not a graph this library can hold
+        if (cnt > 0) {
+            K *sorted = nullptr;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&sorted), size_t(cnt) * sizeof(K)));
+            DevGuard g_sorted{sorted};
+            auto begin = rocprim::make_transform_iterator(d_off + v0, OffsetMinus{base});
+            auto endit = rocprim::make_transform_iterator(d_off + v0 + 1, OffsetMinus{base});
+            size_t tmp_bytes = 0;
+            GMSX_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, keys + base, sorted, unsigned(cnt), unsigned(v1 - v0), begin, endit, 0, end_bit, s));
+            void *tmp = nullptr;
+            GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+            DevGuard g_tmp{tmp};
+            GMSX_HIP(rocprim::segmented_radix_sort_keys(tmp, tmp_bytes, keys + base, sorted, unsigned(cnt), unsigned(v1 - v0), begin, endit, 0, end_bit, s));
+            GMSX_HIP(hipMemcpyAsync(keys + base, sorted, size_t(cnt) * sizeof(K), hipMemcpyDeviceToDevice, s));
+            GMSX_HIP(hipStreamSynchronize(s));
+        }
+        v0 = v1;
+        base = end;
+    }
+    return GMSX_OK;
+}
+
 static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     hipStream_t s = ctx().stream;
     const int64_t n = g->n;
@@ -701,43 +761,12 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         hipLaunchKernelGGL(k_fill_parts, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, g->newid, hub_limit, g->hoff, g->toff,
                            g->hadj, g->tadj);
 
-    // 4a. hub rows ascending by rank id (the 0xFFFF pad sorts last): the dense rows of a pivot list (smallest ids) then
-    //     sit together, so the 16-lane groups of a wave mostly take the same path in the count kernels
-    if (n > 0 && g->hub_entries > 0 && g->hub_entries < (int64_t(1) << 32) && n < (int64_t(1) << 32)) {
-        uint16_t *sorted = nullptr;
-        if (int rc = dmalloc(&sorted, g->hub_entries + 8, nullptr)) return rc;
-        DevGuard g_sorted{sorted};
-        size_t tmp_bytes = 0;
-        GMSX_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, g->hadj, sorted, unsigned(g->hub_entries), unsigned(n), g->hoff,
-                                                    g->hoff + 1, 0, 16, s));
-        void *tmp = nullptr;
-        GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-        DevGuard g_tmp{tmp};
-        GMSX_HIP(rocprim::segmented_radix_sort_keys(tmp, tmp_bytes, g->hadj, sorted, unsigned(g->hub_entries), unsigned(n), g->hoff,
-                                                    g->hoff + 1, 0, 16, s));
-        GMSX_HIP(hipMemcpyAsync(g->hadj, sorted, size_t(g->hub_entries) * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
-        GMSX_HIP(hipStreamSynchronize(s));
-    }
-
-    // tail rows ascending too: the k-clique kernels binary-search a pivot's (short) tail list
-    if (n > 0 && g->tail_entries > 0 && g->tail_entries < (int64_t(1) << 32) && n < (int64_t(1) << 32)) {
-        int32_t *sorted = nullptr;
-        if (int rc = dmalloc(&sorted, g->tail_entries + 4, nullptr)) return rc;
-        DevGuard g_sorted{sorted};
-        size_t tmp_bytes = 0;
-        GMSX_HIP(rocprim::segmented_radix_sort_keys(nullptr, tmp_bytes, g->tadj, sorted, unsigned(g->tail_entries), unsigned(n), g->toff,
-                                                    g->toff + 1, 0, 32, s));
-        void *tmp = nullptr;
-        GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
-        DevGuard g_tmp{tmp};
-        GMSX_HIP(rocprim::segmented_radix_sort_keys(tmp, tmp_bytes, g->tadj, sorted, unsigned(g->tail_entries), unsigned(n), g->toff,
-                                                    g->toff + 1, 0, 32, s));
-        GMSX_HIP(hipMemcpyAsync(g->tadj, sorted, size_t(g->tail_entries) * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-        GMSX_HIP(hipStreamSynchronize(s));
-        g->rows_sorted = true;
-    }
-    if (g->hub_entries >= (int64_t(1) << 32) || n >= (int64_t(1) << 32)) g->rows_sorted = false;
-    if (g->tail_entries == 0 && g->hub_entries < (int64_t(1) << 32) && n < (int64_t(1) << 32)) g->rows_sorted = true;
+    // 4a. both containers of every row ascending by rank id (the 0xFFFF pad sorts last): "the members below v" are then the entries in
+    //     front of v — what the inline rows, the cut of handed-over rows, the delta forms and the k-clique binary searches rely on.
+    //     rocPRIM's segmented sort counts items in 32 bits, so the rows are sorted in vertex ranges of < 2^31 entries each.
+    if (int rc = sort_rows(g->hadj, g->hub_entries, n, g->hoff, 16, s)) return rc;
+    if (int rc = sort_rows(g->tadj, g->tail_entries, n, g->toff, 32, s)) return rc;
+    g->rows_sorted = true;
 
     // 4b. bitset containers: every hub row (rank id < hub_limit) as a bitmap over [0, v) — the dense streaming form of the triangle
     //     kernel and the edge test of the k-clique recursion.  <= 268 MB.
@@ -823,7 +852,6 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
             n_heavy = h[0];
             n_work = h[1];
         }
-        if (!g->rows_sorted && n_work > 0) return GMSX_ERR_UNSUPPORTED;  // "members below v" are the lanes before v: needs ascending rows
         GMSX_HIP(hipMemsetAsync(inl_h, 0, size_t(n + 1) * sizeof(unsigned long long), s));
         GMSX_HIP(hipMemsetAsync(inl_t, 0, size_t(n + 1) * sizeof(unsigned long long), s));
         if (n_work > 0)

@@ -157,3 +157,28 @@ def test_bk_memory_resident_search_equals_register_search(gpu, oracle, maxc):
             os.environ.pop("GMSX_BK_MAXC", None)
         else:
             os.environ["GMSX_BK_MAXC"] = old
+
+
+@pytest.mark.parametrize("chunk", [1, 700, 50000])
+def test_rows_sorted_in_ranges(gpu, oracle, chunk):
+    """rocPRIM's segmented sort counts items in 32 bits, so the upload sorts the rows in vertex ranges of < 2^31 container entries
+    (graphs beyond 2^32 entries used to keep unsorted rows and lose the delta forms and the k-clique kernels).  GMSX_SORT_CHUNK (test
+    hook) forces many ranges on a small graph: every kernel that relies on ascending rows still agrees with the oracle."""
+    old = os.environ.get("GMSX_SORT_CHUNK")
+    os.environ["GMSX_SORT_CHUNK"] = str(chunk)
+    try:
+        for kind, scale, deg, hub_limit in (("kronecker", 12, 16, 0), ("uniform", 11, 40, 64)):
+            csr = host_graph(gpu, kind, scale, deg, True)
+            g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_DEFAULT | (hub_limit << 8))
+            want = _WANT.setdefault(("tc", kind, scale, deg), oracle.tc_total(csr.offsets(), csr.neighbors()))
+            t, st = g.tc_total(stats=True)
+            assert t == want and st["units"] == csr.num_edges
+            assert g.kclique_count(3)[1] == want
+            assert g.kclique_count(4)[0] == _WANT.setdefault(("kc4", kind, scale, deg), oracle.kclique(csr.offsets(), csr.neighbors(), 4))
+            assert g.bk_count() == _WANT.setdefault(("bk", kind, scale, deg), oracle.bk_count(csr.offsets(), csr.neighbors()))
+            g.free()
+    finally:
+        if old is None:
+            os.environ.pop("GMSX_SORT_CHUNK", None)
+        else:
+            os.environ["GMSX_SORT_CHUNK"] = old
