@@ -433,7 +433,8 @@ __device__ __forceinline__ int64_t inline_chunks(const int64_t *__restrict__ iho
 // the inline entries of every receiver: chunk k of its hub inline row and chunk k of its tail inline row share entry k of its list
 template <bool FILL>
 __global__ void k_inline_entries(int64_t n, const int64_t *__restrict__ ihoff, const int64_t *__restrict__ itoff, int64_t base_h, int64_t base_t,
-                                 unsigned long long *__restrict__ cnt, const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ task) {
+                                 unsigned long long *__restrict__ cnt, const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ task,
+                                 uint32_t *__restrict__ tid) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v >= n) return;
     const int64_t c = inline_chunks(ihoff, itoff, v);
@@ -445,6 +446,7 @@ __global__ void k_inline_entries(int64_t n, const int64_t *__restrict__ ihoff, c
     for (int64_t k = 0; k < c; ++k) {
         const int64_t o = k * kInlineChunk;
         const int64_t nh = min(int64_t(kInlineChunk), uh - o), nt = min(int64_t(kInlineChunk), ut - o);
+        tid[tbeg[v] + k] = 0x80000000u | uint32_t(k);  // never a vertex id: no two entries of a list share a key
         task[2 * (tbeg[v] + k)] = nh > 0 ? ((unsigned long long)(base_h + ihoff[v] + o) << 24) | ((unsigned long long)kFormList << 22) | (unsigned long long)nh : 0ull;
         // bit 22 of the tail descriptor (no tail form uses it) marks an inline entry: it stands for no edge of its own in the bookkeeping
         task[2 * (tbeg[v] + k) + 1] = (nt > 0 ? ((unsigned long long)(base_t + itoff[v] + o) << 24) | (unsigned long long)nt : 0ull) | (1ull << 22);
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                                                     const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ task,
                                                     unsigned long long *__restrict__ reversed, const int64_t *__restrict__ ihoff,
                                                     const int64_t *__restrict__ itoff, const uint32_t *__restrict__ spool,
-                                                    const uint32_t *__restrict__ tpool, int32_t inline_limit) {
+                                                    const uint32_t *__restrict__ tpool, int32_t inline_limit, uint32_t *__restrict__ tid) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -521,11 +523,13 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
             if (FILL) {
                 if (v >= 0 && !reverse) {
                     const int64_t slot = fwd + __popcll(fmask & ((1ull << lane) - 1ull));
+                    tid[slot] = uint32_t(v);
                     task[2 * slot] = i > 0 ? srow[v] : 0ull;  // the first member has no member below it: the edge closes no triangle
                     // the tail ids of the first tail member lie below every tail id of the pivot; a hub member has no tail part
                     task[2 * slot + 1] = (i > hl) ? trow[v] : 0ull;
                 } else if (v >= 0) {
                     const int64_t slot = tbeg[v + 1] - 1 - int64_t(atomicAdd(&cnt[v], 1ull));  // reverse entries fill v's list from its end
+                    tid[slot] = uint32_t(u);
                     task[2 * slot] = ch ? (du_s & ~0x3fffffull) | ch : 0ull;
                     task[2 * slot + 1] = ct ? (du_t & ~0x3fffffull) | ct : 0ull;
                 }
@@ -545,9 +549,10 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
         if (lane == 0 && rev) atomicAdd(reversed, rev);
     }
 }
-__global__ void k_task_keys(int64_t entries, const unsigned long long *__restrict__ task, uint32_t *__restrict__ keys) {
+__global__ void k_task_keys(int64_t entries, const unsigned long long *__restrict__ task, const uint32_t *__restrict__ tid,
+                            unsigned long long *__restrict__ keys) {
     const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (e < entries) keys[e] = uint32_t(task[2 * e]) & 0xffffffu;  // form << 22 | units
+    if (e < entries) keys[e] = ((task[2 * e] & 0xffffffull) << 32) | tid[e];  // form << 22 | units, then the streamed vertex (unique per list)
 }
 // work items: the list of every vertex that has one (in launch order) in chunks of kTaskChunk entries
 __global__ void k_item_counts(int64_t n, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, int64_t *__restrict__ items) {
@@ -655,6 +660,7 @@ static int sort_rows(K *keys, int64_t entries, int64_t n, const int64_t *d_off, 
     int64_t *d_v = nullptr;
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_v), sizeof(int64_t)));
     DevGuard g_v{d_v};
+    GMSX_HIP(hipStreamSynchronize(s));  // the offsets are read with blocking copies below: whatever produced them must be done
     int64_t v0 = 0, base = 0;
     while (v0 < n) {
         // the range [v0, v1): as many whole rows as fit below base + chunk, at least one
@@ -688,6 +694,62 @@ static int sort_rows(K *keys, int64_t entries, int64_t n, const int64_t *d_off, 
         base = end;
     }
     return GMSX_OK;
+}
+
+// the same for (key, value) pairs: values reordered in place by their keys, segment by segment
+template <class K, class V>
+static int sort_segment_pairs(K *keys, V *vals, int64_t entries, int64_t n, const int64_t *d_off, int end_bit, hipStream_t s) {
+    if (n <= 0 || entries <= 0) return GMSX_OK;
+    int64_t chunk = int64_t(1) << 31;
+    if (const char *e = std::getenv("GMSX_SORT_CHUNK")) {
+        const long long v = std::atoll(e);
+        if (v > 0) chunk = v;
+    }
+    int64_t *d_v = nullptr;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_v), sizeof(int64_t)));
+    DevGuard g_v{d_v};
+    GMSX_HIP(hipStreamSynchronize(s));  // the offsets are read with blocking copies below: whatever produced them must be done
+    int64_t v0 = 0, base = 0;
+    while (v0 < n) {
+        int64_t v1 = n;
+        if (entries - base > chunk) {
+            hipLaunchKernelGGL(k_lower_bound_i64, dim3(1), dim3(1), 0, s, n + 1, d_off, base + chunk + 1, d_v);
+            GMSX_HIP(hipStreamSynchronize(s));
+            GMSX_HIP(hipMemcpy(&v1, d_v, sizeof(int64_t), hipMemcpyDeviceToHost));
+            v1 = std::max(v0 + 1, std::min(n, v1 - 1));
+        }
+        int64_t end = 0;
+        GMSX_HIP(hipMemcpy(&end, d_off + v1, sizeof(int64_t), hipMemcpyDeviceToHost));
+        const int64_t cnt = end - base;
+        if (cnt >= (int64_t(1) << 32)) return GMSX_ERR_UNSUPPORTED;
+        if (cnt > 0) {
+            K *k_out = nullptr;
+            V *v_out = nullptr;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&k_out), size_t(cnt) * sizeof(K)));
+            DevGuard g_ko{k_out};
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&v_out), size_t(cnt) * sizeof(V)));
+            DevGuard g_vo{v_out};
+            auto begin = rocprim::make_transform_iterator(d_off + v0, OffsetMinus{base});
+            auto endit = rocprim::make_transform_iterator(d_off + v0 + 1, OffsetMinus{base});
+            size_t tmp_bytes = 0;
+            GMSX_HIP(rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, keys + base, k_out, vals + base, v_out, unsigned(cnt), unsigned(v1 - v0), begin, endit, 0,
+                                                         end_bit, s));
+            void *tmp = nullptr;
+            GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
+            DevGuard g_tmp{tmp};
+            GMSX_HIP(rocprim::segmented_radix_sort_pairs(tmp, tmp_bytes, keys + base, k_out, vals + base, v_out, unsigned(cnt), unsigned(v1 - v0), begin, endit, 0,
+                                                         end_bit, s));
+            GMSX_HIP(hipMemcpyAsync(vals + base, v_out, size_t(cnt) * sizeof(V), hipMemcpyDeviceToDevice, s));
+            GMSX_HIP(hipStreamSynchronize(s));
+        }
+        v0 = v1;
+        base = end;
+    }
+    return GMSX_OK;
+}
+__global__ void k_scale_offsets(int64_t count, const int64_t *__restrict__ in, int64_t mul, int64_t *__restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = in[i] * mul;
 }
 
 static int build_device_sets(gmsx_graph *g, uint32_t flags) {
@@ -959,6 +1021,18 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
                            g->tadj, g->dplus, g->inline_limit, inl_h, inl_t, ihoff, itoff, inline_h_base, reinterpret_cast<uint16_t *>(g->spool),
                            inline_t_base, reinterpret_cast<int32_t *>(g->tpool), g->tdesc);
     }
+    // 5d. the ids arrive in the inline rows through atomic cursors, in any order: sort every receiver's rows (fillers last), so that the
+    //     chunks the work items name hold the same ids on every rank of a multi-GPU run
+    if (inline_h_units + inline_t_units > 0) {
+        int64_t *ioff = nullptr;
+        if (int rc = dmalloc(&ioff, n + 1, nullptr)) return rc;
+        DevGuard g_ioff{ioff};
+        const unsigned ob = unsigned((n + 1 + 255) / 256);
+        hipLaunchKernelGGL(k_scale_offsets, dim3(ob), dim3(256), 0, s, n + 1, ihoff, int64_t(8), ioff);
+        if (int rc = sort_rows(reinterpret_cast<uint16_t *>(g->spool) + inline_h_base * 8, inline_h_units * 8, n, ioff, 16, s)) return rc;
+        hipLaunchKernelGGL(k_scale_offsets, dim3(ob), dim3(256), 0, s, n + 1, itoff, int64_t(4), ioff);
+        if (int rc = sort_rows(g->tpool + inline_t_base * 4, inline_t_units * 4, n, ioff, 32, s)) return rc;
+    }
     // 6. task lists: inline entries, then every oriented edge of a heavy pivot at the endpoint whose row is the bigger one
     {
         int two_sided = 1;
@@ -971,53 +1045,40 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         const unsigned vb = unsigned(n / 256 + 1);
         if (n > 0)
             hipLaunchKernelGGL(k_inline_entries<false>, dim3(vb), dim3(256), 0, s, n, ihoff, itoff, inline_h_base, inline_t_base, cnt, g->tbeg,
-                               static_cast<unsigned long long *>(nullptr));
+                               static_cast<unsigned long long *>(nullptr), static_cast<uint32_t *>(nullptr));
         const int grid = grid_for_waves(n_heavy);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
-                               g->trow, two_sided, cnt, g->tbeg, static_cast<unsigned long long *>(nullptr), cnt + n + 1, ihoff, itoff, g->spool, g->tpool, g->inline_limit);
+                               g->trow, two_sided, cnt, g->tbeg, static_cast<unsigned long long *>(nullptr), cnt + n + 1, ihoff, itoff, g->spool, g->tpool, g->inline_limit,
+                               static_cast<uint32_t *>(nullptr));
         if (int rc = exclusive_scan_i64(reinterpret_cast<const int64_t *>(cnt), g->tbeg, n + 1, s)) return rc;
         unsigned long long rev = 0;
         GMSX_HIP(hipMemcpy(&g->task_entries, g->tbeg + n, sizeof(int64_t), hipMemcpyDeviceToHost));
         GMSX_HIP(hipMemcpy(&rev, cnt + n + 1, sizeof(rev), hipMemcpyDeviceToHost));
         g->task_reverse = int64_t(rev);
         if (int rc = dmalloc(&g->task, 2 * g->task_entries + 2, g)) return rc;
+        uint32_t *tid = nullptr;  // per entry: the streamed vertex (chunk number for inline entries) — the tie-break of the sort below
+        if (int rc = dmalloc(&tid, g->task_entries + 1, nullptr)) return rc;
+        DevGuard g_tid{tid};
         GMSX_HIP(hipMemsetAsync(cnt, 0, size_t(n + 2) * sizeof(unsigned long long), s));  // now the reverse cursors
-        if (n > 0) hipLaunchKernelGGL(k_inline_entries<true>, dim3(vb), dim3(256), 0, s, n, ihoff, itoff, inline_h_base, inline_t_base, cnt, g->tbeg, g->task);
+        if (n > 0) hipLaunchKernelGGL(k_inline_entries<true>, dim3(vb), dim3(256), 0, s, n, ihoff, itoff, inline_h_base, inline_t_base, cnt, g->tbeg, g->task, tid);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
-                               g->trow, two_sided, cnt, g->tbeg, g->task, cnt + n + 1, ihoff, itoff, g->spool, g->tpool, g->inline_limit);
-        // every list sorted by (form, units) of the hub stream row: the four rows a wave works on at a time are then equally long
-        // (tc.hip, scan_srows).  The order of a list carries no meaning.  GMSX_TC_SORT_TASKS=0 skips it (A/B knob).
-        bool sort_tasks = g->task_entries > 0 && g->task_entries < (int64_t(1) << 32) && n < (int64_t(1) << 32);
+                               g->trow, two_sided, cnt, g->tbeg, g->task, cnt + n + 1, ihoff, itoff, g->spool, g->tpool, g->inline_limit, tid);
+        // Every list sorted by (form, units) of the hub stream row — the four rows a wave works on at a time are then equally long
+        // (tc.hip, scan_srows) — and, within equal keys, by the id of the streamed vertex.  The second part makes the order a TOTAL
+        // one: the reverse entries arrive through atomic cursors in any order, but every rank of a multi-GPU run must cut the same
+        // lists into the same work items (shard p of N = items p, p+N, …).  GMSX_TC_SORT_TASKS=0 skips the sort (A/B knob, one
+        // process only).
+        bool sort_tasks = g->task_entries > 0;
         if (const char *e = std::getenv("GMSX_TC_SORT_TASKS")) sort_tasks = sort_tasks && std::atoi(e) != 0;
         if (sort_tasks) {
             struct Entry { unsigned long long x, y; };
-            uint32_t *k_in = nullptr, *k_out = nullptr;
-            unsigned long long *sorted = nullptr;
-            if (int rc = dmalloc(&k_in, g->task_entries, nullptr)) return rc;
-            DevGuard g_ki{k_in};
-            if (int rc = dmalloc(&k_out, g->task_entries, nullptr)) return rc;
-            DevGuard g_ko{k_out};
-            if (int rc = dmalloc(&sorted, 2 * g->task_entries + 2, nullptr)) return rc;
-            hipLaunchKernelGGL(k_task_keys, dim3(unsigned((g->task_entries + 255) / 256)), dim3(256), 0, s, g->task_entries, g->task, k_in);
-            size_t tmp_bytes = 0;
-            hipError_t e1 = rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, k_in, k_out, reinterpret_cast<Entry *>(g->task), reinterpret_cast<Entry *>(sorted),
-                                                                unsigned(g->task_entries), unsigned(n), g->tbeg, g->tbeg + 1, 0, 24, s);
-            void *tmp = nullptr;
-            if (e1 == hipSuccess) e1 = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8);
-            if (e1 == hipSuccess)
-                e1 = rocprim::segmented_radix_sort_pairs(tmp, tmp_bytes, k_in, k_out, reinterpret_cast<Entry *>(g->task), reinterpret_cast<Entry *>(sorted),
-                                                         unsigned(g->task_entries), unsigned(n), g->tbeg, g->tbeg + 1, 0, 24, s);
-            if (e1 == hipSuccess) e1 = hipStreamSynchronize(s);
-            (void)hipFree(tmp);
-            if (e1 != hipSuccess) {
-                (void)hipFree(sorted);
-                (void)hipGetLastError();
-                return e1 == hipErrorOutOfMemory ? GMSX_ERR_DEVICE_MEM : GMSX_ERR_KERNEL;
-            }
-            (void)hipFree(g->task);
-            g->task = sorted;
+            unsigned long long *keys = nullptr;
+            if (int rc = dmalloc(&keys, g->task_entries, nullptr)) return rc;
+            DevGuard g_k{keys};
+            hipLaunchKernelGGL(k_task_keys, dim3(unsigned((g->task_entries + 255) / 256)), dim3(256), 0, s, g->task_entries, g->task, tid, keys);
+            if (int rc = sort_segment_pairs(keys, reinterpret_cast<Entry *>(g->task), g->task_entries, n, g->tbeg, 56, s)) return rc;
         }
         int64_t *icnt = nullptr, *ioff = nullptr;
         if (int rc = dmalloc(&icnt, n + 1, nullptr)) return rc;

@@ -259,3 +259,17 @@ def test_stream_row_forms(gpu, oracle, delta):
                 os.environ.pop(name, None)
             else:
                 os.environ[name] = val
+
+
+def test_shards_of_separate_processes_add_up(gpu):
+    """Multi-GPU runs shard the WORK ITEMS (p, p+N, …) and every rank uploads the graph itself: the task lists and the inline rows —
+    filled through atomic cursors in any order — must come out identical in every process (total order of the task sort, sorted
+    inline rows).  Three processes, one shard each, on a graph with reverse entries, inline rows and several items per hub."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "tc_two_process_shards.py"), "19"], capture_output=True, text=True, cwd=root, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rec["ok"] and rec["total"] == rec["sum_of_process_shards"] and rec["units"] == rec["m"], rec
