@@ -58,6 +58,8 @@ struct gmsx_graph {
     //   form 1  bitset           128 ids per unit over [0, v), filler 0 (hub rows only, when smaller than the list)
     //   form 2  byte-delta       unit = 16-bit base id + count byte + 13 gap bytes; a gap above 255 ends the unit early.
     //                            14 ids per unit when gaps < 256: 1.14 B/id against 2 B/id
+    //   form 3  12-bit gaps      unit = 16-bit base id + 4-bit count + nine 12-bit gaps; a gap above 4095 ends the unit early.
+    //                            10 ids per unit = 1.6 B/id: the sparse rows (gaps of 256 … 4095) that would otherwise stay lists
     unsigned long long *srow = nullptr;  // [n]
     uint32_t *spool = nullptr;           // 16-byte units
     int64_t spool_units = 0;
@@ -111,7 +113,7 @@ namespace gmsx {
 static constexpr int kHub = 65535;         // rank ids below this live in the 16-bit hub containers
 static constexpr int kBitmapWords = 2048;  // 65536-bit LDS bitmap over the hub id range
 static constexpr int kAccWords = 64 * 16 + 16;
-static constexpr int kFormList = 0, kFormBitset = 1, kFormDelta = 2;
+static constexpr int kFormList = 0, kFormBitset = 1, kFormDelta = 2, kFormGap12 = 3;
 static constexpr int kTaskChunk = 1024;  // entries per work item of the heavy-pivot kernel 
 static constexpr int kHeavy = 64;        // d+ from which a pivot runs on the workgroup kernel
 static constexpr int kDeltaIds = 14;  // ids per full 16-byte delta unit  // size of gmsx_graph::acc in u64

@@ -97,6 +97,30 @@ __device__ __forceinline__ uint32_t delta_unit_hits(const uint32_t *bm, uint4 p)
     return uint32_t(__popc(hits & ((1u << n) - 1u)));
 }
 
+// one unit of the 12-bit-gap form: 16-bit base, 4-bit count (1 … 10), nine 12-bit gaps from bit 20 on (two of them straddle a dword:
+// v_alignbit).  Unused gaps are 0 — the running id repeats — and the count cuts them off.
+__device__ __forceinline__ uint32_t gap12_unit_hits(const uint32_t *bm, uint4 p) {
+    uint32_t id[10];
+    id[0] = p.x & 0xffffu;
+    id[1] = id[0] + (p.x >> 20);
+    id[2] = id[1] + (p.y & 0xfffu);
+    id[3] = id[2] + __builtin_amdgcn_ubfe(p.y, 12u, 12u);
+    id[4] = id[3] + (__builtin_amdgcn_alignbit(p.z, p.y, 24u) & 0xfffu);
+    id[5] = id[4] + __builtin_amdgcn_ubfe(p.z, 4u, 12u);
+    id[6] = id[5] + __builtin_amdgcn_ubfe(p.z, 16u, 12u);
+    id[7] = id[6] + (__builtin_amdgcn_alignbit(p.w, p.z, 28u) & 0xfffu);
+    id[8] = id[7] + __builtin_amdgcn_ubfe(p.w, 8u, 12u);
+    id[9] = id[8] + (p.w >> 20);
+    uint32_t w[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) w[k] = bm[id[k] >> 5];
+    uint32_t hits = 0;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) hits |= __builtin_amdgcn_ubfe(w[k], id[k], 1u) << k;
+    const uint32_t n = (p.x >> 16) & 0xfu;
+    return uint32_t(__popc(hits & ((1u << n) - 1u)));
+}
+
 // Streams up to 64 stream rows against the LDS bitmap.  Lane l holds the packed descriptor of one row (srow[v]; 0 = no row).
 // A wave works as four 16-lane groups, each on its own row: one 16-byte unit per lane per step, two steps in flight.  Rows are handed
 // out FORM BY FORM (a ballot per form, then the four lowest lanes of the ballot): the three forms cost 12 / 32 / 81 VALU instructions per
@@ -154,6 +178,16 @@ __device__ __forceinline__ uint32_t scan_srows(const uint32_t *bm, const uint32_
             cnt += delta_unit_hits(bm, q);
         }
         if (j < r.units) cnt += delta_unit_hits(bm, r.row[j]);
+    }
+    for (unsigned long long todo = __ballot(any && form == kFormGap12); todo;) {
+        const RowHandout r = take_rows(todo, spool, dlo, dhi, grp);
+        int j = sub;
+        for (; j + 16 < r.units; j += 32) {
+            const uint4 p = r.row[j], q = r.row[j + 16];
+            cnt += gap12_unit_hits(bm, p);
+            cnt += gap12_unit_hits(bm, q);
+        }
+        if (j < r.units) cnt += gap12_unit_hits(bm, r.row[j]);
     }
     for (unsigned long long todo = __ballot(any && form == kFormList); todo;) {  // 16-bit list, 8 ids per unit, filler 0xFFFF
         const RowHandout r = take_rows(todo, spool, dlo, dhi, grp);
@@ -530,7 +564,7 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
     unsigned long long units = 0, probes = 0, bytes = 0;
     auto slots = [](unsigned long long d, bool tail) -> unsigned long long {
         const unsigned long long n = d & 0x3fffffull, f = (d >> 22) & 3ull;
-        return n * (tail ? (f == kFormDelta ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : 4ull));
+        return n * (tail ? (f == kFormDelta ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : f == kFormGap12 ? 10ull : 4ull));
     };
     for (int64_t q = wave0;; q += nwaves) {
         const int64_t pos = first + q * nparts + part;
@@ -581,7 +615,7 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
     unsigned long long units = 0, probes = 0, bytes = 0;
     auto slots = [](unsigned long long d, bool tail) -> unsigned long long {
         const unsigned long long n = d & 0x3fffffull, f = (d >> 22) & 3ull;
-        return n * (tail ? (f == kFormDelta ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : 4ull));
+        return n * (tail ? (f == kFormDelta ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : f == kFormGap12 ? 10ull : 4ull));
     };
     for (int64_t q = wave0;; q += nwaves) {
         const int64_t pos = q * nparts + part;
@@ -704,7 +738,7 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
         }
         for (int i = lane; i < it.count; i += 64) {
             const unsigned long long d = task[2 * (it.begin + i)], t = task[2 * (it.begin + i) + 1];
-            add(int((d >> 22) & 3), d & 0x3fffffull);
+            add(min(int((d >> 22) & 3), 2), d & 0x3fffffull);  // 12-bit-gap rows are counted with the byte-delta ones
             add(((t >> 22) & 3) == kFormDelta ? 4 : 3, t & 0x3fffffull);
             if ((t >> 22) & 1ull) atomicAdd(&h[241], 1ull);
         }
