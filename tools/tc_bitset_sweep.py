@@ -15,7 +15,7 @@ t0 = time.time()
 csr = capi.HostCSR.generate("kronecker", scale, 16)
 print(json.dumps({"scale": scale, "m": csr.num_edges, "gen_s": round(time.time() - t0, 1)}), flush=True)
 for R in limits:
-    os.environ["GMSX_BITSET_LIMIT"] = str(R)
+    os.environ["GMSX_INLINE_LIMIT"] = str(R)  # GMSX_BITSET_LIMIT until the inline rows replaced the near-tail bitsets
     t0 = time.time()
     g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_TRUSTED)
     up = time.time() - t0

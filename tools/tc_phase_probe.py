@@ -1,5 +1,5 @@
-"""GPU probe for phase builds of k_tc_block (-DGMSX_TC_PHASES=1/2/4: only the hub members / the hub parts of tail members / the tail
-parts are scanned — the COUNT IS WRONG by construction, only time and counters mean anything).  usage: tc_phase_probe.py <scale>"""
+"""GPU probe: three serialised triangle-count passes (GMSX_TC_OVERLAP=0) on a cached RMAT graph, meant to run under rocprofv3
+(tools/tc_serial_pmc_probe.sh); also used with one-off phase builds of k_tc_block.  usage: tc_phase_probe.py <scale>"""
 import os, sys, json
 sys.path.insert(0, ".")
 from gms_amd import capi

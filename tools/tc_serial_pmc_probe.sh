@@ -1,3 +1,6 @@
+#!/bin/bash
+# GPU: the triangle-count kernels SERIALISED (GMSX_TC_OVERLAP=0 inside tools/tc_phase_probe.py) under rocprofv3: a kernel trace, then
+# separate --pmc passes for VALU issue / lane utilisation and for FETCH_SIZE (never combined with tracing).  Writes gpurun_out/ts/.
 export TMPDIR=/tmp
 mkdir -p gpurun_out/ts
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ts/trace -o trace -- python3 tools/tc_phase_probe.py 26 > gpurun_out/ts/out.json 2> gpurun_out/ts/err.txt
