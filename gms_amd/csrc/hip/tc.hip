@@ -782,7 +782,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     int64_t n_block = 0, n_work = 0;  // pivots with d+ >= 64, d+ >= 2
-    if (int rc = count_dplus_ge(g, 64, &n_block)) return rc;
+    if (int rc = count_dplus_ge(g, kHeavy, &n_block)) return rc;
     if (int rc = count_dplus_ge(g, 2, &n_work)) return rc;
     unsigned long long *acc = g->acc;  // persistent per-graph accumulators: no allocation on the call path
     static_assert(kAccSlots * kAccStride + 3 <= kAccWords, "gmsx_graph::acc too small");
