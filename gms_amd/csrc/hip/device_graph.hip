@@ -487,6 +487,33 @@ __global__ void k_inline_entries(int64_t n, const int64_t *__restrict__ ihoff, c
     }
 }
 
+// light pivots that keep work for k_tc_wave: at least one far light member (rank id >= inline_limit, d+ < kHeavy) behind the first member
+__global__ __launch_bounds__(256) void k_wave_flags(int64_t first, int64_t end, const int32_t *__restrict__ order, const int64_t *__restrict__ toff,
+                                                    const int32_t *__restrict__ tadj, const int32_t *__restrict__ tsplit, const int32_t *__restrict__ dplus,
+                                                    int64_t *__restrict__ flags) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    for (int64_t pos = first + wave0; pos <= end; pos += nwaves) {
+        if (pos == end) {
+            if (lane == 0) flags[pos - first] = 0;
+            break;
+        }
+        const int32_t u = order[pos];
+        const int64_t tb = toff[u];
+        const int tl = int(toff[u + 1] - tb), ts = tsplit[u];
+        bool mine = false;
+        for (int i = ts + lane; i < tl; i += 64) mine |= dplus[tadj[tb + i]] < kHeavy;
+        const bool any = __ballot(mine) != 0;
+        if (lane == 0) flags[pos - first] = any ? 1 : 0;
+    }
+}
+__global__ void k_wave_scatter(int64_t count, int64_t first, const int32_t *__restrict__ order, const int64_t *__restrict__ flags,
+                               const int64_t *__restrict__ slot, int32_t *__restrict__ worder) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < count && flags[i]) worder[slot[i]] = order[first + i];
+}
+
 // ---- task lists of the heavy pivots (device_graph.hpp) -------------------------------------------------------------------------
 // The rule, evaluated once per oriented edge (u,v), u heavy: the edge is handed to v ("reverse") iff v is heavy too and the part of u's
 // rows that v has to stream (cut at v's id) is strictly fewer 16-byte units than what u would stream of v's; otherwise u keeps it.
@@ -650,6 +677,7 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->task);
     (void)hipFree(g->tbeg);
     (void)hipFree(g->titem);
+    (void)hipFree(g->worder);
     (void)hipFree(g->tpool);
     (void)hipFree(g->dplus);
     (void)hipFree(g->order);
@@ -1073,6 +1101,25 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         if (int rc = sort_rows(reinterpret_cast<uint16_t *>(g->spool) + inline_h_base * 8, inline_h_units * 8, n, ioff, 16, s)) return rc;
         hipLaunchKernelGGL(k_scale_offsets, dim3(ob), dim3(256), 0, s, n + 1, itoff, int64_t(4), ioff);
         if (int rc = sort_rows(g->tpool + inline_t_base * 4, inline_t_units * 4, n, ioff, 32, s)) return rc;
+    }
+    // 5e. the light pivots k_tc_wave still has work for (most handed everything over): a compact list in launch order, built with a scan so
+    //     that it is the same on every rank
+    {
+        const int64_t nl = n_work - n_heavy;
+        g->n_wave = 0;
+        if (nl > 0) {
+            int64_t *flags = nullptr, *slot = nullptr;
+            if (int rc = dmalloc(&flags, nl + 1, nullptr)) return rc;
+            DevGuard g_fl{flags};
+            if (int rc = dmalloc(&slot, nl + 1, nullptr)) return rc;
+            DevGuard g_sl{slot};
+            hipLaunchKernelGGL(k_wave_flags, dim3(grid_for_waves(nl + 1)), dim3(256), 0, s, n_heavy, n_work, g->order, g->toff, g->tadj, g->tsplit, g->dplus, flags);
+            if (int rc = exclusive_scan_i64(flags, slot, nl + 1, s)) return rc;
+            GMSX_HIP(hipMemcpy(&g->n_wave, slot + nl, sizeof(int64_t), hipMemcpyDeviceToHost));
+            if (int rc = dmalloc(&g->worder, g->n_wave + 1, g)) return rc;
+            hipLaunchKernelGGL(k_wave_scatter, dim3(unsigned((nl + 255) / 256)), dim3(256), 0, s, nl, n_heavy, g->order, flags, slot, g->worder);
+            GMSX_HIP(hipStreamSynchronize(s));
+        }
     }
     // 6. task lists: inline entries, then every oriented edge of a heavy pivot at the endpoint whose row is the bigger one
     {

@@ -82,6 +82,8 @@ struct gmsx_graph {
     struct gmsx_task_item *titem = nullptr;
     int64_t task_items = 0;
     int64_t task_reverse = 0;            // entries handed over to the other endpoint
+    int32_t *worder = nullptr;           // the light pivots that still have far light members (in launch order): what k_tc_wave walks
+    int64_t n_wave = 0;
     int32_t inline_limit = 0;            // light pivots hand their edges to members of rank id < inline_limit (and to heavy ones) as INLINE ROWS
     int64_t inline_units = 0;            // 16-byte units of all inline rows (inside spool / tpool)
     unsigned long long *trow = nullptr;

@@ -793,13 +793,13 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     int launches = 0;
     const int cus = c.compute_units > 0 ? c.compute_units : 256;
     const int64_t cap_blocks = int64_t(cus) * 16;
-    const int64_t cnt_heavy = part_count(0, g->task_items, nparts, part), cnt_light = part_count(n_block, n_work, nparts, part);
+    const int64_t cnt_heavy = part_count(0, g->task_items, nparts, part), cnt_light = part_count(0, g->n_wave, nparts, part);
     // CO-SCHEDULING.  The work-item kernel is bound by HBM bandwidth and VALU issue, the light-pivot kernel (short rows behind
     // dependent loads) by memory latency: back to back each leaves what the other needs idle.  So the light kernel goes to a side
     // stream FIRST, as a persistent grid of a few workgroups per CU, and the work items fill the remaining wave slots and LDS of
     // every CU.  GMSX_TC_OVERLAP=0 restores the serial order (full-width light grid), 2 forces co-scheduling on small graphs.
     const int overlap = [] { const char *e = std::getenv("GMSX_TC_OVERLAP"); return e ? std::atoi(e) : 1; }();
-    const int wave_wgs = [] { const char *e = std::getenv("GMSX_TC_WAVE_WGS"); return e ? std::max(1, std::atoi(e)) : 2; }();
+    const int wave_wgs = [] { const char *e = std::getenv("GMSX_TC_WAVE_WGS"); return e ? std::max(1, std::atoi(e)) : 1; }();
     // measured (MI355X, scale 26): serial 95 ms, co-scheduled 93 ms (the light kernel is 15 ms of it); at scale 24 the light kernel is too
     // short to be worth the shared CUs.  So: only in the large-graph regime (inline_limit beyond the hub range).
     const bool co = overlap && cnt_heavy > 0 && cnt_light > 0 && c.side[0] && c.side[1] && (overlap > 1 || g->inline_limit > g->dense_limit);
@@ -823,7 +823,7 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
         const int64_t want = (cnt_light + 3) / 4;
         const int64_t b_wave = std::min<int64_t>(want, co ? int64_t(cus) * wave_wgs : cap_blocks);
         hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(b_wave)), dim3(256), 0, s_wave, g->hoff, g->hadj, g->spool, g->tpool, g->tdesc, g->toff, g->tadj,
-                           g->tsplit, g->order, n_block, n_work, nparts, part, acc);
+                           g->tsplit, g->worder, int64_t(0), g->n_wave, nparts, part, acc);
         ++launches;
     };
     if (co) launch_light();
