@@ -799,10 +799,11 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     // stream FIRST, as a persistent grid of a few workgroups per CU, and the work items fill the remaining wave slots and LDS of
     // every CU.  GMSX_TC_OVERLAP=0 restores the serial order (full-width light grid), 2 forces co-scheduling on small graphs.
     const int overlap = [] { const char *e = std::getenv("GMSX_TC_OVERLAP"); return e ? std::atoi(e) : 1; }();
-    const int wave_wgs = [] { const char *e = std::getenv("GMSX_TC_WAVE_WGS"); return e ? std::max(1, std::atoi(e)) : 1; }();
-    // measured (MI355X, scale 26): serial 95 ms, co-scheduled 93 ms (the light kernel is 15 ms of it); at scale 24 the light kernel is too
-    // short to be worth the shared CUs.  So: only in the large-graph regime (inline_limit beyond the hub range).
-    const bool co = overlap && cnt_heavy > 0 && cnt_light > 0 && c.side[0] && c.side[1] && (overlap > 1 || g->inline_limit > g->dense_limit);
+    const bool large = g->inline_limit > g->dense_limit;  // n >= 2^24: inline limit beyond the hub range
+    const int wave_wgs = [large] { const char *e = std::getenv("GMSX_TC_WAVE_WGS"); return e ? std::max(1, std::atoi(e)) : (large ? 1 : 2); }();
+    // measured (MI355X, tools/tc_overlap_s24.py): scale 26 serial 86.4 ms, co-scheduled 84.6 (2 workgroups per CU) / 82.9 (1); scale 24
+    // 15.05 / 14.45 (2) / erratic (1); scale 22 3.56 serial, 4.45 co-scheduled.  So: from 2^23 vertices on.
+    const bool co = overlap && cnt_heavy > 0 && cnt_light > 0 && c.side[0] && c.side[1] && (overlap > 1 || g->n >= (int64_t(1) << 23));
     hipStream_t s_wave = co ? c.side[1] : s;
     struct Join {  // joins the side streams on every way out once they were forked (error returns included)
         Ctx &c;
