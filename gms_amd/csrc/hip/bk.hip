@@ -197,6 +197,7 @@ struct BkShared {
     const uint32_t *bmpool;
     int32_t dense_limit;
 };
+static constexpr int kBkSplit = 8;    // records a level with pending branches is cut into when a search is split
 static constexpr int kRecHeader = 8;  // v, c, x, xf_ne, arena offset (2 words), 2 spare
 static constexpr unsigned long long kNoArena = ~0ull;
 
@@ -344,11 +345,17 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                 if (lane == 0) xfne_stack[depth] = (unsigned char)xf_ne;
                 if (global_structs) __threadfence();
                 __builtin_amdgcn_wave_barrier();
-                for (int l = 0; l <= depth; ++l) {
-                    uint32_t e = 0;
-                    for (int w = lane; w < cw; w += 64) e |= stack[size_t(l) * lvl + 2 * cw + w];
-                    if (__ballot(e != 0)) ++nrec;
-                }
+                // A level with b pending branch vertices becomes min(b, kBkSplit) records: the branches in ascending order, cut into
+                // equal runs; run j starts from the state its predecessors leave behind (their vertices moved from P to X —
+                // tomita.h:68-70 — which needs no search, only the bitmaps).  One record per level made the siblings of a wide node
+                // run one after the other, a budget at a time: the config-4 graph needed 118 rounds whatever the budget.
+                auto level_bits = [&](int l) {
+                    int b = 0;
+                    for (int w = lane; w < cw; w += 64) b += __popc(stack[size_t(l) * lvl + 2 * cw + w]);
+                    for (int sft = 32; sft > 0; sft >>= 1) b += __shfl_xor(b, sft);
+                    return b;
+                };
+                for (int l = 0; l <= depth; ++l) nrec += min(level_bits(l), kBkSplit);
                 const unsigned long long rec_words = (unsigned long long)(kRecHeader + 3 * cw + xw);
                 unsigned long long p0 = 0, d0 = sh.dir_cap;
                 if (lane == 0) {
@@ -360,26 +367,59 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                 if (p0 + rec_words * nrec > sh.pool_cap || d0 + nrec > sh.dir_cap) {
                     ok = false;  // directory slots that were claimed but not written keep their ~0 fill and are skipped
                 } else {
+                    auto lowest = [](uint32_t x, int k) -> uint32_t {  // the k lowest set bits of x
+                        if (k <= 0) return 0u;
+                        if (k >= __popc(x)) return x;
+                        uint32_t r = 0;
+                        while (k--) {
+                            const uint32_t b = x & (0u - x);
+                            r |= b;
+                            x ^= b;
+                        }
+                        return r;
+                    };
                     int r = 0;
                     for (int l = 0; l <= depth; ++l) {
                         const uint32_t *lv = stack + size_t(l) * lvl;
-                        uint32_t e = 0;
-                        for (int w = lane; w < cw; w += 64) e |= lv[2 * cw + w];
-                        if (!__ballot(e != 0)) continue;
-                        uint32_t *rec = sh.pool + p0 + rec_words * r;
-                        if (lane == 0) {
-                            rec[0] = uint32_t(v);
-                            rec[1] = uint32_t(c);
-                            rec[2] = uint32_t(x);
-                            rec[3] = uint32_t(xfne_stack[l]);
-                            rec[4] = uint32_t(arena_off & 0xffffffffull);
-                            rec[5] = uint32_t(arena_off >> 32);
-                            rec[6] = rec[7] = 0;
-                            sh.dir[d0 + r] = p0 + rec_words * r;
+                        const int nb = level_bits(l);
+                        if (nb == 0) continue;
+                        const int parts = min(nb, kBkSplit);
+                        for (int j = 0; j < parts; ++j) {
+                            const int a = int((long long)nb * j / parts), b = int((long long)nb * (j + 1) / parts);  // ranks [a, b) of the pending branches
+                            uint32_t *rec = sh.pool + p0 + rec_words * r;
+                            if (lane == 0) {
+                                rec[0] = uint32_t(v);
+                                rec[1] = uint32_t(c);
+                                rec[2] = uint32_t(x);
+                                rec[3] = uint32_t(xfne_stack[l]);
+                                rec[4] = uint32_t(arena_off & 0xffffffffull);
+                                rec[5] = uint32_t(arena_off >> 32);
+                                rec[6] = rec[7] = 0;
+                                sh.dir[d0 + r] = p0 + rec_words * r;
+                            }
+                            int base = 0;  // pending branches in the words before this block of 64
+                            for (int w0 = 0; w0 < cw; w0 += 64) {
+                                const int w = w0 + lane;
+                                const uint32_t e = w < cw ? lv[2 * cw + w] : 0u;
+                                const int mine = __popc(e);
+                                int pre = mine;
+                                for (int sft = 1; sft < 64; sft <<= 1) {
+                                    const int o = __shfl_up(pre, sft);
+                                    if (lane >= sft) pre += o;
+                                }
+                                const int rank0 = base + pre - mine;  // rank of this word's first pending branch
+                                base += __builtin_amdgcn_readlane(pre, 63);
+                                if (w < cw) {
+                                    const uint32_t before = lowest(e, a - rank0);        // branches of the runs in front of this one
+                                    const uint32_t run = lowest(e, b - rank0) & ~before;  // this run
+                                    rec[kRecHeader + w] = lv[w] & ~before;                // P
+                                    rec[kRecHeader + cw + w] = lv[cw + w] | before;       // Xc
+                                    rec[kRecHeader + 2 * cw + w] = run;                   // ext
+                                }
+                            }
+                            for (int w = lane; w < xw; w += 64) rec[kRecHeader + 3 * cw + w] = lv[3 * cw + w];
+                            ++r;
                         }
-                        for (int w = lane; w < 3 * cw; w += 64) rec[kRecHeader + w] = lv[w];  // P | Xc | ext
-                        for (int w = lane; w < xw; w += 64) rec[kRecHeader + 3 * cw + w] = lv[3 * cw + w];
-                        ++r;
                     }
                     if (lane == 0) atomicMax(sh.max_stack, (unsigned long long)(c + 1) * (unsigned long long)lvl);
                 }
