@@ -275,3 +275,50 @@ def test_shards_of_separate_processes_add_up(gpu):
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["ok"] and rec["total"] == rec["sum_of_process_shards"] and rec["units"] == rec["m"], rec
+
+
+def test_random_small_graphs_all_paths(gpu, oracle):
+    """Many small random graphs (sparse, dense, clustered, star-heavy) under hub limits that push ids into the tail containers and inline
+    limits that move members between the inline rows and the light-pivot kernel: forward / reverse / cut / inline / first-member entries
+    all occur, every count equals the oracle's, every shard split adds up."""
+    rng = np.random.default_rng(20261003)
+    old = os.environ.get("GMSX_INLINE_LIMIT")
+    try:
+        for trial in range(36):
+            n = int(rng.integers(40, 2500))
+            kind = trial % 4
+            if kind == 0:      # G(n, p) from sparse to fairly dense
+                m = int(n * rng.uniform(2, 60))
+                src, dst = rng.integers(0, n, m), rng.integers(0, n, m)
+            elif kind == 1:    # a dense core + a sparse periphery attached to it (heavy pivots with light members and vice versa)
+                core = int(rng.integers(70, 300))
+                iu = np.triu_indices(core, 1)
+                keep = rng.random(iu[0].size) < rng.uniform(0.3, 0.9)
+                ps, pd = rng.integers(core, n + core, 6 * n), rng.integers(0, core + n, 6 * n)
+                src, dst = np.concatenate([iu[0][keep], ps]), np.concatenate([iu[1][keep], pd])
+            elif kind == 2:    # preferential attachment flavour: targets drawn with a power-law bias
+                m = int(n * rng.uniform(4, 30))
+                src = rng.integers(0, n, m)
+                dst = (n * rng.random(m) ** 3).astype(np.int64)
+            else:              # several hubs seeing everything + random edges among the rest
+                hubs = int(rng.integers(2, 40))
+                hs = np.repeat(np.arange(hubs), n)
+                hd = np.tile(np.arange(n), hubs)
+                m = int(n * rng.uniform(1, 25))
+                src, dst = np.concatenate([hs, rng.integers(0, n, m)]), np.concatenate([hd, rng.integers(0, n, m)])
+            keep = src != dst
+            csr = gpu.HostCSR.from_edges(src[keep].astype(np.int32), dst[keep].astype(np.int32))
+            want = oracle.tc_total(csr.offsets(), csr.neighbors())
+            hub_limit = int(rng.choice([0, 1, 7, 40, 300]))
+            os.environ["GMSX_INLINE_LIMIT"] = str(int(rng.choice([0, 10, 100, 1000, 10 ** 7])))
+            g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_DEFAULT | (hub_limit << 8))
+            t, st = g.tc_total(stats=True)
+            assert t == want and st["units"] == csr.num_edges, (trial, n, kind, hub_limit, os.environ["GMSX_INLINE_LIMIT"])
+            nparts = int(rng.integers(2, 6))
+            assert sum(g.tc_partial(p, nparts) for p in range(nparts)) == want, (trial, nparts)
+            g.free()
+    finally:
+        if old is None:
+            os.environ.pop("GMSX_INLINE_LIMIT", None)
+        else:
+            os.environ["GMSX_INLINE_LIMIT"] = old
