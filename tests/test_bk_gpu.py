@@ -121,3 +121,37 @@ def test_bk_more_than_2048_candidates(gpu, oracle):
     assert g.bk_count() == want
     assert sum(g.bk_partial(p, 3) for p in range(3)) == want
     g.free()
+
+
+@pytest.mark.parametrize("budget", [16, 48, 300])
+def test_bk_tiny_budget_splits_everything(gpu, oracle, budget):
+    """A node budget of a few dozen nodes makes every non-trivial search split, again and again: every level with pending branches is cut
+    into up to eight records whose runs of siblings start from the state their predecessors leave behind (P minus / X plus the earlier
+    branch vertices).  Same counts as the oracle on graphs with deep searches (dense blocks), wide nodes (hubs) and both."""
+    old = {k: os.environ.get(k) for k in ("GMSX_BK_BUDGET", "GMSX_BK_BUDGET0")}
+    os.environ["GMSX_BK_BUDGET"] = str(budget)
+    os.environ["GMSX_BK_BUDGET0"] = str(budget)
+    try:
+        rng = np.random.default_rng(5)
+        graphs = [host_graph(gpu, "kronecker", 11, 16, True), host_graph(gpu, "uniform", 9, 60, True)]
+        k = 220  # a dense random block: long chains of recursion
+        iu = np.triu_indices(k, 1)
+        sel = rng.random(iu[0].size) < 0.5
+        graphs.append(gpu.HostCSR.from_edges(iu[0][sel].astype(np.int32), iu[1][sel].astype(np.int32)))
+        parts = [range(4 * i, 4 * i + 4) for i in range(6)]  # complete multipartite K_{4,4,4,4,4,4}: 4^6 maximal cliques, wide nodes
+        edges = [(a, b) for i, pa in enumerate(parts) for pb in parts[i + 1:] for a in pa for b in pb]
+        graphs.append(gpu.HostCSR.from_edges(np.array([e[0] for e in edges], np.int32), np.array([e[1] for e in edges], np.int32)))
+        for i, csr in enumerate(graphs):
+            want = oracle.bk_count(csr.offsets(), csr.neighbors())
+            g = gpu.DeviceGraph.from_csr(csr)
+            got, st = g.bk_count(stats=True)
+            assert got == want, (i, budget)
+            assert sum(g.bk_partial(p, 3) for p in range(3)) == want
+            g.free()
+        assert oracle.bk_count(graphs[3].offsets(), graphs[3].neighbors()) == 4 ** 6
+    finally:
+        for k_, v in old.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
