@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_dense_fill(int32_t limit, const int64_t
             const uint32_t id = hadj[j];
             if (id != 0xFFFFu) atomicOr(&pool[b + (id >> 5)], 1u << (id & 31u));
         }
-        for (int64_t j = toff[v] + lane; j < toff[v + 1]; j += 64) {  // near-tail rows: their tail targets are < v too
+        for (int64_t j = toff[v] + lane; j < toff[v + 1]; j += 64) {  // (rows beyond the hub range would contribute their tail targets, all < v, too; none has a bitset today)
             const uint32_t id = uint32_t(tadj[j]);
             atomicOr(&pool[b + (id >> 5)], 1u << (id & 31u));
         }
@@ -517,9 +517,6 @@ __global__ void k_wave_scatter(int64_t count, int64_t first, const int32_t *__re
 // ---- task lists of the heavy pivots (device_graph.hpp) -------------------------------------------------------------------------
 // The rule, evaluated once per oriented edge (u,v), u heavy: the edge is handed to v ("reverse") iff v is heavy too and the part of u's
 // rows that v has to stream (cut at v's id) is strictly fewer 16-byte units than what u would stream of v's; otherwise u keeps it.
-__device__ __forceinline__ uint32_t row_units(const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow, int32_t x) {
-    return uint32_t(srow[x] & 0x3fffffull) + uint32_t(trow[x] & 0x3fffffull);
-}
 // A handed-over row is needed only up to the receiving pivot's id: N+(v) lies below v.  The units of u's hub stream row that can hold
 // ids below hub member v (which has `below` hub members of u in front of it), and of u's tail stream row for tail member v:
 __device__ __forceinline__ uint32_t cut_hub_units(const uint32_t *__restrict__ spool, unsigned long long d, int below, int32_t v) {

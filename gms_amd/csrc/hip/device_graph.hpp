@@ -20,12 +20,10 @@
 //                                                     is padded to an even count with 0xFFFF (never a valid target)
 //     tail part  toff int64[n+1], tadj int32[...]    targets with rank id >= kHub, 4 bytes each
 //   On power-law graphs >85 % of all entries and >95 % of the streamed ids are hub entries.
-//     bitset part bmoff int64[R+1], bmpool uint32[...]  every row of rank id < R (R = bitset_limit >= the hub range; sized by the HBM
-//                                                     budget: R^2/16 bytes, 4.3 GB for R = 262144) additionally as a bitmap over [0, v) (Roaring's bitset
-//                                                     container, <= 268 MB in total).  Heavy pivots stream it instead of the
-//                                                     list when it is the smaller form (2*d+ bytes > v/8 bytes: a few thousand
-//                                                     rows that carry >70 % of the streamed ids; AND + popcount, 32 ids per word);
-//                                                     light pivots gather single words from it ("is my member in N+(v)").
+//     bitset part bmoff int64[H+1], bmpool uint32[...]  every hub row (rank id < H = min(n, kHub)) additionally as a bitmap over [0, v)
+//                                                     (Roaring's bitset container, <= 268 MB in total): the dense stream-row form of the
+//                                                     triangle kernel (AND + popcount, 128 ids per 16-byte unit) and the edge test of the
+//                                                     k-clique recursion.
 //
 //   dplus int32[n]                     true out-degree (hub + tail) per rank id
 //   order int32[n]                     rank ids by decreasing d+ (work-sorted launch order, heavy first);
@@ -48,10 +46,8 @@ struct gmsx_graph {
     int64_t *bmoff = nullptr;   // [dense_limit + 1] word offsets into bmpool (multiples of 4); equal neighbours = not dense
     uint32_t *bmpool = nullptr; // bitset containers of the dense hub rows
     int32_t dense_limit = 0;    // = min(n, hub limit): hub rank ids; their rows have a bitset AND only hub entries
-    int32_t bitset_limit = 0;   // >= dense_limit: every rank id below it has a bitset container over [0, v) in bmpool (hub AND tail
-                                // targets); ids in [dense_limit, bitset_limit) are the "near tail": light pivots resolve their rows by
-                                // inverted gathers too instead of streaming them (tc.hip), the other kernels ignore them
-    // STREAM ROWS (heavy-pivot triangle kernel): the hub part of every row once more, in the form that is cheapest to stream,
+    int32_t bitset_limit = 0;   // = dense_limit: every rank id below it has a bitset container over [0, v) in bmpool
+    // STREAM ROWS (triangle kernels): the hub part of every row once more, in the form that is cheapest to stream,
     // every row a whole number of 16-byte units (padded with neutral fillers, so the scanners need no tail handling) at a 16-byte
     // aligned offset of ONE pool; srow[v] packs (offset / 16) << 24 | form << 22 | units into 8 bytes = one load per row fetch.
     //   form 0  16-bit list      8 ids per unit, filler 0xFFFF (never in a pivot bitmap)
@@ -89,9 +85,9 @@ struct gmsx_graph {
     unsigned long long *trow = nullptr;
     uint32_t *tpool = nullptr;
     int64_t tpool_units = 0;
-    int32_t *tsplit = nullptr;  // int32[n]: position in the tail row of the first target >= bitset_limit (= tail length if none)
+    int32_t *tsplit = nullptr;  // int32[n]: position in the tail row of the first target >= inline_limit (= tail length if none)
     int64_t dense_rows = 0, bmpool_words = 0;
-    bool rows_sorted = false;   // both containers of every row ascending (always, below 2^32 entries)
+    bool rows_sorted = false;   // both containers of every row ascending (always: sorted in vertex ranges at upload)
     int32_t *dplus = nullptr;
     int32_t *order = nullptr;
     int32_t *sorted_dplus = nullptr;
