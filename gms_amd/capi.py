@@ -19,7 +19,8 @@ _u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 GEN_KRONECKER, GEN_UNIFORM = 0, 1
 RELABEL_NEVER, RELABEL_AUTO, RELABEL_ALWAYS = 0, 1, 2
 TC_AUTO, TC_ORIENTED, TC_FULL = 0, 1, 2
-UPLOAD_DEFAULT, UPLOAD_TRUSTED = 0, 1
+UPLOAD_DEFAULT, UPLOAD_TRUSTED, UPLOAD_FOR_TC = 0, 1, 2
+PREPARE_TC = 1
 OK, ERR_INVALID, ERR_NOMEM, ERR_IO, ERR_FORMAT, ERR_DIRECTED, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
 ERR_DEVICE_MEM, ERR_NOT_CANONICAL, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_KERNEL, ERR_COMM = -7, -8, -9, -10, -11, -12
 COMM_ID_BYTES = 128
@@ -32,7 +33,7 @@ SYMBOLS = [
     "gmsx_csr_num_edges_directed", "gmsx_csr_offsets", "gmsx_csr_neighbors", "gmsx_csr_merge_elements",
     "gmsx_csr_fingerprint", "gmsx_csr_free", "gmsx_set_host_threads",
     "gmsx_init", "gmsx_set_stream", "gmsx_device_info",
-    "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
+    "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_prepare", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
     "gmsx_graph_device_bytes", "gmsx_graph_max_out_degree",
     "gmsx_tc_total", "gmsx_tc_partial", "gmsx_tc_divisor", "gmsx_tc_stream_breakdown", "gmsx_tc_row_histogram", "gmsx_tc_vertex_count2",
     "gmsx_intersect_count_batch", "gmsx_vertex_similarity_batch", "gmsx_kclique_count", "gmsx_kclique_partial", "gmsx_bk_count", "gmsx_bk_partial",
@@ -96,6 +97,7 @@ def lib():
     L.gmsx_graph_upload.argtypes = [C.c_int64, _i64p, _i32p, C.c_uint32, vpp]
     L.gmsx_graph_upload_csr.argtypes = [vp, C.c_uint32, vpp]
     L.gmsx_graph_free.argtypes = [vp]
+    L.gmsx_graph_prepare.argtypes = [vp, C.c_uint32]
     for f in (L.gmsx_graph_num_nodes, L.gmsx_graph_num_edges, L.gmsx_graph_device_bytes):
         f.restype = C.c_int64
         f.argtypes = [vp]
@@ -265,6 +267,10 @@ class DeviceGraph:
     num_edges = property(lambda self: lib().gmsx_graph_num_edges(self._h))
     device_bytes = property(lambda self: lib().gmsx_graph_device_bytes(self._h))
     max_out_degree = property(lambda self: lib().gmsx_graph_max_out_degree(self._h))
+
+    def prepare(self, what=PREPARE_TC):
+        """gmsx_graph_prepare: build the optional containers (triangle-count task lists) now instead of on first use."""
+        _check(lib().gmsx_graph_prepare(self._h, what), "gmsx_graph_prepare")
 
     def tc_total(self, algo=TC_AUTO, stats=False):
         out, st = C.c_uint64(0), Stats()

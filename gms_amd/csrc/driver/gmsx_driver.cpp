@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <csignal>
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -204,39 +205,86 @@ uint64_t host_bk(const HostGraph &g, const std::vector<int32_t> &rank) {
 constexpr uint64_t kHostTcElements = 20000000000ull;  // Σ(d_u+d_v) merged ids
 constexpr int64_t kHostKcEdges = 1000000, kHostBkEdges = 60000;
 
-int launch_ranks(int argc, char **argv, int gpus) {
-    // one process per GPU, spawned BEFORE this process touches HIP (a process that has initialised the GPU must not exec)
+// `--gpus N`: one process per GPU.  The launcher forks N children BEFORE it touches HIP and stays behind as their supervisor; a child
+// simply returns from here (-1) and continues into main's body as rank r — no exec, no second start-up.  The supervisor reaps with
+// waitpid(-1): the first child that fails (non-zero exit or a signal — e.g. gmsx_init(rank) with fewer devices than ranks, a load error)
+// takes the others down (SIGTERM, SIGKILL after a grace period): ranks blocked in ncclCommInitRank / ncclAllReduce have no timeout of
+// their own and would otherwise wait for the dead one forever.  A failed rank is never restarted.
+// Under a profiler preload (rocprofv3 …) the tool library has initialised the GPU in THIS process already, and a forked child of a
+// process with a live HIP runtime cannot use the GPU: refused with a message.  Profile one rank at a time instead, no launcher hop:
+//   GMSX_DRIVER_RANK=r GMSX_DRIVER_NRANKS=N GMSX_DRIVER_ID_FILE=/tmp/id rocprofv3 … -- gmsx_driver <args without --gpus>
+bool profiler_preloaded() {
+    const char *pre = std::getenv("LD_PRELOAD");
+    if (pre && (std::strstr(pre, "rocprof") || std::strstr(pre, "roctracer") || std::strstr(pre, "rocprofiler"))) return true;
+    for (char **e = environ; e && *e; ++e)
+        if (!std::strncmp(*e, "ROCPROFILER_", 12) || !std::strncmp(*e, "ROCPROF_", 8) || !std::strncmp(*e, "ROCP_", 5)) return true;
+    return false;
+}
+
+int launch_ranks(int gpus) {
+    if (profiler_preloaded()) {
+        std::fprintf(stderr, "gmsx_driver --gpus: a profiler library is preloaded (it has initialised the GPU in this process); ranks cannot be\n"
+                             "forked from it.  Start the ranks directly under the profiler with GMSX_DRIVER_RANK / GMSX_DRIVER_NRANKS /\n"
+                             "GMSX_DRIVER_ID_FILE set and without --gpus.\n");
+        return 6;
+    }
     char idfile[] = "/tmp/gmsx_driver_id_XXXXXX";
     const int fd = mkstemp(idfile);
     if (fd < 0) { std::perror("mkstemp"); return 4; }
     close(fd);
     unlink(idfile);  // rank 0 re-creates it atomically once the id is written
+    std::fflush(stdout);
+    std::fflush(stderr);
     std::vector<pid_t> kids;
+    auto kill_rest = [&](int sig) {
+        for (pid_t k : kids)
+            if (k > 0) kill(k, sig);
+    };
     for (int r = 0; r < gpus; ++r) {
         const pid_t pid = fork();
-        if (pid < 0) { std::perror("fork"); return 4; }
-        if (pid == 0) {
+        if (pid < 0) {
+            std::perror("fork");
+            kill_rest(SIGKILL);
+            while (waitpid(-1, nullptr, 0) > 0) {}
+            return 4;
+        }
+        if (pid == 0) {  // rank r: carry on in main()
             setenv("GMSX_DRIVER_RANK", std::to_string(r).c_str(), 1);
             setenv("GMSX_DRIVER_NRANKS", std::to_string(gpus).c_str(), 1);
             setenv("GMSX_DRIVER_ID_FILE", idfile, 1);
             // one node by construction: keep RCCL's bootstrap off the (possibly absent) external network unless the user chose otherwise
             setenv("NCCL_SOCKET_IFNAME", "lo", 0);
             setenv("NCCL_IB_DISABLE", "1", 0);
-            execv("/proc/self/exe", argv);
-            std::perror("execv");
-            _exit(127);
+            return -1;
         }
         kids.push_back(pid);
     }
-    (void)argc;
-    int worst = 0;
-    for (pid_t k : kids) {
+    int worst = 0, alive = gpus;
+    bool killing = false;
+    auto t_kill = std::chrono::steady_clock::now();
+    while (alive > 0) {
         int st = 0;
-        waitpid(k, &st, 0);
-        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128;
-        worst = std::max(worst, code);
+        const pid_t k = waitpid(-1, &st, killing ? WNOHANG : 0);
+        if (k < 0) break;  // no children left
+        if (k == 0) {      // tearing down: give SIGTERM two seconds, then SIGKILL
+            if (std::chrono::steady_clock::now() - t_kill > std::chrono::seconds(2)) kill_rest(SIGKILL);
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+            continue;
+        }
+        for (pid_t &x : kids)
+            if (x == k) x = -1;
+        --alive;
+        const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
+        if (code != 0 && !killing) {
+            worst = code;
+            std::fprintf(stderr, "gmsx_driver --gpus: a rank ended with status %d; stopping the other %d\n", code, alive);
+            killing = true;
+            t_kill = std::chrono::steady_clock::now();
+            kill_rest(SIGTERM);
+        }
     }
     unlink(idfile);
+    unlink((std::string(idfile) + ".tmp").c_str());
     return worst;
 }
 
@@ -246,8 +294,11 @@ int main(int argc, char **argv) {
     Args args = parse(argc, argv);
     if (args.error) { usage(argv[0]); return args.error; }  // the reference exits with 100 / 101 (cli/cli.h:122-133,159-160)
     if (args.kernel != "tc" && args.kernel != "vertex" && args.kernel != "kclique" && args.kernel != "bk") { usage(argv[0]); return 100; }
+    if (args.gpus >= 1 && !std::getenv("GMSX_DRIVER_RANK")) {
+        const int rc_launch = launch_ranks(args.gpus);
+        if (rc_launch >= 0) return rc_launch;  // the supervisor; a child (-1) falls through as its rank
+    }
     const char *env_rank = std::getenv("GMSX_DRIVER_RANK");
-    if (args.gpus >= 1 && !env_rank) return launch_ranks(argc, argv, args.gpus);
     const int rank = env_rank ? std::atoi(env_rank) : 0;
     const int nranks = env_rank ? std::atoi(std::getenv("GMSX_DRIVER_NRANKS")) : 1;
     const bool root = rank == 0;

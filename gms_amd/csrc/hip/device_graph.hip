@@ -654,6 +654,20 @@ struct DevGuard {
     ~DevGuard() { (void)hipFree(p); }
 };
 
+// the triangle-count containers only (a failed or abandoned build_tc_sets leaves the base layout usable)
+static void free_tc(gmsx_graph *g) {
+    auto drop = [](auto *&p) {
+        (void)hipFree(p);
+        p = nullptr;
+    };
+    drop(g->tsplit); drop(g->srow); drop(g->spool); drop(g->trow); drop(g->tdesc); drop(g->task); drop(g->tbeg); drop(g->titem); drop(g->worder); drop(g->tpool);
+    g->device_bytes -= g->tc_bytes;
+    g->tc_bytes = 0;
+    g->tc_ready = false;
+    g->task_entries = g->task_items = g->task_reverse = g->n_wave = g->inline_units = g->spool_units = g->tpool_units = 0;
+    g->stats_part = g->stats_nparts = -1;
+}
+
 static void free_graph(gmsx_graph *g) {
     if (!g) return;
     (void)hipFree(g->off);
@@ -907,24 +921,6 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         if (K > 0 && g->bmpool_words > 0)
             hipLaunchKernelGGL(k_dense_fill, dim3(grid_for_waves(K)), dim3(256), 0, s, K, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool);
     }
-    // 4c. INLINE LIMIT.  A light pivot u (2 <= d+ < 64) hands the edge (u,v) over to v whenever v is a pivot of the workgroup kernel
-    //     anyway (d+ >= 64) or a popular target (rank id < inline_limit): the members of u below v — the only ids of N+(u) that can
-    //     be in N+(v) — are copied into v's INLINE ROWS, two more stream rows of v (16-bit hub ids / 32-bit tail ids, list form) that
-    //     v's work items scan against v's own row like any other entry.  A 20-byte row behind a pointer would cost a 128-byte line
-    //     per fetch; inline it is streamed.  Only the far, light members stay with the light-pivot kernel (k_tc_wave).
-    {
-        int64_t want = std::min<int64_t>(524288, n / 256);
-        bool forced = false;
-        if (const char *e = std::getenv("GMSX_INLINE_LIMIT")) {  // tuning / test knob
-            const long long v = std::atoll(e);
-            if (v >= 0 && v <= (1ll << 31) - 1) { want = v; forced = true; }
-        }
-        if (!forced && ((flags >> 8) & 0xffffu)) want = int64_t(4) * hub_limit;  // hub-limit test hook: near AND far tail on small graphs
-        g->inline_limit = int32_t(std::min<int64_t>(n, std::max<int64_t>(want, g->dense_limit)));
-        if (int rc = dmalloc(&g->tsplit, n, g)) return rc;
-        if (n > 0) hipLaunchKernelGGL(k_tail_split, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->toff, g->tadj, g->inline_limit, g->tsplit);
-    }
-
     // 5. work-sorted launch order: rank ids by decreasing d+
     if (int rc = dmalloc(&g->order, n, g)) return rc;
     if (int rc = dmalloc(&g->sorted_dplus, n, g)) return rc;
@@ -945,6 +941,42 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         GMSX_HIP(hipMemcpyAsync(&top, g->sorted_dplus, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         GMSX_HIP(hipStreamSynchronize(s));
         g->max_dplus = top;
+    }
+
+    GMSX_HIP(hipStreamSynchronize(s));
+    GMSX_HIP(hipGetLastError());
+    g->hub_limit = hub_limit;
+    g->upload_flags = flags;
+    return GMSX_OK;
+}
+
+// The triangle-count containers on top of the base layout: inline rows, stream rows, descriptors, task lists, work items (device_graph.hpp).
+// Built by gmsx_graph_upload(…GMSX_UPLOAD_FOR_TC), gmsx_graph_prepare(g, GMSX_PREPARE_TC) or the first oriented triangle-count call —
+// a k-clique or Bron–Kerbosch user never pays for them (the reference's set-based k-clique harness builds its SGraph INSIDE the timed
+// region, k_clique_count_set_based.h:22).
+static int build_tc_sets(gmsx_graph *g) {
+    hipStream_t s = ctx().stream;
+    const int64_t n = g->n;
+    const uint32_t flags = g->upload_flags;
+    const int hub_limit = g->hub_limit;
+    const unsigned tb = unsigned((n + 255) / 256);
+    (void)tb;
+    // 4c. INLINE LIMIT.  A light pivot u (2 <= d+ < 64) hands the edge (u,v) over to v whenever v is a pivot of the workgroup kernel
+    //     anyway (d+ >= 64) or a popular target (rank id < inline_limit): the members of u below v — the only ids of N+(u) that can
+    //     be in N+(v) — are copied into v's INLINE ROWS, two more stream rows of v (16-bit hub ids / 32-bit tail ids, list form) that
+    //     v's work items scan against v's own row like any other entry.  A 20-byte row behind a pointer would cost a 128-byte line
+    //     per fetch; inline it is streamed.  Only the far, light members stay with the light-pivot kernel (k_tc_wave).
+    {
+        int64_t want = std::min<int64_t>(524288, n / 256);
+        bool forced = false;
+        if (const char *e = std::getenv("GMSX_INLINE_LIMIT")) {  // tuning / test knob
+            const long long v = std::atoll(e);
+            if (v >= 0 && v <= (1ll << 31) - 1) { want = v; forced = true; }
+        }
+        if (!forced && ((flags >> 8) & 0xffffu)) want = int64_t(4) * hub_limit;  // hub-limit test hook: near AND far tail on small graphs
+        g->inline_limit = int32_t(std::min<int64_t>(n, std::max<int64_t>(want, g->dense_limit)));
+        if (int rc = dmalloc(&g->tsplit, n, g)) return rc;
+        if (n > 0) hipLaunchKernelGGL(k_tail_split, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->toff, g->tadj, g->inline_limit, g->tsplit);
     }
 
     // 5b. sizes of the inline rows (4c): ids handed over per receiving vertex
@@ -1182,6 +1214,20 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     return GMSX_OK;
 }
 
+int ensure_tc(const gmsx_graph *cg) {
+    gmsx_graph *g = const_cast<gmsx_graph *>(cg);  // handles are single-threaded; the build only adds containers, nothing a caller can observe changes
+    if (g->tc_ready) return GMSX_OK;
+    const int64_t before = g->device_bytes;
+    const int rc = build_tc_sets(g);
+    g->tc_bytes = g->device_bytes - before;
+    if (rc) {
+        free_tc(g);
+        return rc;
+    }
+    g->tc_ready = true;
+    return GMSX_OK;
+}
+
 int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out) {
     if (g->n == 0) {
         *out = 0;
@@ -1287,6 +1333,7 @@ int gmsx_graph_upload(int64_t n, const int64_t *offsets, const int32_t *neigh, u
             if (offsets[i + 1] < offsets[i]) { rc = GMSX_ERR_INVALID; break; }
     }
     if (!rc) rc = build_device_sets(g, flags);
+    if (!rc && (flags & GMSX_UPLOAD_FOR_TC)) rc = ensure_tc(g);
     if (rc) {
         free_graph(g);
         return rc;
@@ -1299,6 +1346,14 @@ int gmsx_graph_upload_csr(const gmsx_csr *h, uint32_t flags, gmsx_graph **out) {
     if (!h) return GMSX_ERR_INVALID;
     if (h->g.directed) return GMSX_ERR_DIRECTED;
     return gmsx_graph_upload(h->g.n, h->g.off.get(), h->g.neigh.get(), flags, out);
+}
+
+int gmsx_graph_prepare(gmsx_graph *g, uint32_t what) {
+    if (!g || (what & ~uint32_t(GMSX_PREPARE_TC))) return GMSX_ERR_INVALID;
+    if (int rc = ensure_init()) return rc;
+    if (what & GMSX_PREPARE_TC)
+        if (int rc = ensure_tc(g)) return rc;
+    return GMSX_OK;
 }
 
 int gmsx_graph_free(gmsx_graph *g) {

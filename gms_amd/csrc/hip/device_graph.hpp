@@ -102,6 +102,13 @@ struct gmsx_graph {
     mutable int ge_used = 0;
     mutable int stats_part = -1, stats_nparts = -1;  // shard whose TC bookkeeping (units, probes) is cached below
     mutable uint64_t stats_units = 0, stats_probes = 0, stats_bytes = 0;
+    mutable const int32_t *rank_ok_ptr = nullptr;    // gmsx_bk_partial: the last `rank` array validated as a permutation (+ two probe values)
+    mutable int32_t rank_ok_first = 0, rank_ok_last = 0;
+    // the triangle-count containers (stream rows, inline rows, task lists …) are built on demand: ensure_tc()
+    bool tc_ready = false;
+    int64_t tc_bytes = 0;                   // their share of device_bytes
+    int hub_limit = 0;                      // hub id range this graph was built with (kHub unless the test hook shrank it)
+    uint32_t upload_flags = 0;
     uint64_t alg_elements = 0;              // Σ_{u<v}(d_u+d_v), computed on the device at upload
     int64_t device_bytes = 0;
 };
@@ -133,6 +140,8 @@ int ensure_init();
 // number of vertices with d+ >= threshold (= position in `order` where d+ drops below it)
 int kclique_vertex_counts(const gmsx_graph *g, unsigned long long *d_counts, gmsx_stats *st);  // kclique.hip
 int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out);
+// builds the triangle-count containers of the (otherwise immutable) graph if they are not there yet (device_graph.hip)
+int ensure_tc(const gmsx_graph *g);
 // counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| into a zeroed device array (pairs.hip); shared by the per-vertex count and the TC ordering
 int tc_vertex_counts_device(const gmsx_graph *g, unsigned long long *d_counts, gmsx_stats *st);
 // GMSX_TC_FULL: every edge u<v intersects the FULL rows (pairs.hip); returns the un-divided sum of the shard

@@ -863,32 +863,55 @@ static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
     return span <= 0 ? 0 : (span + nparts - 1) / nparts;
 }
 
-// generic list recursion for the pivots at positions [first, end) of the d+ order, in chunks of at most 60000 pivots (grid.y); every
-// chunk is synchronised and its slab freed before the next one starts — this is the slow path
+// generic list recursion for the pivots at positions [first, end) of the d+ order — the slow path.  The pivots run in chunks (grid.y) sized
+// from a SLAB BUDGET: a wave needs (k-3) level lists of round64(d+) ids, and `order` is d+-descending, so the chunk's own widest pivot is
+// its first one — pivots per chunk = budget / (4 waves * levels * stride of that pivot), never more than 60000 (grid.y < 65536) and never
+// fewer than one (one workgroup: k <= 64 levels of the widest row, megabytes).  One slab, grown only when a chunk needs more than the
+// last, serves every chunk: no request fails for its size and there is no multi-GB malloc / free per chunk.
 static int launch_generic(const gmsx_graph *g, int k, int64_t first, int64_t end, int part, int nparts, unsigned long long *acc, int *launches) {
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
-    const int64_t dmax = std::max<int64_t>(g->max_dplus, 1);
-    const int64_t levels = k > 3 ? k - 3 : 1, stride = (dmax + 63) & ~int64_t(63);
-    for (int64_t lo = first; lo < end; lo += int64_t(60000) * nparts) {
-        const int64_t hi = std::min<int64_t>(end, lo + int64_t(60000) * nparts);
-        const int64_t pivots = part_count(lo, hi, nparts, part);
-        if (pivots <= 0) continue;
-        // waves per pivot: enough to fill the chip a few times over, bounded by a 2 GB slab
-        int64_t blocks_x = std::max<int64_t>(1, std::min<int64_t>((dmax + 3) / 4, std::max<int64_t>(1, int64_t(cu) * 8 / pivots)));
-        while (blocks_x > 1 && pivots * blocks_x * 4 * levels * stride * 4 > (int64_t(2) << 30)) blocks_x /= 2;
-        const int64_t slab_ints = pivots * blocks_x * 4 * levels * stride;
-        if (slab_ints * 4 > (int64_t(32) << 30)) return GMSX_ERR_DEVICE_MEM;
-        int32_t *slab = nullptr;
-        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slab), size_t(slab_ints) * 4));
-        struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{slab};
+    const int64_t levels = k > 3 ? k - 3 : 1;
+    int64_t budget_ints = (int64_t(2) << 30) / 4;  // 2 GB of level lists in flight
+    if (const char *e = std::getenv("GMSX_KC_SLAB_MB")) {  // test hook: a tiny budget forces many chunks on small graphs
+        const long long v = std::atoll(e);
+        if (v >= 1) budget_ints = int64_t(v) * (1 << 20) / 4;
+    }
+    int32_t *slab = nullptr;
+    int64_t slab_ints = 0;
+    struct Guard { int32_t *&p; ~Guard() { (void)hipFree(p); } } guard{slab};
+    for (int64_t lo = first; lo < end;) {
+        const int64_t left = part_count(lo, end, nparts, part);
+        if (left <= 0) break;
+        int32_t u0 = 0, d0 = 0;  // this shard's first pivot of the chunk is its widest
+        GMSX_HIP(hipMemcpyAsync(&u0, g->order + lo + part, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        GMSX_HIP(hipMemcpyAsync(&d0, g->dplus + u0, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        const int64_t stride = (std::max<int64_t>(d0, 1) + 63) & ~int64_t(63);
+        const int64_t per_block = 4 * levels * stride;  // ints one workgroup (4 waves) needs
+        const int64_t pivots = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(60000, budget_ints / per_block), left));
+        const int64_t hi = std::min<int64_t>(end, lo + pivots * nparts);
+        // waves per pivot: enough to fill the chip a few times over, inside the budget
+        int64_t blocks_x = std::max<int64_t>(1, std::min<int64_t>((int64_t(d0) + 3) / 4, std::max<int64_t>(1, int64_t(cu) * 8 / pivots)));
+        while (blocks_x > 1 && pivots * blocks_x * per_block > budget_ints) blocks_x /= 2;
+        const int64_t need = pivots * blocks_x * per_block;
+        if (need > slab_ints) {
+            GMSX_HIP(hipStreamSynchronize(s));  // earlier chunks still read the old slab
+            (void)hipFree(slab);
+            slab = nullptr;
+            slab_ints = 0;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slab), size_t(need) * 4));
+            slab_ints = need;
+        }
         hipLaunchKernelGGL(k_kc_generic, dim3(unsigned(blocks_x), unsigned(pivots)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff,
                            g->bmpool, g->bitset_limit, g->dense_limit, g->dplus, g->order, lo, hi, nparts, part, k, slab, stride, acc);
         ++*launches;
-        GMSX_HIP(hipStreamSynchronize(s));
         GMSX_HIP(hipGetLastError());
+        lo = hi;
     }
+    GMSX_HIP(hipStreamSynchronize(s));  // the slab is freed on return
     return GMSX_OK;
 }
 

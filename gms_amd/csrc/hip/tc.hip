@@ -779,6 +779,7 @@ static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
 }
 
 static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *partial, gmsx_stats *st) {
+    if (int rc = ensure_tc(g)) return rc;  // first call on a graph uploaded without GMSX_UPLOAD_FOR_TC: builds the task lists (untimed)
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     int64_t n_block = 0, n_work = 0;  // pivots with d+ >= 64, d+ >= 2
@@ -896,6 +897,7 @@ int gmsx_tc_divisor(int algo) { return algo == GMSX_TC_FULL ? 3 : 1; }
 int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21) {
     if (!g || !out21) return GMSX_ERR_INVALID;
     if (int rc = ensure_init()) return rc;
+    if (int rc = ensure_tc(g)) return rc;
     hipStream_t s = ctx().stream;
     std::memset(out21, 0, 21 * sizeof(uint64_t));
     if (g->n == 0) return GMSX_OK;
@@ -919,6 +921,7 @@ int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out256) {
     uint64_t *out248 = out256;
     if (!g || !out248) return GMSX_ERR_INVALID;
     if (int rc = ensure_init()) return rc;
+    if (int rc = ensure_tc(g)) return rc;
     hipStream_t s = ctx().stream;
     std::memset(out248, 0, 256 * sizeof(uint64_t));
     if (g->n == 0) return GMSX_OK;

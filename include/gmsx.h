@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GMSX_VERSION 210
+#define GMSX_VERSION 300
 
 /* ---- status codes ---- */
 enum {
@@ -136,7 +136,12 @@ int gmsx_device_info(char *name, size_t name_len, int *compute_units, int64_t *h
 
 enum {
     GMSX_UPLOAD_DEFAULT = 0,
-    GMSX_UPLOAD_TRUSTED = 1 /* skip the device-side check of the canonical-row invariant */
+    GMSX_UPLOAD_TRUSTED = 1, /* skip the device-side check of the canonical-row invariant */
+    GMSX_UPLOAD_FOR_TC = 2   /* also build the triangle-count containers (stream rows, inline rows, task lists: ~5x the CSR) now, inside the
+                                upload — what a triangle-count harness wants in its untimed "GraphExec buildTime" (common/benchmark.h:
+                                105-109).  Without it they are built by gmsx_graph_prepare or by the first gmsx_tc_* call, and a k-clique /
+                                Bron–Kerbosch user never pays for them (the reference's k-clique harness times its SGraph build,
+                                k_clique_count_set_based.h:22) */
     /* bits 8..23 (test hook): if non-zero, the hub-container id range is [0, value) instead of [0, 65535), so that
        small graphs exercise the 32-bit tail containers; results never depend on it */
 };
@@ -147,6 +152,9 @@ enum {
  * like the reference (common/benchmark.h:105-109). */
 int gmsx_graph_upload(int64_t n, const int64_t *offsets, const int32_t *neigh, uint32_t flags, gmsx_graph **out);
 int gmsx_graph_upload_csr(const gmsx_csr *g, uint32_t flags, gmsx_graph **out);
+/* Builds optional containers of an uploaded graph ahead of their first use (so that a caller can time or place the cost). */
+enum { GMSX_PREPARE_TC = 1 /* the triangle-count containers, see GMSX_UPLOAD_FOR_TC */ };
+int gmsx_graph_prepare(gmsx_graph *g, uint32_t what);
 int gmsx_graph_free(gmsx_graph *g);
 int64_t gmsx_graph_num_nodes(const gmsx_graph *g);   /* SetGraph::num_nodes, set_graph.h:115-118 */
 int64_t gmsx_graph_num_edges(const gmsx_graph *g);   /* undirected edges m */

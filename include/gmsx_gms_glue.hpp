@@ -68,9 +68,12 @@ using HipSetRefGraph = gmsx::HipSetRefGraph;    // SetGraph<SortedSetRef> flavou
     }                                                                                                                              \
     }
 
-// CliqueCount builds its SGraph inside the timed region (k_clique_count_set_based.h:22); so does this
+// CliqueCount builds its SGraph inside the timed region (k_clique_count_set_based.h:22); so does this — with the lean upload (DAG containers
+// + bitsets only: no triangle-count task lists), whatever the driver's default flags are
 #define GMSX_GLUE_KC(SET, SGRAPH, SET2)                                                                                            \
-    template <> inline size_t CliqueCount<SET, SGRAPH, SET2>(CSRGraph & g, size_t k) { return gmsx::clique_count(SGRAPH::FromCGraph(g), k); }
+    template <> inline size_t CliqueCount<SET, SGRAPH, SET2>(CSRGraph & g, size_t k) {                                             \
+        return gmsx::clique_count(SGRAPH::FromCGraph(g, GMSX_UPLOAD_DEFAULT), k);                                                  \
+    }
 
 GMSX_GLUE_TC(HipSetGraph)
 GMSX_GLUE_TC(HipRoaringGraph)

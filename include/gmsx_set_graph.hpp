@@ -277,6 +277,18 @@ class SortedSpanRef {
 // without a HIP device the upload is skipped and the first whole-graph call fails loudly instead — the generic host
 // templates keep working.
 // ------------------------------------------------------------------------------------------------------------------
+// Upload flags FromCGraph / FromCsr / clone use when none are given.  GMSX_UPLOAD_DEFAULT builds the degree-oriented containers and
+// bitsets only (what k-clique and Bron–Kerbosch need) and leaves the triangle-count task lists to the first count_total call; a
+// triangle-count driver sets GMSX_UPLOAD_FOR_TC — one line in main(), or -DGMSX_ADAPTOR_UPLOAD_FLAGS=GMSX_UPLOAD_FOR_TC — so that their
+// build lands in the harness's untimed "GraphExec buildTime" (common/benchmark.h:105-109) like the reference's SetGraph construction.
+#ifndef GMSX_ADAPTOR_UPLOAD_FLAGS
+#define GMSX_ADAPTOR_UPLOAD_FLAGS GMSX_UPLOAD_DEFAULT
+#endif
+inline uint32_t &default_upload_flags() {
+    static uint32_t flags = uint32_t(GMSX_ADAPTOR_UPLOAD_FLAGS);
+    return flags;
+}
+
 template <class SetT>
 class HipGraphT {
    public:
@@ -291,7 +303,7 @@ class HipGraphT {
             adj_own_ = std::move(o.adj_own_);
             sets_ = std::move(o.sets_);
             off_ = o.off_; adj_ = o.adj_; n_ = o.n_;
-            dev_ = o.dev_; upload_rc_ = o.upload_rc_;
+            dev_ = o.dev_; upload_rc_ = o.upload_rc_; flags_ = o.flags_;
             o.dev_ = nullptr; o.off_ = nullptr; o.adj_ = nullptr; o.n_ = 0;
         }
         return *this;
@@ -305,8 +317,11 @@ class HipGraphT {
     // adjacency is BORROWED — the CGraph must outlive this object, as it does in the reference harness (set_graph.h:162-168
     // makes the same assumption for SortedSetRef) — otherwise it is copied once and sorted.
     template <class CGraph>
-    static HipGraphT FromCGraph(const CGraph &g) {
+    static HipGraphT FromCGraph(const CGraph &g) { return FromCGraph(g, default_upload_flags()); }
+    template <class CGraph>
+    static HipGraphT FromCGraph(const CGraph &g, uint32_t upload_flags) {
         HipGraphT r;
+        r.flags_ = upload_flags;
         const int64_t n = g.num_nodes();
         r.n_ = n;
         r.off_own_.resize(size_t(n) + 1);
@@ -332,8 +347,9 @@ class HipGraphT {
         return r;
     }
     // borrows the arrays of a gmsx_csr (which must outlive the graph)
-    static HipGraphT FromCsr(const gmsx_csr *c) {
+    static HipGraphT FromCsr(const gmsx_csr *c, uint32_t upload_flags = default_upload_flags()) {
         HipGraphT r;
+        r.flags_ = upload_flags;
         r.n_ = gmsx_csr_num_nodes(c);
         r.off_ = gmsx_csr_offsets(c);
         r.adj_ = gmsx_csr_neighbors(c);
@@ -343,6 +359,7 @@ class HipGraphT {
     }
     HipGraphT clone() const {  // set_graph.h:120-127: an independent deep copy
         HipGraphT r;
+        r.flags_ = flags_;
         r.n_ = n_;
         r.off_own_.assign(off_, off_ + n_ + 1);
         r.adj_own_.assign(adj_, adj_ + off_[n_]);
@@ -403,7 +420,7 @@ class HipGraphT {
     }
     void try_upload() {
         release_device();
-        upload_rc_ = gmsx_graph_upload(n_, off_, adj_, GMSX_UPLOAD_DEFAULT, &dev_);
+        upload_rc_ = gmsx_graph_upload(n_, off_, adj_, flags_, &dev_);
         if (upload_rc_ != GMSX_OK) dev_ = nullptr;
     }
     void release_device() {
@@ -420,6 +437,7 @@ class HipGraphT {
     int64_t n_ = 0;
     gmsx_graph *dev_ = nullptr;
     int upload_rc_ = GMSX_OK;
+    uint32_t flags_ = GMSX_UPLOAD_DEFAULT;
 };
 
 using HipSetGraph = HipGraphT<SortedSpanSet>;       // the SortedSetGraph flavour       (set_graph.h:235)

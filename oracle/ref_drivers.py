@@ -1,4 +1,4 @@
-"""oracle/ref_drivers.py — TEST INFRASTRUCTURE.  Recipe that builds the three REAL reference drivers with the gmsx glue.
+"""oracle/ref_drivers.py — TEST INFRASTRUCTURE.  Recipe that builds the REAL reference drivers (the three algorithm drivers + examples/triangle_counting.cpp) with the gmsx glue.
 
 The driver sources are read from /root/reference where they lie, patched IN MEMORY with the `#include <gmsx_gms_glue.hpp>` line
 of INTEGRATION.md §2 plus ONE driver line each, compiled from a temp file that is deleted right after, and linked against
@@ -25,7 +25,16 @@ DRIVERS = {
         # keep the run short on the GPU box: only the gmsx flavours execute
         drop=[r'\s*benchmark_suite<RoaringGraph>\(args, g, "RoaringGraph"\);', r'\s*benchmark_suite<SortedSetGraph>\(args, g, "SortedSetGraph"\);',
               r'\s*benchmark_suite<RobinHoodGraph>\(args, g, "RobinHoodGraph"\);'],
-        flags=[]),
+        # the triangle-count target builds the task lists inside FromCGraph = the harness's untimed "GraphExec buildTime"
+        flags=["-DGMSX_ADAPTOR_UPLOAD_FLAGS=GMSX_UPLOAD_FOR_TC"]),
+    # BASELINE.json configs[0]: the reference's own demonstration of plugging a new Set into SetGraph (examples/triangle_counting.cpp:62-71)
+    "triangle_counting_example": dict(
+        src="examples/triangle_counting.cpp",
+        anchor='    BenchmarkKernelBk<BetterGraph>(args, g, TriangleCount::Seq::count_total<BetterGraph>, TriangleCount::Verify::total_count, "BetterGraph");',
+        add='    BenchmarkKernelBk<HipSetGraph>(args, g, TriangleCount::Seq::count_total<HipSetGraph>, TriangleCount::Verify::total_count, "HipSetGraph");',
+        # lean: SimpleSet::contains is a linear scan — minutes at scale 18; only the gmsx flavour executes on the GPU box
+        drop=[r'\s*BenchmarkKernelBk<SimpleGraph>\(args, g,[^;]*;', r'\s*BenchmarkKernelBk<BetterGraph>\(args, g,[^;]*;'],
+        flags=["-DGMSX_ADAPTOR_UPLOAD_FLAGS=GMSX_UPLOAD_FOR_TC"]),
     "k_clique_count": dict(
         src="gms/algorithms/set_based/k_clique_count/k_clique_count_set_based.cc",
         anchor="    return 0;",

@@ -1,10 +1,11 @@
-"""CPU: the drop-in claim of INTEGRATION.md §2, compiled.  The three REAL reference drivers — read from /root/reference at
+"""CPU: the drop-in claim of INTEGRATION.md §2, compiled.  The REAL reference drivers — read from /root/reference at
 test time, patched in a temp directory with the `#include <gmsx_gms_glue.hpp>` line plus ONE driver line each, never stored
 in this repository — are compiled and linked against include/gmsx_gms_glue.hpp + libgmsx.so:
 
   gms/algorithms/set_based/triangle_count/triangle_count.cc:43-45                   + benchmark_suite<HipSetGraph / HipRoaringGraph>
   gms/algorithms/set_based/k_clique_count/k_clique_count_set_based.cc:34-45         + BenchmarkKernel(CliqueCount<…HipSetGraph…>)
   gms/algorithms/set_based/maximal_clique_enum/maximal_clique_enum_bron_kerbosch.cc:84-91  + runEppstein<HipRoaringGraph>
+  examples/triangle_counting.cpp:62-71 (BASELINE.json configs[0])                   + BenchmarkKernelBk<HipSetGraph>(…Seq::count_total<HipSetGraph>…)
 
 On the GPU box (`-m gpu`; the binaries prebuilt here by oracle/ref_drivers.py travel under oracle/_ref/drivers/) the patched drivers RUN under the reference's own
 harness with `-v`, i.e. the reference's verifiers (serial host recount for TC, sequential Tomita for BK) judge the device
@@ -41,6 +42,10 @@ def test_real_driver_compiles_with_one_added_line(tmp_path, capi, name):
     ("triangle_count", ["-v", "-n", "2", "-g", "kronecker", "12"], ["tc-total-par-HipSetGraph", "tc-vertex-count2-once-par-HipRoaringGraph"]),
     ("k_clique_count", ["-v", "-n", "1", "-g", "kronecker", "10"], ["total 4-cliques: 9831960", "HipSetRefGraph"]),
     ("bron_kerbosch", ["-v", "-n", "1", "-g", "kronecker", "10"], ["The Number of maximal clique counted: 25467", "BK-GMS-ADG"]),
+    # BASELINE.json configs[0] IS this driver on Kronecker scale 18 ef 16; the harness's -v is the reference's serial host recount
+    # (Verify::total_count, ≈40 s at this size: SURVEY §8a a12) judging the device count
+    ("triangle_counting_example", ["-v", "-n", "2", "-g", "kronecker", "14"], ["HipSetGraph"]),
+    ("triangle_counting_example", ["-v", "-n", "1", "-g", "kronecker", "18"], ["HipSetGraph", "Graph has 262143 nodes and 3805448 undirected edges"]),
 ])
 def test_real_driver_runs_on_device_under_reference_harness(gpu, name, args, needles):
     exe = os.path.join(OUT, name)

@@ -5,6 +5,9 @@
     python tools/make_golden_big.py tc 26          # Par::count_total<RoaringGraph>, ~35 min on 8 threads, ~45 GB
     python tools/make_golden_big.py kc4 16|18|20   # CliqueCount<RoaringSet,RoaringGraph,RoaringSet>(g, 4)
     python tools/make_golden_big.py bk 14          # BkEppsteinPar::mceBench<RoaringGraph>, degree rank
+    python tools/make_golden_big.py bk-rmat 21 56  # BASELINE configs[3]: the com-Orkut-shaped R-MAT (A=.45 B=C=.22) of the gmsx loader,
+                                                   # written as .sg (gmsx_csr_save_sg), read back by the reference (cli.h:96 `-f`,
+                                                   # reader.h:252-305) and enumerated by BkEppsteinPar::mceBench<RoaringGraph>
 
 Every value is computed by the COMPILED REFERENCE (oracle/_ref/libgms_ref.so = spcl/gms headers + vendored
 CRoaring, see oracle/ref_shim.cc) on the graph its own loader generates (`-g kronecker <scale> --deg 16`,
@@ -23,9 +26,46 @@ from oracle.bindings import Reference  # noqa: E402
 PATH = os.path.join(ROOT, "tests", "golden", "graphs.json")
 
 
+def bk_rmat(scale, deg, a=0.45, b=0.22, c=0.22):
+    """configs[3]: the graph is NOT one the reference generator can make (fixed Graph500 skew), so the gmsx loader builds it,
+    the reference reads the .sg file and counts maximal cliques on exactly that adjacency (relabel off: same ids)."""
+    import tempfile
+    import numpy as np
+    from gms_amd import capi
+    R = Reference()
+    t0 = time.time()
+    csr = capi.HostCSR.generate_rmat(scale, deg, a, b, c)
+    n, m, fp = csr.num_nodes, csr.num_edges, csr.fingerprint()
+    path = os.path.join(tempfile.gettempdir(), "gmsx_rmat_%d_%d.sg" % (scale, deg))
+    csr.save_sg(path)
+    del csr
+    g = R.load_file(path, relabel=False)
+    os.unlink(path)
+    assert (R.num_nodes(g), R.nnz(g) // 2) == (n, m)
+    print("rmat %d ef %d (%.2f/%.2f/%.2f): n=%d m=%d through %s in %.1f s" % (scale, deg, a, b, c, n, m, path, time.time() - t0), flush=True)
+    t0 = time.time()
+    val = R.bk_count(g, Reference.ROARING, 0)
+    dt = time.time() - t0
+    R.free(g)
+    key = "rmat-%d-%d-a%02d-b%02d-c%02d" % (scale, deg, round(a * 100), round(b * 100), round(c * 100))
+    with open(PATH) as f:
+        graphs = json.load(f)
+    rec = graphs.setdefault(key, dict(generator="rmat", scale=scale, degree=deg, a=a, b=b, c=c, relabel="auto"))
+    if "bk" in rec:
+        assert rec["bk"] == val, (rec["bk"], val)
+    rec.update(n=n, m=m, offsets_fnv64="%016x" % fp[0], neigh_fnv64="%016x" % fp[1], bk=val)
+    rec.setdefault("sources", {})["bk"] = ("oracle/_ref BkEppsteinPar::mceBench<RoaringGraph>, degree rank, on the .sg file written by "
+                                           "gmsx_csr_save_sg, %d threads, %.0f s (tools/make_golden_big.py bk-rmat)" % (R.omp_threads(), dt))
+    with open(PATH, "w") as f:
+        json.dump(graphs, f, indent=1)
+    print(json.dumps({key: {"bk": val, "n": n, "m": m, "run_s": round(dt, 1)}}), flush=True)
+
+
 def main():
     what, scale = sys.argv[1], int(sys.argv[2])
     deg = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    if what == "bk-rmat":
+        return bk_rmat(scale, deg)
     R = Reference()
     t0 = time.time()
     g = R.generate("kronecker", scale, deg, True)
