@@ -4,6 +4,7 @@
 #include "device_graph.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>  // before rocprim: its texture iterator calls the host memset
@@ -825,8 +826,25 @@ __global__ void k_scale_offsets(int64_t count, const int64_t *__restrict__ in, i
     if (i < count) out[i] = in[i] * mul;
 }
 
+// GMSX_TIMING=1: phase times of the device-side builds on stderr (each mark synchronises the stream)
+struct PhaseTimer {
+    hipStream_t s;
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    const char *what;
+    PhaseTimer(hipStream_t st, const char *w) : s(st), on(std::getenv("GMSX_TIMING") != nullptr), t0(std::chrono::steady_clock::now()), what(w) {}
+    void mark(const char *phase) {
+        if (!on) return;
+        (void)hipStreamSynchronize(s);
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[gmsx %s] %-28s %8.1f ms\n", what, phase, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     hipStream_t s = ctx().stream;
+    PhaseTimer pt(s, "base build");
     const int64_t n = g->n;
     if (int rc = dmalloc(&g->scratch, 16, g)) return rc;
     if (int rc = dmalloc(&g->acc, kAccWords, g)) return rc;
@@ -845,6 +863,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     g->max_deg = int32_t(acc[2]);
     g->m = g->nnz / 2;
 
+    pt.mark("validate");
     const unsigned tb = unsigned((n + 255) / 256);
     // 2. rank ids: sort (degree, id) descending
     if (int rc = dmalloc(&g->newid, n, g)) return rc;
@@ -866,6 +885,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         GMSX_HIP(hipStreamSynchronize(s));
     }
 
+    pt.mark("rank ids");
     // 3. container sizes -> offsets.  Test hook: bits 8..23 of `flags` shrink the hub id range so that small graphs
     //    exercise the tail containers (0 = the production value kHub).
     int hub_limit = int((flags >> 8) & 0xffffu);
@@ -896,6 +916,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         hipLaunchKernelGGL(k_fill_parts, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, g->newid, hub_limit, g->hoff, g->toff,
                            g->hadj, g->tadj);
 
+    pt.mark("containers count+fill");
     // 4a. both containers of every row ascending by rank id (the 0xFFFF pad sorts last): "the members below v" are then the entries in
     //     front of v — what the inline rows, the cut of handed-over rows, the delta forms and the k-clique binary searches rely on.
     //     rocPRIM's segmented sort counts items in 32 bits, so the rows are sorted in vertex ranges of < 2^31 entries each.
@@ -903,6 +924,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     if (int rc = sort_rows(g->tadj, g->tail_entries, n, g->toff, 32, s)) return rc;
     g->rows_sorted = true;
 
+    pt.mark("row sorts");
     // 4b. bitset containers: every hub row (rank id < hub_limit) as a bitmap over [0, v) — the dense streaming form of the triangle
     //     kernel and the edge test of the k-clique recursion.  <= 268 MB.
     g->dense_limit = int32_t(std::min<int64_t>(n, hub_limit));
@@ -921,6 +943,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         if (K > 0 && g->bmpool_words > 0)
             hipLaunchKernelGGL(k_dense_fill, dim3(grid_for_waves(K)), dim3(256), 0, s, K, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool);
     }
+    pt.mark("bitsets");
     // 5. work-sorted launch order: rank ids by decreasing d+
     if (int rc = dmalloc(&g->order, n, g)) return rc;
     if (int rc = dmalloc(&g->sorted_dplus, n, g)) return rc;
@@ -943,6 +966,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
         g->max_dplus = top;
     }
 
+    pt.mark("d+ order");
     GMSX_HIP(hipStreamSynchronize(s));
     GMSX_HIP(hipGetLastError());
     g->hub_limit = hub_limit;
@@ -956,6 +980,7 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
 // region, k_clique_count_set_based.h:22).
 static int build_tc_sets(gmsx_graph *g) {
     hipStream_t s = ctx().stream;
+    PhaseTimer pt(s, "tc build");
     const int64_t n = g->n;
     const uint32_t flags = g->upload_flags;
     const int hub_limit = g->hub_limit;
@@ -979,6 +1004,7 @@ static int build_tc_sets(gmsx_graph *g) {
         if (n > 0) hipLaunchKernelGGL(k_tail_split, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->toff, g->tadj, g->inline_limit, g->tsplit);
     }
 
+    pt.mark("tail split");
     // 5b. sizes of the inline rows (4c): ids handed over per receiving vertex
     int64_t n_heavy = 0, n_work = 0;
     unsigned long long *inl_h = nullptr, *inl_t = nullptr;  // [n + 1] ids per receiver, later the fill cursors
@@ -1024,6 +1050,7 @@ static int build_tc_sets(gmsx_graph *g) {
         g->inline_units = inline_h_units + inline_t_units;
     }
 
+    pt.mark("inline row sizes");
     // 4d. stream rows of the heavy-pivot triangle kernel (needs the hub rows sorted: the delta form encodes ascending ids)
     int64_t inline_h_base = 0, inline_t_base = 0;  // first unit of the inline regions of spool / tpool
     {
@@ -1078,6 +1105,7 @@ static int build_tc_sets(gmsx_graph *g) {
                                g->srow, g->spool);
         GMSX_HIP(hipStreamSynchronize(s));
     }
+    pt.mark("hub stream rows");
     // 4e. … and of the tail parts
     {
         int delta_mode = g->rows_sorted ? 1 : 0;
@@ -1111,6 +1139,7 @@ static int build_tc_sets(gmsx_graph *g) {
         GMSX_HIP(hipStreamSynchronize(s));
     }
 
+    pt.mark("tail stream rows + tdesc");
     // 5c. inline rows: copy the handed-over ids (pools exist now), blank the light pivots' descriptors of handed-over far members
     if (n_work > 0) {
         GMSX_HIP(hipMemsetAsync(inl_h, 0, size_t(n + 1) * sizeof(unsigned long long), s));  // now the fill cursors
@@ -1119,6 +1148,7 @@ static int build_tc_sets(gmsx_graph *g) {
                            g->tadj, g->dplus, g->inline_limit, inl_h, inl_t, ihoff, itoff, inline_h_base, reinterpret_cast<uint16_t *>(g->spool),
                            inline_t_base, reinterpret_cast<int32_t *>(g->tpool), g->tdesc);
     }
+    pt.mark("inline rows fill");
     // 5d. the ids arrive in the inline rows through atomic cursors, in any order: sort every receiver's rows (fillers last), so that the
     //     chunks the work items name hold the same ids on every rank of a multi-GPU run
     if (inline_h_units + inline_t_units > 0) {
@@ -1131,6 +1161,7 @@ static int build_tc_sets(gmsx_graph *g) {
         hipLaunchKernelGGL(k_scale_offsets, dim3(ob), dim3(256), 0, s, n + 1, itoff, int64_t(4), ioff);
         if (int rc = sort_rows(g->tpool + inline_t_base * 4, inline_t_units * 4, n, ioff, 32, s)) return rc;
     }
+    pt.mark("inline rows sort");
     // 5e. the light pivots k_tc_wave still has work for (most handed everything over): a compact list in launch order, built with a scan so
     //     that it is the same on every rank
     {
@@ -1150,6 +1181,7 @@ static int build_tc_sets(gmsx_graph *g) {
             GMSX_HIP(hipStreamSynchronize(s));
         }
     }
+    pt.mark("light pivot list");
     // 6. task lists: inline entries, then every oriented edge of a heavy pivot at the endpoint whose row is the bigger one
     {
         int two_sided = 1;
@@ -1187,6 +1219,7 @@ static int build_tc_sets(gmsx_graph *g) {
         // one: the reverse entries arrive through atomic cursors in any order, but every rank of a multi-GPU run must cut the same
         // lists into the same work items (shard p of N = items p, p+N, …).  GMSX_TC_SORT_TASKS=0 skips the sort (A/B knob, one
         // process only).
+        pt.mark("task lists fill");
         bool sort_tasks = g->task_entries > 0;
         if (const char *e = std::getenv("GMSX_TC_SORT_TASKS")) sort_tasks = sort_tasks && std::atoi(e) != 0;
         if (sort_tasks) {
@@ -1197,6 +1230,7 @@ static int build_tc_sets(gmsx_graph *g) {
             hipLaunchKernelGGL(k_task_keys, dim3(unsigned((g->task_entries + 255) / 256)), dim3(256), 0, s, g->task_entries, g->task, tid, keys);
             if (int rc = sort_segment_pairs(keys, reinterpret_cast<Entry *>(g->task), g->task_entries, n, g->tbeg, 56, s)) return rc;
         }
+        pt.mark("task lists sort");
         int64_t *icnt = nullptr, *ioff = nullptr;
         if (int rc = dmalloc(&icnt, n + 1, nullptr)) return rc;
         DevGuard g_ic{icnt};
@@ -1209,6 +1243,7 @@ static int build_tc_sets(gmsx_graph *g) {
         if (n > 0) hipLaunchKernelGGL(k_item_fill, dim3(vb), dim3(256), 0, s, n, g->order, g->tbeg, ioff, g->titem);
         GMSX_HIP(hipStreamSynchronize(s));
     }
+    pt.mark("work items");
     GMSX_HIP(hipStreamSynchronize(s));
     GMSX_HIP(hipGetLastError());
     return GMSX_OK;

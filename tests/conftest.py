@@ -57,7 +57,10 @@ _GRAPH_CACHE = {}
 def host_graph(capi, generator, scale, degree=16, relabel=True):
     key = (generator, scale, degree, relabel)
     if key not in _GRAPH_CACHE:
-        _GRAPH_CACHE[key] = capi.HostCSR.generate(generator, scale, degree, capi.RELABEL_AUTO if relabel else capi.RELABEL_NEVER)
+        if generator == "rmat":  # the com-Orkut-shaped family of BASELINE configs[3]: own generator, A=.45 B=C=.22 (graphs.json "rmat-*" records)
+            _GRAPH_CACHE[key] = capi.HostCSR.generate_rmat(scale, degree, 0.45, 0.22, 0.22, capi.RELABEL_AUTO if relabel else capi.RELABEL_NEVER)
+        else:
+            _GRAPH_CACHE[key] = capi.HostCSR.generate(generator, scale, degree, capi.RELABEL_AUTO if relabel else capi.RELABEL_NEVER)
     return _GRAPH_CACHE[key]
 
 

@@ -8,7 +8,8 @@ import pytest
 from conftest import GOLDEN, edges_to_csr, host_graph, load_golden
 
 GRAPHS = load_golden("graphs.json")
-FP = [k for k, v in GRAPHS.items() if "offsets_fnv64" in v and v["scale"] <= 16]
+FP = [k for k, v in GRAPHS.items() if "offsets_fnv64" in v and v["scale"] <= 16 and v["generator"] != "rmat"]
+RMAT = [k for k, v in GRAPHS.items() if v.get("generator") == "rmat" and v["scale"] <= 16]
 
 
 @pytest.mark.parametrize("key", FP)
@@ -18,6 +19,16 @@ def test_fingerprints(capi, key):
     fo, fn = csr.fingerprint()
     assert (csr.num_nodes, csr.num_edges) == (rec["n"], rec["m"])
     assert "%016x" % fo == rec["offsets_fnv64"] and "%016x" % fn == rec["neigh_fnv64"]
+
+
+@pytest.mark.parametrize("key", RMAT)
+def test_own_rmat_generator_fingerprints(capi, key):
+    """gmsx_csr_generate_rmat (custom skew, outside the reference generator): the reference's Bron–Kerbosch goldens of this family
+    (tools/make_golden_big.py bk-rmat) were counted on exactly these arrays, so the generator must keep producing them."""
+    rec = GRAPHS[key]
+    csr = capi.HostCSR.generate_rmat(rec["scale"], rec["degree"], rec["a"], rec["b"], rec["c"])
+    assert (csr.num_nodes, csr.num_edges) == (rec["n"], rec["m"])
+    assert ["%016x" % x for x in csr.fingerprint()] == [rec["offsets_fnv64"], rec["neigh_fnv64"]]
 
 
 def test_fingerprint_scale18_and_thread_independence(capi):

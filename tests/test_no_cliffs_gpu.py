@@ -113,6 +113,87 @@ def test_k_beyond_ten(gpu):
     g.free()
 
 
+def planted_cliques_graph(gpu, scale=14, sizes=(16, 17, 18), seed=5):
+    """uniform G(n, m) background (avg degree 32) + cliques planted on random vertex sets; returns (HostCSR, adjacency as python int bitmasks
+    over a DAG order)."""
+    base = gpu.HostCSR.generate("uniform", scale)
+    n = base.num_nodes
+    off, ng = base.offsets(), base.neighbors()
+    src = np.repeat(np.arange(n, dtype=np.int32), np.diff(off))
+    rng = np.random.default_rng(seed)
+    es, ed = [src[src < ng]], [ng[src < ng]]
+    for sz in sizes:
+        mem = rng.choice(n, size=sz, replace=False).astype(np.int32)
+        iu = np.triu_indices(sz, 1)
+        es.append(mem[iu[0]])
+        ed.append(mem[iu[1]])
+    return gpu.HostCSR.from_edges(np.concatenate(es), np.concatenate(ed), num_nodes=n)
+
+
+def dag_clique_count(off, ng, k):
+    """independent CPU count of k-cliques: degree-oriented DAG, python-int bitmasks, pruned recursion (each clique once)"""
+    n = off.size - 1
+    deg = np.diff(off)
+    rank = np.empty(n, dtype=np.int64)
+    rank[np.lexsort((np.arange(n), deg))] = np.arange(n)     # low degree first; edges point to higher rank
+    out = [[int(v) for v in ng[off[u]:off[u + 1]] if rank[v] > rank[u]] for u in range(n)]
+    total = 0
+    for u in range(n):
+        mem = out[u]
+        if len(mem) < k - 1:
+            continue
+        idx = {v: i for i, v in enumerate(mem)}
+        adj = [0] * len(mem)
+        for v in mem:
+            for w in out[v]:
+                if w in idx:
+                    adj[idx[v]] |= 1 << idx[w]
+                    adj[idx[w]] |= 1 << idx[v]
+
+        def rec(need, cand):
+            if need == 0:
+                return 1
+            if bin(cand).count("1") < need:
+                return 0
+            t, c = 0, cand
+            while c:
+                low = c & -c
+                i = low.bit_length() - 1
+                c ^= low
+                t += rec(need - 1, c & adj[i])   # members after i only: every clique once
+            return t
+        total += rec(k - 1, (1 << len(mem)) - 1)
+    return total
+
+
+@pytest.mark.parametrize("slab_mb", [None, 1])
+def test_generic_path_k15_on_a_midsize_graph(gpu, slab_mb):
+    """k >= 11 sends EVERY pivot with d+ >= k-1 through the generic list recursion, whose level lists live in one budgeted slab: pivots per
+    chunk = budget / (levels * stride of the chunk's widest pivot) (fixed 60000-pivot chunks sized by the GLOBAL max d+ asked
+    for tens of GB at k >= 12 on RMAT-26).  16 384 vertices, 262 k background edges, planted 16/17/18-cliques: k = 15 with the default
+    budget and with a 1 MB one (GMSX_KC_SLAB_MB test hook: many chunks through one reused slab) against an independent CPU recursion.
+    (The reference's own recursion enumerates k!·C ordered cliques — 15! per clique — and cannot produce this value in any time.)"""
+    csr = planted_cliques_graph(gpu)
+    want = dag_clique_count(csr.offsets(), csr.neighbors(), 15)
+    assert want >= math.comb(16, 15) + math.comb(17, 15) + math.comb(18, 15)
+    old = os.environ.get("GMSX_KC_SLAB_MB")
+    if slab_mb is not None:
+        os.environ["GMSX_KC_SLAB_MB"] = str(slab_mb)
+    try:
+        g = gpu.DeviceGraph.from_csr(csr)
+        ordered, cliques, st = g.kclique_count(15, stats=True)
+        assert cliques == want and ordered == (want * math.factorial(15)) & ((1 << 64) - 1)
+        if slab_mb is not None:
+            assert st["launches"] >= 8                               # the tiny budget really cut the pivots into many chunks
+        assert sum(g.kclique_partial(15, p, 3) for p in range(3)) == cliques
+        g.free()
+    finally:
+        if old is None:
+            os.environ.pop("GMSX_KC_SLAB_MB", None)
+        else:
+            os.environ["GMSX_KC_SLAB_MB"] = old
+
+
 @pytest.mark.parametrize("a", [4200, 8200])
 def test_bk_beyond_4096_candidates(gpu, oracle, a):
     """Start vertices with 4097..8192 / 8193..16384 candidates: four / eight words per lane in the search kernels."""

@@ -50,7 +50,7 @@ def test_graph_counts_match_reference_goldens(oracle, capi, key):
     for k in (3, 4, 5):
         if f"kc{k}" in rec and (rec["scale"] <= 12 or k == 3):
             assert oracle.kclique(off, ng, k) == rec[f"kc{k}"]
-    if "bk" in rec and rec["scale"] <= 12:
+    if "bk" in rec and (rec["scale"] <= 12 or rec["generator"] == "rmat"):  # the low-skew family enumerates in seconds at scale 14
         assert oracle.bk_count(off, ng) == rec["bk"]
 
 
