@@ -461,31 +461,73 @@ __global__ void k_inline_units(int64_t n, const unsigned long long *__restrict__
     units_h[v] = v < n ? int64_t((ids_h[v] + 7) / 8) : 0;
     units_t[v] = v < n ? int64_t((ids_t[v] + 3) / 4) : 0;
 }
-__device__ __forceinline__ int64_t inline_chunks(const int64_t *__restrict__ ihoff, const int64_t *__restrict__ itoff, int64_t v) {
-    const int64_t uh = ihoff[v + 1] - ihoff[v], ut = itoff[v + 1] - itoff[v];
-    return (max(uh, ut) + kInlineChunk - 1) / kInlineChunk;
+// ---- receivers -----------------------------------------------------------------------------------------------------------------------------
+// A RECEIVER is a vertex that owns task lists: every heavy pivot (d+ >= kHeavy; receiver index = its position in `order`, which lists the
+// heavy pivots first) and every light vertex of rank id < inline_limit (it can only receive inline rows; index n_heavy + its rank among
+// those).  The build keeps kClasses counters per receiver: entries per class, then (after k_list_sizes) the class offsets inside the list.
+__device__ __forceinline__ int64_t receiver_of(int32_t w, const int32_t *__restrict__ dplus, const int32_t *__restrict__ opos, const int64_t *__restrict__ lidx,
+                                               int64_t n_heavy) {
+    return dplus[w] >= kHeavy ? int64_t(opos[w]) : n_heavy + lidx[w];
 }
-// the inline entries of every receiver: chunk k of its hub inline row and chunk k of its tail inline row share entry k of its list
+__global__ void k_opos(int64_t n, const int32_t *__restrict__ order, int32_t *__restrict__ opos) {
+    const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p < n) opos[order[p]] = int32_t(p);
+}
+__global__ void k_light_flags(int64_t limit, const int32_t *__restrict__ dplus, int64_t *__restrict__ flags) {
+    const int64_t w = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (w <= limit) flags[w] = (w < limit && dplus[w] < kHeavy) ? 1 : 0;
+}
+__global__ void k_recv_vertices(int64_t n_heavy, int64_t limit, const int32_t *__restrict__ order, const int32_t *__restrict__ dplus, const int64_t *__restrict__ lidx,
+                                int32_t *__restrict__ recv_v) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n_heavy) recv_v[i] = order[i];
+    if (i < limit && dplus[i] < kHeavy) recv_v[n_heavy + lidx[i]] = int32_t(i);
+}
+// the inline entries of every receiver: its hub inline row and its tail inline row, each in chunks of kInlineChunk units (list form).
+// MODE 0 counts them into the class counters, MODE 1 writes them (cursor = cur).
 template <bool FILL>
-__global__ void k_inline_entries(int64_t n, const int64_t *__restrict__ ihoff, const int64_t *__restrict__ itoff, int64_t base_h, int64_t base_t,
-                                 unsigned long long *__restrict__ cnt, const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ task,
-                                 uint32_t *__restrict__ tid) {
+__global__ void k_inline_entries(int64_t n, const int32_t *__restrict__ dplus, const int32_t *__restrict__ opos, const int64_t *__restrict__ lidx, int64_t n_heavy,
+                                 int32_t inline_limit, const int64_t *__restrict__ ihoff, const int64_t *__restrict__ itoff, int64_t base_h, int64_t base_t,
+                                 uint32_t *__restrict__ cnt, uint32_t *__restrict__ cur, const int64_t *__restrict__ hbeg, const int64_t *__restrict__ tbeg,
+                                 unsigned long long *__restrict__ htask, unsigned long long *__restrict__ ttask, unsigned long long *__restrict__ totals) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v >= n) return;
-    const int64_t c = inline_chunks(ihoff, itoff, v);
-    if (!FILL) {
-        cnt[v] = (unsigned long long)c;
-        return;
-    }
     const int64_t uh = ihoff[v + 1] - ihoff[v], ut = itoff[v + 1] - itoff[v];
-    for (int64_t k = 0; k < c; ++k) {
-        const int64_t o = k * kInlineChunk;
-        const int64_t nh = min(int64_t(kInlineChunk), uh - o), nt = min(int64_t(kInlineChunk), ut - o);
-        tid[tbeg[v] + k] = 0x80000000u | uint32_t(k);  // never a vertex id: no two entries of a list share a key
-        task[2 * (tbeg[v] + k)] = nh > 0 ? ((unsigned long long)(base_h + ihoff[v] + o) << 24) | ((unsigned long long)kFormList << 22) | (unsigned long long)nh : 0ull;
-        // bit 22 of the tail descriptor (no tail form uses it) marks an inline entry: it stands for no edge of its own in the bookkeeping
-        task[2 * (tbeg[v] + k) + 1] = (nt > 0 ? ((unsigned long long)(base_t + itoff[v] + o) << 24) | (unsigned long long)nt : 0ull) | (1ull << 22);
+    if (uh == 0 && ut == 0) return;
+    if (dplus[v] < kHeavy && v >= inline_limit) return;  // cannot happen: only heavy vertices and rank ids < inline_limit receive
+    const int64_t p = receiver_of(int32_t(v), dplus, opos, lidx, n_heavy);
+    uint32_t *c = cnt + p * kClasses;
+    for (int64_t o = 0; o < uh; o += kInlineChunk) {
+        const unsigned long long units = (unsigned long long)min(int64_t(kInlineChunk), uh - o);
+        const unsigned long long d = ((unsigned long long)(base_h + ihoff[v] + o) << 24) | ((unsigned long long)kFormList << 22) | units;
+        const int cls = hub_class(d);
+        if (!FILL) atomicAdd(&c[cls], 1u);
+        else htask[hbeg[p] + c[cls] + atomicAdd(&cur[p * kClasses + cls], 1u)] = d;
     }
+    for (int64_t o = 0; o < ut; o += kInlineChunk) {
+        const unsigned long long units = (unsigned long long)min(int64_t(kInlineChunk), ut - o);
+        const unsigned long long d = ((unsigned long long)(base_t + itoff[v] + o) << 24) | ((unsigned long long)kFormList << 22) | units;
+        const int cls = tail_class(d);
+        if (!FILL) atomicAdd(&c[cls], 1u);
+        else ttask[tbeg[p] + c[cls] + atomicAdd(&cur[p * kClasses + cls], 1u)] = d;
+    }
+    if (!FILL) {
+        atomicAdd(&totals[0], (unsigned long long)((uh + kInlineChunk - 1) / kInlineChunk));
+        atomicAdd(&totals[1], (unsigned long long)((ut + kInlineChunk - 1) / kInlineChunk));
+    }
+}
+// per receiver: the class counters become the class offsets inside its hub list / tail list; the list lengths go to hcnt / tcnt
+__global__ void k_list_sizes(int64_t n_recv, uint32_t *__restrict__ cnt, int64_t *__restrict__ hcnt, int64_t *__restrict__ tcnt) {
+    const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p > n_recv) return;
+    if (p == n_recv) { hcnt[p] = 0; tcnt[p] = 0; return; }
+    uint32_t *c = cnt + p * kClasses;
+    uint32_t run = 0;
+    for (int k = 0; k < kHubClasses; ++k) { const uint32_t x = c[k]; c[k] = run; run += x; }
+    hcnt[p] = run;
+    run = 0;
+    for (int k = kHubClasses; k < kClasses; ++k) { const uint32_t x = c[k]; c[k] = run; run += x; }
+    tcnt[p] = run;
 }
 
 // light pivots that keep work for k_tc_wave: at least one far light member (rank id >= inline_limit, d+ < kHeavy) behind the first member
@@ -543,25 +585,43 @@ __device__ __forceinline__ uint32_t cut_tail_units(const uint32_t *__restrict__ 
     }
     return lo;
 }
+// wave-aggregated claim of `one` slot per active lane in the counter of class `cls` of ONE receiver (all lanes the same receiver, a few
+// distinct classes): one atomic per distinct class; returns this lane's offset behind the counter's old value (FILL) / nothing (COUNT)
+__device__ __forceinline__ uint32_t claim_by_class(uint32_t *ctr, int cls, bool active, int lane) {
+    uint32_t mine = 0;
+    unsigned long long todo = __ballot(active);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int c = __builtin_amdgcn_readlane(cls, leader);
+        const unsigned long long same = __ballot(active && cls == c);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&ctr[c], uint32_t(__popcll(same)));
+        base = uint32_t(__builtin_amdgcn_readlane(int(base), leader));
+        if (active && cls == c) mine = base + uint32_t(__popcll(same & ((1ull << lane) - 1ull)));
+        todo &= ~same;
+    }
+    return mine;
+}
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32_t *__restrict__ order, const int64_t *__restrict__ hoff,
                                                     const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                     const int32_t *__restrict__ dplus, const unsigned long long *__restrict__ srow,
-                                                    const unsigned long long *__restrict__ trow, int two_sided, unsigned long long *__restrict__ cnt,
-                                                    const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ task,
-                                                    unsigned long long *__restrict__ reversed, const int64_t *__restrict__ ihoff,
-                                                    const int64_t *__restrict__ itoff, const uint32_t *__restrict__ spool,
-                                                    const uint32_t *__restrict__ tpool, int32_t inline_limit, uint32_t *__restrict__ tid) {
+                                                    const unsigned long long *__restrict__ trow, int two_sided, const int32_t *__restrict__ opos,
+                                                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ cur, const int64_t *__restrict__ hbeg,
+                                                    const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ htask, unsigned long long *__restrict__ ttask,
+                                                    int32_t *__restrict__ tunits, unsigned long long *__restrict__ reversed, const uint32_t *__restrict__ spool,
+                                                    const uint32_t *__restrict__ tpool, int32_t inline_limit) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
     unsigned long long rev = 0;
-    for (int64_t pos = wave0; pos < n_heavy; pos += nwaves) {
+    for (int64_t pos = wave0; pos < n_heavy; pos += nwaves) {  // the heavy pivots are the first n_heavy of `order`: receiver index = pos
         const int32_t u = order[pos];
         const int64_t hb = hoff[u], tb = toff[u];
         const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
         const unsigned long long du_s = srow[u], du_t = trow[u];
-        int64_t fwd = FILL ? tbeg[u] + inline_chunks(ihoff, itoff, u) : 0;  // next forward slot (wave-uniform); the inline entries come first
+        uint32_t *cu = cnt + pos * kClasses, *ru = cur + pos * kClasses;
+        int kept = 0;
         for (int base = 0; base < hl + tl; base += 64) {
             const int i = base + lane;
             int32_t v = -1;
@@ -578,57 +638,56 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                 const uint32_t keep = uint32_t(srow[v] & 0x3fffffull) + (i > hl ? uint32_t(trow[v] & 0x3fffffull) : 0u);  // what u would stream
                 reverse = ch + ct < keep;
             }
-            const unsigned long long fmask = __ballot(v >= 0 && !reverse);
+            const bool fwd = v >= 0 && !reverse;
+            // forward: v's rows against u — the first member has no member below it (the edge closes no triangle); the tail ids of the first
+            // tail member lie below every tail id of the pivot; a hub member has no tail part
+            const unsigned long long fh = (fwd && i > 0) ? srow[v] : 0ull, ft = (fwd && i > hl) ? trow[v] : 0ull;
+            const bool fh_on = (fh & 0x3fffffull) != 0, ft_on = (ft & 0x3fffffull) != 0;
+            const uint32_t sh = claim_by_class(FILL ? ru : cu, hub_class(fh), fh_on, lane);
+            const uint32_t st = claim_by_class(FILL ? ru : cu, tail_class(ft), ft_on, lane);
             if (FILL) {
-                if (v >= 0 && !reverse) {
-                    const int64_t slot = fwd + __popcll(fmask & ((1ull << lane) - 1ull));
-                    tid[slot] = uint32_t(v);
-                    task[2 * slot] = i > 0 ? srow[v] : 0ull;  // the first member has no member below it: the edge closes no triangle
-                    // the tail ids of the first tail member lie below every tail id of the pivot; a hub member has no tail part
-                    task[2 * slot + 1] = (i > hl) ? trow[v] : 0ull;
-                } else if (v >= 0) {
-                    const int64_t slot = tbeg[v + 1] - 1 - int64_t(atomicAdd(&cnt[v], 1ull));  // reverse entries fill v's list from its end
-                    tid[slot] = uint32_t(u);
-                    task[2 * slot] = ch ? (du_s & ~0x3fffffull) | ch : 0ull;
-                    task[2 * slot + 1] = ct ? (du_t & ~0x3fffffull) | ct : 0ull;
-                }
-                fwd += __popcll(fmask);
-            } else {
-                if (v >= 0 && reverse) {
-                    atomicAdd(&cnt[v], 1ull);
+                if (fh_on) htask[hbeg[pos] + cu[hub_class(fh)] + sh] = fh;
+                if (ft_on) ttask[tbeg[pos] + cu[tail_class(ft)] + st] = ft;
+            }
+            kept += __popcll(__ballot(fwd));
+            if (v >= 0 && reverse) {  // u's rows, cut at v, against v
+                const int64_t pv = opos[v];
+                const unsigned long long rh = ch ? (du_s & ~0x3fffffull) | ch : 0ull, rt = ct ? (du_t & ~0x3fffffull) | ct : 0ull;
+                uint32_t *cv = cnt + pv * kClasses;
+                if (!FILL) {
+                    if (rh) atomicAdd(&cv[hub_class(rh)], 1u);
+                    if (rt) atomicAdd(&cv[tail_class(rt)], 1u);
+                    atomicAdd(&tunits[v], 1);
                     ++rev;
+                } else {
+                    uint32_t *rv = cur + pv * kClasses;
+                    if (rh) htask[hbeg[pv] + cv[hub_class(rh)] + atomicAdd(&rv[hub_class(rh)], 1u)] = rh;
+                    if (rt) ttask[tbeg[pv] + cv[tail_class(rt)] + atomicAdd(&rv[tail_class(rt)], 1u)] = rt;
                 }
-                fwd += __popcll(fmask);
             }
         }
-        if (!FILL && lane == 0 && fwd) atomicAdd(&cnt[u], (unsigned long long)fwd);
+        if (!FILL && lane == 0 && kept) atomicAdd(&tunits[u], kept);
     }
     if (!FILL) {
         for (int s = 32; s > 0; s >>= 1) rev += __shfl_down(rev, s);
         if (lane == 0 && rev) atomicAdd(reversed, rev);
     }
 }
-__global__ void k_task_keys(int64_t entries, const unsigned long long *__restrict__ task, const uint32_t *__restrict__ tid,
-                            unsigned long long *__restrict__ keys) {
-    const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (e < entries) keys[e] = ((task[2 * e] & 0xffffffull) << 32) | tid[e];  // form << 22 | units, then the streamed vertex (unique per list)
+// work items: every receiver's list in chunks of kTaskChunk entries (run once for the hub lists, once for the tail lists)
+__global__ void k_item_counts(int64_t n_recv, const int64_t *__restrict__ lbeg, int64_t *__restrict__ items) {
+    const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p > n_recv) return;
+    items[p] = p < n_recv ? (lbeg[p + 1] - lbeg[p] + kTaskChunk - 1) / kTaskChunk : 0;
 }
-// work items: the list of every vertex that has one (in launch order) in chunks of kTaskChunk entries
-__global__ void k_item_counts(int64_t n, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, int64_t *__restrict__ items) {
-    const int64_t pos = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (pos > n) return;
-    if (pos == n) { items[pos] = 0; return; }
-    const int32_t w = order[pos];
-    items[pos] = (tbeg[w + 1] - tbeg[w] + kTaskChunk - 1) / kTaskChunk;
-}
-__global__ void k_item_fill(int64_t n, const int32_t *__restrict__ order, const int64_t *__restrict__ tbeg, const int64_t *__restrict__ ioff,
-                            gmsx_task_item *__restrict__ items) {
-    const int64_t pos = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (pos >= n) return;
-    const int32_t w = order[pos];
-    const int64_t b = tbeg[w], e = tbeg[w + 1];
-    int64_t k = ioff[pos];
-    for (int64_t x = b; x < e; x += kTaskChunk, ++k) items[k] = gmsx_task_item{x, w, int32_t(min(int64_t(kTaskChunk), e - x))};
+__global__ void k_item_fill(int64_t n_recv, const int32_t *__restrict__ recv_v, const int32_t *__restrict__ opos, const int64_t *__restrict__ lbeg,
+                            const int64_t *__restrict__ ioff, gmsx_task_item *__restrict__ items) {
+    const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p >= n_recv) return;
+    const int32_t w = recv_v[p];
+    const int64_t b = lbeg[p], e = lbeg[p + 1];
+    int64_t k = ioff[p];
+    for (int64_t x = b; x < e; x += kTaskChunk, ++k)
+        items[k] = gmsx_task_item{uint64_t(x) | (uint64_t(min(int64_t(kTaskChunk), e - x)) << 40), w, opos[w]};
 }
 
 static int grid_for_waves(int64_t rows) {
@@ -661,11 +720,13 @@ static void free_tc(gmsx_graph *g) {
         (void)hipFree(p);
         p = nullptr;
     };
-    drop(g->tsplit); drop(g->srow); drop(g->spool); drop(g->trow); drop(g->tdesc); drop(g->task); drop(g->tbeg); drop(g->titem); drop(g->worder); drop(g->tpool);
+    drop(g->tsplit); drop(g->srow); drop(g->spool); drop(g->trow); drop(g->tdesc); drop(g->htask); drop(g->ttask); drop(g->hitem); drop(g->titem); drop(g->tunits);
+    drop(g->worder); drop(g->tpool);
     g->device_bytes -= g->tc_bytes;
     g->tc_bytes = 0;
     g->tc_ready = false;
-    g->task_entries = g->task_items = g->task_reverse = g->n_wave = g->inline_units = g->spool_units = g->tpool_units = 0;
+    g->htask_entries = g->ttask_entries = g->hitems = g->titems = g->inline_hentries = g->inline_tentries = 0;
+    g->task_reverse = g->n_wave = g->inline_units = g->spool_units = g->tpool_units = 0;
     g->stats_part = g->stats_nparts = -1;
 }
 
@@ -686,9 +747,11 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->spool);
     (void)hipFree(g->trow);
     (void)hipFree(g->tdesc);
-    (void)hipFree(g->task);
-    (void)hipFree(g->tbeg);
+    (void)hipFree(g->htask);
+    (void)hipFree(g->ttask);
+    (void)hipFree(g->hitem);
     (void)hipFree(g->titem);
+    (void)hipFree(g->tunits);
     (void)hipFree(g->worder);
     (void)hipFree(g->tpool);
     (void)hipFree(g->dplus);
@@ -1182,65 +1245,106 @@ static int build_tc_sets(gmsx_graph *g) {
         }
     }
     pt.mark("light pivot list");
-    // 6. task lists: inline entries, then every oriented edge of a heavy pivot at the endpoint whose row is the bigger one
+    // 6. task lists: per receiver a hub-entry list and a tail-entry list, each laid out class by class.  COUNT (inline chunks, then every
+    //    oriented edge of a heavy pivot at the endpoint whose row is the bigger one) -> class offsets + list offsets (scans) -> FILL.  No sort:
+    //    the order inside a class is the arrival order of atomic cursors, and nothing depends on it (a multi-GPU shard is a set of pivots).
     {
         int two_sided = 1;
         if (const char *e = std::getenv("GMSX_TC_TWO_SIDED")) two_sided = std::atoi(e) != 0;  // 0 = every heavy pivot keeps all its edges (A/B knob)
-        unsigned long long *cnt = nullptr;
-        if (int rc = dmalloc(&cnt, n + 2, nullptr)) return rc;
-        DevGuard g_cnt{cnt};
-        GMSX_HIP(hipMemsetAsync(cnt, 0, size_t(n + 2) * sizeof(unsigned long long), s));
-        if (int rc = dmalloc(&g->tbeg, n + 1, g)) return rc;
         const unsigned vb = unsigned(n / 256 + 1);
-        if (n > 0)
-            hipLaunchKernelGGL(k_inline_entries<false>, dim3(vb), dim3(256), 0, s, n, ihoff, itoff, inline_h_base, inline_t_base, cnt, g->tbeg,
-                               static_cast<unsigned long long *>(nullptr), static_cast<uint32_t *>(nullptr));
+        int32_t *opos = nullptr;
+        if (int rc = dmalloc(&opos, n + 1, nullptr)) return rc;
+        DevGuard g_opos{opos};
+        if (n > 0) hipLaunchKernelGGL(k_opos, dim3(vb), dim3(256), 0, s, n, g->order, opos);
+        // light receivers: rank ids below inline_limit that are not heavy
+        const int64_t L = g->inline_limit;
+        int64_t *lflag = nullptr, *lidx = nullptr;
+        if (int rc = dmalloc(&lflag, L + 1, nullptr)) return rc;
+        DevGuard g_lf{lflag};
+        if (int rc = dmalloc(&lidx, L + 1, nullptr)) return rc;
+        DevGuard g_li{lidx};
+        hipLaunchKernelGGL(k_light_flags, dim3(unsigned(L / 256 + 1)), dim3(256), 0, s, L, g->dplus, lflag);
+        if (int rc = exclusive_scan_i64(lflag, lidx, L + 1, s)) return rc;
+        int64_t n_light_recv = 0;
+        GMSX_HIP(hipMemcpy(&n_light_recv, lidx + L, sizeof(int64_t), hipMemcpyDeviceToHost));
+        const int64_t n_recv = n_heavy + n_light_recv;
+        int32_t *recv_v = nullptr;
+        if (int rc = dmalloc(&recv_v, n_recv + 1, nullptr)) return rc;
+        DevGuard g_rv{recv_v};
+        if (std::max<int64_t>(n_heavy, L) > 0)
+            hipLaunchKernelGGL(k_recv_vertices, dim3(unsigned(std::max<int64_t>(n_heavy, L) / 256 + 1)), dim3(256), 0, s, n_heavy, L, g->order, g->dplus, lidx, recv_v);
+        uint32_t *cnt = nullptr, *cur = nullptr;
+        if (int rc = dmalloc(&cnt, n_recv * kClasses + 1, nullptr)) return rc;
+        DevGuard g_cnt{cnt};
+        if (int rc = dmalloc(&cur, n_recv * kClasses + 1, nullptr)) return rc;
+        DevGuard g_cur{cur};
+        GMSX_HIP(hipMemsetAsync(cnt, 0, size_t(n_recv * kClasses + 1) * sizeof(uint32_t), s));
+        GMSX_HIP(hipMemsetAsync(cur, 0, size_t(n_recv * kClasses + 1) * sizeof(uint32_t), s));
+        if (int rc = dmalloc(&g->tunits, n + 1, g)) return rc;
+        GMSX_HIP(hipMemsetAsync(g->tunits, 0, size_t(n + 1) * sizeof(int32_t), s));
+        unsigned long long *totals = nullptr;  // [0] hub inline entries [1] tail inline entries [2] reversed edges
+        if (int rc = dmalloc(&totals, 4, nullptr)) return rc;
+        DevGuard g_tot{totals};
+        GMSX_HIP(hipMemsetAsync(totals, 0, 4 * sizeof(unsigned long long), s));
+        int64_t *hcnt = nullptr, *tcnt = nullptr, *hbeg = nullptr, *tbeg = nullptr;
+        if (int rc = dmalloc(&hcnt, n_recv + 1, nullptr)) return rc;
+        DevGuard g_hc{hcnt};
+        if (int rc = dmalloc(&tcnt, n_recv + 1, nullptr)) return rc;
+        DevGuard g_tc{tcnt};
+        if (int rc = dmalloc(&hbeg, n_recv + 1, nullptr)) return rc;
+        DevGuard g_hb{hbeg};
+        if (int rc = dmalloc(&tbeg, n_recv + 1, nullptr)) return rc;
+        DevGuard g_tb{tbeg};
         const int grid = grid_for_waves(n_heavy);
+        // COUNT
+        if (n > 0)
+            hipLaunchKernelGGL(k_inline_entries<false>, dim3(vb), dim3(256), 0, s, n, g->dplus, opos, lidx, n_heavy, g->inline_limit, ihoff, itoff, inline_h_base,
+                               inline_t_base, cnt, cur, hbeg, tbeg, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), totals);
         if (n_heavy > 0)
-            hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
-                               g->trow, two_sided, cnt, g->tbeg, static_cast<unsigned long long *>(nullptr), cnt + n + 1, ihoff, itoff, g->spool, g->tpool, g->inline_limit,
-                               static_cast<uint32_t *>(nullptr));
-        if (int rc = exclusive_scan_i64(reinterpret_cast<const int64_t *>(cnt), g->tbeg, n + 1, s)) return rc;
-        unsigned long long rev = 0;
-        GMSX_HIP(hipMemcpy(&g->task_entries, g->tbeg + n, sizeof(int64_t), hipMemcpyDeviceToHost));
-        GMSX_HIP(hipMemcpy(&rev, cnt + n + 1, sizeof(rev), hipMemcpyDeviceToHost));
-        g->task_reverse = int64_t(rev);
-        if (int rc = dmalloc(&g->task, 2 * g->task_entries + 2, g)) return rc;
-        uint32_t *tid = nullptr;  // per entry: the streamed vertex (chunk number for inline entries) — the tie-break of the sort below
-        if (int rc = dmalloc(&tid, g->task_entries + 1, nullptr)) return rc;
-        DevGuard g_tid{tid};
-        GMSX_HIP(hipMemsetAsync(cnt, 0, size_t(n + 2) * sizeof(unsigned long long), s));  // now the reverse cursors
-        if (n > 0) hipLaunchKernelGGL(k_inline_entries<true>, dim3(vb), dim3(256), 0, s, n, ihoff, itoff, inline_h_base, inline_t_base, cnt, g->tbeg, g->task, tid);
+            hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->trow,
+                               two_sided, opos, cnt, cur, hbeg, tbeg, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), g->tunits,
+                               totals + 2, g->spool, g->tpool, g->inline_limit);
+        pt.mark("task lists count");
+        // class offsets, list offsets
+        hipLaunchKernelGGL(k_list_sizes, dim3(unsigned(n_recv / 256 + 1)), dim3(256), 0, s, n_recv, cnt, hcnt, tcnt);
+        if (int rc = exclusive_scan_i64(hcnt, hbeg, n_recv + 1, s)) return rc;
+        if (int rc = exclusive_scan_i64(tcnt, tbeg, n_recv + 1, s)) return rc;
+        unsigned long long tot[3] = {0, 0, 0};
+        GMSX_HIP(hipMemcpy(&g->htask_entries, hbeg + n_recv, sizeof(int64_t), hipMemcpyDeviceToHost));
+        GMSX_HIP(hipMemcpy(&g->ttask_entries, tbeg + n_recv, sizeof(int64_t), hipMemcpyDeviceToHost));
+        GMSX_HIP(hipMemcpy(tot, totals, sizeof(tot), hipMemcpyDeviceToHost));
+        g->inline_hentries = int64_t(tot[0]);
+        g->inline_tentries = int64_t(tot[1]);
+        g->task_reverse = int64_t(tot[2]);
+        if (g->htask_entries >= (int64_t(1) << 40) || g->ttask_entries >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;  // 40 position bits in a work item
+        if (int rc = dmalloc(&g->htask, g->htask_entries + 2, g)) return rc;
+        if (int rc = dmalloc(&g->ttask, g->ttask_entries + 2, g)) return rc;
+        // FILL
+        if (n > 0)
+            hipLaunchKernelGGL(k_inline_entries<true>, dim3(vb), dim3(256), 0, s, n, g->dplus, opos, lidx, n_heavy, g->inline_limit, ihoff, itoff, inline_h_base,
+                               inline_t_base, cnt, cur, hbeg, tbeg, g->htask, g->ttask, totals);
         if (n_heavy > 0)
-            hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow,
-                               g->trow, two_sided, cnt, g->tbeg, g->task, cnt + n + 1, ihoff, itoff, g->spool, g->tpool, g->inline_limit, tid);
-        // Every list sorted by (form, units) of the hub stream row — the four rows a wave works on at a time are then equally long
-        // (tc.hip, scan_srows) — and, within equal keys, by the id of the streamed vertex.  The second part makes the order a TOTAL
-        // one: the reverse entries arrive through atomic cursors in any order, but every rank of a multi-GPU run must cut the same
-        // lists into the same work items (shard p of N = items p, p+N, …).  GMSX_TC_SORT_TASKS=0 skips the sort (A/B knob, one
-        // process only).
+            hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->trow,
+                               two_sided, opos, cnt, cur, hbeg, tbeg, g->htask, g->ttask, g->tunits, totals + 2, g->spool, g->tpool, g->inline_limit);
         pt.mark("task lists fill");
-        bool sort_tasks = g->task_entries > 0;
-        if (const char *e = std::getenv("GMSX_TC_SORT_TASKS")) sort_tasks = sort_tasks && std::atoi(e) != 0;
-        if (sort_tasks) {
-            struct Entry { unsigned long long x, y; };
-            unsigned long long *keys = nullptr;
-            if (int rc = dmalloc(&keys, g->task_entries, nullptr)) return rc;
-            DevGuard g_k{keys};
-            hipLaunchKernelGGL(k_task_keys, dim3(unsigned((g->task_entries + 255) / 256)), dim3(256), 0, s, g->task_entries, g->task, tid, keys);
-            if (int rc = sort_segment_pairs(keys, reinterpret_cast<Entry *>(g->task), g->task_entries, n, g->tbeg, 56, s)) return rc;
-        }
-        pt.mark("task lists sort");
+        // work items
         int64_t *icnt = nullptr, *ioff = nullptr;
-        if (int rc = dmalloc(&icnt, n + 1, nullptr)) return rc;
+        if (int rc = dmalloc(&icnt, n_recv + 1, nullptr)) return rc;
         DevGuard g_ic{icnt};
-        if (int rc = dmalloc(&ioff, n + 1, nullptr)) return rc;
+        if (int rc = dmalloc(&ioff, n_recv + 1, nullptr)) return rc;
         DevGuard g_io{ioff};
-        hipLaunchKernelGGL(k_item_counts, dim3(vb), dim3(256), 0, s, n, g->order, g->tbeg, icnt);
-        if (int rc = exclusive_scan_i64(icnt, ioff, n + 1, s)) return rc;
-        GMSX_HIP(hipMemcpy(&g->task_items, ioff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
-        if (int rc = dmalloc(&g->titem, g->task_items + 1, g)) return rc;
-        if (n > 0) hipLaunchKernelGGL(k_item_fill, dim3(vb), dim3(256), 0, s, n, g->order, g->tbeg, ioff, g->titem);
+        const unsigned rb = unsigned(n_recv / 256 + 1);
+        hipLaunchKernelGGL(k_item_counts, dim3(rb), dim3(256), 0, s, n_recv, hbeg, icnt);
+        if (int rc = exclusive_scan_i64(icnt, ioff, n_recv + 1, s)) return rc;
+        GMSX_HIP(hipMemcpy(&g->hitems, ioff + n_recv, sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (int rc = dmalloc(&g->hitem, g->hitems + 1, g)) return rc;
+        if (n_recv > 0) hipLaunchKernelGGL(k_item_fill, dim3(rb), dim3(256), 0, s, n_recv, recv_v, opos, hbeg, ioff, g->hitem);
+        hipLaunchKernelGGL(k_item_counts, dim3(rb), dim3(256), 0, s, n_recv, tbeg, icnt);
+        if (int rc = exclusive_scan_i64(icnt, ioff, n_recv + 1, s)) return rc;
+        GMSX_HIP(hipMemcpy(&g->titems, ioff + n_recv, sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (int rc = dmalloc(&g->titem, g->titems + 1, g)) return rc;
+        if (n_recv > 0) hipLaunchKernelGGL(k_item_fill, dim3(rb), dim3(256), 0, s, n_recv, recv_v, opos, tbeg, ioff, g->titem);
+        if (g->hitems >= (int64_t(1) << 31) || g->titems >= (int64_t(1) << 31)) return GMSX_ERR_DEVICE_MEM;  // one workgroup per item: grid.x
         GMSX_HIP(hipStreamSynchronize(s));
     }
     pt.mark("work items");

@@ -28,10 +28,13 @@
 //   dplus int32[n]                     true out-degree (hub + tail) per rank id
 //   order int32[n]                     rank ids by decreasing d+ (work-sorted launch order, heavy first);
 //   sorted_dplus int32[n]              dplus[order[i]] (for bin boundaries)
+// WORK ITEM of the triangle kernels: up to kTaskChunk consecutive entries of ONE pivot's hub-entry list (htask) or tail-entry list
+// (ttask).  16 bytes: bc = first entry (40 bits) | entries << 40; pivot = rank id whose row is staged in LDS; pos = the pivot's position
+// in `order` (what the shard rule of a multi-GPU run is evaluated on).
 struct gmsx_task_item {
-    int64_t begin;  // first entry (index into task / 2)
-    int32_t pivot;  // rank id whose row is staged in LDS
-    int32_t count;  // entries of this chunk (<= kTaskChunk)
+    uint64_t bc;
+    int32_t pivot;
+    int32_t pos;
 };
 struct gmsx_graph {
     int64_t n = 0, nnz = 0, m = 0;
@@ -66,18 +69,23 @@ struct gmsx_graph {
     // dependent 8-byte gathers into 0.5 GB tables (≈60 GB of 64-byte lines per pass at scale 26); hub members keep srow[v]
     // (65535 entries: L2-resident).
     unsigned long long *tdesc = nullptr;
-    // TASK LISTS of the heavy pivots (d+ >= 64; tc.hip).  |N+(u) ∩ N+(v)| of an oriented edge (u,v) can be counted with either
-    // endpoint as the pivot (its row as bitmap + tail set in LDS) and the other one streamed; the pass streams the SMALLER row
-    // (fewer 16-byte units).  So every vertex w owns a list of (srow, trow) descriptor pairs — one per edge it is the pivot of:
-    // members v of its own row whose rows are the smaller ones ("forward"), and in-neighbours u that hand their edge over because
-    // their own row is smaller than w's ("reverse", only towards heavy w) — and the heavy-pivot kernel walks work items = chunks
-    // of at most kTaskChunk entries of one list.  Light pivots hand most of theirs over as INLINE ROWS (inline_limit below).
-    unsigned long long *task = nullptr;  // [2 * task_entries]: srow / trow descriptor of the streamed row (trow 0 = no match possible)
-    int64_t task_entries = 0;
-    int64_t *tbeg = nullptr;             // [n + 1] first entry of vertex w's list
-    struct gmsx_task_item *titem = nullptr;
-    int64_t task_items = 0;
-    int64_t task_reverse = 0;            // entries handed over to the other endpoint
+    // TASK LISTS (tc.hip).  |N+(u) ∩ N+(v)| of an oriented edge (u,v) can be counted with either endpoint as the pivot (its row as bitmap +
+    // tail set in LDS) and the other one streamed; the pass streams the SMALLER row (fewer 16-byte units).  So every receiving vertex w
+    // owns two lists of 8-byte stream-row descriptors — HUB entries (rows probed against w's bitmap) and TAIL entries (rows probed against
+    // w's tail set) — one descriptor per non-empty row part of every edge it is the pivot of: members v of its own row whose rows are the
+    // smaller ones ("forward"), in-neighbours u that hand their edge over because the part of their row below w is smaller ("reverse", cut
+    // at w's id; only towards heavy w), and the 64-unit chunks of w's inline rows.  Each list is laid out CLASS BY CLASS — class = (form,
+    // ceil(log2 units)) — by counting and bucketing at build time (no sort), so the kernels run compile-time-shaped loops over runs of
+    // equally formed, similarly long rows: 4-, 8- or 16-lane groups for rows of <= 4, <= 8, more units.  The order INSIDE a class is the
+    // arrival order of atomic cursors — it differs from process to process, which is why a multi-GPU shard is a set of whole PIVOTS.
+    unsigned long long *htask = nullptr;  // hub entries of all receivers, receiver by receiver (in `order`), class by class
+    unsigned long long *ttask = nullptr;  // tail entries likewise
+    int64_t htask_entries = 0, ttask_entries = 0;
+    struct gmsx_task_item *hitem = nullptr, *titem = nullptr;  // work items over htask / ttask
+    int64_t hitems = 0, titems = 0;
+    int64_t inline_hentries = 0, inline_tentries = 0;  // of which: chunks of inline rows
+    int32_t *tunits = nullptr;           // [n] oriented edges whose entries live at this vertex (forward + reverse): the bookkeeping of gmsx_stats.units
+    int64_t task_reverse = 0;            // edges handed over to the other endpoint
     int32_t *worder = nullptr;           // the light pivots that still have far light members (in launch order): what k_tc_wave walks
     int64_t n_wave = 0;
     int32_t inline_limit = 0;            // light pivots hand their edges to members of rank id < inline_limit (and to heavy ones) as INLINE ROWS
@@ -119,7 +127,19 @@ static constexpr int kHub = 65535;         // rank ids below this live in the 16
 static constexpr int kBitmapWords = 2048;  // 65536-bit LDS bitmap over the hub id range
 static constexpr int kAccWords = 64 * 16 + 16;
 static constexpr int kFormList = 0, kFormBitset = 1, kFormDelta = 2, kFormGap12 = 3;
-static constexpr int kTaskChunk = 1024;  // entries per work item of the heavy-pivot kernel 
+static constexpr int kTaskChunk = 1024;  // entries per work item
+// entry classes: hub = form * 8 + length class (0..31), tail = 32 + (delta ? 8 : 0) + length class; length class = 0: <= 4 units, 1: <= 8,
+// 2: <= 16, 3: <= 32, 4: <= 64, 5: <= 128, 6: more
+static constexpr int kHubClasses = 32, kTailClasses = 16, kClasses = kHubClasses + kTailClasses;
+__host__ __device__ inline int length_class(uint32_t units) { return units <= 4 ? 0 : units <= 8 ? 1 : units <= 16 ? 2 : units <= 32 ? 3 : units <= 64 ? 4 : units <= 128 ? 5 : 6; }
+__host__ __device__ inline int hub_class(unsigned long long d) { return int((uint32_t(d) >> 22) & 3u) * 8 + length_class(uint32_t(d) & 0x3fffffu); }
+__host__ __device__ inline int tail_class(unsigned long long d) { return kHubClasses + (((uint32_t(d) >> 22) & 3u) == 2u ? 8 : 0) + length_class(uint32_t(d) & 0x3fffffu); }
+// which rank of a multi-GPU run owns the pivot at position `pos` of `order`: stripes of nparts positions, every other one reversed (the
+// order is by decreasing d+, so plain striding would always hand the costlier pivot of a stripe to the lower rank)
+__host__ __device__ inline int shard_of(int64_t pos, int nparts) {
+    const int j = int(pos % nparts);
+    return ((pos / nparts) & 1) ? nparts - 1 - j : j;
+}
 static constexpr int kHeavy = 64;        // d+ from which a pivot runs on the workgroup kernel
 static constexpr int kDeltaIds = 14;  // ids per full 16-byte delta unit  // size of gmsx_graph::acc in u64
 

@@ -33,6 +33,7 @@
 #include "device_graph.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -344,53 +345,145 @@ __device__ __forceinline__ uint32_t scan_trows_probe(Probe probe, const uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------
-// Heavy pivots (d+ >= 64): one workgroup per WORK ITEM = up to kTaskChunk entries of one pivot's task list (device_graph.hpp).  The
-// 256 threads = 4 waves stage the pivot's row — hub part as the 65536-bit bitmap, tail part as filter + hash set, tiled if longer than
-// half the table — and wave w streams the rows of entries 64w … 64w+63 of every 256: their hub stream rows against the bitmap, then
-// (pivots with a tail part) their tail stream rows against the set.  An entry is either a member of the pivot's own row or an
-// in-neighbour that handed the edge over because its row is the smaller one: the kernel cannot tell and need not.
-// LDS: 8 KB bitmap + 4 KB filter + 2^kBlockLog x 4 B table.
+// Work items (device_graph.hpp): one workgroup per item = up to kTaskChunk consecutive entries of ONE pivot's hub-entry list (k_tc_block:
+// the pivot's hub part staged as the 65536-bit bitmap, 8 KB) or tail-entry list (k_tc_tail: the pivot's tail part as filter + hash set,
+// tiled if longer than half the table).  An entry is one 8-byte stream-row descriptor — a member's row, the cut row of an in-neighbour
+// that handed its edge over, a 64-unit chunk of an inline row: the kernels cannot tell and need not.
+// The lists are laid out CLASS BY CLASS at build time (class = form x ceil(log2 units)), so an item is a handful of runs of equally
+// formed, similarly long rows.  The workgroup copies the item's descriptors to LDS, marks where each class begins and ends, and then runs
+// one COMPILE-TIME-SHAPED loop per class: groups of W = 4 / 8 / 16 lanes (rows of <= 4 / <= 8 / more units), group g taking entries
+// g, g + 256/W, … with the next descriptor already loaded while the current row is scanned.  No form ballots, no readlane hand-outs, no
+// mixed rows in a wave: what was ~30 VALU instructions per four rows is one LDS read and an address computation per row.
 // ---------------------------------------------------------------------------------------------
+template <int FORM>
+__device__ __forceinline__ uint32_t hub_unit_hits(const uint32_t *bm, uint4 p, int j) {
+    if (FORM == kFormBitset) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(bm + 4 * j);
+        return uint32_t(__popc(p.x & q.x) + __popc(p.y & q.y) + __popc(p.z & q.z) + __popc(p.w & q.w));
+    }
+    if (FORM == kFormDelta) return delta_unit_hits(bm, p);
+    if (FORM == kFormGap12) return gap12_unit_hits(bm, p);
+    return hub_hits8(bm, u4u{p.x, p.y, p.z, p.w});
+}
+template <int FORM>
+__device__ __forceinline__ uint32_t tail_unit_hits_f(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, uint4 p) {
+    return FORM == kFormDelta ? tail_delta_unit_hits(flt, tbl, mask, shift, p) : tail_unit_hits(flt, tbl, mask, shift, p);
+}
+// entries [lo, hi) of the item (descriptors in LDS), all of one class: HIT(p, j) = hits of unit j of a row
+template <int W, class Hit>
+__device__ __forceinline__ uint32_t scan_class(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, int lo, int hi, int tid, Hit hit) {
+    constexpr int G = 256 / W;
+    const int g = tid / W, sub = tid % W;
+    uint32_t cnt = 0;
+    int e = lo + g;
+    unsigned long long d = e < hi ? sdesc[e] : 0ull;
+    while (e < hi) {  // the groups of a wave differ by at most one trip
+        const int en = e + G;
+        const unsigned long long dn = en < hi ? sdesc[en] : 0ull;
+        const uint4 *row = reinterpret_cast<const uint4 *>(pool) + (d >> 24);
+        const int units = int(uint32_t(d) & 0x3fffffu);
+        if (W < 16) {  // the class guarantees units <= W: one load per lane, no loop
+            if (sub < units) cnt += hit(row[sub], sub);
+        } else {
+            int j = sub;
+            for (; j + 16 < units; j += 32) {
+                const uint4 p = row[j], q = row[j + 16];
+                cnt += hit(p, j);
+                cnt += hit(q, j + 16);
+            }
+            if (j < units) cnt += hit(row[j], j);
+        }
+        e = en;
+        d = dn;
+    }
+    return cnt;
+}
+// copies the item's descriptors to LDS and records, per class, where its run begins and ends (the list is class-sorted: one run each)
+template <int NC, class ClassOf>
+__device__ __forceinline__ void stage_item(const unsigned long long *__restrict__ ent, int ne, int tid, unsigned long long *sdesc, unsigned short *cbeg,
+                                           unsigned short *cend, ClassOf class_of) {
+    if (tid < NC) cbeg[tid] = cend[tid] = 0;
+    for (int i = tid; i < ne; i += 256) sdesc[i] = ent[i];
+    __syncthreads();
+    for (int i = tid; i < ne; i += 256) {
+        const int c = class_of(sdesc[i]);
+        if (i == 0 || class_of(sdesc[i - 1]) != c) cbeg[c] = (unsigned short)i;
+        if (i == ne - 1 || class_of(sdesc[i + 1]) != c) cend[c] = (unsigned short)(i + 1);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void block_add(unsigned long long cnt, unsigned long long *red, int lane, int wave, int tid, unsigned long long *__restrict__ acc) {
+    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
+    if (lane == 0) red[wave] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long t = red[0] + red[1] + red[2] + red[3];
+        if (t) atomicAdd(&acc[(blockIdx.x & (kAccSlots - 1)) * kAccStride], t);
+    }
+}
+
 static constexpr int kBlockLog = 10;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                  const uint32_t *__restrict__ spool, const uint32_t *__restrict__ tpool,
-                                                  const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
-                                                  const unsigned long long *__restrict__ task, const gmsx_task_item *__restrict__ items,
-                                                  int64_t n_items, int nparts, int part, unsigned long long *__restrict__ acc) {
-    __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords];
-    __shared__ __attribute__((aligned(16))) int32_t tbl[1 << kBlockLog];
-    __shared__ uint32_t flt[kFilterWords];
+                                                  const uint32_t *__restrict__ spool, const unsigned long long *__restrict__ htask,
+                                                  const gmsx_task_item *__restrict__ items, int64_t n_items, int nparts, int part,
+                                                  unsigned long long *__restrict__ acc) {
+    __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords + 128];  // + slack: the delta probes of unused slots read up to 104 words past the bitmap
+    __shared__ unsigned long long sdesc[kTaskChunk];
+    __shared__ unsigned short cbeg[kHubClasses], cend[kHubClasses];
     __shared__ unsigned long long red[4];
-    constexpr int SIZE = 1 << kBlockLog, SHIFT = 32 - kBlockLog, TILE = SIZE / 2;
-    constexpr uint32_t MASK = SIZE - 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t pos = int64_t(blockIdx.x) * nparts + part;
-    if (pos >= n_items) return;  // uniform per block
-    const gmsx_task_item it = items[pos];
+    const gmsx_task_item it = items[blockIdx.x];
+    if (nparts > 1 && shard_of(it.pos, nparts) != part) return;  // uniform per block
     const int32_t u = it.pivot;
-    const int64_t hb = hoff[u], tb = toff[u];
-    const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
-    const int ne = it.count;
-    const unsigned long long *__restrict__ ent = task + 2 * it.begin;
-
-    for (int i = tid; i < kBitmapWords; i += 256) bm[i] = 0;
-    __syncthreads();
+    const int64_t hb = hoff[u];
+    const int hl = int(hoff[u + 1] - hb);
+    const int ne = int(it.bc >> 40);
+    for (int i = tid; i < kBitmapWords + 128; i += 256) bm[i] = 0;
+    stage_item<kHubClasses>(htask + (it.bc & 0xffffffffffull), ne, tid, sdesc, cbeg, cend, [](unsigned long long d) { return hub_class(d); });
     for (int i = tid; i < hl; i += 256) {
         const uint32_t id = hadj[hb + i];
         if (id != 0xFFFFu) atomicOr(&bm[id >> 5], 1u << (id & 31u));
     }
     __syncthreads();
+    uint32_t cnt = 0;
+    auto run = [&](auto form_tag, int c0) {  // the seven length classes of one form
+        constexpr int FORM = decltype(form_tag)::value;
+        auto hit = [](uint4 p, int j) { return hub_unit_hits<FORM>(bm, p, j); };
+        if (cend[c0] > cbeg[c0]) cnt += scan_class<4>(sdesc, spool, cbeg[c0], cend[c0], tid, hit);
+        if (cend[c0 + 1] > cbeg[c0 + 1]) cnt += scan_class<8>(sdesc, spool, cbeg[c0 + 1], cend[c0 + 1], tid, hit);
+#pragma unroll 1
+        for (int c = c0 + 2; c < c0 + 7; ++c)
+            if (cend[c] > cbeg[c]) cnt += scan_class<16>(sdesc, spool, cbeg[c], cend[c], tid, hit);
+    };
+    run(std::integral_constant<int, kFormList>{}, kFormList * 8);
+    run(std::integral_constant<int, kFormBitset>{}, kFormBitset * 8);
+    run(std::integral_constant<int, kFormDelta>{}, kFormDelta * 8);
+    run(std::integral_constant<int, kFormGap12>{}, kFormGap12 * 8);
+    block_add(cnt, red, lane, wave, tid, acc);
+}
 
-    unsigned long long cnt = 0;
-    // hub stream rows of the entries against the bitmap
-    for (int base = 0; base < ne; base += 256) {
-        const int idx = base + lane * 4 + wave;  // interleaved: the four waves see the same mix of rows
-        const unsigned long long desc = idx < ne ? ent[2 * idx] : 0ull;
-        cnt += scan_srows(bm, spool, desc, lane);
-    }
-    // tail stream rows against the hash set of the pivot's tail part
-    for (int t0 = 0; t0 < tl; t0 += TILE) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_tail(const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                 const uint32_t *__restrict__ tpool, const unsigned long long *__restrict__ ttask,
+                                                 const gmsx_task_item *__restrict__ items, int64_t n_items, int nparts, int part,
+                                                 unsigned long long *__restrict__ acc) {
+    __shared__ __attribute__((aligned(16))) int32_t tbl[1 << kBlockLog];
+    __shared__ uint32_t flt[kFilterWords];
+    __shared__ unsigned long long sdesc[kTaskChunk];
+    __shared__ unsigned short cbeg[kTailClasses], cend[kTailClasses];
+    __shared__ unsigned long long red[4];
+    constexpr int SIZE = 1 << kBlockLog, SHIFT = 32 - kBlockLog, TILE = SIZE / 2;
+    constexpr uint32_t MASK = SIZE - 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const gmsx_task_item it = items[blockIdx.x];
+    if (nparts > 1 && shard_of(it.pos, nparts) != part) return;  // uniform per block
+    const int32_t u = it.pivot;
+    const int64_t tb = toff[u];
+    const int tl = int(toff[u + 1] - tb);
+    const int ne = int(it.bc >> 40);
+    stage_item<kTailClasses>(ttask + (it.bc & 0xffffffffffull), ne, tid, sdesc, cbeg, cend, [](unsigned long long d) { return tail_class(d) - kHubClasses; });
+    uint32_t cnt = 0;
+    for (int t0 = 0; t0 < tl; t0 += TILE) {  // the pivot's tail part, a tile at a time
         const int tn = min(TILE, tl - t0);
         __syncthreads();
         for (int i = tid; i < SIZE; i += 256) tbl[i] = -1;
@@ -402,19 +495,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             atomicOr(&flt[(uint32_t(t) >> 5) & (kFilterWords - 1)], 1u << (uint32_t(t) & 31u));
         }
         __syncthreads();
-        for (int base = 0; base < ne; base += 256) {
-            const int idx = base + lane * 4 + wave;
-            const unsigned long long desc = idx < ne ? ent[2 * idx + 1] : 0ull;
-            cnt += scan_trows(flt, tbl, MASK, SHIFT, tpool, desc, 64, lane);
-        }
+        auto run = [&](auto form_tag, int c0) {
+            constexpr int FORM = decltype(form_tag)::value;
+            auto hit = [](uint4 p, int) { return tail_unit_hits_f<FORM>(flt, tbl, MASK, SHIFT, p); };
+            if (cend[c0] > cbeg[c0]) cnt += scan_class<4>(sdesc, tpool, cbeg[c0], cend[c0], tid, hit);
+            if (cend[c0 + 1] > cbeg[c0 + 1]) cnt += scan_class<8>(sdesc, tpool, cbeg[c0 + 1], cend[c0 + 1], tid, hit);
+#pragma unroll 1
+            for (int c = c0 + 2; c < c0 + 7; ++c)
+                if (cend[c] > cbeg[c]) cnt += scan_class<16>(sdesc, tpool, cbeg[c], cend[c], tid, hit);
+        };
+        run(std::integral_constant<int, kFormList>{}, 0);
+        run(std::integral_constant<int, kFormDelta>{}, 8);
     }
-    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
-    if (lane == 0) red[wave] = cnt;
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long t = red[0] + red[1] + red[2] + red[3];
-        if (t) atomicAdd(&acc[(blockIdx.x & (kAccSlots - 1)) * kAccStride], t);
-    }
+    block_add(cnt, red, lane, wave, tid, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -548,15 +641,17 @@ __global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hof
 // read, byte for byte, assuming no on-chip reuse:
 //   light pivot u (2 <= d+ < 64; k_tc_stats, wave per pivot position): its hub part if it has tail members; per far light member
 //       (rank id >= inline_limit, d+ < 64) the member id, its two descriptors and the stream rows they describe;
-//   work item (k_tc_item_stats, wave per item): the pivot's containers once; per entry 16 bytes of descriptors and the hub + tail
-//       stream rows they describe (whole 16-byte units) — members' rows, handed-over rows and inline rows alike.
-// out[0] = oriented edges counted by the shard (every edge of a light or idle pivot at the pivot, every edge of a heavy pivot where its
-// entry lives); out[1] = id slots probed (per unit: 8 list, 14 byte-delta, 4 bitset words; 4 / 6 tail ids).
+//   work item (k_tc_item_stats, wave per item): the pivot's container (hub part for a hub item, tail part for a tail item) once; per
+//       entry 8 bytes of descriptor and the stream row it describes (whole 16-byte units) — members' rows, cut rows and inline chunks alike.
+// out[0] = oriented edges counted by the shard: every edge of a light or idle pivot at the pivot, the edges a heavy pivot handed to its
+// first members over inline at the pivot, every other edge of a heavy pivot where its entries live (tunits, written by the build);
+// out[1] = id slots probed (per unit: 8 list, 14 byte-delta, 10 gap-12, 4 bitset words; 4 / 6 tail ids).  A shard = the pivots at the
+// positions of `order` that shard_of() gives it.
 __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
                                                   const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
-                                                  int32_t inline_limit, int64_t first, int64_t end, int nparts, int part,
+                                                  const int32_t *__restrict__ tunits, int32_t inline_limit, int64_t end, int nparts, int part,
                                                   unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -566,12 +661,12 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
         const unsigned long long n = d & 0x3fffffull, f = (d >> 22) & 3ull;
         return n * (tail ? (f == kFormDelta ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : f == kFormGap12 ? 10ull : 4ull));
     };
-    for (int64_t q = wave0;; q += nwaves) {
-        const int64_t pos = first + q * nparts + part;
-        if (pos >= end) break;
+    for (int64_t pos = wave0; pos < end; pos += nwaves) {
+        if (nparts > 1 && shard_of(pos, nparts) != part) continue;
         const int32_t u = order[pos];
         const int du = dplus[u];
-        if (du >= kHeavy) {  // counted per work item, except the edges to its first members that went inline (no entry)
+        if (lane == 0) units += (unsigned long long)tunits[u];  // forward + reverse edges whose entries live here
+        if (du >= kHeavy) {  // … and the edges to its first members that went inline (no entry anywhere)
             const int hl = min(int(hoff[u + 1] - hoff[u]), 64), tl = min(int(toff[u + 1] - toff[u]), 64 - hl);
             int32_t v = -1;
             if (lane < hl) {
@@ -606,39 +701,35 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
         if (bytes) atomicAdd(&out[2], bytes);
     }
 }
-__global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict__ hoff, const int64_t *__restrict__ toff,
-                                                       const unsigned long long *__restrict__ task, const gmsx_task_item *__restrict__ items,
-                                                       int64_t n_items, int nparts, int part, unsigned long long *__restrict__ out) {
+// one list of work items (hub or tail)
+__global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict__ coff, int bytes_per_id, int tail, const unsigned long long *__restrict__ task,
+                                                       const gmsx_task_item *__restrict__ items, int64_t n_items, int nparts, int part,
+                                                       unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
-    unsigned long long units = 0, probes = 0, bytes = 0;
-    auto slots = [](unsigned long long d, bool tail) -> unsigned long long {
+    unsigned long long probes = 0, bytes = 0;
+    auto slots = [tail](unsigned long long d) -> unsigned long long {
         const unsigned long long n = d & 0x3fffffull, f = (d >> 22) & 3ull;
         return n * (tail ? (f == kFormDelta ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : f == kFormGap12 ? 10ull : 4ull));
     };
-    for (int64_t q = wave0;; q += nwaves) {
-        const int64_t pos = q * nparts + part;
-        if (pos >= n_items) break;
-        const gmsx_task_item it = items[pos];
-        const int ne = it.count;
-        if (lane == 0) {
-            bytes += 2ull * (unsigned long long)(hoff[it.pivot + 1] - hoff[it.pivot]) + 4ull * (unsigned long long)(toff[it.pivot + 1] - toff[it.pivot]);
-        }
+    for (int64_t q = wave0; q < n_items; q += nwaves) {
+        const gmsx_task_item it = items[q];
+        if (nparts > 1 && shard_of(it.pos, nparts) != part) continue;
+        const int ne = int(it.bc >> 40);
+        const int64_t b = int64_t(it.bc & 0xffffffffffull);
+        if (lane == 0) bytes += (unsigned long long)bytes_per_id * (unsigned long long)(coff[it.pivot + 1] - coff[it.pivot]);
         for (int i = lane; i < ne; i += 64) {
-            const unsigned long long d = task[2 * (it.begin + i)], t = task[2 * (it.begin + i) + 1];
-            bytes += 16ull + 16ull * ((d & 0x3fffffull) + (t & 0x3fffffull));
-            probes += slots(d, false) + slots(t, true);
-            if (!((t >> 22) & 1ull)) ++units;  // bit 22 marks an inline entry: its edges are counted at their light pivots
+            const unsigned long long d = task[b + i];
+            bytes += 8ull + 16ull * (d & 0x3fffffull);
+            probes += slots(d);
         }
     }
     for (int s = 32; s > 0; s >>= 1) {
-        units += __shfl_down(units, s);
         probes += __shfl_down(probes, s);
         bytes += __shfl_down(bytes, s);
     }
     if (lane == 0) {
-        if (units) atomicAdd(&out[0], units);
         if (probes) atomicAdd(&out[1], probes);
         if (bytes) atomicAdd(&out[2], bytes);
     }
@@ -647,8 +738,8 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
 // Diagnostics (gmsx_tc_stream_breakdown): the algorithmic stream bytes of one pass (= gmsx_stats.stream_bytes) by what is read.
 //   out[0..2]  hub stream rows named by the work items' entries, by form (16-bit list, bitset, byte-delta)
 //   out[3..4]  tail stream rows named by the entries (32-bit list, 16-bit delta)
-//   out[5]     the entries themselves (16 bytes each)         out[6]  the pivots' own containers, once per work item
-//   out[7]     of out[0] + out[3]: inline rows (ids handed over by light pivots)
+//   out[5]     the entries themselves (8 bytes each)          out[6]  the pivots' own containers (hub part per hub item, tail part per tail item)
+//   out[7]     of out[0] + out[3]: inline rows (ids handed over by light pivots; filled in by the host from the build's figures)
 //   out[8..9]  light pivots: hub / tail stream rows of their far light members (k_tc_wave)
 //   out[10]    light pivots: their own hub parts + member ids + descriptors (k_tc_wave)
 //   out[11..14] counts: entries, inline entries, work items, far light members streamed by k_tc_wave
@@ -656,28 +747,32 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
 __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict__ hoff, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                       const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
                                                       const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
-                                                      const unsigned long long *__restrict__ task, const gmsx_task_item *__restrict__ items,
-                                                      int64_t n_items, int32_t inline_limit, int64_t first_light, int64_t end_light,
+                                                      const unsigned long long *__restrict__ htask, const gmsx_task_item *__restrict__ hitem, int64_t hitems,
+                                                      const unsigned long long *__restrict__ ttask, const gmsx_task_item *__restrict__ titem, int64_t titems,
+                                                      int32_t inline_limit, int64_t first_light, int64_t end_light,
                                                       unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
     unsigned long long c[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int64_t q = wave0; q < n_items; q += nwaves) {
-        const gmsx_task_item it = items[q];
+    for (int64_t q = wave0; q < hitems + titems; q += nwaves) {
+        const bool tail = q >= hitems;
+        const gmsx_task_item it = tail ? titem[q - hitems] : hitem[q];
+        const unsigned long long *task = tail ? ttask : htask;
+        const int ne = int(it.bc >> 40);
+        const int64_t b0 = int64_t(it.bc & 0xffffffffffull);
         if (lane == 0) {
-            c[6] += 2ull * (unsigned long long)(hoff[it.pivot + 1] - hoff[it.pivot]) + 4ull * (unsigned long long)(toff[it.pivot + 1] - toff[it.pivot]);
-            c[11] += (unsigned long long)it.count;
+            c[6] += tail ? 4ull * (unsigned long long)(toff[it.pivot + 1] - toff[it.pivot]) : 2ull * (unsigned long long)(hoff[it.pivot + 1] - hoff[it.pivot]);
+            c[11] += (unsigned long long)ne;
             c[13] += 1;
         }
-        for (int i = lane; i < it.count; i += 64) {
-            const unsigned long long d = task[2 * (it.begin + i)], t = task[2 * (it.begin + i) + 1];
-            const unsigned long long db = 16ull * (d & 0x3fffffull), tb = 16ull * (t & 0x3fffffull);
+        for (int i = lane; i < ne; i += 64) {
+            const unsigned long long d = task[b0 + i];
+            const unsigned long long db = 16ull * (d & 0x3fffffull);
             const int fd = int((d >> 22) & 3);
-            c[fd == kFormList ? 0 : fd == kFormBitset ? 1 : 2] += db;
-            c[((t >> 22) & 3) == kFormDelta ? 4 : 3] += tb;
-            c[5] += 16;
-            if ((t >> 22) & 1ull) { c[7] += db + tb; c[12] += 1; }
+            if (tail) c[fd == kFormDelta ? 4 : 3] += db;
+            else c[fd == kFormList ? 0 : fd == kFormBitset ? 1 : 2] += db;
+            c[5] += 8;
         }
     }
     for (int64_t pos = first_light + wave0; pos < end_light; pos += nwaves) {
@@ -715,8 +810,9 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
                                                      const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                      const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
                                                      const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
-                                                     const unsigned long long *__restrict__ task, const gmsx_task_item *__restrict__ items,
-                                                     int64_t n_items, int64_t end, unsigned long long *__restrict__ out) {
+                                                     const unsigned long long *__restrict__ htask, const gmsx_task_item *__restrict__ hitem, int64_t hitems,
+                                                     const unsigned long long *__restrict__ ttask, const gmsx_task_item *__restrict__ titem, int64_t titems,
+                                                     int64_t end, unsigned long long *__restrict__ out) {
     __shared__ unsigned long long h[256];
     for (int i = threadIdx.x; i < 256; i += 256) h[i] = 0;
     __syncthreads();
@@ -729,18 +825,21 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
         atomicAdd(&h[b], 1ull);
         atomicAdd(&h[b + 1], units);
     };
-    for (int64_t q = wave0; q < n_items; q += nwaves) {
-        const gmsx_task_item it = items[q];
+    for (int64_t q = wave0; q < hitems + titems; q += nwaves) {
+        const bool tail = q >= hitems;
+        const gmsx_task_item it = tail ? titem[q - hitems] : hitem[q];
+        const unsigned long long *task = tail ? ttask : htask;
+        const int ne = int(it.bc >> 40);
+        const int64_t b0 = int64_t(it.bc & 0xffffffffffull);
         if (lane == 0) {
-            atomicAdd(&h[240], (unsigned long long)it.count);
+            atomicAdd(&h[240], (unsigned long long)ne);
             atomicAdd(&h[242], 1ull);
-            atomicAdd(&h[243], 2ull * (unsigned long long)(hoff[it.pivot + 1] - hoff[it.pivot]) + 4ull * (unsigned long long)(toff[it.pivot + 1] - toff[it.pivot]));
+            atomicAdd(&h[243], tail ? 4ull * (unsigned long long)(toff[it.pivot + 1] - toff[it.pivot]) : 2ull * (unsigned long long)(hoff[it.pivot + 1] - hoff[it.pivot]));
         }
-        for (int i = lane; i < it.count; i += 64) {
-            const unsigned long long d = task[2 * (it.begin + i)], t = task[2 * (it.begin + i) + 1];
-            add(min(int((d >> 22) & 3), 2), d & 0x3fffffull);  // 12-bit-gap rows are counted with the byte-delta ones
-            add(((t >> 22) & 3) == kFormDelta ? 4 : 3, t & 0x3fffffull);
-            if ((t >> 22) & 1ull) atomicAdd(&h[241], 1ull);
+        for (int i = lane; i < ne; i += 64) {
+            const unsigned long long d = task[b0 + i];
+            if (tail) add(((d >> 22) & 3) == kFormDelta ? 4 : 3, d & 0x3fffffull);
+            else add(min(int((d >> 22) & 3), 2), d & 0x3fffffull);  // 12-bit-gap rows are counted with the byte-delta ones
         }
     }
     for (int64_t pos = wave0; pos < end; pos += nwaves) {
@@ -782,9 +881,6 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     if (int rc = ensure_tc(g)) return rc;  // first call on a graph uploaded without GMSX_UPLOAD_FOR_TC: builds the task lists (untimed)
     Ctx &c = ctx();
     hipStream_t s = c.stream;
-    int64_t n_block = 0, n_work = 0;  // pivots with d+ >= 64, d+ >= 2
-    if (int rc = count_dplus_ge(g, kHeavy, &n_block)) return rc;
-    if (int rc = count_dplus_ge(g, 2, &n_work)) return rc;
     unsigned long long *acc = g->acc;  // persistent per-graph accumulators: no allocation on the call path
     static_assert(kAccSlots * kAccStride + 3 <= kAccWords, "gmsx_graph::acc too small");
     GMSX_HIP(hipEventRecord(c.ev[0], s));
@@ -794,68 +890,79 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     int launches = 0;
     const int cus = c.compute_units > 0 ? c.compute_units : 256;
     const int64_t cap_blocks = int64_t(cus) * 16;
-    const int64_t cnt_heavy = part_count(0, g->task_items, nparts, part), cnt_light = part_count(0, g->n_wave, nparts, part);
-    // CO-SCHEDULING.  The work-item kernel is bound by HBM bandwidth and VALU issue, the light-pivot kernel (short rows behind
-    // dependent loads) by memory latency: back to back each leaves what the other needs idle.  So the light kernel goes to a side
-    // stream FIRST, as a persistent grid of a few workgroups per CU, and the work items fill the remaining wave slots and LDS of
-    // every CU.  GMSX_TC_OVERLAP=0 restores the serial order (full-width light grid), 2 forces co-scheduling on small graphs.
+    const int64_t cnt_light = part_count(0, g->n_wave, nparts, part);
+    // CO-SCHEDULING.  The hub-item kernel is bound by HBM bandwidth and VALU issue, the tail-item kernel streams short rows, the light-pivot
+    // kernel (short rows behind dependent loads) is bound by memory latency: back to back each leaves what the others need idle and pays
+    // its own drain.  So the light kernel goes to a side stream FIRST, as a persistent grid of a few workgroups per CU, the tail items to
+    // a second side stream, and the hub items fill the remaining wave slots and LDS of every CU.  GMSX_TC_OVERLAP=0 restores the serial
+    // order (full-width light grid), 2 forces co-scheduling of the light kernel on small graphs.
     const int overlap = [] { const char *e = std::getenv("GMSX_TC_OVERLAP"); return e ? std::atoi(e) : 1; }();
     const bool large = g->inline_limit > g->dense_limit;  // n >= 2^24: inline limit beyond the hub range
     const int wave_wgs = [large] { const char *e = std::getenv("GMSX_TC_WAVE_WGS"); return e ? std::max(1, std::atoi(e)) : (large ? 1 : 2); }();
-    // measured (MI355X, tools/tc_overlap_s24.py): scale 26 serial 86.4 ms, co-scheduled 84.6 (2 workgroups per CU) / 82.9 (1); scale 24
-    // 15.05 / 14.45 (2) / erratic (1); scale 22 3.56 serial, 4.45 co-scheduled.  So: from 2^23 vertices on.
-    const bool co = overlap && cnt_heavy > 0 && cnt_light > 0 && c.side[0] && c.side[1] && (overlap > 1 || g->n >= (int64_t(1) << 23));
-    hipStream_t s_wave = co ? c.side[1] : s;
+    // measured (MI355X, round 2): scale 26 serial 86.4 ms, co-scheduled 84.6 (2 workgroups per CU) / 82.9 (1); scale 24 15.05 / 14.45 (2) /
+    // erratic (1); scale 22 3.56 serial, 4.45 co-scheduled.  So the light kernel moves aside from 2^23 vertices on.
+    const bool sides = overlap && c.side[0] && c.side[1];
+    const bool co_wave = sides && g->hitems > 0 && cnt_light > 0 && (overlap > 1 || g->n >= (int64_t(1) << 23));
+    const bool co_tail = sides && g->hitems > 0 && g->titems > 0;
+    hipStream_t s_wave = co_wave ? c.side[1] : s, s_tail = co_tail ? c.side[0] : s;
     struct Join {  // joins the side streams on every way out once they were forked (error returns included)
         Ctx &c;
         hipStream_t s;
-        bool armed = false;
+        bool armed[2] = {false, false};
         ~Join() {
-            if (!armed) return;
-            if (hipEventRecord(c.ev_join[1], c.side[1]) == hipSuccess) (void)hipStreamWaitEvent(s, c.ev_join[1], 0);
+            for (int i = 0; i < 2; ++i)
+                if (armed[i] && hipEventRecord(c.ev_join[i], c.side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, c.ev_join[i], 0);
         }
     } join{c, s};
-    if (co) {
-        GMSX_HIP(hipEventRecord(c.ev_fork, s));
+    if (co_wave || co_tail) GMSX_HIP(hipEventRecord(c.ev_fork, s));
+    if (co_tail) {
+        GMSX_HIP(hipStreamWaitEvent(c.side[0], c.ev_fork, 0));
+        join.armed[0] = true;
+    }
+    if (co_wave) {
         GMSX_HIP(hipStreamWaitEvent(c.side[1], c.ev_fork, 0));
-        join.armed = true;
+        join.armed[1] = true;
     }
     auto launch_light = [&]() {
         if (cnt_light <= 0) return;
         const int64_t want = (cnt_light + 3) / 4;
-        const int64_t b_wave = std::min<int64_t>(want, co ? int64_t(cus) * wave_wgs : cap_blocks);
+        const int64_t b_wave = std::min<int64_t>(want, co_wave ? int64_t(cus) * wave_wgs : cap_blocks);
         hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(b_wave)), dim3(256), 0, s_wave, g->hoff, g->hadj, g->spool, g->tpool, g->tdesc, g->toff, g->tadj,
                            g->tsplit, g->worder, int64_t(0), g->n_wave, nparts, part, acc);
         ++launches;
     };
-    if (co) launch_light();
-    if (cnt_heavy > 0) {
-        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(cnt_heavy)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->tpool, g->toff, g->tadj, g->task, g->titem,
-                           g->task_items, nparts, part, acc);
+    if (co_wave) launch_light();
+    if (g->hitems > 0) {
+        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(g->hitems)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->htask, g->hitem, g->hitems, nparts, part, acc);
         ++launches;
     }
-    if (!co) launch_light();
-    if (co) {
-        join.armed = false;
-        GMSX_HIP(hipEventRecord(c.ev_join[1], c.side[1]));
-        GMSX_HIP(hipStreamWaitEvent(s, c.ev_join[1], 0));
+    if (g->titems > 0) {
+        hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(g->titems)), dim3(256), 0, s_tail, g->toff, g->tadj, g->tpool, g->ttask, g->titem, g->titems, nparts, part, acc);
+        ++launches;
     }
+    if (!co_wave) launch_light();
+    for (int i = 0; i < 2; ++i)
+        if (join.armed[i]) {
+            join.armed[i] = false;
+            GMSX_HIP(hipEventRecord(c.ev_join[i], c.side[i]));
+            GMSX_HIP(hipStreamWaitEvent(s, c.ev_join[i], 0));
+        }
     GMSX_HIP(hipEventRecord(c.ev[2], s));
     GMSX_HIP(hipGetLastError());
 
     const bool need_stats = st && !(g->stats_part == part && g->stats_nparts == nparts);
     if (need_stats) {  // untimed bookkeeping, once per shard (the graph is immutable)
-        const int64_t cnt = part_count(0, g->n, nparts, part);
-        if (cnt > 0) {
-            const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, cap_blocks);
-            hipLaunchKernelGGL(k_tc_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus,
-                               g->order, g->srow, g->trow, g->inline_limit, int64_t(0), g->n, nparts, part, acc + kAccSlots * kAccStride);
+        if (g->n > 0) {
+            const int64_t blocks = std::min<int64_t>((g->n + 3) / 4, cap_blocks);
+            hipLaunchKernelGGL(k_tc_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow,
+                               g->tunits, g->inline_limit, g->n, nparts, part, acc + kAccSlots * kAccStride);
         }
-        if (cnt_heavy > 0) {
-            const int64_t blocks = std::min<int64_t>((cnt_heavy + 3) / 4, cap_blocks);
-            hipLaunchKernelGGL(k_tc_item_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->toff, g->task, g->titem, g->task_items, nparts, part,
-                               acc + kAccSlots * kAccStride);
-        }
+        if (g->hitems > 0)
+            hipLaunchKernelGGL(k_tc_item_stats, dim3(unsigned(std::min<int64_t>((g->hitems + 3) / 4, cap_blocks))), dim3(256), 0, s, g->hoff, 2, 0, g->htask, g->hitem,
+                               g->hitems, nparts, part, acc + kAccSlots * kAccStride);
+        if (g->titems > 0)
+            hipLaunchKernelGGL(k_tc_item_stats, dim3(unsigned(std::min<int64_t>((g->titems + 3) / 4, cap_blocks))), dim3(256), 0, s, g->toff, 4, 1, g->ttask, g->titem,
+                               g->titems, nparts, part, acc + kAccSlots * kAccStride);
     }
     unsigned long long host[kAccSlots * kAccStride + 3];
     GMSX_HIP(hipMemcpyAsync(host, acc, sizeof(host), hipMemcpyDeviceToHost, s));
@@ -909,11 +1016,13 @@ int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21) {
     struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g1{acc};
     GMSX_HIP(hipMemsetAsync(acc, 0, 21 * 8, s));
     const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
-    hipLaunchKernelGGL(k_tc_breakdown, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->hoff, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow, g->task,
-                       g->titem, g->task_items, g->inline_limit, n_block, n_work, acc);
+    hipLaunchKernelGGL(k_tc_breakdown, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->hoff, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow, g->htask,
+                       g->hitem, g->hitems, g->ttask, g->titem, g->titems, g->inline_limit, n_block, n_work, acc);
     GMSX_HIP(hipMemcpyAsync(out21, acc, 21 * 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     GMSX_HIP(hipGetLastError());
+    out21[7] = uint64_t(g->inline_units) * 16ull;                         // the build's figures: the entries do not say what they name
+    out21[12] = uint64_t(g->inline_hentries + g->inline_tentries);
     return GMSX_OK;
 }
 
@@ -931,10 +1040,12 @@ int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out256) {
     GMSX_HIP(hipMemsetAsync(acc, 0, 256 * 8, s));
     const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
     hipLaunchKernelGGL(k_tc_row_hist, dim3(unsigned(cus * 8)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow,
-                       g->task, g->titem, g->task_items, g->n, acc);
+                       g->htask, g->hitem, g->hitems, g->ttask, g->titem, g->titems, g->n, acc);
+    GMSX_HIP(hipGetLastError());
     GMSX_HIP(hipMemcpyAsync(out248, acc, 256 * 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     GMSX_HIP(hipGetLastError());
+    out248[241] = uint64_t(g->inline_hentries + g->inline_tentries);
     return GMSX_OK;
 }
 

@@ -195,7 +195,7 @@ def test_inline_limit(gpu, oracle, hub_limit, inline_limit):
             os.environ["GMSX_INLINE_LIMIT"] = old
 
 
-@pytest.mark.parametrize("knobs", [{"GMSX_TC_TWO_SIDED": "0"}, {"GMSX_TC_SORT_TASKS": "0"}, {"GMSX_TC_TWO_SIDED": "0", "GMSX_INLINE_LIMIT": "0"},
+@pytest.mark.parametrize("knobs", [{"GMSX_TC_TWO_SIDED": "0"}, {"GMSX_TC_TWO_SIDED": "0", "GMSX_INLINE_LIMIT": "0"},
                                    {"GMSX_TC_OVERLAP": "0"}, {"GMSX_TC_OVERLAP": "2"}, {"GMSX_TC_GAP12": "0"}, {"GMSX_TC_GAP12": "2"},
                                    {"GMSX_TC_GAP12": "2", "GMSX_TC_DELTA": "0"}])
 def test_task_list_knobs(gpu, oracle, knobs):
