@@ -294,10 +294,10 @@ __device__ inline uint32_t tail_delta_encode(const int32_t *__restrict__ row, in
     return units;
 }
 __global__ void k_trow_sizes(int64_t n, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, int delta_mode,
-                             int64_t *__restrict__ units_out, unsigned char *__restrict__ form_out) {
+                             int64_t *__restrict__ units_out, int64_t *__restrict__ small_out, uint32_t *__restrict__ real_out, unsigned char *__restrict__ form_out) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v > n) return;
-    if (v == n) { units_out[n] = 0; return; }
+    if (v == n) { units_out[n] = 0; small_out[n] = 0; return; }
     const int64_t b = toff[v];
     const int len = int(toff[v + 1] - b);
     uint32_t best = uint32_t((len + 3) / 4);  // list: 4 ids per unit
@@ -306,14 +306,21 @@ __global__ void k_trow_sizes(int64_t n, const int64_t *__restrict__ toff, const 
         const uint32_t d = tail_delta_encode(tadj + b, len, nullptr);
         if (delta_mode == 2 || d * 100u <= best * 85u) { best = d; form = kFormDelta; }
     }
-    units_out[v] = int64_t(best);
+    // like the hub rows: rows of 8 units (128 bytes) or more start on 128-byte boundaries of their own region, the small rows are packed
+    // behind them — a row fetch touches ceil(L/128) lines instead of L/128 + 1 (the tail rows average 14 units: 2.8 lines unaligned)
+    const bool big = best >= 8u;
+    units_out[v] = big ? int64_t((best + 7u) & ~7u) : 0;
+    small_out[v] = big ? 0 : int64_t(best);
+    real_out[v] = best;
     form_out[v] = (unsigned char)form;
 }
 __global__ void k_trow_fill(int64_t n, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, const int64_t *__restrict__ uoff,
-                            const unsigned char *__restrict__ form, unsigned long long *__restrict__ trow, uint32_t *__restrict__ tpool) {
+                            const int64_t *__restrict__ soff, const uint32_t *__restrict__ real, const unsigned char *__restrict__ form,
+                            unsigned long long *__restrict__ trow, uint32_t *__restrict__ tpool) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v >= n) return;
-    const int64_t u0 = uoff[v], units = uoff[v + 1] - u0;
+    const int64_t units = int64_t(real[v]);
+    const int64_t u0 = units >= 8 ? uoff[v] : uoff[n] + soff[v];
     trow[v] = ((unsigned long long)u0 << 24) | ((unsigned long long)form[v] << 22) | (unsigned long long)units;
     if (units == 0) return;
     uint32_t *dst = tpool + u0 * 4;
@@ -884,10 +891,6 @@ static int sort_segment_pairs(K *keys, V *vals, int64_t entries, int64_t n, cons
     }
     return GMSX_OK;
 }
-__global__ void k_scale_offsets(int64_t count, const int64_t *__restrict__ in, int64_t mul, int64_t *__restrict__ out) {
-    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < count) out[i] = in[i] * mul;
-}
 
 // GMSX_TIMING=1: phase times of the device-side builds on stderr (each mark synchronises the stream)
 struct PhaseTimer {
@@ -1176,25 +1179,35 @@ static int build_tc_sets(gmsx_graph *g) {
             const int v = std::atoi(e);
             if (v >= 0 && v <= 2 && g->rows_sorted) delta_mode = v;
         }
-        int64_t *units = nullptr, *uoff = nullptr;
+        int64_t *units = nullptr, *uoff = nullptr, *small = nullptr, *soff = nullptr;
+        uint32_t *real = nullptr;
         unsigned char *form = nullptr;
         if (int rc = dmalloc(&units, n + 1, nullptr)) return rc;
         DevGuard g_u{units};
         if (int rc = dmalloc(&uoff, n + 1, nullptr)) return rc;
         DevGuard g_o{uoff};
+        if (int rc = dmalloc(&small, n + 1, nullptr)) return rc;
+        DevGuard g_s{small};
+        if (int rc = dmalloc(&soff, n + 1, nullptr)) return rc;
+        DevGuard g_so{soff};
+        if (int rc = dmalloc(&real, n + 1, nullptr)) return rc;
+        DevGuard g_r{real};
         if (int rc = dmalloc(&form, n + 1, nullptr)) return rc;
         DevGuard g_f{form};
-        hipLaunchKernelGGL(k_trow_sizes, dim3(unsigned(n / 256 + 1)), dim3(256), 0, s, n, g->toff, g->tadj, delta_mode, units, form);
+        hipLaunchKernelGGL(k_trow_sizes, dim3(unsigned(n / 256 + 1)), dim3(256), 0, s, n, g->toff, g->tadj, delta_mode, units, small, real, form);
         if (int rc = exclusive_scan_i64(units, uoff, n + 1, s)) return rc;
-        GMSX_HIP(hipMemcpy(&g->tpool_units, uoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
-        inline_t_base = g->tpool_units;
-        g->tpool_units += inline_t_units;
+        if (int rc = exclusive_scan_i64(small, soff, n + 1, s)) return rc;
+        int64_t big_units = 0, small_units = 0;
+        GMSX_HIP(hipMemcpy(&big_units, uoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        GMSX_HIP(hipMemcpy(&small_units, soff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        inline_t_base = big_units + small_units;
+        g->tpool_units = inline_t_base + inline_t_units;
         if (g->tpool_units >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;
         if (int rc = dmalloc(&g->trow, n, g)) return rc;
         if (int rc = dmalloc(&g->tpool, g->tpool_units * 4 + 4, g)) return rc;
-        if (inline_t_units > 0) GMSX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g->tpool + inline_t_base * 4), int(0xFFFFFFFEu), size_t(inline_t_units) * 4, s));  // filler -2
+        GMSX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g->tpool), int(0xFFFFFFFEu), size_t(g->tpool_units) * 4 + 4, s));  // filler -2 (alignment gaps, inline rows)
         if (n > 0)
-            hipLaunchKernelGGL(k_trow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->toff, g->tadj, uoff, form, g->trow, g->tpool);
+            hipLaunchKernelGGL(k_trow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->toff, g->tadj, uoff, soff, real, form, g->trow, g->tpool);
         if (int rc = dmalloc(&g->tdesc, 2 * g->tail_entries + 2, g)) return rc;
         if (g->tail_entries > 0)
             hipLaunchKernelGGL(k_tdesc_fill, dim3(unsigned((g->tail_entries + 255) / 256)), dim3(256), 0, s, g->tail_entries, g->tadj, g->srow, g->trow,
@@ -1212,19 +1225,9 @@ static int build_tc_sets(gmsx_graph *g) {
                            inline_t_base, reinterpret_cast<int32_t *>(g->tpool), g->tdesc);
     }
     pt.mark("inline rows fill");
-    // 5d. the ids arrive in the inline rows through atomic cursors, in any order: sort every receiver's rows (fillers last), so that the
-    //     chunks the work items name hold the same ids on every rank of a multi-GPU run
-    if (inline_h_units + inline_t_units > 0) {
-        int64_t *ioff = nullptr;
-        if (int rc = dmalloc(&ioff, n + 1, nullptr)) return rc;
-        DevGuard g_ioff{ioff};
-        const unsigned ob = unsigned((n + 1 + 255) / 256);
-        hipLaunchKernelGGL(k_scale_offsets, dim3(ob), dim3(256), 0, s, n + 1, ihoff, int64_t(8), ioff);
-        if (int rc = sort_rows(reinterpret_cast<uint16_t *>(g->spool) + inline_h_base * 8, inline_h_units * 8, n, ioff, 16, s)) return rc;
-        hipLaunchKernelGGL(k_scale_offsets, dim3(ob), dim3(256), 0, s, n + 1, itoff, int64_t(4), ioff);
-        if (int rc = sort_rows(g->tpool + inline_t_base * 4, inline_t_units * 4, n, ioff, 32, s)) return rc;
-    }
-    pt.mark("inline rows sort");
+    // (the ids arrive in the inline rows through atomic cursors, in any order — and stay so: a receiver's inline rows are scanned whole by
+    //  whichever rank owns the receiver, and the count does not depend on the order.  Round 2 sorted them, 0.13–0.8 s at scale 26, because
+    //  its shards cut the lists by position.)
     // 5e. the light pivots k_tc_wave still has work for (most handed everything over): a compact list in launch order, built with a scan so
     //     that it is the same on every rank
     {
