@@ -563,7 +563,9 @@ def main():
     n, m, nnz = csr.num_nodes, csr.num_edges, csr.nnz
     elems = csr.merge_elements()
     t0 = time.perf_counter()
-    g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_DEFAULT)  # H2D + validation (sorted, loop-free, symmetric) + DAG containers + bitsets
+    # H2D + validation (sorted, loop-free, symmetric) + DAG containers + bitsets; for N > 1 a SHARDED upload: this rank's pivots' task lists
+    # and inline rows only (gmsx_graph_upload_csr_shard), so the container build and its memory shrink with N
+    g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_DEFAULT, shard=(rank, world) if world > 1 else None)
     torch.cuda.synchronize()
     t_upload_base = time.perf_counter() - t0
     base_bytes = g.device_bytes

@@ -33,7 +33,7 @@ SYMBOLS = [
     "gmsx_csr_num_edges_directed", "gmsx_csr_offsets", "gmsx_csr_neighbors", "gmsx_csr_merge_elements",
     "gmsx_csr_fingerprint", "gmsx_csr_free", "gmsx_set_host_threads",
     "gmsx_init", "gmsx_set_stream", "gmsx_device_info",
-    "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_prepare", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
+    "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_upload_shard", "gmsx_graph_upload_csr_shard", "gmsx_graph_prepare", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
     "gmsx_graph_device_bytes", "gmsx_graph_max_out_degree",
     "gmsx_tc_total", "gmsx_tc_partial", "gmsx_tc_divisor", "gmsx_tc_stream_breakdown", "gmsx_tc_row_histogram", "gmsx_tc_vertex_count2",
     "gmsx_intersect_count_batch", "gmsx_vertex_similarity_batch", "gmsx_kclique_count", "gmsx_kclique_partial", "gmsx_bk_count", "gmsx_bk_partial",
@@ -96,6 +96,8 @@ def lib():
     L.gmsx_device_info.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_int64)]
     L.gmsx_graph_upload.argtypes = [C.c_int64, _i64p, _i32p, C.c_uint32, vpp]
     L.gmsx_graph_upload_csr.argtypes = [vp, C.c_uint32, vpp]
+    L.gmsx_graph_upload_shard.argtypes = [C.c_int64, _i64p, _i32p, C.c_uint32, C.c_int, C.c_int, vpp]
+    L.gmsx_graph_upload_csr_shard.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, vpp]
     L.gmsx_graph_free.argtypes = [vp]
     L.gmsx_graph_prepare.argtypes = [vp, C.c_uint32]
     for f in (L.gmsx_graph_num_nodes, L.gmsx_graph_num_edges, L.gmsx_graph_device_bytes):
@@ -258,9 +260,13 @@ class DeviceGraph:
         return cls(h)
 
     @classmethod
-    def from_csr(cls, csr, flags=UPLOAD_DEFAULT):
+    def from_csr(cls, csr, flags=UPLOAD_DEFAULT, shard=None):
+        """shard = (part, nparts): gmsx_graph_upload_csr_shard — the triangle-count containers of that shard's pivots only."""
         h = C.c_void_p()
-        _check(lib().gmsx_graph_upload_csr(csr._h, flags, C.byref(h)), "gmsx_graph_upload_csr")
+        if shard is None:
+            _check(lib().gmsx_graph_upload_csr(csr._h, flags, C.byref(h)), "gmsx_graph_upload_csr")
+        else:
+            _check(lib().gmsx_graph_upload_csr_shard(csr._h, flags, int(shard[0]), int(shard[1]), C.byref(h)), "gmsx_graph_upload_csr_shard")
         return cls(h)
 
     num_nodes = property(lambda self: lib().gmsx_graph_num_nodes(self._h))

@@ -354,6 +354,8 @@ int main(int argc, char **argv) {
 
     // ---- BenchmarkKernelBk / BenchmarkKernelBkPP ---------------------------------------------------------------------------
     t.Start();
+    if (nranks > 1 && args.kernel == "tc") gmsx::default_upload_shard() = {rank, nranks};  // this rank's task lists and inline rows only
+    if (args.kernel == "tc") gmsx::default_upload_flags() = GMSX_UPLOAD_FOR_TC;              // … built here, inside "GraphExec buildTime"
     gmsx::HipSetGraph g = gmsx::HipSetGraph::FromCsr(csr);  // borrows the CSR arrays; uploads + builds the device containers
     (void)g.device();
     t.Stop();

@@ -413,7 +413,8 @@ __device__ __forceinline__ bool takes_inline(int32_t v, int32_t inline_limit, co
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_inline_rows(int64_t first, int64_t end, const int32_t *__restrict__ order, const int64_t *__restrict__ hoff,
                                                      const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
-                                                     const int32_t *__restrict__ dplus, int32_t inline_limit, unsigned long long *__restrict__ cnt_h,
+                                                     const int32_t *__restrict__ dplus, int32_t inline_limit, const int32_t *__restrict__ opos, int nparts, int part,
+                                                     unsigned long long *__restrict__ cnt_h,
                                                      unsigned long long *__restrict__ cnt_t, const int64_t *__restrict__ ihoff,
                                                      const int64_t *__restrict__ itoff, int64_t base_h, uint16_t *__restrict__ pool_h, int64_t base_t,
                                                      int32_t *__restrict__ pool_t, unsigned long long *__restrict__ tdesc) {
@@ -437,8 +438,11 @@ __global__ __launch_bounds__(256) void k_inline_rows(int64_t first, int64_t end,
         const int nhub = __popcll(__ballot(valid && lane < hl));  // the valid hub members are the lanes [0, nhub)
         const int below = __popcll(vmask & ((1ull << lane) - 1ull));
         const bool give = valid && below > 0 && takes_inline(mv, inline_limit, dplus);
-        const int nh = give ? (is_tail ? nhub : below) : 0;
-        const int nt = give && is_tail ? lane - hl : 0;
+        // a sharded upload (gmsx_graph_upload_shard) keeps the inline rows of the receivers this rank owns only; the hand-over itself (the
+        // blanked descriptors below) is the same on every rank
+        const bool mine = give && (nparts <= 1 || shard_of(opos[mv], nparts) == part);
+        const int nh = mine ? (is_tail ? nhub : below) : 0;
+        const int nt = mine && is_tail ? lane - hl : 0;
         if (!FILL) {
             if (nh) atomicAdd(&cnt_h[mv], (unsigned long long)nh);
             if (nt) atomicAdd(&cnt_t[mv], (unsigned long long)nt);
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ cur, const int64_t *__restrict__ hbeg,
                                                     const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ htask, unsigned long long *__restrict__ ttask,
                                                     int32_t *__restrict__ tunits, unsigned long long *__restrict__ reversed, const uint32_t *__restrict__ spool,
-                                                    const uint32_t *__restrict__ tpool, int32_t inline_limit) {
+                                                    const uint32_t *__restrict__ tpool, int32_t inline_limit, int nparts, int part) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -628,6 +632,7 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
         const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
         const unsigned long long du_s = srow[u], du_t = trow[u];
         uint32_t *cu = cnt + pos * kClasses, *ru = cur + pos * kClasses;
+        const bool own_u = nparts <= 1 || shard_of(pos, nparts) == part;  // a sharded upload writes the lists of the receivers this rank owns only
         int kept = 0;
         for (int base = 0; base < hl + tl; base += 64) {
             const int i = base + lane;
@@ -645,7 +650,8 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                 const uint32_t keep = uint32_t(srow[v] & 0x3fffffull) + (i > hl ? uint32_t(trow[v] & 0x3fffffull) : 0u);  // what u would stream
                 reverse = ch + ct < keep;
             }
-            const bool fwd = v >= 0 && !reverse;
+            const bool fwd = v >= 0 && !reverse && own_u;
+            if (reverse && nparts > 1 && shard_of(opos[v], nparts) != part) v = -1;
             // forward: v's rows against u — the first member has no member below it (the edge closes no triangle); the tail ids of the first
             // tail member lie below every tail id of the pivot; a hub member has no tail part
             const unsigned long long fh = (fwd && i > 0) ? srow[v] : 0ull, ft = (fwd && i > hl) ? trow[v] : 0ull;
@@ -1051,7 +1057,10 @@ static int build_tc_sets(gmsx_graph *g) {
     const uint32_t flags = g->upload_flags;
     const int hub_limit = g->hub_limit;
     const unsigned tb = unsigned((n + 255) / 256);
-    (void)tb;
+    int32_t *opos = nullptr;  // position of every vertex in `order`: the receiver index of a heavy pivot, and what shard_of() is evaluated on
+    if (int rc = dmalloc(&opos, n + 1, nullptr)) return rc;
+    DevGuard g_opos{opos};
+    if (n > 0) hipLaunchKernelGGL(k_opos, dim3(tb), dim3(256), 0, s, n, g->order, opos);
     // 4c. INLINE LIMIT.  A light pivot u (2 <= d+ < 64) hands the edge (u,v) over to v whenever v is a pivot of the workgroup kernel
     //     anyway (d+ >= 64) or a popular target (rank id < inline_limit): the members of u below v — the only ids of N+(u) that can
     //     be in N+(v) — are copied into v's INLINE ROWS, two more stream rows of v (16-bit hub ids / 32-bit tail ids, list form) that
@@ -1101,7 +1110,7 @@ static int build_tc_sets(gmsx_graph *g) {
         GMSX_HIP(hipMemsetAsync(inl_t, 0, size_t(n + 1) * sizeof(unsigned long long), s));
         if (n_work > 0)
             hipLaunchKernelGGL(k_inline_rows<false>, dim3(grid_for_waves(n_work)), dim3(256), 0, s, int64_t(0), n_work, g->order, g->hoff, g->hadj,
-                               g->toff, g->tadj, g->dplus, g->inline_limit, inl_h, inl_t, ihoff, itoff, int64_t(0), static_cast<uint16_t *>(nullptr),
+                               g->toff, g->tadj, g->dplus, g->inline_limit, opos, g->shard_nparts, g->shard_part, inl_h, inl_t, ihoff, itoff, int64_t(0), static_cast<uint16_t *>(nullptr),
                                int64_t(0), static_cast<int32_t *>(nullptr), static_cast<unsigned long long *>(nullptr));
         int64_t *uh = nullptr, *ut = nullptr;
         if (int rc = dmalloc(&uh, n + 1, nullptr)) return rc;
@@ -1221,7 +1230,7 @@ static int build_tc_sets(gmsx_graph *g) {
         GMSX_HIP(hipMemsetAsync(inl_h, 0, size_t(n + 1) * sizeof(unsigned long long), s));  // now the fill cursors
         GMSX_HIP(hipMemsetAsync(inl_t, 0, size_t(n + 1) * sizeof(unsigned long long), s));
         hipLaunchKernelGGL(k_inline_rows<true>, dim3(grid_for_waves(n_work)), dim3(256), 0, s, int64_t(0), n_work, g->order, g->hoff, g->hadj, g->toff,
-                           g->tadj, g->dplus, g->inline_limit, inl_h, inl_t, ihoff, itoff, inline_h_base, reinterpret_cast<uint16_t *>(g->spool),
+                           g->tadj, g->dplus, g->inline_limit, opos, g->shard_nparts, g->shard_part, inl_h, inl_t, ihoff, itoff, inline_h_base, reinterpret_cast<uint16_t *>(g->spool),
                            inline_t_base, reinterpret_cast<int32_t *>(g->tpool), g->tdesc);
     }
     pt.mark("inline rows fill");
@@ -1255,10 +1264,6 @@ static int build_tc_sets(gmsx_graph *g) {
         int two_sided = 1;
         if (const char *e = std::getenv("GMSX_TC_TWO_SIDED")) two_sided = std::atoi(e) != 0;  // 0 = every heavy pivot keeps all its edges (A/B knob)
         const unsigned vb = unsigned(n / 256 + 1);
-        int32_t *opos = nullptr;
-        if (int rc = dmalloc(&opos, n + 1, nullptr)) return rc;
-        DevGuard g_opos{opos};
-        if (n > 0) hipLaunchKernelGGL(k_opos, dim3(vb), dim3(256), 0, s, n, g->order, opos);
         // light receivers: rank ids below inline_limit that are not heavy
         const int64_t L = g->inline_limit;
         int64_t *lflag = nullptr, *lidx = nullptr;
@@ -1306,7 +1311,7 @@ static int build_tc_sets(gmsx_graph *g) {
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->trow,
                                two_sided, opos, cnt, cur, hbeg, tbeg, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), g->tunits,
-                               totals + 2, g->spool, g->tpool, g->inline_limit);
+                               totals + 2, g->spool, g->tpool, g->inline_limit, g->shard_nparts, g->shard_part);
         pt.mark("task lists count");
         // class offsets, list offsets
         hipLaunchKernelGGL(k_list_sizes, dim3(unsigned(n_recv / 256 + 1)), dim3(256), 0, s, n_recv, cnt, hcnt, tcnt);
@@ -1328,7 +1333,7 @@ static int build_tc_sets(gmsx_graph *g) {
                                inline_t_base, cnt, cur, hbeg, tbeg, g->htask, g->ttask, totals);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->trow,
-                               two_sided, opos, cnt, cur, hbeg, tbeg, g->htask, g->ttask, g->tunits, totals + 2, g->spool, g->tpool, g->inline_limit);
+                               two_sided, opos, cnt, cur, hbeg, tbeg, g->htask, g->ttask, g->tunits, totals + 2, g->spool, g->tpool, g->inline_limit, g->shard_nparts, g->shard_part);
         pt.mark("task lists fill");
         // work items
         int64_t *icnt = nullptr, *ioff = nullptr;
@@ -1451,13 +1456,19 @@ int gmsx_device_info(char *name, size_t name_len, int *compute_units, int64_t *h
 }
 
 int gmsx_graph_upload(int64_t n, const int64_t *offsets, const int32_t *neigh, uint32_t flags, gmsx_graph **out) {
-    if (!out || n < 0 || !offsets || n > 0x7fffffffll) return GMSX_ERR_INVALID;
+    return gmsx_graph_upload_shard(n, offsets, neigh, flags, 0, 1, out);
+}
+
+int gmsx_graph_upload_shard(int64_t n, const int64_t *offsets, const int32_t *neigh, uint32_t flags, int part, int nparts, gmsx_graph **out) {
+    if (!out || n < 0 || !offsets || n > 0x7fffffffll || nparts < 1 || part < 0 || part >= nparts) return GMSX_ERR_INVALID;
     if (offsets[0] != 0 || offsets[n] < 0 || (offsets[n] > 0 && !neigh)) return GMSX_ERR_INVALID;
     if (int rc = ensure_init()) return rc;
     gmsx_graph *g = new (std::nothrow) gmsx_graph;
     if (!g) return GMSX_ERR_NOMEM;
     g->n = n;
     g->nnz = offsets[n];
+    g->shard_part = part;
+    g->shard_nparts = nparts;
     int rc = dmalloc(&g->off, n + 1, g);
     if (!rc) rc = dmalloc(&g->adj, g->nnz, g);
     if (!rc) {
@@ -1484,10 +1495,12 @@ int gmsx_graph_upload(int64_t n, const int64_t *offsets, const int32_t *neigh, u
     return GMSX_OK;
 }
 
-int gmsx_graph_upload_csr(const gmsx_csr *h, uint32_t flags, gmsx_graph **out) {
+int gmsx_graph_upload_csr(const gmsx_csr *h, uint32_t flags, gmsx_graph **out) { return gmsx_graph_upload_csr_shard(h, flags, 0, 1, out); }
+
+int gmsx_graph_upload_csr_shard(const gmsx_csr *h, uint32_t flags, int part, int nparts, gmsx_graph **out) {
     if (!h) return GMSX_ERR_INVALID;
     if (h->g.directed) return GMSX_ERR_DIRECTED;
-    return gmsx_graph_upload(h->g.n, h->g.off.get(), h->g.neigh.get(), flags, out);
+    return gmsx_graph_upload_shard(h->g.n, h->g.off.get(), h->g.neigh.get(), flags, part, nparts, out);
 }
 
 int gmsx_graph_prepare(gmsx_graph *g, uint32_t what) {

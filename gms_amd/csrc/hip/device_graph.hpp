@@ -113,6 +113,7 @@ struct gmsx_graph {
     mutable const int32_t *rank_ok_ptr = nullptr;    // gmsx_bk_partial: the last `rank` array validated as a permutation (+ two probe values)
     mutable int32_t rank_ok_first = 0, rank_ok_last = 0;
     // the triangle-count containers (stream rows, inline rows, task lists …) are built on demand: ensure_tc()
+    int shard_part = 0, shard_nparts = 1;   // gmsx_graph_upload_shard: the triangle-count containers hold this rank's pivots only
     bool tc_ready = false;
     int64_t tc_bytes = 0;                   // their share of device_bytes
     int hub_limit = 0;                      // hub id range this graph was built with (kHub unless the test hook shrank it)

@@ -1054,6 +1054,8 @@ int gmsx_tc_partial(const gmsx_graph *g, int algo, int part, int nparts, uint64_
     if (algo != GMSX_TC_AUTO && algo != GMSX_TC_ORIENTED && algo != GMSX_TC_FULL) return GMSX_ERR_INVALID;
     if (int rc = ensure_init()) return rc;
     if (algo == GMSX_TC_FULL) return tc_full_partial(g, part, nparts, partial, stats);
+    // a sharded upload holds the task lists of ONE shard: that is the only one it can count
+    if (g->shard_nparts > 1 && (nparts != g->shard_nparts || part != g->shard_part)) return GMSX_ERR_INVALID;
     return tc_oriented(g, part, nparts, partial, stats);
 }
 

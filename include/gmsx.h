@@ -152,6 +152,13 @@ enum {
  * like the reference (common/benchmark.h:105-109). */
 int gmsx_graph_upload(int64_t n, const int64_t *offsets, const int32_t *neigh, uint32_t flags, gmsx_graph **out);
 int gmsx_graph_upload_csr(const gmsx_csr *g, uint32_t flags, gmsx_graph **out);
+/* The same for ONE rank of a multi-GPU run: the CSR and the oriented containers are complete on every rank (any row may be
+ * streamed; k-clique / Bron-Kerbosch shards of any (part, nparts) still work), but the triangle-count containers — task lists and inline
+ * rows, ~4/5 of the device bytes — are built for the pivots of shard `part` of `nparts` only, so their memory and build time shrink with
+ * the number of ranks.  gmsx_tc_partial on such a graph accepts exactly (part, nparts) (GMSX_TC_FULL any).  part = 0, nparts = 1 is
+ * gmsx_graph_upload. */
+int gmsx_graph_upload_shard(int64_t n, const int64_t *offsets, const int32_t *neigh, uint32_t flags, int part, int nparts, gmsx_graph **out);
+int gmsx_graph_upload_csr_shard(const gmsx_csr *g, uint32_t flags, int part, int nparts, gmsx_graph **out);
 /* Builds optional containers of an uploaded graph ahead of their first use (so that a caller can time or place the cost). */
 enum { GMSX_PREPARE_TC = 1 /* the triangle-count containers, see GMSX_UPLOAD_FOR_TC */ };
 int gmsx_graph_prepare(gmsx_graph *g, uint32_t what);

@@ -288,6 +288,12 @@ inline uint32_t &default_upload_flags() {
     static uint32_t flags = uint32_t(GMSX_ADAPTOR_UPLOAD_FLAGS);
     return flags;
 }
+// (part, nparts) of the uploads of THIS process: a rank of a multi-GPU run sets it once (before the first FromCGraph / FromCsr), so that
+// only its own shard's triangle-count containers are built (gmsx_graph_upload_shard); {0, 1} = the whole graph
+inline std::pair<int, int> &default_upload_shard() {
+    static std::pair<int, int> shard{0, 1};
+    return shard;
+}
 
 template <class SetT>
 class HipGraphT {
@@ -420,7 +426,7 @@ class HipGraphT {
     }
     void try_upload() {
         release_device();
-        upload_rc_ = gmsx_graph_upload(n_, off_, adj_, flags_, &dev_);
+        upload_rc_ = gmsx_graph_upload_shard(n_, off_, adj_, flags_, default_upload_shard().first, default_upload_shard().second, &dev_);
         if (upload_rc_ != GMSX_OK) dev_ = nullptr;
     }
     void release_device() {

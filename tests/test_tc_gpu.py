@@ -264,9 +264,11 @@ def test_stream_row_forms(gpu, oracle, delta):
 
 
 def test_shards_of_separate_processes_add_up(gpu):
-    """Multi-GPU runs shard the WORK ITEMS (p, p+N, …) and every rank uploads the graph itself: the task lists and the inline rows —
-    filled through atomic cursors in any order — must come out identical in every process (total order of the task sort, sorted
-    inline rows).  Three processes, one shard each, on a graph with reverse entries, inline rows and several items per hub."""
+    """Multi-GPU runs shard whole PIVOTS (shard_of(position in the d+ order)) and every rank uploads the graph itself.  The task lists are
+    filled through atomic cursors — their order differs from process to process — so nothing may depend on it: three processes, one shard
+    each, on a graph with reverse entries, inline rows and several items per hub, (a) on full uploads, (b) on SHARDED uploads
+    (gmsx_graph_upload_csr_shard: only the rank's own task lists and inline rows are built).  Both sums equal the count, the bookkeeping
+    units add up to m, a sharded graph refuses the other shards, its k-clique shards still work, and it is much smaller."""
     import json
     import subprocess
     import sys
@@ -274,7 +276,8 @@ def test_shards_of_separate_processes_add_up(gpu):
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "tc_two_process_shards.py"), "19"], capture_output=True, text=True, cwd=root, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
-    assert rec["ok"] and rec["total"] == rec["sum_of_process_shards"] and rec["units"] == rec["m"], rec
+    assert rec["ok"] and rec["total"] == rec["sum_of_process_shards"] == rec["sum_of_sharded_uploads"] and rec["units"] == rec["m"], rec
+    assert max(rec["bytes_sharded"]) < 0.75 * rec["bytes_full"], rec  # a third of the task lists and inline rows each
 
 
 def test_random_small_graphs_all_paths(gpu, oracle):
