@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgmsx.so")
+LIB_PATH = os.environ.get("GMSX_LIB") or os.path.join(_HERE, "lib", "libgmsx.so")  # GMSX_LIB: an A/B build of the same library (tools/)
 
 _i64p = np.ctypeslib.ndpointer(np.int64, flags="C_CONTIGUOUS")
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")

@@ -129,12 +129,18 @@ static constexpr int kBitmapWords = 2048;  // 65536-bit LDS bitmap over the hub 
 static constexpr int kAccWords = 64 * 16 + 16;
 static constexpr int kFormList = 0, kFormBitset = 1, kFormDelta = 2, kFormGap12 = 3;
 static constexpr int kTaskChunk = 1024;  // entries per work item
-// entry classes: hub = form * 8 + length class (0..31), tail = 32 + (delta ? 8 : 0) + length class; length class = 0: <= 4 units, 1: <= 8,
-// 2: <= 16, 3: <= 32, 4: <= 64, 5: <= 128, 6: more
-static constexpr int kHubClasses = 32, kTailClasses = 16, kClasses = kHubClasses + kTailClasses;
-__host__ __device__ inline int length_class(uint32_t units) { return units <= 4 ? 0 : units <= 8 ? 1 : units <= 16 ? 2 : units <= 32 ? 3 : units <= 64 ? 4 : units <= 128 ? 5 : 6; }
-__host__ __device__ inline int hub_class(unsigned long long d) { return int((uint32_t(d) >> 22) & 3u) * 8 + length_class(uint32_t(d) & 0x3fffffu); }
-__host__ __device__ inline int tail_class(unsigned long long d) { return kHubClasses + (((uint32_t(d) >> 22) & 3u) == 2u ? 8 : 0) + length_class(uint32_t(d) & 0x3fffffu); }
+// entry classes: hub = form * kLenClasses + length class, tail = kHubClasses + (delta ? kLenClasses : 0) + length class.  Length classes
+// in steps of ~sqrt(2): <= 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, more units — the groups of a wave work on rows of one class side
+// by side, and the wave is done when its longest row is.
+static constexpr int kLenClasses = 12;
+static constexpr int kHubClasses = 4 * kLenClasses, kTailClasses = 2 * kLenClasses, kClasses = kHubClasses + kTailClasses;
+__host__ __device__ inline int length_class(uint32_t u) {
+    return u <= 16 ? (u <= 4 ? 0 : u <= 8 ? 1 : u <= 12 ? 2 : 3) : u <= 64 ? (u <= 24 ? 4 : u <= 32 ? 5 : u <= 48 ? 6 : 7) : (u <= 96 ? 8 : u <= 128 ? 9 : u <= 192 ? 10 : 11);
+}
+__host__ __device__ inline int hub_class(unsigned long long d) { return int((uint32_t(d) >> 22) & 3u) * kLenClasses + length_class(uint32_t(d) & 0x3fffffu); }
+__host__ __device__ inline int tail_class(unsigned long long d) {
+    return kHubClasses + (((uint32_t(d) >> 22) & 3u) == 2u ? kLenClasses : 0) + length_class(uint32_t(d) & 0x3fffffu);
+}
 // which rank of a multi-GPU run owns the pivot at position `pos` of `order`: stripes of nparts positions, every other one reversed (the
 // order is by decreasing d+, so plain striding would always hand the costlier pivot of a stripe to the lower rank)
 __host__ __device__ inline int shard_of(int64_t pos, int nparts) {

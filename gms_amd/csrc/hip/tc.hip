@@ -225,12 +225,12 @@ __device__ __forceinline__ uint32_t set_contains(const int32_t *tbl, uint32_t ma
 // Tail stream rows (trow / tpool: 32-bit ids, 4 per 16-byte unit, filler -2 — or 16-bit delta units, 6 ids each) against the pivot's
 // tail set; same shape as scan_srows.
 // Almost every streamed tail id is a miss (scale 24: 0.7 M of 10.3 G triangles close through a tail id), so the set is fronted by a
-// FILTER: a 32768-bit bitmap of (id & 0x7fff).  One LDS word read + bit test answers "no" for all but tl/32768 of the ids; only
+// FILTER: a bitmap of the low id bits, 32 bits per table slot (32768 bits for a full 512-key tile).  One LDS word read + bit test answers "no" for all but tl/32768 of the ids; only
 // the lanes with a positive walk the open-addressing table (whose divergent probe loops were 47 of k_tc_block's 165 ms at scale 26).
-static constexpr int kFilterWords = 1024;
-__device__ __forceinline__ uint32_t flt_bit(const uint32_t *flt, uint32_t id) { return __builtin_amdgcn_ubfe(flt[(id >> 5) & (kFilterWords - 1)], id, 1u); }
+static constexpr int kFilterWords = 1024;  // filter words = table slots (32 bits per slot); both sized per pivot, at most this
+__device__ __forceinline__ uint32_t flt_bit(const uint32_t *flt, uint32_t mask, uint32_t id) { return __builtin_amdgcn_ubfe(flt[(id >> 5) & mask], id, 1u); }
 __device__ __forceinline__ uint32_t tail_unit_hits(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, uint4 p) {
-    const uint32_t m = flt_bit(flt, p.x) | (flt_bit(flt, p.y) << 1) | (flt_bit(flt, p.z) << 2) | (flt_bit(flt, p.w) << 3);
+    const uint32_t m = flt_bit(flt, mask, p.x) | (flt_bit(flt, mask, p.y) << 1) | (flt_bit(flt, mask, p.z) << 2) | (flt_bit(flt, mask, p.w) << 3);
     uint32_t c = 0;
     if (m) {  // rare: exact membership for the ids the filter let through (the filler -2 may pass the filter, it is never a key)
         if (m & 1u) c += set_contains(tbl, mask, shift, int32_t(p.x));
@@ -245,8 +245,8 @@ __device__ __forceinline__ uint32_t tail_delta_unit_hits(const uint32_t *flt, co
     const uint32_t id0 = p.x, id1 = id0 + (p.y >> 16), id2 = id1 + (p.z & 0xffffu), id3 = id2 + (p.z >> 16), id4 = id3 + (p.w & 0xffffu),
                    id5 = id4 + (p.w >> 16);
     const uint32_t n = p.y & 0xffu;
-    const uint32_t m = (flt_bit(flt, id0) | (flt_bit(flt, id1) << 1) | (flt_bit(flt, id2) << 2) | (flt_bit(flt, id3) << 3) | (flt_bit(flt, id4) << 4) |
-                        (flt_bit(flt, id5) << 5)) & ((1u << n) - 1u);
+    const uint32_t m = (flt_bit(flt, mask, id0) | (flt_bit(flt, mask, id1) << 1) | (flt_bit(flt, mask, id2) << 2) | (flt_bit(flt, mask, id3) << 3) |
+                        (flt_bit(flt, mask, id4) << 4) | (flt_bit(flt, mask, id5) << 5)) & ((1u << n) - 1u);
     uint32_t c = 0;
     if (m) {
         if (m & 1u) c += set_contains(tbl, mask, shift, int32_t(id0));
@@ -258,41 +258,6 @@ __device__ __forceinline__ uint32_t tail_delta_unit_hits(const uint32_t *flt, co
     }
     return c;
 }
-__device__ __forceinline__ uint32_t scan_trows(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, const uint32_t *__restrict__ tpool,
-                                               unsigned long long desc, int rows, int lane) {
-    const int grp = lane >> 4, sub = lane & 15;
-    uint32_t cnt = 0;
-    for (int r0 = 0; r0 < rows; r0 += 4) {
-        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
-        const uint32_t lo0 = __builtin_amdgcn_readlane(uint32_t(desc), m0), lo1 = __builtin_amdgcn_readlane(uint32_t(desc), m1),
-                       lo2 = __builtin_amdgcn_readlane(uint32_t(desc), m2), lo3 = __builtin_amdgcn_readlane(uint32_t(desc), m3);
-        if (((lo0 | lo1 | lo2 | lo3) & 0x3fffffu) == 0) continue;  // wave-uniform
-        const uint32_t hi0 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m0), hi1 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m1),
-                       hi2 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m2), hi3 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m3);
-        const uint32_t lo = grp == 0 ? lo0 : grp == 1 ? lo1 : grp == 2 ? lo2 : lo3;
-        const uint32_t hi = grp == 0 ? hi0 : grp == 1 ? hi1 : grp == 2 ? hi2 : hi3;
-        const int units = int(lo & 0x3fffffu), form = int((lo >> 22) & 3u);
-        const uint4 *row = reinterpret_cast<const uint4 *>(tpool) + ((uint64_t(hi) << 8) | (lo >> 24));
-        int j = sub;
-        if (form == kFormDelta) {
-            for (; j + 16 < units; j += 32) {
-                const uint4 p = row[j], q = row[j + 16];
-                cnt += tail_delta_unit_hits(flt, tbl, mask, shift, p);
-                cnt += tail_delta_unit_hits(flt, tbl, mask, shift, q);
-            }
-            if (j < units) cnt += tail_delta_unit_hits(flt, tbl, mask, shift, row[j]);
-        } else {
-            for (; j + 16 < units; j += 32) {
-                const uint4 p = row[j], q = row[j + 16];
-                cnt += tail_unit_hits(flt, tbl, mask, shift, p);
-                cnt += tail_unit_hits(flt, tbl, mask, shift, q);
-            }
-            if (j < units) cnt += tail_unit_hits(flt, tbl, mask, shift, row[j]);
-        }
-    }
-    return cnt;
-}
-
 // Bucketed tail set for the light-pivot kernel (<= 63 keys): 64 buckets x 4 slots, 16-byte aligned, so a probe is ONE
 // ds_read_b128 and four compares -- no probe loop, no divergence, and the four probes of a 16-byte load are
 // independent.  A pivot whose keys overflow a bucket (five keys with the same hash) falls back to the open-addressing
@@ -355,6 +320,11 @@ __device__ __forceinline__ uint32_t scan_trows_probe(Probe probe, const uint32_t
 // g, g + 256/W, … with the next descriptor already loaded while the current row is scanned.  No form ballots, no readlane hand-outs, no
 // mixed rows in a wave: what was ~30 VALU instructions per four rows is one LDS read and an address computation per row.
 // ---------------------------------------------------------------------------------------------
+static constexpr int kBlockLog = 10;
+#ifndef GMSX_TC_WIDE_GROUP
+#define GMSX_TC_WIDE_GROUP 16  // lanes per row for rows of more than 8 units (A/B: -DGMSX_TC_WIDE_GROUP=8)
+#endif
+static constexpr int kWideGroup = GMSX_TC_WIDE_GROUP;
 template <int FORM>
 __device__ __forceinline__ uint32_t hub_unit_hits(const uint32_t *bm, uint4 p, int j) {
     if (FORM == kFormBitset) {
@@ -369,8 +339,9 @@ template <int FORM>
 __device__ __forceinline__ uint32_t tail_unit_hits_f(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, uint4 p) {
     return FORM == kFormDelta ? tail_delta_unit_hits(flt, tbl, mask, shift, p) : tail_unit_hits(flt, tbl, mask, shift, p);
 }
-// entries [lo, hi) of the item (descriptors in LDS), all of one class: HIT(p, j) = hits of unit j of a row
-template <int W, class Hit>
+// entries [lo, hi) of the item (descriptors in LDS), one form, rows of similar length: HIT(p, j) = hits of unit j of a row.  ONE_STEP: the
+// classes of the run guarantee units <= W (one load per lane, no loop).
+template <int W, bool ONE_STEP, class Hit>
 __device__ __forceinline__ uint32_t scan_class(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, int lo, int hi, int tid, Hit hit) {
     constexpr int G = 256 / W;
     const int g = tid / W, sub = tid % W;
@@ -382,14 +353,14 @@ __device__ __forceinline__ uint32_t scan_class(const unsigned long long *sdesc, 
         const unsigned long long dn = en < hi ? sdesc[en] : 0ull;
         const uint4 *row = reinterpret_cast<const uint4 *>(pool) + (d >> 24);
         const int units = int(uint32_t(d) & 0x3fffffu);
-        if (W < 16) {  // the class guarantees units <= W: one load per lane, no loop
+        if (ONE_STEP) {
             if (sub < units) cnt += hit(row[sub], sub);
         } else {
             int j = sub;
-            for (; j + 16 < units; j += 32) {
-                const uint4 p = row[j], q = row[j + 16];
+            for (; j + W < units; j += 2 * W) {
+                const uint4 p = row[j], q = row[j + W];
                 cnt += hit(p, j);
-                cnt += hit(q, j + 16);
+                cnt += hit(q, j + W);
             }
             if (j < units) cnt += hit(row[j], j);
         }
@@ -398,7 +369,25 @@ __device__ __forceinline__ uint32_t scan_class(const unsigned long long *sdesc, 
     }
     return cnt;
 }
-// copies the item's descriptors to LDS and records, per class, where its run begins and ends (the list is class-sorted: one run each)
+// the runs of one form inside an item: rows of <= 4 units (4-lane groups), of <= 8 units (8-lane groups), all longer ones TOGETHER
+// (kWideGroup lanes per row; the finer length classes of the build only ORDER the rows, so that the groups of a wave work on rows of
+// similar length — one loop per class would leave most groups of the workgroup idle on the short class runs of a small item, and every
+// extra run costs every wave of every item its bookkeeping).  Run type = form * 3 + {0: <= 4 units, 1: <= 8, 2: longer}.
+__device__ __forceinline__ int run_type(unsigned long long d) {
+    const uint32_t u = uint32_t(d) & 0x3fffffu;
+    return int((uint32_t(d) >> 22) & 3u) * 3 + (u <= 4 ? 0 : u <= 8 ? 1 : 2);
+}
+template <class Hit>
+__device__ __forceinline__ uint32_t scan_form(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, const unsigned short *rbeg, const unsigned short *rend,
+                                              int form, int tid, Hit hit) {
+    uint32_t cnt = 0;
+    const int r0 = form * 3;
+    if (rend[r0] > rbeg[r0]) cnt += scan_class<4, true>(sdesc, pool, rbeg[r0], rend[r0], tid, hit);
+    if (rend[r0 + 1] > rbeg[r0 + 1]) cnt += scan_class<8, true>(sdesc, pool, rbeg[r0 + 1], rend[r0 + 1], tid, hit);
+    if (rend[r0 + 2] > rbeg[r0 + 2]) cnt += scan_class<kWideGroup, false>(sdesc, pool, rbeg[r0 + 2], rend[r0 + 2], tid, hit);
+    return cnt;
+}
+// copies the item's descriptors to LDS and records, per run type, where its run begins and ends (the list is class-sorted: one run each)
 template <int NC, class ClassOf>
 __device__ __forceinline__ void stage_item(const unsigned long long *__restrict__ ent, int ne, int tid, unsigned long long *sdesc, unsigned short *cbeg,
                                            unsigned short *cend, ClassOf class_of) {
@@ -422,7 +411,6 @@ __device__ __forceinline__ void block_add(unsigned long long cnt, unsigned long 
     }
 }
 
-static constexpr int kBlockLog = 10;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const uint32_t *__restrict__ spool, const unsigned long long *__restrict__ htask,
@@ -430,7 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                   unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords + 128];  // + slack: the delta probes of unused slots read up to 104 words past the bitmap
     __shared__ unsigned long long sdesc[kTaskChunk];
-    __shared__ unsigned short cbeg[kHubClasses], cend[kHubClasses];
+    __shared__ unsigned short cbeg[12], cend[12];  // run types
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const gmsx_task_item it = items[blockIdx.x];
@@ -439,27 +427,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int64_t hb = hoff[u];
     const int hl = int(hoff[u + 1] - hb);
     const int ne = int(it.bc >> 40);
-    for (int i = tid; i < kBitmapWords + 128; i += 256) bm[i] = 0;
-    stage_item<kHubClasses>(htask + (it.bc & 0xffffffffffull), ne, tid, sdesc, cbeg, cend, [](unsigned long long d) { return hub_class(d); });
+    for (int i = tid; i < (kBitmapWords + 128) / 4; i += 256) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    stage_item<12>(htask + (it.bc & 0xffffffffffull), ne, tid, sdesc, cbeg, cend, [](unsigned long long d) { return run_type(d); });
     for (int i = tid; i < hl; i += 256) {
         const uint32_t id = hadj[hb + i];
         if (id != 0xFFFFu) atomicOr(&bm[id >> 5], 1u << (id & 31u));
     }
     __syncthreads();
     uint32_t cnt = 0;
-    auto run = [&](auto form_tag, int c0) {  // the seven length classes of one form
+    auto run = [&](auto form_tag) {
         constexpr int FORM = decltype(form_tag)::value;
-        auto hit = [](uint4 p, int j) { return hub_unit_hits<FORM>(bm, p, j); };
-        if (cend[c0] > cbeg[c0]) cnt += scan_class<4>(sdesc, spool, cbeg[c0], cend[c0], tid, hit);
-        if (cend[c0 + 1] > cbeg[c0 + 1]) cnt += scan_class<8>(sdesc, spool, cbeg[c0 + 1], cend[c0 + 1], tid, hit);
-#pragma unroll 1
-        for (int c = c0 + 2; c < c0 + 7; ++c)
-            if (cend[c] > cbeg[c]) cnt += scan_class<16>(sdesc, spool, cbeg[c], cend[c], tid, hit);
+        cnt += scan_form(sdesc, spool, cbeg, cend, FORM, tid, [](uint4 p, int j) { return hub_unit_hits<FORM>(bm, p, j); });
     };
-    run(std::integral_constant<int, kFormList>{}, kFormList * 8);
-    run(std::integral_constant<int, kFormBitset>{}, kFormBitset * 8);
-    run(std::integral_constant<int, kFormDelta>{}, kFormDelta * 8);
-    run(std::integral_constant<int, kFormGap12>{}, kFormGap12 * 8);
+    run(std::integral_constant<int, kFormList>{});
+    run(std::integral_constant<int, kFormBitset>{});
+    run(std::integral_constant<int, kFormDelta>{});
+    run(std::integral_constant<int, kFormGap12>{});
     block_add(cnt, red, lane, wave, tid, acc);
 }
 
@@ -470,10 +453,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ __attribute__((aligned(16))) int32_t tbl[1 << kBlockLog];
     __shared__ uint32_t flt[kFilterWords];
     __shared__ unsigned long long sdesc[kTaskChunk];
-    __shared__ unsigned short cbeg[kTailClasses], cend[kTailClasses];
+    __shared__ unsigned short cbeg[12], cend[12];  // run types (tail forms: list = 0, delta = 2)
     __shared__ unsigned long long red[4];
-    constexpr int SIZE = 1 << kBlockLog, SHIFT = 32 - kBlockLog, TILE = SIZE / 2;
-    constexpr uint32_t MASK = SIZE - 1;
+    constexpr int TILE = (1 << kBlockLog) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const gmsx_task_item it = items[blockIdx.x];
     if (nparts > 1 && shard_of(it.pos, nparts) != part) return;  // uniform per block
@@ -481,31 +463,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int64_t tb = toff[u];
     const int tl = int(toff[u + 1] - tb);
     const int ne = int(it.bc >> 40);
-    stage_item<kTailClasses>(ttask + (it.bc & 0xffffffffffull), ne, tid, sdesc, cbeg, cend, [](unsigned long long d) { return tail_class(d) - kHubClasses; });
+    stage_item<12>(ttask + (it.bc & 0xffffffffffull), ne, tid, sdesc, cbeg, cend, [](unsigned long long d) { return run_type(d); });
+    // table and filter sized for THIS pivot (most tail parts are a few dozen ids: clearing 8 KB per item cost more than scanning its rows):
+    // 2^log slots >= 2 x keys, the filter 32 bits per slot (a false positive per ~64 probes)
+    int log = 6;
+    while ((1 << log) < 2 * min(tl, TILE)) ++log;
+    const int size = 1 << log, shift = 32 - log;
+    const uint32_t mask = uint32_t(size - 1);
     uint32_t cnt = 0;
     for (int t0 = 0; t0 < tl; t0 += TILE) {  // the pivot's tail part, a tile at a time
         const int tn = min(TILE, tl - t0);
         __syncthreads();
-        for (int i = tid; i < SIZE; i += 256) tbl[i] = -1;
-        for (int i = tid; i < kFilterWords; i += 256) flt[i] = 0;
+        for (int i = tid; i < size; i += 256) {
+            tbl[i] = -1;
+            flt[i] = 0;
+        }
         __syncthreads();
         for (int i = tid; i < tn; i += 256) {
             const int32_t t = tadj[tb + t0 + i];
-            set_insert(tbl, MASK, SHIFT, t);
-            atomicOr(&flt[(uint32_t(t) >> 5) & (kFilterWords - 1)], 1u << (uint32_t(t) & 31u));
+            set_insert(tbl, mask, shift, t);
+            atomicOr(&flt[(uint32_t(t) >> 5) & mask], 1u << (uint32_t(t) & 31u));
         }
         __syncthreads();
-        auto run = [&](auto form_tag, int c0) {
+        auto run = [&](auto form_tag) {
             constexpr int FORM = decltype(form_tag)::value;
-            auto hit = [](uint4 p, int) { return tail_unit_hits_f<FORM>(flt, tbl, MASK, SHIFT, p); };
-            if (cend[c0] > cbeg[c0]) cnt += scan_class<4>(sdesc, tpool, cbeg[c0], cend[c0], tid, hit);
-            if (cend[c0 + 1] > cbeg[c0 + 1]) cnt += scan_class<8>(sdesc, tpool, cbeg[c0 + 1], cend[c0 + 1], tid, hit);
-#pragma unroll 1
-            for (int c = c0 + 2; c < c0 + 7; ++c)
-                if (cend[c] > cbeg[c]) cnt += scan_class<16>(sdesc, tpool, cbeg[c], cend[c], tid, hit);
+            cnt += scan_form(sdesc, tpool, cbeg, cend, FORM, tid, [mask, shift](uint4 p, int) { return tail_unit_hits_f<FORM>(flt, tbl, mask, shift, p); });
         };
-        run(std::integral_constant<int, kFormList>{}, 0);
-        run(std::integral_constant<int, kFormDelta>{}, 8);
+        run(std::integral_constant<int, kFormList>{});
+        run(std::integral_constant<int, kFormDelta>{});
     }
     block_add(cnt, red, lane, wave, tid, acc);
 }
