@@ -22,6 +22,7 @@
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 
 namespace gmsx {
 
@@ -614,6 +615,121 @@ __device__ __forceinline__ void bk_search_mem(const uint32_t *Cadj, const uint32
     }
 }
 
+// BUILD of one start vertex (one wave): the id -> index map of its candidates, Cadj (symmetric closure of the DAG rows inside C) and
+// XT (C x X0 adjacency) — into LDS (tiny tasks), a per-wave slab (k_bk_wave) or straight into the arena (k_bk_build).
+template <bool LDS_SLAB>
+__device__ __forceinline__ void bk_build(const int64_t *__restrict__ off, const int32_t *__restrict__ adj, const int32_t *__restrict__ newid,
+                                         const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff,
+                                         const int32_t *__restrict__ tadj, const BkShared &sh, int32_t v, int c, int x, int64_t ob, int64_t oe,
+                                         unsigned long long *map, uint32_t msize, uint32_t *Cadj, uint32_t *XT, int32_t *in_stage, int lane) {
+    const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
+    const uint32_t mmask = msize - 1;
+    (void)off;
+            // ---- build: map, Cadj (symmetric closure of the DAG rows inside C), XT (C x X0 adjacency) -------------------
+            for (uint32_t i = lane; i < msize; i += 64) map[i] = kEmptySlot;
+            {
+                const size_t nz = size_t(c) * cw + size_t(c) * xw;
+                size_t head = (16 - (reinterpret_cast<uintptr_t>(Cadj) & 15)) & 15;  // bytes to the next 16-byte boundary
+                head = min(nz, head / 4);
+                for (size_t i = lane; i < head; i += 64) Cadj[i] = 0;
+                uint4 *z4 = reinterpret_cast<uint4 *>(Cadj + head);
+                const size_t n4 = (nz - head) / 4;
+                for (size_t i = lane; i < n4; i += 64) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+                for (size_t i = head + n4 * 4 + lane; i < nz; i += 64) Cadj[i] = 0;
+            }
+            if (!LDS_SLAB) __threadfence();
+            __builtin_amdgcn_wave_barrier();
+            const int64_t hb = uni64(hoff[v]), tb = uni64(toff[v]);
+            int hc = int(uni64(hoff[v + 1]) - hb);
+            if (hc > 0 && uni32(uint32_t(hadj[hb + hc - 1])) == 0xFFFFu) --hc;
+            for (int i = lane; i < c; i += 64) {
+                const int32_t a = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
+                uint32_t h = bk_hash(a, mmask);
+                const unsigned long long packed = ((unsigned long long)uint32_t(a) << 32) | (unsigned long long)uint32_t(i);
+                while (atomicCAS(&map[h], kEmptySlot, packed) != kEmptySlot) h = (h + 1) & mmask;
+            }
+            if (!LDS_SLAB) __threadfence();
+            __builtin_amdgcn_wave_barrier();
+            // rows of the hub candidates (all of them have a bitset container): lane k asks "is candidate k in N+(a_i)?" with
+            // one word gather; the candidate ids of a 64-chunk are loaded once, the rows go eight at a time (eight gathers
+            // in flight).  Candidates ascend with their index, so only rows i > k can hit.
+            {
+                for (int k0 = 0; k0 < hc; k0 += 64) {
+                    const int k = k0 + lane;
+                    const uint32_t w = k < hc ? uint32_t(hadj[hb + k]) : 0xFFFFFFFFu;
+                    for (int i0 = k0; i0 < hc; i0 += 64) {  // 64 rows: ids and bitset offsets lane-parallel, then by readlane
+                        int32_t ai = 0;
+                        int64_t rbi = 0;
+                        if (i0 + lane < hc) {
+                            ai = int32_t(hadj[hb + i0 + lane]);
+                            rbi = sh.bmoff[ai];
+                        }
+                        const int nrow = min(64, hc - i0);
+                        for (int r0 = 0; r0 < nrow; r0 += 8) {
+                            uint32_t wd[8];
+    #pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                const int32_t a = __builtin_amdgcn_readlane(ai, (r0 + r) & 63);  // 0 beyond the last row: never > w
+                                const int64_t rb = bk_readlane64(rbi, (r0 + r) & 63);
+                                wd[r] = (w < uint32_t(a)) ? sh.bmpool[rb + (w >> 5)] : 0u;
+                            }
+    #pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                if ((wd[r] >> (w & 31u)) & 1u) {
+                                    const int i = i0 + r0 + r;
+                                    atomicOr(&Cadj[size_t(i) * cw + (k >> 5)], 1u << (k & 31));
+                                    atomicOr(&Cadj[size_t(k) * cw + (i >> 5)], 1u << (i & 31));
+                                }
+                            }
+                        }
+                    }
+                }
+                // tail candidates: stream their containers through the map, four rows per trip (one per 16-lane group)
+                for (int i0 = hc; i0 < c; i0 += 4) {
+                    const int i = i0 + (lane >> 4);
+                    if (i < c) {
+                        const int32_t a = tadj[tb + (i - hc)];
+                        bk_scan_row_group(hoff, hadj, toff, tadj, a, map, mmask, lane & 15, [&](int k) {
+                            atomicOr(&Cadj[size_t(i) * cw + (k >> 5)], 1u << (k & 31));
+                            atomicOr(&Cadj[size_t(k) * cw + (i >> 5)], 1u << (i & 31));
+                        });
+                    }
+                }
+            }
+            // rows of the in-neighbours, 64 CSR entries per batch; t = index of the in-neighbour in X0
+            int xbase = 0;
+            for (int64_t e0 = ob; e0 < oe; e0 += 64) {
+                const int64_t e = e0 + lane;
+                int32_t nw = -1;
+                bool keep = false;
+                if (e < oe) {
+                    nw = newid[adj[e]];
+                    keep = nw > v;
+                }
+                const unsigned long long m = __ballot(keep);
+                const int kept = __popcll(m);
+                // compact the kept in-neighbours of this batch, then eight rows per step, one per 8-lane group
+                __builtin_amdgcn_wave_barrier();
+                if (keep) in_stage[__popcll(m & ((1ull << lane) - 1ull))] = nw;
+                __builtin_amdgcn_wave_barrier();
+                for (int r0 = 0; r0 < kept; r0 += 8) {
+                    const int r = r0 + (lane >> 3);
+                    if (r < kept) {
+                        const int t = xbase + r;
+                        bk_scan_row_group8(hoff, hadj, toff, tadj, in_stage[r], map, mmask, lane & 7,
+                                           [&](int k) { atomicOr(&XT[size_t(k) * xw + (t >> 5)], 1u << (t & 31)); });
+                    }
+                }
+                xbase += kept;
+            }
+            if (!LDS_SLAB) {
+                __threadfence();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop L1 lines of the slab cached for an earlier task
+            }
+            __builtin_amdgcn_wave_barrier();
+
+}
+
 // Round 0: one wave per start vertex.  LDS_SLAB: every structure of the search lives in this wave's LDS slab (tasks of
 // at most kLdsSlabWords words); otherwise in slabs[block * slab_words].
 template <bool LDS_SLAB, int WPL>
@@ -655,114 +771,13 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
         const int64_t ob = uni64(off[vo]), oe = uni64(off[vo + 1]);
         const int x = int(oe - ob) - c;
         const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
-        const uint32_t msize = bk_map_size(c), mmask = msize - 1;
+        const uint32_t msize = bk_map_size(c);
         unsigned long long *map = (!LDS_SLAB && msize <= kLdsMapSlots) ? lds_map : reinterpret_cast<unsigned long long *>(slab);
         uint32_t *Cadj = slab + 2 * size_t(msize);
         uint32_t *XT = Cadj + size_t(c) * cw;
         uint32_t *stack = XT + size_t(c) * xw;
 
-        // ---- build: map, Cadj (symmetric closure of the DAG rows inside C), XT (C x X0 adjacency) -------------------
-        for (uint32_t i = lane; i < msize; i += 64) map[i] = kEmptySlot;
-        {
-            const size_t nz = size_t(c) * cw + size_t(c) * xw;
-            size_t head = (16 - (reinterpret_cast<uintptr_t>(Cadj) & 15)) & 15;  // bytes to the next 16-byte boundary
-            head = min(nz, head / 4);
-            for (size_t i = lane; i < head; i += 64) Cadj[i] = 0;
-            uint4 *z4 = reinterpret_cast<uint4 *>(Cadj + head);
-            const size_t n4 = (nz - head) / 4;
-            for (size_t i = lane; i < n4; i += 64) z4[i] = make_uint4(0u, 0u, 0u, 0u);
-            for (size_t i = head + n4 * 4 + lane; i < nz; i += 64) Cadj[i] = 0;
-        }
-        if (!LDS_SLAB) __threadfence();
-        __builtin_amdgcn_wave_barrier();
-        const int64_t hb = uni64(hoff[v]), tb = uni64(toff[v]);
-        int hc = int(uni64(hoff[v + 1]) - hb);
-        if (hc > 0 && uni32(uint32_t(hadj[hb + hc - 1])) == 0xFFFFu) --hc;
-        for (int i = lane; i < c; i += 64) {
-            const int32_t a = i < hc ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
-            uint32_t h = bk_hash(a, mmask);
-            const unsigned long long packed = ((unsigned long long)uint32_t(a) << 32) | (unsigned long long)uint32_t(i);
-            while (atomicCAS(&map[h], kEmptySlot, packed) != kEmptySlot) h = (h + 1) & mmask;
-        }
-        if (!LDS_SLAB) __threadfence();
-        __builtin_amdgcn_wave_barrier();
-        // rows of the hub candidates (all of them have a bitset container): lane k asks "is candidate k in N+(a_i)?" with
-        // one word gather; the candidate ids of a 64-chunk are loaded once, the rows go eight at a time (eight gathers
-        // in flight).  Candidates ascend with their index, so only rows i > k can hit.
-        {
-            for (int k0 = 0; k0 < hc; k0 += 64) {
-                const int k = k0 + lane;
-                const uint32_t w = k < hc ? uint32_t(hadj[hb + k]) : 0xFFFFFFFFu;
-                for (int i0 = k0; i0 < hc; i0 += 64) {  // 64 rows: ids and bitset offsets lane-parallel, then by readlane
-                    int32_t ai = 0;
-                    int64_t rbi = 0;
-                    if (i0 + lane < hc) {
-                        ai = int32_t(hadj[hb + i0 + lane]);
-                        rbi = sh.bmoff[ai];
-                    }
-                    const int nrow = min(64, hc - i0);
-                    for (int r0 = 0; r0 < nrow; r0 += 8) {
-                        uint32_t wd[8];
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            const int32_t a = __builtin_amdgcn_readlane(ai, (r0 + r) & 63);  // 0 beyond the last row: never > w
-                            const int64_t rb = bk_readlane64(rbi, (r0 + r) & 63);
-                            wd[r] = (w < uint32_t(a)) ? sh.bmpool[rb + (w >> 5)] : 0u;
-                        }
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            if ((wd[r] >> (w & 31u)) & 1u) {
-                                const int i = i0 + r0 + r;
-                                atomicOr(&Cadj[size_t(i) * cw + (k >> 5)], 1u << (k & 31));
-                                atomicOr(&Cadj[size_t(k) * cw + (i >> 5)], 1u << (i & 31));
-                            }
-                        }
-                    }
-                }
-            }
-            // tail candidates: stream their containers through the map, four rows per trip (one per 16-lane group)
-            for (int i0 = hc; i0 < c; i0 += 4) {
-                const int i = i0 + (lane >> 4);
-                if (i < c) {
-                    const int32_t a = tadj[tb + (i - hc)];
-                    bk_scan_row_group(hoff, hadj, toff, tadj, a, map, mmask, lane & 15, [&](int k) {
-                        atomicOr(&Cadj[size_t(i) * cw + (k >> 5)], 1u << (k & 31));
-                        atomicOr(&Cadj[size_t(k) * cw + (i >> 5)], 1u << (i & 31));
-                    });
-                }
-            }
-        }
-        // rows of the in-neighbours, 64 CSR entries per batch; t = index of the in-neighbour in X0
-        int xbase = 0;
-        for (int64_t e0 = ob; e0 < oe; e0 += 64) {
-            const int64_t e = e0 + lane;
-            int32_t nw = -1;
-            bool keep = false;
-            if (e < oe) {
-                nw = newid[adj[e]];
-                keep = nw > v;
-            }
-            const unsigned long long m = __ballot(keep);
-            const int kept = __popcll(m);
-            // compact the kept in-neighbours of this batch, then eight rows per step, one per 8-lane group
-            __builtin_amdgcn_wave_barrier();
-            if (keep) in_stage[__popcll(m & ((1ull << lane) - 1ull))] = nw;
-            __builtin_amdgcn_wave_barrier();
-            for (int r0 = 0; r0 < kept; r0 += 8) {
-                const int r = r0 + (lane >> 3);
-                if (r < kept) {
-                    const int t = xbase + r;
-                    bk_scan_row_group8(hoff, hadj, toff, tadj, in_stage[r], map, mmask, lane & 7,
-                                       [&](int k) { atomicOr(&XT[size_t(k) * xw + (t >> 5)], 1u << (t & 31)); });
-                }
-            }
-            xbase += kept;
-        }
-        if (!LDS_SLAB) {
-            __threadfence();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop L1 lines of the slab cached for an earlier task
-        }
-        __builtin_amdgcn_wave_barrier();
+        bk_build<LDS_SLAB>(off, adj, newid, hoff, hadj, toff, tadj, sh, v, c, x, ob, oe, map, msize, Cadj, XT, in_stage, lane);
 
         // ---- search from the root: P = C, Xc = {}, Xf = X0 ------------------------------------------------------
         for (int w = lane; w < xw; w += 64) {
@@ -797,6 +812,267 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
     if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
 }
 
+// ---- round 0 of the start vertices too big for an LDS slab: BUILD and SEARCH are separate kernels -------------------------------------
+// k_bk_wave builds Cadj | XT of a start vertex and searches it in the same wave: ~110 VGPRs and 11 KB of LDS, 3.5 waves per SIMD — for a
+// build that is bound by the latency of dependent row fetches (27 % VALU issue, 64 % of the wave cycles waiting, round 2).  The build
+// alone needs neither the search's registers nor its stack, so it runs as its own kernel at twice the occupancy and writes Cadj | XT
+// STRAIGHT INTO THE ARENA (offsets from a prefix sum over the chunk: no slab, no copy when the search is split later) plus a ROOT RECORD
+// per start vertex (P = all candidates, Xc = {}, Xf = X0, flag "entering"); the search of the roots is then the ordinary resume kernel.
+// k_bk_layout: per task of a chunk the arena words, the record words, and the maxima the launch needs.
+__global__ void k_bk_layout(int64_t lo, int64_t cnt, int nparts, int part, const int32_t *__restrict__ task_v, const int64_t *__restrict__ off,
+                            const int32_t *__restrict__ oldid, const int32_t *__restrict__ dplus, int x_is_degree, int64_t *__restrict__ need_a,
+                            int64_t *__restrict__ need_r, unsigned long long *__restrict__ maxima /* [0] (c+1)*lvl  [1] global map words */) {
+    const int64_t qi = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (qi > cnt) return;
+    if (qi == cnt) { need_a[qi] = 0; need_r[qi] = 0; return; }
+    const int32_t v = task_v[lo + qi * nparts + part];
+    const int32_t vo = oldid[v];
+    const long long c = dplus[v], x = (off[vo + 1] - off[vo]) - (x_is_degree ? 0 : c);  // k_bk_block: one XT column per CSR position of v's row
+    const long long cw = (c + 31) >> 5, xw = (x + 31) >> 5;
+    need_a[qi] = (c * cw + c * xw + 3) & ~3ll;
+    need_r[qi] = kRecHeader + 3 * cw + xw;
+    atomicMax(&maxima[0], (unsigned long long)((c + 1) * (3 * cw + xw + 1)));
+    const unsigned long long msize = bk_map_size(int(c));
+    if (msize > 1024) atomicMax(&maxima[1], 2ull * msize);
+}
+// first index i in [0, cnt] whose prefix exceeds either budget (prefixes relative to index `start`)
+__global__ void k_bk_chunk_end(int64_t start, int64_t cnt, const int64_t *__restrict__ aoff, const int64_t *__restrict__ roff, int64_t a_cap, int64_t r_cap,
+                               int64_t max_tasks, int64_t *__restrict__ out) {
+    int64_t lo = start + 1, hi = min(cnt, start + max_tasks);  // at least one task per chunk
+    while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (aoff[mid] - aoff[start] <= a_cap && roff[mid] - roff[start] <= r_cap) lo = mid; else hi = mid - 1;
+    }
+    out[0] = lo;
+}
+// k_bk_block: the same build by a WORKGROUP per start vertex, shaped like the triangle kernels — the candidates C = N+(v) staged in LDS as
+// the 65536-bit hub bitmap + the index of the first candidate of every bitmap word (candidates ascend, so local index = that + popcount
+// of the lower bits) and a 32768-bit filter in front of the ascending tail-candidate list; then every row that can hold an edge into C
+// is STREAMED with 16-byte loads by a 16-lane group: the rows N+(a_i) of the candidates (hits -> Cadj, both directions) and the rows
+// N+(t) of the in-neighbours t (hits -> XT).  A streamed id costs a bitmap probe (one LDS read + bit test) instead of a hash-table walk,
+// sixteen rows are in flight per workgroup with the ids and extents of the next two batches already loading, and no wave idles behind a
+// dependent chain.  XT has one column per CSR POSITION of v's row (x = degree; the positions of out-neighbours stay empty), so no
+// compaction or scan over the in-neighbours is needed; the root record's Xf is the mask of the in-neighbour positions.
+struct BkRowJob {
+    int32_t a;         // rank id whose oriented row is streamed; < 0: nothing (an out-neighbour position, or past the end)
+    int64_t hs, he, ts, te;
+};
+__global__ __launch_bounds__(256) void k_bk_block(const int64_t *__restrict__ off, const int32_t *__restrict__ adj, const int32_t *__restrict__ newid,
+                                                  const int32_t *__restrict__ oldid, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                  const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, const int32_t *__restrict__ dplus,
+                                                  const int32_t *__restrict__ task_v, int64_t lo, int nparts, int part, int64_t q0, int64_t q1,
+                                                  const int64_t *__restrict__ aoff, const int64_t *__restrict__ roff, unsigned long long *__restrict__ queue,
+                                                  BkShared sh) {
+    __shared__ __attribute__((aligned(16))) uint32_t bm[2048];
+    __shared__ unsigned short pre[2048];
+    __shared__ __attribute__((aligned(16))) uint32_t flt[1024];
+    __shared__ long long s_task;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = tid >> 4, sub = tid & 15;  // 16 groups of 16 lanes
+    while (true) {
+        __syncthreads();
+        if (tid == 0) s_task = (long long)atomicAdd(queue, 1ull);
+        __syncthreads();
+        const int64_t qi = q0 + s_task;
+        if (qi >= q1) break;
+        const int32_t v = task_v[lo + qi * nparts + part];
+        const int32_t vo = oldid[v];
+        const int c = dplus[v];
+        const int64_t ob = off[vo], oe = off[vo + 1];
+        const int deg = int(oe - ob);
+        const int cw = (c + 31) >> 5, xw = (deg + 31) >> 5;
+        const int64_t vhb = hoff[v], vtb = toff[v];
+        const int tc = int(toff[v + 1] - vtb), hc = c - tc;  // hub candidates (the 0xFFFF pad excluded), tail candidates
+        const unsigned long long a0 = (unsigned long long)(aoff[qi] - aoff[q0]);
+        uint32_t *Cadj = sh.arena + a0;
+        uint32_t *XT = Cadj + size_t(c) * cw;
+        uint32_t *rec = sh.pool + (unsigned long long)(roff[qi] - roff[q0]);
+        {   // zero Cadj | XT (the arena offset and the rounded size are multiples of four words), the LDS sets, the record's Xf
+            const size_t n4 = ((size_t(c) * cw + size_t(c) * xw + 3) & ~size_t(3)) / 4;
+            uint4 *z4 = reinterpret_cast<uint4 *>(Cadj);
+            for (size_t i = tid; i < n4; i += 256) z4[i] = make_uint4(0u, 0u, 0u, 0u);
+            for (int i = tid; i < 512; i += 256) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+            reinterpret_cast<uint4 *>(flt)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        __threadfence();
+        __syncthreads();
+        for (int i = tid; i < hc; i += 256) {
+            const uint32_t id = hadj[vhb + i];
+            atomicOr(&bm[id >> 5], 1u << (id & 31u));
+            if (i == 0 || (uint32_t(hadj[vhb + i - 1]) >> 5) != (id >> 5)) pre[id >> 5] = (unsigned short)i;  // candidates ascend
+        }
+        for (int i = tid; i < tc; i += 256) {
+            const uint32_t id = uint32_t(tadj[vtb + i]);
+            atomicOr(&flt[(id >> 5) & 1023u], 1u << (id & 31u));
+        }
+        // the record: header, P = C, Xc = ext = {}, Xf = the in-neighbour positions of v's CSR row
+        if (tid == 0) {
+            rec[0] = uint32_t(v);
+            rec[1] = uint32_t(c);
+            rec[2] = uint32_t(deg);
+            rec[3] = deg > c ? 1u : 0u;
+            rec[4] = uint32_t(a0 & 0xffffffffull);
+            rec[5] = uint32_t(a0 >> 32);
+            rec[6] = 1u;  // root: enter the node
+            rec[7] = 0u;
+            sh.dir[qi - q0] = (unsigned long long)(roff[qi] - roff[q0]);
+        }
+        for (int w = tid; w < cw; w += 256) {
+            const int bits = c - w * 32;
+            rec[kRecHeader + w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+            rec[kRecHeader + cw + w] = 0u;
+            rec[kRecHeader + 2 * cw + w] = 0u;
+        }
+        for (int p0 = wave * 64; p0 < deg; p0 += 256) {
+            const int p = p0 + lane;
+            const bool keep = p < deg && newid[adj[ob + p]] > v;
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) {
+                rec[kRecHeader + 3 * cw + (p0 >> 5)] = uint32_t(m);
+                if ((p0 >> 5) + 1 < xw) rec[kRecHeader + 3 * cw + (p0 >> 5) + 1] = uint32_t(m >> 32);
+            }
+        }
+        __syncthreads();
+        // ---- the row jobs: j < c -> candidate i = j (hits into Cadj); else CSR position p = j - c (in-neighbours only; hits into XT column p)
+        const int njobs = c + deg;
+        auto job_id = [&](int j) -> int32_t {  // the rank id whose row job j streams, -1 = none
+            if (j >= njobs) return -1;
+            if (j < c) return j < hc ? int32_t(hadj[vhb + j]) : tadj[vtb + (j - hc)];
+            const int32_t nw = newid[adj[ob + (j - c)]];
+            return nw > v ? nw : -1;
+        };
+        auto job_rows = [&](int32_t a) -> BkRowJob {
+            BkRowJob r{a, 0, 0, 0, 0};
+            if (a >= 0) {
+                r.hs = hoff[a];
+                r.he = hoff[a + 1];
+                r.ts = toff[a];
+                r.te = toff[a + 1];
+            }
+            return r;
+        };
+        // three-stage pipeline per group: ids of job k+2, extents of job k+1, rows of job k
+        int j = grp;
+        BkRowJob cur = job_rows(job_id(j));
+        BkRowJob nxt = job_rows(job_id(j + 16));
+        int32_t id2 = job_id(j + 32);
+        for (; j < njobs; j += 16) {
+            const int32_t id3 = job_id(j + 48);
+            const BkRowJob nx2 = job_rows(id2);
+            if (cur.a >= 0) {
+                const bool is_cand = j < c;
+                const int col = j - c;
+                auto hit = [&](int k) {
+                    if (is_cand) {
+                        atomicOr(&Cadj[size_t(j) * cw + (k >> 5)], 1u << (k & 31));
+                        atomicOr(&Cadj[size_t(k) * cw + (j >> 5)], 1u << (j & 31));
+                    } else {
+                        atomicOr(&XT[size_t(k) * xw + (col >> 5)], 1u << (col & 31));
+                    }
+                };
+                // hub part: eight 16-bit ids per 16-byte load against the bitmap
+                for (int64_t q = cur.hs + sub * 8; q < cur.he; q += 128) {
+                    const bk_u4 p4 = *reinterpret_cast<const bk_u4 *>(hadj + q);
+                    const int left = int(min(int64_t(8), cur.he - q));  // even, >= 2; the 0xFFFF pad is never in the bitmap
+                    const uint32_t wds[4] = {p4.x, p4.y, p4.z, p4.w};
+                    uint32_t mask = 0;
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const uint32_t id = (wds[t >> 1] >> ((t & 1) * 16)) & 0xffffu;
+                        mask |= ((bm[id >> 5] >> (id & 31u)) & 1u) << t;
+                    }
+                    mask &= (1u << left) - 1u;
+                    while (mask) {
+                        const int t = __ffs(mask) - 1;
+                        mask &= mask - 1;
+                        const uint32_t id = (wds[t >> 1] >> ((t & 1) * 16)) & 0xffffu;
+                        const uint32_t word = bm[id >> 5];
+                        hit(int(pre[id >> 5]) + __popc(word & ((1u << (id & 31u)) - 1u)));
+                    }
+                }
+                // tail part: four 32-bit ids per load against the filter, the few that pass against the ascending tail-candidate list
+                if (tc > 0) {
+                    for (int64_t q = cur.ts + sub * 4; q < cur.te; q += 64) {
+                        const bk_u4 p4 = *reinterpret_cast<const bk_u4 *>(tadj + q);  // tadj is padded by four ids
+                        const int left = int(min(int64_t(4), cur.te - q));
+                        const uint32_t wds[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const uint32_t id = wds[t];
+                            if (t < left && ((flt[(id >> 5) & 1023u] >> (id & 31u)) & 1u)) {
+                                int lo2 = 0, hi2 = tc;
+                                while (lo2 < hi2) {
+                                    const int mid = (lo2 + hi2) >> 1;
+                                    if (uint32_t(tadj[vtb + mid]) < id) lo2 = mid + 1; else hi2 = mid;
+                                }
+                                if (lo2 < tc && uint32_t(tadj[vtb + lo2]) == id) hit(hc + lo2);
+                            }
+                        }
+                    }
+                }
+            }
+            cur = nxt;
+            nxt = nx2;
+            id2 = id3;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_bk_build(const int64_t *__restrict__ off, const int32_t *__restrict__ adj, const int32_t *__restrict__ newid,
+                                                 const int32_t *__restrict__ oldid, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
+                                                 const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, const int32_t *__restrict__ dplus,
+                                                 const int32_t *__restrict__ task_v, int64_t lo, int nparts, int part, int64_t q0, int64_t q1,
+                                                 const int64_t *__restrict__ aoff, const int64_t *__restrict__ roff, unsigned long long *__restrict__ queue,
+                                                 uint32_t *__restrict__ map_scratch, unsigned long long map_words, BkShared sh) {
+    constexpr uint32_t kLdsMapSlots = 1024;
+    __shared__ __attribute__((aligned(16))) unsigned long long lds_map[kLdsMapSlots];
+    __shared__ int32_t in_stage[64];
+    const int lane = threadIdx.x;
+    while (true) {
+        unsigned long long t0 = 0;
+        if (lane == 0) t0 = atomicAdd(queue, 1ull);
+        const int64_t qi = q0 + int64_t(uni64(t0));
+        if (qi >= q1) break;
+        const int32_t v = uni32(task_v[lo + qi * nparts + part]);
+        const int32_t vo = uni32(oldid[v]);
+        const int c = uni32(dplus[v]);
+        const int64_t ob = uni64(off[vo]), oe = uni64(off[vo + 1]);
+        const int x = int(oe - ob) - c;
+        const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
+        const uint32_t msize = bk_map_size(c);
+        unsigned long long *map = msize <= kLdsMapSlots ? lds_map : reinterpret_cast<unsigned long long *>(map_scratch + size_t(blockIdx.x) * map_words);
+        const unsigned long long a0 = (unsigned long long)(uni64(aoff[qi]) - uni64(aoff[q0]));
+        uint32_t *Cadj = sh.arena + a0;
+        uint32_t *XT = Cadj + size_t(c) * cw;
+        bk_build<false>(off, adj, newid, hoff, hadj, toff, tadj, sh, v, c, x, ob, oe, map, msize, Cadj, XT, in_stage, lane);
+        // the root record: P = C, Xc = {}, ext unused (the search enters the node and picks its pivot), Xf = X0
+        const unsigned long long r0 = (unsigned long long)(uni64(roff[qi]) - uni64(roff[q0]));
+        uint32_t *rec = sh.pool + r0;
+        if (lane == 0) {
+            rec[0] = uint32_t(v);
+            rec[1] = uint32_t(c);
+            rec[2] = uint32_t(x);
+            rec[3] = x > 0 ? 1u : 0u;
+            rec[4] = uint32_t(a0 & 0xffffffffull);
+            rec[5] = uint32_t(a0 >> 32);
+            rec[6] = 1u;  // root: enter the node
+            rec[7] = 0u;
+            sh.dir[qi - q0] = r0;
+        }
+        for (int w = lane; w < cw; w += 64) {
+            const int bits = c - w * 32;
+            rec[kRecHeader + w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+            rec[kRecHeader + cw + w] = 0u;
+            rec[kRecHeader + 2 * cw + w] = 0u;
+        }
+        for (int w = lane; w < xw; w += 64) {
+            const int bits = x - w * 32;
+            rec[kRecHeader + 3 * cw + w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // Rounds >= 1: one wave per resumable record; Cadj | XT are read from the arena, the stack lives in this wave's slab.
 template <int WPL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? 6 : WPL == 2 ? 3 : 1))) void k_bk_resume(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in,
@@ -819,6 +1095,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? 6
         const uint32_t *rec = pool_in + roff;
         const int32_t v = uni32(int32_t(rec[0]));
         const int c = uni32(int(rec[1])), x = uni32(int(rec[2])), xf_ne = uni32(int(rec[3]));
+        const bool root = uni32(rec[6]) != 0;  // written by k_bk_build: the node is entered (pivot choice), not resumed
         const unsigned long long aoff = (unsigned long long)uni32(rec[4]) | ((unsigned long long)uni32(rec[5]) << 32);
         const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
         const uint32_t *Cadj = sh.arena + aoff;
@@ -833,7 +1110,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? 6
         }
         for (int w = lane; w < xw; w += 64) stack[3 * cw + w] = rec[kRecHeader + 3 * cw + w];
         __builtin_amdgcn_wave_barrier();
-        bk_search<WPL>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, xf_ne, false, lane, cnt, sh, aoff, true, piv_P, piv_list);
+        bk_search<WPL>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, xf_ne, root, lane, cnt, sh, aoff, true, piv_P, piv_list);
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
@@ -940,57 +1217,22 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipMemsetAsync(sh.dir, 0xff, sh.dir_cap * 8, s));
     GMSX_HIP(hipEventRecord(c.ev[1], s));
 
-    // ---- round 0: start vertices, binned by slab size (4x steps); the last bin (<= kLdsSlabWords) runs out of LDS
+    // ---- round 0.  Start vertices whose structures fit an LDS slab (<= kLdsSlabWords): one wave builds and searches (k_bk_wave<true>).
+    //      The others (GMSX_BK_SPLIT_BUILD=0 restores round 2's one-kernel bins): k_bk_build writes Cadj | XT into the arena and a root
+    //      record per start vertex, in chunks that fit the arena and the record pool; the resume rounds below search them.
+    // 2 (default): k_bk_block, a workgroup per start vertex, rows streamed against an LDS bitmap; 1: k_bk_build, a wave per start vertex with
+    // the hash-map build of k_bk_wave; 0: round 2's combined build + search bins
+    const int split_build = [] { const char *e = std::getenv("GMSX_BK_SPLIT_BUILD"); return e ? std::atoi(e) : 2; }();
     int64_t n_tasks = 0;
     while (n_tasks < n && words[size_t(n_tasks)] > 0) ++n_tasks;
+    int64_t n_glob = 0;  // tasks beyond an LDS slab: sorted first (the wide ones, > 2048 candidates, at the very front)
+    while (n_glob < n_tasks && (n_glob < n_wide || words[size_t(n_glob)] > (unsigned long long)kLdsSlabWords)) ++n_glob;
     int launches = 0;
-    int64_t lo = 0;
-    while (lo < n_tasks) {
-        const bool wide = lo < n_wide;
-        const int64_t bin_end = wide ? n_wide : n_tasks;  // the wide tasks form their own bins
-        const unsigned long long top = words[size_t(lo)];
-        const bool lds = !wide && top <= (unsigned long long)kLdsSlabWords;
-        int64_t hi = lo;
-        while (hi < bin_end && (lds || words[size_t(hi)] * 4 > top)) ++hi;
-        const int64_t cnt = part_count(lo, hi, nparts, part);
-        if (cnt > 0) {
-            GMSX_HIP(hipMemsetAsync(queue, 0, 8, s));
-            if (lds) {
-                const int64_t waves = std::min<int64_t>(cnt, int64_t(cu) * 16);
-                hipLaunchKernelGGL((k_bk_wave<true, 1>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff,
-                                   g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue,
-                                   static_cast<uint32_t *>(nullptr), 0ull, acc, sh);
-            } else {
-                const unsigned long long slab_w = (top + 3ull) & ~3ull;  // 16-byte aligned slabs (64-bit map slots)
-                const unsigned long long slab_bytes = slab_w * 4ull;
-                if (slab_bytes > budget_bytes) return GMSX_ERR_DEVICE_MEM;
-                const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({cnt, int64_t(cu) * 16, int64_t(budget_bytes / slab_bytes)}));
-                uint32_t *slabs = nullptr;
-                GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(waves) * slab_bytes));
-                Guard g_slabs;  // freed on every path out of this bin, error returns included
-                g_slabs.p = slabs;
-                if (wide && wpl_wide == 2)
-                    hipLaunchKernelGGL((k_bk_wave<false, 2>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
-                                       g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
-                else if (wide && wpl_wide == 4)
-                    hipLaunchKernelGGL((k_bk_wave<false, 4>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
-                                       g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
-                else if (wide)
-                    hipLaunchKernelGGL((k_bk_wave<false, 8>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
-                                       g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
-                else
-                    hipLaunchKernelGGL((k_bk_wave<false, 1>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
-                                       g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
-                GMSX_HIP(hipStreamSynchronize(s));
-            }
-            ++launches;
-        }
-        lo = hi;
-    }
-    // ---- rounds >= 1: resume the split searches until no record is left
+    // ---- rounds >= 1: resume the split searches (and search the root records of k_bk_build) until no record is left
     int rounds = 0;
     Guard g_rslab;
     size_t resume_cap = 0;
+    auto run_rounds = [&]() -> int {
     while (true) {
         unsigned long long ctl[4] = {0, 0, 0, 0};  // pool_head, dir_count, max_stack
         GMSX_HIP(hipMemcpyAsync(ctl, sh.pool_head, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -1033,6 +1275,144 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                                static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
         ++launches;
         if (++rounds > 100000) return GMSX_ERR_KERNEL;
+    }
+    return GMSX_OK;
+    };
+
+    auto launch_tiny = [&](int64_t lo, int64_t hi) {
+        const int64_t cnt = part_count(lo, hi, nparts, part);
+        if (cnt <= 0) return;
+        (void)hipMemsetAsync(queue, 0, 8, s);
+        const int64_t waves = std::min<int64_t>(cnt, int64_t(cu) * 16);
+        hipLaunchKernelGGL((k_bk_wave<true, 1>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff, g->hadj, g->toff, g->tadj,
+                           g->dplus, v_out, lo, hi, nparts, part, queue, static_cast<uint32_t *>(nullptr), 0ull, acc, sh);
+        ++launches;
+    };
+    if (split_build) {
+        const int64_t cnt_glob = part_count(0, n_glob, nparts, part);
+        bool tiny_done = false;
+        if (cnt_glob > 0) {
+            int64_t *need_a = nullptr, *need_r = nullptr, *aoff = nullptr, *roff = nullptr, *d_end = nullptr;
+            Guard g_na, g_nr, g_ao, g_ro, g_de, g_map;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&need_a), size_t(cnt_glob + 1) * 8)); g_na.p = need_a;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&need_r), size_t(cnt_glob + 1) * 8)); g_nr.p = need_r;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&aoff), size_t(cnt_glob + 1) * 8)); g_ao.p = aoff;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&roff), size_t(cnt_glob + 1) * 8)); g_ro.p = roff;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_end), 8)); g_de.p = d_end;
+            unsigned long long *maxima = acc + kCtl + 9;  // [0] stack words, [1] global map words
+            GMSX_HIP(hipMemsetAsync(maxima, 0, 16, s));
+            hipLaunchKernelGGL(k_bk_layout, dim3(unsigned(cnt_glob / 256 + 1)), dim3(256), 0, s, int64_t(0), cnt_glob, nparts, part, v_out, g->off, g->oldid, g->dplus,
+                               split_build >= 2 ? 1 : 0, need_a, need_r, maxima);
+            {
+                size_t scan_bytes = 0;
+                GMSX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, need_a, aoff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
+                void *scan_tmp = nullptr;
+                GMSX_HIP(hipMalloc(&scan_tmp, scan_bytes ? scan_bytes : 8));
+                Guard g_scan;
+                g_scan.p = scan_tmp;
+                GMSX_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, need_a, aoff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
+                GMSX_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, need_r, roff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
+                GMSX_HIP(hipStreamSynchronize(s));
+            }
+            unsigned long long mx[2] = {0, 0};
+            GMSX_HIP(hipMemcpy(mx, maxima, sizeof(mx), hipMemcpyDeviceToHost));
+            const unsigned long long map_words = split_build >= 2 ? 0ull : (mx[1] + 3ull) & ~3ull;
+            const int64_t build_waves = std::min<int64_t>(cnt_glob, int64_t(cu) * 24);
+            uint32_t *map_scratch = nullptr;
+            if (map_words > 0) {
+                GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&map_scratch), size_t(build_waves) * map_words * 4));
+                g_map.p = map_scratch;
+            }
+            unsigned long long *bqueue = acc + kCtl + 8;
+            // the roots may take at most half of the arena and of the pool: searches of the LDS-slab tasks that split need room too
+            const int64_t a_cap = int64_t(sh.arena_cap / 2), r_cap = int64_t(sh.pool_cap / 2), max_tasks = int64_t(sh.dir_cap / 2);
+            for (int64_t q0 = 0; q0 < cnt_glob;) {
+                hipLaunchKernelGGL(k_bk_chunk_end, dim3(1), dim3(1), 0, s, q0, cnt_glob, aoff, roff, a_cap, r_cap, max_tasks, d_end);
+                int64_t q1 = 0, span[4] = {0, 0, 0, 0};
+                GMSX_HIP(hipMemcpyAsync(&q1, d_end, 8, hipMemcpyDeviceToHost, s));
+                GMSX_HIP(hipStreamSynchronize(s));
+                GMSX_HIP(hipMemcpy(&span[0], aoff + q0, 8, hipMemcpyDeviceToHost));
+                GMSX_HIP(hipMemcpy(&span[1], aoff + q1, 8, hipMemcpyDeviceToHost));
+                GMSX_HIP(hipMemcpy(&span[2], roff + q0, 8, hipMemcpyDeviceToHost));
+                GMSX_HIP(hipMemcpy(&span[3], roff + q1, 8, hipMemcpyDeviceToHost));
+                if (uint64_t(span[1] - span[0]) > sh.arena_cap || uint64_t(span[3] - span[2]) > sh.pool_cap) return GMSX_ERR_DEVICE_MEM;  // one start vertex beyond the arena
+                // pool_head / dir_count / max_stack as if the roots had been split off by an earlier round; arena_head behind their structures
+                const unsigned long long ctl0[3] = {(unsigned long long)(span[3] - span[2]), (unsigned long long)(q1 - q0), mx[0]};
+                const unsigned long long ah = (unsigned long long)(span[1] - span[0]);
+                GMSX_HIP(hipMemcpyAsync(sh.pool_head, ctl0, sizeof(ctl0), hipMemcpyHostToDevice, s));
+                GMSX_HIP(hipMemcpyAsync(sh.arena_head, &ah, 8, hipMemcpyHostToDevice, s));
+                GMSX_HIP(hipMemsetAsync(bqueue, 0, 8, s));
+                GMSX_HIP(hipStreamSynchronize(s));  // ctl0 / ah are stack variables
+                if (split_build >= 2)
+                    hipLaunchKernelGGL(k_bk_block, dim3(unsigned(std::min<int64_t>(q1 - q0, int64_t(cu) * 8))), dim3(256), 0, s, g->off, g->adj, g->newid, g->oldid,
+                                       g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, int64_t(0), nparts, part, q0, q1, aoff, roff, bqueue, sh);
+                else
+                    hipLaunchKernelGGL(k_bk_build, dim3(unsigned(std::min<int64_t>(q1 - q0, build_waves))), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff,
+                                       g->hadj, g->toff, g->tadj, g->dplus, v_out, int64_t(0), nparts, part, q0, q1, aoff, roff, bqueue, map_scratch, map_words, sh);
+                ++launches;
+                if (!tiny_done) {  // the LDS-slab tasks run with the first chunk; what they split off joins its records
+                    launch_tiny(n_glob, n_tasks);
+                    tiny_done = true;
+                }
+                if (int rc = run_rounds()) return rc;
+                // the next chunk starts from empty pools again
+                sh.pool = pools[cur];
+                sh.dir = dirs[cur];
+                GMSX_HIP(hipMemsetAsync(sh.dir, 0xff, sh.dir_cap * 8, s));
+                GMSX_HIP(hipMemsetAsync(sh.pool_head, 0, 3 * sizeof(unsigned long long), s));
+                GMSX_HIP(hipMemsetAsync(sh.arena_head, 0, 8, s));
+                q0 = q1;
+            }
+        }
+        if (!tiny_done) {
+            launch_tiny(n_glob, n_tasks);
+            if (int rc = run_rounds()) return rc;
+        }
+    } else {
+        int64_t lo = 0;
+        while (lo < n_tasks) {
+            const bool wide = lo < n_wide;
+            const int64_t bin_end = wide ? n_wide : n_tasks;  // the wide tasks form their own bins
+            const unsigned long long top = words[size_t(lo)];
+            const bool lds = !wide && top <= (unsigned long long)kLdsSlabWords;
+            int64_t hi = lo;
+            while (hi < bin_end && (lds || words[size_t(hi)] * 4 > top)) ++hi;
+            const int64_t cnt = part_count(lo, hi, nparts, part);
+            if (cnt > 0) {
+                GMSX_HIP(hipMemsetAsync(queue, 0, 8, s));
+                if (lds) {
+                    const int64_t waves = std::min<int64_t>(cnt, int64_t(cu) * 16);
+                    hipLaunchKernelGGL((k_bk_wave<true, 1>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff,
+                                       g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue,
+                                       static_cast<uint32_t *>(nullptr), 0ull, acc, sh);
+                } else {
+                    const unsigned long long slab_w = (top + 3ull) & ~3ull;  // 16-byte aligned slabs (64-bit map slots)
+                    const unsigned long long slab_bytes = slab_w * 4ull;
+                    if (slab_bytes > budget_bytes) return GMSX_ERR_DEVICE_MEM;
+                    const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({cnt, int64_t(cu) * 16, int64_t(budget_bytes / slab_bytes)}));
+                    uint32_t *slabs = nullptr;
+                    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&slabs), size_t(waves) * slab_bytes));
+                    Guard g_slabs;  // freed on every path out of this bin, error returns included
+                    g_slabs.p = slabs;
+                    if (wide && wpl_wide == 2)
+                        hipLaunchKernelGGL((k_bk_wave<false, 2>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
+                                           g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
+                    else if (wide && wpl_wide == 4)
+                        hipLaunchKernelGGL((k_bk_wave<false, 4>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
+                                           g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
+                    else if (wide)
+                        hipLaunchKernelGGL((k_bk_wave<false, 8>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
+                                           g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
+                    else
+                        hipLaunchKernelGGL((k_bk_wave<false, 1>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid,
+                                           g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, lo, hi, nparts, part, queue, slabs, slab_w, acc, sh);
+                    GMSX_HIP(hipStreamSynchronize(s));
+                }
+                ++launches;
+            }
+            lo = hi;
+        }
+        if (int rc = run_rounds()) return rc;
     }
     // ---- start vertices too wide for the register-resident search: one wave each, the whole search in its global slab
     if (n_giant > 0) {

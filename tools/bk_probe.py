@@ -1,0 +1,26 @@
+"""GPU probe: Bron-Kerbosch on the BASELINE configs[3] graph (or `scale ef`): count vs golden, kernel time, rounds.  usage: bk_probe.py [scale ef]"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gms_amd import capi
+scale, ef = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (21, 56)
+capi.init(0)
+try:
+    q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+    if q != "max":
+        capi.set_host_threads(max(1, int(int(q) / int(p) + 0.999)))
+except (OSError, ValueError):
+    pass
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "graphs.json")))
+csr = capi.HostCSR.generate_rmat(scale, ef, 0.45, 0.22, 0.22)
+g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_TRUSTED)
+for knobs in ({}, {"GMSX_BK_SPLIT_BUILD": "1"}, {"GMSX_BK_SPLIT_BUILD": "0"}, {}):
+    os.environ.pop("GMSX_BK_SPLIT_BUILD", None)
+    os.environ.update(knobs)
+    ms = []
+    for _ in range(3):
+        total, st = g.bk_count(stats=True)
+        ms.append(round(st["kernel_ms"], 1))
+    gold = GOLD.get("rmat-%d-%d-a45-b22-c22" % (scale, ef), {}).get("bk")
+    print(json.dumps({"graph": [scale, ef], "m": csr.num_edges, "knobs": knobs, "maximal_cliques": total, "golden_ok": (total == gold) if gold else None, "kernel_ms": ms,
+                      "rounds": st["probes"], "launches": st["launches"]}), flush=True)
+os.environ.pop("GMSX_BK_SPLIT_BUILD", None)
