@@ -1181,7 +1181,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipMemGetInfo(&free_b, &total_b));
     const unsigned long long budget_bytes = std::min<unsigned long long>(free_b / 4, 16ull << 30);
     BkShared sh{};
-    sh.arena_cap = std::min<unsigned long long>(free_b / 8, 8ull << 30) / 4;
+    sh.arena_cap = std::min<unsigned long long>(free_b / 4, 48ull << 30) / 4;  // Cadj | XT of the start vertices of a chunk + of the LDS-slab searches that split
     sh.pool_cap = std::min<unsigned long long>(free_b / 16, 2ull << 30) / 4;
     sh.dir_cap = 8ull << 20;
     uint32_t *pools[2] = {nullptr, nullptr};
@@ -1279,14 +1279,45 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     return GMSX_OK;
     };
 
-    auto launch_tiny = [&](int64_t lo, int64_t hi) {
+    // the LDS-slab tasks: their own queue word; `beside` = on a side stream next to the build kernel that was just launched on s (the build
+    // streams rows at 8 workgroups per CU, the tiny searches live in LDS: each leaves what the other needs), joined before the rounds
+    unsigned long long *tqueue = acc + kCtl + 11;
+    bool tiny_beside = false;
+    struct TinyJoin {  // every way out joins the side stream again (error returns free buffers the kernel beside may still use)
+        Ctx &c;
+        hipStream_t s;
+        bool &armed;
+        ~TinyJoin() {
+            if (armed && hipEventRecord(c.ev_join[0], c.side[0]) == hipSuccess) {
+                (void)hipStreamWaitEvent(s, c.ev_join[0], 0);
+                (void)hipStreamSynchronize(s);
+            }
+        }
+    } tiny_join{c, s, tiny_beside};
+    auto launch_tiny = [&](int64_t lo, int64_t hi, bool beside) -> int {
         const int64_t cnt = part_count(lo, hi, nparts, part);
-        if (cnt <= 0) return;
-        (void)hipMemsetAsync(queue, 0, 8, s);
+        if (cnt <= 0) return GMSX_OK;
+        GMSX_HIP(hipMemsetAsync(tqueue, 0, 8, s));
+        hipStream_t st = s;
+        if (beside && c.side[0] && c.ev_fork && c.ev_join[0]) {
+            st = c.side[0];
+            GMSX_HIP(hipEventRecord(c.ev_fork, s));
+            GMSX_HIP(hipStreamWaitEvent(st, c.ev_fork, 0));
+        }
         const int64_t waves = std::min<int64_t>(cnt, int64_t(cu) * 16);
-        hipLaunchKernelGGL((k_bk_wave<true, 1>), dim3(unsigned(waves)), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff, g->hadj, g->toff, g->tadj,
-                           g->dplus, v_out, lo, hi, nparts, part, queue, static_cast<uint32_t *>(nullptr), 0ull, acc, sh);
+        hipLaunchKernelGGL((k_bk_wave<true, 1>), dim3(unsigned(waves)), dim3(64), 0, st, g->off, g->adj, g->newid, g->oldid, g->hoff, g->hadj, g->toff, g->tadj,
+                           g->dplus, v_out, lo, hi, nparts, part, tqueue, static_cast<uint32_t *>(nullptr), 0ull, acc, sh);
         ++launches;
+        tiny_beside = st != s;
+        return GMSX_OK;
+    };
+    auto join_tiny = [&]() -> int {  // after the kernel that runs beside it was launched on s
+        if (tiny_beside) {
+            tiny_beside = false;
+            GMSX_HIP(hipEventRecord(c.ev_join[0], c.side[0]));
+            GMSX_HIP(hipStreamWaitEvent(s, c.ev_join[0], 0));
+        }
+        return GMSX_OK;
     };
     if (split_build) {
         const int64_t cnt_glob = part_count(0, n_glob, nparts, part);
@@ -1324,8 +1355,8 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 g_map.p = map_scratch;
             }
             unsigned long long *bqueue = acc + kCtl + 8;
-            // the roots may take at most half of the arena and of the pool: searches of the LDS-slab tasks that split need room too
-            const int64_t a_cap = int64_t(sh.arena_cap / 2), r_cap = int64_t(sh.pool_cap / 2), max_tasks = int64_t(sh.dir_cap / 2);
+            // the roots may take at most 3/4 of the arena and half of the pool: searches of the LDS-slab tasks that split need room too
+            const int64_t a_cap = int64_t(sh.arena_cap / 4 * 3), r_cap = int64_t(sh.pool_cap / 2), max_tasks = int64_t(sh.dir_cap / 2);
             for (int64_t q0 = 0; q0 < cnt_glob;) {
                 hipLaunchKernelGGL(k_bk_chunk_end, dim3(1), dim3(1), 0, s, q0, cnt_glob, aoff, roff, a_cap, r_cap, max_tasks, d_end);
                 int64_t q1 = 0, span[4] = {0, 0, 0, 0};
@@ -1343,6 +1374,10 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 GMSX_HIP(hipMemcpyAsync(sh.arena_head, &ah, 8, hipMemcpyHostToDevice, s));
                 GMSX_HIP(hipMemsetAsync(bqueue, 0, 8, s));
                 GMSX_HIP(hipStreamSynchronize(s));  // ctl0 / ah are stack variables
+                if (!tiny_done) {  // the LDS-slab tasks run beside the first chunk's build; what they split off joins its records
+                    if (int rc = launch_tiny(n_glob, n_tasks, true)) return rc;
+                    tiny_done = true;
+                }
                 if (split_build >= 2)
                     hipLaunchKernelGGL(k_bk_block, dim3(unsigned(std::min<int64_t>(q1 - q0, int64_t(cu) * 8))), dim3(256), 0, s, g->off, g->adj, g->newid, g->oldid,
                                        g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, int64_t(0), nparts, part, q0, q1, aoff, roff, bqueue, sh);
@@ -1350,10 +1385,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                     hipLaunchKernelGGL(k_bk_build, dim3(unsigned(std::min<int64_t>(q1 - q0, build_waves))), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff,
                                        g->hadj, g->toff, g->tadj, g->dplus, v_out, int64_t(0), nparts, part, q0, q1, aoff, roff, bqueue, map_scratch, map_words, sh);
                 ++launches;
-                if (!tiny_done) {  // the LDS-slab tasks run with the first chunk; what they split off joins its records
-                    launch_tiny(n_glob, n_tasks);
-                    tiny_done = true;
-                }
+                if (int rc = join_tiny()) return rc;
                 if (int rc = run_rounds()) return rc;
                 // the next chunk starts from empty pools again
                 sh.pool = pools[cur];
@@ -1365,7 +1397,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
             }
         }
         if (!tiny_done) {
-            launch_tiny(n_glob, n_tasks);
+            if (int rc = launch_tiny(n_glob, n_tasks, false)) return rc;
             if (int rc = run_rounds()) return rc;
         }
     } else {
