@@ -33,7 +33,7 @@ SYMBOLS = [
     "gmsx_csr_num_edges_directed", "gmsx_csr_offsets", "gmsx_csr_neighbors", "gmsx_csr_merge_elements",
     "gmsx_csr_fingerprint", "gmsx_csr_free", "gmsx_set_host_threads",
     "gmsx_init", "gmsx_set_stream", "gmsx_device_info",
-    "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_upload_shard", "gmsx_graph_upload_csr_shard", "gmsx_graph_prepare", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
+    "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_upload_shard", "gmsx_graph_upload_csr_shard", "gmsx_graph_prepare", "gmsx_graph_tc_passes", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
     "gmsx_graph_device_bytes", "gmsx_graph_max_out_degree",
     "gmsx_tc_total", "gmsx_tc_partial", "gmsx_tc_divisor", "gmsx_tc_stream_breakdown", "gmsx_tc_row_histogram", "gmsx_tc_vertex_count2",
     "gmsx_intersect_count_batch", "gmsx_vertex_similarity_batch", "gmsx_kclique_count", "gmsx_kclique_partial", "gmsx_bk_count", "gmsx_bk_partial",
@@ -100,6 +100,7 @@ def lib():
     L.gmsx_graph_upload_csr_shard.argtypes = [vp, C.c_uint32, C.c_int, C.c_int, vpp]
     L.gmsx_graph_free.argtypes = [vp]
     L.gmsx_graph_prepare.argtypes = [vp, C.c_uint32]
+    L.gmsx_graph_tc_passes.argtypes = [vp]
     for f in (L.gmsx_graph_num_nodes, L.gmsx_graph_num_edges, L.gmsx_graph_device_bytes):
         f.restype = C.c_int64
         f.argtypes = [vp]
@@ -273,6 +274,7 @@ class DeviceGraph:
     num_edges = property(lambda self: lib().gmsx_graph_num_edges(self._h))
     device_bytes = property(lambda self: lib().gmsx_graph_device_bytes(self._h))
     max_out_degree = property(lambda self: lib().gmsx_graph_max_out_degree(self._h))
+    tc_passes = property(lambda self: lib().gmsx_graph_tc_passes(self._h))
 
     def prepare(self, what=PREPARE_TC):
         """gmsx_graph_prepare: build the optional containers (triangle-count task lists) now instead of on first use."""

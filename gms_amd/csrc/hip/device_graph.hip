@@ -713,6 +713,10 @@ static int grid_for_waves(int64_t rows) {
 template <class T>
 static int dmalloc(T **p, int64_t count, gmsx_graph *g) {
     const size_t bytes = size_t(count > 0 ? count : 1) * sizeof(T);
+    if (g && g->tc_building && g->tc_limit_bytes > 0 && g->device_bytes + int64_t(bytes) - g->tc_base_bytes > g->tc_limit_bytes) {
+        *p = nullptr;  // test hook: pretend the device is this small
+        return GMSX_ERR_DEVICE_MEM;
+    }
     if (hipMalloc(reinterpret_cast<void **>(p), bytes) != hipSuccess) {
         (void)hipGetLastError();
         *p = nullptr;
@@ -1361,18 +1365,53 @@ static int build_tc_sets(gmsx_graph *g) {
     return GMSX_OK;
 }
 
-int ensure_tc(const gmsx_graph *cg) {
-    gmsx_graph *g = const_cast<gmsx_graph *>(cg);  // handles are single-threaded; the build only adds containers, nothing a caller can observe changes
-    if (g->tc_ready) return GMSX_OK;
-    const int64_t before = g->device_bytes;
+static int build_tc_once(gmsx_graph *g) {
+    g->tc_base_bytes = g->device_bytes;
+    g->tc_building = true;
     const int rc = build_tc_sets(g);
-    g->tc_bytes = g->device_bytes - before;
+    g->tc_building = false;
+    g->tc_bytes = g->device_bytes - g->tc_base_bytes;
     if (rc) {
         free_tc(g);
         return rc;
     }
     g->tc_ready = true;
     return GMSX_OK;
+}
+
+int ensure_tc(const gmsx_graph *cg) {
+    gmsx_graph *g = const_cast<gmsx_graph *>(cg);  // handles are single-threaded; the build only adds containers, nothing a caller can observe changes
+    if (g->tc_ready) return GMSX_OK;
+    if (const char *e = std::getenv("GMSX_TC_MEM_LIMIT_MB")) {  // test hook: the budget of the triangle-count containers
+        const long long v = std::atoll(e);
+        g->tc_limit_bytes = v > 0 ? int64_t(v) << 20 : 0;
+    }
+    int rc = build_tc_once(g);
+    if (rc == GMSX_ERR_DEVICE_MEM && g->shard_nparts == 1) {
+        // the containers of all pivots do not fit: halve the share of the pivots that is resident until it does (the base layout and the
+        // stream rows stay; inline rows and task lists shrink with the share).  Calls then walk the passes (tc.hip).
+        (void)hipGetLastError();
+        for (int k = 2; k <= 4096 && rc == GMSX_ERR_DEVICE_MEM; k *= 2) {
+            g->shard_part = 0;
+            g->shard_nparts = k;
+            rc = build_tc_once(g);
+            if (rc == GMSX_OK) g->tc_passes = k;
+        }
+        if (rc) {
+            g->shard_part = 0;
+            g->shard_nparts = 1;
+        }
+    }
+    return rc;
+}
+
+int ensure_tc_shard(const gmsx_graph *cg, int part, int nparts) {
+    gmsx_graph *g = const_cast<gmsx_graph *>(cg);
+    if (g->tc_ready && g->shard_part == part && g->shard_nparts == nparts) return GMSX_OK;
+    free_tc(g);
+    g->shard_part = part;
+    g->shard_nparts = nparts;
+    return build_tc_once(g);
 }
 
 int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out) {
@@ -1510,6 +1549,8 @@ int gmsx_graph_prepare(gmsx_graph *g, uint32_t what) {
         if (int rc = ensure_tc(g)) return rc;
     return GMSX_OK;
 }
+
+int gmsx_graph_tc_passes(const gmsx_graph *g) { return !g ? GMSX_ERR_INVALID : (g->tc_ready ? g->tc_passes : 0); }
 
 int gmsx_graph_free(gmsx_graph *g) {
     free_graph(g);

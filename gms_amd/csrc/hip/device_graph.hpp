@@ -114,6 +114,11 @@ struct gmsx_graph {
     mutable int32_t rank_ok_first = 0, rank_ok_last = 0;
     // the triangle-count containers (stream rows, inline rows, task lists …) are built on demand: ensure_tc()
     int shard_part = 0, shard_nparts = 1;   // gmsx_graph_upload_shard: the triangle-count containers hold this rank's pivots only
+    // FALLBACK when the triangle-count containers of the whole graph do not fit the device: they are built for 1/tc_passes of the pivots at
+    // a time (the sharded-upload machinery, shards = passes) and a call walks the passes, rebuilding between them — slower, never refused
+    int tc_passes = 1;
+    int64_t tc_limit_bytes = 0, tc_base_bytes = 0;  // GMSX_TC_MEM_LIMIT_MB (test hook): budget of the containers; device_bytes before them
+    bool tc_building = false;
     bool tc_ready = false;
     int64_t tc_bytes = 0;                   // their share of device_bytes
     int hub_limit = 0;                      // hub id range this graph was built with (kHub unless the test hook shrank it)
@@ -169,6 +174,8 @@ int kclique_vertex_counts(const gmsx_graph *g, unsigned long long *d_counts, gms
 int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out);
 // builds the triangle-count containers of the (otherwise immutable) graph if they are not there yet (device_graph.hip)
 int ensure_tc(const gmsx_graph *g);
+// … for one shard / pass (frees and rebuilds when another one is resident)
+int ensure_tc_shard(const gmsx_graph *g, int part, int nparts);
 // counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| into a zeroed device array (pairs.hip); shared by the per-vertex count and the TC ordering
 int tc_vertex_counts_device(const gmsx_graph *g, unsigned long long *d_counts, gmsx_stats *st);
 // GMSX_TC_FULL: every edge u<v intersects the FULL rows (pairs.hip); returns the un-divided sum of the shard

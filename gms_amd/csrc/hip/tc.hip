@@ -439,10 +439,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         constexpr int FORM = decltype(form_tag)::value;
         cnt += scan_form(sdesc, spool, cbeg, cend, FORM, tid, [](uint4 p, int j) { return hub_unit_hits<FORM>(bm, p, j); });
     };
+#ifndef GMSX_TC_STAGING_ONLY  // (A/B build: what the per-item fixed cost alone takes)
     run(std::integral_constant<int, kFormList>{});
     run(std::integral_constant<int, kFormBitset>{});
     run(std::integral_constant<int, kFormDelta>{});
     run(std::integral_constant<int, kFormGap12>{});
+#endif
     block_add(cnt, red, lane, wave, tid, acc);
 }
 
@@ -489,8 +491,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             constexpr int FORM = decltype(form_tag)::value;
             cnt += scan_form(sdesc, tpool, cbeg, cend, FORM, tid, [mask, shift](uint4 p, int) { return tail_unit_hits_f<FORM>(flt, tbl, mask, shift, p); });
         };
+#ifndef GMSX_TC_STAGING_ONLY
         run(std::integral_constant<int, kFormList>{});
         run(std::integral_constant<int, kFormDelta>{});
+#endif
     }
     block_add(cnt, red, lane, wave, tid, acc);
 }
@@ -862,8 +866,42 @@ static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
     return span <= 0 ? 0 : (span + nparts - 1) / nparts;
 }
 
+static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, gmsx_stats *st);
+
 static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *partial, gmsx_stats *st) {
     if (int rc = ensure_tc(g)) return rc;  // first call on a graph uploaded without GMSX_UPLOAD_FOR_TC: builds the task lists (untimed)
+    if (g->tc_passes == 1) return tc_one(g, part, nparts, partial, st);
+    // FALLBACK (device_graph.hpp, tc_passes): the containers of all pivots did not fit.  A whole-graph call walks the passes — shard p of
+    // tc_passes resident at a time, rebuilt between the passes (untimed like every build; kernel_ms is the sum of the passes' kernels); a
+    // sharded call builds exactly its shard.
+    if (nparts > 1) {
+        if (int rc = ensure_tc_shard(g, part, nparts)) return rc;
+        return tc_one(g, part, nparts, partial, st);
+    }
+    uint64_t total = 0;
+    gmsx_stats sum{};
+    for (int p = 0; p < g->tc_passes; ++p) {
+        if (int rc = ensure_tc_shard(g, p, g->tc_passes)) return rc;
+        uint64_t pp = 0;
+        gmsx_stats sp{};
+        if (int rc = tc_one(g, p, g->tc_passes, &pp, st ? &sp : nullptr)) return rc;
+        total += pp;
+        sum.kernel_ms += sp.kernel_ms;
+        sum.setup_ms += sp.setup_ms;
+        sum.units += sp.units;
+        sum.probes += sp.probes;
+        sum.stream_bytes += sp.stream_bytes;
+        sum.launches += sp.launches;
+    }
+    *partial = total;
+    if (st) {
+        sum.alg_elements = g->alg_elements;
+        *st = sum;
+    }
+    return GMSX_OK;
+}
+
+static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, gmsx_stats *st) {
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     unsigned long long *acc = g->acc;  // persistent per-graph accumulators: no allocation on the call path
@@ -1040,7 +1078,7 @@ int gmsx_tc_partial(const gmsx_graph *g, int algo, int part, int nparts, uint64_
     if (int rc = ensure_init()) return rc;
     if (algo == GMSX_TC_FULL) return tc_full_partial(g, part, nparts, partial, stats);
     // a sharded upload holds the task lists of ONE shard: that is the only one it can count
-    if (g->shard_nparts > 1 && (nparts != g->shard_nparts || part != g->shard_part)) return GMSX_ERR_INVALID;
+    if (g->tc_passes == 1 && g->shard_nparts > 1 && (nparts != g->shard_nparts || part != g->shard_part)) return GMSX_ERR_INVALID;
     return tc_oriented(g, part, nparts, partial, stats);
 }
 

@@ -162,6 +162,9 @@ int gmsx_graph_upload_csr_shard(const gmsx_csr *g, uint32_t flags, int part, int
 /* Builds optional containers of an uploaded graph ahead of their first use (so that a caller can time or place the cost). */
 enum { GMSX_PREPARE_TC = 1 /* the triangle-count containers, see GMSX_UPLOAD_FOR_TC */ };
 int gmsx_graph_prepare(gmsx_graph *g, uint32_t what);
+/* 0 = the triangle-count containers are not built yet; 1 = they hold every pivot (the normal case); k > 1 = they did not fit the device:
+ * 1/k of the pivots is resident at a time and every gmsx_tc_* call walks k passes, rebuilding between them (slower, never refused). */
+int gmsx_graph_tc_passes(const gmsx_graph *g);
 int gmsx_graph_free(gmsx_graph *g);
 int64_t gmsx_graph_num_nodes(const gmsx_graph *g);   /* SetGraph::num_nodes, set_graph.h:115-118 */
 int64_t gmsx_graph_num_edges(const gmsx_graph *g);   /* undirected edges m */

@@ -280,6 +280,44 @@ def test_shards_of_separate_processes_add_up(gpu):
     assert max(rec["bytes_sharded"]) < 0.85 * rec["bytes_full"], rec  # a third of the task lists and inline rows each (scale 19: 0.75; scale 26: 0.45)
 
 
+def test_containers_that_do_not_fit_fall_back_to_passes(gpu, oracle):
+    """When the triangle-count containers of the whole graph do not fit the device, the library builds them for 1/k of the pivots at a time
+    and walks k passes instead of returning GMSX_ERR_DEVICE_MEM.  GMSX_TC_MEM_LIMIT_MB (test hook) pretends the device is small: RMAT scale
+    18 needs ~0.3 GB of containers; with a 96 MB budget the count, the units, the shard sums and the per-vertex path stay exact."""
+    csr = host_graph(gpu, "kronecker", 18)
+    want = oracle.tc_total(csr.offsets(), csr.neighbors())
+    g0 = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_FOR_TC)
+    assert g0.tc_passes == 1
+    full_bytes = g0.device_bytes
+    t0, st0 = g0.tc_total(stats=True)
+    g0.free()
+    old = os.environ.get("GMSX_TC_MEM_LIMIT_MB")
+    os.environ["GMSX_TC_MEM_LIMIT_MB"] = "96"
+    try:
+        g = gpu.DeviceGraph.from_csr(csr)
+        assert g.tc_passes == 0                      # lazy: nothing built yet
+        t, st = g.tc_total(stats=True)
+        assert g.tc_passes >= 2 and g.device_bytes < full_bytes
+        assert t == t0 == want and st["units"] == csr.num_edges and st["stream_bytes"] > 0 and st["kernel_ms"] > 0
+        assert g.tc_total() == want                  # walks the passes again
+        assert sum(g.tc_partial(p, 3) for p in range(3)) == want   # a sharded call builds exactly its shard
+        assert g.tc_total() == want
+        assert g.kclique_count(3)[1] == want         # the base layout is untouched
+        g.free()
+        os.environ["GMSX_TC_MEM_LIMIT_MB"] = "1"     # nothing fits, not even 1/4096 of the pivots: the one refusal left
+        g = gpu.DeviceGraph.from_csr(csr)
+        with pytest.raises(gpu.GmsxError) as ei:
+            g.tc_total()
+        assert ei.value.status == gpu.ERR_DEVICE_MEM
+        assert g.kclique_count(3)[1] == want
+        g.free()
+    finally:
+        if old is None:
+            os.environ.pop("GMSX_TC_MEM_LIMIT_MB", None)
+        else:
+            os.environ["GMSX_TC_MEM_LIMIT_MB"] = old
+
+
 def test_random_small_graphs_all_paths(gpu, oracle):
     """Many small random graphs (sparse, dense, clustered, star-heavy) under hub limits that push ids into the tail containers and inline
     limits that move members between the inline rows and the light-pivot kernel: forward / reverse / cut / inline / first-member entries
