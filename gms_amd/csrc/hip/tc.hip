@@ -348,15 +348,21 @@ __device__ __forceinline__ uint32_t scan_class(const unsigned long long *sdesc, 
     uint32_t cnt = 0;
     int e = lo + g;
     unsigned long long d = e < hi ? sdesc[e] : 0ull;
+    // The FIRST unit of a group's next row is loaded while its current row is probed: short rows (the tail rows average 14 units, one step
+    // of a 16-lane group) otherwise leave one load per group in flight behind a descriptor read — 3.6 TB/s for the tail items against
+    // 7 TB/s for the hub items (serial kernel trace, scale 26).
+    uint4 p0 = make_uint4(0u, 0u, 0u, 0u);
+    if (sub < int(uint32_t(d) & 0x3fffffu)) p0 = (reinterpret_cast<const uint4 *>(pool) + (d >> 24))[sub];
     while (e < hi) {  // the groups of a wave differ by at most one trip
         const int en = e + G;
         const unsigned long long dn = en < hi ? sdesc[en] : 0ull;
-        const uint4 *row = reinterpret_cast<const uint4 *>(pool) + (d >> 24);
+        uint4 pn = make_uint4(0u, 0u, 0u, 0u);
+        if (sub < int(uint32_t(dn) & 0x3fffffu)) pn = (reinterpret_cast<const uint4 *>(pool) + (dn >> 24))[sub];
         const int units = int(uint32_t(d) & 0x3fffffu);
-        if (ONE_STEP) {
-            if (sub < units) cnt += hit(row[sub], sub);
-        } else {
-            int j = sub;
+        if (sub < units) cnt += hit(p0, sub);
+        if (!ONE_STEP) {  // (ONE_STEP: the classes of the run guarantee units <= W)
+            const uint4 *row = reinterpret_cast<const uint4 *>(pool) + (d >> 24);
+            int j = sub + W;
             for (; j + W < units; j += 2 * W) {
                 const uint4 p = row[j], q = row[j + W];
                 cnt += hit(p, j);
@@ -366,6 +372,7 @@ __device__ __forceinline__ uint32_t scan_class(const unsigned long long *sdesc, 
         }
         e = en;
         d = dn;
+        p0 = pn;
     }
     return cnt;
 }
@@ -926,7 +933,8 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     // erratic (1); scale 22 3.56 serial, 4.45 co-scheduled.  So the light kernel moves aside from 2^23 vertices on.
     const bool sides = overlap && c.side[0] && c.side[1];
     const bool co_wave = sides && g->hitems > 0 && cnt_light > 0 && (overlap > 1 || g->n >= (int64_t(1) << 23));
-    const bool co_tail = sides && g->hitems > 0 && g->titems > 0;
+    const int tail_mode = [] { const char *e = std::getenv("GMSX_TC_TAIL"); return e ? std::atoi(e) : 1; }();  // A/B: 0 = tail items behind the hub items on the launch stream, 2 = before them
+    const bool co_tail = sides && g->hitems > 0 && g->titems > 0 && tail_mode == 1;
     hipStream_t s_wave = co_wave ? c.side[1] : s, s_tail = co_tail ? c.side[0] : s;
     struct Join {  // joins the side streams on every way out once they were forked (error returns included)
         Ctx &c;
@@ -955,11 +963,15 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
         ++launches;
     };
     if (co_wave) launch_light();
+    if (g->titems > 0 && tail_mode == 2) {
+        hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(g->titems)), dim3(256), 0, s, g->toff, g->tadj, g->tpool, g->ttask, g->titem, g->titems, nparts, part, acc);
+        ++launches;
+    }
     if (g->hitems > 0) {
         hipLaunchKernelGGL(k_tc_block, dim3(unsigned(g->hitems)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->htask, g->hitem, g->hitems, nparts, part, acc);
         ++launches;
     }
-    if (g->titems > 0) {
+    if (g->titems > 0 && tail_mode != 2) {
         hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(g->titems)), dim3(256), 0, s_tail, g->toff, g->tadj, g->tpool, g->ttask, g->titem, g->titems, nparts, part, acc);
         ++launches;
     }
