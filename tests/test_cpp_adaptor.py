@@ -32,6 +32,33 @@ def test_driver_builds_and_rejects_bad_usage(capi):
     assert subprocess.run([exe, "tc", "--bogus"]).returncode == 100     # unparsable flags (cli/cli.h:122-127)
 
 
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_have_gpu(), reason="exercises the failure path of a GPU-less host")
+def test_gpus_launcher_reaps_failed_ranks_instead_of_hanging(capi):
+    """`--gpus N` forks its ranks and supervises them with waitpid(-1): a rank that ends non-zero (here: every rank, gmsx_init finds no HIP
+    device) takes the others down instead of leaving them in a collective without a timeout.  The launcher returns the failing
+    rank's status, promptly, removes its id file, and refuses to fork ranks under a profiler preload."""
+    import glob
+    import time
+    exe = os.path.join(ROOT, "gms_amd", "lib", "gmsx_driver")
+    before = set(glob.glob("/tmp/gmsx_driver_id_*"))
+    t0 = time.time()
+    r = subprocess.run([exe, "tc", "-g", "kronecker", "6", "--gpus", "3", "-n", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and time.time() - t0 < 60, (r.returncode, r.stderr)
+    assert "a rank ended with status 3" in r.stderr and "no HIP device" in r.stdout
+    assert set(glob.glob("/tmp/gmsx_driver_id_*")) == before
+    r = subprocess.run([exe, "tc", "-g", "kronecker", "6", "--gpus", "2"], capture_output=True, text=True, timeout=60,
+                       env=dict(os.environ, ROCPROF_TEST_MARKER="1"))
+    assert r.returncode == 6 and "profiler library is preloaded" in r.stderr
+
+
 @pytest.mark.gpu
 def test_driver_runs_every_kernel_with_reference_output_lines(gpu):
     exe = os.path.join(ROOT, "gms_amd", "lib", "gmsx_driver")
