@@ -950,26 +950,41 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     // Two streams: the wide bins (slab, 1024, 704: one or two workgroups per CU, LDS-bound occupancy) on the caller's
     // stream, the narrow bins and the wave kernel on a side stream — their small workgroups fill the wave slots and the
     // LDS the wide ones leave free.  All kernels add into the same accumulators; the side stream is joined below.
-    static hipStream_t side = nullptr;
-    static hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (!side) {
-        GMSX_HIP(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    // FOUR streams (round 3; two before): the bins differ in workgroup size and LDS footprint (one workgroup per CU for the 1024-wide
+    // matrices … sixteen for the narrow ones), each leaves wave slots and LDS the others can use, and a bin's last workgroups no longer hold
+    // up the next bin of the same stream.  GMSX_KC_STREAMS=1 … 4 (A/B).
+    constexpr int kSides = 3;
+    static hipStream_t sides[kSides] = {nullptr, nullptr, nullptr};
+    static hipEvent_t ev_fork = nullptr, ev_joins[kSides] = {nullptr, nullptr, nullptr};
+    if (!sides[0]) {
+        for (int i = 0; i < kSides; ++i) {
+            GMSX_HIP(hipStreamCreateWithFlags(&sides[i], hipStreamNonBlocking));
+            GMSX_HIP(hipEventCreateWithFlags(&ev_joins[i], hipEventDisableTiming));
+        }
         GMSX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        GMSX_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     }
+    const int n_streams = [] { const char *e = std::getenv("GMSX_KC_STREAMS"); const int v = e ? std::atoi(e) : 4; return v < 1 ? 1 : v > 4 ? 4 : v; }();
     GMSX_HIP(hipEventRecord(ev_fork, s));
-    GMSX_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-    // every way out of this function joins the side stream again — error returns included, so that no later call on the launch
+    for (int i = 0; i < kSides; ++i) GMSX_HIP(hipStreamWaitEvent(sides[i], ev_fork, 0));
+    hipStream_t side = n_streams > 1 ? sides[0] : s;
+    int next_stream = 0;
+    auto pick = [&]() -> hipStream_t {  // round robin over the launch stream and the side streams in use
+        const int i = next_stream++ % n_streams;
+        return i == 0 ? s : sides[i - 1];
+    };
+    // every way out of this function joins the side streams again — error returns included, so that no later call on the launch
     // stream can overtake kernels still running beside it
     struct Join {
-        hipStream_t main, side;
-        hipEvent_t ev;
+        hipStream_t main;
+        hipStream_t *sides;
+        hipEvent_t *evs;
         bool armed = true;
         ~Join() {
-            if (armed && hipEventRecord(ev, side) == hipSuccess) (void)hipStreamWaitEvent(main, ev, 0);
+            if (!armed) return;
+            for (int i = 0; i < kSides; ++i)
+                if (hipEventRecord(evs[i], sides[i]) == hipSuccess) (void)hipStreamWaitEvent(main, evs[i], 0);
         }
-    } join{s, side, ev_join};
-
+    } join{s, sides, ev_joins};
     // L: 1024 < d+ <= 4096 (8192 for k <= 4), bit-matrix in a global slab per workgroup; one launch per row width (one / two / four words per lane)
     constexpr int NL = (LV <= 2) ? 3 : 2;
     size_t slab_bytes[3] = {0, 0, 0};
@@ -1031,7 +1046,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             const size_t lds = size_t(dmax) * WS * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + (VTX ? size_t(dmax) * 4 : 0);
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
             const int threads = dmax >= 704 ? 1024 : dmax >= 384 ? 512 : 256;
-            hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX>), dim3(unsigned(blocks)), dim3(threads), lds, dmax >= 704 ? s : side, g->hoff, g->hadj, g->toff,
+            hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX>), dim3(unsigned(blocks)), dim3(threads), lds, n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj, g->toff,
                                g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts);
             ++*launches;
         }
@@ -1049,8 +1064,10 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         }
     }
     join.armed = false;
-    GMSX_HIP(hipEventRecord(ev_join, side));
-    GMSX_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    for (int i = 0; i < kSides; ++i) {
+        GMSX_HIP(hipEventRecord(ev_joins[i], sides[i]));
+        GMSX_HIP(hipStreamWaitEvent(s, ev_joins[i], 0));
+    }
     return GMSX_OK;
 }
 

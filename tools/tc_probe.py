@@ -1,5 +1,5 @@
 """GPU probe: triangle count on RMAT scale(s) — count vs the reference golden, best-of-N pass time, upload / container-build times.
-usage: python tools/tc_probe.py 22 24 26 [--passes 5]"""
+usage: python tools/tc_probe.py 22 24 26 [--passes 5] [--shards 8]   (--shards N: also the kernel time of every shard of N on this one GPU)"""
 import json
 import os
 import sys
@@ -8,8 +8,16 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gms_amd import capi  # noqa: E402
 
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
-passes = int(sys.argv[sys.argv.index("--passes") + 1]) if "--passes" in sys.argv else 5
+opts = {}
+args = []
+it = iter(sys.argv[1:])
+for a in it:
+    if a.startswith("--"):
+        opts[a] = int(next(it))
+    else:
+        args.append(a)
+passes = opts.get("--passes", 5)
+nshards = opts.get("--shards", 0)
 with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "graphs.json")) as f:
     GOLD = json.load(f)
 capi.init(0)
@@ -33,7 +41,12 @@ for s in (int(a) for a in args):
         ms.append(round(st["kernel_ms"], 3))
     gold = GOLD.get("kronecker-%d-16-relabel" % s, {}).get("triangles")
     shards = sum(g.tc_partial(p, 3) for p in range(3))
-    print(json.dumps({"scale": s, "m": csr.num_edges, "triangles": t, "golden_ok": (t == gold) if gold is not None else None, "shards_ok": shards == t,
+    shard_ms = None
+    if nshards > 1:
+        parts = [min((g.tc_partial(p, nshards, stats=True) for _ in range(3)), key=lambda r: r[1]["kernel_ms"]) for p in range(nshards)]
+        assert sum(p[0] for p in parts) == t
+        shard_ms = [round(p[1]["kernel_ms"], 2) for p in parts]
+    print(json.dumps({"scale": s, "m": csr.num_edges, "shard_kernel_ms": shard_ms, "triangles": t, "golden_ok": (t == gold) if gold is not None else None, "shards_ok": shards == t,
                       "units_ok": st["units"] == csr.num_edges, "kernel_ms": ms, "best_G_edges_per_s": round(csr.num_edges / min(ms) / 1e6, 3),
                       "upload_s": round(t_up, 3), "build_tc_s": round(t_tc, 3), "stream_GB": round(st["stream_bytes"] / 1e9, 2), "probes_G": round(st["probes"] / 1e9, 2),
                       "device_GB": round(g.device_bytes / 1e9, 2)}), flush=True)
