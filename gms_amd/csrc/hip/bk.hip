@@ -244,6 +244,50 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                 xf_ne = int(xfne_stack[depth]);
                 continue;
             }
+            // FAST PATH: one candidate left (the commonest node of the whole search tree).  Whatever the pivot, the node has at most the
+            // branch q = that candidate, whose child has P' = {} — so the node yields one maximal clique iff no finished vertex is
+            // adjacent to q (Xc ∩ N(q) = Xf ∩ N(q) = {}), and nothing otherwise (a pivot adjacent to q removes the branch; tomita.h:12-40,
+            // 51-86 reaches the same two outcomes through findPivot + one more expand).  No pivot scoring, no push / pop of a level.
+            {
+                int lanes_nz = 0;
+#pragma unroll
+                for (int h = 0; h < WPL; ++h) lanes_nz += __popcll(__ballot(P[h] != 0));
+                if (lanes_nz == 1) {  // wave-uniform
+                    int hsel = 0;
+#pragma unroll
+                    for (int h = 0; h < WPL; ++h)
+                        if (__ballot(P[h] != 0)) hsel = h;
+                    unsigned long long nzl = 0;
+                    uint32_t pw = 0;
+#pragma unroll
+                    for (int h = 0; h < WPL; ++h)
+                        if (h == hsel) {
+                            nzl = __ballot(P[h] != 0);
+                            pw = __builtin_amdgcn_readlane(P[h], __ffsll((long long)nzl) - 1);
+                        }
+                    if ((pw & (pw - 1u)) == 0u) {
+                        const int q = ((__ffsll((long long)nzl) - 1 + 64 * hsel) << 5) + __ffs(pw) - 1;
+                        uint32_t any = 0;
+#pragma unroll
+                        for (int h = 0; h < WPL; ++h) {
+                            const int w = lane + 64 * h;
+                            any |= w < cw ? (Xc[h] & Cadj[size_t(q) * cw + w]) : 0u;
+                        }
+                        if (xf_ne) {
+                            const uint32_t *lvx = stack + size_t(depth) * lvl + 3 * cw;
+                            const uint32_t *xt = XT + size_t(q) * xw;
+                            for (int w = lane; w < xw; w += 64) any |= lvx[w] & xt[w];
+                        }
+                        if (__ballot(any != 0) == 0) cnt++;
+                        entering = false;
+                        if (depth == 0) break;
+                        --depth;  // pop
+                        pop_level(stack + size_t(depth) * lvl);
+                        xf_ne = int(xfne_stack[depth]);
+                        continue;
+                    }
+                }
+            }
             // pivot: argmax over u in P ∪ Xc of |P ∩ N(u)|.  One LANE per candidate: P is parked in LDS, the members of
             // P ∪ Xc are expanded into an LDS list (wave prefix sum of the per-word popcounts), then every lane scores its
             // own candidates with independent row loads (64 rows in flight instead of one dependent load per candidate).
@@ -1181,12 +1225,19 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipMemGetInfo(&free_b, &total_b));
     const unsigned long long budget_bytes = std::min<unsigned long long>(free_b / 4, 16ull << 30);
     BkShared sh{};
-    sh.arena_cap = std::min<unsigned long long>(free_b / 4, 48ull << 30) / 4;  // Cadj | XT of the start vertices of a chunk + of the LDS-slab searches that split
+    // the arena (Cadj | XT of the start vertices of a chunk + of the LDS-slab searches that split) is sized by NEED once the layout of the
+    // start vertices is known — a fixed 48 GB allocation per call cost seconds of first-touch time now and then
+    const unsigned long long arena_hard_cap = std::min<unsigned long long>(free_b / 4, 48ull << 30) / 4;
+    auto alloc_arena = [&](unsigned long long want_words) -> int {
+        sh.arena_cap = std::min(arena_hard_cap, std::max<unsigned long long>(want_words, (256ull << 20) / 4));
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&sh.arena), sh.arena_cap * 4));
+        g_arena.p = sh.arena;
+        return GMSX_OK;
+    };
     sh.pool_cap = std::min<unsigned long long>(free_b / 16, 2ull << 30) / 4;
     sh.dir_cap = 8ull << 20;
     uint32_t *pools[2] = {nullptr, nullptr};
     unsigned long long *dirs[2] = {nullptr, nullptr};
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&sh.arena), sh.arena_cap * 4)); g_arena.p = sh.arena;
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&pools[0]), sh.pool_cap * 4)); g_pool0.p = pools[0];
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&pools[1]), sh.pool_cap * 4)); g_pool1.p = pools[1];
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dirs[0]), sh.dir_cap * 8)); g_dir0.p = dirs[0];
@@ -1347,6 +1398,10 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
             }
             unsigned long long mx[2] = {0, 0};
             GMSX_HIP(hipMemcpy(mx, maxima, sizeof(mx), hipMemcpyDeviceToHost));
+            int64_t need_total = 0;
+            GMSX_HIP(hipMemcpy(&need_total, aoff + cnt_glob, 8, hipMemcpyDeviceToHost));
+            // the roots may take 3/4 of the arena (below): everything in one chunk when the device allows, + room for the LDS-slab searches that split
+            if (int rc = alloc_arena((unsigned long long)need_total / 3 * 4 + (512ull << 20) / 4)) return rc;
             const unsigned long long map_words = split_build >= 2 ? 0ull : (mx[1] + 3ull) & ~3ull;
             const int64_t build_waves = std::min<int64_t>(cnt_glob, int64_t(cu) * 24);
             uint32_t *map_scratch = nullptr;
@@ -1397,10 +1452,13 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
             }
         }
         if (!tiny_done) {
+            if (!sh.arena)
+                if (int rc = alloc_arena(std::min<unsigned long long>(free_b / 8, 8ull << 30) / 4)) return rc;
             if (int rc = launch_tiny(n_glob, n_tasks, false)) return rc;
             if (int rc = run_rounds()) return rc;
         }
     } else {
+        if (int rc = alloc_arena(std::min<unsigned long long>(free_b / 8, 8ull << 30) / 4)) return rc;
         int64_t lo = 0;
         while (lo < n_tasks) {
             const bool wide = lo < n_wide;
