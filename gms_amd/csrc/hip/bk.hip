@@ -493,6 +493,25 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
             Xcn[h] = Xc[h] & qrow;
         }
         uint32_t *lv = stack + size_t(depth) * lvl;
+        if (__ballot(any_of(Pn) != 0) == 0) {
+            // FAST PATH: the child has no candidate — it is a leaf: one maximal clique iff no finished vertex is adjacent to all of R ∪ {q}.
+            // Decided right here (no level pushed, entered and popped again); the node goes on with q moved from cand to fini.
+            uint32_t any = any_of(Xcn);
+            if (xf_ne && __ballot(any != 0) == 0) {
+                const uint32_t *xt = XT + size_t(q) * xw;
+                for (int w = lane; w < xw; w += 64) any |= lv[3 * cw + w] & xt[w];
+            }
+            if (__ballot(any != 0) == 0) cnt++;
+            ++nodes;
+#pragma unroll
+            for (int h = 0; h < WPL; ++h)
+                if (h == hsel && lane == L) {
+                    ext[h] &= ~(1u << bit);
+                    P[h] &= ~(1u << bit);
+                    Xc[h] |= 1u << bit;
+                }
+            continue;
+        }
         uint32_t *nx = lv + lvl;
         int child_ne = 0;
         if (xf_ne) {
@@ -1266,11 +1285,6 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     sh.pool = pools[cur];
     sh.dir = dirs[cur];
     GMSX_HIP(hipMemsetAsync(sh.dir, 0xff, sh.dir_cap * 8, s));
-    GMSX_HIP(hipEventRecord(c.ev[1], s));
-
-    // ---- round 0.  Start vertices whose structures fit an LDS slab (<= kLdsSlabWords): one wave builds and searches (k_bk_wave<true>).
-    //      The others (GMSX_BK_SPLIT_BUILD=0 restores round 2's one-kernel bins): k_bk_build writes Cadj | XT into the arena and a root
-    //      record per start vertex, in chunks that fit the arena and the record pool; the resume rounds below search them.
     // 2 (default): k_bk_block, a workgroup per start vertex, rows streamed against an LDS bitmap; 1: k_bk_build, a wave per start vertex with
     // the hash-map build of k_bk_wave; 0: round 2's combined build + search bins
     const int split_build = [] { const char *e = std::getenv("GMSX_BK_SPLIT_BUILD"); return e ? std::atoi(e) : 2; }();
@@ -1278,11 +1292,67 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     while (n_tasks < n && words[size_t(n_tasks)] > 0) ++n_tasks;
     int64_t n_glob = 0;  // tasks beyond an LDS slab: sorted first (the wide ones, > 2048 candidates, at the very front)
     while (n_glob < n_tasks && (n_glob < n_wide || words[size_t(n_glob)] > (unsigned long long)kLdsSlabWords)) ++n_glob;
+    // LAYOUT of the start vertices that get their own build kernel (arena and record offsets by prefix sums) and the arena itself: setup like
+    // the task sort above — allocations of gigabytes now and then stall for a second, they are not part of the kernels' time
+    const int64_t cnt_glob = split_build ? part_count(0, n_glob, nparts, part) : 0;
+    int64_t *need_a = nullptr, *need_r = nullptr, *aoff = nullptr, *roff = nullptr, *d_end = nullptr;
+    Guard g_na, g_nr, g_ao, g_ro, g_de, g_map;
+    unsigned long long *maxima = acc + kCtl + 9;  // [0] stack words, [1] global map words
+    unsigned long long mx[2] = {0, 0}, map_words = 0;
+    int64_t build_waves = 0;
+    uint32_t *map_scratch = nullptr;
+    if (cnt_glob > 0) {
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&need_a), size_t(cnt_glob + 1) * 8)); g_na.p = need_a;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&need_r), size_t(cnt_glob + 1) * 8)); g_nr.p = need_r;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&aoff), size_t(cnt_glob + 1) * 8)); g_ao.p = aoff;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&roff), size_t(cnt_glob + 1) * 8)); g_ro.p = roff;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_end), 8)); g_de.p = d_end;
+        GMSX_HIP(hipMemsetAsync(maxima, 0, 16, s));
+        hipLaunchKernelGGL(k_bk_layout, dim3(unsigned(cnt_glob / 256 + 1)), dim3(256), 0, s, int64_t(0), cnt_glob, nparts, part, v_out, g->off, g->oldid, g->dplus,
+                           split_build >= 2 ? 1 : 0, need_a, need_r, maxima);
+        {
+            size_t scan_bytes = 0;
+            GMSX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, need_a, aoff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
+            void *scan_tmp = nullptr;
+            GMSX_HIP(hipMalloc(&scan_tmp, scan_bytes ? scan_bytes : 8));
+            Guard g_scan;
+            g_scan.p = scan_tmp;
+            GMSX_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, need_a, aoff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
+            GMSX_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, need_r, roff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
+            GMSX_HIP(hipStreamSynchronize(s));
+        }
+        GMSX_HIP(hipMemcpy(mx, maxima, sizeof(mx), hipMemcpyDeviceToHost));
+        int64_t need_total = 0;
+        GMSX_HIP(hipMemcpy(&need_total, aoff + cnt_glob, 8, hipMemcpyDeviceToHost));
+        // the roots may take 3/4 of the arena (below): everything in one chunk when the device allows, + room for the LDS-slab searches that split
+        if (int rc = alloc_arena((unsigned long long)need_total / 3 * 4 + (512ull << 20) / 4)) return rc;
+        map_words = split_build >= 2 ? 0ull : (mx[1] + 3ull) & ~3ull;
+        build_waves = std::min<int64_t>(cnt_glob, int64_t(cu) * 24);
+        if (map_words > 0) {
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&map_scratch), size_t(build_waves) * map_words * 4));
+            g_map.p = map_scratch;
+        }
+    }
+    // the stack slabs of the resume kernel (grow-only, reused by every round): for the root round their size is known from the layout
+    Guard g_rslab;
+    size_t resume_cap = 0;
+    if (cnt_glob > 0 && mx[0] > 0) {
+        const unsigned long long slab_bytes = ((mx[0] + 3ull) & ~3ull) * 4ull;
+        if (slab_bytes <= budget_bytes) {
+            const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({cnt_glob, int64_t(cu) * 24, int64_t(budget_bytes / slab_bytes)}));
+            resume_cap = size_t(waves) * slab_bytes;
+            GMSX_HIP(hipMalloc(&g_rslab.p, resume_cap));
+        }
+    }
+    GMSX_HIP(hipStreamSynchronize(s));
+    GMSX_HIP(hipEventRecord(c.ev[1], s));
+
+    // ---- round 0.  Start vertices whose structures fit an LDS slab (<= kLdsSlabWords): one wave builds and searches (k_bk_wave<true>).
+    //      The others (GMSX_BK_SPLIT_BUILD=0 restores round 2's one-kernel bins): k_bk_build writes Cadj | XT into the arena and a root
+    //      record per start vertex, in chunks that fit the arena and the record pool; the resume rounds below search them.
     int launches = 0;
     // ---- rounds >= 1: resume the split searches (and search the root records of k_bk_build) until no record is left
     int rounds = 0;
-    Guard g_rslab;
-    size_t resume_cap = 0;
     auto run_rounds = [&]() -> int {
     while (true) {
         unsigned long long ctl[4] = {0, 0, 0, 0};  // pool_head, dir_count, max_stack
@@ -1371,44 +1441,8 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         return GMSX_OK;
     };
     if (split_build) {
-        const int64_t cnt_glob = part_count(0, n_glob, nparts, part);
         bool tiny_done = false;
         if (cnt_glob > 0) {
-            int64_t *need_a = nullptr, *need_r = nullptr, *aoff = nullptr, *roff = nullptr, *d_end = nullptr;
-            Guard g_na, g_nr, g_ao, g_ro, g_de, g_map;
-            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&need_a), size_t(cnt_glob + 1) * 8)); g_na.p = need_a;
-            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&need_r), size_t(cnt_glob + 1) * 8)); g_nr.p = need_r;
-            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&aoff), size_t(cnt_glob + 1) * 8)); g_ao.p = aoff;
-            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&roff), size_t(cnt_glob + 1) * 8)); g_ro.p = roff;
-            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_end), 8)); g_de.p = d_end;
-            unsigned long long *maxima = acc + kCtl + 9;  // [0] stack words, [1] global map words
-            GMSX_HIP(hipMemsetAsync(maxima, 0, 16, s));
-            hipLaunchKernelGGL(k_bk_layout, dim3(unsigned(cnt_glob / 256 + 1)), dim3(256), 0, s, int64_t(0), cnt_glob, nparts, part, v_out, g->off, g->oldid, g->dplus,
-                               split_build >= 2 ? 1 : 0, need_a, need_r, maxima);
-            {
-                size_t scan_bytes = 0;
-                GMSX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, need_a, aoff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
-                void *scan_tmp = nullptr;
-                GMSX_HIP(hipMalloc(&scan_tmp, scan_bytes ? scan_bytes : 8));
-                Guard g_scan;
-                g_scan.p = scan_tmp;
-                GMSX_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, need_a, aoff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
-                GMSX_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, need_r, roff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
-                GMSX_HIP(hipStreamSynchronize(s));
-            }
-            unsigned long long mx[2] = {0, 0};
-            GMSX_HIP(hipMemcpy(mx, maxima, sizeof(mx), hipMemcpyDeviceToHost));
-            int64_t need_total = 0;
-            GMSX_HIP(hipMemcpy(&need_total, aoff + cnt_glob, 8, hipMemcpyDeviceToHost));
-            // the roots may take 3/4 of the arena (below): everything in one chunk when the device allows, + room for the LDS-slab searches that split
-            if (int rc = alloc_arena((unsigned long long)need_total / 3 * 4 + (512ull << 20) / 4)) return rc;
-            const unsigned long long map_words = split_build >= 2 ? 0ull : (mx[1] + 3ull) & ~3ull;
-            const int64_t build_waves = std::min<int64_t>(cnt_glob, int64_t(cu) * 24);
-            uint32_t *map_scratch = nullptr;
-            if (map_words > 0) {
-                GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&map_scratch), size_t(build_waves) * map_words * 4));
-                g_map.p = map_scratch;
-            }
             unsigned long long *bqueue = acc + kCtl + 8;
             // the roots may take at most 3/4 of the arena and half of the pool: searches of the LDS-slab tasks that split need room too
             const int64_t a_cap = int64_t(sh.arena_cap / 4 * 3), r_cap = int64_t(sh.pool_cap / 2), max_tasks = int64_t(sh.dir_cap / 2);
