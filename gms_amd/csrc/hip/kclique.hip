@@ -612,6 +612,10 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         } else {
             __syncthreads();
         }
+#ifdef GMSX_KC_BUILD_ONLY  // A/B build: what the BUILD phase alone takes (k = 4, scale 22: 12.4 of 22.6 ms)
+        if (true) {
+        } else
+#endif
         if constexpr (VTX) {
             // per-vertex triangle counts (vertex_count2 = 2 x triangles at the vertex): a set bit (i, j) is the triangle
             // (u, v_i, v_j).  Column sums with byte-sliced counters: lane = word (32 columns), eight registers of four 8-bit
