@@ -207,12 +207,28 @@ __device__ inline uint32_t gap12_encode(const uint16_t *__restrict__ row, int le
     return units;
 }
 // delta_mode: 0 = never, 1 = when it is at least 15 % smaller than the list, 2 = whenever possible (test hook)
-__global__ void k_srow_sizes(int64_t n, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, int32_t dense_limit, int delta_mode,
-                             int delta_pct, int gap12_mode, int64_t *__restrict__ units_out, int64_t *__restrict__ small_out, uint32_t *__restrict__ real_out,
-                             unsigned char *__restrict__ form_out) {
+// Every row has TWO slots (2v, 2v+1).  Slot 1 is used by the HYBRID form only (round 3): the ids of a heavy row below B — 512 … 4096, the
+// rank ids of the biggest hubs, where the neighbours of every vertex of a power-law graph crowd — as a PREFIX BITMAP over [0, B) in slot 0
+// (B/128 units, probed by AND + popcount like a bitset row) and the ids from B on as a list / byte-delta row of their own in slot 1.  It
+// is Roaring's per-chunk choice of container (bitset where dense, array where sparse) applied at the one boundary that matters; on the
+// forward streams of RMAT scale 21 it takes 10 % off the hub stream units (numpy estimate), and a bitmap unit costs 14 VALU instructions
+// against 32 (list) / 81 (delta).  ksplit[v] = ids below B (0 = not hybrid).
+static constexpr int kHybridB[4] = {512, 1024, 2048, 4096};
+__device__ inline int lower_bound_u16(const uint16_t *__restrict__ row, int len, uint32_t key) {  // first index with row[i] >= key (the 0xFFFF pad sorts last)
+    int lo = 0, hi = len;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (uint32_t(row[mid]) < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+__global__ void k_srow_sizes(int64_t n, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, const int32_t *__restrict__ dplus,
+                             int32_t dense_limit, int delta_mode, int delta_pct, int gap12_mode, int hybrid_mode, int64_t *__restrict__ units_out,
+                             int64_t *__restrict__ small_out, uint32_t *__restrict__ real_out, unsigned char *__restrict__ form_out,
+                             int32_t *__restrict__ ksplit) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v > n) return;
-    if (v == n) { units_out[n] = 0; small_out[n] = 0; return; }
+    if (v == n) { units_out[2 * n] = 0; small_out[2 * n] = 0; return; }
     const int64_t b = hoff[v];
     const int len = int(hoff[v + 1] - b);
     uint32_t best = uint32_t((len + 7) / 8);  // list: 8 ids per unit
@@ -229,39 +245,86 @@ __global__ void k_srow_sizes(int64_t n, const int64_t *__restrict__ hoff, const 
         const uint32_t d = gap12_encode(hadj + b, len, nullptr);
         if (gap12_mode == 2 || d * 100u <= best * 90u) { best = d; form = kFormGap12; }
     }
+    // hybrid: prefix bitmap over [0, B) + the rest as list / delta.  Heavy rows only (the light-pivot kernel reads ONE descriptor per
+    // member), and only when it is at least 10 % smaller in all
+    uint32_t best2 = 0;
+    int form2 = kFormList, ks = 0;
+    if (hybrid_mode > 0 && len >= 32 && dplus[v] >= kHeavy && form != kFormBitset) {
+        uint32_t tot = best;
+        for (int t = 0; t < 4; ++t) {
+            const int B = kHybridB[t];
+            if (v <= B) break;
+            const int k = lower_bound_u16(hadj + b, len, uint32_t(B));
+            if (k * 2 <= B / 8 + 16) continue;  // the prefix as a list would be no bigger than its bitmap
+            const int rl = len - k;
+            uint32_t r = uint32_t((rl + 7) / 8);
+            int rf = kFormList;
+            if (rl >= 24 && delta_mode > 0) {
+                const uint32_t d = delta_encode(hadj + b + k, rl, nullptr);
+                if (d * 100u <= r * uint32_t(delta_pct)) { r = d; rf = kFormDelta; }
+            }
+            const uint32_t cand = uint32_t(B / 128) + r;
+            if (cand < tot && (hybrid_mode == 2 || cand * 100u <= best * 90u)) {
+                tot = cand;
+                ks = k;
+                best2 = r;
+                form2 = rf;
+            }
+        }
+        if (ks > 0) {
+            best = tot - best2;  // B / 128 units of prefix bitmap
+            form = kFormBitset;
+        }
+    }
+    ksplit[v] = ks;
     // rows of 8 units (128 bytes) or more start on 128-byte boundaries of their own region of the pool: a row fetch then touches
     // ceil(L/128) lines instead of L/128 + 1 (≈5 % of the heavy-pivot traffic); the small rows are packed behind them
-    const bool big = best >= 8u;
-    units_out[v] = big ? int64_t((best + 7u) & ~7u) : 0;
-    small_out[v] = big ? 0 : int64_t(best);
-    real_out[v] = best;
-    form_out[v] = (unsigned char)form;
+    const uint32_t u2[2] = {best, best2};
+    const int f2[2] = {form, form2};
+    for (int sl = 0; sl < 2; ++sl) {
+        const bool big = u2[sl] >= 8u;
+        units_out[2 * v + sl] = big ? int64_t((u2[sl] + 7u) & ~7u) : 0;
+        small_out[2 * v + sl] = big ? 0 : int64_t(u2[sl]);
+        real_out[2 * v + sl] = u2[sl];
+        form_out[2 * v + sl] = (unsigned char)f2[sl];
+    }
 }
 __global__ void k_srow_fill(int64_t n, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, const int64_t *__restrict__ bmoff,
                             const uint32_t *__restrict__ bmpool, const int64_t *__restrict__ uoff, const int64_t *__restrict__ soff,
-                            const uint32_t *__restrict__ real, const unsigned char *__restrict__ form, unsigned long long *__restrict__ srow,
-                            uint32_t *__restrict__ spool) {
+                            const uint32_t *__restrict__ real, const unsigned char *__restrict__ form, const int32_t *__restrict__ ksplit,
+                            unsigned long long *__restrict__ srow, unsigned long long *__restrict__ srow2, uint32_t *__restrict__ spool) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v >= n) return;
-    const int64_t units = int64_t(real[v]);
-    const int64_t u0 = units >= 8 ? uoff[v] : uoff[n] + soff[v];  // big rows: 128-byte aligned region first; small rows behind it
-    srow[v] = ((unsigned long long)u0 << 24) | ((unsigned long long)form[v] << 22) | (unsigned long long)units;
-    if (units == 0) return;
-    uint32_t *dst = spool + u0 * 4;
     const int64_t b = hoff[v];
     const int len = int(hoff[v + 1] - b);
-    if (form[v] == kFormDelta) {
-        delta_encode(hadj + b, len, dst);
-    } else if (form[v] == kFormGap12) {
-        gap12_encode(hadj + b, len, dst);
-    } else if (form[v] == kFormBitset) {
-        const uint32_t *src = bmpool + bmoff[v];  // bitset_words(v) is a multiple of 4 words = whole units
-        for (int64_t w = 0; w < units * 4; ++w) dst[w] = src[w];
-    } else {
-        for (int64_t w = 0; w < units * 4; ++w) {
-            const int i = int(w) * 2;
-            const uint32_t lo = i < len ? hadj[b + i] : 0xFFFFu, hi = i + 1 < len ? hadj[b + i + 1] : 0xFFFFu;
-            dst[w] = lo | (hi << 16);
+    const int ks = ksplit[v];  // > 0: slot 0 = prefix bitmap of the first ks ids, slot 1 = the ids behind them
+    for (int sl = 0; sl < 2; ++sl) {
+        const int64_t units = int64_t(real[2 * v + sl]);
+        const int64_t u0 = units >= 8 ? uoff[2 * v + sl] : uoff[2 * n] + soff[2 * v + sl];  // big rows: 128-byte aligned region first; small rows behind it
+        const int fm = form[2 * v + sl];
+        const unsigned long long d = units ? ((unsigned long long)u0 << 24) | ((unsigned long long)fm << 22) | (unsigned long long)units : 0ull;
+        if (sl == 0) srow[v] = units ? d : ((unsigned long long)u0 << 24) | ((unsigned long long)fm << 22);
+        else srow2[v] = d;
+        if (units == 0) continue;
+        uint32_t *dst = spool + u0 * 4;
+        const uint16_t *row = hadj + b + (sl ? ks : 0);
+        const int rl = sl ? len - ks : len;
+        if (sl == 0 && ks > 0) {  // prefix bitmap
+            for (int64_t w = 0; w < units * 4; ++w) dst[w] = 0;
+            for (int i = 0; i < ks; ++i) dst[row[i] >> 5] |= 1u << (row[i] & 31u);
+        } else if (fm == kFormDelta) {
+            delta_encode(row, rl, dst);
+        } else if (fm == kFormGap12) {
+            gap12_encode(row, rl, dst);
+        } else if (fm == kFormBitset) {
+            const uint32_t *src = bmpool + bmoff[v];  // bitset_words(v) is a multiple of 4 words = whole units
+            for (int64_t w = 0; w < units * 4; ++w) dst[w] = src[w];
+        } else {
+            for (int64_t w = 0; w < units * 4; ++w) {
+                const int i = int(w) * 2;
+                const uint32_t lo = i < rl ? row[i] : 0xFFFFu, hi = i + 1 < rl ? row[i + 1] : 0xFFFFu;
+                dst[w] = lo | (hi << 16);
+            }
         }
     }
 }
@@ -617,6 +680,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32_t *__restrict__ order, const int64_t *__restrict__ hoff,
                                                     const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                     const int32_t *__restrict__ dplus, const unsigned long long *__restrict__ srow,
+                                                    const unsigned long long *__restrict__ srow2, const int32_t *__restrict__ ksplit,
                                                     const unsigned long long *__restrict__ trow, int two_sided, const int32_t *__restrict__ opos,
                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ cur, const int64_t *__restrict__ hbeg,
                                                     const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ htask, unsigned long long *__restrict__ ttask,
@@ -630,7 +694,8 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
         const int32_t u = order[pos];
         const int64_t hb = hoff[u], tb = toff[u];
         const int hl = int(hoff[u + 1] - hb), tl = int(toff[u + 1] - tb);
-        const unsigned long long du_s = srow[u], du_t = trow[u];
+        const unsigned long long du_s = srow[u], du_s2 = srow2[u], du_t = trow[u];  // du_s2 != 0: hybrid row — du_s is the prefix bitmap, du_s2 the ids behind it
+        const int ks_u = ksplit[u];
         uint32_t *cu = cnt + pos * kClasses, *ru = cur + pos * kClasses;
         const bool own_u = nparts <= 1 || shard_of(pos, nparts) == part;  // a sharded upload writes the lists of the receivers this rank owns only
         int kept = 0;
@@ -643,38 +708,49 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
             } else if (i < hl + tl) v = tadj[tb + i - hl];
             if (v >= 0 && i > 0 && i < kInlineFirst && takes_inline(v, inline_limit, dplus)) v = -1;  // handed over inline (k_inline_rows): no entry
             bool reverse = false;
-            uint32_t ch = 0, ct = 0;  // units of u's rows that v would have to stream
+            uint32_t ch = 0, ch2 = 0, ct = 0;  // units of u's rows that v would have to stream (ch2: the second slot of a hybrid row)
             if (v >= 0 && i > 0 && two_sided && dplus[v] >= kHeavy) {
-                ch = i < hl ? cut_hub_units(spool, du_s, i, v) : uint32_t(du_s) & 0x3fffffu;  // a tail member sees the whole hub part
+                if (i < hl) {
+                    ch = cut_hub_units(spool, du_s, i, v);  // (a prefix bitmap is cut like a bitset row: ceil(v / 128) units)
+                    if (du_s2 && i > ks_u) ch2 = cut_hub_units(spool, du_s2, i - ks_u, v);  // members behind the prefix: i - ks_u ids of the second slot lie below v
+                } else {  // a tail member sees the whole hub part
+                    ch = uint32_t(du_s) & 0x3fffffu;
+                    ch2 = uint32_t(du_s2) & 0x3fffffu;
+                }
                 ct = (i < hl || toff[v + 1] == toff[v]) ? 0u : cut_tail_units(tpool, du_t, i - hl, v);  // a pivot without tail part has nothing to match
-                const uint32_t keep = uint32_t(srow[v] & 0x3fffffull) + (i > hl ? uint32_t(trow[v] & 0x3fffffull) : 0u);  // what u would stream
-                reverse = ch + ct < keep;
+                const uint32_t keep = uint32_t(srow[v] & 0x3fffffull) + uint32_t(srow2[v] & 0x3fffffull) + (i > hl ? uint32_t(trow[v] & 0x3fffffull) : 0u);  // what u would stream
+                reverse = ch + ch2 + ct < keep;
             }
             const bool fwd = v >= 0 && !reverse && own_u;
             if (reverse && nparts > 1 && shard_of(opos[v], nparts) != part) v = -1;
             // forward: v's rows against u — the first member has no member below it (the edge closes no triangle); the tail ids of the first
             // tail member lie below every tail id of the pivot; a hub member has no tail part
-            const unsigned long long fh = (fwd && i > 0) ? srow[v] : 0ull, ft = (fwd && i > hl) ? trow[v] : 0ull;
-            const bool fh_on = (fh & 0x3fffffull) != 0, ft_on = (ft & 0x3fffffull) != 0;
+            const unsigned long long fh = (fwd && i > 0) ? srow[v] : 0ull, fh2 = (fwd && i > 0) ? srow2[v] : 0ull, ft = (fwd && i > hl) ? trow[v] : 0ull;
+            const bool fh_on = (fh & 0x3fffffull) != 0, fh2_on = (fh2 & 0x3fffffull) != 0, ft_on = (ft & 0x3fffffull) != 0;
             const uint32_t sh = claim_by_class(FILL ? ru : cu, hub_class(fh), fh_on, lane);
+            const uint32_t sh2 = claim_by_class(FILL ? ru : cu, hub_class(fh2), fh2_on, lane);
             const uint32_t st = claim_by_class(FILL ? ru : cu, tail_class(ft), ft_on, lane);
             if (FILL) {
                 if (fh_on) htask[hbeg[pos] + cu[hub_class(fh)] + sh] = fh;
+                if (fh2_on) htask[hbeg[pos] + cu[hub_class(fh2)] + sh2] = fh2;
                 if (ft_on) ttask[tbeg[pos] + cu[tail_class(ft)] + st] = ft;
             }
             kept += __popcll(__ballot(fwd));
             if (v >= 0 && reverse) {  // u's rows, cut at v, against v
                 const int64_t pv = opos[v];
-                const unsigned long long rh = ch ? (du_s & ~0x3fffffull) | ch : 0ull, rt = ct ? (du_t & ~0x3fffffull) | ct : 0ull;
+                const unsigned long long rh = ch ? (du_s & ~0x3fffffull) | ch : 0ull, rh2 = ch2 ? (du_s2 & ~0x3fffffull) | ch2 : 0ull,
+                                         rt = ct ? (du_t & ~0x3fffffull) | ct : 0ull;
                 uint32_t *cv = cnt + pv * kClasses;
                 if (!FILL) {
                     if (rh) atomicAdd(&cv[hub_class(rh)], 1u);
+                    if (rh2) atomicAdd(&cv[hub_class(rh2)], 1u);
                     if (rt) atomicAdd(&cv[tail_class(rt)], 1u);
                     atomicAdd(&tunits[v], 1);
                     ++rev;
                 } else {
                     uint32_t *rv = cur + pv * kClasses;
                     if (rh) htask[hbeg[pv] + cv[hub_class(rh)] + atomicAdd(&rv[hub_class(rh)], 1u)] = rh;
+                    if (rh2) htask[hbeg[pv] + cv[hub_class(rh2)] + atomicAdd(&rv[hub_class(rh2)], 1u)] = rh2;
                     if (rt) ttask[tbeg[pv] + cv[tail_class(rt)] + atomicAdd(&rv[tail_class(rt)], 1u)] = rt;
                 }
             }
@@ -737,7 +813,7 @@ static void free_tc(gmsx_graph *g) {
         (void)hipFree(p);
         p = nullptr;
     };
-    drop(g->tsplit); drop(g->srow); drop(g->spool); drop(g->trow); drop(g->tdesc); drop(g->htask); drop(g->ttask); drop(g->hitem); drop(g->titem); drop(g->tunits);
+    drop(g->tsplit); drop(g->srow); drop(g->srow2); drop(g->ksplit); drop(g->spool); drop(g->trow); drop(g->tdesc); drop(g->htask); drop(g->ttask); drop(g->hitem); drop(g->titem); drop(g->tunits);
     drop(g->worder); drop(g->tpool);
     g->device_bytes -= g->tc_bytes;
     g->tc_bytes = 0;
@@ -761,6 +837,8 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->bmpool);
     (void)hipFree(g->tsplit);
     (void)hipFree(g->srow);
+    (void)hipFree(g->srow2);
+    (void)hipFree(g->ksplit);
     (void)hipFree(g->spool);
     (void)hipFree(g->trow);
     (void)hipFree(g->tdesc);
@@ -1150,41 +1228,51 @@ static int build_tc_sets(gmsx_graph *g) {
             const int v = std::atoi(e);
             if (v >= 0 && v <= 2 && g->rows_sorted) gap12_mode = v;
         }
+        // measured (MI355X, scale 26): mode 1 takes 0.3 % off the algorithmic stream bytes, mode 2 3.4 % — the 10 % of the forward-stream
+        // estimate does not survive the two-sided design (the rows that end up streamed are the SMALLER ones of every edge and the cuts
+        // already drop their low-id prefixes for the receivers that matter) — and the pass time does not move (80.5–80.9 ms all three).  OFF.
+        int hybrid_mode = 0;
+        if (const char *e = std::getenv("GMSX_TC_HYBRID")) {  // 1 = when at least 10 % smaller than the row's best single form, 2 = wherever smaller at all
+            const int v = std::atoi(e);
+            if (v >= 0 && v <= 2 && g->rows_sorted) hybrid_mode = v;
+        }
         int64_t *units = nullptr, *uoff = nullptr, *small = nullptr, *soff = nullptr;
         uint32_t *real = nullptr;
         unsigned char *form = nullptr;
-        if (int rc = dmalloc(&units, n + 1, nullptr)) return rc;
+        const int64_t n2 = 2 * n;  // two slots per row
+        if (int rc = dmalloc(&units, n2 + 1, nullptr)) return rc;
         DevGuard g_u{units};
-        if (int rc = dmalloc(&uoff, n + 1, nullptr)) return rc;
+        if (int rc = dmalloc(&uoff, n2 + 1, nullptr)) return rc;
         DevGuard g_o{uoff};
-        if (int rc = dmalloc(&small, n + 1, nullptr)) return rc;
+        if (int rc = dmalloc(&small, n2 + 1, nullptr)) return rc;
         DevGuard g_s{small};
-        if (int rc = dmalloc(&soff, n + 1, nullptr)) return rc;
+        if (int rc = dmalloc(&soff, n2 + 1, nullptr)) return rc;
         DevGuard g_so{soff};
-        if (int rc = dmalloc(&real, n + 1, nullptr)) return rc;
+        if (int rc = dmalloc(&real, n2 + 1, nullptr)) return rc;
         DevGuard g_r{real};
-        if (int rc = dmalloc(&form, n + 1, nullptr)) return rc;
+        if (int rc = dmalloc(&form, n2 + 1, nullptr)) return rc;
         DevGuard g_f{form};
-        hipLaunchKernelGGL(k_srow_sizes, dim3(unsigned(n / 256 + 1)), dim3(256), 0, s, n, g->hoff, g->hadj, g->dense_limit, delta_mode, delta_pct, gap12_mode, units, small,
-                           real, form);
-        if (int rc = exclusive_scan_i64(units, uoff, n + 1, s)) return rc;
-        if (int rc = exclusive_scan_i64(small, soff, n + 1, s)) return rc;
+        if (int rc = dmalloc(&g->ksplit, n + 1, g)) return rc;
+        hipLaunchKernelGGL(k_srow_sizes, dim3(unsigned(n / 256 + 1)), dim3(256), 0, s, n, g->hoff, g->hadj, g->dplus, g->dense_limit, delta_mode, delta_pct, gap12_mode,
+                           hybrid_mode, units, small, real, form, g->ksplit);
+        if (int rc = exclusive_scan_i64(units, uoff, n2 + 1, s)) return rc;
+        if (int rc = exclusive_scan_i64(small, soff, n2 + 1, s)) return rc;
         int64_t big_units = 0, small_units = 0;
-        GMSX_HIP(hipMemcpy(&big_units, uoff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
-        GMSX_HIP(hipMemcpy(&small_units, soff + n, sizeof(int64_t), hipMemcpyDeviceToHost));
+        GMSX_HIP(hipMemcpy(&big_units, uoff + n2, sizeof(int64_t), hipMemcpyDeviceToHost));
+        GMSX_HIP(hipMemcpy(&small_units, soff + n2, sizeof(int64_t), hipMemcpyDeviceToHost));
         g->spool_units = big_units + small_units + inline_h_units;
         inline_h_base = big_units + small_units;
         if (g->spool_units >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;  // 40 offset bits in a srow entry (16 TB)
         if (int rc = dmalloc(&g->srow, n, g)) return rc;
+        if (int rc = dmalloc(&g->srow2, n, g)) return rc;
         if (int rc = dmalloc(&g->spool, g->spool_units * 4 + 4, g)) return rc;
         GMSX_HIP(hipMemsetAsync(g->spool, 0, size_t(g->spool_units * 4 + 4) * sizeof(uint32_t), s));  // the alignment gaps are never read, but keep them defined
         if (inline_h_units > 0) GMSX_HIP(hipMemsetAsync(g->spool + inline_h_base * 4, 0xff, size_t(inline_h_units) * 16, s));  // list filler 0xFFFF
         if (n > 0)
             hipLaunchKernelGGL(k_srow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->hoff, g->hadj, g->bmoff, g->bmpool, uoff, soff, real, form,
-                               g->srow, g->spool);
+                               g->ksplit, g->srow, g->srow2, g->spool);
         GMSX_HIP(hipStreamSynchronize(s));
     }
-    pt.mark("hub stream rows");
     // 4e. … and of the tail parts
     {
         int delta_mode = g->rows_sorted ? 1 : 0;
@@ -1313,7 +1401,7 @@ static int build_tc_sets(gmsx_graph *g) {
             hipLaunchKernelGGL(k_inline_entries<false>, dim3(vb), dim3(256), 0, s, n, g->dplus, opos, lidx, n_heavy, g->inline_limit, ihoff, itoff, inline_h_base,
                                inline_t_base, cnt, cur, hbeg, tbeg, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), totals);
         if (n_heavy > 0)
-            hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->trow,
+            hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->srow2, g->ksplit, g->trow,
                                two_sided, opos, cnt, cur, hbeg, tbeg, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), g->tunits,
                                totals + 2, g->spool, g->tpool, g->inline_limit, g->shard_nparts, g->shard_part);
         pt.mark("task lists count");
@@ -1336,7 +1424,7 @@ static int build_tc_sets(gmsx_graph *g) {
             hipLaunchKernelGGL(k_inline_entries<true>, dim3(vb), dim3(256), 0, s, n, g->dplus, opos, lidx, n_heavy, g->inline_limit, ihoff, itoff, inline_h_base,
                                inline_t_base, cnt, cur, hbeg, tbeg, g->htask, g->ttask, totals);
         if (n_heavy > 0)
-            hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->trow,
+            hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->srow2, g->ksplit, g->trow,
                                two_sided, opos, cnt, cur, hbeg, tbeg, g->htask, g->ttask, g->tunits, totals + 2, g->spool, g->tpool, g->inline_limit, g->shard_nparts, g->shard_part);
         pt.mark("task lists fill");
         // work items

@@ -60,6 +60,8 @@ struct gmsx_graph {
     //   form 3  12-bit gaps      unit = 16-bit base id + 4-bit count + nine 12-bit gaps; a gap above 4095 ends the unit early.
     //                            10 ids per unit = 1.6 B/id: the sparse rows (gaps of 256 … 4095) that would otherwise stay lists
     unsigned long long *srow = nullptr;  // [n]
+    unsigned long long *srow2 = nullptr; // [n] second descriptor of a HYBRID row (0 otherwise): srow = prefix bitmap over [0, B), srow2 = the ids from B on
+    int32_t *ksplit = nullptr;           // [n] ids of the row below B (0 = not hybrid)
     uint32_t *spool = nullptr;           // 16-byte units
     int64_t spool_units = 0;
     // … and the TAIL part of every row the same way (trow / tpool): form 0 = 32-bit ids, 4 per unit, filler -2 (never a key of a
