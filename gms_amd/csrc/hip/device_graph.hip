@@ -814,7 +814,8 @@ static void free_tc(gmsx_graph *g) {
         p = nullptr;
     };
     drop(g->tsplit); drop(g->srow); drop(g->srow2); drop(g->ksplit); drop(g->spool); drop(g->trow); drop(g->tdesc); drop(g->htask); drop(g->ttask); drop(g->hitem); drop(g->titem); drop(g->tunits);
-    drop(g->worder); drop(g->tpool);
+    drop(g->worder); drop(g->tpool); drop(g->shard_hidx); drop(g->shard_tidx);
+    g->shard_idx_part = g->shard_idx_nparts = -1;
     g->device_bytes -= g->tc_bytes;
     g->tc_bytes = 0;
     g->tc_ready = false;
@@ -847,6 +848,8 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->hitem);
     (void)hipFree(g->titem);
     (void)hipFree(g->tunits);
+    (void)hipFree(g->shard_hidx);
+    (void)hipFree(g->shard_tidx);
     (void)hipFree(g->worder);
     (void)hipFree(g->tpool);
     (void)hipFree(g->dplus);
@@ -1491,6 +1494,44 @@ int ensure_tc(const gmsx_graph *cg) {
         }
     }
     return rc;
+}
+
+__global__ void k_shard_flags(int64_t n_items, const gmsx_task_item *__restrict__ items, int nparts, int part, int64_t *__restrict__ flags) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i <= n_items) flags[i] = (i < n_items && shard_of(items[i].pos, nparts) == part) ? 1 : 0;
+}
+__global__ void k_shard_scatter(int64_t n_items, const int64_t *__restrict__ flags, const int64_t *__restrict__ slot, int32_t *__restrict__ idx) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n_items && flags[i]) idx[slot[i]] = int32_t(i);
+}
+int tc_shard_items(const gmsx_graph *g, int part, int nparts) {
+    if (g->shard_idx_part == part && g->shard_idx_nparts == nparts) return GMSX_OK;
+    hipStream_t s = ctx().stream;
+    (void)hipFree(g->shard_hidx);
+    (void)hipFree(g->shard_tidx);
+    g->shard_hidx = g->shard_tidx = nullptr;
+    g->shard_idx_part = g->shard_idx_nparts = -1;
+    auto one = [&](const gmsx_task_item *items, int64_t n_items, int32_t **idx, int64_t *count) -> int {
+        *count = 0;
+        if (n_items == 0) return GMSX_OK;
+        int64_t *flags = nullptr, *slot = nullptr;
+        if (int rc = dmalloc(&flags, n_items + 1, nullptr)) return rc;
+        DevGuard g_f{flags};
+        if (int rc = dmalloc(&slot, n_items + 1, nullptr)) return rc;
+        DevGuard g_s{slot};
+        hipLaunchKernelGGL(k_shard_flags, dim3(unsigned(n_items / 256 + 1)), dim3(256), 0, s, n_items, items, nparts, part, flags);
+        if (int rc = exclusive_scan_i64(flags, slot, n_items + 1, s)) return rc;
+        GMSX_HIP(hipMemcpy(count, slot + n_items, sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (int rc = dmalloc(idx, *count + 1, nullptr)) return rc;
+        hipLaunchKernelGGL(k_shard_scatter, dim3(unsigned(n_items / 256 + 1)), dim3(256), 0, s, n_items, flags, slot, *idx);
+        GMSX_HIP(hipStreamSynchronize(s));
+        return GMSX_OK;
+    };
+    if (int rc = one(g->hitem, g->hitems, &g->shard_hidx, &g->shard_hitems)) return rc;
+    if (int rc = one(g->titem, g->titems, &g->shard_tidx, &g->shard_titems)) return rc;
+    g->shard_idx_part = part;
+    g->shard_idx_nparts = nparts;
+    return GMSX_OK;
 }
 
 int ensure_tc_shard(const gmsx_graph *cg, int part, int nparts) {

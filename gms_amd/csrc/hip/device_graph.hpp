@@ -86,6 +86,11 @@ struct gmsx_graph {
     struct gmsx_task_item *hitem = nullptr, *titem = nullptr;  // work items over htask / ttask
     int64_t hitems = 0, titems = 0;
     int64_t inline_hentries = 0, inline_tentries = 0;  // of which: chunks of inline rows
+    // gmsx_tc_partial(part, nparts) on a FULL upload: the indices of the work items of that shard, compacted on demand (cached for the last
+    // (part, nparts)), so that a shard launches its own workgroups only
+    mutable int32_t *shard_hidx = nullptr, *shard_tidx = nullptr;
+    mutable int64_t shard_hitems = 0, shard_titems = 0;
+    mutable int shard_idx_part = -1, shard_idx_nparts = -1;
     int32_t *tunits = nullptr;           // [n] oriented edges whose entries live at this vertex (forward + reverse): the bookkeeping of gmsx_stats.units
     int64_t task_reverse = 0;            // edges handed over to the other endpoint
     int32_t *worder = nullptr;           // the light pivots that still have far light members (in launch order): what k_tc_wave walks
@@ -178,6 +183,8 @@ int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out);
 int ensure_tc(const gmsx_graph *g);
 // … for one shard / pass (frees and rebuilds when another one is resident)
 int ensure_tc_shard(const gmsx_graph *g, int part, int nparts);
+// fills g->shard_hidx / shard_tidx for (part, nparts) (device_graph.hip)
+int tc_shard_items(const gmsx_graph *g, int part, int nparts);
 // counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| into a zeroed device array (pairs.hip); shared by the per-vertex count and the TC ordering
 int tc_vertex_counts_device(const gmsx_graph *g, unsigned long long *d_counts, gmsx_stats *st);
 // GMSX_TC_FULL: every edge u<v intersects the FULL rows (pairs.hip); returns the un-divided sum of the shard

@@ -16,19 +16,20 @@
 //     a 20-byte row behind a pointer would cost a 128-byte line per fetch, inline it is streamed; only far light members v stay
 //     with u and the light-pivot kernel.
 // Kernel shape, Roaring-style sets:
-//   1. k_tc_block — one workgroup per WORK ITEM (<= 1024 entries of one pivot's task list).  The pivot row is staged into LDS: its
-//      hub part (rank ids < 65535) as a 65536-bit BITMAP (8 KB), its tail part as an open-addressing hash set fronted by a
-//      32768-bit filter;
+//   1. every receiving vertex owns a HUB-entry list and a TAIL-entry list of 8-byte stream-row descriptors, laid out class by class
+//      (form x length step) at build time; a WORK ITEM is <= 1024 consecutive entries of one list, one workgroup each.  k_tc_block runs
+//      the hub items — the pivot's hub part (rank ids < 65535) staged as a 65536-bit BITMAP (8 KB of LDS) — and k_tc_tail the tail items —
+//      the pivot's tail part as an open-addressing hash set fronted by a filter bitmap, both sized per pivot;
 //   2. the rows the entries name are streamed from HBM with coalesced 16-byte loads as STREAM ROWS (device_graph.hpp): whole
-//      16-byte units of the cheapest of three forms per row — bitset (AND + popcount, 128 ids per unit), 16-bit list (8 ids),
-//      byte-delta (base + count + 13 gaps: 14 ids) — for the hub part, 32-bit ids or 16-bit delta units (6 ids) for the tail
-//      part; a wave works as four 16-lane groups, each on its own row, two loads in flight; the lists are sorted by (form,
-//      length) so that the four rows are equally long;
+//      16-byte units of the cheapest form per row — bitset (AND + popcount, 128 ids per unit), 16-bit list (8 ids), byte-delta (base +
+//      count + 13 gaps: 14 ids), 12-bit gaps (10 ids; off) — for the hub part, 32-bit ids or 16-bit delta units (6 ids) for the tail part.
+//      The workgroup copies its descriptors to LDS, finds the runs (form x {<= 4, <= 8, more units}) and executes one compile-time-shaped
+//      loop per run: groups of 4 / 8 / 16 lanes, a row per group, the first unit of the group's next row already loading;
 //   3. every streamed hub id is one LDS word read + bit test (no collisions, no branches); a tail id is one filter-bit test and,
 //      for the few that pass, a table probe; hits are counted per lane, reduced per workgroup, added to one of 64 spread u64
 //      accumulators (one atomic per workgroup);
-//   4. k_tc_wave — light pivots with far light members: wave per pivot, private bitmap + bucket set, streams those members' rows;
-//      on large graphs it runs BESIDE k_tc_block on a side stream.
+//   4. k_tc_wave — light pivots with far light members: wave per pivot, private bitmap + bucket set, streams those members' rows.
+//   The three kernels run side by side on three streams (hub items: bandwidth + VALU; tail items: short rows; light pivots: latency).
 // No MFMA: integer/indexing work bounded by row streaming (HBM) and VALU issue of the decode + probe sequence.
 #include "device_graph.hpp"
 
@@ -122,13 +123,11 @@ __device__ __forceinline__ uint32_t gap12_unit_hits(const uint32_t *bm, uint4 p)
     return uint32_t(__popc(hits & ((1u << n) - 1u)));
 }
 
-// Streams up to 64 stream rows against the LDS bitmap.  Lane l holds the packed descriptor of one row (srow[v]; 0 = no row).
-// A wave works as four 16-lane groups, each on its own row: one 16-byte unit per lane per step, two steps in flight.  Rows are handed
-// out FORM BY FORM (a ballot per form, then the four lowest lanes of the ballot): the three forms cost 12 / 32 / 81 VALU instructions per
-// unit, and a hand-out that mixes them executes every branch with a quarter of the lanes.  The four rows of a hand-out should also be
-// equally long — the wave works until the longest is done — which the BUILD takes care of: every task list is sorted by (form, units)
-// (device_graph.hip), so neighbouring lanes hold rows of nearly the same length.  (Tried instead: 32-unit chunks handed out by a scalar
-// cursor — balanced too, but ~45 VALU instructions per hand-out of at most 128 units against ~30 per four whole rows.)
+// The LIGHT-PIVOT kernel's row scan (k_tc_wave; the work-item kernels have their own typed loops below): streams up to 64 stream rows
+// against the wave's LDS bitmap.  Lane l holds the packed descriptor of one row (srow[v]; 0 = no row).  A wave works as four 16-lane
+// groups, each on its own row: one 16-byte unit per lane per step, two steps in flight.  Rows are handed out FORM BY FORM (a ballot per
+// form, then the four lowest lanes of the ballot): the forms cost 12 / 32 / 81 VALU instructions per unit, and a hand-out that mixes them
+// executes every branch with a quarter of the lanes.
 struct RowHandout {
     const uint4 *row;
     int units;
@@ -421,15 +420,15 @@ __device__ __forceinline__ void block_add(unsigned long long cnt, unsigned long 
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const uint32_t *__restrict__ spool, const unsigned long long *__restrict__ htask,
-                                                  const gmsx_task_item *__restrict__ items, int64_t n_items, int nparts, int part,
+                                                  const gmsx_task_item *__restrict__ items, const int32_t *__restrict__ idx, int nparts, int part,
                                                   unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords + 128];  // + slack: the delta probes of unused slots read up to 104 words past the bitmap
     __shared__ unsigned long long sdesc[kTaskChunk];
     __shared__ unsigned short cbeg[12], cend[12];  // run types
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const gmsx_task_item it = items[blockIdx.x];
-    if (nparts > 1 && shard_of(it.pos, nparts) != part) return;  // uniform per block
+    const gmsx_task_item it = items[idx ? idx[blockIdx.x] : int32_t(blockIdx.x)];  // idx: the items of this shard (a sharded call on a full upload)
+    if (nparts > 1 && shard_of(it.pos, nparts) != part) return;  // uniform per block (never taken with idx or on a sharded upload)
     const int32_t u = it.pivot;
     const int64_t hb = hoff[u];
     const int hl = int(hoff[u + 1] - hb);
@@ -457,7 +456,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_tail(const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                  const uint32_t *__restrict__ tpool, const unsigned long long *__restrict__ ttask,
-                                                 const gmsx_task_item *__restrict__ items, int64_t n_items, int nparts, int part,
+                                                 const gmsx_task_item *__restrict__ items, const int32_t *__restrict__ idx, int nparts, int part,
                                                  unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) int32_t tbl[1 << kBlockLog];
     __shared__ uint32_t flt[kFilterWords];
@@ -466,7 +465,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ unsigned long long red[4];
     constexpr int TILE = (1 << kBlockLog) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const gmsx_task_item it = items[blockIdx.x];
+    const gmsx_task_item it = items[idx ? idx[blockIdx.x] : int32_t(blockIdx.x)];
     if (nparts > 1 && shard_of(it.pos, nparts) != part) return;  // uniform per block
     const int32_t u = it.pivot;
     const int64_t tb = toff[u];
@@ -909,6 +908,13 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
 }
 
 static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, gmsx_stats *st) {
+    // a sharded call on a FULL upload launches the work items of its shard only (compacted index lists, cached per (part, nparts)); a sharded
+    // upload holds nothing but its own items
+    const bool use_idx = nparts > 1 && g->shard_nparts == 1;
+    if (use_idx)
+        if (int rc = tc_shard_items(g, part, nparts)) return rc;
+    const int32_t *hidx = use_idx ? g->shard_hidx : nullptr, *tidx = use_idx ? g->shard_tidx : nullptr;
+    const int64_t n_hitems = use_idx ? g->shard_hitems : g->hitems, n_titems = use_idx ? g->shard_titems : g->titems;
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     unsigned long long *acc = g->acc;  // persistent per-graph accumulators: no allocation on the call path
@@ -932,9 +938,9 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     // measured (MI355X, round 2): scale 26 serial 86.4 ms, co-scheduled 84.6 (2 workgroups per CU) / 82.9 (1); scale 24 15.05 / 14.45 (2) /
     // erratic (1); scale 22 3.56 serial, 4.45 co-scheduled.  So the light kernel moves aside from 2^23 vertices on.
     const bool sides = overlap && c.side[0] && c.side[1];
-    const bool co_wave = sides && g->hitems > 0 && cnt_light > 0 && (overlap > 1 || g->n >= (int64_t(1) << 23));
+    const bool co_wave = sides && n_hitems > 0 && cnt_light > 0 && (overlap > 1 || g->n >= (int64_t(1) << 23));
     const int tail_mode = [] { const char *e = std::getenv("GMSX_TC_TAIL"); return e ? std::atoi(e) : 1; }();  // A/B: 0 = tail items behind the hub items on the launch stream, 2 = before them
-    const bool co_tail = sides && g->hitems > 0 && g->titems > 0 && tail_mode == 1;
+    const bool co_tail = sides && n_hitems > 0 && n_titems > 0 && tail_mode == 1;
     hipStream_t s_wave = co_wave ? c.side[1] : s, s_tail = co_tail ? c.side[0] : s;
     struct Join {  // joins the side streams on every way out once they were forked (error returns included)
         Ctx &c;
@@ -945,6 +951,25 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
                 if (armed[i] && hipEventRecord(c.ev_join[i], c.side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, c.ev_join[i], 0);
         }
     } join{c, s};
+    if (tail_mode == 3 && sides && n_hitems > 0) {
+        // A/B: the hub items ALONE first (they run at 7 TB/s by themselves), then the tail items on the launch stream with the light pivots
+        // beside them (neither of the two is bandwidth-bound)
+        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(n_hitems)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->htask, g->hitem, hidx, nparts, part, acc);
+        ++launches;
+        GMSX_HIP(hipEventRecord(c.ev_fork, s));
+        GMSX_HIP(hipStreamWaitEvent(c.side[1], c.ev_fork, 0));
+        join.armed[1] = true;
+        if (cnt_light > 0) {
+            const int64_t b_wave = std::min<int64_t>((cnt_light + 3) / 4, int64_t(cus) * 4);
+            hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(b_wave)), dim3(256), 0, c.side[1], g->hoff, g->hadj, g->spool, g->tpool, g->tdesc, g->toff, g->tadj,
+                               g->tsplit, g->worder, int64_t(0), g->n_wave, nparts, part, acc);
+            ++launches;
+        }
+        if (n_titems > 0) {
+            hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, s, g->toff, g->tadj, g->tpool, g->ttask, g->titem, tidx, nparts, part, acc);
+            ++launches;
+        }
+    } else {
     if (co_wave || co_tail) GMSX_HIP(hipEventRecord(c.ev_fork, s));
     if (co_tail) {
         GMSX_HIP(hipStreamWaitEvent(c.side[0], c.ev_fork, 0));
@@ -963,19 +988,20 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
         ++launches;
     };
     if (co_wave) launch_light();
-    if (g->titems > 0 && tail_mode == 2) {
-        hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(g->titems)), dim3(256), 0, s, g->toff, g->tadj, g->tpool, g->ttask, g->titem, g->titems, nparts, part, acc);
+    if (n_titems > 0 && tail_mode == 2) {
+        hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, s, g->toff, g->tadj, g->tpool, g->ttask, g->titem, tidx, nparts, part, acc);
         ++launches;
     }
-    if (g->hitems > 0) {
-        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(g->hitems)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->htask, g->hitem, g->hitems, nparts, part, acc);
+    if (n_hitems > 0) {
+        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(n_hitems)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->htask, g->hitem, hidx, nparts, part, acc);
         ++launches;
     }
-    if (g->titems > 0 && tail_mode != 2) {
-        hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(g->titems)), dim3(256), 0, s_tail, g->toff, g->tadj, g->tpool, g->ttask, g->titem, g->titems, nparts, part, acc);
+    if (n_titems > 0 && tail_mode != 2) {
+        hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, s_tail, g->toff, g->tadj, g->tpool, g->ttask, g->titem, tidx, nparts, part, acc);
         ++launches;
     }
     if (!co_wave) launch_light();
+    }
     for (int i = 0; i < 2; ++i)
         if (join.armed[i]) {
             join.armed[i] = false;
