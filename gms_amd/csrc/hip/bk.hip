@@ -195,6 +195,7 @@ struct BkShared {
     unsigned long long *dir_count;
     unsigned long long *max_stack;      // max (c+1)*lvl over the dumped records
     unsigned budget;                    // nodes per task before it is split
+    int small_p;                        // nodes with at most this many candidates take their first candidate as the pivot (no scoring)
     const int64_t *bmoff;               // bitset containers of the hub rows (device_graph.hpp)
     const uint32_t *bmpool;
     int32_t dense_limit;
@@ -288,6 +289,38 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                     }
                 }
             }
+            // SMALL NODES: with two or three candidates left the best pivot saves at most a branch or two, while finding it costs the
+            // expansion of P ∪ Xc, a scored row fetch per member and a wave argmax.  Any pivot yields the same count (tomita.h:12-40 is a
+            // heuristic): such a node takes its FIRST candidate.
+            if (sh.small_p > 1) {
+                int pc = 0;
+#pragma unroll
+                for (int h = 0; h < WPL; ++h) pc += __popc(P[h]);
+                pc = wave_sum(pc);
+                if (pc <= sh.small_p) {  // wave-uniform
+                    int hsel = 0;
+#pragma unroll
+                    for (int h = WPL - 1; h >= 0; --h)
+                        if (__ballot(P[h] != 0)) hsel = h;
+                    uint32_t pw = 0;
+                    int L0 = 0;
+#pragma unroll
+                    for (int h = 0; h < WPL; ++h)
+                        if (h == hsel) {
+                            L0 = __ffsll((long long)__ballot(P[h] != 0)) - 1;
+                            pw = __builtin_amdgcn_readlane(P[h], L0);
+                        }
+                    const int best0 = ((L0 + 64 * hsel) << 5) + __ffs(pw) - 1;
+#pragma unroll
+                    for (int h = 0; h < WPL; ++h) {
+                        const int w = lane + 64 * h;
+                        const uint32_t prow = w < cw ? Cadj[size_t(best0) * cw + w] : 0u;
+                        ext[h] = P[h] & ~prow;
+                    }
+                    entering = false;
+                }
+            }
+            if (entering) {
             // pivot: argmax over u in P ∪ Xc of |P ∩ N(u)|.  One LANE per candidate: P is parked in LDS, the members of
             // P ∪ Xc are expanded into an LDS list (wave prefix sum of the per-word popcounts), then every lane scores its
             // own candidates with independent row loads (64 rows in flight instead of one dependent load per candidate).
@@ -344,6 +377,7 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                 ext[h] = P[h] & ~prow;
             }
             entering = false;
+            }
         }
         // next branch vertex q of this node
         unsigned long long nzh[WPL];
@@ -1267,6 +1301,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     sh.dir_count = acc + kCtl + 5;
     sh.max_stack = acc + kCtl + 6;
     sh.budget = 512;  // nodes before a search is re-split: swept 128 … 8192 on the config-4 graph and Kronecker scale 14 after the occupancy work
+    sh.small_p = [] { const char *e = std::getenv("GMSX_BK_SMALL_P"); return e ? std::atoi(e) : 3; }();  // A/B knob
     sh.bmoff = g->bmoff;
     sh.bmpool = g->bmpool;
     sh.dense_limit = g->dense_limit;
