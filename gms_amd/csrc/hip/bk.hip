@@ -1301,7 +1301,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     sh.dir_count = acc + kCtl + 5;
     sh.max_stack = acc + kCtl + 6;
     sh.budget = 512;  // nodes before a search is re-split: swept 128 … 8192 on the config-4 graph and Kronecker scale 14 after the occupancy work
-    sh.small_p = [] { const char *e = std::getenv("GMSX_BK_SMALL_P"); return e ? std::atoi(e) : 3; }();  // A/B knob
+    sh.small_p = [] { const char *e = std::getenv("GMSX_BK_SMALL_P"); return e ? std::atoi(e) : 6; }();  // swept on the configs[3] graph: 0 (off) 316 ms, 2 304, 3 ~300, 4 295, 6 293, 8 295, 16 303
     sh.bmoff = g->bmoff;
     sh.bmpool = g->bmpool;
     sh.dense_limit = g->dense_limit;
