@@ -546,6 +546,50 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                 }
             continue;
         }
+        {
+            // FAST PATH: the child has ONE candidate q2 — the child is decided like a one-candidate node above, with its Xf = Xf ∩ N(q) formed
+            // on the fly: one maximal clique iff nothing finished is adjacent to q2 as well.  No level pushed.
+            int lanes_nz = 0;
+#pragma unroll
+            for (int h = 0; h < WPL; ++h) lanes_nz += __popcll(__ballot(Pn[h] != 0));
+            if (lanes_nz == 1) {
+                int h2 = 0;
+#pragma unroll
+                for (int h = 0; h < WPL; ++h)
+                    if (__ballot(Pn[h] != 0)) h2 = h;
+                unsigned long long nzl = 0;
+                uint32_t pw = 0;
+#pragma unroll
+                for (int h = 0; h < WPL; ++h)
+                    if (h == h2) {
+                        nzl = __ballot(Pn[h] != 0);
+                        pw = __builtin_amdgcn_readlane(Pn[h], __ffsll((long long)nzl) - 1);
+                    }
+                if ((pw & (pw - 1u)) == 0u) {
+                    const int q2 = ((__ffsll((long long)nzl) - 1 + 64 * h2) << 5) + __ffs(pw) - 1;
+                    uint32_t any = 0;
+#pragma unroll
+                    for (int h = 0; h < WPL; ++h) {
+                        const int w = lane + 64 * h;
+                        any |= w < cw ? (Xcn[h] & Cadj[size_t(q2) * cw + w]) : 0u;
+                    }
+                    if (xf_ne && __ballot(any != 0) == 0) {
+                        const uint32_t *xt = XT + size_t(q) * xw, *xt2 = XT + size_t(q2) * xw;
+                        for (int w = lane; w < xw; w += 64) any |= lv[3 * cw + w] & xt[w] & xt2[w];
+                    }
+                    if (__ballot(any != 0) == 0) cnt++;
+                    nodes += 2;
+#pragma unroll
+                    for (int h = 0; h < WPL; ++h)
+                        if (h == hsel && lane == L) {
+                            ext[h] &= ~(1u << bit);
+                            P[h] &= ~(1u << bit);
+                            Xc[h] |= 1u << bit;
+                        }
+                    continue;
+                }
+            }
+        }
         uint32_t *nx = lv + lvl;
         int child_ne = 0;
         if (xf_ne) {
