@@ -1104,6 +1104,10 @@ __global__ __launch_bounds__(256) void k_bk_block(const int64_t *__restrict__ of
                 const bool is_cand = j < c;
                 const int col = j - c;
                 auto hit = [&](int k) {
+#ifdef GMSX_BK_NO_HIT_ATOMICS  // A/B build (wrong counts): the build without its global atomics — 100 of 103 ms remain: they are not its limit
+                    if (k < 0) Cadj[0] = 1;
+                    return;
+#endif
                     if (is_cand) {
                         atomicOr(&Cadj[size_t(j) * cw + (k >> 5)], 1u << (k & 31));
                         atomicOr(&Cadj[size_t(k) * cw + (j >> 5)], 1u << (j & 31));
@@ -1214,9 +1218,13 @@ __global__ __launch_bounds__(64) void k_bk_build(const int64_t *__restrict__ off
     }
 }
 
+#ifndef GMSX_BK_RESUME_WAVES
+#define GMSX_BK_RESUME_WAVES 5  // waves per SIMD the one-word-per-lane resume kernel is compiled for: at 6 (80 VGPRs) the fast paths of the search
+                                // spill 40 bytes per lane; 5 (102 VGPRs, no scratch) is 5 ms faster on the configs[3] graph
+#endif
 // Rounds >= 1: one wave per resumable record; Cadj | XT are read from the arena, the stack lives in this wave's slab.
 template <int WPL>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? 6 : WPL == 2 ? 3 : 1))) void k_bk_resume(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? GMSX_BK_RESUME_WAVES : WPL == 2 ? 3 : 1))) void k_bk_resume(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in,
                                                   unsigned long long n_records, unsigned long long *__restrict__ queue,
                                                   uint32_t *__restrict__ slabs, unsigned long long slab_words,
                                                   unsigned long long *__restrict__ acc, BkShared sh) {
