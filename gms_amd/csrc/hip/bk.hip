@@ -998,7 +998,10 @@ struct BkRowJob {
     int32_t a;         // rank id whose oriented row is streamed; < 0: nothing (an out-neighbour position, or past the end)
     int64_t hs, he, ts, te;
 };
-__global__ __launch_bounds__(256) void k_bk_block(const int64_t *__restrict__ off, const int32_t *__restrict__ adj, const int32_t *__restrict__ newid,
+#ifndef GMSX_BK_BLOCK_WAVES
+#define GMSX_BK_BLOCK_WAVES 5
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLOCK_WAVES))) void k_bk_block(const int64_t *__restrict__ off, const int32_t *__restrict__ adj, const int32_t *__restrict__ newid,
                                                   const int32_t *__restrict__ oldid, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, const int32_t *__restrict__ dplus,
                                                   const int32_t *__restrict__ task_v, int64_t lo, int nparts, int part, int64_t q0, int64_t q1,
