@@ -52,7 +52,7 @@ def test_gpus_launcher_reaps_failed_ranks_instead_of_hanging(capi):
     t0 = time.time()
     r = subprocess.run([exe, "tc", "-g", "kronecker", "6", "--gpus", "3", "-n", "1"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 3 and time.time() - t0 < 60, (r.returncode, r.stderr)
-    assert "a rank ended with status 3" in r.stderr and "no HIP device" in r.stdout
+    assert "a rank ended with status 3" in r.stderr  # (rank 0's own "no HIP device" line may or may not get out before it is stopped)
     assert set(glob.glob("/tmp/gmsx_driver_id_*")) == before
     r = subprocess.run([exe, "tc", "-g", "kronecker", "6", "--gpus", "2"], capture_output=True, text=True, timeout=60,
                        env=dict(os.environ, ROCPROF_TEST_MARKER="1"))
