@@ -16,6 +16,7 @@
 #include "device_graph.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -959,19 +960,25 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
 // alone needs neither the search's registers nor its stack, so it runs as its own kernel at twice the occupancy and writes Cadj | XT
 // STRAIGHT INTO THE ARENA (offsets from a prefix sum over the chunk: no slab, no copy when the search is split later) plus a ROOT RECORD
 // per start vertex (P = all candidates, Xc = {}, Xf = X0, flag "entering"); the search of the roots is then the ordinary resume kernel.
-// k_bk_layout: per task of a chunk the arena words, the record words, and the maxima the launch needs.
+// k_bk_layout: per task of a chunk the arena words, the record words, the pieces of the workgroup build, and the maxima the launch needs.
+#ifndef GMSX_BK_PIECE_JOBS
+#define GMSX_BK_PIECE_JOBS 2048
+#endif
+static constexpr int kBkPieceJobs = GMSX_BK_PIECE_JOBS;  // row jobs (candidate rows + CSR positions) of one k_bk_block work item: 128 trips of 16 rows
 __global__ void k_bk_layout(int64_t lo, int64_t cnt, int nparts, int part, const int32_t *__restrict__ task_v, const int64_t *__restrict__ off,
                             const int32_t *__restrict__ oldid, const int32_t *__restrict__ dplus, int x_is_degree, int64_t *__restrict__ need_a,
-                            int64_t *__restrict__ need_r, unsigned long long *__restrict__ maxima /* [0] (c+1)*lvl  [1] global map words */) {
+                            int64_t *__restrict__ need_r, int64_t *__restrict__ need_p,
+                            unsigned long long *__restrict__ maxima /* [0] (c+1)*lvl  [1] global map words */) {
     const int64_t qi = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (qi > cnt) return;
-    if (qi == cnt) { need_a[qi] = 0; need_r[qi] = 0; return; }
+    if (qi == cnt) { need_a[qi] = 0; need_r[qi] = 0; need_p[qi] = 0; return; }
     const int32_t v = task_v[lo + qi * nparts + part];
     const int32_t vo = oldid[v];
     const long long c = dplus[v], x = (off[vo + 1] - off[vo]) - (x_is_degree ? 0 : c);  // k_bk_block: one XT column per CSR position of v's row
     const long long cw = (c + 31) >> 5, xw = (x + 31) >> 5;
     need_a[qi] = (c * cw + c * xw + 3) & ~3ll;
     need_r[qi] = kRecHeader + 3 * cw + xw;
+    need_p[qi] = (c + (off[vo + 1] - off[vo]) + kBkPieceJobs - 1) / kBkPieceJobs;  // k_bk_block: pieces of kBkPieceJobs row jobs (>= 1: c > 0)
     atomicMax(&maxima[0], (unsigned long long)((c + 1) * (3 * cw + xw + 1)));
     const unsigned long long msize = bk_map_size(int(c));
     if (msize > 1024) atomicMax(&maxima[1], 2ull * msize);
@@ -986,6 +993,13 @@ __global__ void k_bk_chunk_end(int64_t start, int64_t cnt, const int64_t *__rest
     }
     out[0] = lo;
 }
+// one entry per piece: task index << 20 | piece index (a start vertex of degree 2^31 has 2^20 pieces)
+__global__ void k_bk_pieces(int64_t cnt, const int64_t *__restrict__ poff, unsigned long long *__restrict__ pieces) {
+    const int64_t qi = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (qi >= cnt) return;
+    const int64_t b = poff[qi], e = poff[qi + 1];
+    for (int64_t i = b; i < e; ++i) pieces[i] = ((unsigned long long)qi << 20) | (unsigned long long)(i - b);
+}
 // k_bk_block: the same build by a WORKGROUP per start vertex, shaped like the triangle kernels — the candidates C = N+(v) staged in LDS as
 // the 65536-bit hub bitmap + the index of the first candidate of every bitmap word (candidates ascend, so local index = that + popcount
 // of the lower bits) and a 32768-bit filter in front of the ascending tail-candidate list; then every row that can hold an edge into C
@@ -994,6 +1008,10 @@ __global__ void k_bk_chunk_end(int64_t start, int64_t cnt, const int64_t *__rest
 // sixteen rows are in flight per workgroup with the ids and extents of the next two batches already loading, and no wave idles behind a
 // dependent chain.  XT has one column per CSR POSITION of v's row (x = degree; the positions of out-neighbours stay empty), so no
 // compaction or scan over the in-neighbours is needed; the root record's Xf is the mask of the in-neighbour positions.
+// A work item is a PIECE of a start vertex: kBkPieceJobs of its row jobs.  A hub late in the order has few candidates but 10^5..10^6 CSR
+// positions, and one workgroup walking them sixteen at a time WAS the kernel's duration (measured: 94 of 129 ms remained with the row scans
+// compiled out); the LDS sets cost only the candidates to rebuild, every hit is an atomic OR, so the pieces of one vertex run anywhere.
+// Cadj | XT are zeroed by the host (one fill of the chunk's arena span) before the launch; piece 0 writes the root record.
 struct BkRowJob {
     int32_t a;         // rank id whose oriented row is streamed; < 0: nothing (an out-neighbour position, or past the end)
     int64_t hs, he, ts, te;
@@ -1004,12 +1022,16 @@ struct BkRowJob {
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLOCK_WAVES))) void k_bk_block(const int64_t *__restrict__ off, const int32_t *__restrict__ adj, const int32_t *__restrict__ newid,
                                                   const int32_t *__restrict__ oldid, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, const int32_t *__restrict__ dplus,
-                                                  const int32_t *__restrict__ task_v, int64_t lo, int nparts, int part, int64_t q0, int64_t q1,
+                                                  const int32_t *__restrict__ task_v, int64_t lo, int nparts, int part, int64_t q0,
+                                                  const unsigned long long *__restrict__ pieces, int64_t p0, int64_t p1,
                                                   const int64_t *__restrict__ aoff, const int64_t *__restrict__ roff, unsigned long long *__restrict__ queue,
                                                   BkShared sh) {
     __shared__ __attribute__((aligned(16))) uint32_t bm[2048];
     __shared__ unsigned short pre[2048];
     __shared__ __attribute__((aligned(16))) uint32_t flt[1024];
+    constexpr int kTailLds = 1024;
+    __shared__ int32_t tcand[kTailLds];  // the ascending tail candidates (when they fit): the filter lets ~tc / 32768 of the streamed tail ids
+                                          // through, and a binary search in GLOBAL memory behind it stalled the whole wave for ~8 dependent round trips
     __shared__ long long s_task;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = tid >> 4, sub = tid & 15;  // 16 groups of 16 lanes
@@ -1017,8 +1039,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
         __syncthreads();
         if (tid == 0) s_task = (long long)atomicAdd(queue, 1ull);
         __syncthreads();
-        const int64_t qi = q0 + s_task;
-        if (qi >= q1) break;
+        if (p0 + s_task >= p1) break;
+        const unsigned long long piece = pieces[p0 + s_task];
+        const int64_t qi = int64_t(piece >> 20);
+        const int piece_i = int(piece & 0xfffffull);
         const int32_t v = task_v[lo + qi * nparts + part];
         const int32_t vo = oldid[v];
         const int c = dplus[v];
@@ -1031,14 +1055,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
         uint32_t *Cadj = sh.arena + a0;
         uint32_t *XT = Cadj + size_t(c) * cw;
         uint32_t *rec = sh.pool + (unsigned long long)(roff[qi] - roff[q0]);
-        {   // zero Cadj | XT (the arena offset and the rounded size are multiples of four words), the LDS sets, the record's Xf
-            const size_t n4 = ((size_t(c) * cw + size_t(c) * xw + 3) & ~size_t(3)) / 4;
-            uint4 *z4 = reinterpret_cast<uint4 *>(Cadj);
-            for (size_t i = tid; i < n4; i += 256) z4[i] = make_uint4(0u, 0u, 0u, 0u);
-            for (int i = tid; i < 512; i += 256) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
-            reinterpret_cast<uint4 *>(flt)[tid] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        __threadfence();
+        for (int i = tid; i < 512; i += 256) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4 *>(flt)[tid] = make_uint4(0u, 0u, 0u, 0u);
         __syncthreads();
         for (int i = tid; i < hc; i += 256) {
             const uint32_t id = hadj[vhb + i];
@@ -1048,8 +1066,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
         for (int i = tid; i < tc; i += 256) {
             const uint32_t id = uint32_t(tadj[vtb + i]);
             atomicOr(&flt[(id >> 5) & 1023u], 1u << (id & 31u));
+            if (i < kTailLds) tcand[i] = int32_t(id);
         }
-        // the record: header, P = C, Xc = ext = {}, Xf = the in-neighbour positions of v's CSR row
+        // the record (piece 0): header, P = C, Xc = ext = {}, Xf = the in-neighbour positions of v's CSR row
+        if (piece_i == 0) {
         if (tid == 0) {
             rec[0] = uint32_t(v);
             rec[1] = uint32_t(c);
@@ -1067,18 +1087,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
             rec[kRecHeader + cw + w] = 0u;
             rec[kRecHeader + 2 * cw + w] = 0u;
         }
-        for (int p0 = wave * 64; p0 < deg; p0 += 256) {
-            const int p = p0 + lane;
+        for (int pb = wave * 64; pb < deg; pb += 256) {
+            const int p = pb + lane;
             const bool keep = p < deg && newid[adj[ob + p]] > v;
             const unsigned long long m = __ballot(keep);
             if (lane == 0) {
-                rec[kRecHeader + 3 * cw + (p0 >> 5)] = uint32_t(m);
-                if ((p0 >> 5) + 1 < xw) rec[kRecHeader + 3 * cw + (p0 >> 5) + 1] = uint32_t(m >> 32);
+                rec[kRecHeader + 3 * cw + (pb >> 5)] = uint32_t(m);
+                if ((pb >> 5) + 1 < xw) rec[kRecHeader + 3 * cw + (pb >> 5) + 1] = uint32_t(m >> 32);
             }
+        }
         }
         __syncthreads();
         // ---- the row jobs: j < c -> candidate i = j (hits into Cadj); else CSR position p = j - c (in-neighbours only; hits into XT column p)
-        const int njobs = c + deg;
+        const int njobs = int(min(int64_t(c) + deg, (int64_t(piece_i) + 1) * kBkPieceJobs));  // this piece: jobs [piece_i * kBkPieceJobs, njobs)
         auto job_id = [&](int j) -> int32_t {  // the rank id whose row job j streams, -1 = none
             if (j >= njobs) return -1;
             if (j < c) return j < hc ? int32_t(hadj[vhb + j]) : tadj[vtb + (j - hc)];
@@ -1095,15 +1116,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
             }
             return r;
         };
-        // three-stage pipeline per group: ids of job k+2, extents of job k+1, rows of job k
-        int j = grp;
+        // A job's id is itself a chain of two fetches (CSR entry -> rank id): resolved in ONE iteration it stalls the group for a full round
+        // trip in the middle of every trip (vmcnt waits in order: the new load's value is needed at once, so everything in flight is waited
+        // for).  Split: raw(j) = the CSR entry (or, for a candidate job, its rank id, tagged), resolve() = the rank-id lookup one trip later.
+        auto job_raw = [&](int j) -> int32_t {  // >= 0: old id of CSR position j - c; <= -2: candidate job, rank id = -(x) - 2; -1: none
+            if (j >= njobs) return -1;
+            if (j < c) return -(j < hc ? int32_t(hadj[vhb + j]) : tadj[vtb + (j - hc)]) - 2;
+            return adj[ob + (j - c)];
+        };
+        auto job_resolve = [&](int32_t raw) -> int32_t {
+            if (raw == -1) return -1;
+            if (raw <= -2) return -(raw + 2);
+            const int32_t nw = newid[raw];
+            return nw > v ? nw : -1;
+        };
+        // four-stage pipeline per group: CSR entry of job k+4, rank id of job k+3, extents of job k+2 … wait, k+1: see below
+        //   trip t issues: raw(t+4)  |  resolve(raw(t+3))  |  extents(id(t+2))  |  rows(t)   — every load of a trip is independent of the others
+        int j = piece_i * kBkPieceJobs + grp;
         BkRowJob cur = job_rows(job_id(j));
         BkRowJob nxt = job_rows(job_id(j + 16));
         int32_t id2 = job_id(j + 32);
+        int32_t raw3 = job_raw(j + 48);
         for (; j < njobs; j += 16) {
-            const int32_t id3 = job_id(j + 48);
+            const int32_t raw4 = job_raw(j + 64);
+            const int32_t id3 = job_resolve(raw3);
             const BkRowJob nx2 = job_rows(id2);
+#if defined(GMSX_BK_AB) && GMSX_BK_AB == 1  // A/B builds (wrong counts): 1 = the job pipeline alone, 2 = + the row loads without their probes
+            if (cur.a == -12345) {
+#else
             if (cur.a >= 0) {
+#endif
                 const bool is_cand = j < c;
                 const int col = j - c;
                 auto hit = [&](int k) {
@@ -1118,18 +1160,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
                         atomicOr(&XT[size_t(k) * xw + (col >> 5)], 1u << (col & 31));
                     }
                 };
-                // hub part: eight 16-bit ids per 16-byte load against the bitmap
-                for (int64_t q = cur.hs + sub * 8; q < cur.he; q += 128) {
-                    const bk_u4 p4 = *reinterpret_cast<const bk_u4 *>(hadj + q);
-                    const int left = int(min(int64_t(8), cur.he - q));  // even, >= 2; the 0xFFFF pad is never in the bitmap
+                // A streamed id costs almost nothing next to the round trip that fetches it, and a 16-lane group with ONE 16-byte load in flight
+                // per lane waits a full trip per 128 hub ids / 64 tail ids: the first two hub loads and the first tail load of a row are issued
+                // together (rows of up to 256 + 64 ids cost one trip), longer rows continue two loads at a time.
+                auto probe_hub = [&](const bk_u4 &p4, int left) {  // eight 16-bit ids against the bitmap; the 0xFFFF pad is never in it
                     const uint32_t wds[4] = {p4.x, p4.y, p4.z, p4.w};
+#if defined(GMSX_BK_AB) && GMSX_BK_AB == 2
+                    if ((wds[0] ^ wds[1] ^ wds[2] ^ wds[3]) == 0x12345678u && left == 7) hit(0);
+                    return;
+#endif
                     uint32_t mask = 0;
 #pragma unroll
                     for (int t = 0; t < 8; ++t) {
                         const uint32_t id = (wds[t >> 1] >> ((t & 1) * 16)) & 0xffffu;
                         mask |= ((bm[id >> 5] >> (id & 31u)) & 1u) << t;
                     }
-                    mask &= (1u << left) - 1u;
+                    mask &= left >= 8 ? 0xffu : ((1u << max(left, 0)) - 1u);
                     while (mask) {
                         const int t = __ffs(mask) - 1;
                         mask &= mask - 1;
@@ -1137,18 +1183,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
                         const uint32_t word = bm[id >> 5];
                         hit(int(pre[id >> 5]) + __popc(word & ((1u << (id & 31u)) - 1u)));
                     }
-                }
-                // tail part: four 32-bit ids per load against the filter, the few that pass against the ascending tail-candidate list
-                if (tc > 0) {
-                    for (int64_t q = cur.ts + sub * 4; q < cur.te; q += 64) {
-                        const bk_u4 p4 = *reinterpret_cast<const bk_u4 *>(tadj + q);  // tadj is padded by four ids
-                        const int left = int(min(int64_t(4), cur.te - q));
-                        const uint32_t wds[4] = {p4.x, p4.y, p4.z, p4.w};
+                };
+                auto probe_tail = [&](const bk_u4 &p4, int left) {  // four 32-bit ids against the filter, the few that pass against the ascending list
+                    const uint32_t wds[4] = {p4.x, p4.y, p4.z, p4.w};
+#if defined(GMSX_BK_AB) && GMSX_BK_AB == 2
+                    if ((wds[0] ^ wds[1] ^ wds[2] ^ wds[3]) == 0x12345678u && left == 7) hit(0);
+                    return;
+#endif
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const uint32_t id = wds[t];
-                            if (t < left && ((flt[(id >> 5) & 1023u] >> (id & 31u)) & 1u)) {
-                                int lo2 = 0, hi2 = tc;
+                    for (int t = 0; t < 4; ++t) {
+                        const uint32_t id = wds[t];
+                        if (t < left && ((flt[(id >> 5) & 1023u] >> (id & 31u)) & 1u)) {
+                            int lo2 = 0, hi2 = tc;
+                            if (tc <= kTailLds) {
+                                while (lo2 < hi2) {
+                                    const int mid = (lo2 + hi2) >> 1;
+                                    if (uint32_t(tcand[mid]) < id) lo2 = mid + 1; else hi2 = mid;
+                                }
+                                if (lo2 < tc && uint32_t(tcand[lo2]) == id) hit(hc + lo2);
+                            } else {
                                 while (lo2 < hi2) {
                                     const int mid = (lo2 + hi2) >> 1;
                                     if (uint32_t(tadj[vtb + mid]) < id) lo2 = mid + 1; else hi2 = mid;
@@ -1157,11 +1210,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
                             }
                         }
                     }
+                };
+                const bk_u4 zero4{0u, 0u, 0u, 0u};
+                const int64_t te = tc > 0 ? cur.te : cur.ts;  // no tail candidates: the tail part of the row cannot hit
+                int64_t qh = cur.hs + sub * 8, qt = cur.ts + sub * 4;
+                {
+                    const bk_u4 h0 = qh < cur.he ? *reinterpret_cast<const bk_u4 *>(hadj + qh) : zero4;
+                    const bk_u4 h1 = qh + 128 < cur.he ? *reinterpret_cast<const bk_u4 *>(hadj + qh + 128) : zero4;
+                    const bk_u4 t0 = qt < te ? *reinterpret_cast<const bk_u4 *>(tadj + qt) : zero4;  // tadj is padded by four ids
+                    probe_hub(h0, int(min(int64_t(8), cur.he - qh)));
+                    probe_hub(h1, int(min(int64_t(8), cur.he - qh - 128)));
+                    probe_tail(t0, int(min(int64_t(4), te - qt)));
+                    qh += 256;
+                    qt += 64;
+                }
+                for (; qh < cur.he; qh += 256) {
+                    const bk_u4 h0 = *reinterpret_cast<const bk_u4 *>(hadj + qh);
+                    const bk_u4 h1 = qh + 128 < cur.he ? *reinterpret_cast<const bk_u4 *>(hadj + qh + 128) : zero4;
+                    probe_hub(h0, int(min(int64_t(8), cur.he - qh)));
+                    probe_hub(h1, int(min(int64_t(8), cur.he - qh - 128)));
+                }
+                for (; qt < te; qt += 128) {
+                    const bk_u4 t0 = *reinterpret_cast<const bk_u4 *>(tadj + qt);
+                    const bk_u4 t1 = qt + 64 < te ? *reinterpret_cast<const bk_u4 *>(tadj + qt + 64) : zero4;
+                    probe_tail(t0, int(min(int64_t(4), te - qt)));
+                    probe_tail(t1, int(min(int64_t(4), te - qt - 64)));
                 }
             }
             cur = nxt;
             nxt = nx2;
             id2 = id3;
+            raw3 = raw4;
         }
     }
 }
@@ -1385,8 +1464,9 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     // LAYOUT of the start vertices that get their own build kernel (arena and record offsets by prefix sums) and the arena itself: setup like
     // the task sort above — allocations of gigabytes now and then stall for a second, they are not part of the kernels' time
     const int64_t cnt_glob = split_build ? part_count(0, n_glob, nparts, part) : 0;
-    int64_t *need_a = nullptr, *need_r = nullptr, *aoff = nullptr, *roff = nullptr, *d_end = nullptr;
-    Guard g_na, g_nr, g_ao, g_ro, g_de, g_map;
+    int64_t *need_a = nullptr, *need_r = nullptr, *aoff = nullptr, *roff = nullptr, *d_end = nullptr, *need_p = nullptr, *poff = nullptr;
+    unsigned long long *pieces = nullptr;
+    Guard g_na, g_nr, g_ao, g_ro, g_de, g_map, g_np, g_po, g_pc;
     unsigned long long *maxima = acc + kCtl + 9;  // [0] stack words, [1] global map words
     unsigned long long mx[2] = {0, 0}, map_words = 0;
     int64_t build_waves = 0;
@@ -1397,9 +1477,11 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&aoff), size_t(cnt_glob + 1) * 8)); g_ao.p = aoff;
         GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&roff), size_t(cnt_glob + 1) * 8)); g_ro.p = roff;
         GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_end), 8)); g_de.p = d_end;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&need_p), size_t(cnt_glob + 1) * 8)); g_np.p = need_p;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&poff), size_t(cnt_glob + 1) * 8)); g_po.p = poff;
         GMSX_HIP(hipMemsetAsync(maxima, 0, 16, s));
         hipLaunchKernelGGL(k_bk_layout, dim3(unsigned(cnt_glob / 256 + 1)), dim3(256), 0, s, int64_t(0), cnt_glob, nparts, part, v_out, g->off, g->oldid, g->dplus,
-                           split_build >= 2 ? 1 : 0, need_a, need_r, maxima);
+                           split_build >= 2 ? 1 : 0, need_a, need_r, need_p, maxima);
         {
             size_t scan_bytes = 0;
             GMSX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, need_a, aoff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
@@ -1409,13 +1491,23 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
             g_scan.p = scan_tmp;
             GMSX_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, need_a, aoff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
             GMSX_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, need_r, roff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
+            GMSX_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, need_p, poff, int64_t(0), size_t(cnt_glob + 1), rocprim::plus<int64_t>(), s));
             GMSX_HIP(hipStreamSynchronize(s));
+        }
+        if (split_build >= 2) {  // the work items of k_bk_block
+            int64_t n_pieces = 0;
+            GMSX_HIP(hipMemcpy(&n_pieces, poff + cnt_glob, 8, hipMemcpyDeviceToHost));
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&pieces), size_t(n_pieces + 1) * 8)); g_pc.p = pieces;
+            hipLaunchKernelGGL(k_bk_pieces, dim3(unsigned(cnt_glob / 256 + 1)), dim3(256), 0, s, cnt_glob, poff, pieces);
         }
         GMSX_HIP(hipMemcpy(mx, maxima, sizeof(mx), hipMemcpyDeviceToHost));
         int64_t need_total = 0;
         GMSX_HIP(hipMemcpy(&need_total, aoff + cnt_glob, 8, hipMemcpyDeviceToHost));
         // the roots may take 3/4 of the arena (below): everything in one chunk when the device allows, + room for the LDS-slab searches that split
         if (int rc = alloc_arena((unsigned long long)need_total / 3 * 4 + (512ull << 20) / 4)) return rc;
+        if (std::getenv("GMSX_BK_VERBOSE"))
+            std::fprintf(stderr, "[gmsx bk] start vertices %lld: %lld built in the arena (%lld words), %lld in LDS slabs\n", (long long)n_tasks, (long long)cnt_glob,
+                         (long long)need_total, (long long)(n_tasks - n_glob));
         map_words = split_build >= 2 ? 0ull : (mx[1] + 3ull) & ~3ull;
         build_waves = std::min<int64_t>(cnt_glob, int64_t(cu) * 24);
         if (map_words > 0) {
@@ -1552,14 +1644,21 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 GMSX_HIP(hipMemcpyAsync(sh.pool_head, ctl0, sizeof(ctl0), hipMemcpyHostToDevice, s));
                 GMSX_HIP(hipMemcpyAsync(sh.arena_head, &ah, 8, hipMemcpyHostToDevice, s));
                 GMSX_HIP(hipMemsetAsync(bqueue, 0, 8, s));
-                GMSX_HIP(hipStreamSynchronize(s));  // ctl0 / ah are stack variables
+                int64_t pspan[2] = {0, 0};
+                if (split_build >= 2) {  // Cadj | XT of the chunk start empty: the pieces of a start vertex only OR into them
+                    GMSX_HIP(hipMemsetAsync(sh.arena, 0, size_t(ah) * 4, s));
+                    GMSX_HIP(hipMemcpyAsync(&pspan[0], poff + q0, 8, hipMemcpyDeviceToHost, s));
+                    GMSX_HIP(hipMemcpyAsync(&pspan[1], poff + q1, 8, hipMemcpyDeviceToHost, s));
+                }
+                GMSX_HIP(hipStreamSynchronize(s));  // ctl0 / ah / pspan are stack variables
                 if (!tiny_done) {  // the LDS-slab tasks run beside the first chunk's build; what they split off joins its records
                     if (int rc = launch_tiny(n_glob, n_tasks, true)) return rc;
                     tiny_done = true;
                 }
                 if (split_build >= 2)
-                    hipLaunchKernelGGL(k_bk_block, dim3(unsigned(std::min<int64_t>(q1 - q0, int64_t(cu) * 8))), dim3(256), 0, s, g->off, g->adj, g->newid, g->oldid,
-                                       g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, int64_t(0), nparts, part, q0, q1, aoff, roff, bqueue, sh);
+                    hipLaunchKernelGGL(k_bk_block, dim3(unsigned(std::min<int64_t>(pspan[1] - pspan[0], int64_t(cu) * 8))), dim3(256), 0, s, g->off, g->adj, g->newid,
+                                       g->oldid, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, v_out, int64_t(0), nparts, part, q0, pieces, pspan[0], pspan[1], aoff, roff,
+                                       bqueue, sh);
                 else
                     hipLaunchKernelGGL(k_bk_build, dim3(unsigned(std::min<int64_t>(q1 - q0, build_waves))), dim3(64), 0, s, g->off, g->adj, g->newid, g->oldid, g->hoff,
                                        g->hadj, g->toff, g->tadj, g->dplus, v_out, int64_t(0), nparts, part, q0, q1, aoff, roff, bqueue, map_scratch, map_words, sh);
