@@ -1652,7 +1652,8 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 }
                 GMSX_HIP(hipStreamSynchronize(s));  // ctl0 / ah / pspan are stack variables
                 if (!tiny_done) {  // the LDS-slab tasks run beside the first chunk's build; what they split off joins its records
-                    if (int rc = launch_tiny(n_glob, n_tasks, true)) return rc;
+                    static const bool beside = [] { const char *e = std::getenv("GMSX_BK_TINY_BESIDE"); return !e || std::atoi(e) != 0; }();  // 0: one after the other (profiling)
+                    if (int rc = launch_tiny(n_glob, n_tasks, beside)) return rc;
                     tiny_done = true;
                 }
                 if (split_build >= 2)
