@@ -140,9 +140,24 @@ __device__ __forceinline__ void bk_scan_row_group(const int64_t *__restrict__ ho
         bk_probe2(map, mask, cur.z, left > 4, f);
         bk_probe2(map, mask, cur.w, left > 6, f);
     }
-    for (int64_t j = tb + sub; j < te; j += 16) {
-        const int k = bk_find(map, mask, tadj[j]);
-        if (k >= 0) f(k);
+    // the tail container with 16-byte loads, two in flight per lane: 128 ids per trip of the group.  (One 4-byte load per lane and trip —
+    // 16 ids — made a candidate row of a few hundred ids a chain of a dozen dependent round trips: most of the LDS tasks' build time.)
+    for (int64_t j = tb + sub * 4; j < te; j += 128) {
+        const bk_u4 cur = *reinterpret_cast<const bk_u4 *>(tadj + j);  // tadj is padded by four ids
+        const bool two = j + 64 < te;
+        bk_u4 nxt{0u, 0u, 0u, 0u};
+        if (two) nxt = *reinterpret_cast<const bk_u4 *>(tadj + j + 64);
+        const int64_t left = te - j;  // >= 1
+        { const int k = bk_find(map, mask, int32_t(cur.x)); if (k >= 0) f(k); }
+        if (left > 1) { const int k = bk_find(map, mask, int32_t(cur.y)); if (k >= 0) f(k); }
+        if (left > 2) { const int k = bk_find(map, mask, int32_t(cur.z)); if (k >= 0) f(k); }
+        if (left > 3) { const int k = bk_find(map, mask, int32_t(cur.w)); if (k >= 0) f(k); }
+        if (two) {
+            { const int k = bk_find(map, mask, int32_t(nxt.x)); if (k >= 0) f(k); }
+            if (left > 65) { const int k = bk_find(map, mask, int32_t(nxt.y)); if (k >= 0) f(k); }
+            if (left > 66) { const int k = bk_find(map, mask, int32_t(nxt.z)); if (k >= 0) f(k); }
+            if (left > 67) { const int k = bk_find(map, mask, int32_t(nxt.w)); if (k >= 0) f(k); }
+        }
     }
 }
 
@@ -163,13 +178,22 @@ __device__ __forceinline__ void bk_scan_row_group8(const int64_t *__restrict__ h
         bk_probe2(map, mask, cur.z, left > 4, f);
         bk_probe2(map, mask, cur.w, left > 6, f);
     }
-    for (int64_t j = tb + sub * 4; j < te; j += 32) {
+    for (int64_t j = tb + sub * 4; j < te; j += 64) {  // two loads in flight per lane: 64 ids per trip of the group
         const bk_u4 cur = *reinterpret_cast<const bk_u4 *>(tadj + j);  // tadj is padded by four ids
+        const bool two = j + 32 < te;
+        bk_u4 nxt{0u, 0u, 0u, 0u};
+        if (two) nxt = *reinterpret_cast<const bk_u4 *>(tadj + j + 32);
         const int64_t left = te - j;  // >= 1
         { const int k = bk_find(map, mask, int32_t(cur.x)); if (k >= 0) f(k); }
         if (left > 1) { const int k = bk_find(map, mask, int32_t(cur.y)); if (k >= 0) f(k); }
         if (left > 2) { const int k = bk_find(map, mask, int32_t(cur.z)); if (k >= 0) f(k); }
         if (left > 3) { const int k = bk_find(map, mask, int32_t(cur.w)); if (k >= 0) f(k); }
+        if (two) {
+            { const int k = bk_find(map, mask, int32_t(nxt.x)); if (k >= 0) f(k); }
+            if (left > 33) { const int k = bk_find(map, mask, int32_t(nxt.y)); if (k >= 0) f(k); }
+            if (left > 34) { const int k = bk_find(map, mask, int32_t(nxt.z)); if (k >= 0) f(k); }
+            if (left > 35) { const int k = bk_find(map, mask, int32_t(nxt.w)); if (k >= 0) f(k); }
+        }
     }
 }
 
@@ -827,6 +851,11 @@ __device__ __forceinline__ void bk_build(const int64_t *__restrict__ off, const 
                     }
                 }
                 // tail candidates: stream their containers through the map, four rows per trip (one per 16-lane group)
+#if defined(GMSX_BK_AB) && GMSX_BK_AB == 5  // A/B builds (wrong counts): 4 = no in-neighbour rows, 5 = no tail-candidate rows, 6 = neither
+                if (c < 0)
+#elif defined(GMSX_BK_AB) && GMSX_BK_AB == 6
+                if (c < 0)
+#endif
                 for (int i0 = hc; i0 < c; i0 += 4) {
                     const int i = i0 + (lane >> 4);
                     if (i < c) {
@@ -840,6 +869,9 @@ __device__ __forceinline__ void bk_build(const int64_t *__restrict__ off, const 
             }
             // rows of the in-neighbours, 64 CSR entries per batch; t = index of the in-neighbour in X0
             int xbase = 0;
+#if defined(GMSX_BK_AB) && (GMSX_BK_AB == 4 || GMSX_BK_AB == 6)
+            if (c < 0)
+#endif
             for (int64_t e0 = ob; e0 < oe; e0 += 64) {
                 const int64_t e = e0 + lane;
                 int32_t nw = -1;
@@ -874,6 +906,9 @@ __device__ __forceinline__ void bk_build(const int64_t *__restrict__ off, const 
 
 // Round 0: one wave per start vertex.  LDS_SLAB: every structure of the search lives in this wave's LDS slab (tasks of
 // at most kLdsSlabWords words); otherwise in slabs[block * slab_words].
+#ifndef GMSX_BK_GRAB
+#define GMSX_BK_GRAB 8
+#endif
 template <bool LDS_SLAB, int WPL>
 __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off, const int32_t *__restrict__ adj,
                                                 const int32_t *__restrict__ newid, const int32_t *__restrict__ oldid,
@@ -901,10 +936,18 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
     const int lane = threadIdx.x;
     uint32_t *slab = LDS_SLAB ? lds_slab : slabs + size_t(blockIdx.x) * slab_words;
     unsigned long long cnt = 0;
+    // the LDS tasks take kGrab consecutive start vertices per queue ticket: 1.65 M tickets on ONE address (a device-scope atomic is resolved
+    // behind the L2s of the eight XCDs) were a serial resource of the kernel
+    constexpr int64_t kGrab = LDS_SLAB ? GMSX_BK_GRAB : 1;
+    int64_t q_next = 0, q_end = 0;
     while (true) {
-        unsigned long long q0 = 0;
-        if (lane == 0) q0 = atomicAdd(queue, 1ull);
-        const int64_t qi = int64_t(uni64(q0));
+        if (q_next == q_end) {
+            unsigned long long q0 = 0;
+            if (lane == 0) q0 = atomicAdd(queue, (unsigned long long)kGrab);
+            q_next = int64_t(uni64(q0));
+            q_end = q_next + kGrab;
+        }
+        const int64_t qi = q_next++;
         const int64_t pos = first + qi * nparts + part;
         if (pos >= end) break;
         const int32_t v = uni32(task_v[pos]);
@@ -947,6 +990,9 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
                 }
             }
             __builtin_amdgcn_wave_barrier();
+#if defined(GMSX_BK_AB) && GMSX_BK_AB >= 3  // A/B build (wrong counts): the LDS tasks' build without their search
+            if (LDS_SLAB) { cnt += Cadj[0] & 1u; continue; }
+#endif
             bk_search<WR>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, x > 0 ? 1 : 0, true, lane, cnt, sh, kNoArena, !LDS_SLAB, piv_P, piv_list);
         }
         __builtin_amdgcn_wave_barrier();
@@ -964,7 +1010,11 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
 #ifndef GMSX_BK_PIECE_JOBS
 #define GMSX_BK_PIECE_JOBS 2048
 #endif
-static constexpr int kBkPieceJobs = GMSX_BK_PIECE_JOBS;  // row jobs (candidate rows + CSR positions) of one k_bk_block work item: 128 trips of 16 rows
+static constexpr int kBkPieceJobs = GMSX_BK_PIECE_JOBS;
+#ifndef GMSX_BK_BLOCK_GRAB
+#define GMSX_BK_BLOCK_GRAB 4
+#endif
+static constexpr int kBkBlockGrab = GMSX_BK_BLOCK_GRAB;  // pieces per queue ticket  // row jobs (candidate rows + CSR positions) of one k_bk_block work item: 128 trips of 16 rows
 __global__ void k_bk_layout(int64_t lo, int64_t cnt, int nparts, int part, const int32_t *__restrict__ task_v, const int64_t *__restrict__ off,
                             const int32_t *__restrict__ oldid, const int32_t *__restrict__ dplus, int x_is_degree, int64_t *__restrict__ need_a,
                             int64_t *__restrict__ need_r, int64_t *__restrict__ need_p,
@@ -1035,12 +1085,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
     __shared__ long long s_task;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = tid >> 4, sub = tid & 15;  // 16 groups of 16 lanes
+    long long t_next = 0;
+    int t_have = 0;  // pieces left of this workgroup's queue ticket (kBkBlockGrab per ticket)
     while (true) {
         __syncthreads();
-        if (tid == 0) s_task = (long long)atomicAdd(queue, 1ull);
-        __syncthreads();
-        if (p0 + s_task >= p1) break;
-        const unsigned long long piece = pieces[p0 + s_task];
+        if (t_have == 0) {
+            if (tid == 0) s_task = (long long)atomicAdd(queue, (unsigned long long)kBkBlockGrab);
+            __syncthreads();
+            t_next = s_task;
+            t_have = kBkBlockGrab;
+        }
+        const long long t_cur = t_next++;
+        --t_have;
+        if (p0 + t_cur >= p1) break;
+        const unsigned long long piece = pieces[p0 + t_cur];
         const int64_t qi = int64_t(piece >> 20);
         const int piece_i = int(piece & 0xfffffull);
         const int32_t v = task_v[lo + qi * nparts + part];
@@ -1307,7 +1365,7 @@ __global__ __launch_bounds__(64) void k_bk_build(const int64_t *__restrict__ off
 // Rounds >= 1: one wave per resumable record; Cadj | XT are read from the arena, the stack lives in this wave's slab.
 template <int WPL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? GMSX_BK_RESUME_WAVES : WPL == 2 ? 3 : 1))) void k_bk_resume(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in,
-                                                  unsigned long long n_records, unsigned long long *__restrict__ queue,
+                                                  unsigned long long n_records, unsigned long long *__restrict__ queue, unsigned grab,
                                                   uint32_t *__restrict__ slabs, unsigned long long slab_words,
                                                   unsigned long long *__restrict__ acc, BkShared sh) {
     __shared__ unsigned char xfne_stack[2052 * WPL];
@@ -1316,10 +1374,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? G
     const int lane = threadIdx.x;
     uint32_t *stack = slabs + size_t(blockIdx.x) * slab_words;
     unsigned long long cnt = 0;
+    unsigned long long q_next = 0, q_end = 0;  // `grab` records per queue ticket (tickets on one address are a serial resource: ~10 ns each)
     while (true) {
-        unsigned long long q0 = 0;
-        if (lane == 0) q0 = atomicAdd(queue, 1ull);
-        q0 = uni64(q0);
+        if (q_next == q_end) {
+            unsigned long long t0 = 0;
+            if (lane == 0) t0 = atomicAdd(queue, (unsigned long long)grab);
+            q_next = uni64(t0);
+            q_end = q_next + grab;
+        }
+        const unsigned long long q0 = q_next++;
         if (q0 >= n_records) break;
         const unsigned long long roff = uni64(dir_in[q0]);
         if (roff == ~0ull) continue;  // a claimed-but-unwritten directory slot (its wave kept the search)
@@ -1456,6 +1519,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipMemsetAsync(sh.dir, 0xff, sh.dir_cap * 8, s));
     // 2 (default): k_bk_block, a workgroup per start vertex, rows streamed against an LDS bitmap; 1: k_bk_build, a wave per start vertex with
     // the hash-map build of k_bk_wave; 0: round 2's combined build + search bins
+    const int64_t resume_grab = [] { const char *e = std::getenv("GMSX_BK_RESUME_GRAB"); return e ? std::max(1, std::atoi(e)) : 1; }();  // measured on configs[3]: 8 costs 4 ms (the records of a round differ in cost; their queue is not the limit)
     const int split_build = [] { const char *e = std::getenv("GMSX_BK_SPLIT_BUILD"); return e ? std::atoi(e) : 2; }();
     int64_t n_tasks = 0;
     while (n_tasks < n && words[size_t(n_tasks)] > 0) ++n_tasks;
@@ -1564,17 +1628,19 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
             resume_cap = size_t(waves) * slab_bytes;
             GMSX_HIP(hipMalloc(&g_rslab.p, resume_cap));
         }
+        // records per queue ticket (GMSX_BK_RESUME_GRAB, default 1): one while the waves get fewer than 16 each
+        const unsigned grab = unsigned(std::max<int64_t>(1, std::min<int64_t>(resume_grab, int64_t(n_rec) / (waves * 16))));
         if (n_wide > 0 && wpl_wide == 2)  // records of wide tasks may be anywhere in the pool
-            hipLaunchKernelGGL(k_bk_resume<2>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue,
+            hipLaunchKernelGGL(k_bk_resume<2>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
                                static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
         else if (n_wide > 0 && wpl_wide == 4)
-            hipLaunchKernelGGL(k_bk_resume<4>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue,
+            hipLaunchKernelGGL(k_bk_resume<4>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
                                static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
         else if (n_wide > 0)
-            hipLaunchKernelGGL(k_bk_resume<8>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue,
+            hipLaunchKernelGGL(k_bk_resume<8>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
                                static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
         else
-            hipLaunchKernelGGL(k_bk_resume<1>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue,
+            hipLaunchKernelGGL(k_bk_resume<1>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
                                static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
         ++launches;
         if (++rounds > 100000) return GMSX_ERR_KERNEL;
