@@ -1629,6 +1629,9 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
             GMSX_HIP(hipMalloc(&g_rslab.p, resume_cap));
         }
         // records per queue ticket (GMSX_BK_RESUME_GRAB, default 1): one while the waves get fewer than 16 each
+        if (std::getenv("GMSX_BK_VERBOSE"))
+            std::fprintf(stderr, "[gmsx bk] round %d: %llu records (%llu pool words), %lld waves, stack %llu words, budget %u\n", rounds + 1, n_rec, ctl[0],
+                         (long long)waves, stack_w, sh.budget);
         const unsigned grab = unsigned(std::max<int64_t>(1, std::min<int64_t>(resume_grab, int64_t(n_rec) / (waves * 16))));
         if (n_wide > 0 && wpl_wide == 2)  // records of wide tasks may be anywhere in the pool
             hipLaunchKernelGGL(k_bk_resume<2>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,

@@ -595,7 +595,11 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                     const bool is_hub = i < hc;
                     const int32_t v = is_hub ? int32_t(hub_list[i]) : tail_list[i - hc];
                     uint32_t *orow = GLOBAL_ROWS ? stage + grp * W : rows + size_t(i) * WS;
+#ifdef GMSX_KC_NO_ROWS  // A/B build (wrong counts): the BUILD phase without its row streams
+                    if (v == -7) orow[0] = 1;
+#else
                     kc_build_member(hoff, hadj, toff, tadj, bmoff, bmpool, dense_limit, v, is_hub, hc, tail_list, tc, bm, pre, orow, sub);
+#endif
                 }
                 if (GLOBAL_ROWS) {
                     __builtin_amdgcn_wave_barrier();
