@@ -123,6 +123,31 @@ def test_bk_more_than_2048_candidates(gpu, oracle):
     g.free()
 
 
+def test_bk_late_hubs_are_built_in_pieces(gpu, oracle):
+    """Three mutually adjacent hubs that see every vertex of a sparse random graph H: whatever the order, a start vertex ends up with
+    20 000 CSR positions — a dozen pieces of the workgroup build (k_bk_block takes 2048 row jobs of a start vertex per work item, the
+    pieces of one vertex on different workgroups) — and, ranked last, with two candidates against 20 000 finished neighbours.  Every
+    maximal clique is (a maximal clique of H, isolated vertices included) + the three hubs: MC(H) from the oracle on H alone."""
+    n, eh, hubs = 20000, 50000, 3
+    rng = np.random.default_rng(33)
+    hu, hv = rng.integers(0, n, eh), rng.integers(0, n, eh)
+    keep = hu != hv
+    hcsr = gpu.HostCSR.from_edges(hu[keep].astype(np.int32), hv[keep].astype(np.int32), num_nodes=n)
+    want = oracle.bk_count(hcsr.offsets(), hcsr.neighbors())
+    hub_ids = np.arange(n, n + hubs, dtype=np.int32)
+    su, sv = np.meshgrid(hub_ids, np.arange(n, dtype=np.int32), indexing="ij")
+    hh = np.array([(a, b) for i, a in enumerate(hub_ids) for b in hub_ids[i + 1:]], dtype=np.int32)
+    src = np.concatenate([su.ravel(), hh[:, 0], hu[keep].astype(np.int32)])
+    dst = np.concatenate([sv.ravel(), hh[:, 1], hv[keep].astype(np.int32)])
+    g = gpu.DeviceGraph.from_csr(gpu.HostCSR.from_edges(src, dst))
+    assert g.bk_count() == want
+    ident = np.arange(n + hubs, dtype=np.int32)
+    assert g.bk_count(rank=ident) == want              # hubs last: few candidates, 20 000 finished neighbours each
+    assert g.bk_count(rank=ident[::-1].copy()) == want  # hubs first: 20 000 candidates each (the wide search kernels)
+    assert sum(g.bk_partial(p, 3) for p in range(3)) == want
+    g.free()
+
+
 @pytest.mark.parametrize("budget", [16, 48, 300])
 def test_bk_tiny_budget_splits_everything(gpu, oracle, budget):
     """A node budget of a few dozen nodes makes every non-trivial search split, again and again: every level with pending branches is cut
