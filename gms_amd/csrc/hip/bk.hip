@@ -1394,6 +1394,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? G
         const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
         const uint32_t *Cadj = sh.arena + aoff;
         const uint32_t *XT = Cadj + size_t(c) * cw;
+#ifdef GMSX_BK_STATS  // profiling build: records and their Xf words by candidate-count bucket, in the unused slots beside the accumulators
+        if (lane == 0) {
+            const int b = c <= 32 ? 0 : c <= 64 ? 1 : c <= 128 ? 2 : c <= 256 ? 3 : c <= 512 ? 4 : c <= 1024 ? 5 : 6;
+            atomicAdd(&acc[(blockIdx.x & 63) * 16 + 1 + b], 1ull);
+            atomicAdd(&acc[(blockIdx.x & 63) * 16 + 8 + b], (unsigned long long)xw);
+        }
+#endif
         uint32_t P[WPL], Xc[WPL], ext[WPL];
 #pragma unroll
         for (int h = 0; h < WPL; ++h) {
@@ -1477,7 +1484,11 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     BkShared sh{};
     // the arena (Cadj | XT of the start vertices of a chunk + of the LDS-slab searches that split) is sized by NEED once the layout of the
     // start vertices is known — a fixed 48 GB allocation per call cost seconds of first-touch time now and then
-    const unsigned long long arena_hard_cap = std::min<unsigned long long>(free_b / 4, 48ull << 30) / 4;
+    unsigned long long arena_hard_cap = std::min<unsigned long long>(free_b / 4, 48ull << 30) / 4;
+    if (const char *e = std::getenv("GMSX_BK_ARENA_MB")) {  // test hook: a small arena makes small graphs build their roots in several chunks
+        const long v = std::atol(e);
+        if (v >= 1) arena_hard_cap = std::min<unsigned long long>(arena_hard_cap, ((unsigned long long)v << 20) / 4);
+    }
     auto alloc_arena = [&](unsigned long long want_words) -> int {
         sh.arena_cap = std::min(arena_hard_cap, std::max<unsigned long long>(want_words, (256ull << 20) / 4));
         GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&sh.arena), sh.arena_cap * 4));
@@ -1837,6 +1848,13 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipStreamSynchronize(s));
     unsigned long long total = 0;
     for (int i = 0; i < 64; ++i) total += host[i * 16];
+#ifdef GMSX_BK_STATS
+    for (int b = 0; b < 7; ++b) {
+        unsigned long long nrec = 0, xws = 0;
+        for (int i = 0; i < 64; ++i) { nrec += host[i * 16 + 1 + b]; xws += host[i * 16 + 8 + b]; }
+        std::fprintf(stderr, "[gmsx bk] resumed records with c <= %d: %llu, mean Xf words %.1f\n", b < 6 ? 32 << b : 1 << 30, nrec, nrec ? double(xws) / double(nrec) : 0.0);
+    }
+#endif
     if (part == 0) total += host[kCtl];  // isolated vertices, counted once
     *out = total;
     if (st) {

@@ -148,6 +148,31 @@ def test_bk_late_hubs_are_built_in_pieces(gpu, oracle):
     g.free()
 
 
+def test_bk_roots_that_do_not_fit_the_arena_are_built_in_chunks(gpu):
+    """GMSX_BK_ARENA_MB (test hook) caps the arena: the start vertices too big for an LDS slab are then built and searched chunk by chunk
+    (as many heavy-first start vertices as fit 3/4 of the arena), every chunk with its own span of build pieces, arena fill and record
+    pool.  Same count as the oracle and as the one-chunk run; more launches."""
+    rec = GRAPHS["kronecker-14-16-relabel"]
+    want = rec["bk"]  # the compiled reference's count
+    csr = host_graph(gpu, rec["generator"], rec["scale"], rec["degree"], rec["relabel"])
+    g = gpu.DeviceGraph.from_csr(csr)
+    got, st = g.bk_count(stats=True)
+    assert got == want
+    old = os.environ.get("GMSX_BK_ARENA_MB")
+    os.environ["GMSX_BK_ARENA_MB"] = "1"
+    try:
+        got2, st2 = g.bk_count(stats=True)
+        assert got2 == want
+        assert st2["launches"] > st["launches"], (st, st2)
+        assert sum(g.bk_partial(p, 2) for p in range(2)) == want
+    finally:
+        if old is None:
+            os.environ.pop("GMSX_BK_ARENA_MB", None)
+        else:
+            os.environ["GMSX_BK_ARENA_MB"] = old
+    g.free()
+
+
 @pytest.mark.parametrize("budget", [16, 48, 300])
 def test_bk_tiny_budget_splits_everything(gpu, oracle, budget):
     """A node budget of a few dozen nodes makes every non-trivial search split, again and again: every level with pending branches is cut
