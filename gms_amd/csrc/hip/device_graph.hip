@@ -4,11 +4,13 @@
 #include "device_graph.hpp"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>  // before rocprim: its texture iterator calls the host memset
 #include <new>
+#include <random>
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -29,34 +31,47 @@ int ensure_init() { return ctx().device >= 0 ? GMSX_OK : gmsx_init(-1); }
 // ---- preprocessing kernels ------------------------------------------------------------------
 
 // One wave per row: checks the canonical-row invariant and accumulates Σ_{u<v}(d_u+d_v) and max degree.
-// flags[0] |= 1 unsorted/duplicate, 2 id out of range, 4 self loop, 8 asymmetric
+// flags[0] |= 1 unsorted/duplicate, 2 id out of range, 4 self loop; acc[3..6] = the arc-set hashes of the symmetry check.
+// SYMMETRY without a search per arc: the rows are strictly ascending (checked here), so the arcs form a SET, and the graph is symmetric iff
+// that set equals its transpose.  Both are hashed as multisets — Σ mix(u, v) and Σ mix(v, u) mod 2^64, twice with independent keyed mixes
+// (the keys are drawn per process) — and compared on the host: equal sets give equal sums, different sets collide with probability 2^-128.
+// A binary search of u in row v per arc (2.1 G random probes at scale 26) was 0.39 s of a 1.3 s upload; this streams the CSR once.
+// Σ_{u<v}(d_u+d_v) = Σ_u d_u² on a symmetric graph (every vertex is counted once per incident edge): no degree gathers either.
+__device__ __forceinline__ unsigned long long arc_mix(unsigned long long x) {  // splitmix64 finaliser
+    x ^= x >> 30;
+    x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27;
+    x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
 __global__ __launch_bounds__(256) void k_validate(int64_t n, const int64_t *__restrict__ off,
-                                                  const int32_t *__restrict__ adj, int check_symmetry,
-                                                  unsigned long long *__restrict__ acc /* [0]=flags [1]=elements [2]=maxdeg */) {
+                                                  const int32_t *__restrict__ adj, int check_symmetry, unsigned long long key0,
+                                                  unsigned long long key1,
+                                                  unsigned long long *__restrict__ acc /* [0]=flags [1]=elements [2]=maxdeg [3..6]=hashes */) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
     unsigned flags = 0;
     unsigned long long elems = 0;
     unsigned long long maxdeg = 0;
+    unsigned long long f0 = 0, r0 = 0, f1 = 0, r1 = 0;
     for (int64_t u = wave0; u < n; u += nwaves) {
         const int64_t b = off[u], e = off[u + 1];
         const unsigned long long du = (unsigned long long)(e - b);
         if (du > maxdeg) maxdeg = du;
+        if (lane == 0) elems += du * du;
         for (int64_t j = b + lane; j < e; j += 64) {
             const int32_t v = adj[j];
             if (v < 0 || v >= n) { flags |= 2; continue; }
             if (v == u) flags |= 4;
             if (j + 1 < e && adj[j + 1] <= v) flags |= 1;
-            const int64_t vb = off[v], ve = off[v + 1];
-            if (u < v) elems += du + (unsigned long long)(ve - vb);
             if (check_symmetry) {
-                int64_t lo = vb, hi = ve;
-                while (lo < hi) {
-                    const int64_t mid = (lo + hi) >> 1;
-                    if (adj[mid] < u) lo = mid + 1; else hi = mid;
-                }
-                if (lo >= ve || adj[lo] != u) flags |= 8;
+                const unsigned long long uv = ((unsigned long long)uint32_t(u) << 32) | uint32_t(v), vu = ((unsigned long long)uint32_t(v) << 32) | uint32_t(u);
+                f0 += arc_mix(uv ^ key0);
+                r0 += arc_mix(vu ^ key0);
+                f1 += arc_mix(uv * 0x9e3779b97f4a7c15ull + key1);
+                r1 += arc_mix(vu * 0x9e3779b97f4a7c15ull + key1);
             }
         }
     }
@@ -65,11 +80,21 @@ __global__ __launch_bounds__(256) void k_validate(int64_t n, const int64_t *__re
         flags |= __shfl_down(flags, s);
         const unsigned long long o = __shfl_down(maxdeg, s);
         maxdeg = o > maxdeg ? o : maxdeg;
+        f0 += __shfl_down(f0, s);
+        r0 += __shfl_down(r0, s);
+        f1 += __shfl_down(f1, s);
+        r1 += __shfl_down(r1, s);
     }
     if (lane == 0) {
         if (flags) atomicOr(&acc[0], (unsigned long long)flags);
         if (elems) atomicAdd(&acc[1], elems);
         atomicMax(&acc[2], maxdeg);
+        if (check_symmetry) {
+            atomicAdd(&acc[3], f0);
+            atomicAdd(&acc[4], r0);
+            atomicAdd(&acc[5], f1);
+            atomicAdd(&acc[6], r1);
+        }
     }
 }
 
@@ -1009,10 +1034,16 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
 
     // 1. invariant check + Σ(d_u+d_v) + max degree
     const int check_sym = (flags & GMSX_UPLOAD_TRUSTED) ? 0 : 1;
-    if (n > 0) hipLaunchKernelGGL(k_validate, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, check_sym, g->scratch);
-    unsigned long long acc[3] = {0, 0, 0};
+    static const std::array<unsigned long long, 2> sym_keys = [] {  // per-process keys of the symmetry hashes: no fixed input collides in every process
+        std::random_device rd;
+        return std::array<unsigned long long, 2>{((unsigned long long)rd() << 32) | rd(), ((unsigned long long)rd() << 32) | rd()};
+    }();
+    if (n > 0)
+        hipLaunchKernelGGL(k_validate, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, check_sym, sym_keys[0], sym_keys[1], g->scratch);
+    unsigned long long acc[7] = {0, 0, 0, 0, 0, 0, 0};
     GMSX_HIP(hipMemcpyAsync(acc, g->scratch, sizeof(acc), hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
+    if (check_sym && (acc[3] != acc[4] || acc[5] != acc[6])) acc[0] |= 8;  // the arc set differs from its transpose
     if (!(flags & GMSX_UPLOAD_TRUSTED) && acc[0] != 0) return GMSX_ERR_NOT_CANONICAL;
     if ((flags & GMSX_UPLOAD_TRUSTED) && (acc[0] & 2)) return GMSX_ERR_NOT_CANONICAL;  // out-of-range ids are never tolerated
     if (!(flags & GMSX_UPLOAD_TRUSTED) && (g->nnz & 1)) return GMSX_ERR_NOT_CANONICAL;

@@ -113,6 +113,25 @@ def test_upload_rejects_non_canonical_input(gpu):
     with pytest.raises(gpu.GmsxError) as ei:
         gpu.DeviceGraph.upload(off, np.array([1, 7, 0, 0], dtype=np.int32))
     assert ei.value.status == gpu.ERR_NOT_CANONICAL
+    # one arc of a real graph bent to a non-neighbour (rows stay ascending, loop-free, the arc count even): only the symmetry check —
+    # the keyed multiset hashes of the arc set and of its transpose — can see it; the untouched graph passes
+    csr = host_graph(gpu, "kronecker", 10)
+    off, adj = csr.offsets().copy(), csr.neighbors().copy()
+    gpu.DeviceGraph.upload(off, adj).free()
+    bent = 0
+    for u in range(len(off) - 1):
+        for j in range(off[u], off[u + 1] - 1):
+            if adj[j] + 1 < adj[j + 1] and adj[j] + 1 != u:
+                bad = adj.copy()
+                bad[j] += 1
+                with pytest.raises(gpu.GmsxError) as ei:
+                    gpu.DeviceGraph.upload(off, bad)
+                assert ei.value.status == gpu.ERR_NOT_CANONICAL
+                bent += 1
+                break
+        if bent == 20:
+            break
+    assert bent == 20
 
 
 def test_relabel_invariance_and_golden_scale20(gpu):
