@@ -1069,6 +1069,10 @@ struct BkRowJob {
 #ifndef GMSX_BK_BLOCK_WAVES
 #define GMSX_BK_BLOCK_WAVES 5
 #endif
+#ifndef GMSX_BK_ROWSCAN
+#define GMSX_BK_ROWSCAN 0  // 0: one 16-byte load in flight per lane and row part; 1: two.  configs[3]: alone 37.6 / 36.7 ms, the whole call 212.3 / 214.0 ms
+                           // (beside the LDS tasks the extra registers and instructions cost more than the second load gains)
+#endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLOCK_WAVES))) void k_bk_block(const int64_t *__restrict__ off, const int32_t *__restrict__ adj, const int32_t *__restrict__ newid,
                                                   const int32_t *__restrict__ oldid, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj, const int32_t *__restrict__ dplus,
@@ -1218,9 +1222,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
                         atomicOr(&XT[size_t(k) * xw + (col >> 5)], 1u << (col & 31));
                     }
                 };
-                // A streamed id costs almost nothing next to the round trip that fetches it, and a 16-lane group with ONE 16-byte load in flight
-                // per lane waits a full trip per 128 hub ids / 64 tail ids: the first two hub loads and the first tail load of a row are issued
-                // together (rows of up to 256 + 64 ids cost one trip), longer rows continue two loads at a time.
                 auto probe_hub = [&](const bk_u4 &p4, int left) {  // eight 16-bit ids against the bitmap; the 0xFFFF pad is never in it
                     const uint32_t wds[4] = {p4.x, p4.y, p4.z, p4.w};
 #if defined(GMSX_BK_AB) && GMSX_BK_AB == 2
@@ -1269,31 +1270,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
                         }
                     }
                 };
-                const bk_u4 zero4{0u, 0u, 0u, 0u};
                 const int64_t te = tc > 0 ? cur.te : cur.ts;  // no tail candidates: the tail part of the row cannot hit
-                int64_t qh = cur.hs + sub * 8, qt = cur.ts + sub * 4;
-                {
-                    const bk_u4 h0 = qh < cur.he ? *reinterpret_cast<const bk_u4 *>(hadj + qh) : zero4;
-                    const bk_u4 h1 = qh + 128 < cur.he ? *reinterpret_cast<const bk_u4 *>(hadj + qh + 128) : zero4;
-                    const bk_u4 t0 = qt < te ? *reinterpret_cast<const bk_u4 *>(tadj + qt) : zero4;  // tadj is padded by four ids
-                    probe_hub(h0, int(min(int64_t(8), cur.he - qh)));
-                    probe_hub(h1, int(min(int64_t(8), cur.he - qh - 128)));
-                    probe_tail(t0, int(min(int64_t(4), te - qt)));
-                    qh += 256;
-                    qt += 64;
+#if GMSX_BK_ROWSCAN == 0
+                for (int64_t q = cur.hs + sub * 8; q < cur.he; q += 128) probe_hub(*reinterpret_cast<const bk_u4 *>(hadj + q), int(min(int64_t(8), cur.he - q)));
+                for (int64_t q = cur.ts + sub * 4; q < te; q += 64) probe_tail(*reinterpret_cast<const bk_u4 *>(tadj + q), int(min(int64_t(4), te - q)));
+#else
+                // two loads in flight per lane and part; a probe is issued only where a load was (most rows of a late start vertex have no hub
+                // part at all: probing the zeros of an absent load cost a third of the kernel's VALU instructions)
+                for (int64_t q = cur.hs + sub * 8; q < cur.he; q += 256) {
+                    const bk_u4 h0 = *reinterpret_cast<const bk_u4 *>(hadj + q);
+                    const bool two = q + 128 < cur.he;
+                    bk_u4 h1{0u, 0u, 0u, 0u};
+                    if (two) h1 = *reinterpret_cast<const bk_u4 *>(hadj + q + 128);
+                    probe_hub(h0, int(min(int64_t(8), cur.he - q)));
+                    if (two) probe_hub(h1, int(min(int64_t(8), cur.he - q - 128)));
                 }
-                for (; qh < cur.he; qh += 256) {
-                    const bk_u4 h0 = *reinterpret_cast<const bk_u4 *>(hadj + qh);
-                    const bk_u4 h1 = qh + 128 < cur.he ? *reinterpret_cast<const bk_u4 *>(hadj + qh + 128) : zero4;
-                    probe_hub(h0, int(min(int64_t(8), cur.he - qh)));
-                    probe_hub(h1, int(min(int64_t(8), cur.he - qh - 128)));
+                for (int64_t q = cur.ts + sub * 4; q < te; q += 128) {
+                    const bk_u4 t0 = *reinterpret_cast<const bk_u4 *>(tadj + q);  // tadj is padded by four ids
+                    const bool two = q + 64 < te;
+                    bk_u4 t1{0u, 0u, 0u, 0u};
+                    if (two) t1 = *reinterpret_cast<const bk_u4 *>(tadj + q + 64);
+                    probe_tail(t0, int(min(int64_t(4), te - q)));
+                    if (two) probe_tail(t1, int(min(int64_t(4), te - q - 64)));
                 }
-                for (; qt < te; qt += 128) {
-                    const bk_u4 t0 = *reinterpret_cast<const bk_u4 *>(tadj + qt);
-                    const bk_u4 t1 = qt + 64 < te ? *reinterpret_cast<const bk_u4 *>(tadj + qt + 64) : zero4;
-                    probe_tail(t0, int(min(int64_t(4), te - qt)));
-                    probe_tail(t1, int(min(int64_t(4), te - qt - 64)));
-                }
+#endif
             }
             cur = nxt;
             nxt = nx2;

@@ -1,8 +1,11 @@
-"""GPU probe: Bron-Kerbosch on the BASELINE configs[3] graph (or `scale ef`): count vs golden, kernel time, rounds.  usage: bk_probe.py [scale ef]"""
+"""GPU probe: Bron-Kerbosch on the BASELINE configs[3] graph (or `scale ef`): count vs golden, kernel time, rounds.
+usage: bk_probe.py [scale ef] [--default-only]   (--default-only: skip the GMSX_BK_SPLIT_BUILD=1 / 0 comparison runs, e.g. under a profiler)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gms_amd import capi
-scale, ef = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (21, 56)
+default_only = "--default-only" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+scale, ef = (int(argv[0]), int(argv[1])) if len(argv) > 1 else (21, 56)
 capi.init(0)
 try:
     q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -13,7 +16,7 @@ except (OSError, ValueError):
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "graphs.json")))
 csr = capi.HostCSR.generate_rmat(scale, ef, 0.45, 0.22, 0.22)
 g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_TRUSTED)
-for knobs in ({}, {"GMSX_BK_SPLIT_BUILD": "1"}, {"GMSX_BK_SPLIT_BUILD": "0"}, {}):
+for knobs in (({},) if default_only else ({}, {"GMSX_BK_SPLIT_BUILD": "1"}, {"GMSX_BK_SPLIT_BUILD": "0"}, {})):
     os.environ.pop("GMSX_BK_SPLIT_BUILD", None)
     os.environ.update(knobs)
     ms = []
