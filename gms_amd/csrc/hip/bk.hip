@@ -208,6 +208,9 @@ __device__ __forceinline__ int wave_sum(int x) {
 // resumable RECORD into the next round's pool, and moves on.  The host launches rounds until the pool is empty, so a
 // huge search tree is re-split level by level across thousands of waves without any inter-wave synchronisation
 // inside a kernel.  If the arena or the pool is full the wave simply keeps searching (correctness never depends on it).
+#ifdef GMSX_BK_STATS
+__device__ unsigned long long g_bk_nodes;  // profiling build: nodes of the register-resident searches since the last read
+#endif
 struct BkShared {
     uint32_t *arena;
     unsigned long long arena_cap;       // words
@@ -529,6 +532,9 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                     if (lane == 0) atomicMax(sh.max_stack, (unsigned long long)(c + 1) * (unsigned long long)lvl);
                 }
             }
+#ifdef GMSX_BK_STATS
+            if (ok && lane == 0) atomicAdd(&g_bk_nodes, (unsigned long long)nodes);
+#endif
             if (ok) return;          // the rest of this search belongs to the next round
             budget = 0xffffffffu;    // no room: finish it here
         }
@@ -653,6 +659,9 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
         xf_ne = child_ne;
         entering = true;
     }
+#ifdef GMSX_BK_STATS
+    if (lane == 0) atomicAdd(&g_bk_nodes, (unsigned long long)nodes);
+#endif
 }
 
 // Memory-resident Tomita search for start vertices with more candidates than the register-resident kernels hold (c > 16384, or
@@ -1849,6 +1858,12 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     unsigned long long total = 0;
     for (int i = 0; i < 64; ++i) total += host[i * 16];
 #ifdef GMSX_BK_STATS
+    {
+        unsigned long long nodes = 0, zero = 0;
+        (void)hipMemcpyFromSymbol(&nodes, HIP_SYMBOL(g_bk_nodes), 8);
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bk_nodes), &zero, 8);
+        std::fprintf(stderr, "[gmsx bk] search nodes %llu, maximal cliques %llu\n", nodes, total);
+    }
     for (int b = 0; b < 7; ++b) {
         unsigned long long nrec = 0, xws = 0;
         for (int i = 0; i < 64; ++i) { nrec += host[i * 16 + 1 + b]; xws += host[i * 16 + 8 + b]; }
