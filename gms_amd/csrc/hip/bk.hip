@@ -11,8 +11,10 @@
 //   fini.intersect(N(q))  ->  Xc & Cadj[q]  (finished candidates)   and   Xf & XT[q]  (the in-neighbours, x-bit rows)
 //   cand.difference(N(p)) ->  P & ~Cadj[p]
 //   findPivot             ->  argmax_u popc(P & Cadj[u]) over u in P ∪ Xc  (any pivot choice yields the same count)
-// One wave per start vertex runs the recursion with an explicit stack; tiny problems keep every structure in LDS,
-// larger ones in a per-wave slab of global memory (L2-resident).  Start vertices are pulled heavy-first from a queue.
+// Round 0: start vertices whose structures fit 8 KB of LDS are built and searched by one wave each (k_bk_wave<true>, eight per queue ticket);
+// the others are BUILT by workgroups — k_bk_block, a piece of 2048 row jobs of a start vertex per work item, Cadj | XT straight into an arena
+// — and leave a root record.  Rounds >= 1 (k_bk_resume): one wave per record runs the recursion with an explicit stack in a global slab and,
+// past its node budget, re-splits what is left into records for the next round.
 #include "device_graph.hpp"
 
 #include <algorithm>
@@ -1201,8 +1203,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
             const int32_t nw = newid[raw];
             return nw > v ? nw : -1;
         };
-        // four-stage pipeline per group: CSR entry of job k+4, rank id of job k+3, extents of job k+2 … wait, k+1: see below
-        //   trip t issues: raw(t+4)  |  resolve(raw(t+3))  |  extents(id(t+2))  |  rows(t)   — every load of a trip is independent of the others
+        // four stages per group, a trip apart: trip t issues  raw(t+4) | resolve(raw(t+3)) | extents(id(t+2)) | the rows of job t
+        // — every load of a trip is independent of the others of that trip
         int j = piece_i * kBkPieceJobs + grp;
         BkRowJob cur = job_rows(job_id(j));
         BkRowJob nxt = job_rows(job_id(j + 16));
