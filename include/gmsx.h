@@ -136,7 +136,10 @@ int gmsx_device_info(char *name, size_t name_len, int *compute_units, int64_t *h
 
 enum {
     GMSX_UPLOAD_DEFAULT = 0,
-    GMSX_UPLOAD_TRUSTED = 1, /* skip the device-side check of the canonical-row invariant */
+    GMSX_UPLOAD_TRUSTED = 1, /* skip the device-side check of the canonical-row invariant.  The check (default): every row strictly
+                                ascending, ids in range, no self loops — exact — and the arc set equal to its transpose, decided by two
+                                keyed 64-bit multiset hashes of both (keys drawn per process): an asymmetric input passes with
+                                probability 2^-128, a symmetric one never fails */
     GMSX_UPLOAD_FOR_TC = 2   /* also build the triangle-count containers (stream rows, inline rows, task lists: ~5x the CSR) now, inside the
                                 upload — what a triangle-count harness wants in its untimed "GraphExec buildTime" (common/benchmark.h:
                                 105-109).  Without it they are built by gmsx_graph_prepare or by the first gmsx_tc_* call, and a k-clique /
