@@ -36,17 +36,22 @@ __device__ __forceinline__ uint32_t kc_hash(int32_t w, int shift) { return (uint
 // resolved in a short loop, so the probe path stays branch-free.
 struct __attribute__((packed, aligned(4))) kc_u4u { uint32_t x, y, z, w; };
 
-__device__ __forceinline__ uint32_t kc_bit(const uint32_t *bm, uint32_t id) { return (bm[id >> 5] >> (id & 31u)) & 1u; }
-
 __device__ __forceinline__ void kc_set_hub_hit(const uint32_t *bm, const unsigned short *pre, uint32_t *orow, uint32_t id) {
     const uint32_t word = bm[id >> 5];
     const int idx = int(pre[id >> 5]) + __popc(word & ((1u << (id & 31u)) - 1u));
     atomicOr(&orow[idx >> 5], 1u << (idx & 31));
 }
 
+// the bit of the low / high 16-bit id of a packed pair: one shift + mask for the word address, v_bfe_u32 for the bit (it uses offset[4:0] only,
+// so the low id needs no "& 31" and no "& 0xffff")
+__device__ __forceinline__ uint32_t kc_bit_lo(const uint32_t *bm, uint32_t p) { return __builtin_amdgcn_ubfe(bm[(p >> 5) & 0x7ffu], p, 1u); }
+__device__ __forceinline__ uint32_t kc_bit_hi(const uint32_t *bm, uint32_t p) {
+    const uint32_t q = p >> 16;
+    return __builtin_amdgcn_ubfe(bm[q >> 5], q, 1u);
+}
 __device__ __forceinline__ void kc_probe8(const uint32_t *bm, const unsigned short *pre, uint32_t *orow, kc_u4u p) {
-    uint32_t mask = kc_bit(bm, p.x & 0xffffu) | (kc_bit(bm, p.x >> 16) << 1) | (kc_bit(bm, p.y & 0xffffu) << 2) | (kc_bit(bm, p.y >> 16) << 3) |
-                    (kc_bit(bm, p.z & 0xffffu) << 4) | (kc_bit(bm, p.z >> 16) << 5) | (kc_bit(bm, p.w & 0xffffu) << 6) | (kc_bit(bm, p.w >> 16) << 7);
+    uint32_t mask = kc_bit_lo(bm, p.x) | (kc_bit_hi(bm, p.x) << 1) | (kc_bit_lo(bm, p.y) << 2) | (kc_bit_hi(bm, p.y) << 3) |
+                    (kc_bit_lo(bm, p.z) << 4) | (kc_bit_hi(bm, p.z) << 5) | (kc_bit_lo(bm, p.w) << 6) | (kc_bit_hi(bm, p.w) << 7);
     const unsigned long long lo = (unsigned long long)p.x | ((unsigned long long)p.y << 32), hi = (unsigned long long)p.z | ((unsigned long long)p.w << 32);
     while (mask) {
         const int s = __ffs(mask) - 1;
