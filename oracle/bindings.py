@@ -176,6 +176,9 @@ class Reference:
         L.ref_kclique.argtypes = [vp, C.c_int, C.c_int]
         L.ref_bk_count.restype = C.c_uint64
         L.ref_bk_count.argtypes = [vp, C.c_int, C.c_int]
+        if hasattr(L, "ref_kclist_count"):
+            L.ref_kclist_count.restype = C.c_uint64
+            L.ref_kclist_count.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ref_rank.argtypes = [vp, C.c_int, _i32p]
         if hasattr(L, "ref_tc_ordering"):
             L.ref_tc_ordering.argtypes = [vp, C.c_int, _i32p]
@@ -222,6 +225,13 @@ class Reference:
 
     def bk_count(self, g, set_kind=1, order=0):
         return int(self.L.ref_bk_count(g, set_kind, order))
+
+    def kclist_count(self, g, k, order=0, times=False):
+        """TRUE k-clique count (each clique once) by the reference's kClist pipeline (ref_shim.cc: ref_kclist_count).
+        order 0 = degeneracy (Danisch heap), 1 = degree, 2 = id."""
+        p, c = C.c_double(0), C.c_double(0)
+        v = int(self.L.ref_kclist_count(g, k, order, C.byref(p), C.byref(c)))
+        return (v, p.value, c.value) if times else v
 
     def rank(self, g, order=0):
         r = np.empty(self.L.ref_num_nodes(g), dtype=np.int32)

@@ -13,6 +13,10 @@
 //   BK          gms/algorithms/set_based/maximal_clique_enum/parallel/eppsteinPAR.h:18-53 (+ sequential/tomita.h:12-86)
 //   set algebra gms/representations/sets/sorted_set.h:21-272, roaring_set.h:15-229
 //   orderings   gms/algorithms/preprocessing/parallel/degeneracy_approx_set.h:14-86, degree.h:26-62, triangle_count.h:11-30
+//   kClist      gms/algorithms/non_set_based/k_clique_list/bench_helper.h:16-106 (CliqueCountPipeline: Preprocess + kclisting),
+//               kernels/kclisting.h:163-188 (KcListing::count), parallelizationStrategy/parallelize.h:38-80 (node-parallel):
+//               the reference's own source of TRUE k-clique counts (each clique once) — the only reference path that reaches
+//               RMAT scale 24/26 for k = 4 (the set-based CliqueCount needs 5 843 s at scale 22 and x7 per +2 scale)
 #include "gms/third_party/gapbs/benchmark.h"
 #include <gms/common/cli/cli.h>
 #include <gms/common/types.h>
@@ -23,6 +27,8 @@
 #include <gms/algorithms/set_based/maximal_clique_enum/bron_kerbosch.h>
 #include <gms/algorithms/set_based/vertex_similarity/vertex_similarity.h>
 #include <gms/algorithms/preprocessing/parallel/triangle_count.h>
+#include <gms/algorithms/preprocessing/preprocessing.h>
+#include <gms/algorithms/non_set_based/k_clique_list/bench_helper.h>
 
 #include <fcntl.h>
 #include <unistd.h>
@@ -222,6 +228,34 @@ void ref_vertex_similarity(void *h, int metric, int set_kind, int64_t n_pairs, c
     };
     if (set_kind == 0) { auto sg = SortedSetGraph::FromCGraph(g); run(sg); }
     else { auto sg = RoaringGraph::FromCGraph(g); run(sg); }
+}
+// TRUE k-clique count (every clique once) through the reference's kClist pipeline, driven exactly as
+// k_clique_list_danisch_node_parallel.cc:15-24 / bench_helper.h:33-38,71-77 do: `Preprocess` (sequential
+// getDegeneracyOrderingDanischHeap + InduceDirectedGraph) then `kclisting` (Par::NP_kclisting = Parallelize::node over
+// SubGraphBuilder + KcListing).  order: 0 = degeneracy (Preprocess), 1 = degree (PreprocessDegree), 2 = id (PreprocessSimple);
+// the count does not depend on it.  Returns the count; *prep_s / *count_s (may be NULL) receive the wall time of the two stages.
+uint64_t ref_kclist_count(void *h, int k, int order, double *prep_s, double *count_s) {
+    Quiet q;
+    CSRGraph &g = static_cast<RefGraph *>(h)->g;
+    std::vector<std::string> a = {"ref", "-g", "kronecker", "4"};  // only the harness fields of CLApp are read (clique size below)
+    std::vector<char *> argv;
+    for (auto &s : a) argv.push_back(const_cast<char *>(s.c_str()));
+    CLI::Parser parser;
+    CLI::Args args = parser.parse((int)argv.size(), argv.data());
+    KClique::CLCliqueApp app(args, CLI::Param(std::make_shared<std::string>(std::to_string(k))));
+    using P = KClique::CliqueCountPipeline<true, CSRGraph>;
+    P pipeline(app);
+    pipeline.originalGraph = &g;
+    double t0 = omp_get_wtime();
+    if (order == 0) pipeline.Preprocess();
+    else if (order == 1) pipeline.PreprocessDegree();
+    else pipeline.PreprocessSimple();
+    double t1 = omp_get_wtime();
+    pipeline.kclisting();
+    double t2 = omp_get_wtime();
+    if (prep_s) *prep_s = t1 - t0;
+    if (count_s) *count_s = t2 - t1;
+    return pipeline.count;
 }
 int ref_omp_threads(void) { return omp_get_max_threads(); }
 }

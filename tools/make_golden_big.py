@@ -5,6 +5,10 @@
     python tools/make_golden_big.py tc 26          # Par::count_total<RoaringGraph>, ~35 min on 8 threads, ~45 GB
     python tools/make_golden_big.py kc4 16|18|20   # CliqueCount<RoaringSet,RoaringGraph,RoaringSet>(g, 4)
     python tools/make_golden_big.py bk 14          # BkEppsteinPar::mceBench<RoaringGraph>, degree rank
+    python tools/make_golden_big.py kclist 24|26   # TRUE 4-clique count (each clique once) by the reference's kClist pipeline
+                                                   # (CliqueCountPipeline<true>: getDegeneracyOrderingDanischHeap + InduceDirectedGraph +
+                                                   # Par::NP_kclisting, bench_helper.h:33-38,71-77) -> field kc4_true; where the set-based
+                                                   # kc4 (= 24 * kc4_true) exists it is asserted equal
     python tools/make_golden_big.py bk-rmat 21 56  # BASELINE configs[3]: the com-Orkut-shaped R-MAT (A=.45 B=C=.22) of the gmsx loader,
                                                    # written as .sg (gmsx_csr_save_sg), read back by the reference (cli.h:96 `-f`,
                                                    # reader.h:252-305) and enumerated by BkEppsteinPar::mceBench<RoaringGraph>
@@ -79,8 +83,13 @@ def main():
         field, val, how = "kc4", R.kclique(g, 4, Reference.ROARING), "CliqueCount<RoaringSet,RoaringGraph,RoaringSet>(g,4)"
     elif what == "bk":
         field, val, how = "bk", R.bk_count(g, Reference.ROARING, 0), "BkEppsteinPar::mceBench<RoaringGraph>, degree rank"
+    elif what == "kclist":
+        val, prep_s, count_s = R.kclist_count(g, 4, 0, times=True)
+        field = "kc4_true"
+        how = ("kClist CliqueCountPipeline<true,CSRGraph>: Preprocess (DanischHeap degeneracy order + InduceDirectedGraph, %.0f s) + "
+               "Par::NP_kclisting k=4 (%.0f s)" % (prep_s, count_s))
     else:
-        raise SystemExit("what = tc | kc4 | bk")
+        raise SystemExit("what = tc | kc4 | bk | kclist")
     dt = time.time() - t0
     R.free(g)
     key = "kronecker-%d-%d-relabel" % (scale, deg)
@@ -92,6 +101,10 @@ def main():
         assert rec[field] == val, "existing golden %s=%d disagrees with the reference run: %d" % (field, rec[field], val)
     rec.update(n=n, m=m)
     rec[field] = val
+    if field == "kc4_true" and "kc4" in rec:
+        assert rec["kc4"] == 24 * val, "the reference's two k-clique paths disagree: set-based %d vs 24 * kClist %d" % (rec["kc4"], val)
+    if field == "kc4" and "kc4_true" in rec:
+        assert val == 24 * rec["kc4_true"], (val, rec["kc4_true"])
     rec.setdefault("sources", {})[field] = "oracle/_ref %s, %d threads, %.0f s (tools/make_golden_big.py)" % (how, R.omp_threads(), dt)
     with open(PATH, "w") as f:
         json.dump(graphs, f, indent=1)
