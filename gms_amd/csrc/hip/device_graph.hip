@@ -793,15 +793,35 @@ __global__ void k_item_counts(int64_t n_recv, const int64_t *__restrict__ lbeg, 
     if (p > n_recv) return;
     items[p] = p < n_recv ? (lbeg[p + 1] - lbeg[p] + kTaskChunk - 1) / kTaskChunk : 0;
 }
+// one thread per receiver: its list in chunks of kTaskChunk entries, each a self-contained record (device_graph.hpp) — the run
+// boundaries by binary search over the class-sorted chunk, the pivot's container part from coff (hoff / toff)
 __global__ void k_item_fill(int64_t n_recv, const int32_t *__restrict__ recv_v, const int32_t *__restrict__ opos, const int64_t *__restrict__ lbeg,
-                            const int64_t *__restrict__ ioff, gmsx_task_item *__restrict__ items) {
+                            const int64_t *__restrict__ ioff, const unsigned long long *__restrict__ task, const int64_t *__restrict__ coff, int kind,
+                            gmsx_tc_item *__restrict__ items) {
     const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p >= n_recv) return;
     const int32_t w = recv_v[p];
     const int64_t b = lbeg[p], e = lbeg[p + 1];
+    const uint64_t cont = uint64_t(coff[w]) | (uint64_t(coff[w + 1] - coff[w]) << 40);
     int64_t k = ioff[p];
-    for (int64_t x = b; x < e; x += kTaskChunk, ++k)
-        items[k] = gmsx_task_item{uint64_t(x) | (uint64_t(min(int64_t(kTaskChunk), e - x)) << 40), w, opos[w]};
+    for (int64_t x = b; x < e; x += kTaskChunk, ++k) {
+        const int ne = int(min(int64_t(kTaskChunk), e - x));
+        gmsx_tc_item it{};
+        it.bc = uint64_t(x) | (uint64_t(ne) << 40);
+        it.cont = cont;
+        it.pivot = w;
+        it.pos = opos[w];
+        it.kind = uint16_t(kind);
+        for (int r = 0; r <= 12; ++r) {  // first entry of run type >= r
+            int lo = 0, hi = ne;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (run_type(task[x + mid]) < r) lo = mid + 1; else hi = mid;
+            }
+            it.run[r] = uint16_t(lo);
+        }
+        items[k] = it;
+    }
 }
 
 static int grid_for_waves(int64_t rows) {
@@ -839,7 +859,7 @@ static void free_tc(gmsx_graph *g) {
         p = nullptr;
     };
     drop(g->tsplit); drop(g->srow); drop(g->srow2); drop(g->ksplit); drop(g->spool); drop(g->trow); drop(g->tdesc); drop(g->htask); drop(g->ttask); drop(g->hitem); drop(g->titem); drop(g->tunits);
-    drop(g->worder); drop(g->tpool); drop(g->shard_hidx); drop(g->shard_tidx);
+    drop(g->worder); drop(g->tpool); drop(g->shard_hitem); drop(g->shard_titem);
     g->shard_idx_part = g->shard_idx_nparts = -1;
     g->device_bytes -= g->tc_bytes;
     g->tc_bytes = 0;
@@ -873,8 +893,8 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->hitem);
     (void)hipFree(g->titem);
     (void)hipFree(g->tunits);
-    (void)hipFree(g->shard_hidx);
-    (void)hipFree(g->shard_tidx);
+    (void)hipFree(g->shard_hitem);
+    (void)hipFree(g->shard_titem);
     (void)hipFree(g->worder);
     (void)hipFree(g->tpool);
     (void)hipFree(g->dplus);
@@ -1472,13 +1492,13 @@ static int build_tc_sets(gmsx_graph *g) {
         if (int rc = exclusive_scan_i64(icnt, ioff, n_recv + 1, s)) return rc;
         GMSX_HIP(hipMemcpy(&g->hitems, ioff + n_recv, sizeof(int64_t), hipMemcpyDeviceToHost));
         if (int rc = dmalloc(&g->hitem, g->hitems + 1, g)) return rc;
-        if (n_recv > 0) hipLaunchKernelGGL(k_item_fill, dim3(rb), dim3(256), 0, s, n_recv, recv_v, opos, hbeg, ioff, g->hitem);
+        if (n_recv > 0) hipLaunchKernelGGL(k_item_fill, dim3(rb), dim3(256), 0, s, n_recv, recv_v, opos, hbeg, ioff, g->htask, g->hoff, 0, g->hitem);
         hipLaunchKernelGGL(k_item_counts, dim3(rb), dim3(256), 0, s, n_recv, tbeg, icnt);
         if (int rc = exclusive_scan_i64(icnt, ioff, n_recv + 1, s)) return rc;
         GMSX_HIP(hipMemcpy(&g->titems, ioff + n_recv, sizeof(int64_t), hipMemcpyDeviceToHost));
         if (int rc = dmalloc(&g->titem, g->titems + 1, g)) return rc;
-        if (n_recv > 0) hipLaunchKernelGGL(k_item_fill, dim3(rb), dim3(256), 0, s, n_recv, recv_v, opos, tbeg, ioff, g->titem);
-        if (g->hitems >= (int64_t(1) << 31) || g->titems >= (int64_t(1) << 31)) return GMSX_ERR_DEVICE_MEM;  // one workgroup per item: grid.x
+        if (n_recv > 0) hipLaunchKernelGGL(k_item_fill, dim3(rb), dim3(256), 0, s, n_recv, recv_v, opos, tbeg, ioff, g->ttask, g->toff, 1, g->titem);
+        if (g->hitems >= (int64_t(1) << 31) || g->titems >= (int64_t(1) << 31)) return GMSX_ERR_DEVICE_MEM;  // 32-bit queue tickets
         GMSX_HIP(hipStreamSynchronize(s));
     }
     pt.mark("work items");
@@ -1527,22 +1547,23 @@ int ensure_tc(const gmsx_graph *cg) {
     return rc;
 }
 
-__global__ void k_shard_flags(int64_t n_items, const gmsx_task_item *__restrict__ items, int nparts, int part, int64_t *__restrict__ flags) {
+__global__ void k_shard_flags(int64_t n_items, const gmsx_tc_item *__restrict__ items, int nparts, int part, int64_t *__restrict__ flags) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i <= n_items) flags[i] = (i < n_items && shard_of(items[i].pos, nparts) == part) ? 1 : 0;
 }
-__global__ void k_shard_scatter(int64_t n_items, const int64_t *__restrict__ flags, const int64_t *__restrict__ slot, int32_t *__restrict__ idx) {
+__global__ void k_shard_scatter(int64_t n_items, const int64_t *__restrict__ flags, const int64_t *__restrict__ slot, const gmsx_tc_item *__restrict__ items,
+                                gmsx_tc_item *__restrict__ out) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < n_items && flags[i]) idx[slot[i]] = int32_t(i);
+    if (i < n_items && flags[i]) out[slot[i]] = items[i];
 }
 int tc_shard_items(const gmsx_graph *g, int part, int nparts) {
     if (g->shard_idx_part == part && g->shard_idx_nparts == nparts) return GMSX_OK;
     hipStream_t s = ctx().stream;
-    (void)hipFree(g->shard_hidx);
-    (void)hipFree(g->shard_tidx);
-    g->shard_hidx = g->shard_tidx = nullptr;
+    (void)hipFree(g->shard_hitem);
+    (void)hipFree(g->shard_titem);
+    g->shard_hitem = g->shard_titem = nullptr;
     g->shard_idx_part = g->shard_idx_nparts = -1;
-    auto one = [&](const gmsx_task_item *items, int64_t n_items, int32_t **idx, int64_t *count) -> int {
+    auto one = [&](const gmsx_tc_item *items, int64_t n_items, gmsx_tc_item **idx, int64_t *count) -> int {
         *count = 0;
         if (n_items == 0) return GMSX_OK;
         int64_t *flags = nullptr, *slot = nullptr;
@@ -1554,12 +1575,12 @@ int tc_shard_items(const gmsx_graph *g, int part, int nparts) {
         if (int rc = exclusive_scan_i64(flags, slot, n_items + 1, s)) return rc;
         GMSX_HIP(hipMemcpy(count, slot + n_items, sizeof(int64_t), hipMemcpyDeviceToHost));
         if (int rc = dmalloc(idx, *count + 1, nullptr)) return rc;
-        hipLaunchKernelGGL(k_shard_scatter, dim3(unsigned(n_items / 256 + 1)), dim3(256), 0, s, n_items, flags, slot, *idx);
+        hipLaunchKernelGGL(k_shard_scatter, dim3(unsigned(n_items / 256 + 1)), dim3(256), 0, s, n_items, flags, slot, items, *idx);
         GMSX_HIP(hipStreamSynchronize(s));
         return GMSX_OK;
     };
-    if (int rc = one(g->hitem, g->hitems, &g->shard_hidx, &g->shard_hitems)) return rc;
-    if (int rc = one(g->titem, g->titems, &g->shard_tidx, &g->shard_titems)) return rc;
+    if (int rc = one(g->hitem, g->hitems, &g->shard_hitem, &g->shard_hitems)) return rc;
+    if (int rc = one(g->titem, g->titems, &g->shard_titem, &g->shard_titems)) return rc;
     g->shard_idx_part = part;
     g->shard_idx_nparts = nparts;
     return GMSX_OK;

@@ -29,13 +29,21 @@
 //   order int32[n]                     rank ids by decreasing d+ (work-sorted launch order, heavy first);
 //   sorted_dplus int32[n]              dplus[order[i]] (for bin boundaries)
 // WORK ITEM of the triangle kernels: up to kTaskChunk consecutive entries of ONE pivot's hub-entry list (htask) or tail-entry list
-// (ttask).  16 bytes: bc = first entry (40 bits) | entries << 40; pivot = rank id whose row is staged in LDS; pos = the pivot's position
-// in `order` (what the shard rule of a multi-GPU run is evaluated on).
-struct gmsx_task_item {
+// (ttask).  A self-contained 64-byte record — everything a persistent workgroup needs to stage the item without a dependent lookup:
+// bc = first entry (40 bits) | entries << 40; cont = where the pivot's own container part lies (first id in hadj / tadj, 40 bits) | its
+// ids << 40; pivot = rank id whose row is staged in LDS; pos = the pivot's position in `order` (what the shard rule of a multi-GPU run
+// is evaluated on); run[r] … run[r+1] = the entries of run type r inside the item (the lists are class-sorted, run_type() below; written
+// by the build, so the kernels neither search nor mark them).
+struct __attribute__((aligned(64))) gmsx_tc_item {
     uint64_t bc;
+    uint64_t cont;
     int32_t pivot;
     int32_t pos;
+    uint16_t run[13];
+    uint16_t kind;  // 0 = hub item, 1 = tail item
+    uint32_t reserved[3];
 };
+static_assert(sizeof(gmsx_tc_item) == 64, "work item record = one 64-byte line");
 struct gmsx_graph {
     int64_t n = 0, nnz = 0, m = 0;
     int64_t *off = nullptr;
@@ -83,12 +91,12 @@ struct gmsx_graph {
     unsigned long long *htask = nullptr;  // hub entries of all receivers, receiver by receiver (in `order`), class by class
     unsigned long long *ttask = nullptr;  // tail entries likewise
     int64_t htask_entries = 0, ttask_entries = 0;
-    struct gmsx_task_item *hitem = nullptr, *titem = nullptr;  // work items over htask / ttask
+    struct gmsx_tc_item *hitem = nullptr, *titem = nullptr;  // work items over htask / ttask
     int64_t hitems = 0, titems = 0;
     int64_t inline_hentries = 0, inline_tentries = 0;  // of which: chunks of inline rows
-    // gmsx_tc_partial(part, nparts) on a FULL upload: the indices of the work items of that shard, compacted on demand (cached for the last
-    // (part, nparts)), so that a shard launches its own workgroups only
-    mutable int32_t *shard_hidx = nullptr, *shard_tidx = nullptr;
+    // gmsx_tc_partial(part, nparts) on a FULL upload: the work items of that shard, compacted on demand (cached for the last
+    // (part, nparts)), so that a shard walks its own items only
+    mutable struct gmsx_tc_item *shard_hitem = nullptr, *shard_titem = nullptr;
     mutable int64_t shard_hitems = 0, shard_titems = 0;
     mutable int shard_idx_part = -1, shard_idx_nparts = -1;
     int32_t *tunits = nullptr;           // [n] oriented edges whose entries live at this vertex (forward + reverse): the bookkeeping of gmsx_stats.units
@@ -140,7 +148,13 @@ static constexpr int kHub = 65535;         // rank ids below this live in the 16
 static constexpr int kBitmapWords = 2048;  // 65536-bit LDS bitmap over the hub id range
 static constexpr int kAccWords = 64 * 16 + 16;
 static constexpr int kFormList = 0, kFormBitset = 1, kFormDelta = 2, kFormGap12 = 3;
-static constexpr int kTaskChunk = 1024;  // entries per work item
+static constexpr int kTaskChunk = 512;   // entries per work item (4 KB of descriptors: two such buffers per workgroup, the next item's arriving while this one is scanned)
+// run type of an entry inside a work item = form * 3 + {0: <= 4 units, 1: <= 8, 2: longer}: the three lane-group widths of the scan
+// loops (tc.hip).  Monotone in the class order of the lists, so an item is at most 12 consecutive runs.
+__host__ __device__ inline int run_type(unsigned long long d) {
+    const uint32_t u = uint32_t(d) & 0x3fffffu;
+    return int((uint32_t(d) >> 22) & 3u) * 3 + (u <= 4 ? 0 : u <= 8 ? 1 : 2);
+}
 // entry classes: hub = form * kLenClasses + length class, tail = kHubClasses + (delta ? kLenClasses : 0) + length class.  Length classes
 // in steps of ~sqrt(2): <= 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, more units — the groups of a wave work on rows of one class side
 // by side, and the wave is done when its longest row is.
@@ -183,7 +197,7 @@ int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out);
 int ensure_tc(const gmsx_graph *g);
 // … for one shard / pass (frees and rebuilds when another one is resident)
 int ensure_tc_shard(const gmsx_graph *g, int part, int nparts);
-// fills g->shard_hidx / shard_tidx for (part, nparts) (device_graph.hip)
+// fills g->shard_hitem / shard_titem for (part, nparts) (device_graph.hip)
 int tc_shard_items(const gmsx_graph *g, int part, int nparts);
 // counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| into a zeroed device array (pairs.hip); shared by the per-vertex count and the TC ordering
 int tc_vertex_counts_device(const gmsx_graph *g, unsigned long long *d_counts, gmsx_stats *st);

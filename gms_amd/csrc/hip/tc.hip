@@ -379,10 +379,6 @@ __device__ __forceinline__ uint32_t scan_class(const unsigned long long *sdesc, 
 // (kWideGroup lanes per row; the finer length classes of the build only ORDER the rows, so that the groups of a wave work on rows of
 // similar length — one loop per class would leave most groups of the workgroup idle on the short class runs of a small item, and every
 // extra run costs every wave of every item its bookkeeping).  Run type = form * 3 + {0: <= 4 units, 1: <= 8, 2: longer}.
-__device__ __forceinline__ int run_type(unsigned long long d) {
-    const uint32_t u = uint32_t(d) & 0x3fffffu;
-    return int((uint32_t(d) >> 22) & 3u) * 3 + (u <= 4 ? 0 : u <= 8 ? 1 : 2);
-}
 template <class Hit>
 __device__ __forceinline__ uint32_t scan_form(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, const unsigned short *rbeg, const unsigned short *rend,
                                               int form, int tid, Hit hit) {
@@ -420,15 +416,13 @@ __device__ __forceinline__ void block_add(unsigned long long cnt, unsigned long 
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const uint32_t *__restrict__ spool, const unsigned long long *__restrict__ htask,
-                                                  const gmsx_task_item *__restrict__ items, const int32_t *__restrict__ idx, int nparts, int part,
-                                                  unsigned long long *__restrict__ acc) {
+                                                  const gmsx_tc_item *__restrict__ items, unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords + 128];  // + slack: the delta probes of unused slots read up to 104 words past the bitmap
     __shared__ unsigned long long sdesc[kTaskChunk];
     __shared__ unsigned short cbeg[12], cend[12];  // run types
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const gmsx_task_item it = items[idx ? idx[blockIdx.x] : int32_t(blockIdx.x)];  // idx: the items of this shard (a sharded call on a full upload)
-    if (nparts > 1 && shard_of(it.pos, nparts) != part) return;  // uniform per block (never taken with idx or on a sharded upload)
+    const gmsx_tc_item &it = items[blockIdx.x];
     const int32_t u = it.pivot;
     const int64_t hb = hoff[u];
     const int hl = int(hoff[u + 1] - hb);
@@ -456,8 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_tail(const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                  const uint32_t *__restrict__ tpool, const unsigned long long *__restrict__ ttask,
-                                                 const gmsx_task_item *__restrict__ items, const int32_t *__restrict__ idx, int nparts, int part,
-                                                 unsigned long long *__restrict__ acc) {
+                                                 const gmsx_tc_item *__restrict__ items, unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) int32_t tbl[1 << kBlockLog];
     __shared__ uint32_t flt[kFilterWords];
     __shared__ unsigned long long sdesc[kTaskChunk];
@@ -465,8 +458,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ unsigned long long red[4];
     constexpr int TILE = (1 << kBlockLog) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const gmsx_task_item it = items[idx ? idx[blockIdx.x] : int32_t(blockIdx.x)];
-    if (nparts > 1 && shard_of(it.pos, nparts) != part) return;  // uniform per block
+    const gmsx_tc_item &it = items[blockIdx.x];
     const int32_t u = it.pivot;
     const int64_t tb = toff[u];
     const int tl = int(toff[u + 1] - tb);
@@ -503,6 +495,236 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 #endif
     }
     block_add(cnt, red, lane, wave, tid, acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PERSISTENT work-item kernel (round 4): what k_tc_block + k_tc_tail did with one workgroup per item — 5.4 M workgroups per pass at scale
+// 26, each opening with a chain of dependent round trips (item -> offsets -> descriptors / pivot ids -> LDS) before its first row load:
+// a third of a tail item's slot time — as ONE launch of as many workgroups as the chip holds.  A workgroup walks items off two queues
+// (hub items, tail items; tickets of kGrab consecutive items, fetched one chunk ahead) and keeps a three-deep pipeline over them:
+//   item i+2   its 64-byte record is loading (one dword per lane; fields come back out with v_readlane: the record is wave-uniform)
+//   item i+1   its descriptors and the pivot's ids are on their way into the OTHER half of the LDS staging buffers by LDS-DMA
+//              (global_load_lds: no registers, no instructions at arrival)
+//   item i     is scanned.
+// Records are self-contained (device_graph.hpp: entries, the pivot's container part, run boundaries), so nothing in the chain depends on
+// a second lookup.  The pivot bitmap is MAINTAINED instead of rebuilt: consecutive items of one pivot share it; otherwise the ids of the
+// previous pivot (still in the other staging half) are XORed out and the new ones XORed in — both commute, so no barrier separates them
+// and nothing clears 8 KB per item.  Tail items alias the bitmap's LDS as filter + hash set (sized per pivot) and leave it invalid.
+// Roles: (blockIdx & 7) < tail_share starts on the tail queue, the rest on the hub queue — the latency-bound short tail rows run BESIDE
+// the bandwidth-bound hub rows for the whole pass — and a workgroup whose queue runs dry moves to the other one.
+// ---------------------------------------------------------------------------------------------
+static constexpr int kGrab = 8;        // items per queue ticket
+static constexpr int kIdStage = 256;   // dwords per id staging half: 512 hub ids / 256 tail ids; longer containers read the rest from memory
+static constexpr int kQueueStride = 16;  // the two queue heads, 64 bytes apart (unsigned int)
+
+// LDS-DMA, one dword per lane: lane l's source is its own, the destination is lds + 4 l (wave-uniform base in M0).  Invisible to the
+// compiler's s_waitcnt bookkeeping: the issuing wave drains it with an explicit vmcnt(0) before the barrier that publishes the data.
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return uint32_t(uintptr_t((const __attribute__((address_space(3))) void *)p)); }
+__device__ __forceinline__ void glds_dword(const uint32_t *src, uint32_t lds_byte_addr) {  // LDS addresses as 32-bit numbers: no 64-bit generic pointers per lane
+    unsigned keep;
+    const unsigned dst = uni32(lds_byte_addr);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+__device__ __forceinline__ void stage_dwords(const uint32_t *__restrict__ src, uint32_t lds_byte_addr, int ndw, int lane, int wave) {
+    for (int base = wave * 64; base < ndw; base += 256)  // uniform per wave
+        if (base + lane < ndw) glds_dword(src + base + lane, lds_byte_addr + 4u * uint32_t(base));
+}
+// run boundaries of the item whose record sits in LDS (dwords 6 … 12 of the record: thirteen 16-bit positions; uniform)
+__device__ __forceinline__ int run_bound(const uint32_t *rec, int r) {
+    const uint32_t w = uni32(rec[6 + (r >> 1)]);
+    return int((r & 1) ? (w >> 16) : (w & 0xffffu));
+}
+template <class Hit>
+__device__ __forceinline__ uint32_t scan_form_r(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, const uint32_t *rec, int form, int tid, Hit hit) {
+    uint32_t cnt = 0;
+    const int r0 = form * 3;
+    const int b0 = run_bound(rec, r0), b1 = run_bound(rec, r0 + 1), b2 = run_bound(rec, r0 + 2), b3 = run_bound(rec, r0 + 3);
+    if (b1 > b0) cnt += scan_class<4, true>(sdesc, pool, b0, b1, tid, hit);
+    if (b2 > b1) cnt += scan_class<8, true>(sdesc, pool, b1, b2, tid, hit);
+    if (b3 > b2) cnt += scan_class<kWideGroup, false>(sdesc, pool, b2, b3, tid, hit);
+    return cnt;
+}
+// LDS of a k_tc_items workgroup (18.9 KB: eight per CU)
+struct ItemLds {
+    uint32_t bm[kBitmapWords + 128];  // hub items: the pivot bitmap (+ slack: the delta probes of unused slots read up to 104 words past it); tail items: table | filter
+    unsigned long long sdesc[2][kTaskChunk];
+    uint32_t idst[2][kIdStage];
+    uint32_t rec[3][16];  // records of the items A (scanned), B (staging), C (arriving)
+    unsigned long long red[4];
+    int chunk[2];  // first item of the chunk behind the one the cursor walks (-1: the queue is dry)
+};
+// One queue (hub items or tail items) until it is dry.
+template <bool TAIL>
+__device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint32_t *__restrict__ pool,
+                                          const unsigned long long *__restrict__ task, const gmsx_tc_item *__restrict__ items, int n_items,
+                                          unsigned int *__restrict__ qhead, unsigned long long &total) {
+    constexpr int TILE = (1 << kBlockLog) / 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *bm = L.bm;
+    const uint32_t a_sdesc = lds_addr(&L.sdesc[0][0]), a_idst = lds_addr(&L.idst[0][0]), a_rec = lds_addr(&L.rec[0][0]);
+    __syncthreads();  // the previous phase is over: its LDS is free
+    if (tid == 0) {
+        const unsigned a = atomicAdd(qhead, unsigned(kGrab));
+        const unsigned b = a < unsigned(n_items) ? atomicAdd(qhead, unsigned(kGrab)) : a;
+        L.chunk[0] = a < unsigned(n_items) ? int(a) : -1;
+        L.chunk[1] = b < unsigned(n_items) ? int(b) : -1;
+    }
+    if (!TAIL)
+        for (int i = tid; i < (kBitmapWords + 128) / 4; i += 256) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    // cursor over the item stream of this workgroup (uniform): item ci of the chunk [.., ce); -1 = none
+    int ci = uni32(L.chunk[0]);
+    int ce = ci < 0 ? 0 : min(ci + kGrab, n_items);
+    auto advance = [&]() -> bool {  // to the next item; true when it entered the next chunk (thread 0 then fetches the one after it)
+        if (ci < 0) return false;
+        if (++ci < ce) return false;
+        ci = uni32(L.chunk[1]);
+        ce = ci < 0 ? 0 : min(ci + kGrab, n_items);
+        return true;
+    };
+    auto fetch_rec = [&](int slot, int lane, int wave) {  // the cursor's record -> LDS (wave 0, lanes 0 … 15, asynchronous)
+        if (wave == 0 && lane < 16) glds_dword(reinterpret_cast<const uint32_t *>(items + ci) + lane, a_rec + 64u * uint32_t(slot));
+    };
+    auto stage = [&](const uint32_t *rec, int b, int lane, int wave) {  // descriptors and pivot ids of a record -> staging half b (asynchronous)
+        const uint32_t bc_lo = uni32(rec[0]), bc_hi = uni32(rec[1]), c_lo = uni32(rec[2]), c_hi = uni32(rec[3]);
+        const uint64_t first = (uint64_t(bc_hi & 0xffu) << 32) | bc_lo, cb = (uint64_t(c_hi & 0xffu) << 32) | c_lo;
+        const int ne = int(bc_hi >> 8), cn = int(c_hi >> 8);
+        stage_dwords(reinterpret_cast<const uint32_t *>(task + first), a_sdesc + uint32_t(b) * uint32_t(sizeof(L.sdesc[0])), 2 * ne, lane, wave);
+        if (TAIL) stage_dwords(reinterpret_cast<const uint32_t *>(tadj + cb), a_idst + uint32_t(b) * uint32_t(sizeof(L.idst[0])), min(cn, kIdStage), lane, wave);
+        else stage_dwords(reinterpret_cast<const uint32_t *>(hadj + cb), a_idst + uint32_t(b) * uint32_t(sizeof(L.idst[0])), min(cn, 2 * kIdStage) / 2, lane, wave);
+    };
+    auto flip2 = [&](uint32_t w) {  // two 16-bit hub ids: toggle their bits (0xFFFF = row padding)
+        const uint32_t lo = w & 0xffffu, hi = w >> 16;
+        if (lo != 0xFFFFu) atomicXor(&bm[lo >> 5], 1u << (lo & 31u));
+        if (hi != 0xFFFFu) atomicXor(&bm[hi >> 5], 1u << (hi & 31u));
+    };
+    // prologue: records A and B, then A's staging
+    bool vA = ci >= 0, vB = false;
+    if (vA) fetch_rec(0, lane, wave);
+    if (advance()) {  // (a first chunk of one item: the cursor is in the second chunk already)
+        __syncthreads();  // everybody has read chunk[1]
+        if (tid == 0 && ci >= 0) {
+            const unsigned x = atomicAdd(qhead, unsigned(kGrab));
+            L.chunk[1] = x < unsigned(n_items) ? int(x) : -1;
+        }
+    }
+    vB = ci >= 0;
+    if (vB) fetch_rec(1, lane, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (vA) stage(L.rec[0], 0, lane, wave);
+    int ra = 0, buf = 0;
+    bool bm_valid = true, bm_small = true;  // the bitmap holds exactly the hub ids of bm_pivot; all of them are in the other staging half
+    int bm_pivot = -1, bm_n = 0;
+    const int tid0 = tid;
+    while (vA) {
+        // per-lane address parts (pool + 16 * sub for every group width, staging offsets …) are loop-invariant, and hoisted out of THIS loop
+        // they cost 40 VGPRs for the whole kernel (spills at the 64 that eight waves per SIMD allow): an opaque copy of the thread id per item
+        // keeps them inside the item, where they cost a handful of VALU instructions
+        int tid = tid0;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = tid >> 6;
+        const int rb = ra == 2 ? 0 : ra + 1, rc = rb == 2 ? 0 : rb + 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of item A's staging (and of record B) has landed …
+        __syncthreads();                                   // (1) … everybody's has, and nobody reads the previous item's LDS any more
+        const bool crossed = advance();
+        const bool vC = ci >= 0;
+        if (vC) fetch_rec(rc, lane, wave);
+        unsigned pend = 0;
+        const bool fetch = tid == 0 && crossed && vC;
+        if (fetch) pend = atomicAdd(qhead, unsigned(kGrab));  // consumed after the scan: the round trip stays off the path
+        const uint32_t *recA = L.rec[ra];
+        const uint32_t c_lo = uni32(recA[2]), c_hi = uni32(recA[3]);
+        const int64_t cb = int64_t((uint64_t(c_hi & 0xffu) << 32) | c_lo);
+        const int cn = int(c_hi >> 8);
+        const unsigned long long *sd = L.sdesc[buf];
+        uint32_t c = 0;
+        if (!TAIL) {
+            const int pivotA = int(uni32(recA[4]));
+            if (!(bm_valid && bm_pivot == pivotA)) {
+                if (bm_valid && bm_small) {
+                    for (int i = tid; i < bm_n / 2; i += 256) flip2(L.idst[buf ^ 1][i]);  // the previous pivot's ids out …
+                } else {
+                    for (int i = tid; i < (kBitmapWords + 128) / 4; i += 256) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
+                    __syncthreads();
+                }
+                const int ns = min(cn, 2 * kIdStage);
+                for (int i = tid; i < ns / 2; i += 256) flip2(L.idst[buf][i]);  // … this one's in (XOR commutes: no barrier in between)
+                for (int i = 2 * kIdStage + 2 * tid; i < cn; i += 512) flip2(*reinterpret_cast<const uint32_t *>(hadj + cb + i));
+                bm_valid = true;
+                bm_pivot = pivotA;
+                bm_n = ns;
+                bm_small = cn <= 2 * kIdStage;
+            }
+            __syncthreads();  // (2)
+            if (vB) stage(L.rec[rb], buf ^ 1, lane, wave);
+#ifndef GMSX_TC_STAGING_ONLY
+            c += scan_form_r(sd, pool, recA, kFormList, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormList>(bm, p, j); });
+            c += scan_form_r(sd, pool, recA, kFormBitset, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormBitset>(bm, p, j); });
+            c += scan_form_r(sd, pool, recA, kFormDelta, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormDelta>(bm, p, j); });
+            c += scan_form_r(sd, pool, recA, kFormGap12, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormGap12>(bm, p, j); });
+#endif
+        } else {
+            int32_t *tbl = reinterpret_cast<int32_t *>(bm);
+            uint32_t *flt = bm + (1 << kBlockLog);
+            // table and filter sized for THIS pivot: 2^log slots >= 2 x keys of a tile, the filter 32 bits per slot
+            int log = 6;
+            while ((1 << log) < 2 * min(cn, TILE)) ++log;
+            const int size = 1 << log, shift = 32 - log;
+            const uint32_t mask = uint32_t(size - 1);
+            bool staged = false;
+            for (int t0 = 0; t0 < cn; t0 += TILE) {  // the pivot's tail part, a tile at a time (one tile for all but a handful of pivots)
+                const int tn = min(TILE, cn - t0);
+                if (t0 > 0) __syncthreads();
+                for (int i = tid; i < size; i += 256) {
+                    tbl[i] = -1;
+                    flt[i] = 0;
+                }
+                __syncthreads();
+                for (int i = tid; i < tn; i += 256) {
+                    const int32_t t = t0 + i < kIdStage ? int32_t(L.idst[buf][t0 + i]) : tadj[cb + t0 + i];
+                    set_insert(tbl, mask, shift, t);
+                    atomicOr(&flt[(uint32_t(t) >> 5) & mask], 1u << (uint32_t(t) & 31u));
+                }
+                __syncthreads();  // (2)
+                if (!staged && vB) stage(L.rec[rb], buf ^ 1, lane, wave);
+                staged = true;
+#ifndef GMSX_TC_STAGING_ONLY
+                c += scan_form_r(sd, pool, recA, kFormList, tid, [=](uint4 p, int) { return tail_unit_hits_f<kFormList>(flt, tbl, mask, shift, p); });
+                c += scan_form_r(sd, pool, recA, kFormDelta, tid, [=](uint4 p, int) { return tail_unit_hits_f<kFormDelta>(flt, tbl, mask, shift, p); });
+#endif
+            }
+            if (!staged) {  // (a pivot without tail ids: nothing can match)
+                __syncthreads();
+                if (vB) stage(L.rec[rb], buf ^ 1, lane, wave);
+            }
+        }
+        total += c;
+        if (fetch) L.chunk[1] = pend < unsigned(n_items) ? int(pend) : -1;  // the chunk behind the one the cursor just entered
+        ra = rb;
+        vA = vB;
+        vB = vC;
+        buf ^= 1;
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_items(
+    const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint32_t *__restrict__ spool, const uint32_t *__restrict__ tpool,
+    const unsigned long long *__restrict__ htask, const unsigned long long *__restrict__ ttask, const gmsx_tc_item *__restrict__ hitem, int n_hitems,
+    const gmsx_tc_item *__restrict__ titem, int n_titems, int tail_share, unsigned int *__restrict__ qhead, unsigned long long *__restrict__ acc) {
+    __shared__ __attribute__((aligned(16))) ItemLds L;
+    const int tid = threadIdx.x;
+    const bool tail_first = (int(blockIdx.x) & 7) < tail_share;
+    unsigned long long total = 0;
+#pragma nounroll
+    for (int phase = 0; phase < 2; ++phase) {  // a workgroup whose queue has run dry moves to the other one
+        if ((phase == 0) == tail_first) {
+            if (n_titems > 0) item_loop<true>(L, hadj, tadj, tpool, ttask, titem, n_titems, qhead + kQueueStride, total);
+        } else {
+            if (n_hitems > 0) item_loop<false>(L, hadj, tadj, spool, htask, hitem, n_hitems, qhead, total);
+        }
+    }
+    block_add(total, L.red, tid & 63, tid >> 6, tid, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -698,7 +920,7 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
 }
 // one list of work items (hub or tail)
 __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict__ coff, int bytes_per_id, int tail, const unsigned long long *__restrict__ task,
-                                                       const gmsx_task_item *__restrict__ items, int64_t n_items, int nparts, int part,
+                                                       const gmsx_tc_item *__restrict__ items, int64_t n_items, int nparts, int part,
                                                        unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -709,7 +931,7 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
         return n * (tail ? (f == kFormDelta ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : f == kFormGap12 ? 10ull : 4ull));
     };
     for (int64_t q = wave0; q < n_items; q += nwaves) {
-        const gmsx_task_item it = items[q];
+        const gmsx_tc_item &it = items[q];
         if (nparts > 1 && shard_of(it.pos, nparts) != part) continue;
         const int ne = int(it.bc >> 40);
         const int64_t b = int64_t(it.bc & 0xffffffffffull);
@@ -742,8 +964,8 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
 __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict__ hoff, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                       const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
                                                       const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
-                                                      const unsigned long long *__restrict__ htask, const gmsx_task_item *__restrict__ hitem, int64_t hitems,
-                                                      const unsigned long long *__restrict__ ttask, const gmsx_task_item *__restrict__ titem, int64_t titems,
+                                                      const unsigned long long *__restrict__ htask, const gmsx_tc_item *__restrict__ hitem, int64_t hitems,
+                                                      const unsigned long long *__restrict__ ttask, const gmsx_tc_item *__restrict__ titem, int64_t titems,
                                                       int32_t inline_limit, int64_t first_light, int64_t end_light,
                                                       unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -752,7 +974,7 @@ __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict_
     unsigned long long c[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t q = wave0; q < hitems + titems; q += nwaves) {
         const bool tail = q >= hitems;
-        const gmsx_task_item it = tail ? titem[q - hitems] : hitem[q];
+        const gmsx_tc_item &it = tail ? titem[q - hitems] : hitem[q];
         const unsigned long long *task = tail ? ttask : htask;
         const int ne = int(it.bc >> 40);
         const int64_t b0 = int64_t(it.bc & 0xffffffffffull);
@@ -805,8 +1027,8 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
                                                      const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                      const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
                                                      const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
-                                                     const unsigned long long *__restrict__ htask, const gmsx_task_item *__restrict__ hitem, int64_t hitems,
-                                                     const unsigned long long *__restrict__ ttask, const gmsx_task_item *__restrict__ titem, int64_t titems,
+                                                     const unsigned long long *__restrict__ htask, const gmsx_tc_item *__restrict__ hitem, int64_t hitems,
+                                                     const unsigned long long *__restrict__ ttask, const gmsx_tc_item *__restrict__ titem, int64_t titems,
                                                      int64_t end, unsigned long long *__restrict__ out) {
     __shared__ unsigned long long h[256];
     for (int i = threadIdx.x; i < 256; i += 256) h[i] = 0;
@@ -822,7 +1044,7 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
     };
     for (int64_t q = wave0; q < hitems + titems; q += nwaves) {
         const bool tail = q >= hitems;
-        const gmsx_task_item it = tail ? titem[q - hitems] : hitem[q];
+        const gmsx_tc_item &it = tail ? titem[q - hitems] : hitem[q];
         const unsigned long long *task = tail ? ttask : htask;
         const int ne = int(it.bc >> 40);
         const int64_t b0 = int64_t(it.bc & 0xffffffffffull);
@@ -913,14 +1135,16 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     const bool use_idx = nparts > 1 && g->shard_nparts == 1;
     if (use_idx)
         if (int rc = tc_shard_items(g, part, nparts)) return rc;
-    const int32_t *hidx = use_idx ? g->shard_hidx : nullptr, *tidx = use_idx ? g->shard_tidx : nullptr;
+    const gmsx_tc_item *hitem = use_idx ? g->shard_hitem : g->hitem, *titem = use_idx ? g->shard_titem : g->titem;
     const int64_t n_hitems = use_idx ? g->shard_hitems : g->hitems, n_titems = use_idx ? g->shard_titems : g->titems;
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     unsigned long long *acc = g->acc;  // persistent per-graph accumulators: no allocation on the call path
-    static_assert(kAccSlots * kAccStride + 3 <= kAccWords, "gmsx_graph::acc too small");
+    static_assert(kAccSlots * kAccStride + 16 <= kAccWords, "gmsx_graph::acc too small");
+    unsigned int *qhead = reinterpret_cast<unsigned int *>(acc + kAccSlots * kAccStride + 4);  // the two queue heads of k_tc_items (behind the 3 stats words)
+    static_assert((kQueueStride + 1) * sizeof(unsigned int) <= 12 * sizeof(unsigned long long), "queue heads past gmsx_graph::acc");
     GMSX_HIP(hipEventRecord(c.ev[0], s));
-    GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * (kAccSlots * kAccStride + 3), s));
+    GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * kAccWords, s));
     GMSX_HIP(hipEventRecord(c.ev[1], s));
 
     int launches = 0;
@@ -951,10 +1175,39 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
                 if (armed[i] && hipEventRecord(c.ev_join[i], c.side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, c.ev_join[i], 0);
         }
     } join{c, s};
-    if (tail_mode == 3 && sides && n_hitems > 0) {
+    const int persist = [] { const char *e = std::getenv("GMSX_TC_PERSIST"); return e ? std::atoi(e) : 1; }();  // A/B: 0 = one workgroup per item (rounds 2-3)
+    if (persist) {
+        // ONE persistent launch walks the hub and the tail items (k_tc_items); the light-pivot kernel goes beside it as before
+        const bool co = sides && cnt_light > 0 && n_hitems + n_titems > 0 && (overlap > 1 || g->n >= (int64_t(1) << 23));
+        if (co) {
+            GMSX_HIP(hipEventRecord(c.ev_fork, s));
+            GMSX_HIP(hipStreamWaitEvent(c.side[1], c.ev_fork, 0));
+            join.armed[1] = true;
+        }
+        auto launch_light = [&](hipStream_t sw, bool beside) {
+            if (cnt_light <= 0) return;
+            const int64_t b_wave = std::min<int64_t>((cnt_light + 3) / 4, beside ? int64_t(cus) * wave_wgs : cap_blocks);
+            hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(b_wave)), dim3(256), 0, sw, g->hoff, g->hadj, g->spool, g->tpool, g->tdesc, g->toff, g->tadj,
+                               g->tsplit, g->worder, int64_t(0), g->n_wave, nparts, part, acc);
+            ++launches;
+        };
+        if (co) launch_light(c.side[1], true);
+        if (n_hitems + n_titems > 0) {
+            static const int share_env = [] { const char *e = std::getenv("GMSX_TC_TAIL_SHARE"); return e ? std::atoi(e) : -1; }();
+            static const int wgs_env = [] { const char *e = std::getenv("GMSX_TC_ITEM_WGS"); return e ? std::atoi(e) : 8; }();
+            // workgroups that START on the tail queue, of every 8 (the queues drain into each other, so this only shapes the mix)
+            const int tail_share = share_env >= 0 ? std::min(share_env, 8) : (n_titems == 0 ? 0 : n_hitems == 0 ? 8 : 2);
+            const int64_t want = (n_hitems + n_titems + kGrab - 1) / kGrab;
+            const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(want, int64_t(cus) * std::max(1, wgs_env)));
+            hipLaunchKernelGGL(k_tc_items, dim3(unsigned(blocks)), dim3(256), 0, s, g->hadj, g->tadj, g->spool, g->tpool, g->htask, g->ttask, hitem, int(n_hitems),
+                               titem, int(n_titems), tail_share, qhead, acc);
+            ++launches;
+        }
+        if (!co) launch_light(s, false);
+    } else if (tail_mode == 3 && sides && n_hitems > 0) {
         // A/B: the hub items ALONE first (they run at 7 TB/s by themselves), then the tail items on the launch stream with the light pivots
         // beside them (neither of the two is bandwidth-bound)
-        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(n_hitems)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->htask, g->hitem, hidx, nparts, part, acc);
+        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(n_hitems)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->htask, hitem, acc);
         ++launches;
         GMSX_HIP(hipEventRecord(c.ev_fork, s));
         GMSX_HIP(hipStreamWaitEvent(c.side[1], c.ev_fork, 0));
@@ -966,7 +1219,7 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
             ++launches;
         }
         if (n_titems > 0) {
-            hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, s, g->toff, g->tadj, g->tpool, g->ttask, g->titem, tidx, nparts, part, acc);
+            hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, s, g->toff, g->tadj, g->tpool, g->ttask, titem, acc);
             ++launches;
         }
     } else {
@@ -989,15 +1242,15 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     };
     if (co_wave) launch_light();
     if (n_titems > 0 && tail_mode == 2) {
-        hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, s, g->toff, g->tadj, g->tpool, g->ttask, g->titem, tidx, nparts, part, acc);
+        hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, s, g->toff, g->tadj, g->tpool, g->ttask, titem, acc);
         ++launches;
     }
     if (n_hitems > 0) {
-        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(n_hitems)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->htask, g->hitem, hidx, nparts, part, acc);
+        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(n_hitems)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->htask, hitem, acc);
         ++launches;
     }
     if (n_titems > 0 && tail_mode != 2) {
-        hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, s_tail, g->toff, g->tadj, g->tpool, g->ttask, g->titem, tidx, nparts, part, acc);
+        hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, s_tail, g->toff, g->tadj, g->tpool, g->ttask, titem, acc);
         ++launches;
     }
     if (!co_wave) launch_light();
