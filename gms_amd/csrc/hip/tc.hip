@@ -226,8 +226,12 @@ __device__ __forceinline__ uint32_t set_contains(const int32_t *tbl, uint32_t ma
 // Almost every streamed tail id is a miss (scale 24: 0.7 M of 10.3 G triangles close through a tail id), so the set is fronted by a
 // FILTER: a bitmap of the low id bits, 32 bits per table slot (32768 bits for a full 512-key tile).  One LDS word read + bit test answers "no" for all but tl/32768 of the ids; only
 // the lanes with a positive walk the open-addressing table (whose divergent probe loops were 47 of k_tc_block's 165 ms at scale 26).
-static constexpr int kFilterWords = 1024;  // filter words = table slots (32 bits per slot); both sized per pivot, at most this
-__device__ __forceinline__ uint32_t flt_bit(const uint32_t *flt, uint32_t mask, uint32_t id) { return __builtin_amdgcn_ubfe(flt[(id >> 5) & mask], id, 1u); }
+// The filter is ALWAYS 32768 bits (round 4), whatever the table: a wave probes 64 x 6 ids per step, and the exact-probe branch runs for the
+// whole wave when ANY of them passes.  Sized with the table (32 bits per slot, 2 slots per key: one false positive per 64 probes, rounds
+// 2-3) that was nearly every step, and the walk of the table for a handful of lanes cost three times the filter pass itself (scale 26:
+// 180 wave-instructions per step against ~50; the scalar unit 60 % busy with the branches).  A few dozen keys in 32768 bits: ~0.1 %.
+static constexpr int kFilterWords = 1024;
+__device__ __forceinline__ uint32_t flt_bit(const uint32_t *flt, uint32_t, uint32_t id) { return __builtin_amdgcn_ubfe(flt[(id >> 5) & uint32_t(kFilterWords - 1)], id, 1u); }
 __device__ __forceinline__ uint32_t tail_unit_hits(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, uint4 p) {
     const uint32_t m = flt_bit(flt, mask, p.x) | (flt_bit(flt, mask, p.y) << 1) | (flt_bit(flt, mask, p.z) << 2) | (flt_bit(flt, mask, p.w) << 3);
     uint32_t c = 0;
@@ -340,53 +344,67 @@ __device__ __forceinline__ uint32_t tail_unit_hits_f(const uint32_t *flt, const 
 }
 // entries [lo, hi) of the item (descriptors in LDS), one form, rows of similar length: HIT(p, j) = hits of unit j of a row.  ONE_STEP: the
 // classes of the run guarantee units <= W (one load per lane, no loop).
-template <int W, bool ONE_STEP, class Hit>
-__device__ __forceinline__ uint32_t scan_class(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, int lo, int hi, int tid, Hit hit) {
+#ifndef GMSX_TC_TAIL_DEPTH
+#define GMSX_TC_TAIL_DEPTH 3  // 16-byte loads a lane of the TAIL scans keeps in flight
+#endif
+#ifndef GMSX_TC_HUB_DEPTH
+#define GMSX_TC_HUB_DEPTH 2   // … of the hub scans (the decode of a byte-delta unit wants 30 registers of its own)
+#endif
+// Entries [lo, hi) of an item (descriptors in LDS), one form, rows of one width class, as a STREAM OF STEPS: a group of W lanes works on
+// one row, a step = W consecutive units of it (one 16-byte load per lane), and a lane keeps D steps in flight across row boundaries.
+// Every load is UNCONDITIONAL — a lane without a unit in the step re-reads unit 0 of its row, a group past its last entry unit 0 of the
+// pool — because a load under a divergent branch cannot be counted: hipcc then waits with vmcnt(0) at every use, i.e. for the load it
+// issued a moment ago, and a wave never has more than one load instruction in flight (rounds 2-3: that, times 32 waves per CU, was the
+// 3.7 TB/s of the tail items — 0.9 KB per wave and memory latency).  With counted waits the D loads overlap.
+// HIT(p, j) = hits of unit j of a row.
+template <int W, int D, class Hit>
+__device__ __forceinline__ uint32_t scan_run(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, int lo, int hi, int tid, Hit hit) {
     constexpr int G = 256 / W;
-    const int g = tid / W, sub = tid % W;
+    const int sub = tid % W;
+    const uint4 *pool4 = reinterpret_cast<const uint4 *>(pool);
     uint32_t cnt = 0;
-    int e = lo + g;
+    // cursor of the step to ISSUE: entry e (descriptor d = first unit << 24 | form << 22 | units), unit j of this lane
+    int e = lo + tid / W;
     unsigned long long d = e < hi ? sdesc[e] : 0ull;
-    // The FIRST unit of a group's next row is loaded while its current row is probed: short rows (the tail rows average 14 units, one step
-    // of a 16-lane group) otherwise leave one load per group in flight behind a descriptor read — 3.6 TB/s for the tail items against
-    // 7 TB/s for the hub items (serial kernel trace, scale 26).
-    uint4 p0 = make_uint4(0u, 0u, 0u, 0u);
-    if (sub < int(uint32_t(d) & 0x3fffffu)) p0 = (reinterpret_cast<const uint4 *>(pool) + (d >> 24))[sub];
-    while (e < hi) {  // the groups of a wave differ by at most one trip
-        const int en = e + G;
-        const unsigned long long dn = en < hi ? sdesc[en] : 0ull;
-        uint4 pn = make_uint4(0u, 0u, 0u, 0u);
-        if (sub < int(uint32_t(dn) & 0x3fffffu)) pn = (reinterpret_cast<const uint4 *>(pool) + (dn >> 24))[sub];
+    int j = sub;
+    int pending = 0;  // steps of real entries in the ring
+    uint4 p[D];
+    int pj[D];  // unit index of the lane in that step, -1 = none
+    auto issue = [&](int k) {
         const int units = int(uint32_t(d) & 0x3fffffu);
-        if (sub < units) cnt += hit(p0, sub);
-        if (!ONE_STEP) {  // (ONE_STEP: the classes of the run guarantee units <= W)
-            const uint4 *row = reinterpret_cast<const uint4 *>(pool) + (d >> 24);
-            int j = sub + W;
-            for (; j + W < units; j += 2 * W) {
-                const uint4 p = row[j], q = row[j + W];
-                cnt += hit(p, j);
-                cnt += hit(q, j + W);
-            }
-            if (j < units) cnt += hit(row[j], j);
+        const bool live = j < units;
+        p[k] = pool4[(d >> 24) + (unsigned long long)(live ? j : 0)];
+        pj[k] = live ? j : -1;
+        pending += e < hi ? 1 : 0;
+        j += W;
+        if (j - sub >= units) {  // the row is through (uniform per group): next entry of the group
+            e += G;
+            d = e < hi ? sdesc[e] : 0ull;
+            j = sub;
         }
-        e = en;
-        d = dn;
-        p0 = pn;
+    };
+#pragma unroll
+    for (int k = 0; k < D; ++k) issue(k);
+    while (pending > 0) {  // the groups of a wave differ by the lengths of their rows
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const uint4 pc = p[k];
+            const int jc = pj[k];
+            pending -= 1;  // (slots of dead entries push it below zero: the loop ends at the first check after the last real step)
+            issue(k);
+            if (jc >= 0) cnt += hit(pc, jc);
+        }
     }
     return cnt;
 }
-// the runs of one form inside an item: rows of <= 4 units (4-lane groups), of <= 8 units (8-lane groups), all longer ones TOGETHER
-// (kWideGroup lanes per row; the finer length classes of the build only ORDER the rows, so that the groups of a wave work on rows of
-// similar length — one loop per class would leave most groups of the workgroup idle on the short class runs of a small item, and every
-// extra run costs every wave of every item its bookkeeping).  Run type = form * 3 + {0: <= 4 units, 1: <= 8, 2: longer}.
-template <class Hit>
+template <int D, class Hit>
 __device__ __forceinline__ uint32_t scan_form(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, const unsigned short *rbeg, const unsigned short *rend,
                                               int form, int tid, Hit hit) {
     uint32_t cnt = 0;
     const int r0 = form * 3;
-    if (rend[r0] > rbeg[r0]) cnt += scan_class<4, true>(sdesc, pool, rbeg[r0], rend[r0], tid, hit);
-    if (rend[r0 + 1] > rbeg[r0 + 1]) cnt += scan_class<8, true>(sdesc, pool, rbeg[r0 + 1], rend[r0 + 1], tid, hit);
-    if (rend[r0 + 2] > rbeg[r0 + 2]) cnt += scan_class<kWideGroup, false>(sdesc, pool, rbeg[r0 + 2], rend[r0 + 2], tid, hit);
+    if (rend[r0] > rbeg[r0]) cnt += scan_run<4, D>(sdesc, pool, rbeg[r0], rend[r0], tid, hit);
+    if (rend[r0 + 1] > rbeg[r0 + 1]) cnt += scan_run<8, D>(sdesc, pool, rbeg[r0 + 1], rend[r0 + 1], tid, hit);
+    if (rend[r0 + 2] > rbeg[r0 + 2]) cnt += scan_run<kWideGroup, D>(sdesc, pool, rbeg[r0 + 2], rend[r0 + 2], tid, hit);
     return cnt;
 }
 // copies the item's descriptors to LDS and records, per run type, where its run begins and ends (the list is class-sorted: one run each)
@@ -437,7 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t cnt = 0;
     auto run = [&](auto form_tag) {
         constexpr int FORM = decltype(form_tag)::value;
-        cnt += scan_form(sdesc, spool, cbeg, cend, FORM, tid, [](uint4 p, int j) { return hub_unit_hits<FORM>(bm, p, j); });
+        cnt += scan_form<GMSX_TC_HUB_DEPTH>(sdesc, spool, cbeg, cend, FORM, tid, [](uint4 p, int j) { return hub_unit_hits<FORM>(bm, p, j); });
     };
 #ifndef GMSX_TC_STAGING_ONLY  // (A/B build: what the per-item fixed cost alone takes)
     run(std::integral_constant<int, kFormList>{});
@@ -452,7 +470,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                  const uint32_t *__restrict__ tpool, const unsigned long long *__restrict__ ttask,
                                                  const gmsx_tc_item *__restrict__ items, unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) int32_t tbl[1 << kBlockLog];
-    __shared__ uint32_t flt[kFilterWords];
+    __shared__ __attribute__((aligned(16))) uint32_t flt[kFilterWords];
     __shared__ unsigned long long sdesc[kTaskChunk];
     __shared__ unsigned short cbeg[12], cend[12];  // run types (tail forms: list = 0, delta = 2)
     __shared__ unsigned long long red[4];
@@ -464,8 +482,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int tl = int(toff[u + 1] - tb);
     const int ne = int(it.bc >> 40);
     stage_item<12>(ttask + (it.bc & 0xffffffffffull), ne, tid, sdesc, cbeg, cend, [](unsigned long long d) { return run_type(d); });
-    // table and filter sized for THIS pivot (most tail parts are a few dozen ids: clearing 8 KB per item cost more than scanning its rows):
-    // 2^log slots >= 2 x keys, the filter 32 bits per slot (a false positive per ~64 probes)
+    // the table sized for THIS pivot (most tail parts are a few dozen ids): 2^log slots >= 2 x keys
     int log = 6;
     while ((1 << log) < 2 * min(tl, TILE)) ++log;
     const int size = 1 << log, shift = 32 - log;
@@ -474,20 +491,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     for (int t0 = 0; t0 < tl; t0 += TILE) {  // the pivot's tail part, a tile at a time
         const int tn = min(TILE, tl - t0);
         __syncthreads();
-        for (int i = tid; i < size; i += 256) {
-            tbl[i] = -1;
-            flt[i] = 0;
-        }
+        for (int i = tid; i < size; i += 256) tbl[i] = -1;
+        reinterpret_cast<uint4 *>(flt)[tid] = make_uint4(0u, 0u, 0u, 0u);  // kFilterWords = 4 x 256
         __syncthreads();
         for (int i = tid; i < tn; i += 256) {
             const int32_t t = tadj[tb + t0 + i];
             set_insert(tbl, mask, shift, t);
-            atomicOr(&flt[(uint32_t(t) >> 5) & mask], 1u << (uint32_t(t) & 31u));
+            atomicOr(&flt[(uint32_t(t) >> 5) & uint32_t(kFilterWords - 1)], 1u << (uint32_t(t) & 31u));
         }
         __syncthreads();
         auto run = [&](auto form_tag) {
             constexpr int FORM = decltype(form_tag)::value;
-            cnt += scan_form(sdesc, tpool, cbeg, cend, FORM, tid, [mask, shift](uint4 p, int) { return tail_unit_hits_f<FORM>(flt, tbl, mask, shift, p); });
+            cnt += scan_form<GMSX_TC_TAIL_DEPTH>(sdesc, tpool, cbeg, cend, FORM, tid, [mask, shift](uint4 p, int) { return tail_unit_hits_f<FORM>(flt, tbl, mask, shift, p); });
         };
 #ifndef GMSX_TC_STAGING_ONLY
         run(std::integral_constant<int, kFormList>{});
@@ -534,14 +549,14 @@ __device__ __forceinline__ int run_bound(const uint32_t *rec, int r) {
     const uint32_t w = uni32(rec[6 + (r >> 1)]);
     return int((r & 1) ? (w >> 16) : (w & 0xffffu));
 }
-template <class Hit>
+template <int D, class Hit>
 __device__ __forceinline__ uint32_t scan_form_r(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, const uint32_t *rec, int form, int tid, Hit hit) {
     uint32_t cnt = 0;
     const int r0 = form * 3;
     const int b0 = run_bound(rec, r0), b1 = run_bound(rec, r0 + 1), b2 = run_bound(rec, r0 + 2), b3 = run_bound(rec, r0 + 3);
-    if (b1 > b0) cnt += scan_class<4, true>(sdesc, pool, b0, b1, tid, hit);
-    if (b2 > b1) cnt += scan_class<8, true>(sdesc, pool, b1, b2, tid, hit);
-    if (b3 > b2) cnt += scan_class<kWideGroup, false>(sdesc, pool, b2, b3, tid, hit);
+    if (b1 > b0) cnt += scan_run<4, D>(sdesc, pool, b0, b1, tid, hit);
+    if (b2 > b1) cnt += scan_run<8, D>(sdesc, pool, b1, b2, tid, hit);
+    if (b3 > b2) cnt += scan_run<kWideGroup, D>(sdesc, pool, b2, b3, tid, hit);
     return cnt;
 }
 // LDS of a k_tc_items workgroup (18.9 KB: eight per CU)
@@ -659,15 +674,15 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
             __syncthreads();  // (2)
             if (vB) stage(L.rec[rb], buf ^ 1, lane, wave);
 #ifndef GMSX_TC_STAGING_ONLY
-            c += scan_form_r(sd, pool, recA, kFormList, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormList>(bm, p, j); });
-            c += scan_form_r(sd, pool, recA, kFormBitset, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormBitset>(bm, p, j); });
-            c += scan_form_r(sd, pool, recA, kFormDelta, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormDelta>(bm, p, j); });
-            c += scan_form_r(sd, pool, recA, kFormGap12, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormGap12>(bm, p, j); });
+            c += scan_form_r<GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormList, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormList>(bm, p, j); });
+            c += scan_form_r<GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormBitset, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormBitset>(bm, p, j); });
+            c += scan_form_r<GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormDelta, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormDelta>(bm, p, j); });
+            c += scan_form_r<GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormGap12, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormGap12>(bm, p, j); });
 #endif
         } else {
             int32_t *tbl = reinterpret_cast<int32_t *>(bm);
             uint32_t *flt = bm + (1 << kBlockLog);
-            // table and filter sized for THIS pivot: 2^log slots >= 2 x keys of a tile, the filter 32 bits per slot
+            // the table sized for THIS pivot: 2^log slots >= 2 x keys of a tile
             int log = 6;
             while ((1 << log) < 2 * min(cn, TILE)) ++log;
             const int size = 1 << log, shift = 32 - log;
@@ -676,22 +691,20 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
             for (int t0 = 0; t0 < cn; t0 += TILE) {  // the pivot's tail part, a tile at a time (one tile for all but a handful of pivots)
                 const int tn = min(TILE, cn - t0);
                 if (t0 > 0) __syncthreads();
-                for (int i = tid; i < size; i += 256) {
-                    tbl[i] = -1;
-                    flt[i] = 0;
-                }
+                for (int i = tid; i < size; i += 256) tbl[i] = -1;
+                reinterpret_cast<uint4 *>(flt)[tid] = make_uint4(0u, 0u, 0u, 0u);  // kFilterWords = 4 x 256
                 __syncthreads();
                 for (int i = tid; i < tn; i += 256) {
                     const int32_t t = t0 + i < kIdStage ? int32_t(L.idst[buf][t0 + i]) : tadj[cb + t0 + i];
                     set_insert(tbl, mask, shift, t);
-                    atomicOr(&flt[(uint32_t(t) >> 5) & mask], 1u << (uint32_t(t) & 31u));
+                    atomicOr(&flt[(uint32_t(t) >> 5) & uint32_t(kFilterWords - 1)], 1u << (uint32_t(t) & 31u));
                 }
                 __syncthreads();  // (2)
                 if (!staged && vB) stage(L.rec[rb], buf ^ 1, lane, wave);
                 staged = true;
 #ifndef GMSX_TC_STAGING_ONLY
-                c += scan_form_r(sd, pool, recA, kFormList, tid, [=](uint4 p, int) { return tail_unit_hits_f<kFormList>(flt, tbl, mask, shift, p); });
-                c += scan_form_r(sd, pool, recA, kFormDelta, tid, [=](uint4 p, int) { return tail_unit_hits_f<kFormDelta>(flt, tbl, mask, shift, p); });
+                c += scan_form_r<GMSX_TC_TAIL_DEPTH>(sd, pool, recA, kFormList, tid, [=](uint4 p, int) { return tail_unit_hits_f<kFormList>(flt, tbl, mask, shift, p); });
+                c += scan_form_r<GMSX_TC_TAIL_DEPTH>(sd, pool, recA, kFormDelta, tid, [=](uint4 p, int) { return tail_unit_hits_f<kFormDelta>(flt, tbl, mask, shift, p); });
 #endif
             }
             if (!staged) {  // (a pivot without tail ids: nothing can match)
