@@ -324,10 +324,6 @@ __device__ __forceinline__ uint32_t scan_trows_probe(Probe probe, const uint32_t
 // mixed rows in a wave: what was ~30 VALU instructions per four rows is one LDS read and an address computation per row.
 // ---------------------------------------------------------------------------------------------
 static constexpr int kBlockLog = 10;
-#ifndef GMSX_TC_WIDE_GROUP
-#define GMSX_TC_WIDE_GROUP 16  // lanes per row for rows of more than 8 units (A/B: -DGMSX_TC_WIDE_GROUP=8)
-#endif
-static constexpr int kWideGroup = GMSX_TC_WIDE_GROUP;
 template <int FORM>
 __device__ __forceinline__ uint32_t hub_unit_hits(const uint32_t *bm, uint4 p, int j) {
     if (FORM == kFormBitset) {
@@ -397,15 +393,29 @@ __device__ __forceinline__ uint32_t scan_run(const unsigned long long *sdesc, co
     }
     return cnt;
 }
-template <int D, class Hit>
+// One run per FORM (round 4): with the step streams a group moves from row to row on its own, so rows of unequal length side by side
+// cost nothing, and a single width serves them all — kRowGroup = 8 lanes = one 128-byte line per row and step (rows average 40 units in
+// the hub lists, 14 in the tail lists; 16 lanes left the short ones half empty).  Rounds 2-3 ran three loops per form (4 / 8 / 16 lanes):
+// every loop has a prologue and a drain, and a typical item of ~110 rows paid for eight of them.
+#ifndef GMSX_TC_HUB_GROUP
+#define GMSX_TC_HUB_GROUP 16
+#endif
+#ifndef GMSX_TC_TAIL_GROUP
+#define GMSX_TC_TAIL_GROUP 16
+#endif
+template <int W, int D, class Hit>
 __device__ __forceinline__ uint32_t scan_form(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, const unsigned short *rbeg, const unsigned short *rend,
                                               int form, int tid, Hit hit) {
-    uint32_t cnt = 0;
+    // the runs of a form are adjacent in the class-sorted list: [first non-empty begin, last non-empty end)
     const int r0 = form * 3;
-    if (rend[r0] > rbeg[r0]) cnt += scan_run<4, D>(sdesc, pool, rbeg[r0], rend[r0], tid, hit);
-    if (rend[r0 + 1] > rbeg[r0 + 1]) cnt += scan_run<8, D>(sdesc, pool, rbeg[r0 + 1], rend[r0 + 1], tid, hit);
-    if (rend[r0 + 2] > rbeg[r0 + 2]) cnt += scan_run<kWideGroup, D>(sdesc, pool, rbeg[r0 + 2], rend[r0 + 2], tid, hit);
-    return cnt;
+    int lo = 0x7fffffff, hi = 0;
+#pragma unroll
+    for (int r = r0; r < r0 + 3; ++r)
+        if (rend[r] > rbeg[r]) {
+            lo = min(lo, int(rbeg[r]));
+            hi = max(hi, int(rend[r]));
+        }
+    return hi > lo ? scan_run<W, D>(sdesc, pool, lo, hi, tid, hit) : 0u;
 }
 // copies the item's descriptors to LDS and records, per run type, where its run begins and ends (the list is class-sorted: one run each)
 template <int NC, class ClassOf>
@@ -455,7 +465,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     uint32_t cnt = 0;
     auto run = [&](auto form_tag) {
         constexpr int FORM = decltype(form_tag)::value;
-        cnt += scan_form<GMSX_TC_HUB_DEPTH>(sdesc, spool, cbeg, cend, FORM, tid, [](uint4 p, int j) { return hub_unit_hits<FORM>(bm, p, j); });
+        cnt += scan_form<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH>(sdesc, spool, cbeg, cend, FORM, tid, [](uint4 p, int j) { return hub_unit_hits<FORM>(bm, p, j); });
     };
 #ifndef GMSX_TC_STAGING_ONLY  // (A/B build: what the per-item fixed cost alone takes)
     run(std::integral_constant<int, kFormList>{});
@@ -502,7 +512,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         __syncthreads();
         auto run = [&](auto form_tag) {
             constexpr int FORM = decltype(form_tag)::value;
-            cnt += scan_form<GMSX_TC_TAIL_DEPTH>(sdesc, tpool, cbeg, cend, FORM, tid, [mask, shift](uint4 p, int) { return tail_unit_hits_f<FORM>(flt, tbl, mask, shift, p); });
+            cnt += scan_form<GMSX_TC_TAIL_GROUP, GMSX_TC_TAIL_DEPTH>(sdesc, tpool, cbeg, cend, FORM, tid, [mask, shift](uint4 p, int) { return tail_unit_hits_f<FORM>(flt, tbl, mask, shift, p); });
         };
 #ifndef GMSX_TC_STAGING_ONLY
         run(std::integral_constant<int, kFormList>{});
@@ -549,14 +559,12 @@ __device__ __forceinline__ int run_bound(const uint32_t *rec, int r) {
     const uint32_t w = uni32(rec[6 + (r >> 1)]);
     return int((r & 1) ? (w >> 16) : (w & 0xffffu));
 }
-template <int D, class Hit>
+template <int W, int D, class Hit>
 __device__ __forceinline__ uint32_t scan_form_r(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, const uint32_t *rec, int form, int tid, Hit hit) {
     uint32_t cnt = 0;
     const int r0 = form * 3;
-    const int b0 = run_bound(rec, r0), b1 = run_bound(rec, r0 + 1), b2 = run_bound(rec, r0 + 2), b3 = run_bound(rec, r0 + 3);
-    if (b1 > b0) cnt += scan_run<4, D>(sdesc, pool, b0, b1, tid, hit);
-    if (b2 > b1) cnt += scan_run<8, D>(sdesc, pool, b1, b2, tid, hit);
-    if (b3 > b2) cnt += scan_run<kWideGroup, D>(sdesc, pool, b2, b3, tid, hit);
+    const int b0 = run_bound(rec, r0), b3 = run_bound(rec, r0 + 3);
+    if (b3 > b0) cnt += scan_run<W, D>(sdesc, pool, b0, b3, tid, hit);
     return cnt;
 }
 // LDS of a k_tc_items workgroup (18.9 KB: eight per CU)
@@ -674,10 +682,10 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
             __syncthreads();  // (2)
             if (vB) stage(L.rec[rb], buf ^ 1, lane, wave);
 #ifndef GMSX_TC_STAGING_ONLY
-            c += scan_form_r<GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormList, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormList>(bm, p, j); });
-            c += scan_form_r<GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormBitset, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormBitset>(bm, p, j); });
-            c += scan_form_r<GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormDelta, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormDelta>(bm, p, j); });
-            c += scan_form_r<GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormGap12, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormGap12>(bm, p, j); });
+            c += scan_form_r<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormList, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormList>(bm, p, j); });
+            c += scan_form_r<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormBitset, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormBitset>(bm, p, j); });
+            c += scan_form_r<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormDelta, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormDelta>(bm, p, j); });
+            c += scan_form_r<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormGap12, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormGap12>(bm, p, j); });
 #endif
         } else {
             int32_t *tbl = reinterpret_cast<int32_t *>(bm);
@@ -703,8 +711,8 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
                 if (!staged && vB) stage(L.rec[rb], buf ^ 1, lane, wave);
                 staged = true;
 #ifndef GMSX_TC_STAGING_ONLY
-                c += scan_form_r<GMSX_TC_TAIL_DEPTH>(sd, pool, recA, kFormList, tid, [=](uint4 p, int) { return tail_unit_hits_f<kFormList>(flt, tbl, mask, shift, p); });
-                c += scan_form_r<GMSX_TC_TAIL_DEPTH>(sd, pool, recA, kFormDelta, tid, [=](uint4 p, int) { return tail_unit_hits_f<kFormDelta>(flt, tbl, mask, shift, p); });
+                c += scan_form_r<GMSX_TC_TAIL_GROUP, GMSX_TC_TAIL_DEPTH>(sd, pool, recA, kFormList, tid, [=](uint4 p, int) { return tail_unit_hits_f<kFormList>(flt, tbl, mask, shift, p); });
+                c += scan_form_r<GMSX_TC_TAIL_GROUP, GMSX_TC_TAIL_DEPTH>(sd, pool, recA, kFormDelta, tid, [=](uint4 p, int) { return tail_unit_hits_f<kFormDelta>(flt, tbl, mask, shift, p); });
 #endif
             }
             if (!staged) {  // (a pivot without tail ids: nothing can match)
@@ -1149,7 +1157,11 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     if (use_idx)
         if (int rc = tc_shard_items(g, part, nparts)) return rc;
     const gmsx_tc_item *hitem = use_idx ? g->shard_hitem : g->hitem, *titem = use_idx ? g->shard_titem : g->titem;
-    const int64_t n_hitems = use_idx ? g->shard_hitems : g->hitems, n_titems = use_idx ? g->shard_titems : g->titems;
+    int64_t n_hitems = use_idx ? g->shard_hitems : g->hitems, n_titems = use_idx ? g->shard_titems : g->titems;
+    if (const char *only = std::getenv("GMSX_TC_ONLY")) {  // profiling (WRONG counts): the hub items / the tail items / the light pivots alone
+        if (std::strcmp(only, "hub") != 0) n_hitems = 0;
+        if (std::strcmp(only, "tail") != 0) n_titems = 0;
+    }
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     unsigned long long *acc = g->acc;  // persistent per-graph accumulators: no allocation on the call path
@@ -1163,7 +1175,10 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     int launches = 0;
     const int cus = c.compute_units > 0 ? c.compute_units : 256;
     const int64_t cap_blocks = int64_t(cus) * 16;
-    const int64_t cnt_light = part_count(0, g->n_wave, nparts, part);
+    const int64_t cnt_light = [&] {
+        const char *only = std::getenv("GMSX_TC_ONLY");
+        return only && std::strcmp(only, "light") != 0 ? int64_t(0) : part_count(0, g->n_wave, nparts, part);
+    }();
     // CO-SCHEDULING.  The hub-item kernel is bound by HBM bandwidth and VALU issue, the tail-item kernel streams short rows, the light-pivot
     // kernel (short rows behind dependent loads) is bound by memory latency: back to back each leaves what the others need idle and pays
     // its own drain.  So the light kernel goes to a side stream FIRST, as a persistent grid of a few workgroups per CU, the tail items to
