@@ -47,7 +47,12 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md, "Chip-level parameters")
 METRIC = "edges-intersected/sec + achieved HBM GB/s, RMAT-26 triangle count @1/2/4/8 GPU"  # BASELINE.json "metric", verbatim
-KERNEL_SOURCES = ["gms_amd/csrc/hip/tc.hip", "gms_amd/csrc/hip/device_graph.hip", "gms_amd/csrc/hip/device_graph.hpp"]
+# per workload: the sources its kernels and containers are built from (every PMC figure carries the hash of what it was measured on)
+KERNEL_SOURCES = {
+    "tc": ["gms_amd/csrc/hip/tc.hip", "gms_amd/csrc/hip/device_graph.hip", "gms_amd/csrc/hip/device_graph.hpp"],
+    "kc4": ["gms_amd/csrc/hip/kclique.hip", "gms_amd/csrc/hip/device_graph.hip", "gms_amd/csrc/hip/device_graph.hpp"],
+    "bk": ["gms_amd/csrc/hip/bk.hip", "gms_amd/csrc/hip/device_graph.hip", "gms_amd/csrc/hip/device_graph.hpp"],
+}
 SHARD_COUNTS = (1, 2, 4, 8)
 
 
@@ -56,10 +61,10 @@ def log(rank, *a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def kernel_hash():
-    """Identity of the triangle-count kernels + containers: PMC numbers are only valid for the build they were measured on."""
+def kernel_hash(workload="tc"):
+    """Identity of a workload's kernels + containers: PMC numbers are only valid for the build they were measured on."""
     h = hashlib.sha256()
-    for rel in KERNEL_SOURCES:
+    for rel in KERNEL_SOURCES[workload]:
         with open(os.path.join(ROOT, rel), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -265,6 +270,7 @@ def side_workload(capi, args, name, traffic, rank):
         out["roofline"] = {"bound": "hbm", "traffic": trec["bytes"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                            "traffic_source": "rocprofv3 --pmc child passes of this run (2*FETCH_SIZE + WRITE_SIZE, separate passes, one call)",
                            "memory_level": "beyond-L2 (Infinity Cache + HBM)", "kernel_ms_under_pmc": trec.get("kernel_ms_under_pmc"),
+                           "kernel_hash": kernel_hash(name),
                            "per_kernel": {k: {"dispatches": v.get("dispatches"), "bytes": v.get("bytes")} for k, v in trec["kernels"].items()},
                            "note": "latency/issue-bound kernels (build of bit matrices + bitmap recursion): frac says how far from the HBM roof, "
                                    "not how much work is left"}
@@ -417,6 +423,8 @@ def measure_traffic(args, rank, workload="tc"):
         for key, rec in res.items():
             t = table.setdefault(key, {"kernels": {}, "stream_bytes": rec["stream_bytes"]})
             t.update(rec["counters"])
+            if counters[0] == "FETCH_SIZE":  # the call the fetch bytes were counted on: its own kernel time travels with them
+                t["kernel_ms_under_pmc"] = rec.get("kernel_ms_under_pmc")
             if "result" in rec:
                 t["result"] = rec["result"]
             for k, c in rec["kernels"].items():
@@ -662,10 +670,9 @@ def main():
         "achieved_is": achieved_src, "traffic_source": traffic_source,
         "memory_level": "beyond-L2 (Infinity Cache + HBM): FETCH_SIZE counts L2 misses, MALL hits included; no DRAM-side counter separates them",
         "kernel_ms": avg_kernel_ms, "kernel_hash": khash,
-        "kernel": "k_tc_block (work items: a pivot row in LDS, the stream rows its task-list entries name) + k_tc_wave (light pivots' far light "
-                  "members) = one logical kernel; on large graphs k_tc_wave runs BESIDE k_tc_block on a side stream, so kernel_ms is the HIP-event "
-                  "wall time of the pass on the launch stream, not a sum of per-kernel durations; traffic is summed over both (PMC passes "
-                  "serialise them)",
+        "kernel": "k_tc_items (ONE persistent launch over the work items: a pivot's row part in LDS, the stream rows its task-list entries name "
+                  "streamed through it; >98 % of the bytes and of the time) + k_tc_light (edges between two light vertices, all-pairs in registers) "
+                  "behind it on the launch stream; kernel_ms is the HIP-event wall time of the pass; traffic is summed over both",
         "algorithmic_bytes": stream_bytes, "algorithmic_GBps": stream_bytes / t_kernel / 1e9,
         "work_efficiency_traffic_over_algorithmic": (traffic / stream_bytes) if (traffic and stream_bytes) else None,
         "l2_hit_rate": trec.get("l2_hit_rate") if trec else None,

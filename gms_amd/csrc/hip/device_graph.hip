@@ -419,17 +419,6 @@ __global__ void k_trow_fill(int64_t n, const int64_t *__restrict__ toff, const i
         for (int64_t w = 0; w < units * 4; ++w) dst[w] = w < len ? uint32_t(tadj[b + w]) : 0xfffffffeu;
 }
 
-__global__ void k_tdesc_fill(int64_t entries, const int32_t *__restrict__ tadj, const unsigned long long *__restrict__ srow,
-                             const unsigned long long *__restrict__ trow, unsigned long long *__restrict__ tdesc) {
-    const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (e >= entries) return;
-    const int32_t v = tadj[e];
-    tdesc[2 * e] = srow[v];
-    tdesc[2 * e + 1] = trow[v];
-}
-
-// ---- bitset containers of dense hub rows -------------------------------------------------------------------
-// words of the bitset of rank id v (covers ids [0, v)), rounded to 16 bytes; 0 if the list form is smaller
 __global__ void k_dense_sizes(int32_t limit, const int32_t *__restrict__ dplus, int64_t *__restrict__ sizes) {
     const int32_t v = int32_t(blockIdx.x * blockDim.x + threadIdx.x);
     // every hub vertex with out-neighbours gets a bitset (<= 268 MB in total); the kernels pick bitset or list per use
@@ -497,7 +486,7 @@ __device__ __forceinline__ bool takes_inline(int32_t v, int32_t inline_limit, co
 }
 // Wave per pivot u (positions [first, end) of `order`: every pivot with d+ >= 2), one lane per member (hub part — padded at its end — in
 // the low lanes, tail part behind it, both ascending; a light pivot has hl + tl <= 64, a heavy one takes part with its first 64).  COUNT: ids handed over per receiving member; FILL: copies them (cnt_* are
-// the cursors then) and blanks the tdesc descriptors of the far members that were handed over, so that k_tc_wave skips them.
+// the cursors then).  (A far member that is HEAVY takes the edge over inline like a near one; k_tc_light's edge list leaves it out.)
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_inline_rows(int64_t first, int64_t end, const int32_t *__restrict__ order, const int64_t *__restrict__ hoff,
                                                      const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
@@ -505,7 +494,7 @@ __global__ __launch_bounds__(256) void k_inline_rows(int64_t first, int64_t end,
                                                      unsigned long long *__restrict__ cnt_h,
                                                      unsigned long long *__restrict__ cnt_t, const int64_t *__restrict__ ihoff,
                                                      const int64_t *__restrict__ itoff, int64_t base_h, uint16_t *__restrict__ pool_h, int64_t base_t,
-                                                     int32_t *__restrict__ pool_t, unsigned long long *__restrict__ tdesc) {
+                                                     int32_t *__restrict__ pool_t) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -545,10 +534,6 @@ __global__ __launch_bounds__(256) void k_inline_rows(int64_t first, int64_t end,
             for (int k = 0; k < tl; ++k) {
                 const int32_t x = __shfl(mv, hl + k);
                 if (k < nt) pool_t[at_t + k] = x;
-            }
-            if (give && is_tail && mv >= inline_limit) {  // a far member, handed over because it is heavy
-                tdesc[2 * (tb + lane - hl)] = 0ull;
-                tdesc[2 * (tb + lane - hl) + 1] = 0ull;
             }
         }
     }
@@ -629,31 +614,43 @@ __global__ void k_list_sizes(int64_t n_recv, uint32_t *__restrict__ cnt, int64_t
     tcnt[p] = run;
 }
 
-// light pivots that keep work for k_tc_wave: at least one far light member (rank id >= inline_limit, d+ < kHeavy) behind the first member
-__global__ __launch_bounds__(256) void k_wave_flags(int64_t first, int64_t end, const int32_t *__restrict__ order, const int64_t *__restrict__ toff,
-                                                    const int32_t *__restrict__ tadj, const int32_t *__restrict__ tsplit, const int32_t *__restrict__ dplus,
-                                                    int64_t *__restrict__ flags) {
-    const int lane = threadIdx.x & 63;
-    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
-    for (int64_t pos = first + wave0; pos <= end; pos += nwaves) {
-        if (pos == end) {
-            if (lane == 0) flags[pos - first] = 0;
-            break;
-        }
+// ---- light edges (device_graph.hpp): thread per light pivot (positions [first, end) of `order`) ----------------------------------------
+__global__ void k_ledge_count(int64_t first, int64_t end, const int32_t *__restrict__ order, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                              const int32_t *__restrict__ tsplit, const int32_t *__restrict__ dplus, int64_t *__restrict__ cnt) {
+    const int64_t pos = first + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (pos > end) return;
+    int64_t c = 0;
+    if (pos < end) {
         const int32_t u = order[pos];
         const int64_t tb = toff[u];
-        const int tl = int(toff[u + 1] - tb), ts = tsplit[u];
-        bool mine = false;
-        for (int i = ts + lane; i < tl; i += 64) mine |= dplus[tadj[tb + i]] < kHeavy;
-        const bool any = __ballot(mine) != 0;
-        if (lane == 0) flags[pos - first] = any ? 1 : 0;
+        const int tl = int(toff[u + 1] - tb);
+        for (int i = tsplit[u]; i < tl; ++i) c += dplus[tadj[tb + i]] < kHeavy ? 1 : 0;
     }
+    cnt[pos - first] = c;
 }
-__global__ void k_wave_scatter(int64_t count, int64_t first, const int32_t *__restrict__ order, const int64_t *__restrict__ flags,
-                               const int64_t *__restrict__ slot, int32_t *__restrict__ worder) {
-    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < count && flags[i]) worder[slot[i]] = order[first + i];
+__global__ void k_ledge_fill(int64_t first, int64_t end, const int32_t *__restrict__ order, const int64_t *__restrict__ hoff, const int64_t *__restrict__ toff,
+                             const int32_t *__restrict__ tadj, const int32_t *__restrict__ tsplit, const int32_t *__restrict__ dplus,
+                             const int64_t *__restrict__ ebeg, int nparts, int part, uint4 *__restrict__ ledge) {
+    const int64_t pos = first + int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (pos >= end) return;
+    const int32_t u = order[pos];
+    const int64_t hb = hoff[u], tb = toff[u];
+    const int tl = int(toff[u + 1] - tb);
+    const unsigned long long hu = (unsigned long long)hb | ((unsigned long long)(hoff[u + 1] - hb) << 40);
+    int64_t e = ebeg[pos - first];
+    for (int i = tsplit[u]; i < tl; ++i) {
+        const int32_t v = tadj[tb + i];
+        if (dplus[v] >= kHeavy) continue;
+        if (nparts <= 1 || e % nparts == part) {
+            const unsigned long long tu = (unsigned long long)tb | ((unsigned long long)i << 40);  // the tail ids of u in front of v
+            const unsigned long long hv = (unsigned long long)hoff[v] | ((unsigned long long)(hoff[v + 1] - hoff[v]) << 40);
+            const unsigned long long tv = (unsigned long long)toff[v] | ((unsigned long long)(toff[v + 1] - toff[v]) << 40);
+            const int64_t slot = nparts <= 1 ? e : e / nparts;
+            ledge[2 * slot] = make_uint4(uint32_t(hu), uint32_t(hu >> 32), uint32_t(tu), uint32_t(tu >> 32));
+            ledge[2 * slot + 1] = make_uint4(uint32_t(hv), uint32_t(hv >> 32), uint32_t(tv), uint32_t(tv >> 32));
+        }
+        ++e;
+    }
 }
 
 // ---- task lists of the heavy pivots (device_graph.hpp) -------------------------------------------------------------------------
@@ -858,14 +855,15 @@ static void free_tc(gmsx_graph *g) {
         (void)hipFree(p);
         p = nullptr;
     };
-    drop(g->tsplit); drop(g->srow); drop(g->srow2); drop(g->ksplit); drop(g->spool); drop(g->trow); drop(g->tdesc); drop(g->htask); drop(g->ttask); drop(g->hitem); drop(g->titem); drop(g->tunits);
-    drop(g->worder); drop(g->tpool); drop(g->shard_hitem); drop(g->shard_titem);
+    drop(g->tsplit); drop(g->srow); drop(g->srow2); drop(g->ksplit); drop(g->spool); drop(g->trow); drop(g->htask); drop(g->ttask); drop(g->hitem); drop(g->titem); drop(g->tunits);
+    drop(g->ledge); drop(g->tpool); drop(g->shard_hitem); drop(g->shard_titem);
     g->shard_idx_part = g->shard_idx_nparts = -1;
     g->device_bytes -= g->tc_bytes;
     g->tc_bytes = 0;
     g->tc_ready = false;
     g->htask_entries = g->ttask_entries = g->hitems = g->titems = g->inline_hentries = g->inline_tentries = 0;
-    g->task_reverse = g->n_wave = g->inline_units = g->spool_units = g->tpool_units = 0;
+    g->n_ledge = g->ledge_total = 0;
+    g->task_reverse = g->inline_units = g->spool_units = g->tpool_units = 0;
     g->stats_part = g->stats_nparts = -1;
 }
 
@@ -887,7 +885,6 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->ksplit);
     (void)hipFree(g->spool);
     (void)hipFree(g->trow);
-    (void)hipFree(g->tdesc);
     (void)hipFree(g->htask);
     (void)hipFree(g->ttask);
     (void)hipFree(g->hitem);
@@ -895,7 +892,7 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->tunits);
     (void)hipFree(g->shard_hitem);
     (void)hipFree(g->shard_titem);
-    (void)hipFree(g->worder);
+    (void)hipFree(g->ledge);
     (void)hipFree(g->tpool);
     (void)hipFree(g->dplus);
     (void)hipFree(g->order);
@@ -1247,7 +1244,7 @@ static int build_tc_sets(gmsx_graph *g) {
         if (n_work > 0)
             hipLaunchKernelGGL(k_inline_rows<false>, dim3(grid_for_waves(n_work)), dim3(256), 0, s, int64_t(0), n_work, g->order, g->hoff, g->hadj,
                                g->toff, g->tadj, g->dplus, g->inline_limit, opos, g->shard_nparts, g->shard_part, inl_h, inl_t, ihoff, itoff, int64_t(0), static_cast<uint16_t *>(nullptr),
-                               int64_t(0), static_cast<int32_t *>(nullptr), static_cast<unsigned long long *>(nullptr));
+                               int64_t(0), static_cast<int32_t *>(nullptr));
         int64_t *uh = nullptr, *ut = nullptr;
         if (int rc = dmalloc(&uh, n + 1, nullptr)) return rc;
         DevGuard g_uh{uh};
@@ -1319,8 +1316,8 @@ static int build_tc_sets(gmsx_graph *g) {
         if (g->spool_units >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;  // 40 offset bits in a srow entry (16 TB)
         if (int rc = dmalloc(&g->srow, n, g)) return rc;
         if (int rc = dmalloc(&g->srow2, n, g)) return rc;
-        if (int rc = dmalloc(&g->spool, g->spool_units * 4 + 4, g)) return rc;
-        GMSX_HIP(hipMemsetAsync(g->spool, 0, size_t(g->spool_units * 4 + 4) * sizeof(uint32_t), s));  // the alignment gaps are never read, but keep them defined
+        if (int rc = dmalloc(&g->spool, (g->spool_units + kPoolSlack) * 4, g)) return rc;  // + slack: the scans load whole lane groups past a row's end
+        GMSX_HIP(hipMemsetAsync(g->spool, 0, size_t((g->spool_units + kPoolSlack) * 4) * sizeof(uint32_t), s));  // the alignment gaps are never read, but keep them defined
         if (inline_h_units > 0) GMSX_HIP(hipMemsetAsync(g->spool + inline_h_base * 4, 0xff, size_t(inline_h_units) * 16, s));  // list filler 0xFFFF
         if (n > 0)
             hipLaunchKernelGGL(k_srow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->hoff, g->hadj, g->bmoff, g->bmpool, uoff, soff, real, form,
@@ -1359,46 +1356,44 @@ static int build_tc_sets(gmsx_graph *g) {
         g->tpool_units = inline_t_base + inline_t_units;
         if (g->tpool_units >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;
         if (int rc = dmalloc(&g->trow, n, g)) return rc;
-        if (int rc = dmalloc(&g->tpool, g->tpool_units * 4 + 4, g)) return rc;
+        if (int rc = dmalloc(&g->tpool, (g->tpool_units + kPoolSlack) * 4, g)) return rc;
         GMSX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g->tpool), int(0xFFFFFFFEu), size_t(g->tpool_units) * 4 + 4, s));  // filler -2 (alignment gaps, inline rows)
         if (n > 0)
             hipLaunchKernelGGL(k_trow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->toff, g->tadj, uoff, soff, real, form, g->trow, g->tpool);
-        if (int rc = dmalloc(&g->tdesc, 2 * g->tail_entries + 2, g)) return rc;
-        if (g->tail_entries > 0)
-            hipLaunchKernelGGL(k_tdesc_fill, dim3(unsigned((g->tail_entries + 255) / 256)), dim3(256), 0, s, g->tail_entries, g->tadj, g->srow, g->trow,
-                               g->tdesc);
         GMSX_HIP(hipStreamSynchronize(s));
     }
 
-    pt.mark("tail stream rows + tdesc");
+    pt.mark("tail stream rows");
     // 5c. inline rows: copy the handed-over ids (pools exist now), blank the light pivots' descriptors of handed-over far members
     if (n_work > 0) {
         GMSX_HIP(hipMemsetAsync(inl_h, 0, size_t(n + 1) * sizeof(unsigned long long), s));  // now the fill cursors
         GMSX_HIP(hipMemsetAsync(inl_t, 0, size_t(n + 1) * sizeof(unsigned long long), s));
         hipLaunchKernelGGL(k_inline_rows<true>, dim3(grid_for_waves(n_work)), dim3(256), 0, s, int64_t(0), n_work, g->order, g->hoff, g->hadj, g->toff,
                            g->tadj, g->dplus, g->inline_limit, opos, g->shard_nparts, g->shard_part, inl_h, inl_t, ihoff, itoff, inline_h_base, reinterpret_cast<uint16_t *>(g->spool),
-                           inline_t_base, reinterpret_cast<int32_t *>(g->tpool), g->tdesc);
+                           inline_t_base, reinterpret_cast<int32_t *>(g->tpool));
     }
     pt.mark("inline rows fill");
     // (the ids arrive in the inline rows through atomic cursors, in any order — and stay so: a receiver's inline rows are scanned whole by
     //  whichever rank owns the receiver, and the count does not depend on the order.  Round 2 sorted them, 0.13–0.8 s at scale 26, because
     //  its shards cut the lists by position.)
-    // 5e. the light pivots k_tc_wave still has work for (most handed everything over): a compact list in launch order, built with a scan so
-    //     that it is the same on every rank
+    // 5e. light edges (k_tc_light): count per light pivot -> scan -> fill (the same list on every rank: built with a scan)
     {
         const int64_t nl = n_work - n_heavy;
-        g->n_wave = 0;
+        g->n_ledge = g->ledge_total = 0;
         if (nl > 0) {
-            int64_t *flags = nullptr, *slot = nullptr;
-            if (int rc = dmalloc(&flags, nl + 1, nullptr)) return rc;
-            DevGuard g_fl{flags};
-            if (int rc = dmalloc(&slot, nl + 1, nullptr)) return rc;
-            DevGuard g_sl{slot};
-            hipLaunchKernelGGL(k_wave_flags, dim3(grid_for_waves(nl + 1)), dim3(256), 0, s, n_heavy, n_work, g->order, g->toff, g->tadj, g->tsplit, g->dplus, flags);
-            if (int rc = exclusive_scan_i64(flags, slot, nl + 1, s)) return rc;
-            GMSX_HIP(hipMemcpy(&g->n_wave, slot + nl, sizeof(int64_t), hipMemcpyDeviceToHost));
-            if (int rc = dmalloc(&g->worder, g->n_wave + 1, g)) return rc;
-            hipLaunchKernelGGL(k_wave_scatter, dim3(unsigned((nl + 255) / 256)), dim3(256), 0, s, nl, n_heavy, g->order, flags, slot, g->worder);
+            int64_t *ecnt = nullptr, *ebeg = nullptr;
+            if (int rc = dmalloc(&ecnt, nl + 1, nullptr)) return rc;
+            DevGuard g_ec{ecnt};
+            if (int rc = dmalloc(&ebeg, nl + 1, nullptr)) return rc;
+            DevGuard g_eb{ebeg};
+            hipLaunchKernelGGL(k_ledge_count, dim3(unsigned(nl / 256 + 1)), dim3(256), 0, s, n_heavy, n_work, g->order, g->toff, g->tadj, g->tsplit, g->dplus, ecnt);
+            if (int rc = exclusive_scan_i64(ecnt, ebeg, nl + 1, s)) return rc;
+            GMSX_HIP(hipMemcpy(&g->ledge_total, ebeg + nl, sizeof(int64_t), hipMemcpyDeviceToHost));
+            const int np = g->shard_nparts > 1 ? g->shard_nparts : 1, pp = g->shard_nparts > 1 ? g->shard_part : 0;
+            g->n_ledge = g->ledge_total > pp ? (g->ledge_total - pp + np - 1) / np : 0;
+            if (int rc = dmalloc(&g->ledge, 2 * g->n_ledge + 2, g)) return rc;
+            hipLaunchKernelGGL(k_ledge_fill, dim3(unsigned(nl / 256 + 1)), dim3(256), 0, s, n_heavy, n_work, g->order, g->hoff, g->toff, g->tadj, g->tsplit, g->dplus, ebeg,
+                               np, pp, g->ledge);
             GMSX_HIP(hipStreamSynchronize(s));
         }
     }

@@ -74,11 +74,6 @@ struct gmsx_graph {
     int64_t spool_units = 0;
     // … and the TAIL part of every row the same way (trow / tpool): form 0 = 32-bit ids, 4 per unit, filler -2 (never a key of a
     // pivot's tail set); form 2 = 16-bit delta: 32-bit base, count, five 16-bit gaps — 6 ids per unit, 2.67 B/id against 4 B/id
-    // both descriptors of every TAIL entry once more, next to the entry: tdesc[2*e] = srow[tadj[e]], tdesc[2*e+1] = trow[tadj[e]].
-    // A heavy pivot then reads the descriptors of its tail members as one coalesced 16-byte load per member instead of two
-    // dependent 8-byte gathers into 0.5 GB tables (≈60 GB of 64-byte lines per pass at scale 26); hub members keep srow[v]
-    // (65535 entries: L2-resident).
-    unsigned long long *tdesc = nullptr;
     // TASK LISTS (tc.hip).  |N+(u) ∩ N+(v)| of an oriented edge (u,v) can be counted with either endpoint as the pivot (its row as bitmap +
     // tail set in LDS) and the other one streamed; the pass streams the SMALLER row (fewer 16-byte units).  So every receiving vertex w
     // owns two lists of 8-byte stream-row descriptors — HUB entries (rows probed against w's bitmap) and TAIL entries (rows probed against
@@ -101,8 +96,13 @@ struct gmsx_graph {
     mutable int shard_idx_part = -1, shard_idx_nparts = -1;
     int32_t *tunits = nullptr;           // [n] oriented edges whose entries live at this vertex (forward + reverse): the bookkeeping of gmsx_stats.units
     int64_t task_reverse = 0;            // edges handed over to the other endpoint
-    int32_t *worder = nullptr;           // the light pivots that still have far light members (in launch order): what k_tc_wave walks
-    int64_t n_wave = 0;
+    // LIGHT EDGES (round 4, k_tc_light): the oriented edges (u, v) no work item covers — u light (2 <= d+ < kHeavy), v a FAR LIGHT member of it
+    // (rank id >= inline_limit, d+ < kHeavy) — as self-contained 32-byte records: where the hub part and the tail part of u's row and of
+    // v's row lie in hadj / tadj (first id, 40 bits | ids << 40; of u's tail part only the ids in front of v: nothing else can be in N+(v)).
+    // Both rows are short (< 64 ids), so the edge is ONE all-pairs comparison in registers: no LDS, no per-pivot state, every edge
+    // independent.  Edge e of the (deterministic) list belongs to shard e % nparts; a sharded upload keeps its own at slot e / nparts.
+    uint4 *ledge = nullptr;
+    int64_t n_ledge = 0, ledge_total = 0;
     int32_t inline_limit = 0;            // light pivots hand their edges to members of rank id < inline_limit (and to heavy ones) as INLINE ROWS
     int64_t inline_units = 0;            // 16-byte units of all inline rows (inside spool / tpool)
     unsigned long long *trow = nullptr;
@@ -148,6 +148,7 @@ static constexpr int kHub = 65535;         // rank ids below this live in the 16
 static constexpr int kBitmapWords = 2048;  // 65536-bit LDS bitmap over the hub id range
 static constexpr int kAccWords = 64 * 16 + 16;
 static constexpr int kFormList = 0, kFormBitset = 1, kFormDelta = 2, kFormGap12 = 3;
+static constexpr int kPoolSlack = 64;    // 16-byte units of padding behind spool / tpool: a lane group loads up to 15 units past the end of a row (tc.hip, scan_run)
 static constexpr int kTaskChunk = 512;   // entries per work item (4 KB of descriptors: two such buffers per workgroup, the next item's arriving while this one is scanned)
 // run type of an entry inside a work item = form * 3 + {0: <= 4 units, 1: <= 8, 2: longer}: the three lane-group widths of the scan
 // loops (tc.hip).  Monotone in the class order of the lists, so an item is at most 12 consecutive runs.

@@ -28,7 +28,7 @@
 //   3. every streamed hub id is one LDS word read + bit test (no collisions, no branches); a tail id is one filter-bit test and,
 //      for the few that pass, a table probe; hits are counted per lane, reduced per workgroup, added to one of 64 spread u64
 //      accumulators (one atomic per workgroup);
-//   4. k_tc_wave — light pivots with far light members: wave per pivot, private bitmap + bucket set, streams those members' rows.
+//   4. k_tc_light — the edges between two light vertices that no work item covers: one 16-lane group per edge, all-pairs in registers.
 //   The three kernels run side by side on three streams (hub items: bandwidth + VALU; tail items: short rows; light pivots: latency).
 // No MFMA: integer/indexing work bounded by row streaming (HBM) and VALU issue of the decode + probe sequence.
 #include "device_graph.hpp"
@@ -123,88 +123,6 @@ __device__ __forceinline__ uint32_t gap12_unit_hits(const uint32_t *bm, uint4 p)
     return uint32_t(__popc(hits & ((1u << n) - 1u)));
 }
 
-// The LIGHT-PIVOT kernel's row scan (k_tc_wave; the work-item kernels have their own typed loops below): streams up to 64 stream rows
-// against the wave's LDS bitmap.  Lane l holds the packed descriptor of one row (srow[v]; 0 = no row).  A wave works as four 16-lane
-// groups, each on its own row: one 16-byte unit per lane per step, two steps in flight.  Rows are handed out FORM BY FORM (a ballot per
-// form, then the four lowest lanes of the ballot): the forms cost 12 / 32 / 81 VALU instructions per unit, and a hand-out that mixes them
-// executes every branch with a quarter of the lanes.
-struct RowHandout {
-    const uint4 *row;
-    int units;
-};
-__device__ __forceinline__ RowHandout take_rows(unsigned long long &todo, const uint32_t *__restrict__ pool, uint32_t dlo, uint32_t dhi, int grp) {
-    uint32_t lo[4], hi[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        lo[k] = 0;
-        hi[k] = 0;
-        if (todo) {  // wave-uniform
-            const int i = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            lo[k] = __builtin_amdgcn_readlane(dlo, i);
-            hi[k] = __builtin_amdgcn_readlane(dhi, i);
-        }
-    }
-    const uint32_t l = grp == 0 ? lo[0] : grp == 1 ? lo[1] : grp == 2 ? lo[2] : lo[3];
-    const uint32_t h = grp == 0 ? hi[0] : grp == 1 ? hi[1] : grp == 2 ? hi[2] : hi[3];
-    return RowHandout{reinterpret_cast<const uint4 *>(pool) + ((uint64_t(h) << 8) | (l >> 24)), int(l & 0x3fffffu)};
-}
-__device__ __forceinline__ uint32_t scan_srows(const uint32_t *bm, const uint32_t *__restrict__ spool, unsigned long long desc, int lane) {
-    const int grp = lane >> 4, sub = lane & 15;
-    const uint32_t dlo = uint32_t(desc), dhi = uint32_t(desc >> 32);
-    const bool any = (dlo & 0x3fffffu) != 0;
-    const uint32_t form = (dlo >> 22) & 3u;
-    uint32_t cnt = 0;
-    for (unsigned long long todo = __ballot(any && form == kFormBitset); todo;) {  // AND the bitset with the pivot bitmap, 128 ids per unit
-        const RowHandout r = take_rows(todo, spool, dlo, dhi, grp);
-        for (int j = sub; j < r.units; j += 32) {
-            const uint4 p = r.row[j];
-            const uint4 q = *reinterpret_cast<const uint4 *>(bm + 4 * j);
-            uint32_t c = uint32_t(__popc(p.x & q.x) + __popc(p.y & q.y) + __popc(p.z & q.z) + __popc(p.w & q.w));
-            if (j + 16 < r.units) {
-                const uint4 p2 = r.row[j + 16];
-                const uint4 q2 = *reinterpret_cast<const uint4 *>(bm + 4 * (j + 16));
-                c += uint32_t(__popc(p2.x & q2.x) + __popc(p2.y & q2.y) + __popc(p2.z & q2.z) + __popc(p2.w & q2.w));
-            }
-            cnt += c;
-        }
-    }
-    for (unsigned long long todo = __ballot(any && form == kFormDelta); todo;) {
-        const RowHandout r = take_rows(todo, spool, dlo, dhi, grp);
-        int j = sub;
-        for (; j + 16 < r.units; j += 32) {
-            const uint4 p = r.row[j], q = r.row[j + 16];
-            cnt += delta_unit_hits(bm, p);
-            cnt += delta_unit_hits(bm, q);
-        }
-        if (j < r.units) cnt += delta_unit_hits(bm, r.row[j]);
-    }
-    for (unsigned long long todo = __ballot(any && form == kFormGap12); todo;) {
-        const RowHandout r = take_rows(todo, spool, dlo, dhi, grp);
-        int j = sub;
-        for (; j + 16 < r.units; j += 32) {
-            const uint4 p = r.row[j], q = r.row[j + 16];
-            cnt += gap12_unit_hits(bm, p);
-            cnt += gap12_unit_hits(bm, q);
-        }
-        if (j < r.units) cnt += gap12_unit_hits(bm, r.row[j]);
-    }
-    for (unsigned long long todo = __ballot(any && form == kFormList); todo;) {  // 16-bit list, 8 ids per unit, filler 0xFFFF
-        const RowHandout r = take_rows(todo, spool, dlo, dhi, grp);
-        int j = sub;
-        for (; j + 16 < r.units; j += 32) {
-            const uint4 p = r.row[j], q = r.row[j + 16];
-            cnt += hub_hits8(bm, u4u{p.x, p.y, p.z, p.w});
-            cnt += hub_hits8(bm, u4u{q.x, q.y, q.z, q.w});
-        }
-        if (j < r.units) {
-            const uint4 p = r.row[j];
-            cnt += hub_hits8(bm, u4u{p.x, p.y, p.z, p.w});
-        }
-    }
-    return cnt;
-}
-
 // ---- tail side: open-addressing hash set in LDS (keys are rank ids >= kHub; -1 = empty) ------------------------
 __device__ __forceinline__ uint32_t hash_slot(int32_t w, int shift) { return (uint32_t(w) * 0x9E3779B1u) >> shift; }
 
@@ -231,97 +149,44 @@ __device__ __forceinline__ uint32_t set_contains(const int32_t *tbl, uint32_t ma
 // 2-3) that was nearly every step, and the walk of the table for a handful of lanes cost three times the filter pass itself (scale 26:
 // 180 wave-instructions per step against ~50; the scalar unit 60 % busy with the branches).  A few dozen keys in 32768 bits: ~0.1 %.
 static constexpr int kFilterWords = 1024;
-__device__ __forceinline__ uint32_t flt_bit(const uint32_t *flt, uint32_t, uint32_t id) { return __builtin_amdgcn_ubfe(flt[(id >> 5) & uint32_t(kFilterWords - 1)], id, 1u); }
-__device__ __forceinline__ uint32_t tail_unit_hits(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, uint4 p) {
-    const uint32_t m = flt_bit(flt, mask, p.x) | (flt_bit(flt, mask, p.y) << 1) | (flt_bit(flt, mask, p.z) << 2) | (flt_bit(flt, mask, p.w) << 3);
+// FAST PATH: the filter words of all ids of the unit, each shifted by its id's bit position, ORed — bit 0 of the result says "some id
+// may be a key" (2 VALU instructions per id behind the LDS read; v_lshrrev takes the low five bits of the id by itself).  Only then the
+// SLOW PATH: which ids (bit tests, the unit's count cut off), and one exact probe per set bit, lane by lane (ffs loop: the lanes that
+// got here are few, and six exec-masked blocks — rounds 2-3 — cost 90 instructions for the wave whoever had a bit).
+__device__ __forceinline__ uint32_t flt_word(const uint32_t *flt, uint32_t id) { return flt[(id >> 5) & uint32_t(kFilterWords - 1)] >> (id & 31u); }
+__device__ __forceinline__ uint32_t probe_set_bits(const int32_t *tbl, uint32_t mask, int shift, uint32_t m, const uint32_t (&id)[6]) {
     uint32_t c = 0;
-    if (m) {  // rare: exact membership for the ids the filter let through (the filler -2 may pass the filter, it is never a key)
-        if (m & 1u) c += set_contains(tbl, mask, shift, int32_t(p.x));
-        if (m & 2u) c += set_contains(tbl, mask, shift, int32_t(p.y));
-        if (m & 4u) c += set_contains(tbl, mask, shift, int32_t(p.z));
-        if (m & 8u) c += set_contains(tbl, mask, shift, int32_t(p.w));
+    while (m) {
+        const int k = __ffs(int(m)) - 1;
+        m &= m - 1u;
+        const uint32_t w = k == 0 ? id[0] : k == 1 ? id[1] : k == 2 ? id[2] : k == 3 ? id[3] : k == 4 ? id[4] : id[5];
+        c += set_contains(tbl, mask, shift, int32_t(w));
     }
     return c;
 }
-// one unit of the 16-bit delta form: 32-bit base, count (low half of word 1), five 16-bit gaps
+__device__ __forceinline__ uint32_t tail_unit_hits(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, uint4 p) {
+    const uint32_t w0 = flt_word(flt, p.x), w1 = flt_word(flt, p.y), w2 = flt_word(flt, p.z), w3 = flt_word(flt, p.w);
+    if (((w0 | w1 | w2 | w3) & 1u) == 0) return 0u;
+    const uint32_t id[6] = {p.x, p.y, p.z, p.w, 0u, 0u};  // (the filler -2 may pass the filter, it is never a key)
+    return probe_set_bits(tbl, mask, shift, (w0 & 1u) | ((w1 & 1u) << 1) | ((w2 & 1u) << 2) | ((w3 & 1u) << 3), id);
+}
+// one unit of the 16-bit delta form: 32-bit base, count (low half of word 1), five 16-bit gaps (unused gaps are 0: the id repeats)
 __device__ __forceinline__ uint32_t tail_delta_unit_hits(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, uint4 p) {
     const uint32_t id0 = p.x, id1 = id0 + (p.y >> 16), id2 = id1 + (p.z & 0xffffu), id3 = id2 + (p.z >> 16), id4 = id3 + (p.w & 0xffffu),
                    id5 = id4 + (p.w >> 16);
+    const uint32_t w0 = flt_word(flt, id0), w1 = flt_word(flt, id1), w2 = flt_word(flt, id2), w3 = flt_word(flt, id3), w4 = flt_word(flt, id4),
+                   w5 = flt_word(flt, id5);
+    if (((w0 | w1 | w2 | w3 | w4 | w5) & 1u) == 0) return 0u;
     const uint32_t n = p.y & 0xffu;
-    const uint32_t m = (flt_bit(flt, mask, id0) | (flt_bit(flt, mask, id1) << 1) | (flt_bit(flt, mask, id2) << 2) | (flt_bit(flt, mask, id3) << 3) |
-                        (flt_bit(flt, mask, id4) << 4) | (flt_bit(flt, mask, id5) << 5)) & ((1u << n) - 1u);
-    uint32_t c = 0;
-    if (m) {
-        if (m & 1u) c += set_contains(tbl, mask, shift, int32_t(id0));
-        if (m & 2u) c += set_contains(tbl, mask, shift, int32_t(id1));
-        if (m & 4u) c += set_contains(tbl, mask, shift, int32_t(id2));
-        if (m & 8u) c += set_contains(tbl, mask, shift, int32_t(id3));
-        if (m & 16u) c += set_contains(tbl, mask, shift, int32_t(id4));
-        if (m & 32u) c += set_contains(tbl, mask, shift, int32_t(id5));
-    }
-    return c;
+    const uint32_t m = ((w0 & 1u) | ((w1 & 1u) << 1) | ((w2 & 1u) << 2) | ((w3 & 1u) << 3) | ((w4 & 1u) << 4) | ((w5 & 1u) << 5)) & ((1u << n) - 1u);
+    const uint32_t id[6] = {id0, id1, id2, id3, id4, id5};
+    return probe_set_bits(tbl, mask, shift, m, id);
 }
-// Bucketed tail set for the light-pivot kernel (<= 63 keys): 64 buckets x 4 slots, 16-byte aligned, so a probe is ONE
-// ds_read_b128 and four compares -- no probe loop, no divergence, and the four probes of a 16-byte load are
-// independent.  A pivot whose keys overflow a bucket (five keys with the same hash) falls back to the open-addressing
-// table above, built in the same 1 KB.
-template <int NB>
-__device__ __forceinline__ uint32_t bucket_of(int32_t w) {  // NB buckets (power of two)
-    return NB == 64 ? (uint32_t(w) ^ (uint32_t(w) >> 6)) & 63u : (uint32_t(w) ^ (uint32_t(w) >> 9)) & uint32_t(NB - 1);
-}
-template <int NB>
-__device__ __forceinline__ uint32_t bucket_contains(const int32_t *tbl, int32_t w) {
-    const int4 b = *reinterpret_cast<const int4 *>(tbl + bucket_of<NB>(w) * 4);
-    return uint32_t((b.x == w) | (b.y == w) | (b.z == w) | (b.w == w));
-}
-// Tail stream rows against an arbitrary exact membership probe (the light-pivot kernel: bucket set or open-addressing table, no filter).
-template <class Probe>
-__device__ __forceinline__ uint32_t tail_unit_probe(Probe probe, uint4 p, int form) {
-    if (form == kFormDelta) {
-        const uint32_t id0 = p.x, id1 = id0 + (p.y >> 16), id2 = id1 + (p.z & 0xffffu), id3 = id2 + (p.z >> 16), id4 = id3 + (p.w & 0xffffu),
-                       id5 = id4 + (p.w >> 16);
-        const uint32_t n = p.y & 0xffu;
-        return probe(int32_t(id0)) + (n > 1 ? probe(int32_t(id1)) : 0u) + (n > 2 ? probe(int32_t(id2)) : 0u) + (n > 3 ? probe(int32_t(id3)) : 0u) +
-               (n > 4 ? probe(int32_t(id4)) : 0u) + (n > 5 ? probe(int32_t(id5)) : 0u);
-    }
-    return probe(int32_t(p.x)) + probe(int32_t(p.y)) + probe(int32_t(p.z)) + probe(int32_t(p.w));  // the filler -2 is never a key
-}
-template <class Probe>
-__device__ __forceinline__ uint32_t scan_trows_probe(Probe probe, const uint32_t *__restrict__ tpool, unsigned long long desc, int rows, int lane) {
-    const int grp = lane >> 4, sub = lane & 15;
-    uint32_t cnt = 0;
-    for (int r0 = 0; r0 < rows; r0 += 4) {
-        const int m0 = r0 & 63, m1 = (r0 + 1) & 63, m2 = (r0 + 2) & 63, m3 = (r0 + 3) & 63;
-        const uint32_t lo0 = __builtin_amdgcn_readlane(uint32_t(desc), m0), lo1 = __builtin_amdgcn_readlane(uint32_t(desc), m1),
-                       lo2 = __builtin_amdgcn_readlane(uint32_t(desc), m2), lo3 = __builtin_amdgcn_readlane(uint32_t(desc), m3);
-        if (((lo0 | lo1 | lo2 | lo3) & 0x3fffffu) == 0) continue;  // wave-uniform
-        const uint32_t hi0 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m0), hi1 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m1),
-                       hi2 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m2), hi3 = __builtin_amdgcn_readlane(uint32_t(desc >> 32), m3);
-        const uint32_t lo = grp == 0 ? lo0 : grp == 1 ? lo1 : grp == 2 ? lo2 : lo3;
-        const uint32_t hi = grp == 0 ? hi0 : grp == 1 ? hi1 : grp == 2 ? hi2 : hi3;
-        const int units = int(lo & 0x3fffffu), form = int((lo >> 22) & 3u);
-        const uint4 *row = reinterpret_cast<const uint4 *>(tpool) + ((uint64_t(hi) << 8) | (lo >> 24));
-        int j = sub;
-        for (; j + 16 < units; j += 32) {
-            const uint4 p = row[j], q = row[j + 16];
-            cnt += tail_unit_probe(probe, p, form);
-            cnt += tail_unit_probe(probe, q, form);
-        }
-        if (j < units) cnt += tail_unit_probe(probe, row[j], form);
-    }
-    return cnt;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Work items (device_graph.hpp): one workgroup per item = up to kTaskChunk consecutive entries of ONE pivot's hub-entry list (k_tc_block:
 // the pivot's hub part staged as the 65536-bit bitmap, 8 KB) or tail-entry list (k_tc_tail: the pivot's tail part as filter + hash set,
 // tiled if longer than half the table).  An entry is one 8-byte stream-row descriptor — a member's row, the cut row of an in-neighbour
 // that handed its edge over, a 64-unit chunk of an inline row: the kernels cannot tell and need not.
-// The lists are laid out CLASS BY CLASS at build time (class = form x ceil(log2 units)), so an item is a handful of runs of equally
-// formed, similarly long rows.  The workgroup copies the item's descriptors to LDS, marks where each class begins and ends, and then runs
-// one COMPILE-TIME-SHAPED loop per class: groups of W = 4 / 8 / 16 lanes (rows of <= 4 / <= 8 / more units), group g taking entries
-// g, g + 256/W, … with the next descriptor already loaded while the current row is scanned.  No form ballots, no readlane hand-outs, no
-// mixed rows in a wave: what was ~30 VALU instructions per four rows is one LDS read and an address computation per row.
 // ---------------------------------------------------------------------------------------------
 static constexpr int kBlockLog = 10;
 template <int FORM>
@@ -348,8 +213,8 @@ __device__ __forceinline__ uint32_t tail_unit_hits_f(const uint32_t *flt, const 
 #endif
 // Entries [lo, hi) of an item (descriptors in LDS), one form, rows of one width class, as a STREAM OF STEPS: a group of W lanes works on
 // one row, a step = W consecutive units of it (one 16-byte load per lane), and a lane keeps D steps in flight across row boundaries.
-// Every load is UNCONDITIONAL — a lane without a unit in the step re-reads unit 0 of its row, a group past its last entry unit 0 of the
-// pool — because a load under a divergent branch cannot be counted: hipcc then waits with vmcnt(0) at every use, i.e. for the load it
+// Every load is UNCONDITIONAL — a lane without a unit in the step re-reads the last unit of its row, a group past its last entry unit 0
+// of the pool — because a load under a divergent branch cannot be counted: hipcc then waits with vmcnt(0) at every use, i.e. for the load it
 // issued a moment ago, and a wave never has more than one load instruction in flight (rounds 2-3: that, times 32 waves per CU, was the
 // 3.7 TB/s of the tail items — 0.9 KB per wave and memory latency).  With counted waits the D loads overlap.
 // HIT(p, j) = hits of unit j of a row.
@@ -359,23 +224,29 @@ __device__ __forceinline__ uint32_t scan_run(const unsigned long long *sdesc, co
     const int sub = tid % W;
     const uint4 *pool4 = reinterpret_cast<const uint4 *>(pool);
     uint32_t cnt = 0;
-    // cursor of the step to ISSUE: entry e (descriptor d = first unit << 24 | form << 22 | units), unit j of this lane
+    // cursor of the step to ISSUE: entry e (descriptor d = first unit << 24 | form << 22 | units), unit j of this lane.  Per row: its
+    // first unit's address, the index of its last unit (a lane without a unit in the step re-reads that one: same line as its
+    // neighbours'), and j's bound for "the row is through"
     int e = lo + tid / W;
     unsigned long long d = e < hi ? sdesc[e] : 0ull;
+    const uint4 *row = pool4 + (d >> 24);
+    int units = int(uint32_t(d) & 0x3fffffu), last = max(units - 1, 0), lim = units + sub;
     int j = sub;
     int pending = 0;  // steps of real entries in the ring
     uint4 p[D];
     int pj[D];  // unit index of the lane in that step, -1 = none
     auto issue = [&](int k) {
-        const int units = int(uint32_t(d) & 0x3fffffu);
-        const bool live = j < units;
-        p[k] = pool4[(d >> 24) + (unsigned long long)(live ? j : 0)];
-        pj[k] = live ? j : -1;
+        p[k] = row[uint32_t(min(j, last))];
+        pj[k] = j < units ? j : -1;
         pending += e < hi ? 1 : 0;
         j += W;
-        if (j - sub >= units) {  // the row is through (uniform per group): next entry of the group
+        if (j >= lim) {  // the row is through (uniform per group): next entry of the group
             e += G;
             d = e < hi ? sdesc[e] : 0ull;
+            row = pool4 + (d >> 24);
+            units = int(uint32_t(d) & 0x3fffffu);
+            last = max(units - 1, 0);
+            lim = units + sub;
             j = sub;
         }
     };
@@ -388,7 +259,11 @@ __device__ __forceinline__ uint32_t scan_run(const unsigned long long *sdesc, co
             const int jc = pj[k];
             pending -= 1;  // (slots of dead entries push it below zero: the loop ends at the first check after the last real step)
             issue(k);
+#ifdef GMSX_TC_NO_PROBE  // A/B build (WRONG counts): every unit is loaded, nothing is probed — what the memory side alone takes
+            if (jc >= 0) cnt += pc.x & 1u;
+#else
             if (jc >= 0) cnt += hit(pc, jc);
+#endif
         }
     }
     return cnt;
@@ -749,136 +624,118 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
 }
 
 // ---------------------------------------------------------------------------------------------
-// Light pivots (2 <= d+ < 64): the rows of their FAR, LIGHT members (rank id >= inline_limit and d+ < 64).  Every other edge of a light
-// pivot was handed over to the member at upload (inline rows, device_graph.hpp) and is counted by k_tc_block.  Each of the 4 waves of a
-// workgroup owns a private bitmap (8 KB) and a 64 x 4 bucket set for the tail part and walks its pivots with a grid
-// stride; pivots without tail members are skipped.  The bitmap is cleared once; each pivot sets its bits and clears
-// exactly those words again.
-// The dependent loads  order[] -> offsets -> member ids -> row extents  form a four-deep software pipeline over the
-// pivots of the wave: while pivot D is scanned, the members and row extents of pivot C, the offsets of B and the id
-// of A are in flight, so a pivot pays only the round trips of its own row scans.
+// LIGHT EDGES (round 4; device_graph.hpp): the edges (u, v) between two light vertices that no work item covers, one 16-lane group per
+// edge, no LDS.  Both rows are short (hub part + tail part < 64 ids), so |N+(u) ∩ N+(v)| is an ALL-PAIRS comparison in registers: the
+// ids of a part sit interleaved over the 16 lanes (id i in lane i & 15, register i >> 4), v's registers are rotated through the group with
+// DPP row_ror, and every lane compares what passes by with its own ids of u — 16 rotations x (registers of u) x (registers of v), the
+// register counts being wave-uniform maxima (typically 1 x 1 or 2 x 2).  Every load is unconditional (clamped index, sentinel afterwards)
+// and the next edge's record and rows are in flight while this one is compared: k_tc_wave — a wave per pivot, an 8 KB bitmap per wave,
+// 16 waves per CU, one load in flight per wave behind a chain of dependent loads — took 10.6 ms for 14 GB at scale 26 (1.3 TB/s).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tc_wave(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                 const uint32_t *__restrict__ spool, const uint32_t *__restrict__ tpool,
-                                                 const unsigned long long *__restrict__ tdesc, const int64_t *__restrict__ toff,
-                                                 const int32_t *__restrict__ tadj, const int32_t *__restrict__ tsplit,
-                                                 const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts, int part,
-                                                 unsigned long long *__restrict__ acc) {
-    constexpr int LOG = 8, SIZE = 1 << LOG, SHIFT = 32 - LOG;
-    constexpr uint32_t MASK = SIZE - 1;
-    __shared__ __attribute__((aligned(16))) uint32_t bm_all[4 * kBitmapWords + 128];  // + slack: the delta probes of unused slots read up to 104 words past a bitmap
-    __shared__ __attribute__((aligned(16))) int32_t tbl_all[4 * SIZE];
-    __shared__ uint32_t fill_all[4 * 64];
+__device__ __forceinline__ uint32_t ror1_in_row(uint32_t x) { return uint32_t(__builtin_amdgcn_mov_dpp(int(x), 0x121, 0xf, 0xf, false)); }  // row_ror:1
+struct LightRows {
+    uint32_t ah[4], at[4], bh[4], bt[4];  // u's hub / tail ids, v's hub / tail ids (interleaved over the 16 lanes)
+};
+struct LightRec {
+    uint4 r0, r1;
+};
+__global__ __launch_bounds__(256) void k_tc_light(const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint4 *__restrict__ ledge, int64_t first,
+                                                  int64_t stride, int64_t count, unsigned long long *__restrict__ acc) {
     __shared__ unsigned long long red[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t *bm = bm_all + wave * kBitmapWords;
-    int32_t *tbl = tbl_all + wave * SIZE;
-    uint32_t *fill = fill_all + wave * 64;
-    for (int i = lane; i < kBitmapWords; i += 64) bm[i] = 0;
-    const int64_t step = int64_t(gridDim.x) * 4 * nparts;
-    const int64_t pos0 = first + (int64_t(blockIdx.x) * 4 + wave) * nparts + part;
-    unsigned long long cnt = 0;
-
-    // The dependent loads  order[] -> offsets -> (member ids, stream-row descriptors)  form a three-deep software pipeline over the
-    // pivots of the wave.  The descriptors of a pivot's tail members sit next to the members (tdesc), so they no longer wait for the
-    // member ids: stage C loads ids and descriptors together, stage D scans.
-    int64_t hbC = 0, tbC = 0, hbB = 0, tbB = 0;
-    int hlC = 0, tlC = 0, hlB = 0, tlB = 0;
-    int tsC = 0, tsB = 0, tsD = 0;  // members below inline_limit come first in a tail row: handed over
-    int32_t uA = -1;
-    int tlD = 0;
-    uint32_t hvD = 0xFFFFu;
-    int32_t vD = -1;
-    unsigned long long dsD = 0, dtD = 0;  // stream-row descriptors (hub part, tail part) of this lane's far member; 0 = nothing to stream
-    auto load_members = [&](int64_t hb, int hl, int64_t tb, int tl, int ts, uint32_t &hv, int32_t &v, unsigned long long &ds, unsigned long long &dt) {
-        hv = 0xFFFFu; v = -1; ds = 0; dt = 0;
-        if (tl > 0) {
-            if (lane < hl) hv = hadj[hb + lane];
-            if (lane < tl) {
-                v = tadj[tb + lane];
-                if (lane >= ts) {
-                    const ulonglong2 d = *reinterpret_cast<const ulonglong2 *>(tdesc + 2 * (tb + lane));
-                    ds = d.x;
-                    if (lane > 0) dt = d.y;  // the first tail member's tail ids are all below every tail id of the pivot: no match possible
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15;
+    const int64_t ngroups = int64_t(gridDim.x) * 16, g0 = int64_t(blockIdx.x) * 16 + (tid >> 4);
+    const int64_t trips = (count + ngroups - 1) / ngroups;  // the same for every group (uniform loop): a group without an edge runs on empty rows
+    auto load_rec = [&](int64_t t) -> LightRec {
+        const int64_t k = g0 + t * ngroups;
+        const int64_t e = k < count ? first + k * stride : first;  // (count > 0 here)
+        LightRec r;
+        r.r0 = ledge[2 * e];
+        r.r1 = ledge[2 * e + 1];
+        if (k >= count || t >= trips) {  // lengths 0: everything below degenerates to sentinels
+            r.r0.y &= 0xffu;
+            r.r0.w &= 0xffu;
+            r.r1.y &= 0xffu;
+            r.r1.w &= 0xffu;
+        }
+        return r;
+    };
+    auto load_rows = [&](const LightRec &r) -> LightRows {
+        const int64_t hu = int64_t((uint64_t(r.r0.y & 0xffu) << 32) | r.r0.x), tu = int64_t((uint64_t(r.r0.w & 0xffu) << 32) | r.r0.z);
+        const int64_t hv = int64_t((uint64_t(r.r1.y & 0xffu) << 32) | r.r1.x), tv = int64_t((uint64_t(r.r1.w & 0xffu) << 32) | r.r1.z);
+        const int hlu = int(r.r0.y >> 8), tlu = int(r.r0.w >> 8), hlv = int(r.r1.y >> 8), tlv = int(r.r1.w >> 8);
+        LightRows w;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = sub + 16 * k;
+            w.ah[k] = hadj[hlu ? hu + min(i, hlu - 1) : 0];
+            w.bh[k] = hadj[hlv ? hv + min(i, hlv - 1) : 0];
+            w.at[k] = uint32_t(tadj[tlu ? tu + min(i, tlu - 1) : 0]);
+            w.bt[k] = uint32_t(tadj[tlv ? tv + min(i, tlv - 1) : 0]);
+        }
+        return w;
+    };
+    unsigned long long total = 0;
+    if (trips > 0) {
+        LightRec rec = load_rec(0);
+        LightRows rows = load_rows(rec);
+        LightRec rec_n = load_rec(1);
+        for (int64_t t = 0; t < trips; ++t) {
+            const LightRows rows_n = load_rows(rec_n);  // the next edge's rows and the record behind it are in flight while this edge is compared
+            const LightRec rec_nn = load_rec(t + 2);
+            const int hlu = int(rec.r0.y >> 8), tlu = int(rec.r0.w >> 8), hlv = int(rec.r1.y >> 8), tlv = int(rec.r1.w >> 8);
+            // registers in use, the maximum over the four groups of the wave (uniform)
+            auto wave_max = [](int x) {
+                return max(max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)), max(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+            };
+            const int nah = wave_max((hlu + 15) >> 4), nbh = wave_max((hlv + 15) >> 4), nat = wave_max((tlu + 15) >> 4), nbt = wave_max((tlv + 15) >> 4);
+            uint32_t c = 0;
+#pragma unroll
+            for (int ka = 0; ka < 4; ++ka) {
+                if (ka >= nah) break;
+                const int ia = sub + 16 * ka;
+                const uint32_t a = (ia < hlu && rows.ah[ka] != 0xFFFFu) ? rows.ah[ka] : 0xFFFFFFFFu;  // 0xFFFF = row padding
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    if (kb >= nbh) break;
+                    const int ib = sub + 16 * kb;
+                    uint32_t x = (ib < hlv && rows.bh[kb] != 0xFFFFu) ? rows.bh[kb] : 0xFFFFFFFEu;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        c += a == x ? 1u : 0u;
+                        x = ror1_in_row(x);
+                    }
                 }
             }
-        }
-    };
-    auto load_offsets = [&](int32_t u, int64_t &hb, int &hl, int64_t &tb, int &tl, int &ts) {
-        hb = hoff[u];
-        hl = int(hoff[u + 1] - hb);
-        tb = toff[u];
-        tl = int(toff[u + 1] - tb);
-        ts = tsplit[u];
-        if (tl <= ts) tl = 0;  // no member beyond inline_limit: nothing to stream for this pivot
-    };
-    {  // prologue
-        int64_t hb0 = 0, tb0 = 0;
-        int hl0 = 0;
-        if (pos0 < end) load_offsets(order[pos0], hb0, hl0, tb0, tlD, tsD);
-        if (pos0 + step < end) load_offsets(order[pos0 + step], hbC, hlC, tbC, tlC, tsC);
-        if (pos0 + 2 * step < end) load_offsets(order[pos0 + 2 * step], hbB, hlB, tbB, tlB, tsB);
-        if (pos0 + 3 * step < end) uA = order[pos0 + 3 * step];
-        load_members(hb0, hl0, tb0, tlD, tsD, hvD, vD, dsD, dtD);
-    }
-    for (int64_t pos = pos0; pos < end; pos += step) {  // uniform per wave
-        // loads of the later stages first; they complete while D is scanned
-        int64_t hbN = 0, tbN = 0;
-        int hlN = 0, tlN = 0, tsN = 0;
-        if (uA >= 0) load_offsets(uA, hbN, hlN, tbN, tlN, tsN);
-        const int32_t uN = (pos + 4 * step < end) ? order[pos + 4 * step] : -1;
-        uint32_t hvC;
-        int32_t vC;
-        unsigned long long dsC, dtC;
-        load_members(hbC, hlC, tbC, tlC, tsC, hvC, vC, dsC, dtC);
-        if (tlD > 0) {
-            uint32_t c = 0;
-            __builtin_amdgcn_wave_barrier();
-            // hub members: only their bits are needed here (their edges were handed over)
-            if (hvD != 0xFFFFu) atomicOr(&bm[hvD >> 5], 1u << (hvD & 31u));
-            for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
-            fill[lane] = 0;
-            __builtin_amdgcn_wave_barrier();
-            uint32_t slot = 0;
-            if (vD >= 0) {
-                slot = atomicAdd(&fill[bucket_of<64>(vD)], 1u);
-                if (slot < 4) tbl[bucket_of<64>(vD) * 4 + slot] = vD;
+#pragma unroll
+            for (int ka = 0; ka < 4; ++ka) {
+                if (ka >= nat) break;
+                const int ia = sub + 16 * ka;
+                const uint32_t a = ia < tlu ? rows.at[ka] : 0xFFFFFFFFu;
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    if (kb >= nbt) break;
+                    const int ib = sub + 16 * kb;
+                    uint32_t x = ib < tlv ? rows.bt[kb] : 0xFFFFFFFEu;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        c += a == x ? 1u : 0u;
+                        x = ror1_in_row(x);
+                    }
+                }
             }
-            const bool bucketed = __ballot(slot >= 4) == 0;
-            if (!bucketed) {  // rare: some bucket took a fifth key; rebuild as an open-addressing table
-                __builtin_amdgcn_wave_barrier();
-                for (int i = lane; i < SIZE; i += 64) tbl[i] = -1;
-                __builtin_amdgcn_wave_barrier();
-                if (vD >= 0) set_insert(tbl, MASK, SHIFT, vD);
-            }
-            __builtin_amdgcn_wave_barrier();
-            c = scan_srows(bm, spool, dsD, lane);
-            if (bucketed)
-                c += scan_trows_probe([tbl](int32_t w) { return bucket_contains<64>(tbl, w); }, tpool, dtD, tlD, lane);
-            else
-                c += scan_trows_probe([tbl](int32_t w) { return set_contains(tbl, MASK, SHIFT, w); }, tpool, dtD, tlD, lane);
-            cnt += c;
-            __builtin_amdgcn_wave_barrier();
-            if (hvD != 0xFFFFu) bm[hvD >> 5] = 0;  // every bit in this wave's bitmap belongs to this pivot
+            total += c;
+            rec = rec_n;
+            rows = rows_n;
+            rec_n = rec_nn;
         }
-        tlD = tlC; tsD = tsC; hvD = hvC; vD = vC; dsD = dsC; dtD = dtC;
-        hbC = hbB; hlC = hlB; tbC = tbB; tlC = tlB; tsC = tsB;
-        hbB = hbN; hlB = hlN; tbB = tbN; tlB = tlN; tsB = tsN;
-        uA = uN;
     }
-    for (int s = 32; s > 0; s >>= 1) cnt += __shfl_down(cnt, s);
-    if (lane == 0) red[wave] = cnt;
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned long long t = red[0] + red[1] + red[2] + red[3];
-        if (t) atomicAdd(&acc[(blockIdx.x & (kAccSlots - 1)) * kAccStride], t);
-    }
+    block_add(total, red, lane, wave, tid, acc);
 }
 
 // units / probes / algorithmic stream bytes of a shard (untimed bookkeeping for gmsx_stats).  out[2] follows what the count kernels
 // read, byte for byte, assuming no on-chip reuse:
-//   light pivot u (2 <= d+ < 64; k_tc_stats, wave per pivot position): its hub part if it has tail members; per far light member
-//       (rank id >= inline_limit, d+ < 64) the member id, its two descriptors and the stream rows they describe;
+//   light pivot u (2 <= d+ < 64; k_tc_stats, wave per pivot position): per far light member v (rank id >= inline_limit, d+ < 64) the
+//       32-byte edge record and the hub / tail parts of both rows as k_tc_light reads them (u's tail part up to v);
 //   work item (k_tc_item_stats, wave per item): the pivot's container (hub part for a hub item, tail part for a tail item) once; per
 //       entry 8 bytes of descriptor and the stream row it describes (whole 16-byte units) — members' rows, cut rows and inline chunks alike.
 // out[0] = oriented edges counted by the shard: every edge of a light or idle pivot at the pivot, the edges a heavy pivot handed to its
@@ -914,18 +771,16 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
             if (v >= 0 && lane > 0 && (v < inline_limit || dplus[v] >= kHeavy)) ++units;
             continue;
         }
-        const int hl = int(hoff[u + 1] - hoff[u]), tl = int(toff[u + 1] - toff[u]);
-        if (lane == 0) {
-            units += (unsigned long long)du;
-            if (du >= 2 && tl > 0) bytes += 2ull * hl;  // k_tc_wave reads the hub part of every pivot that has tail members
-        }
+        const int hl = int(hoff[u + 1] - hoff[u]);
+        if (lane == 0) units += (unsigned long long)du;
         if (du < 2) continue;
         for (int64_t j = toff[u] + lane; j < toff[u + 1]; j += 64) {
             const int32_t v = tadj[j];
             if (v < inline_limit || dplus[v] >= kHeavy) continue;  // handed over: the ids are in v's inline rows, counted with its items
-            const unsigned long long d = srow[v], t = j > toff[u] ? trow[v] : 0ull;
-            bytes += 16ull * ((d & 0x3fffffull) + (t & 0x3fffffull)) + 20ull;  // the rows + the member id and its descriptors
-            probes += slots(d, false) + slots(t, true);
+            // a light edge (k_tc_light): its 32-byte record, both parts of u's row (the tail part up to v) and of v's row
+            const unsigned long long hv = (unsigned long long)(hoff[v + 1] - hoff[v]), tv = (unsigned long long)(toff[v + 1] - toff[v]);
+            bytes += 32ull + 2ull * hl + 4ull * (unsigned long long)(j - toff[u]) + 2ull * hv + 4ull * tv;
+            probes += hv + tv;  // v's ids, each compared with u's
         }
     }
     for (int s = 32; s > 0; s >>= 1) {
@@ -978,9 +833,9 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
 //   out[3..4]  tail stream rows named by the entries (32-bit list, 16-bit delta)
 //   out[5]     the entries themselves (8 bytes each)          out[6]  the pivots' own containers (hub part per hub item, tail part per tail item)
 //   out[7]     of out[0] + out[3]: inline rows (ids handed over by light pivots; filled in by the host from the build's figures)
-//   out[8..9]  light pivots: hub / tail stream rows of their far light members (k_tc_wave)
-//   out[10]    light pivots: their own hub parts + member ids + descriptors (k_tc_wave)
-//   out[11..14] counts: entries, inline entries, work items, far light members streamed by k_tc_wave
+//   out[8..9]  light edges (k_tc_light): hub / tail parts of the far light members' rows
+//   out[10]    light edges: the 32-byte records + the pivots' own hub / tail parts (once per edge)
+//   out[11..14] counts: entries, inline entries, work items, light edges
 //   out[15..20] reserved (0)
 __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict__ hoff, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                       const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
@@ -1016,13 +871,13 @@ __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict_
     for (int64_t pos = first_light + wave0; pos < end_light; pos += nwaves) {
         const int32_t u = order[pos];
         const int64_t tb0 = toff[u], te = toff[u + 1];
-        if (lane == 0 && te > tb0) c[10] += 2ull * (unsigned long long)(hoff[u + 1] - hoff[u]);
+        const unsigned long long hl = (unsigned long long)(hoff[u + 1] - hoff[u]);
         for (int64_t j = tb0 + lane; j < te; j += 64) {
             const int32_t v = tadj[j];
             if (v < inline_limit || dplus[v] >= kHeavy) continue;
-            c[8] += 16ull * (srow[v] & 0x3fffffull);
-            if (j > tb0) c[9] += 16ull * (trow[v] & 0x3fffffull);
-            c[10] += 20;
+            c[8] += 2ull * (unsigned long long)(hoff[v + 1] - hoff[v]);
+            c[9] += 4ull * (unsigned long long)(toff[v + 1] - toff[v]);
+            c[10] += 32ull + 2ull * hl + 4ull * (unsigned long long)(j - tb0);
             c[14] += 1;
         }
     }
@@ -1175,25 +1030,19 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     int launches = 0;
     const int cus = c.compute_units > 0 ? c.compute_units : 256;
     const int64_t cap_blocks = int64_t(cus) * 16;
-    const int64_t cnt_light = [&] {
-        const char *only = std::getenv("GMSX_TC_ONLY");
-        return only && std::strcmp(only, "light") != 0 ? int64_t(0) : part_count(0, g->n_wave, nparts, part);
-    }();
-    // CO-SCHEDULING.  The hub-item kernel is bound by HBM bandwidth and VALU issue, the tail-item kernel streams short rows, the light-pivot
-    // kernel (short rows behind dependent loads) is bound by memory latency: back to back each leaves what the others need idle and pays
-    // its own drain.  So the light kernel goes to a side stream FIRST, as a persistent grid of a few workgroups per CU, the tail items to
-    // a second side stream, and the hub items fill the remaining wave slots and LDS of every CU.  GMSX_TC_OVERLAP=0 restores the serial
-    // order (full-width light grid), 2 forces co-scheduling of the light kernel on small graphs.
-    const int overlap = [] { const char *e = std::getenv("GMSX_TC_OVERLAP"); return e ? std::atoi(e) : 1; }();
-    const bool large = g->inline_limit > g->dense_limit;  // n >= 2^24: inline limit beyond the hub range
-    const int wave_wgs = [large] { const char *e = std::getenv("GMSX_TC_WAVE_WGS"); return e ? std::max(1, std::atoi(e)) : (large ? 1 : 2); }();
-    // measured (MI355X, round 2): scale 26 serial 86.4 ms, co-scheduled 84.6 (2 workgroups per CU) / 82.9 (1); scale 24 15.05 / 14.45 (2) /
-    // erratic (1); scale 22 3.56 serial, 4.45 co-scheduled.  So the light kernel moves aside from 2^23 vertices on.
+    const char *only = std::getenv("GMSX_TC_ONLY");
+    const bool run_light = !only || std::strcmp(only, "light") == 0;
+    // the light edges of this call: a full upload holds every edge (shard = e % nparts), a sharded one its own, densely
+    const bool strided = nparts > 1 && g->shard_nparts == 1;
+    const int64_t cnt_light = !run_light ? 0 : strided ? (g->n_ledge > part ? (g->n_ledge - part + nparts - 1) / nparts : 0) : g->n_ledge;
+    // LAUNCH PLAN (round 4).  k_tc_items — one persistent launch over the hub and the tail items — then k_tc_light, both on the launch stream.
+    // GMSX_TC_OVERLAP=1 puts k_tc_light on a side stream behind the item kernel (its workgroups need no LDS and start wherever a persistent
+    // workgroup has left): measured 72.0-72.4 ms against 71.3-71.6 one after the other at scale 26 — the items kernel is bound by memory and
+    // the light edges are 10 GB of it — and beside it from the start 72-80.  GMSX_TC_PERSIST=0 (A/B): rounds 2-3's one-workgroup-per-item
+    // kernels (with GMSX_TC_OVERLAP=1 the tail items on a side stream of their own).
+    const int overlap = [] { const char *e = std::getenv("GMSX_TC_OVERLAP"); return e ? std::atoi(e) : 0; }();
+    const int persist = [] { const char *e = std::getenv("GMSX_TC_PERSIST"); return e ? std::atoi(e) : 1; }();
     const bool sides = overlap && c.side[0] && c.side[1];
-    const bool co_wave = sides && n_hitems > 0 && cnt_light > 0 && (overlap > 1 || g->n >= (int64_t(1) << 23));
-    const int tail_mode = [] { const char *e = std::getenv("GMSX_TC_TAIL"); return e ? std::atoi(e) : 1; }();  // A/B: 0 = tail items behind the hub items on the launch stream, 2 = before them
-    const bool co_tail = sides && n_hitems > 0 && n_titems > 0 && tail_mode == 1;
-    hipStream_t s_wave = co_wave ? c.side[1] : s, s_tail = co_tail ? c.side[0] : s;
     struct Join {  // joins the side streams on every way out once they were forked (error returns included)
         Ctx &c;
         hipStream_t s;
@@ -1203,23 +1052,18 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
                 if (armed[i] && hipEventRecord(c.ev_join[i], c.side[i]) == hipSuccess) (void)hipStreamWaitEvent(s, c.ev_join[i], 0);
         }
     } join{c, s};
-    const int persist = [] { const char *e = std::getenv("GMSX_TC_PERSIST"); return e ? std::atoi(e) : 1; }();  // A/B: 0 = one workgroup per item (rounds 2-3)
+    const bool side_light = sides && cnt_light > 0 && n_hitems + n_titems > 0;
+    const bool side_tail = sides && !persist && n_hitems > 0 && n_titems > 0;
+    if (side_light || side_tail) GMSX_HIP(hipEventRecord(c.ev_fork, s));
+    if (side_tail) {
+        GMSX_HIP(hipStreamWaitEvent(c.side[0], c.ev_fork, 0));
+        join.armed[0] = true;
+    }
+    if (side_light) {
+        GMSX_HIP(hipStreamWaitEvent(c.side[1], c.ev_fork, 0));
+        join.armed[1] = true;
+    }
     if (persist) {
-        // ONE persistent launch walks the hub and the tail items (k_tc_items); the light-pivot kernel goes beside it as before
-        const bool co = sides && cnt_light > 0 && n_hitems + n_titems > 0 && (overlap > 1 || g->n >= (int64_t(1) << 23));
-        if (co) {
-            GMSX_HIP(hipEventRecord(c.ev_fork, s));
-            GMSX_HIP(hipStreamWaitEvent(c.side[1], c.ev_fork, 0));
-            join.armed[1] = true;
-        }
-        auto launch_light = [&](hipStream_t sw, bool beside) {
-            if (cnt_light <= 0) return;
-            const int64_t b_wave = std::min<int64_t>((cnt_light + 3) / 4, beside ? int64_t(cus) * wave_wgs : cap_blocks);
-            hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(b_wave)), dim3(256), 0, sw, g->hoff, g->hadj, g->spool, g->tpool, g->tdesc, g->toff, g->tadj,
-                               g->tsplit, g->worder, int64_t(0), g->n_wave, nparts, part, acc);
-            ++launches;
-        };
-        if (co) launch_light(c.side[1], true);
         if (n_hitems + n_titems > 0) {
             static const int share_env = [] { const char *e = std::getenv("GMSX_TC_TAIL_SHARE"); return e ? std::atoi(e) : -1; }();
             static const int wgs_env = [] { const char *e = std::getenv("GMSX_TC_ITEM_WGS"); return e ? std::atoi(e) : 8; }();
@@ -1231,57 +1075,21 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
                                titem, int(n_titems), tail_share, qhead, acc);
             ++launches;
         }
-        if (!co) launch_light(s, false);
-    } else if (tail_mode == 3 && sides && n_hitems > 0) {
-        // A/B: the hub items ALONE first (they run at 7 TB/s by themselves), then the tail items on the launch stream with the light pivots
-        // beside them (neither of the two is bandwidth-bound)
-        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(n_hitems)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->htask, hitem, acc);
-        ++launches;
-        GMSX_HIP(hipEventRecord(c.ev_fork, s));
-        GMSX_HIP(hipStreamWaitEvent(c.side[1], c.ev_fork, 0));
-        join.armed[1] = true;
-        if (cnt_light > 0) {
-            const int64_t b_wave = std::min<int64_t>((cnt_light + 3) / 4, int64_t(cus) * 4);
-            hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(b_wave)), dim3(256), 0, c.side[1], g->hoff, g->hadj, g->spool, g->tpool, g->tdesc, g->toff, g->tadj,
-                               g->tsplit, g->worder, int64_t(0), g->n_wave, nparts, part, acc);
+    } else {
+        if (n_hitems > 0) {
+            hipLaunchKernelGGL(k_tc_block, dim3(unsigned(n_hitems)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->htask, hitem, acc);
             ++launches;
         }
         if (n_titems > 0) {
-            hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, s, g->toff, g->tadj, g->tpool, g->ttask, titem, acc);
+            hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, side_tail ? c.side[0] : s, g->toff, g->tadj, g->tpool, g->ttask, titem, acc);
             ++launches;
         }
-    } else {
-    if (co_wave || co_tail) GMSX_HIP(hipEventRecord(c.ev_fork, s));
-    if (co_tail) {
-        GMSX_HIP(hipStreamWaitEvent(c.side[0], c.ev_fork, 0));
-        join.armed[0] = true;
     }
-    if (co_wave) {
-        GMSX_HIP(hipStreamWaitEvent(c.side[1], c.ev_fork, 0));
-        join.armed[1] = true;
-    }
-    auto launch_light = [&]() {
-        if (cnt_light <= 0) return;
-        const int64_t want = (cnt_light + 3) / 4;
-        const int64_t b_wave = std::min<int64_t>(want, co_wave ? int64_t(cus) * wave_wgs : cap_blocks);
-        hipLaunchKernelGGL(k_tc_wave, dim3(unsigned(b_wave)), dim3(256), 0, s_wave, g->hoff, g->hadj, g->spool, g->tpool, g->tdesc, g->toff, g->tadj,
-                           g->tsplit, g->worder, int64_t(0), g->n_wave, nparts, part, acc);
+    if (cnt_light > 0) {
+        const int64_t blocks = std::min<int64_t>((cnt_light + 15) / 16, int64_t(cus) * 8);
+        hipLaunchKernelGGL(k_tc_light, dim3(unsigned(blocks)), dim3(256), 0, side_light ? c.side[1] : s, g->hadj, g->tadj, g->ledge, int64_t(strided ? part : 0),
+                           int64_t(strided ? nparts : 1), cnt_light, acc);
         ++launches;
-    };
-    if (co_wave) launch_light();
-    if (n_titems > 0 && tail_mode == 2) {
-        hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, s, g->toff, g->tadj, g->tpool, g->ttask, titem, acc);
-        ++launches;
-    }
-    if (n_hitems > 0) {
-        hipLaunchKernelGGL(k_tc_block, dim3(unsigned(n_hitems)), dim3(256), 0, s, g->hoff, g->hadj, g->spool, g->htask, hitem, acc);
-        ++launches;
-    }
-    if (n_titems > 0 && tail_mode != 2) {
-        hipLaunchKernelGGL(k_tc_tail, dim3(unsigned(n_titems)), dim3(256), 0, s_tail, g->toff, g->tadj, g->tpool, g->ttask, titem, acc);
-        ++launches;
-    }
-    if (!co_wave) launch_light();
     }
     for (int i = 0; i < 2; ++i)
         if (join.armed[i]) {

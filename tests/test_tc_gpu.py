@@ -190,7 +190,7 @@ def test_tail_bucket_overflow(gpu, oracle):
 @pytest.mark.parametrize("hub_limit,inline_limit", [(16, 0), (16, 40), (16, 700), (16, 10 ** 6), (300, 301), (300, 4000), (0, 3000)])
 def test_inline_limit(gpu, oracle, hub_limit, inline_limit):
     """Light pivots hand the edges to their heavy members and to members of rank id < inline_limit over as inline rows (the members
-    below v copied next to v, scanned by v's work items); only far light members stay with k_tc_wave.  Any limit gives the same
+    below v copied next to v, scanned by v's work items); only the edges to far light members stay behind (k_tc_light).  Any limit gives the same
     counts — for the triangle kernels and for the k-clique / Bron–Kerbosch kernels that share the containers."""
     old = os.environ.get("GMSX_INLINE_LIMIT")
     os.environ["GMSX_INLINE_LIMIT"] = str(inline_limit)
@@ -215,15 +215,16 @@ def test_inline_limit(gpu, oracle, hub_limit, inline_limit):
 
 
 @pytest.mark.parametrize("knobs", [{"GMSX_TC_TWO_SIDED": "0"}, {"GMSX_TC_TWO_SIDED": "0", "GMSX_INLINE_LIMIT": "0"},
-                                   {"GMSX_TC_OVERLAP": "0"}, {"GMSX_TC_OVERLAP": "2"}, {"GMSX_TC_GAP12": "0"}, {"GMSX_TC_GAP12": "2"},
+                                   {"GMSX_TC_OVERLAP": "1"}, {"GMSX_TC_PERSIST": "0"}, {"GMSX_TC_PERSIST": "0", "GMSX_TC_OVERLAP": "1"},
+                                   {"GMSX_TC_TAIL_SHARE": "0"}, {"GMSX_TC_TAIL_SHARE": "8"}, {"GMSX_TC_ITEM_WGS": "1"}, {"GMSX_TC_GAP12": "0"}, {"GMSX_TC_GAP12": "2"},
                                    {"GMSX_TC_GAP12": "2", "GMSX_TC_DELTA": "0"}, {"GMSX_TC_HYBRID": "1"}, {"GMSX_TC_HYBRID": "2"},
-                                   {"GMSX_TC_HYBRID": "2", "GMSX_TC_DELTA": "0"}, {"GMSX_TC_TAIL": "0"}, {"GMSX_TC_TAIL": "2"}])
+                                   {"GMSX_TC_HYBRID": "2", "GMSX_TC_DELTA": "0"}])
 def test_task_list_knobs(gpu, oracle, knobs):
     """Every oriented edge is counted at exactly one endpoint: at the pivot that keeps it (forward entry), at the member it was handed
     to because the member's row is the bigger one (reverse entry, cut at the member's id), or inside the member's inline rows.  With
-    the hand-over off, the task lists unsorted, the kernels serial / always co-scheduled, or the sparse rows without / all in the
-    12-bit-gap form, heavy rows split into a prefix bitmap + the rest (GMSX_TC_HYBRID), the tail items behind / before the hub items
-    on the launch stream, the count and the bookkeeping stay."""
+    the hand-over off, the light-edge kernel on a side stream, the one-workgroup-per-item kernels of rounds 2-3 instead of the persistent
+    one, every persistent workgroup starting on the hub / on the tail queue, one workgroup per CU, or the sparse rows without / all in
+    the 12-bit-gap form, heavy rows split into a prefix bitmap + the rest (GMSX_TC_HYBRID), the count and the bookkeeping stay."""
     old = {k: os.environ.get(k) for k in knobs}
     os.environ.update(knobs)
     try:
