@@ -9,14 +9,16 @@
 //   verifiers    triangle_count/verifier.h:13-85 (serial host recount), maximal_clique_enum/verifier.h:41-49 (sequential Tomita
 //                recount): `-v` recounts ON THE HOST with this file's own plain loops (not the device, not oracle/) for graphs up
 //                to a stated size; beyond it the check is a differently decomposed device run and the output says so.
-// Added:  --gpus N   one process per GPU (this binary re-launches itself N times before touching HIP), every rank counts its
+// Added:  --gpus N   one process per GPU (this binary FORKS its N ranks before it touches HIP and stays behind as their supervisor), every rank counts its
 //                    shard (gmsx_*_partial) and ONE u64 all-reduce over RCCL (gmsx_comm_allreduce_u64) replaces the OpenMP
 //                    reduction(+:total) of parallel/total.h:12.  --gpus 1 runs the same path with a 1-rank communicator.
 // Usage:  gmsx_driver <tc|vertex|kclique|bk> [reference flags] [--gpus N]     e.g.  gmsx_driver tc -g kronecker 20 --deg 16 -n 3 -v
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <csignal>
 #include <cinttypes>
@@ -213,13 +215,17 @@ constexpr int64_t kHostKcEdges = 1000000, kHostBkEdges = 60000;
 // Under a profiler preload (rocprofv3 …) the tool library has initialised the GPU in THIS process already, and a forked child of a
 // process with a live HIP runtime cannot use the GPU: refused with a message.  Profile one rank at a time instead, no launcher hop:
 //   GMSX_DRIVER_RANK=r GMSX_DRIVER_NRANKS=N GMSX_DRIVER_ID_FILE=/tmp/id rocprofv3 … -- gmsx_driver <args without --gpus>
+// (Only what actually puts a tool library into THIS process counts: an LD_PRELOAD entry, or the tool list rocprofv3 exports for the
+// rocprofiler-register hook — a user's own ROCPROF_* / ROCP_* configuration variables alone do not.)
 bool profiler_preloaded() {
     const char *pre = std::getenv("LD_PRELOAD");
     if (pre && (std::strstr(pre, "rocprof") || std::strstr(pre, "roctracer") || std::strstr(pre, "rocprofiler"))) return true;
-    for (char **e = environ; e && *e; ++e)
-        if (!std::strncmp(*e, "ROCPROFILER_", 12) || !std::strncmp(*e, "ROCPROF_", 8) || !std::strncmp(*e, "ROCP_", 5)) return true;
-    return false;
+    const char *tools = std::getenv("ROCP_TOOL_LIBRARIES");
+    return tools && *tools;
 }
+// the supervisor's SIGTERM / SIGINT (a `timeout`, a scheduler cancel, Ctrl-C): taken note of here, acted on in the reaping loop
+volatile std::sig_atomic_t g_stop_signal = 0;
+extern "C" void on_stop_signal(int sig) { g_stop_signal = sig; }
 
 int launch_ranks(int gpus) {
     if (profiler_preloaded()) {
@@ -249,23 +255,42 @@ int launch_ranks(int gpus) {
             return 4;
         }
         if (pid == 0) {  // rank r: carry on in main()
+            prctl(PR_SET_PDEATHSIG, SIGTERM);  // … and never outlive the supervisor (SIGKILLed, say): a rank blocked in RCCL holds its GPU for good
+            if (getppid() == 1) _exit(4);      // (it died between fork and prctl)
             setenv("GMSX_DRIVER_RANK", std::to_string(r).c_str(), 1);
             setenv("GMSX_DRIVER_NRANKS", std::to_string(gpus).c_str(), 1);
             setenv("GMSX_DRIVER_ID_FILE", idfile, 1);
             // one node by construction: keep RCCL's bootstrap off the (possibly absent) external network unless the user chose otherwise
             setenv("NCCL_SOCKET_IFNAME", "lo", 0);
             setenv("NCCL_IB_DISABLE", "1", 0);
+            if (std::getenv("GMSX_DRIVER_TEST_HANG")) pause();  // test hook: a rank that never finishes (as one blocked in a collective would)
             return -1;
         }
         kids.push_back(pid);
     }
+    // a stop signal to the supervisor goes on to the ranks (no SA_RESTART: the blocking waitpid returns EINTR and the loop sees the flag)
+    struct sigaction sa {};
+    sa.sa_handler = on_stop_signal;
+    sigemptyset(&sa.sa_mask);
+    sigaction(SIGTERM, &sa, nullptr);
+    sigaction(SIGINT, &sa, nullptr);
     int worst = 0, alive = gpus;
     bool killing = false;
     auto t_kill = std::chrono::steady_clock::now();
     while (alive > 0) {
+        if (g_stop_signal && !killing) {
+            std::fprintf(stderr, "gmsx_driver --gpus: signal %d; stopping the %d rank(s)\n", int(g_stop_signal), alive);
+            worst = 128 + int(g_stop_signal);
+            killing = true;
+            t_kill = std::chrono::steady_clock::now();
+            kill_rest(SIGTERM);
+        }
         int st = 0;
         const pid_t k = waitpid(-1, &st, killing ? WNOHANG : 0);
-        if (k < 0) break;  // no children left
+        if (k < 0) {
+            if (errno == EINTR) continue;  // a stop signal arrived while waiting
+            break;                         // no children left
+        }
         if (k == 0) {      // tearing down: give SIGTERM two seconds, then SIGKILL
             if (std::chrono::steady_clock::now() - t_kill > std::chrono::seconds(2)) kill_rest(SIGKILL);
             std::this_thread::sleep_for(std::chrono::milliseconds(20));

@@ -1474,9 +1474,11 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
     g_tmp.p = tmp;
     GMSX_HIP(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, k_in, k_out, v_in, v_out, size_t(n), 0, 64, s));
-    std::vector<unsigned long long> words(static_cast<size_t>(n));
+    std::unique_ptr<unsigned long long[]> words_mem(new (std::nothrow) unsigned long long[static_cast<size_t>(n > 0 ? n : 1)]);  // 1 GB at scale 27
+    if (!words_mem) return GMSX_ERR_NOMEM;
+    unsigned long long *const words = words_mem.get();
     unsigned long long head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    GMSX_HIP(hipMemcpyAsync(words.data(), k_out, size_t(n) * 8, hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipMemcpyAsync(words, k_out, size_t(n) * 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipMemcpyAsync(head, acc + kCtl, sizeof(head), hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     const int64_t n_giant = int64_t(head[1]);    // start vertices beyond the register-resident width: memory-resident search after the rounds
@@ -1890,40 +1892,39 @@ using namespace gmsx;
 extern "C" {
 
 int gmsx_bk_partial(const gmsx_graph *g, const int32_t *rank, int part, int nparts, uint64_t *partial, gmsx_stats *stats) {
-    if (!g || !partial || nparts < 1 || part < 0 || part >= nparts) return GMSX_ERR_INVALID;
-    // `rank` is what the reference's drivers hand from the preprocessing step to mceBench(graph, ordering).  The number of
-    // maximal cliques does not depend on it and the device splits by its own degree rank, so it is validated
-    // (a permutation of 0..n-1, as every rank-format ordering is) and otherwise not needed.
-    // No exception may cross the C ABI: the scratch bitmap is a nothrow allocation.  A (pointer, first/last value) memo on the handle
-    // skips the O(n) pass when the same array comes back (every shard call and every trial of a harness hands the same ordering).
-    if (rank && !(g->rank_ok_ptr == rank && g->n > 0 && g->rank_ok_first == rank[0] && g->rank_ok_last == rank[g->n - 1])) {
-        const int64_t n = g->n;
-        const size_t words = size_t((n + 63) / 64 + 1);
-        uint64_t *seen = new (std::nothrow) uint64_t[words]();
-        if (!seen) return GMSX_ERR_NOMEM;
-        bool ok = true;
-        for (int64_t i = 0; i < n && ok; ++i) {
-            const int64_t r = rank[i];
-            if (r < 0 || r >= n) { ok = false; break; }
-            uint64_t &w = seen[size_t(r >> 6)];
-            const uint64_t bit = 1ull << (r & 63);
-            if (w & bit) ok = false;
-            w |= bit;
+    return gmsx::guard([&]() -> int {
+        if (!g || !partial || nparts < 1 || part < 0 || part >= nparts) return GMSX_ERR_INVALID;
+        // `rank` is what the reference's drivers hand from the preprocessing step to mceBench(graph, ordering).  The number of
+        // maximal cliques does not depend on it and the device splits by its own degree rank, so it is validated
+        // (a permutation of 0..n-1, as every rank-format ordering is) and otherwise not needed.
+        // No exception may cross the C ABI: the scratch bitmap is a nothrow allocation.  Validated on EVERY call (an O(n) pass next to an
+        // enumeration): a memo keyed on the pointer would accept an array that was changed, or another one at the same address.
+        if (rank) {
+            const int64_t n = g->n;
+            const size_t words = size_t((n + 63) / 64 + 1);
+            uint64_t *seen = new (std::nothrow) uint64_t[words]();
+            if (!seen) return GMSX_ERR_NOMEM;
+            bool ok = true;
+            for (int64_t i = 0; i < n && ok; ++i) {
+                const int64_t r = rank[i];
+                if (r < 0 || r >= n) { ok = false; break; }
+                uint64_t &w = seen[size_t(r >> 6)];
+                const uint64_t bit = 1ull << (r & 63);
+                if (w & bit) ok = false;
+                w |= bit;
+            }
+            delete[] seen;
+            if (!ok) return GMSX_ERR_INVALID;
         }
-        delete[] seen;
-        if (!ok) return GMSX_ERR_INVALID;
-        if (n > 0) {
-            g->rank_ok_ptr = rank;
-            g->rank_ok_first = rank[0];
-            g->rank_ok_last = rank[n - 1];
-        }
-    }
-    if (int rc = ensure_init()) return rc;
-    return bk_partial(g, part, nparts, partial, stats);
+        if (int rc = ensure_init()) return rc;
+        return bk_partial(g, part, nparts, partial, stats);
+    });
 }
 
 int gmsx_bk_count(const gmsx_graph *g, const int32_t *rank, uint64_t *maximal_cliques, gmsx_stats *stats) {
-    return gmsx_bk_partial(g, rank, 0, 1, maximal_cliques, stats);
+    return gmsx::guard([&]() -> int {
+        return gmsx_bk_partial(g, rank, 0, 1, maximal_cliques, stats);
+    });
 }
 
 }  // extern "C"

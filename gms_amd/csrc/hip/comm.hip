@@ -61,58 +61,66 @@ using namespace gmsx;
 extern "C" {
 
 int gmsx_comm_unique_id(void *id) {
-    if (!id) return GMSX_ERR_INVALID;
-    if (!rccl().ok) return GMSX_ERR_COMM;
-    ncclUniqueId u;
-    if (rccl().GetUniqueId(&u) != kNcclSuccess) return GMSX_ERR_COMM;
-    std::memcpy(id, &u, sizeof(u));
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (!id) return GMSX_ERR_INVALID;
+        if (!rccl().ok) return GMSX_ERR_COMM;
+        ncclUniqueId u;
+        if (rccl().GetUniqueId(&u) != kNcclSuccess) return GMSX_ERR_COMM;
+        std::memcpy(id, &u, sizeof(u));
+        return GMSX_OK;
+    });
 }
 
 int gmsx_comm_init(int rank, int nranks, const void *id, gmsx_comm **out) {
-    if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) return GMSX_ERR_INVALID;
-    if (int rc = ensure_init()) return rc;  // the communicator lives on the device this process is bound to (gmsx_init)
-    if (!rccl().ok) return GMSX_ERR_COMM;
-    gmsx_comm *c = new (std::nothrow) gmsx_comm;
-    if (!c) return GMSX_ERR_NOMEM;
-    c->rank = rank;
-    c->nranks = nranks;
-    if (hipMalloc(reinterpret_cast<void **>(&c->buf), 16) != hipSuccess) {
-        (void)hipGetLastError();
-        delete c;
-        return GMSX_ERR_DEVICE_MEM;
-    }
-    ncclUniqueId u;
-    std::memcpy(&u, id, sizeof(u));
-    if (rccl().CommInitRank(&c->comm, nranks, u, rank) != kNcclSuccess) {
-        (void)hipFree(c->buf);
-        delete c;
-        return GMSX_ERR_COMM;
-    }
-    *out = c;
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (!out || !id || nranks < 1 || rank < 0 || rank >= nranks) return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;  // the communicator lives on the device this process is bound to (gmsx_init)
+        if (!rccl().ok) return GMSX_ERR_COMM;
+        gmsx_comm *c = new (std::nothrow) gmsx_comm;
+        if (!c) return GMSX_ERR_NOMEM;
+        c->rank = rank;
+        c->nranks = nranks;
+        if (hipMalloc(reinterpret_cast<void **>(&c->buf), 16) != hipSuccess) {
+            (void)hipGetLastError();
+            delete c;
+            return GMSX_ERR_DEVICE_MEM;
+        }
+        ncclUniqueId u;
+        std::memcpy(&u, id, sizeof(u));
+        if (rccl().CommInitRank(&c->comm, nranks, u, rank) != kNcclSuccess) {
+            (void)hipFree(c->buf);
+            delete c;
+            return GMSX_ERR_COMM;
+        }
+        *out = c;
+        return GMSX_OK;
+    });
 }
 
 int gmsx_comm_allreduce_u64(gmsx_comm *c, uint64_t *value) {
-    if (!c || !value) return GMSX_ERR_INVALID;
-    hipStream_t s = ctx().stream;
-    GMSX_HIP(hipMemcpyAsync(c->buf, value, sizeof(uint64_t), hipMemcpyHostToDevice, s));
-    if (rccl().AllReduce(c->buf, c->buf, 1, kNcclUint64, kNcclSum, c->comm, s) != kNcclSuccess) return GMSX_ERR_COMM;
-    GMSX_HIP(hipMemcpyAsync(value, c->buf, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    GMSX_HIP(hipStreamSynchronize(s));
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (!c || !value) return GMSX_ERR_INVALID;
+        hipStream_t s = ctx().stream;
+        GMSX_HIP(hipMemcpyAsync(c->buf, value, sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        if (rccl().AllReduce(c->buf, c->buf, 1, kNcclUint64, kNcclSum, c->comm, s) != kNcclSuccess) return GMSX_ERR_COMM;
+        GMSX_HIP(hipMemcpyAsync(value, c->buf, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        return GMSX_OK;
+    });
 }
 
 int gmsx_comm_rank(const gmsx_comm *c) { return c ? c->rank : GMSX_ERR_INVALID; }
 int gmsx_comm_size(const gmsx_comm *c) { return c ? c->nranks : GMSX_ERR_INVALID; }
 
 int gmsx_comm_finalize(gmsx_comm *c) {
-    if (!c) return GMSX_OK;
-    int rc = GMSX_OK;
-    if (c->comm && rccl().ok && rccl().CommDestroy(c->comm) != kNcclSuccess) rc = GMSX_ERR_COMM;
-    (void)hipFree(c->buf);
-    delete c;
-    return rc;
+    return gmsx::guard([&]() -> int {
+        if (!c) return GMSX_OK;
+        int rc = GMSX_OK;
+        if (c->comm && rccl().ok && rccl().CommDestroy(c->comm) != kNcclSuccess) rc = GMSX_ERR_COMM;
+        (void)hipFree(c->buf);
+        delete c;
+        return rc;
+    });
 }
 
 }  // extern "C"

@@ -1051,9 +1051,15 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
 
     // 1. invariant check + Σ(d_u+d_v) + max degree
     const int check_sym = (flags & GMSX_UPLOAD_TRUSTED) ? 0 : 1;
-    static const std::array<unsigned long long, 2> sym_keys = [] {  // per-process keys of the symmetry hashes: no fixed input collides in every process
-        std::random_device rd;
-        return std::array<unsigned long long, 2>{((unsigned long long)rd() << 32) | rd(), ((unsigned long long)rd() << 32) | rd()};
+    static const std::array<unsigned long long, 2> sym_keys = []() noexcept {  // per-process keys of the symmetry hashes: no fixed input collides in every process
+        try {
+            std::random_device rd;  // (may throw where no entropy source is reachable)
+            return std::array<unsigned long long, 2>{((unsigned long long)rd() << 32) | rd(), ((unsigned long long)rd() << 32) | rd()};
+        } catch (...) {  // fallback: clock + address-space layout — still different from process to process
+            const unsigned long long t = (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count();
+            const unsigned long long a = (unsigned long long)reinterpret_cast<uintptr_t>(&t);
+            return std::array<unsigned long long, 2>{t * 0x9E3779B97F4A7C15ull ^ a, (a * 0xC2B2AE3D27D4EB4Full) ^ (t << 17)};
+        }
     }();
     if (n > 0)
         hipLaunchKernelGGL(k_validate, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->off, g->adj, check_sym, sym_keys[0], sym_keys[1], g->scratch);
@@ -1619,118 +1625,134 @@ using namespace gmsx;
 extern "C" {
 
 int gmsx_init(int device) {
-    Ctx &c = ctx();
-    int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
-        (void)hipGetLastError();
-        return GMSX_ERR_NO_DEVICE;
-    }
-    if (device < 0) {
-        if (hipGetDevice(&device) != hipSuccess) return GMSX_ERR_NO_DEVICE;
-    }
-    if (device >= count) return GMSX_ERR_INVALID;
-    // one device per process (one process per GPU): the library's stream, events and every graph handle live on the first
-    // device bound; re-binding to another one is refused rather than silently launching on a foreign stream
-    if (c.device >= 0 && c.device != device) return GMSX_ERR_UNSUPPORTED;
-    if (hipSetDevice(device) != hipSuccess) return GMSX_ERR_NO_DEVICE;  // also makes the device current for a new host thread
-    if (c.device == device) return GMSX_OK;
-    if (!c.own_stream) {
-        if (hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking) != hipSuccess) return GMSX_ERR_NO_DEVICE;
-        for (auto &e : c.ev)
-            if (hipEventCreate(&e) != hipSuccess) return GMSX_ERR_NO_DEVICE;
-        for (auto &st : c.side)
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return GMSX_ERR_NO_DEVICE;
-        if (hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess) return GMSX_ERR_NO_DEVICE;
-        for (auto &e : c.ev_join)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return GMSX_ERR_NO_DEVICE;
-    }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GMSX_ERR_NO_DEVICE;
-    c.compute_units = prop.multiProcessorCount;
-    c.stream = c.own_stream;
-    c.device = device;
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        Ctx &c = ctx();
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+            (void)hipGetLastError();
+            return GMSX_ERR_NO_DEVICE;
+        }
+        if (device < 0) {
+            if (hipGetDevice(&device) != hipSuccess) return GMSX_ERR_NO_DEVICE;
+        }
+        if (device >= count) return GMSX_ERR_INVALID;
+        // one device per process (one process per GPU): the library's stream, events and every graph handle live on the first
+        // device bound; re-binding to another one is refused rather than silently launching on a foreign stream
+        if (c.device >= 0 && c.device != device) return GMSX_ERR_UNSUPPORTED;
+        if (hipSetDevice(device) != hipSuccess) return GMSX_ERR_NO_DEVICE;  // also makes the device current for a new host thread
+        if (c.device == device) return GMSX_OK;
+        if (!c.own_stream) {
+            if (hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking) != hipSuccess) return GMSX_ERR_NO_DEVICE;
+            for (auto &e : c.ev)
+                if (hipEventCreate(&e) != hipSuccess) return GMSX_ERR_NO_DEVICE;
+            for (auto &st : c.side)
+                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return GMSX_ERR_NO_DEVICE;
+            if (hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess) return GMSX_ERR_NO_DEVICE;
+            for (auto &e : c.ev_join)
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return GMSX_ERR_NO_DEVICE;
+        }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GMSX_ERR_NO_DEVICE;
+        c.compute_units = prop.multiProcessorCount;
+        c.stream = c.own_stream;
+        c.device = device;
+        return GMSX_OK;
+    });
 }
 
 int gmsx_set_stream(void *hip_stream) {
-    if (int rc = ensure_init()) return rc;
-    ctx().stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx().own_stream;
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (int rc = ensure_init()) return rc;
+        ctx().stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx().own_stream;
+        return GMSX_OK;
+    });
 }
 
 int gmsx_device_info(char *name, size_t name_len, int *compute_units, int64_t *hbm_bytes) {
-    if (int rc = ensure_init()) return rc;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx().device) != hipSuccess) return GMSX_ERR_NO_DEVICE;
-    if (name && name_len) {
-        std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
-    }
-    if (compute_units) *compute_units = prop.multiProcessorCount;
-    if (hbm_bytes) *hbm_bytes = int64_t(prop.totalGlobalMem);
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (int rc = ensure_init()) return rc;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx().device) != hipSuccess) return GMSX_ERR_NO_DEVICE;
+        if (name && name_len) {
+            std::snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+        }
+        if (compute_units) *compute_units = prop.multiProcessorCount;
+        if (hbm_bytes) *hbm_bytes = int64_t(prop.totalGlobalMem);
+        return GMSX_OK;
+    });
 }
 
 int gmsx_graph_upload(int64_t n, const int64_t *offsets, const int32_t *neigh, uint32_t flags, gmsx_graph **out) {
-    return gmsx_graph_upload_shard(n, offsets, neigh, flags, 0, 1, out);
+    return gmsx::guard([&]() -> int {
+        return gmsx_graph_upload_shard(n, offsets, neigh, flags, 0, 1, out);
+    });
 }
 
 int gmsx_graph_upload_shard(int64_t n, const int64_t *offsets, const int32_t *neigh, uint32_t flags, int part, int nparts, gmsx_graph **out) {
-    if (!out || n < 0 || !offsets || n > 0x7fffffffll || nparts < 1 || part < 0 || part >= nparts) return GMSX_ERR_INVALID;
-    if (offsets[0] != 0 || offsets[n] < 0 || (offsets[n] > 0 && !neigh)) return GMSX_ERR_INVALID;
-    if (int rc = ensure_init()) return rc;
-    gmsx_graph *g = new (std::nothrow) gmsx_graph;
-    if (!g) return GMSX_ERR_NOMEM;
-    g->n = n;
-    g->nnz = offsets[n];
-    g->shard_part = part;
-    g->shard_nparts = nparts;
-    int rc = dmalloc(&g->off, n + 1, g);
-    if (!rc) rc = dmalloc(&g->adj, g->nnz, g);
-    if (!rc) {
-        hipStream_t s = ctx().stream;
-        if (hipMemcpyAsync(g->off, offsets, size_t(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s) != hipSuccess ||
-            (g->nnz && hipMemcpyAsync(g->adj, neigh, size_t(g->nnz) * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) ||
-            hipStreamSynchronize(s) != hipSuccess) {
-            (void)hipGetLastError();
-            rc = GMSX_ERR_KERNEL;
+    return gmsx::guard([&]() -> int {
+        if (!out || n < 0 || !offsets || n > 0x7fffffffll || nparts < 1 || part < 0 || part >= nparts) return GMSX_ERR_INVALID;
+        if (offsets[0] != 0 || offsets[n] < 0 || (offsets[n] > 0 && !neigh)) return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;
+        gmsx_graph *g = new (std::nothrow) gmsx_graph;
+        if (!g) return GMSX_ERR_NOMEM;
+        g->n = n;
+        g->nnz = offsets[n];
+        g->shard_part = part;
+        g->shard_nparts = nparts;
+        int rc = dmalloc(&g->off, n + 1, g);
+        if (!rc) rc = dmalloc(&g->adj, g->nnz, g);
+        if (!rc) {
+            hipStream_t s = ctx().stream;
+            if (hipMemcpyAsync(g->off, offsets, size_t(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s) != hipSuccess ||
+                (g->nnz && hipMemcpyAsync(g->adj, neigh, size_t(g->nnz) * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) ||
+                hipStreamSynchronize(s) != hipSuccess) {
+                (void)hipGetLastError();
+                rc = GMSX_ERR_KERNEL;
+            }
         }
-    }
-    // offsets must be monotone before any kernel walks the rows
-    if (!rc) {
-        for (int64_t i = 0; i < n; ++i)
-            if (offsets[i + 1] < offsets[i]) { rc = GMSX_ERR_INVALID; break; }
-    }
-    if (!rc) rc = build_device_sets(g, flags);
-    if (!rc && (flags & GMSX_UPLOAD_FOR_TC)) rc = ensure_tc(g);
-    if (rc) {
-        free_graph(g);
-        return rc;
-    }
-    *out = g;
-    return GMSX_OK;
+        // offsets must be monotone before any kernel walks the rows
+        if (!rc) {
+            for (int64_t i = 0; i < n; ++i)
+                if (offsets[i + 1] < offsets[i]) { rc = GMSX_ERR_INVALID; break; }
+        }
+        if (!rc) rc = build_device_sets(g, flags);
+        if (!rc && (flags & GMSX_UPLOAD_FOR_TC)) rc = ensure_tc(g);
+        if (rc) {
+            free_graph(g);
+            return rc;
+        }
+        *out = g;
+        return GMSX_OK;
+    });
 }
 
 int gmsx_graph_upload_csr(const gmsx_csr *h, uint32_t flags, gmsx_graph **out) { return gmsx_graph_upload_csr_shard(h, flags, 0, 1, out); }
 
 int gmsx_graph_upload_csr_shard(const gmsx_csr *h, uint32_t flags, int part, int nparts, gmsx_graph **out) {
-    if (!h) return GMSX_ERR_INVALID;
-    if (h->g.directed) return GMSX_ERR_DIRECTED;
-    return gmsx_graph_upload_shard(h->g.n, h->g.off.get(), h->g.neigh.get(), flags, part, nparts, out);
+    return gmsx::guard([&]() -> int {
+        if (!h) return GMSX_ERR_INVALID;
+        if (h->g.directed) return GMSX_ERR_DIRECTED;
+        return gmsx_graph_upload_shard(h->g.n, h->g.off.get(), h->g.neigh.get(), flags, part, nparts, out);
+    });
 }
 
 int gmsx_graph_prepare(gmsx_graph *g, uint32_t what) {
-    if (!g || (what & ~uint32_t(GMSX_PREPARE_TC))) return GMSX_ERR_INVALID;
-    if (int rc = ensure_init()) return rc;
-    if (what & GMSX_PREPARE_TC)
-        if (int rc = ensure_tc(g)) return rc;
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (!g || (what & ~uint32_t(GMSX_PREPARE_TC))) return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;
+        if (what & GMSX_PREPARE_TC)
+            if (int rc = ensure_tc(g)) return rc;
+        return GMSX_OK;
+    });
 }
 
 int gmsx_graph_tc_passes(const gmsx_graph *g) { return !g ? GMSX_ERR_INVALID : (g->tc_ready ? g->tc_passes : 0); }
 
 int gmsx_graph_free(gmsx_graph *g) {
-    free_graph(g);
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        free_graph(g);
+        return GMSX_OK;
+    });
 }
 
 int64_t gmsx_graph_num_nodes(const gmsx_graph *g) { return g ? g->n : int64_t(GMSX_ERR_INVALID); }

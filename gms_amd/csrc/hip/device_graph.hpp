@@ -5,6 +5,7 @@
 #include <cstdint>
 
 #include "gmsx.h"
+#include "gmsx_internal.hpp"  // gmsx::guard: no exception crosses the C ABI
 
 // Layout in HBM (all arrays hipMalloc'd once at upload, read-only afterwards):
 //
@@ -125,8 +126,6 @@ struct gmsx_graph {
     mutable int ge_used = 0;
     mutable int stats_part = -1, stats_nparts = -1;  // shard whose TC bookkeeping (units, probes) is cached below
     mutable uint64_t stats_units = 0, stats_probes = 0, stats_bytes = 0;
-    mutable const int32_t *rank_ok_ptr = nullptr;    // gmsx_bk_partial: the last `rank` array validated as a permutation (+ two probe values)
-    mutable int32_t rank_ok_first = 0, rank_ok_last = 0;
     // the triangle-count containers (stream rows, inline rows, task lists …) are built on demand: ensure_tc()
     int shard_part = 0, shard_nparts = 1;   // gmsx_graph_upload_shard: the triangle-count containers hold this rank's pivots only
     // FALLBACK when the triangle-count containers of the whole graph do not fit the device: they are built for 1/tc_passes of the pivots at

@@ -1169,21 +1169,25 @@ using namespace gmsx;
 extern "C" {
 
 int gmsx_kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint64_t *cliques_partial, gmsx_stats *stats) {
-    if (!g || !cliques_partial || nparts < 1 || part < 0 || part >= nparts || k < 2) return GMSX_ERR_INVALID;
-    if (k > kMaxGenericK) return GMSX_ERR_UNSUPPORTED;  // the generic recursion keeps its per-level cursors in LDS: k <= 64
-    if (int rc = ensure_init()) return rc;
-    return kclique_partial(g, k, part, nparts, cliques_partial, stats);
+    return gmsx::guard([&]() -> int {
+        if (!g || !cliques_partial || nparts < 1 || part < 0 || part >= nparts || k < 2) return GMSX_ERR_INVALID;
+        if (k > kMaxGenericK) return GMSX_ERR_UNSUPPORTED;  // the generic recursion keeps its per-level cursors in LDS: k <= 64
+        if (int rc = ensure_init()) return rc;
+        return kclique_partial(g, k, part, nparts, cliques_partial, stats);
+    });
 }
 
 int gmsx_kclique_count(const gmsx_graph *g, int k, uint64_t *ordered_count, uint64_t *cliques, gmsx_stats *stats) {
-    if (!ordered_count) return GMSX_ERR_INVALID;
-    uint64_t c = 0;
-    if (int rc = gmsx_kclique_partial(g, k, 0, 1, &c, stats)) return rc;
-    uint64_t fact = 1;
-    for (int i = 2; i <= k; ++i) fact *= uint64_t(i);  // mod 2^64, like the reference's size_t sum of ordered cliques
-    *ordered_count = c * fact;
-    if (cliques) *cliques = c;
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (!ordered_count) return GMSX_ERR_INVALID;
+        uint64_t c = 0;
+        if (int rc = gmsx_kclique_partial(g, k, 0, 1, &c, stats)) return rc;
+        uint64_t fact = 1;
+        for (int i = 2; i <= k; ++i) fact *= uint64_t(i);  // mod 2^64, like the reference's size_t sum of ordered cliques
+        *ordered_count = c * fact;
+        if (cliques) *cliques = c;
+        return GMSX_OK;
+    });
 }
 
 }  // extern "C"

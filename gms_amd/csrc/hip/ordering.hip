@@ -129,98 +129,102 @@ using namespace gmsx;
 extern "C" {
 
 int gmsx_adg_rank(const gmsx_graph *g, double epsilon, int rank_format, int32_t *out, int32_t *rounds_out, gmsx_stats *stats) {
-    if (!g || !out || !(epsilon >= 0.0)) return GMSX_ERR_INVALID;
-    if (int rc = ensure_init()) return rc;
-    Ctx &c = ctx();
-    hipStream_t s = c.stream;
-    const int64_t n = g->n;
-    if (stats) *stats = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
-    if (rounds_out) *rounds_out = 0;
-    if (n == 0) return GMSX_OK;
-    Dev d_deg, d_state, d_keys, d_sorted, d_out, d_acc, d_tmp;
-    if (int rc = dalloc<int32_t>(d_deg, n)) return rc;
-    if (int rc = dalloc<int32_t>(d_state, n)) return rc;
-    if (int rc = dalloc<unsigned long long>(d_keys, n)) return rc;
-    if (int rc = dalloc<unsigned long long>(d_sorted, n)) return rc;
-    if (int rc = dalloc<int32_t>(d_out, n)) return rc;
-    if (int rc = dalloc<unsigned long long>(d_acc, 4)) return rc;
-    size_t tmp_bytes = 0;
-    GMSX_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys.as<unsigned long long>(), d_sorted.as<unsigned long long>(), size_t(n), 0, 64, s));
-    if (int rc = dalloc<char>(d_tmp, int64_t(tmp_bytes))) return rc;
+    return gmsx::guard([&]() -> int {
+        if (!g || !out || !(epsilon >= 0.0)) return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;
+        Ctx &c = ctx();
+        hipStream_t s = c.stream;
+        const int64_t n = g->n;
+        if (stats) *stats = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
+        if (rounds_out) *rounds_out = 0;
+        if (n == 0) return GMSX_OK;
+        Dev d_deg, d_state, d_keys, d_sorted, d_out, d_acc, d_tmp;
+        if (int rc = dalloc<int32_t>(d_deg, n)) return rc;
+        if (int rc = dalloc<int32_t>(d_state, n)) return rc;
+        if (int rc = dalloc<unsigned long long>(d_keys, n)) return rc;
+        if (int rc = dalloc<unsigned long long>(d_sorted, n)) return rc;
+        if (int rc = dalloc<int32_t>(d_out, n)) return rc;
+        if (int rc = dalloc<unsigned long long>(d_acc, 4)) return rc;
+        size_t tmp_bytes = 0;
+        GMSX_HIP(rocprim::radix_sort_keys(nullptr, tmp_bytes, d_keys.as<unsigned long long>(), d_sorted.as<unsigned long long>(), size_t(n), 0, 64, s));
+        if (int rc = dalloc<char>(d_tmp, int64_t(tmp_bytes))) return rc;
 
-    const unsigned tb = unsigned((n + 255) / 256);
-    const int cus = c.compute_units > 0 ? c.compute_units : 256;
-    const unsigned sweep = unsigned(std::min<int64_t>((n + 255) / 256, int64_t(cus) * 16));
-    GMSX_HIP(hipEventRecord(c.ev[0], s));
-    hipLaunchKernelGGL(k_adg_init, dim3(tb), dim3(256), 0, s, n, g->off, d_deg.as<int32_t>(), d_state.as<int32_t>());
-    int64_t counter = 0;
-    int32_t round = 0;
-    int launches = 1;
-    while (counter < n) {
-        unsigned long long acc[3] = {0, 0, 0};
-        GMSX_HIP(hipMemsetAsync(d_acc.p, 0, 3 * sizeof(unsigned long long), s));
-        hipLaunchKernelGGL(k_adg_sum, dim3(sweep), dim3(256), 0, s, n, d_deg.as<int32_t>(), d_state.as<int32_t>(), d_acc.as<unsigned long long>());
-        GMSX_HIP(hipMemcpyAsync(acc, d_acc.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        const unsigned tb = unsigned((n + 255) / 256);
+        const int cus = c.compute_units > 0 ? c.compute_units : 256;
+        const unsigned sweep = unsigned(std::min<int64_t>((n + 255) / 256, int64_t(cus) * 16));
+        GMSX_HIP(hipEventRecord(c.ev[0], s));
+        hipLaunchKernelGGL(k_adg_init, dim3(tb), dim3(256), 0, s, n, g->off, d_deg.as<int32_t>(), d_state.as<int32_t>());
+        int64_t counter = 0;
+        int32_t round = 0;
+        int launches = 1;
+        while (counter < n) {
+            unsigned long long acc[3] = {0, 0, 0};
+            GMSX_HIP(hipMemsetAsync(d_acc.p, 0, 3 * sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(k_adg_sum, dim3(sweep), dim3(256), 0, s, n, d_deg.as<int32_t>(), d_state.as<int32_t>(), d_acc.as<unsigned long long>());
+            GMSX_HIP(hipMemcpyAsync(acc, d_acc.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            GMSX_HIP(hipStreamSynchronize(s));
+            if (int64_t(acc[1]) != n - counter || acc[1] == 0) return GMSX_ERR_KERNEL;
+            // boundary_function.h:14-23 + degeneracy_approx_set.h:39: the sum of ints accumulated in a double is exact below 2^53
+            const double res = double(acc[0]);
+            const unsigned border = unsigned((1 + epsilon) * (res / double(int(acc[1]))));
+            hipLaunchKernelGGL(k_adg_select, dim3(sweep), dim3(256), 0, s, n, d_deg.as<int32_t>(), d_state.as<int32_t>(), uint32_t(border), round,
+                               d_keys.as<unsigned long long>(), d_acc.as<unsigned long long>() + 2);
+            GMSX_HIP(hipMemcpyAsync(&acc[2], d_acc.as<unsigned long long>() + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+            GMSX_HIP(hipStreamSynchronize(s));
+            const int64_t batch = int64_t(acc[2]);
+            if (batch <= 0 || batch > n - counter) return GMSX_ERR_KERNEL;  // the minimum is never above the mean: a round cannot be empty
+            // :55-59 sort the batch by remaining degree (ties: id); degrees < 2^31, so 63 key bits carry everything
+            GMSX_HIP(rocprim::radix_sort_keys(d_tmp.p, tmp_bytes, d_keys.as<unsigned long long>(), d_sorted.as<unsigned long long>(), size_t(batch), 0, 64, s));
+            const unsigned pb = unsigned(std::min<int64_t>((batch + 3) / 4, int64_t(cus) * 32));
+            hipLaunchKernelGGL(k_adg_push, dim3(pb), dim3(256), 0, s, batch, d_sorted.as<unsigned long long>(), counter, rank_format ? 1 : 0, g->off,
+                               g->adj, d_state.as<int32_t>(), d_deg.as<int32_t>(), d_out.as<int32_t>());
+            counter += batch;
+            ++round;
+            launches += 4;
+        }
+        GMSX_HIP(hipEventRecord(c.ev[1], s));
+        GMSX_HIP(hipMemcpyAsync(out, d_out.p, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
         GMSX_HIP(hipStreamSynchronize(s));
-        if (int64_t(acc[1]) != n - counter || acc[1] == 0) return GMSX_ERR_KERNEL;
-        // boundary_function.h:14-23 + degeneracy_approx_set.h:39: the sum of ints accumulated in a double is exact below 2^53
-        const double res = double(acc[0]);
-        const unsigned border = unsigned((1 + epsilon) * (res / double(int(acc[1]))));
-        hipLaunchKernelGGL(k_adg_select, dim3(sweep), dim3(256), 0, s, n, d_deg.as<int32_t>(), d_state.as<int32_t>(), uint32_t(border), round,
-                           d_keys.as<unsigned long long>(), d_acc.as<unsigned long long>() + 2);
-        GMSX_HIP(hipMemcpyAsync(&acc[2], d_acc.as<unsigned long long>() + 2, sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-        GMSX_HIP(hipStreamSynchronize(s));
-        const int64_t batch = int64_t(acc[2]);
-        if (batch <= 0 || batch > n - counter) return GMSX_ERR_KERNEL;  // the minimum is never above the mean: a round cannot be empty
-        // :55-59 sort the batch by remaining degree (ties: id); degrees < 2^31, so 63 key bits carry everything
-        GMSX_HIP(rocprim::radix_sort_keys(d_tmp.p, tmp_bytes, d_keys.as<unsigned long long>(), d_sorted.as<unsigned long long>(), size_t(batch), 0, 64, s));
-        const unsigned pb = unsigned(std::min<int64_t>((batch + 3) / 4, int64_t(cus) * 32));
-        hipLaunchKernelGGL(k_adg_push, dim3(pb), dim3(256), 0, s, batch, d_sorted.as<unsigned long long>(), counter, rank_format ? 1 : 0, g->off,
-                           g->adj, d_state.as<int32_t>(), d_deg.as<int32_t>(), d_out.as<int32_t>());
-        counter += batch;
-        ++round;
-        launches += 4;
-    }
-    GMSX_HIP(hipEventRecord(c.ev[1], s));
-    GMSX_HIP(hipMemcpyAsync(out, d_out.p, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    GMSX_HIP(hipStreamSynchronize(s));
-    GMSX_HIP(hipGetLastError());
-    if (rounds_out) *rounds_out = round;
-    if (stats) {
-        float ms = 0.f;
-        GMSX_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
-        *stats = gmsx_stats{double(ms), 0.0, uint64_t(n), 0, uint64_t(round), launches, 0};
-    }
-    return GMSX_OK;
+        GMSX_HIP(hipGetLastError());
+        if (rounds_out) *rounds_out = round;
+        if (stats) {
+            float ms = 0.f;
+            GMSX_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+            *stats = gmsx_stats{double(ms), 0.0, uint64_t(n), 0, uint64_t(round), launches, 0};
+        }
+        return GMSX_OK;
+    });
 }
 
 int gmsx_tc_ordering(const gmsx_graph *g, int32_t *ordering, gmsx_stats *stats) {
-    if (!g || !ordering) return GMSX_ERR_INVALID;
-    if (int rc = ensure_init()) return rc;
-    hipStream_t s = ctx().stream;
-    const int64_t n = g->n;
-    if (stats) *stats = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
-    if (n == 0) return GMSX_OK;
-    Dev d_counts, d_counts_sorted, d_ids, d_ids_sorted, d_tmp;
-    if (int rc = dalloc<unsigned long long>(d_counts, n)) return rc;
-    if (int rc = dalloc<unsigned long long>(d_counts_sorted, n)) return rc;
-    if (int rc = dalloc<int32_t>(d_ids, n)) return rc;
-    if (int rc = dalloc<int32_t>(d_ids_sorted, n)) return rc;
-    GMSX_HIP(hipMemsetAsync(d_counts.p, 0, size_t(n) * sizeof(unsigned long long), s));
-    // counts[u] = Σ_{v∈N(u)} |N(u) ∩ N(v)|: CountFn = Par::vertex_count2_once (triangle_count.h:14, parallel/vertex.h:30-49)
-    if (int rc = tc_vertex_counts_device(g, d_counts.as<unsigned long long>(), stats)) return rc;
-    hipLaunchKernelGGL(k_iota, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, d_ids.as<int32_t>());
-    // sort ids by count ascending (:23-29); the radix sort is stable, so equal counts keep ascending ids
-    size_t tmp_bytes = 0;
-    GMSX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_counts.as<unsigned long long>(), d_counts_sorted.as<unsigned long long>(),
-                                       d_ids.as<int32_t>(), d_ids_sorted.as<int32_t>(), size_t(n), 0, 64, s));
-    if (int rc = dalloc<char>(d_tmp, int64_t(tmp_bytes))) return rc;
-    GMSX_HIP(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_counts.as<unsigned long long>(), d_counts_sorted.as<unsigned long long>(),
-                                       d_ids.as<int32_t>(), d_ids_sorted.as<int32_t>(), size_t(n), 0, 64, s));
-    GMSX_HIP(hipMemcpyAsync(ordering, d_ids_sorted.p, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    GMSX_HIP(hipStreamSynchronize(s));
-    GMSX_HIP(hipGetLastError());
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (!g || !ordering) return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;
+        hipStream_t s = ctx().stream;
+        const int64_t n = g->n;
+        if (stats) *stats = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
+        if (n == 0) return GMSX_OK;
+        Dev d_counts, d_counts_sorted, d_ids, d_ids_sorted, d_tmp;
+        if (int rc = dalloc<unsigned long long>(d_counts, n)) return rc;
+        if (int rc = dalloc<unsigned long long>(d_counts_sorted, n)) return rc;
+        if (int rc = dalloc<int32_t>(d_ids, n)) return rc;
+        if (int rc = dalloc<int32_t>(d_ids_sorted, n)) return rc;
+        GMSX_HIP(hipMemsetAsync(d_counts.p, 0, size_t(n) * sizeof(unsigned long long), s));
+        // counts[u] = Σ_{v∈N(u)} |N(u) ∩ N(v)|: CountFn = Par::vertex_count2_once (triangle_count.h:14, parallel/vertex.h:30-49)
+        if (int rc = tc_vertex_counts_device(g, d_counts.as<unsigned long long>(), stats)) return rc;
+        hipLaunchKernelGGL(k_iota, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, d_ids.as<int32_t>());
+        // sort ids by count ascending (:23-29); the radix sort is stable, so equal counts keep ascending ids
+        size_t tmp_bytes = 0;
+        GMSX_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_counts.as<unsigned long long>(), d_counts_sorted.as<unsigned long long>(),
+                                           d_ids.as<int32_t>(), d_ids_sorted.as<int32_t>(), size_t(n), 0, 64, s));
+        if (int rc = dalloc<char>(d_tmp, int64_t(tmp_bytes))) return rc;
+        GMSX_HIP(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_counts.as<unsigned long long>(), d_counts_sorted.as<unsigned long long>(),
+                                           d_ids.as<int32_t>(), d_ids_sorted.as<int32_t>(), size_t(n), 0, 64, s));
+        GMSX_HIP(hipMemcpyAsync(ordering, d_ids_sorted.p, size_t(n) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        GMSX_HIP(hipGetLastError());
+        return GMSX_OK;
+    });
 }
 
 }  // extern "C"

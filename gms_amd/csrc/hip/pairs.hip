@@ -221,93 +221,99 @@ using namespace gmsx;
 extern "C" {
 
 int gmsx_tc_vertex_count2(const gmsx_graph *g, int64_t *counts, gmsx_stats *stats) {
-    if (!g || !counts) return GMSX_ERR_INVALID;
-    if (int rc = ensure_init()) return rc;
-    hipStream_t s = ctx().stream;
-    unsigned long long *d_counts = nullptr;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_counts), sizeof(unsigned long long) * size_t(std::max<int64_t>(g->n, 1))));
-    struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{d_counts};
-    GMSX_HIP(hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * size_t(std::max<int64_t>(g->n, 1)), s));
-    if (int rc = tc_vertex_counts_device(g, d_counts, stats)) return rc;
-    if (g->n > 0) GMSX_HIP(hipMemcpy(counts, d_counts, sizeof(int64_t) * size_t(g->n), hipMemcpyDeviceToHost));
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (!g || !counts) return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;
+        hipStream_t s = ctx().stream;
+        unsigned long long *d_counts = nullptr;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_counts), sizeof(unsigned long long) * size_t(std::max<int64_t>(g->n, 1))));
+        struct Guard { void *p; ~Guard() { (void)hipFree(p); } } guard{d_counts};
+        GMSX_HIP(hipMemsetAsync(d_counts, 0, sizeof(unsigned long long) * size_t(std::max<int64_t>(g->n, 1)), s));
+        if (int rc = tc_vertex_counts_device(g, d_counts, stats)) return rc;
+        if (g->n > 0) GMSX_HIP(hipMemcpy(counts, d_counts, sizeof(int64_t) * size_t(g->n), hipMemcpyDeviceToHost));
+        return GMSX_OK;
+    });
 }
 
 int gmsx_vertex_similarity_batch(const gmsx_graph *g, int metric, int64_t n_pairs, const int32_t *u, const int32_t *v, double *out,
                                  gmsx_stats *stats) {
-    if (!g || n_pairs < 0 || metric < GMSX_SIM_JACCARD || metric > GMSX_SIM_PREF_ATTACHMENT || (n_pairs > 0 && (!u || !v || !out)))
-        return GMSX_ERR_INVALID;
-    if (int rc = ensure_init()) return rc;
-    if (n_pairs == 0) {
-        if (stats) *stats = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
-        return GMSX_OK;
-    }
-    Ctx &c = ctx();
-    hipStream_t s = c.stream;
-    int32_t *du = nullptr, *dv = nullptr;
-    double *dout = nullptr;
-    unsigned long long *flags = nullptr;
-    struct Guard { void *p = nullptr; ~Guard() { (void)hipFree(p); } } g1, g2, g3, g4;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&du), size_t(n_pairs) * 4)); g1.p = du;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dv), size_t(n_pairs) * 4)); g2.p = dv;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dout), size_t(n_pairs) * 8)); g3.p = dout;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&flags), 8)); g4.p = flags;
-    GMSX_HIP(hipMemcpyAsync(du, u, size_t(n_pairs) * 4, hipMemcpyHostToDevice, s));
-    GMSX_HIP(hipMemcpyAsync(dv, v, size_t(n_pairs) * 4, hipMemcpyHostToDevice, s));
-    GMSX_HIP(hipMemsetAsync(flags, 0, 8, s));
-    GMSX_HIP(hipEventRecord(c.ev[0], s));
-    const int64_t blocks = std::min<int64_t>((n_pairs + 3) / 4, int64_t(c.compute_units > 0 ? c.compute_units : 256) * 32);
-    hipLaunchKernelGGL(k_pair_similarity, dim3(unsigned(blocks)), dim3(256), 0, s, g->off, g->adj, g->n, metric, n_pairs, du, dv, dout, flags);
-    GMSX_HIP(hipEventRecord(c.ev[1], s));
-    GMSX_HIP(hipGetLastError());
-    unsigned long long bad = 0;
-    GMSX_HIP(hipMemcpyAsync(out, dout, size_t(n_pairs) * 8, hipMemcpyDeviceToHost, s));
-    GMSX_HIP(hipMemcpyAsync(&bad, flags, 8, hipMemcpyDeviceToHost, s));
-    GMSX_HIP(hipStreamSynchronize(s));
-    if (stats) {
-        float ms = 0.f;
-        GMSX_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
-        *stats = gmsx_stats{double(ms), 0.0, uint64_t(n_pairs), 0, 0, 1, 0};
-    }
-    return bad ? GMSX_ERR_INVALID : GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (!g || n_pairs < 0 || metric < GMSX_SIM_JACCARD || metric > GMSX_SIM_PREF_ATTACHMENT || (n_pairs > 0 && (!u || !v || !out)))
+            return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;
+        if (n_pairs == 0) {
+            if (stats) *stats = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
+            return GMSX_OK;
+        }
+        Ctx &c = ctx();
+        hipStream_t s = c.stream;
+        int32_t *du = nullptr, *dv = nullptr;
+        double *dout = nullptr;
+        unsigned long long *flags = nullptr;
+        struct Guard { void *p = nullptr; ~Guard() { (void)hipFree(p); } } g1, g2, g3, g4;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&du), size_t(n_pairs) * 4)); g1.p = du;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dv), size_t(n_pairs) * 4)); g2.p = dv;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dout), size_t(n_pairs) * 8)); g3.p = dout;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&flags), 8)); g4.p = flags;
+        GMSX_HIP(hipMemcpyAsync(du, u, size_t(n_pairs) * 4, hipMemcpyHostToDevice, s));
+        GMSX_HIP(hipMemcpyAsync(dv, v, size_t(n_pairs) * 4, hipMemcpyHostToDevice, s));
+        GMSX_HIP(hipMemsetAsync(flags, 0, 8, s));
+        GMSX_HIP(hipEventRecord(c.ev[0], s));
+        const int64_t blocks = std::min<int64_t>((n_pairs + 3) / 4, int64_t(c.compute_units > 0 ? c.compute_units : 256) * 32);
+        hipLaunchKernelGGL(k_pair_similarity, dim3(unsigned(blocks)), dim3(256), 0, s, g->off, g->adj, g->n, metric, n_pairs, du, dv, dout, flags);
+        GMSX_HIP(hipEventRecord(c.ev[1], s));
+        GMSX_HIP(hipGetLastError());
+        unsigned long long bad = 0;
+        GMSX_HIP(hipMemcpyAsync(out, dout, size_t(n_pairs) * 8, hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipMemcpyAsync(&bad, flags, 8, hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        if (stats) {
+            float ms = 0.f;
+            GMSX_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+            *stats = gmsx_stats{double(ms), 0.0, uint64_t(n_pairs), 0, 0, 1, 0};
+        }
+        return bad ? GMSX_ERR_INVALID : GMSX_OK;
+    });
 }
 
 int gmsx_intersect_count_batch(const gmsx_graph *g, int64_t n_pairs, const int32_t *u, const int32_t *v, uint32_t *out,
                                gmsx_stats *stats) {
-    if (!g || n_pairs < 0 || (n_pairs > 0 && (!u || !v || !out))) return GMSX_ERR_INVALID;
-    if (int rc = ensure_init()) return rc;
-    if (n_pairs == 0) {
-        if (stats) *stats = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
-        return GMSX_OK;
-    }
-    Ctx &c = ctx();
-    hipStream_t s = c.stream;
-    int32_t *du = nullptr, *dv = nullptr;
-    uint32_t *dout = nullptr;
-    unsigned long long *flags = nullptr;
-    struct Guard { void *p = nullptr; ~Guard() { (void)hipFree(p); } } g1, g2, g3, g4;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&du), size_t(n_pairs) * 4)); g1.p = du;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dv), size_t(n_pairs) * 4)); g2.p = dv;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dout), size_t(n_pairs) * 4)); g3.p = dout;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&flags), 8)); g4.p = flags;
-    GMSX_HIP(hipMemcpyAsync(du, u, size_t(n_pairs) * 4, hipMemcpyHostToDevice, s));
-    GMSX_HIP(hipMemcpyAsync(dv, v, size_t(n_pairs) * 4, hipMemcpyHostToDevice, s));
-    GMSX_HIP(hipMemsetAsync(flags, 0, 8, s));
-    GMSX_HIP(hipEventRecord(c.ev[0], s));
-    const int64_t blocks = std::min<int64_t>((n_pairs + 3) / 4, int64_t(c.compute_units > 0 ? c.compute_units : 256) * 32);
-    hipLaunchKernelGGL(k_pair_batch, dim3(unsigned(blocks)), dim3(256), 0, s, g->off, g->adj, g->n, n_pairs, du, dv, dout, flags);
-    GMSX_HIP(hipEventRecord(c.ev[1], s));
-    GMSX_HIP(hipGetLastError());
-    unsigned long long bad = 0;
-    GMSX_HIP(hipMemcpyAsync(out, dout, size_t(n_pairs) * 4, hipMemcpyDeviceToHost, s));
-    GMSX_HIP(hipMemcpyAsync(&bad, flags, 8, hipMemcpyDeviceToHost, s));
-    GMSX_HIP(hipStreamSynchronize(s));
-    if (stats) {
-        float ms = 0.f;
-        GMSX_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
-        *stats = gmsx_stats{double(ms), 0.0, uint64_t(n_pairs), 0, 0, 1, 0};
-    }
-    return bad ? GMSX_ERR_INVALID : GMSX_OK;  // a vertex id outside [0, n)
+    return gmsx::guard([&]() -> int {
+        if (!g || n_pairs < 0 || (n_pairs > 0 && (!u || !v || !out))) return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;
+        if (n_pairs == 0) {
+            if (stats) *stats = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
+            return GMSX_OK;
+        }
+        Ctx &c = ctx();
+        hipStream_t s = c.stream;
+        int32_t *du = nullptr, *dv = nullptr;
+        uint32_t *dout = nullptr;
+        unsigned long long *flags = nullptr;
+        struct Guard { void *p = nullptr; ~Guard() { (void)hipFree(p); } } g1, g2, g3, g4;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&du), size_t(n_pairs) * 4)); g1.p = du;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dv), size_t(n_pairs) * 4)); g2.p = dv;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dout), size_t(n_pairs) * 4)); g3.p = dout;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&flags), 8)); g4.p = flags;
+        GMSX_HIP(hipMemcpyAsync(du, u, size_t(n_pairs) * 4, hipMemcpyHostToDevice, s));
+        GMSX_HIP(hipMemcpyAsync(dv, v, size_t(n_pairs) * 4, hipMemcpyHostToDevice, s));
+        GMSX_HIP(hipMemsetAsync(flags, 0, 8, s));
+        GMSX_HIP(hipEventRecord(c.ev[0], s));
+        const int64_t blocks = std::min<int64_t>((n_pairs + 3) / 4, int64_t(c.compute_units > 0 ? c.compute_units : 256) * 32);
+        hipLaunchKernelGGL(k_pair_batch, dim3(unsigned(blocks)), dim3(256), 0, s, g->off, g->adj, g->n, n_pairs, du, dv, dout, flags);
+        GMSX_HIP(hipEventRecord(c.ev[1], s));
+        GMSX_HIP(hipGetLastError());
+        unsigned long long bad = 0;
+        GMSX_HIP(hipMemcpyAsync(out, dout, size_t(n_pairs) * 4, hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipMemcpyAsync(&bad, flags, 8, hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        if (stats) {
+            float ms = 0.f;
+            GMSX_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+            *stats = gmsx_stats{double(ms), 0.0, uint64_t(n_pairs), 0, 0, 1, 0};
+        }
+        return bad ? GMSX_ERR_INVALID : GMSX_OK;  // a vertex id outside [0, n)
+    });
 }
 
 }  // extern "C"

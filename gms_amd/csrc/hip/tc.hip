@@ -1152,71 +1152,79 @@ extern "C" {
 int gmsx_tc_divisor(int algo) { return algo == GMSX_TC_FULL ? 3 : 1; }
 
 int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21) {
-    if (!g || !out21) return GMSX_ERR_INVALID;
-    if (int rc = ensure_init()) return rc;
-    if (int rc = ensure_tc(g)) return rc;
-    hipStream_t s = ctx().stream;
-    std::memset(out21, 0, 21 * sizeof(uint64_t));
-    if (g->n == 0) return GMSX_OK;
-    int64_t n_block = 0, n_work = 0;
-    if (int rc = count_dplus_ge(g, kHeavy, &n_block)) return rc;
-    if (int rc = count_dplus_ge(g, 2, &n_work)) return rc;
-    unsigned long long *acc = nullptr;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), 21 * 8));
-    struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g1{acc};
-    GMSX_HIP(hipMemsetAsync(acc, 0, 21 * 8, s));
-    const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
-    hipLaunchKernelGGL(k_tc_breakdown, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->hoff, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow, g->htask,
-                       g->hitem, g->hitems, g->ttask, g->titem, g->titems, g->inline_limit, n_block, n_work, acc);
-    GMSX_HIP(hipMemcpyAsync(out21, acc, 21 * 8, hipMemcpyDeviceToHost, s));
-    GMSX_HIP(hipStreamSynchronize(s));
-    GMSX_HIP(hipGetLastError());
-    out21[7] = uint64_t(g->inline_units) * 16ull;                         // the build's figures: the entries do not say what they name
-    out21[12] = uint64_t(g->inline_hentries + g->inline_tentries);
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (!g || !out21) return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;
+        if (int rc = ensure_tc(g)) return rc;
+        hipStream_t s = ctx().stream;
+        std::memset(out21, 0, 21 * sizeof(uint64_t));
+        if (g->n == 0) return GMSX_OK;
+        int64_t n_block = 0, n_work = 0;
+        if (int rc = count_dplus_ge(g, kHeavy, &n_block)) return rc;
+        if (int rc = count_dplus_ge(g, 2, &n_work)) return rc;
+        unsigned long long *acc = nullptr;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), 21 * 8));
+        struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g1{acc};
+        GMSX_HIP(hipMemsetAsync(acc, 0, 21 * 8, s));
+        const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
+        hipLaunchKernelGGL(k_tc_breakdown, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->hoff, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow, g->htask,
+                           g->hitem, g->hitems, g->ttask, g->titem, g->titems, g->inline_limit, n_block, n_work, acc);
+        GMSX_HIP(hipMemcpyAsync(out21, acc, 21 * 8, hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        GMSX_HIP(hipGetLastError());
+        out21[7] = uint64_t(g->inline_units) * 16ull;                         // the build's figures: the entries do not say what they name
+        out21[12] = uint64_t(g->inline_hentries + g->inline_tentries);
+        return GMSX_OK;
+    });
 }
 
 int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out256) {
-    uint64_t *out248 = out256;
-    if (!g || !out248) return GMSX_ERR_INVALID;
-    if (int rc = ensure_init()) return rc;
-    if (int rc = ensure_tc(g)) return rc;
-    hipStream_t s = ctx().stream;
-    std::memset(out248, 0, 256 * sizeof(uint64_t));
-    if (g->n == 0) return GMSX_OK;
-    unsigned long long *acc = nullptr;
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), 256 * 8));
-    struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g1{acc};
-    GMSX_HIP(hipMemsetAsync(acc, 0, 256 * 8, s));
-    const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
-    hipLaunchKernelGGL(k_tc_row_hist, dim3(unsigned(cus * 8)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow,
-                       g->htask, g->hitem, g->hitems, g->ttask, g->titem, g->titems, g->n, acc);
-    GMSX_HIP(hipGetLastError());
-    GMSX_HIP(hipMemcpyAsync(out248, acc, 256 * 8, hipMemcpyDeviceToHost, s));
-    GMSX_HIP(hipStreamSynchronize(s));
-    GMSX_HIP(hipGetLastError());
-    out248[241] = uint64_t(g->inline_hentries + g->inline_tentries);
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        uint64_t *out248 = out256;
+        if (!g || !out248) return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;
+        if (int rc = ensure_tc(g)) return rc;
+        hipStream_t s = ctx().stream;
+        std::memset(out248, 0, 256 * sizeof(uint64_t));
+        if (g->n == 0) return GMSX_OK;
+        unsigned long long *acc = nullptr;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), 256 * 8));
+        struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g1{acc};
+        GMSX_HIP(hipMemsetAsync(acc, 0, 256 * 8, s));
+        const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
+        hipLaunchKernelGGL(k_tc_row_hist, dim3(unsigned(cus * 8)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow,
+                           g->htask, g->hitem, g->hitems, g->ttask, g->titem, g->titems, g->n, acc);
+        GMSX_HIP(hipGetLastError());
+        GMSX_HIP(hipMemcpyAsync(out248, acc, 256 * 8, hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        GMSX_HIP(hipGetLastError());
+        out248[241] = uint64_t(g->inline_hentries + g->inline_tentries);
+        return GMSX_OK;
+    });
 }
 
 int gmsx_tc_partial(const gmsx_graph *g, int algo, int part, int nparts, uint64_t *partial, gmsx_stats *stats) {
-    if (!g || !partial || nparts < 1 || part < 0 || part >= nparts) return GMSX_ERR_INVALID;
-    if (algo != GMSX_TC_AUTO && algo != GMSX_TC_ORIENTED && algo != GMSX_TC_FULL) return GMSX_ERR_INVALID;
-    if (int rc = ensure_init()) return rc;
-    if (algo == GMSX_TC_FULL) return tc_full_partial(g, part, nparts, partial, stats);
-    // a sharded upload holds the task lists of ONE shard: that is the only one it can count
-    if (g->tc_passes == 1 && g->shard_nparts > 1 && (nparts != g->shard_nparts || part != g->shard_part)) return GMSX_ERR_INVALID;
-    return tc_oriented(g, part, nparts, partial, stats);
+    return gmsx::guard([&]() -> int {
+        if (!g || !partial || nparts < 1 || part < 0 || part >= nparts) return GMSX_ERR_INVALID;
+        if (algo != GMSX_TC_AUTO && algo != GMSX_TC_ORIENTED && algo != GMSX_TC_FULL) return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;
+        if (algo == GMSX_TC_FULL) return tc_full_partial(g, part, nparts, partial, stats);
+        // a sharded upload holds the task lists of ONE shard: that is the only one it can count
+        if (g->tc_passes == 1 && g->shard_nparts > 1 && (nparts != g->shard_nparts || part != g->shard_part)) return GMSX_ERR_INVALID;
+        return tc_oriented(g, part, nparts, partial, stats);
+    });
 }
 
 int gmsx_tc_total(const gmsx_graph *g, int algo, uint64_t *triangles, gmsx_stats *stats) {
-    if (!triangles) return GMSX_ERR_INVALID;
-    uint64_t partial = 0;
-    if (int rc = gmsx_tc_partial(g, algo, 0, 1, &partial, stats)) return rc;
-    const uint64_t div = uint64_t(gmsx_tc_divisor(algo));
-    if (partial % div != 0) return GMSX_ERR_KERNEL;  // the reference asserts total % 3 == 0 (parallel/total.h:22)
-    *triangles = partial / div;
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (!triangles) return GMSX_ERR_INVALID;
+        uint64_t partial = 0;
+        if (int rc = gmsx_tc_partial(g, algo, 0, 1, &partial, stats)) return rc;
+        const uint64_t div = uint64_t(gmsx_tc_divisor(algo));
+        if (partial % div != 0) return GMSX_ERR_KERNEL;  // the reference asserts total % 3 == 0 (parallel/total.h:22)
+        *triangles = partial / div;
+        return GMSX_OK;
+    });
 }
 
 }  // extern "C"

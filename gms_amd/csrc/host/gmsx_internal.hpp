@@ -1,11 +1,32 @@
 // Internal declarations shared by the host substrate and the device layer of libgmsx.
 #pragma once
 #include <cstdint>
+#include <ios>
 #include <memory>
+#include <new>
+#include <stdexcept>
 
 #include "gmsx.h"
 
 namespace gmsx {
+
+// No exception crosses the C ABI: every exported function that can reach an allocation of the C++ library (containers, strings, streams,
+// rocPRIM's host side) runs its body under this guard and returns a status code instead — the reference's convention is exit codes, never
+// unwinding through a caller (gapbs/reader.h:45,228: std::exit(-2) on a failed open), and a C / cgo / ctypes caller cannot catch anything.
+template <class F>
+inline int guard(F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return GMSX_ERR_NOMEM;
+    } catch (const std::length_error &) {
+        return GMSX_ERR_NOMEM;
+    } catch (const std::ios_base::failure &) {
+        return GMSX_ERR_IO;
+    } catch (...) {
+        return GMSX_ERR_KERNEL;
+    }
+}
 
 // Host CSR with 64-bit offsets and 32-bit ids (the reference keeps row POINTERS, gapbs/graph.h:361-364;
 // offsets are what the device wants and what the .sg file stores).

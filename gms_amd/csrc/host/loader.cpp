@@ -662,146 +662,162 @@ using namespace gmsx;
 extern "C" {
 
 int gmsx_csr_generate(int generator, int scale, int degree, int relabel, int threads, gmsx_csr **out) {
-    if (!out || scale < 1 || degree < 1 || relabel < 0 || relabel > 2) return GMSX_ERR_INVALID;
-    if (scale > 30) return GMSX_ERR_OVERFLOW;  // ids are int32 (generator.h:41-48 exits with -31)
-    if (generator != GMSX_GEN_KRONECKER && generator != GMSX_GEN_UNIFORM) return GMSX_ERR_INVALID;
-#ifdef _OPENMP
-    const int saved = omp_get_max_threads();
-    if (threads > 0) omp_set_num_threads(threads);
-#else
-    (void)threads;
-#endif
-    int rc;
-    {
-        Csr g;
+    return gmsx::guard([&]() -> int {
+        if (!out || scale < 1 || degree < 1 || relabel < 0 || relabel > 2) return GMSX_ERR_INVALID;
+        if (scale > 30) return GMSX_ERR_OVERFLOW;  // ids are int32 (generator.h:41-48 exits with -31)
+        if (generator != GMSX_GEN_KRONECKER && generator != GMSX_GEN_UNIFORM) return GMSX_ERR_INVALID;
+    #ifdef _OPENMP
+        const int saved = omp_get_max_threads();
+        if (threads > 0) omp_set_num_threads(threads);
+    #else
+        (void)threads;
+    #endif
+        int rc;
         {
-            PhaseTimer pt;
-            EdgeList el;
-            rc = generator == GMSX_GEN_UNIFORM ? make_uniform(scale, degree, el) : make_rmat(scale, degree, el);
-            pt.lap("generate edge list");
-            if (!rc) rc = build_from_el(el, -1, true, g);
+            Csr g;
+            {
+                PhaseTimer pt;
+                EdgeList el;
+                rc = generator == GMSX_GEN_UNIFORM ? make_uniform(scale, degree, el) : make_rmat(scale, degree, el);
+                pt.lap("generate edge list");
+                if (!rc) rc = build_from_el(el, -1, true, g);
+            }
+            PhaseTimer pf;
+            if (!rc) rc = finish(std::move(g), relabel, out);
+            pf.lap("relabel decision + relabel");
         }
-        PhaseTimer pf;
-        if (!rc) rc = finish(std::move(g), relabel, out);
-        pf.lap("relabel decision + relabel");
-    }
-#ifdef _OPENMP
-    if (threads > 0) omp_set_num_threads(saved);
-#endif
-    return rc;
+    #ifdef _OPENMP
+        if (threads > 0) omp_set_num_threads(saved);
+    #endif
+        return rc;
+    });
 }
 
 int gmsx_csr_generate_rmat(int scale, int degree, double a, double b, double c, int relabel, int threads, gmsx_csr **out) {
-    if (!out || scale < 1 || degree < 1 || relabel < 0 || relabel > 2) return GMSX_ERR_INVALID;
-    if (!(a > 0 && b >= 0 && c >= 0 && a + b + c < 1.0)) return GMSX_ERR_INVALID;
-    if (scale > 30) return GMSX_ERR_OVERFLOW;
-#ifdef _OPENMP
-    const int saved = omp_get_max_threads();
-    if (threads > 0) omp_set_num_threads(threads);
-#else
-    (void)threads;
-#endif
-    int rc;
-    {
-        Csr g;
+    return gmsx::guard([&]() -> int {
+        if (!out || scale < 1 || degree < 1 || relabel < 0 || relabel > 2) return GMSX_ERR_INVALID;
+        if (!(a > 0 && b >= 0 && c >= 0 && a + b + c < 1.0)) return GMSX_ERR_INVALID;
+        if (scale > 30) return GMSX_ERR_OVERFLOW;
+    #ifdef _OPENMP
+        const int saved = omp_get_max_threads();
+        if (threads > 0) omp_set_num_threads(threads);
+    #else
+        (void)threads;
+    #endif
+        int rc;
         {
-            EdgeList el;
-            rc = make_rmat(scale, degree, el, float(a), float(b), float(c));
-            if (!rc) rc = build_from_el(el, -1, true, g);
+            Csr g;
+            {
+                EdgeList el;
+                rc = make_rmat(scale, degree, el, float(a), float(b), float(c));
+                if (!rc) rc = build_from_el(el, -1, true, g);
+            }
+            if (!rc) rc = finish(std::move(g), relabel, out);
         }
-        if (!rc) rc = finish(std::move(g), relabel, out);
-    }
-#ifdef _OPENMP
-    if (threads > 0) omp_set_num_threads(saved);
-#endif
-    return rc;
+    #ifdef _OPENMP
+        if (threads > 0) omp_set_num_threads(saved);
+    #endif
+        return rc;
+    });
 }
 
 int gmsx_csr_from_edges(int64_t num_nodes, int64_t num_edges, const int32_t *src, const int32_t *dst,
                         int symmetrize, int relabel, gmsx_csr **out) {
-    if (!out || num_edges < 0 || (num_edges && (!src || !dst)) || relabel < 0 || relabel > 2) return GMSX_ERR_INVALID;
-    EdgeList el;
-    if (int rc = el.alloc(num_edges)) return rc;
-    if (num_edges) {
-        std::memcpy(el.u.get(), src, size_t(num_edges) * 4);
-        std::memcpy(el.v.get(), dst, size_t(num_edges) * 4);
-    }
-    Csr g;
-    if (int rc = build_from_el(el, num_nodes, symmetrize != 0, g)) return rc;
-    return finish(std::move(g), relabel, out);
+    return gmsx::guard([&]() -> int {
+        if (!out || num_edges < 0 || (num_edges && (!src || !dst)) || relabel < 0 || relabel > 2) return GMSX_ERR_INVALID;
+        EdgeList el;
+        if (int rc = el.alloc(num_edges)) return rc;
+        if (num_edges) {
+            std::memcpy(el.u.get(), src, size_t(num_edges) * 4);
+            std::memcpy(el.v.get(), dst, size_t(num_edges) * 4);
+        }
+        Csr g;
+        if (int rc = build_from_el(el, num_nodes, symmetrize != 0, g)) return rc;
+        return finish(std::move(g), relabel, out);
+    });
 }
 
 int gmsx_csr_load(const char *path, int symmetrize, int relabel, gmsx_csr **out) {
-    if (!path || !out || relabel < 0 || relabel > 2) return GMSX_ERR_INVALID;
-    const std::string p(path), suf = suffix_of(p);
-    Csr g;
-    if (suf == ".sg") {
-        if (int rc = read_sg(p, g)) return rc;
-    } else if (suf == ".el" || suf == ".wel" || suf == ".gr" || suf == ".graph" || suf == ".mtx") {
-        EdgeList el;
-        const int rc = suf == ".el" ? read_el(p, el) : suf == ".wel" ? read_wel(p, el) : suf == ".gr" ? read_gr(p, el)
-                     : suf == ".graph" ? read_metis(p, el) : read_mtx(p, el);
-        if (rc) return rc;
-        if (int rc2 = build_from_el(el, -1, symmetrize != 0, g)) return rc2;
-    } else {
-        return GMSX_ERR_FORMAT;
-    }
-    return finish(std::move(g), relabel, out);
+    return gmsx::guard([&]() -> int {
+        if (!path || !out || relabel < 0 || relabel > 2) return GMSX_ERR_INVALID;
+        const std::string p(path), suf = suffix_of(p);
+        Csr g;
+        if (suf == ".sg") {
+            if (int rc = read_sg(p, g)) return rc;
+        } else if (suf == ".el" || suf == ".wel" || suf == ".gr" || suf == ".graph" || suf == ".mtx") {
+            EdgeList el;
+            const int rc = suf == ".el" ? read_el(p, el) : suf == ".wel" ? read_wel(p, el) : suf == ".gr" ? read_gr(p, el)
+                         : suf == ".graph" ? read_metis(p, el) : read_mtx(p, el);
+            if (rc) return rc;
+            if (int rc2 = build_from_el(el, -1, symmetrize != 0, g)) return rc2;
+        } else {
+            return GMSX_ERR_FORMAT;
+        }
+        return finish(std::move(g), relabel, out);
+    });
 }
 
 int gmsx_csr_save_sg(const gmsx_csr *h, const char *path) {
-    if (!h || !path) return GMSX_ERR_INVALID;
-    std::FILE *f = std::fopen(path, "wb");
-    if (!f) return GMSX_ERR_IO;
-    const Csr &g = h->g;
-    const unsigned char directed = g.directed ? 1 : 0;
-    bool ok = std::fwrite(&directed, 1, 1, f) == 1 && std::fwrite(&g.nnz, 8, 1, f) == 1 &&
-              std::fwrite(&g.n, 8, 1, f) == 1 && std::fwrite(g.off.get(), 8, size_t(g.n + 1), f) == size_t(g.n + 1) &&
-              (g.nnz == 0 || std::fwrite(g.neigh.get(), 4, size_t(g.nnz), f) == size_t(g.nnz));
-    ok = (std::fclose(f) == 0) && ok;
-    return ok ? GMSX_OK : GMSX_ERR_IO;
+    return gmsx::guard([&]() -> int {
+        if (!h || !path) return GMSX_ERR_INVALID;
+        std::FILE *f = std::fopen(path, "wb");
+        if (!f) return GMSX_ERR_IO;
+        const Csr &g = h->g;
+        const unsigned char directed = g.directed ? 1 : 0;
+        bool ok = std::fwrite(&directed, 1, 1, f) == 1 && std::fwrite(&g.nnz, 8, 1, f) == 1 &&
+                  std::fwrite(&g.n, 8, 1, f) == 1 && std::fwrite(g.off.get(), 8, size_t(g.n + 1), f) == size_t(g.n + 1) &&
+                  (g.nnz == 0 || std::fwrite(g.neigh.get(), 4, size_t(g.nnz), f) == size_t(g.nnz));
+        ok = (std::fclose(f) == 0) && ok;
+        return ok ? GMSX_OK : GMSX_ERR_IO;
+    });
 }
 
 int gmsx_csr_from_arrays(int64_t n, const int64_t *offsets, const int32_t *neigh, gmsx_csr **out) {
-    if (!out || n < 0 || !offsets || n > std::numeric_limits<int32_t>::max()) return GMSX_ERR_INVALID;
-    if (offsets[0] != 0) return GMSX_ERR_INVALID;
-    for (int64_t i = 0; i < n; ++i)
-        if (offsets[i + 1] < offsets[i]) return GMSX_ERR_INVALID;
-    const int64_t nnz = offsets[n];
-    if (nnz && !neigh) return GMSX_ERR_INVALID;
-    for (int64_t e = 0; e < nnz; ++e)
-        if (neigh[e] < 0 || neigh[e] >= n) return GMSX_ERR_INVALID;
-    std::unique_ptr<gmsx_csr> h(new (std::nothrow) gmsx_csr);
-    if (!h) return GMSX_ERR_NOMEM;
-    if (int rc = alloc_csr(h->g, n, nnz)) return rc;
-    std::memcpy(h->g.off.get(), offsets, size_t(n + 1) * 8);
-    if (nnz) std::memcpy(h->g.neigh.get(), neigh, size_t(nnz) * 4);
-    *out = h.release();
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (!out || n < 0 || !offsets || n > std::numeric_limits<int32_t>::max()) return GMSX_ERR_INVALID;
+        if (offsets[0] != 0) return GMSX_ERR_INVALID;
+        for (int64_t i = 0; i < n; ++i)
+            if (offsets[i + 1] < offsets[i]) return GMSX_ERR_INVALID;
+        const int64_t nnz = offsets[n];
+        if (nnz && !neigh) return GMSX_ERR_INVALID;
+        for (int64_t e = 0; e < nnz; ++e)
+            if (neigh[e] < 0 || neigh[e] >= n) return GMSX_ERR_INVALID;
+        std::unique_ptr<gmsx_csr> h(new (std::nothrow) gmsx_csr);
+        if (!h) return GMSX_ERR_NOMEM;
+        if (int rc = alloc_csr(h->g, n, nnz)) return rc;
+        std::memcpy(h->g.off.get(), offsets, size_t(n + 1) * 8);
+        if (nnz) std::memcpy(h->g.neigh.get(), neigh, size_t(nnz) * 4);
+        *out = h.release();
+        return GMSX_OK;
+    });
 }
 
 int gmsx_csr_worth_relabelling(const gmsx_csr *h) { return h ? int(worth_relabelling(h->g)) : GMSX_ERR_INVALID; }
 
 int gmsx_csr_relabel_by_degree(const gmsx_csr *h, gmsx_csr **out) {
-    if (!h || !out) return GMSX_ERR_INVALID;
-    std::unique_ptr<gmsx_csr> r(new (std::nothrow) gmsx_csr);
-    if (!r) return GMSX_ERR_NOMEM;
-    if (int rc = relabel_by_degree(h->g, r->g)) return rc;
-    r->relabelled = true;
-    *out = r.release();
-    return GMSX_OK;
+    return gmsx::guard([&]() -> int {
+        if (!h || !out) return GMSX_ERR_INVALID;
+        std::unique_ptr<gmsx_csr> r(new (std::nothrow) gmsx_csr);
+        if (!r) return GMSX_ERR_NOMEM;
+        if (int rc = relabel_by_degree(h->g, r->g)) return rc;
+        r->relabelled = true;
+        *out = r.release();
+        return GMSX_OK;
+    });
 }
 
 int64_t gmsx_csr_num_nodes(const gmsx_csr *h) { return h ? h->g.n : int64_t(GMSX_ERR_INVALID); }
 int gmsx_set_host_threads(int n) {
-#ifdef _OPENMP
-    const int before = omp_get_max_threads();
-    omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
-    return before;
-#else
-    (void)n;
-    return 1;
-#endif
+    return gmsx::guard([&]() -> int {
+    #ifdef _OPENMP
+        const int before = omp_get_max_threads();
+        omp_set_num_threads(n > 0 ? n : omp_get_num_procs());
+        return before;
+    #else
+        (void)n;
+        return 1;
+    #endif
+    });
 }
 
 int64_t gmsx_csr_num_edges(const gmsx_csr *h) { return h ? (h->g.directed ? h->g.nnz : h->g.nnz / 2) : int64_t(GMSX_ERR_INVALID); }

@@ -179,6 +179,9 @@ class Reference:
         if hasattr(L, "ref_kclist_count"):
             L.ref_kclist_count.restype = C.c_uint64
             L.ref_kclist_count.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        if hasattr(L, "ref_kclist_count_wide"):
+            L.ref_kclist_count_wide.restype = C.c_uint64
+            L.ref_kclist_count_wide.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ref_rank.argtypes = [vp, C.c_int, _i32p]
         if hasattr(L, "ref_tc_ordering"):
             L.ref_tc_ordering.argtypes = [vp, C.c_int, _i32p]
@@ -231,6 +234,13 @@ class Reference:
         order 0 = degeneracy (Danisch heap), 1 = degree, 2 = id."""
         p, c = C.c_double(0), C.c_double(0)
         v = int(self.L.ref_kclist_count(g, k, order, C.byref(p), C.byref(c)))
+        return (v, p.value, c.value) if times else v
+
+    def kclist_count_wide(self, g, k, times=False):
+        """The same count with the reference's Preprocess and KcListing::count under a node-parallel loop whose subgraph arrays are sized in
+        64 bits (ref_shim.cc: ref_kclist_count_wide) — for graphs whose hubs overflow the reference's own `new NodeId[count * count]`."""
+        p, c = C.c_double(0), C.c_double(0)
+        v = int(self.L.ref_kclist_count_wide(g, k, C.byref(p), C.byref(c)))
         return (v, p.value, c.value) if times else v
 
     def rank(self, g, order=0):

@@ -257,5 +257,70 @@ uint64_t ref_kclist_count(void *h, int k, int order, double *prep_s, double *cou
     if (count_s) *count_s = t2 - t1;
     return pipeline.count;
 }
+// The same count where the reference's own node-parallel driver cannot run: Parallelize::node sizes a subgraph's edge array as
+// `new NodeId[count * count]` with `uint count` = the node's out-degree (SubGraphBuilder.h:49) — and the DAG InduceDirectedGraph builds
+// points from the LATER-removed (denser) endpoint to the earlier-removed one (apply_order.h:24-27 with ranking = n - removal order,
+// degeneracy_danisch.h:30), so a hub's out-degree is its whole degree: at RMAT scale 26 (max degree ~1 M) count * count wraps in 32 bits,
+// the array is too small and the run segfaults inside KcListing::orderAndCount (observed: gpurun_out/bg/kclist_big.log, dmesg ip in
+// Parallelize::node._omp_fn.0).  Here: the reference's Preprocess (ordering + induced DAG) and the reference's counting kernel
+// KcListing::count, UNCHANGED; only the loop around them — parallelize.h:38-80 — is restated with the edge array sized by a counting pass
+// in 64 bits (the subgraph it hands to KcListing is the one SubGraphBuilder::buildSubGraph(node) describes: the out-neighbours of `node`
+// renumbered in row order, their out-edges among themselves).  tools/make_golden_big.py asserts it equal to ref_kclist_count wherever
+// that one runs (scale <= 24).
+uint64_t ref_kclist_count_wide(void *h, int k, double *prep_s, double *count_s) {
+    Quiet q;
+    CSRGraph &g0 = static_cast<RefGraph *>(h)->g;
+    std::vector<std::string> a = {"ref", "-g", "kronecker", "4"};
+    std::vector<char *> argv;
+    for (auto &s : a) argv.push_back(const_cast<char *>(s.c_str()));
+    CLI::Parser parser;
+    CLI::Args args = parser.parse((int)argv.size(), argv.data());
+    KClique::CLCliqueApp app(args, CLI::Param(std::make_shared<std::string>(std::to_string(k))));
+    using P = KClique::CliqueCountPipeline<true, CSRGraph>;
+    P pipeline(app);
+    pipeline.originalGraph = &g0;
+    double t0 = omp_get_wtime();
+    pipeline.Preprocess();
+    double t1 = omp_get_wtime();
+    CSRGraph &g = pipeline.orderedGraph.value();
+    unsigned long long count = 0;
+    if (k == 1) count = (unsigned long long)g.num_nodes();
+    else if (k == 2) count = (unsigned long long)g.num_edges();
+    else {
+        unsigned core = 0;
+        for (NodeId v = 0; v < g.num_nodes(); v++) core = std::max<unsigned>(core, (unsigned)g.out_degree(v));
+#pragma omp parallel reduction(+ : count)
+        {
+            std::vector<NodeId> new_idx((size_t)g.num_nodes(), -1);
+            KClique::KcListing<CSRGraph> counter(k - 1, core);
+#pragma omp for schedule(dynamic, 1) nowait
+            for (NodeId node = 0; node < g.num_nodes(); node++) {
+                const int64_t cnt = g.out_degree(node);
+                NodeId idx = 0;
+                for (NodeId w : g.out_neigh(node)) new_idx[(size_t)w] = idx++;
+                int64_t edges = 0;
+                for (NodeId w : g.out_neigh(node))
+                    for (NodeId x : g.out_neigh(w)) edges += new_idx[(size_t)x] >= 0 ? 1 : 0;
+                NodeId *out_neighs = new NodeId[(size_t)std::max<int64_t>(edges, 1)];
+                NodeId **out_index = new NodeId *[(size_t)cnt + 1];
+                int64_t cd = 0;
+                int64_t row = 0;
+                out_index[0] = out_neighs;
+                for (NodeId w : g.out_neigh(node)) {
+                    for (NodeId x : g.out_neigh(w))
+                        if (new_idx[(size_t)x] >= 0) out_neighs[cd++] = new_idx[(size_t)x];
+                    out_index[++row] = out_neighs + cd;
+                }
+                for (NodeId w : g.out_neigh(node)) new_idx[(size_t)w] = -1;
+                CSRGraph sub(cnt, out_index, out_neighs, nullptr, nullptr);  // (owns and frees the two arrays, as in SubGraphBuilder.h:137-140)
+                count += counter.count(sub);
+            }
+        }
+    }
+    double t2 = omp_get_wtime();
+    if (prep_s) *prep_s = t1 - t0;
+    if (count_s) *count_s = t2 - t1;
+    return count;
+}
 int ref_omp_threads(void) { return omp_get_max_threads(); }
 }

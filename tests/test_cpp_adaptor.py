@@ -55,8 +55,36 @@ def test_gpus_launcher_reaps_failed_ranks_instead_of_hanging(capi):
     assert "a rank ended with status 3" in r.stderr  # (rank 0's own "no HIP device" line may or may not get out before it is stopped)
     assert set(glob.glob("/tmp/gmsx_driver_id_*")) == before
     r = subprocess.run([exe, "tc", "-g", "kronecker", "6", "--gpus", "2"], capture_output=True, text=True, timeout=60,
-                       env=dict(os.environ, ROCPROF_TEST_MARKER="1"))
+                       env=dict(os.environ, ROCP_TOOL_LIBRARIES="/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so"))
     assert r.returncode == 6 and "profiler library is preloaded" in r.stderr
+    # a user's own ROCPROF_* configuration variable is not a preload: the ranks are forked (and fail for lack of a device)
+    r = subprocess.run([exe, "tc", "-g", "kronecker", "6", "--gpus", "2"], capture_output=True, text=True, timeout=60,
+                       env=dict(os.environ, ROCPROF_OUTPUT_PATH="/tmp/x"))
+    assert r.returncode == 3, (r.returncode, r.stderr)
+
+
+def test_gpus_supervisor_passes_a_stop_signal_on(capi):
+    """SIGTERM to the supervisor (a `timeout`, a scheduler cancel) stops the ranks too — they would otherwise stay behind, blocked in a
+    collective without a timeout, holding their GPUs.  GMSX_DRIVER_TEST_HANG parks the ranks like a blocked collective would."""
+    import signal
+    import time
+    exe = os.path.join(ROOT, "gms_amd", "lib", "gmsx_driver")
+    p = subprocess.Popen([exe, "tc", "-g", "kronecker", "6", "--gpus", "2"], env=dict(os.environ, GMSX_DRIVER_TEST_HANG="1"),
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        time.sleep(1.0)
+        kids = subprocess.run(["ps", "-o", "pid=", "--ppid", str(p.pid)], capture_output=True, text=True).stdout.split()
+        assert len(kids) == 2, kids
+        p.send_signal(signal.SIGTERM)
+        _, err = p.communicate(timeout=20)
+        assert p.returncode == 128 + signal.SIGTERM, (p.returncode, err)
+        assert "stopping the 2 rank(s)" in err
+        time.sleep(0.2)
+        for k in kids:
+            assert not os.path.exists("/proc/%s" % k), "rank %s outlived the supervisor" % k
+    finally:
+        if p.poll() is None:
+            p.kill()
 
 
 @pytest.mark.gpu

@@ -9,6 +9,9 @@
                                                    # (CliqueCountPipeline<true>: getDegeneracyOrderingDanischHeap + InduceDirectedGraph +
                                                    # Par::NP_kclisting, bench_helper.h:33-38,71-77) -> field kc4_true; where the set-based
                                                    # kc4 (= 24 * kc4_true) exists it is asserted equal
+    python tools/make_golden_big.py kclist-wide 26 # the same count where the reference's own node-parallel loop overflows (`new NodeId[count*count]`,
+                                                   # uint count = a hub's out-degree: segfault at scale 26): reference Preprocess + reference
+                                                   # KcListing::count under the loop of oracle/ref_shim.cc ref_kclist_count_wide (64-bit sizes)
     python tools/make_golden_big.py bk-rmat 21 56  # BASELINE configs[3]: the com-Orkut-shaped R-MAT (A=.45 B=C=.22) of the gmsx loader,
                                                    # written as .sg (gmsx_csr_save_sg), read back by the reference (cli.h:96 `-f`,
                                                    # reader.h:252-305) and enumerated by BkEppsteinPar::mceBench<RoaringGraph>
@@ -88,8 +91,15 @@ def main():
         field = "kc4_true"
         how = ("kClist CliqueCountPipeline<true,CSRGraph>: Preprocess (DanischHeap degeneracy order + InduceDirectedGraph, %.0f s) + "
                "Par::NP_kclisting k=4 (%.0f s)" % (prep_s, count_s))
+    elif what == "kclist-wide":
+        val, prep_s, count_s = R.kclist_count_wide(g, 4, times=True)
+        field = "kc4_true"
+        how = ("kClist: the reference's CliqueCountPipeline::Preprocess (DanischHeap degeneracy order + InduceDirectedGraph, %.0f s) + the "
+               "reference's KcListing::count per node subgraph (%.0f s) under the node-parallel loop of oracle/ref_shim.cc "
+               "ref_kclist_count_wide — Par::NP_kclisting itself segfaults on this graph (uint `count*count` in SubGraphBuilder.h:49 wraps "
+               "for a hub); equal to it wherever it runs (scales 10-20 checked)" % (prep_s, count_s))
     else:
-        raise SystemExit("what = tc | kc4 | bk | kclist")
+        raise SystemExit("what = tc | kc4 | bk | kclist | kclist-wide")
     dt = time.time() - t0
     R.free(g)
     key = "kronecker-%d-%d-relabel" % (scale, deg)
