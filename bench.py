@@ -702,6 +702,8 @@ def main():
                          "rows materialise the members below v of every light pivot — the per-edge decisions — and are reused by every pass; every pass "
                          "still performs every membership probe)",
         "graph_device_bytes": {"base": int(base_bytes), "with_tc_containers": int(g.device_bytes)},
+        # N > 1: every rank builds the triangle-count containers of ITS pivots only (gmsx_graph_upload_csr_shard); rank 0's figures above
+        "upload": {"sharded": world > 1, "shard": [rank, world] if world > 1 else None},
     }
     if comm is not None:
         comm.finalize()

@@ -641,7 +641,7 @@ __global__ void k_ledge_fill(int64_t first, int64_t end, const int32_t *__restri
     for (int i = tsplit[u]; i < tl; ++i) {
         const int32_t v = tadj[tb + i];
         if (dplus[v] >= kHeavy) continue;
-        if (nparts <= 1 || e % nparts == part) {
+        if (nparts <= 1 || shard_of(e, nparts) == part) {  // (every stripe of nparts consecutive edges has one member per shard: slot e / nparts)
             const unsigned long long tu = (unsigned long long)tb | ((unsigned long long)i << 40);  // the tail ids of u in front of v
             const unsigned long long hv = (unsigned long long)hoff[v] | ((unsigned long long)(hoff[v + 1] - hoff[v]) << 40);
             const unsigned long long tv = (unsigned long long)toff[v] | ((unsigned long long)(toff[v + 1] - toff[v]) << 40);
@@ -1396,7 +1396,10 @@ static int build_tc_sets(gmsx_graph *g) {
             if (int rc = exclusive_scan_i64(ecnt, ebeg, nl + 1, s)) return rc;
             GMSX_HIP(hipMemcpy(&g->ledge_total, ebeg + nl, sizeof(int64_t), hipMemcpyDeviceToHost));
             const int np = g->shard_nparts > 1 ? g->shard_nparts : 1, pp = g->shard_nparts > 1 ? g->shard_part : 0;
-            g->n_ledge = g->ledge_total > pp ? (g->ledge_total - pp + np - 1) / np : 0;
+            {
+                const int64_t full = g->ledge_total / np, rem = g->ledge_total % np;  // whole stripes of np edges + this shard's share of the partial one
+                g->n_ledge = np <= 1 ? g->ledge_total : full + (((full & 1) ? np - 1 - pp : pp) < rem ? 1 : 0);
+            }
             if (int rc = dmalloc(&g->ledge, 2 * g->n_ledge + 2, g)) return rc;
             hipLaunchKernelGGL(k_ledge_fill, dim3(unsigned(nl / 256 + 1)), dim3(256), 0, s, n_heavy, n_work, g->order, g->hoff, g->toff, g->tadj, g->tsplit, g->dplus, ebeg,
                                np, pp, g->ledge);

@@ -101,7 +101,7 @@ struct gmsx_graph {
     // (rank id >= inline_limit, d+ < kHeavy) — as self-contained 32-byte records: where the hub part and the tail part of u's row and of
     // v's row lie in hadj / tadj (first id, 40 bits | ids << 40; of u's tail part only the ids in front of v: nothing else can be in N+(v)).
     // Both rows are short (< 64 ids), so the edge is ONE all-pairs comparison in registers: no LDS, no per-pivot state, every edge
-    // independent.  Edge e of the (deterministic) list belongs to shard e % nparts; a sharded upload keeps its own at slot e / nparts.
+    // independent.  Edge e of the (deterministic) list belongs to shard shard_of(e, nparts) — the pivots' rule; a sharded upload keeps its own at slot e / nparts.
     uint4 *ledge = nullptr;
     int64_t n_ledge = 0, ledge_total = 0;
     int32_t inline_limit = 0;            // light pivots hand their edges to members of rank id < inline_limit (and to heavy ones) as INLINE ROWS

@@ -604,7 +604,13 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_items(
+// Seven waves per SIMD (72 registers), not eight (64): the loop around the scans carries the per-lane total, the queue / pipeline state and
+// what the compiler keeps of the staging addresses; at 64 registers it spilled 42 of them to scratch — 32 KB of scratch traffic per item,
+// +24 GB beyond the L2 per pass at scale 26 — and the pass is bound by memory, not by an eighth of the wave slots (72.5 -> 71.4 ms).
+#ifndef GMSX_TC_ITEMS_MIN_WAVES
+#define GMSX_TC_ITEMS_MIN_WAVES 7
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_TC_ITEMS_MIN_WAVES, 8))) void k_tc_items(
     const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint32_t *__restrict__ spool, const uint32_t *__restrict__ tpool,
     const unsigned long long *__restrict__ htask, const unsigned long long *__restrict__ ttask, const gmsx_tc_item *__restrict__ hitem, int n_hitems,
     const gmsx_tc_item *__restrict__ titem, int n_titems, int tail_share, unsigned int *__restrict__ qhead, unsigned long long *__restrict__ acc) {
@@ -639,19 +645,22 @@ struct LightRows {
 struct LightRec {
     uint4 r0, r1;
 };
-__global__ __launch_bounds__(256) void k_tc_light(const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint4 *__restrict__ ledge, int64_t first,
-                                                  int64_t stride, int64_t count, unsigned long long *__restrict__ acc) {
+// The k-th edge of shard `part` of `nparts` in a FULL list is edge k * nparts + (k odd ? nparts - 1 - part : part) — shard_of() of the edge's
+// index, the rule the pivots are sharded by (a sharded upload holds its edges densely: nparts = 1 here).
+__global__ __launch_bounds__(256) void k_tc_light(const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint4 *__restrict__ ledge, int nparts,
+                                                  int part, int64_t count, unsigned long long *__restrict__ acc) {
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, sub = lane & 15;
     const int64_t ngroups = int64_t(gridDim.x) * 16, g0 = int64_t(blockIdx.x) * 16 + (tid >> 4);
     const int64_t trips = (count + ngroups - 1) / ngroups;  // the same for every group (uniform loop): a group without an edge runs on empty rows
     auto load_rec = [&](int64_t t) -> LightRec {
         const int64_t k = g0 + t * ngroups;
-        const int64_t e = k < count ? first + k * stride : first;  // (count > 0 here)
+        const int64_t kk = k < count ? k : 0;  // (count > 0 here)
+        const int64_t e = nparts <= 1 ? kk : kk * nparts + ((kk & 1) ? nparts - 1 - part : part);
         LightRec r;
         r.r0 = ledge[2 * e];
         r.r1 = ledge[2 * e + 1];
-        if (k >= count || t >= trips) {  // lengths 0: everything below degenerates to sentinels
+        if (k >= count) {  // lengths 0: everything below degenerates to sentinels
             r.r0.y &= 0xffu;
             r.r0.w &= 0xffu;
             r.r1.y &= 0xffu;
@@ -979,8 +988,43 @@ static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *part
     // tc_passes resident at a time, rebuilt between the passes (untimed like every build; kernel_ms is the sum of the passes' kernels); a
     // sharded call builds exactly its shard.
     if (nparts > 1) {
-        if (int rc = ensure_tc_shard(g, part, nparts)) return rc;
-        return tc_one(g, part, nparts, partial, st);
+        // A shard of a graph whose containers need tc_passes passes: the shard itself may not fit either (nparts < tc_passes).  It is cut
+        // into J sub-shards of nparts * J — with J even (or 1) the snake rule nests: sub-shard a * nparts + (a even ? part : nparts - 1 - part),
+        // a = 0 … J-1, lies inside shard `part` of nparts, and the J of them cover it — built and counted one after the other.  "Slower,
+        // never refused": J doubles while a sub-shard does not fit.  On a failure the handle goes back to (pass 0 of tc_passes), not built.
+        auto restore = [&](int rc) {
+            gmsx_graph *m = const_cast<gmsx_graph *>(g);
+            if (m->tc_ready && m->shard_part == 0 && m->shard_nparts == m->tc_passes) return rc;
+            (void)ensure_tc_shard(g, 0, g->tc_passes);  // (leaves shard_part / shard_nparts at (0, tc_passes) whether or not the build succeeds)
+            return rc;
+        };
+        int J = nparts >= g->tc_passes ? 1 : (g->tc_passes + nparts - 1) / nparts;
+        if (J > 1 && (J & 1)) ++J;
+        for (;; J *= 2) {
+            uint64_t total = 0;
+            gmsx_stats sum{};
+            int rc = GMSX_OK;
+            for (int a = 0; a < J && rc == GMSX_OK; ++a) {
+                const int sub = a * nparts + ((a & 1) ? nparts - 1 - part : part);
+                rc = ensure_tc_shard(g, sub, nparts * J);
+                if (rc) break;
+                uint64_t pp = 0;
+                gmsx_stats sp{};
+                rc = tc_one(g, sub, nparts * J, &pp, st ? &sp : nullptr);
+                total += pp;
+                sum.kernel_ms += sp.kernel_ms;
+                sum.setup_ms += sp.setup_ms;
+                sum.units += sp.units;
+                sum.probes += sp.probes;
+                sum.stream_bytes += sp.stream_bytes;
+                sum.launches += sp.launches;
+            }
+            if (rc == GMSX_ERR_DEVICE_MEM && nparts * J <= (1 << 20)) continue;  // finer sub-shards
+            if (rc) return restore(rc);
+            *partial = total;
+            if (st) *st = sum;
+            return GMSX_OK;
+        }
     }
     uint64_t total = 0;
     gmsx_stats sum{};
@@ -1032,9 +1076,14 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     const int64_t cap_blocks = int64_t(cus) * 16;
     const char *only = std::getenv("GMSX_TC_ONLY");
     const bool run_light = !only || std::strcmp(only, "light") == 0;
-    // the light edges of this call: a full upload holds every edge (shard = e % nparts), a sharded one its own, densely
+    // the light edges of this call: a full upload holds every edge (shard = shard_of(e, nparts)), a sharded one its own, densely
     const bool strided = nparts > 1 && g->shard_nparts == 1;
-    const int64_t cnt_light = !run_light ? 0 : strided ? (g->n_ledge > part ? (g->n_ledge - part + nparts - 1) / nparts : 0) : g->n_ledge;
+    const int64_t cnt_light = [&]() -> int64_t {
+        if (!run_light) return 0;
+        if (!strided) return g->n_ledge;
+        const int64_t full = g->n_ledge / nparts, rem = g->n_ledge % nparts;  // whole stripes + the members of the last, partial one
+        return full + (((full & 1) ? nparts - 1 - part : part) < rem ? 1 : 0);
+    }();
     // LAUNCH PLAN (round 4).  k_tc_items — one persistent launch over the hub and the tail items — then k_tc_light, both on the launch stream.
     // GMSX_TC_OVERLAP=1 puts k_tc_light on a side stream behind the item kernel (its workgroups need no LDS and start wherever a persistent
     // workgroup has left): measured 72.0-72.4 ms against 71.3-71.6 one after the other at scale 26 — the items kernel is bound by memory and
@@ -1066,7 +1115,7 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     if (persist) {
         if (n_hitems + n_titems > 0) {
             static const int share_env = [] { const char *e = std::getenv("GMSX_TC_TAIL_SHARE"); return e ? std::atoi(e) : -1; }();
-            static const int wgs_env = [] { const char *e = std::getenv("GMSX_TC_ITEM_WGS"); return e ? std::atoi(e) : 8; }();
+            static const int wgs_env = [] { const char *e = std::getenv("GMSX_TC_ITEM_WGS"); return e ? std::atoi(e) : GMSX_TC_ITEMS_MIN_WAVES; }();  // workgroups per CU
             // workgroups that START on the tail queue, of every 8 (the queues drain into each other, so this only shapes the mix)
             const int tail_share = share_env >= 0 ? std::min(share_env, 8) : (n_titems == 0 ? 0 : n_hitems == 0 ? 8 : 2);
             const int64_t want = (n_hitems + n_titems + kGrab - 1) / kGrab;
@@ -1087,8 +1136,8 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     }
     if (cnt_light > 0) {
         const int64_t blocks = std::min<int64_t>((cnt_light + 15) / 16, int64_t(cus) * 8);
-        hipLaunchKernelGGL(k_tc_light, dim3(unsigned(blocks)), dim3(256), 0, side_light ? c.side[1] : s, g->hadj, g->tadj, g->ledge, int64_t(strided ? part : 0),
-                           int64_t(strided ? nparts : 1), cnt_light, acc);
+        hipLaunchKernelGGL(k_tc_light, dim3(unsigned(blocks)), dim3(256), 0, side_light ? c.side[1] : s, g->hadj, g->tadj, g->ledge, strided ? nparts : 1,
+                           strided ? part : 0, cnt_light, acc);
         ++launches;
     }
     for (int i = 0; i < 2; ++i)

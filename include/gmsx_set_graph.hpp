@@ -383,6 +383,7 @@ class HipGraphT {
     const int64_t *offsets() const { return off_; }
     const SetElement *neighbors() const { return adj_; }
 
+    std::pair<int, int> upload_shard() const { return shard_; }  // (part, nparts) of the device copy ({0, 1} = the whole graph)
     // device handle; failures follow the reference's convention: message + exit (gapbs/reader.h:45,228; cli/cli.h:159-171) —
     // nothing is thrown across the C-ABI
     const gmsx_graph *device() const {
@@ -426,7 +427,8 @@ class HipGraphT {
     }
     void try_upload() {
         release_device();
-        upload_rc_ = gmsx_graph_upload_shard(n_, off_, adj_, flags_, default_upload_shard().first, default_upload_shard().second, &dev_);
+        shard_ = default_upload_shard();
+        upload_rc_ = gmsx_graph_upload_shard(n_, off_, adj_, flags_, shard_.first, shard_.second, &dev_);
         if (upload_rc_ != GMSX_OK) dev_ = nullptr;
     }
     void release_device() {
@@ -444,6 +446,7 @@ class HipGraphT {
     gmsx_graph *dev_ = nullptr;
     int upload_rc_ = GMSX_OK;
     uint32_t flags_ = GMSX_UPLOAD_DEFAULT;
+    std::pair<int, int> shard_{0, 1};  // (part, nparts) the device copy was uploaded with
 };
 
 using HipSetGraph = HipGraphT<SortedSpanSet>;       // the SortedSetGraph flavour       (set_graph.h:235)
@@ -453,10 +456,16 @@ using HipSetRefGraph = HipGraphT<SortedSpanRef>;    // the SetGraph<SortedSetRef
 // ---- whole-graph algorithms: the hot path, forwarded to the device ---------------------------------------------------
 
 // GMS::TriangleCount::Par::count_total / Seq::count_total (triangle_count/parallel/total.h:7-24, sequential/total.h:7-23)
+// A graph uploaded as shard (part, nparts) of a multi-GPU run (default_upload_shard) holds the triangle-count containers of that shard
+// only: count_total then returns the shard's PARTIAL count (gmsx_tc_partial) — the rank's term of the reference's reduction(+:total),
+// which the caller sums over the ranks (gmsx_comm_allreduce_u64), as gmsx_driver --gpus does.
 template <class S>
 inline size_t count_total(const HipGraphT<S> &g) {
     uint64_t t = 0;
-    detail::check(gmsx_tc_total(g.device(), GMSX_TC_AUTO, &t, nullptr), "gmsx_tc_total");
+    if (g.upload_shard().second > 1)
+        detail::check(gmsx_tc_partial(g.device(), GMSX_TC_AUTO, g.upload_shard().first, g.upload_shard().second, &t, nullptr), "gmsx_tc_partial");
+    else
+        detail::check(gmsx_tc_total(g.device(), GMSX_TC_AUTO, &t, nullptr), "gmsx_tc_total");
     return size_t(t);
 }
 // GMS::TriangleCount::Par::vertex_count2 / vertex_count2_once / Seq::vertex_count2 (parallel/vertex.h:14-49)

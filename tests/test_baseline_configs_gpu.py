@@ -132,11 +132,31 @@ def test_north_star_scale26_reference_golden(gpu):
     o3, c3 = g.kclique_count(3)
     assert c3 == t
     o4, c4 = g.kclique_count(4)                                    # north_star: "bit-exact triangle and k-clique counts on scale-26"
-    assert o4 == (24 * c4) & ((1 << 64) - 1)
+    # golden: the reference's kClist (CliqueCountPipeline::Preprocess + KcListing::count, each clique once — tools/make_golden_big.py
+    # kclist / kclist-wide; the set-based CliqueCount cannot reach this size: 5 843 s at scale 22, x7 per +2 scale)
+    if rec and "kc4_true" in rec:
+        assert c4 == rec["kc4_true"], (c4, rec["kc4_true"])
+        assert o4 == (24 * rec["kc4_true"]) & ((1 << 64) - 1)
     assert sum(g.kclique_partial(4, p, 5) for p in range(5)) == c4
     g.free()
     if not (rec and "triangles" in rec):
         pytest.fail("tests/golden/graphs.json holds no reference golden for scale 26 (run tools/make_golden_big.py tc 26)")
+
+
+def test_scale24_kclique4_reference_kclist_golden(gpu):
+    """k = 4 at RMAT scale 24 against the reference's OWN kClist pipeline (Par::NP_kclisting on the degeneracy DAG, 2 804 s on 8 host
+    threads: tests/golden/graphs.json kc4_true) — the two reference paths agree wherever both run (set-based kc4 = 24 * kc4_true at scales
+    16-22, asserted by tools/make_golden_big.py), so this pins the device beyond the set-based recursion's reach."""
+    threads(gpu)
+    rec = GRAPHS["kronecker-24-16-relabel"]
+    assert rec["kc4_true"] == 879950888260
+    csr = gpu.HostCSR.generate("kronecker", 24)
+    assert (csr.num_nodes, csr.num_edges) == (rec["n"], rec["m"])
+    g = gpu.DeviceGraph.from_csr(csr)
+    o4, c4 = g.kclique_count(4)
+    assert c4 == rec["kc4_true"] and o4 == 24 * c4
+    assert sum(g.kclique_partial(4, p, 3) for p in range(3)) == c4
+    g.free()
 
 
 def test_config5_scale27_eight_shards_on_one_gpu(gpu):

@@ -135,6 +135,37 @@ def test_oracle_equals_compiled_reference(oracle, reference, spec):
         reference.free(g)
 
 
+@pytest.mark.parametrize("spec", [("kronecker", 10, 16), ("kronecker", 12, 16), ("uniform", 11, 12), ("kronecker", 8, 40)])
+def test_reference_kclist_agrees_with_its_set_based_count(oracle, reference, spec):
+    """The reference has two k-clique paths: the set-based CliqueCount (k! x each clique; what the hot path replaces) and kClist on the
+    degeneracy DAG (each clique once; its source of true counts).  They agree — which is what lets kClist pin the device at
+    sizes the set-based recursion cannot reach (tests/golden/graphs.json kc4_true at scales 24 / 26) — and so does the oracle; the
+    64-bit-safe driver loop of oracle/ref_shim.cc (ref_kclist_count_wide) equals the reference's own Par::NP_kclisting."""
+    kind, scale, deg = spec
+    g = reference.generate(kind, scale, deg, relabel=True)
+    try:
+        off, ng = reference.csr(g)
+        for k, f in ((3, 6), (4, 24), (5, 120)):
+            ordered = reference.kclique(g, k, 1)
+            assert ordered % f == 0
+            assert reference.kclist_count(g, k) == reference.kclist_count_wide(g, k) == ordered // f == oracle.kclique(off, ng, k) // f
+        assert reference.kclist_count(g, 4, order=1) == reference.kclist_count(g, 4, order=0)  # any acyclic orientation
+    finally:
+        reference.free(g)
+
+
+def test_golden_kc4_true_is_kc4_over_24():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graphs.json")) as f:
+        graphs = json.load(f)
+    both = [k for k, r in graphs.items() if "kc4" in r and "kc4_true" in r]
+    assert {"kronecker-16-16-relabel", "kronecker-18-16-relabel", "kronecker-20-16-relabel", "kronecker-22-16-relabel"} <= set(both)
+    for k in both:
+        assert graphs[k]["kc4"] == 24 * graphs[k]["kc4_true"], k
+    assert graphs["kronecker-24-16-relabel"]["kc4_true"] == 879950888260
+
+
 def test_set_ops_against_compiled_reference(oracle, reference):
     rng = np.random.default_rng(7)
     for _ in range(200):
