@@ -1173,47 +1173,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
         __syncthreads();
         // ---- the row jobs: j < c -> candidate i = j (hits into Cadj); else CSR position p = j - c (in-neighbours only; hits into XT column p)
         const int njobs = int(min(int64_t(c) + deg, (int64_t(piece_i) + 1) * kBkPieceJobs));  // this piece: jobs [piece_i * kBkPieceJobs, njobs)
-        auto job_id = [&](int j) -> int32_t {  // the rank id whose row job j streams, -1 = none
-            if (j >= njobs) return -1;
-            if (j < c) return j < hc ? int32_t(hadj[vhb + j]) : tadj[vtb + (j - hc)];
-            const int32_t nw = newid[adj[ob + (j - c)]];
-            return nw > v ? nw : -1;
-        };
-        auto job_rows = [&](int32_t a) -> BkRowJob {
-            BkRowJob r{a, 0, 0, 0, 0};
-            if (a >= 0) {
-                r.hs = hoff[a];
-                r.he = hoff[a + 1];
-                r.ts = toff[a];
-                r.te = toff[a + 1];
-            }
+        // THE JOB PIPELINE.  A job's row sits behind a chain of dependent fetches: CSR entry -> rank id (newid) -> extents (hoff / toff)
+        // -> the row.  Three stages run a trip apart per lane group — trip t issues  raw(t+3) | newid(raw(t+2)) | extents(id(t+1))  and
+        // streams the rows of job t — under two rules without which hipcc serialises them again (rounds 2-3: 33 of the kernel's 42 waits
+        // were vmcnt(0), the kernel 76 % waiting):
+        //   * every load is UNCONDITIONAL (clamped index, the value dropped afterwards, written as selects — behind an `if` the compiler
+        //     sinks the load into the branch): a load under a branch cannot be counted, and every later wait becomes vmcnt(0);
+        //   * a loaded value is first TOUCHED one trip later (the stage registers hold raw loaded words; the selects that turn them into a
+        //     job id / an extent run at the top of the next trip): a use right behind the load is a wait right behind the load.
+        const int j0 = piece_i * kBkPieceJobs + grp;  // this group's jobs: j0, j0 + 16, … < njobs
+        struct RawLoad { int32_t xh, xt, xa; };
+        struct ExtLoad { int64_t hs, he, ts, te; };
+        auto load_raw = [&](int j) -> RawLoad {
+            const int jj = max(min(j, njobs - 1), 0);
+            RawLoad r;
+            r.xh = int32_t(hadj[vhb + min(jj, max(hc - 1, 0))]);  // (hadj / tadj end in padding: an empty part reads it)
+            r.xt = tadj[vtb + min(max(jj - hc, 0), max(tc - 1, 0))];
+            r.xa = adj[ob + min(max(jj - c, 0), max(deg - 1, 0))];
             return r;
         };
-        // A job's id is itself a chain of two fetches (CSR entry -> rank id): resolved in ONE iteration it stalls the group for a full round
-        // trip in the middle of every trip (vmcnt waits in order: the new load's value is needed at once, so everything in flight is waited
-        // for).  Split: raw(j) = the CSR entry (or, for a candidate job, its rank id, tagged), resolve() = the rank-id lookup one trip later.
-        auto job_raw = [&](int j) -> int32_t {  // >= 0: old id of CSR position j - c; <= -2: candidate job, rank id = -(x) - 2; -1: none
-            if (j >= njobs) return -1;
-            if (j < c) return -(j < hc ? int32_t(hadj[vhb + j]) : tadj[vtb + (j - hc)]) - 2;
-            return adj[ob + (j - c)];
+        auto fin_raw = [&](const RawLoad &r, int j) -> int32_t {  // >= 0: old id of CSR position j - c; <= -2: candidate job, rank id = -(x) - 2; -1: none
+            const int32_t cand = -(j < hc ? r.xh : r.xt) - 2;
+            const int32_t x = j < c ? cand : r.xa;
+            return (j < j0 || j >= njobs) ? -1 : x;
         };
-        auto job_resolve = [&](int32_t raw) -> int32_t {
-            if (raw == -1) return -1;
-            if (raw <= -2) return -(raw + 2);
-            const int32_t nw = newid[raw];
-            return nw > v ? nw : -1;
+        auto fin_id = [&](int32_t nw, int32_t raw) -> int32_t {  // the rank id whose row the job streams, -1 = none
+            const int32_t in = nw > v ? nw : -1;
+            return raw >= 0 ? in : (raw == -1 ? -1 : -(raw + 2));
         };
-        // four stages per group, a trip apart: trip t issues  raw(t+4) | resolve(raw(t+3)) | extents(id(t+2)) | the rows of job t
-        // — every load of a trip is independent of the others of that trip
-        int j = piece_i * kBkPieceJobs + grp;
-        BkRowJob cur = job_rows(job_id(j));
-        BkRowJob nxt = job_rows(job_id(j + 16));
-        int32_t id2 = job_id(j + 32);
-        int32_t raw3 = job_raw(j + 48);
-        for (; j < njobs; j += 16) {
-            const int32_t raw4 = job_raw(j + 64);
-            const int32_t id3 = job_resolve(raw3);
-            const BkRowJob nx2 = job_rows(id2);
+        auto load_ext = [&](int32_t a) -> ExtLoad {
+            const int32_t aa = max(a, 0);
+            return ExtLoad{hoff[aa], hoff[aa + 1], toff[aa], toff[aa + 1]};
+        };
+        RawLoad l_raw = load_raw(j0 - 16);        // (jobs in front of j0 do not exist: fin_raw drops them)
+        int32_t raw_n = -1, l_nw = 0;             // the raw job whose newid is in flight, and that word
+        int32_t id_e = -1;                        // the job id whose extents are in flight
+        ExtLoad l_ext = load_ext(-1);
+        for (int j = j0 - 48; j < njobs; j += 16) {
+            // top of the trip: what the previous trip loaded becomes values
+            const int32_t raw2 = fin_raw(l_raw, j + 32);
+            const int32_t id1 = fin_id(l_nw, raw_n);
+            const BkRowJob cur{id_e, id_e >= 0 ? l_ext.hs : 0, id_e >= 0 ? l_ext.he : 0, id_e >= 0 ? l_ext.ts : 0, id_e >= 0 ? l_ext.te : 0};
+            // … and the next round of fetches goes out before this trip's rows
+            l_raw = load_raw(j + 48);
+            l_nw = newid[max(raw2, 0)];
+            raw_n = raw2;
+            l_ext = load_ext(id1);
+            id_e = id1;
 #if defined(GMSX_BK_AB) && GMSX_BK_AB == 1  // A/B builds (wrong counts): 1 = the job pipeline alone, 2 = + the row loads without their probes
             if (cur.a == -12345) {
 #else
@@ -1306,10 +1312,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
                 }
 #endif
             }
-            cur = nxt;
-            nxt = nx2;
-            id2 = id3;
-            raw3 = raw4;
         }
     }
 }

@@ -72,17 +72,43 @@ __device__ __forceinline__ kc_u4u kc_load8(const uint16_t *row, int j, int l) {
     return p;
 }
 
-// 16-bit list container [row, row + l) (l even, padded with 0xFFFF) of one member; sub = lane within the 16-lane group
+// 16-bit list container [row, row + l) (l even, padded with 0xFFFF) of one member; sub = lane within the 16-lane group.
+// A ring of kKcDepth loads per lane, refilled before the oldest one is probed; the loads are UNCONDITIONAL (an index past the row is
+// clamped to its last pair: in bounds, probed never) so that the waits are counted — under a branch every wait is vmcnt(0) and the
+// group has ONE load in flight: long member rows (the pivots of the big bins have members of d+ up to 3000) were a chain of round trips.
+#ifndef GMSX_KC_DEPTH
+#define GMSX_KC_DEPTH 2  // (measured, k = 4 at scale 22 / 24: depth 2 22.6 / 143.4 ms, depth 3 24.9 / 154.5, depth 4 25.1 / 155.2 — the registers of a deeper ring cost a wave per SIMD, and the BUILD waits on its LDS probes, not on the row loads)
+#endif
+static constexpr int kKcDepth = GMSX_KC_DEPTH;
+__device__ __forceinline__ kc_u4u kc_cut8(kc_u4u p, int valid) {  // ids behind the row become 0xFFFF, which is never in the bitmap (valid even, >= 2)
+    if (valid < 8) {
+        if (valid < 6) p.z = 0xffffffffu;
+        if (valid < 4) p.y = 0xffffffffu;
+        p.w = 0xffffffffu;
+    }
+    return p;
+}
+__device__ __forceinline__ void kc_stream_list_from(const uint16_t *__restrict__ row, int l, int j0, int sub, const uint32_t *bm, const unsigned short *pre,
+                                                    uint32_t *orow) {
+    (void)sub;
+    if (l <= 0) return;  // uniform per group
+    kc_u4u p[kKcDepth];
+    const int jmax = l - 2;
+#pragma unroll
+    for (int k = 0; k < kKcDepth; ++k) p[k] = *reinterpret_cast<const kc_u4u *>(row + min(j0 + 128 * k, jmax));
+    for (int j = j0; j < l; j += 128 * kKcDepth) {  // the lanes of a group differ by at most one step
+#pragma unroll
+        for (int k = 0; k < kKcDepth; ++k) {
+            const kc_u4u cur = p[k];
+            const int jc = j + 128 * k;
+            p[k] = *reinterpret_cast<const kc_u4u *>(row + min(jc + 128 * kKcDepth, jmax));
+            if (jc < l) kc_probe8(bm, pre, orow, kc_cut8(cur, l - jc));
+        }
+    }
+}
 __device__ __forceinline__ void kc_stream_list(const uint16_t *__restrict__ row, int l, int sub, const uint32_t *bm, const unsigned short *pre,
                                                uint32_t *orow) {
-    int j = sub * 8;
-    for (; j + 128 < l; j += 256) {
-        const kc_u4u p = kc_load8(row, j, l);
-        const kc_u4u q = kc_load8(row, j + 128, l);
-        kc_probe8(bm, pre, orow, p);
-        kc_probe8(bm, pre, orow, q);
-    }
-    if (j < l) kc_probe8(bm, pre, orow, kc_load8(row, j, l));
+    kc_stream_list_from(row, l, sub * 8, sub, bm, pre, orow);
 }
 
 __device__ __forceinline__ void kc_and_word(uint32_t x, uint32_t pivot_word, int k, const unsigned short *pre, uint32_t *orow) {
@@ -101,24 +127,26 @@ __device__ __forceinline__ void kc_and4(uint4 p, uint4 q, int j, const unsigned 
     kc_and_word(p.z & q.z, q.z, j + 2, pre, orow);
     kc_and_word(p.w & q.w, q.w, j + 3, pre, orow);
 }
+__device__ __forceinline__ void kc_stream_bitset_from(const uint32_t *__restrict__ brow, int nw, int j0, const uint32_t *bm, const unsigned short *pre,
+                                                      uint32_t *orow) {
+    if (nw <= 0) return;
+    uint4 p[kKcDepth];
+    const int jmax = nw - 4;  // nw is a multiple of 4
+#pragma unroll
+    for (int k = 0; k < kKcDepth; ++k) p[k] = *reinterpret_cast<const uint4 *>(brow + min(j0 + 64 * k, jmax));
+    for (int j = j0; j < nw; j += 64 * kKcDepth) {
+#pragma unroll
+        for (int k = 0; k < kKcDepth; ++k) {
+            const uint4 cur = p[k];
+            const int jc = j + 64 * k;
+            p[k] = *reinterpret_cast<const uint4 *>(brow + min(jc + 64 * kKcDepth, jmax));
+            if (jc < nw) kc_and4(cur, *reinterpret_cast<const uint4 *>(bm + jc), jc, pre, orow);
+        }
+    }
+}
 __device__ __forceinline__ void kc_stream_bitset(const uint32_t *__restrict__ brow, int nw, int sub, const uint32_t *bm, const unsigned short *pre,
                                                  uint32_t *orow) {
-    int j = sub * 4;
-    for (; j + 192 < nw; j += 256) {  // four 16-byte loads in flight (the hit loops below keep the compiler from overlapping them itself)
-        const uint4 p0 = *reinterpret_cast<const uint4 *>(brow + j), p1 = *reinterpret_cast<const uint4 *>(brow + j + 64),
-                    p2 = *reinterpret_cast<const uint4 *>(brow + j + 128), p3 = *reinterpret_cast<const uint4 *>(brow + j + 192);
-        const uint4 q0 = *reinterpret_cast<const uint4 *>(bm + j), q1 = *reinterpret_cast<const uint4 *>(bm + j + 64),
-                    q2 = *reinterpret_cast<const uint4 *>(bm + j + 128), q3 = *reinterpret_cast<const uint4 *>(bm + j + 192);
-        kc_and4(p0, q0, j, pre, orow);
-        kc_and4(p1, q1, j + 64, pre, orow);
-        kc_and4(p2, q2, j + 128, pre, orow);
-        kc_and4(p3, q3, j + 192, pre, orow);
-    }
-    for (; j < nw; j += 64) {
-        const uint4 p = *reinterpret_cast<const uint4 *>(brow + j);
-        const uint4 q = *reinterpret_cast<const uint4 *>(bm + j);
-        kc_and4(p, q, j, pre, orow);
-    }
+    kc_stream_bitset_from(brow, nw, sub * 4, bm, pre, orow);
 }
 
 // position of w in the ascending list [lst, lst+len), or -1
@@ -132,14 +160,95 @@ __device__ __forceinline__ int sorted_find(const int32_t *__restrict__ lst, int 
 }
 
 // 32-bit tail container [row, row + l) of one tail member against the pivot's ascending tail list (local index hc + position)
+__device__ __forceinline__ void kc_stream_tail_from(const int32_t *__restrict__ row, int l, int j0, const int32_t *__restrict__ tail_list, int tc, int hc,
+                                                    uint32_t *orow) {
+    if (l <= 0) return;
+    int32_t p[kKcDepth];
+#pragma unroll
+    for (int k = 0; k < kKcDepth; ++k) p[k] = row[min(j0 + 16 * k, l - 1)];
+    for (int j = j0; j < l; j += 16 * kKcDepth) {
+#pragma unroll
+        for (int k = 0; k < kKcDepth; ++k) {
+            const int32_t cur = p[k];
+            const int jc = j + 16 * k;
+            p[k] = row[min(jc + 16 * kKcDepth, l - 1)];
+            if (jc < l) {
+                const int t = sorted_find(tail_list, tc, cur);
+                if (t >= 0) {
+                    const int idx = hc + t;
+                    atomicOr(&orow[idx >> 5], 1u << (idx & 31));
+                }
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void kc_stream_tail(const int32_t *__restrict__ row, int l, int sub, const int32_t *__restrict__ tail_list, int tc, int hc,
                                                uint32_t *orow) {
-    for (int j = sub; j < l; j += 16) {
-        const int t = sorted_find(tail_list, tc, row[j]);
-        if (t >= 0) {
-            const int idx = hc + t;
-            atomicOr(&orow[idx >> 5], 1u << (idx & 31));
+    kc_stream_tail_from(row, l, sub, tail_list, tc, hc, orow);
+}
+
+// ---- the BUILD as a pipeline over the members of a lane group (round 4) ---------------------------------------------------------------
+// A member's row sits behind a chain of dependent loads: member id -> extents (hoff / toff / bmoff) -> first units of the row.  Walked
+// member by member (rounds 1-3) the group paid the three round trips for every member — k_kc_block spent 62 % of its wave cycles waiting.
+// Here the chain is three stages deep ACROSS the members of the group: while member t is probed, the first units of member t+1, the
+// extents of member t+2 and the id of member t+3 are in flight.  Every load of the pipeline is unconditional (clamped to a valid
+// address, its result ignored) so that the waits are counted, not vmcnt(0).
+struct KcExt {      // what stage B fetches for a member
+    int64_t hb, tb, bo;
+    int hl, tl;
+};
+struct KcFirst {    // … and stage C: the first 16-byte unit of its hub container (list or bitset) and the first id of its tail container
+    uint4 h;
+    int32_t t;
+};
+__device__ __forceinline__ KcExt kc_load_ext(const int64_t *__restrict__ hoff, const int64_t *__restrict__ toff, const int64_t *__restrict__ bmoff,
+                                             int32_t dense_limit, int32_t v) {
+    KcExt e;
+    e.hb = hoff[v];
+    e.hl = int(hoff[v + 1] - e.hb);
+    e.tb = toff[v];
+    e.tl = int(toff[v + 1] - e.tb);
+    e.bo = bmoff[max(min(v, dense_limit - 1), 0)];
+    return e;
+}
+// does member v (a hub member of the pivot, below dense_limit) stream its bitset container rather than its list?
+__device__ __forceinline__ bool kc_use_bitset(int32_t v, bool is_hub, int32_t dense_limit, int hl) {
+    return is_hub && v < dense_limit && int(bitset_words(v)) * 4 + 32 < hl * 2;
+}
+__device__ __forceinline__ KcFirst kc_load_first(const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint32_t *__restrict__ bmpool,
+                                                 const KcExt &e, bool bitset, int nw, int sub) {
+    KcFirst f;
+    // (an empty or too short container: unit 0 of the array — loaded, never probed)
+    const uint16_t *lrow = hadj + (sub * 8 < e.hl ? e.hb + sub * 8 : 0);
+    const uint32_t *brow = bmpool + (sub * 4 < nw ? e.bo + sub * 4 : 0);
+    const kc_u4u x = *reinterpret_cast<const kc_u4u *>(bitset ? reinterpret_cast<const uint16_t *>(brow) : lrow);
+    f.h = make_uint4(x.x, x.y, x.z, x.w);
+    f.t = tadj[sub < e.tl ? e.tb + sub : 0];
+    return f;
+}
+// member v's row into orow, its first units already here
+__device__ __forceinline__ void kc_build_member_first(const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint32_t *__restrict__ bmpool,
+                                                      const KcExt &e, const KcFirst &f, bool bitset, int nw, bool is_hub, int hc,
+                                                      const int32_t *__restrict__ tail_list, int tc, const uint32_t *bm, const unsigned short *pre,
+                                                      uint32_t *orow, int sub) {
+    if (bitset) {
+        const int j = sub * 4;
+        if (j < nw) kc_and4(f.h, *reinterpret_cast<const uint4 *>(bm + j), j, pre, orow);
+        kc_stream_bitset_from(bmpool + e.bo, nw, j + 64, bm, pre, orow);
+        return;
+    }
+    if (hc > 0) {
+        const int j = sub * 8;
+        if (j < e.hl) kc_probe8(bm, pre, orow, kc_cut8(kc_u4u{f.h.x, f.h.y, f.h.z, f.h.w}, e.hl - j));
+        kc_stream_list_from(hadj + e.hb, e.hl, j + 128, sub, bm, pre, orow);
+    }
+    if (!is_hub && tc > 0) {
+        if (sub < e.tl) {
+            const int t = sorted_find(tail_list, tc, f.t);
+            if (t >= 0) atomicOr(&orow[(hc + t) >> 5], 1u << ((hc + t) & 31));
         }
+        kc_stream_tail_from(tadj + e.tb, e.tl, sub + 16, tail_list, tc, hc, orow);
     }
 }
 
@@ -522,7 +631,7 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
 // (d <= 1024); true: in a per-workgroup global slab (d up to 64*32*WPL), workgroups walk their pivots with a grid stride.
 // dynamic LDS layout: [rows: dmax*WS u32 (LDS variant only)] [bm: 2048 u32] [pre: 2048 u16] [row stage: nwaves*4*W u32 (slab variant only)]
 // ---------------------------------------------------------------------------------------------
-template <int LV, int WPL, bool GLOBAL_ROWS, bool VTX>
+template <int LV, int WPL, bool GLOBAL_ROWS, bool VTX, bool PIPE = GLOBAL_ROWS>
 __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                    const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                    const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
@@ -590,27 +699,61 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         {
             const int grp = lane >> 4, sub = lane & 15;
             uint32_t *stage = GLOBAL_ROWS ? reinterpret_cast<uint32_t *>(pre + kBitmapWords) + size_t(wave) * 4 * W : nullptr;
-            for (int i0 = wave * 4; i0 < d; i0 += nwaves * 4) {
-                const int i = i0 + grp;
-                if (GLOBAL_ROWS) {
-                    for (int t = lane; t < 4 * W; t += 64) stage[t] = 0;
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (i < d) {
-                    const bool is_hub = i < hc;
-                    const int32_t v = is_hub ? int32_t(hub_list[i]) : tail_list[i - hc];
-                    uint32_t *orow = GLOBAL_ROWS ? stage + grp * W : rows + size_t(i) * WS;
+            if constexpr (PIPE) {
+                const int istep = nwaves * 4;
+                // member i of the pivot: its rank id (an index past the row: vertex 0 — loaded, never used)
+                auto member = [&](int i) -> int32_t { return i < hc ? int32_t(hub_list[i]) : tail_list[i < d ? i - hc : 0]; };
+                // the pipeline (kc_load_ext / kc_load_first above): ids three members ahead, extents two, first units one
+                const int ig = wave * 4 + grp;
+                int32_t v0 = member(min(ig, d - 1)), v1 = member(min(ig + istep, d - 1)), v2 = member(min(ig + 2 * istep, d - 1));
+                KcExt e0 = kc_load_ext(hoff, toff, bmoff, dense_limit, v0), e1 = kc_load_ext(hoff, toff, bmoff, dense_limit, v1);
+                bool b0 = kc_use_bitset(v0, ig < hc, dense_limit, e0.hl);
+                KcFirst f0 = kc_load_first(hadj, tadj, bmpool, e0, b0, b0 ? int(bitset_words(v0)) : 0, sub);
+                for (int i0 = wave * 4; i0 < d; i0 += istep) {
+                    const int i = i0 + grp;
+                    // later stages first: they complete while member i is probed
+                    const int32_t v3 = member(min(i + 3 * istep, d - 1));
+                    const KcExt e2 = kc_load_ext(hoff, toff, bmoff, dense_limit, v2);
+                    const bool b1 = kc_use_bitset(v1, i + istep < hc, dense_limit, e1.hl);
+                    const KcFirst f1 = kc_load_first(hadj, tadj, bmpool, e1, b1, b1 ? int(bitset_words(v1)) : 0, sub);
+                    if (GLOBAL_ROWS) {
+                        for (int t = lane; t < 4 * W; t += 64) stage[t] = 0;
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    if (i < d) {
+                        const bool is_hub = i < hc;
+                        uint32_t *orow = GLOBAL_ROWS ? stage + grp * W : rows + size_t(i) * WS;
 #ifdef GMSX_KC_NO_ROWS  // A/B build (wrong counts): the BUILD phase without its row streams
-                    if (v == -7) orow[0] = 1;
+                        if (v0 == -7) orow[0] = 1;
 #else
-                    kc_build_member(hoff, hadj, toff, tadj, bmoff, bmpool, dense_limit, v, is_hub, hc, tail_list, tc, bm, pre, orow, sub);
+                        kc_build_member_first(hadj, tadj, bmpool, e0, f0, b0, b0 ? int(bitset_words(v0)) : 0, is_hub, hc, tail_list, tc, bm, pre, orow, sub);
 #endif
+                    }
+                    if (GLOBAL_ROWS) {
+                        __builtin_amdgcn_wave_barrier();
+                        const int nr = min(4, d - i0);
+                        for (int t = lane; t < nr * W; t += 64) rows[size_t(i0 + t / W) * WS + t % W] = stage[t];
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    v0 = v1; v1 = v2; v2 = v3;
+                    e0 = e1; e1 = e2;
+                    b0 = b1;
+                    f0 = f1;
                 }
-                if (GLOBAL_ROWS) {
-                    __builtin_amdgcn_wave_barrier();
-                    const int nr = min(4, d - i0);
-                    for (int t = lane; t < nr * W; t += 64) rows[size_t(i0 + t / W) * WS + t % W] = stage[t];
-                    __builtin_amdgcn_wave_barrier();
+            } else {
+                // small matrices, several workgroups per CU: the 30 registers of the pipeline would cost a third of the waves (80 -> 110
+                // VGPRs: 6 -> 4 per SIMD; measured 22.6 -> 25.9 ms at scale 22 with the pipeline everywhere) — member by member
+                for (int i0 = wave * 4; i0 < d; i0 += nwaves * 4) {
+                    const int i = i0 + grp;
+                    if (i < d) {
+                        const bool is_hub = i < hc;
+                        const int32_t v = is_hub ? int32_t(hub_list[i]) : tail_list[i - hc];
+#ifdef GMSX_KC_NO_ROWS
+                        if (v == -7) rows[size_t(i) * WS] = 1;
+#else
+                        kc_build_member(hoff, hadj, toff, tadj, bmoff, bmpool, dense_limit, v, is_hub, hc, tail_list, tc, bm, pre, rows + size_t(i) * WS, sub);
+#endif
+                    }
                 }
             }
         }
@@ -1045,7 +1188,9 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     // M: 32 < d+ <= 1024, bit-matrix in LDS; one launch per bin — the bins are cut where another workgroup fits a CU
     static bool attr_set[kMaxK + 1] = {false};
     if (!attr_set[VTX ? kMaxK : LV]) {
-        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX>),
+        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, false>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr_set[VTX ? kMaxK : LV] = true;
     }
@@ -1059,8 +1204,13 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             const size_t lds = size_t(dmax) * WS * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + (VTX ? size_t(dmax) * 4 : 0);
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
             const int threads = dmax >= 704 ? 1024 : dmax >= 384 ? 512 : 256;
-            hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX>), dim3(unsigned(blocks)), dim3(threads), lds, n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj, g->toff,
-                               g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts);
+            // (one 1024-thread workgroup per CU from d+ = 513 on: four waves per SIMD whatever the registers — the pipelined BUILD pays there)
+            if (threads == 1024)
+                hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, true>), dim3(unsigned(blocks)), dim3(threads), lds, n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
+                                   g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts);
+            else
+                hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, false>), dim3(unsigned(blocks)), dim3(threads), lds, n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
+                                   g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts);
             ++*launches;
         }
     }

@@ -324,6 +324,16 @@ def test_containers_that_do_not_fit_fall_back_to_passes(gpu, oracle):
         assert g.tc_total() == want                  # walks the passes again
         assert sum(g.tc_partial(p, 3) for p in range(3)) == want   # a sharded call builds exactly its shard
         assert g.tc_total() == want
+        # fewer shards than passes: a shard that cannot fit either is cut into nested sub-shards — slower, never refused —
+        # and the handle stays usable for whole-graph calls afterwards
+        os.environ["GMSX_TC_MEM_LIMIT_MB"] = "40"
+        g2 = gpu.DeviceGraph.from_csr(csr)
+        assert g2.tc_total() == want and g2.tc_passes >= 4
+        parts = [g2.tc_partial(p, 2, stats=True) for p in range(2)]
+        assert sum(p[0] for p in parts) == want and sum(p[1]["units"] for p in parts) == csr.num_edges
+        assert g2.tc_partial(0, 1) == want and g2.tc_total() == want and g2.tc_passes >= 4
+        g2.free()
+        os.environ["GMSX_TC_MEM_LIMIT_MB"] = "96"
         assert g.kclique_count(3)[1] == want         # the base layout is untouched
         g.free()
         os.environ["GMSX_TC_MEM_LIMIT_MB"] = "1"     # nothing fits, not even 1/4096 of the pivots: the one refusal left
