@@ -36,7 +36,7 @@ SYMBOLS = [
     "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_upload_shard", "gmsx_graph_upload_csr_shard", "gmsx_graph_prepare", "gmsx_graph_tc_passes", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
     "gmsx_graph_device_bytes", "gmsx_graph_max_out_degree",
     "gmsx_tc_total", "gmsx_tc_partial", "gmsx_tc_divisor", "gmsx_tc_stream_breakdown", "gmsx_tc_row_histogram", "gmsx_tc_vertex_count2",
-    "gmsx_intersect_count_batch", "gmsx_vertex_similarity_batch", "gmsx_kclique_count", "gmsx_kclique_partial", "gmsx_bk_count", "gmsx_bk_partial",
+    "gmsx_intersect_count_batch", "gmsx_vertex_similarity_batch", "gmsx_kclique_count", "gmsx_kclique_partial", "gmsx_kclique_star_count", "gmsx_bk_count", "gmsx_bk_partial",
     "gmsx_adg_rank", "gmsx_tc_ordering",
     "gmsx_comm_unique_id", "gmsx_comm_init", "gmsx_comm_allreduce_u64", "gmsx_comm_rank", "gmsx_comm_size", "gmsx_comm_finalize",
 ]
@@ -118,6 +118,7 @@ def lib():
     L.gmsx_vertex_similarity_batch.argtypes = [vp, C.c_int, C.c_int64, _i32p, _i32p, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), sp]
     L.gmsx_kclique_count.argtypes = [vp, C.c_int, u64p, u64p, sp]
     L.gmsx_kclique_partial.argtypes = [vp, C.c_int, C.c_int, C.c_int, u64p, sp]
+    L.gmsx_kclique_star_count.argtypes = [vp, C.c_int, u64p, u64p, sp]
     L.gmsx_bk_count.argtypes = [vp, C.c_void_p, u64p, sp]
     L.gmsx_bk_partial.argtypes = [vp, C.c_void_p, C.c_int, C.c_int, u64p, sp]
     L.gmsx_adg_rank.argtypes = [vp, C.c_double, C.c_int, _i32p, C.POINTER(C.c_int32), sp]
@@ -339,6 +340,13 @@ class DeviceGraph:
         ordered, cliques, st = C.c_uint64(0), C.c_uint64(0), Stats()
         _check(lib().gmsx_kclique_count(self._h, k, C.byref(ordered), C.byref(cliques), C.byref(st)), "gmsx_kclique_count")
         r = (int(ordered.value), int(cliques.value))
+        return (r + (st.as_dict(),)) if stats else r
+
+    def kclique_star_count(self, k, members=True, stats=False):
+        """KCliqueStar::Par::CliqueStar in count mode: (number of k-clique-stars = C_k, total cardinality of the stars = (k+1) C_{k+1})."""
+        stars, mem, st = C.c_uint64(0), C.c_uint64(0), Stats()
+        _check(lib().gmsx_kclique_star_count(self._h, k, C.byref(stars), C.byref(mem) if members else None, C.byref(st)), "gmsx_kclique_star_count")
+        r = (int(stars.value), int(mem.value) if members else None)
         return (r + (st.as_dict(),)) if stats else r
 
     def kclique_partial(self, k, part, nparts, stats=False):

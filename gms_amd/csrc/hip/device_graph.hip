@@ -790,8 +790,8 @@ __global__ void k_item_counts(int64_t n_recv, const int64_t *__restrict__ lbeg, 
     if (p > n_recv) return;
     items[p] = p < n_recv ? (lbeg[p + 1] - lbeg[p] + kTaskChunk - 1) / kTaskChunk : 0;
 }
-// one thread per receiver: its list in chunks of kTaskChunk entries, each a self-contained record (device_graph.hpp) — the run
-// boundaries by binary search over the class-sorted chunk, the pivot's container part from coff (hoff / toff)
+// one thread per receiver: its list in chunks of kTaskChunk entries, each a self-contained record (device_graph.hpp); the pivot's
+// container part from coff (hoff / toff)
 __global__ void k_item_fill(int64_t n_recv, const int32_t *__restrict__ recv_v, const int32_t *__restrict__ opos, const int64_t *__restrict__ lbeg,
                             const int64_t *__restrict__ ioff, const unsigned long long *__restrict__ task, const int64_t *__restrict__ coff, int kind,
                             gmsx_tc_item *__restrict__ items) {
@@ -808,14 +808,14 @@ __global__ void k_item_fill(int64_t n_recv, const int32_t *__restrict__ recv_v, 
         it.cont = cont;
         it.pivot = w;
         it.pos = opos[w];
-        it.kind = uint16_t(kind);
-        for (int r = 0; r <= 12; ++r) {  // first entry of run type >= r
+        it.kind = uint32_t(kind);
+        for (int f = 0; f < 4; ++f) {  // first entry of form >= f (binary search over the form-sorted chunk)
             int lo = 0, hi = ne;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (run_type(task[x + mid]) < r) lo = mid + 1; else hi = mid;
+                if (int((uint32_t(task[x + mid]) >> 22) & 3u) < f) lo = mid + 1; else hi = mid;
             }
-            it.run[r] = uint16_t(lo);
+            it.fbeg[f] = uint16_t(lo);
         }
         items[k] = it;
     }
@@ -1508,6 +1508,20 @@ static int build_tc_sets(gmsx_graph *g) {
     pt.mark("work items");
     GMSX_HIP(hipStreamSynchronize(s));
     GMSX_HIP(hipGetLastError());
+    // what only the BUILD read — the tail split, the second descriptors and the split points of hybrid rows — does not stay on the device
+    // (16 bytes per vertex: 1.07 GB at scale 26); build_tc_once takes tc_bytes from device_bytes afterwards, so the bookkeeping follows
+    {
+        auto drop = [&](auto *&p, size_t bytes) {
+            if (!p) return;
+            (void)hipFree(p);
+            p = nullptr;
+            g->device_bytes -= int64_t(bytes);
+        };
+        const size_t nn = size_t(n > 0 ? n : 1);
+        drop(g->tsplit, nn * sizeof(int32_t));
+        drop(g->srow2, nn * sizeof(unsigned long long));
+        drop(g->ksplit, size_t(n + 1) * sizeof(int32_t));
+    }
     return GMSX_OK;
 }
 

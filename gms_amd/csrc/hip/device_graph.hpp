@@ -33,16 +33,16 @@
 // (ttask).  A self-contained 64-byte record — everything a persistent workgroup needs to stage the item without a dependent lookup:
 // bc = first entry (40 bits) | entries << 40; cont = where the pivot's own container part lies (first id in hadj / tadj, 40 bits) | its
 // ids << 40; pivot = rank id whose row is staged in LDS; pos = the pivot's position in `order` (what the shard rule of a multi-GPU run
-// is evaluated on); run[r] … run[r+1] = the entries of run type r inside the item (the lists are class-sorted, run_type() below; written
-// by the build, so the kernels neither search nor mark them).
+// is evaluated on).  (The lists are class-sorted — form, then length step: an item is a few runs of equally formed rows, which is all the
+// kernels' one step stream per item needs.)
 struct __attribute__((aligned(64))) gmsx_tc_item {
     uint64_t bc;
     uint64_t cont;
     int32_t pivot;
     int32_t pos;
-    uint16_t run[13];
-    uint16_t kind;  // 0 = hub item, 1 = tail item
-    uint32_t reserved[3];
+    uint32_t kind;       // 0 = hub item, 1 = tail item
+    uint16_t fbeg[4];    // fbeg[f] = entries of the item whose form is below f (the lists are sorted by form first): where form f begins
+    uint32_t reserved[7];
 };
 static_assert(sizeof(gmsx_tc_item) == 64, "work item record = one 64-byte line");
 struct gmsx_graph {
@@ -149,12 +149,6 @@ static constexpr int kAccWords = 64 * 16 + 16;
 static constexpr int kFormList = 0, kFormBitset = 1, kFormDelta = 2, kFormGap12 = 3;
 static constexpr int kPoolSlack = 64;    // 16-byte units of padding behind spool / tpool: a lane group loads up to 15 units past the end of a row (tc.hip, scan_run)
 static constexpr int kTaskChunk = 512;   // entries per work item (4 KB of descriptors: two such buffers per workgroup, the next item's arriving while this one is scanned)
-// run type of an entry inside a work item = form * 3 + {0: <= 4 units, 1: <= 8, 2: longer}: the three lane-group widths of the scan
-// loops (tc.hip).  Monotone in the class order of the lists, so an item is at most 12 consecutive runs.
-__host__ __device__ inline int run_type(unsigned long long d) {
-    const uint32_t u = uint32_t(d) & 0x3fffffu;
-    return int((uint32_t(d) >> 22) & 3u) * 3 + (u <= 4 ? 0 : u <= 8 ? 1 : 2);
-}
 // entry classes: hub = form * kLenClasses + length class, tail = kHubClasses + (delta ? kLenClasses : 0) + length class.  Length classes
 // in steps of ~sqrt(2): <= 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, more units — the groups of a wave work on rows of one class side
 // by side, and the wave is done when its longest row is.

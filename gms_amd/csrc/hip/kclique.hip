@@ -1340,4 +1340,29 @@ int gmsx_kclique_count(const gmsx_graph *g, int k, uint64_t *ordered_count, uint
     });
 }
 
+int gmsx_kclique_star_count(const gmsx_graph *g, int k, uint64_t *stars, uint64_t *star_members, gmsx_stats *stats) {
+    return gmsx::guard([&]() -> int {
+        if (!g || !stars || k < 1) return GMSX_ERR_INVALID;
+        if (k + 1 > kMaxGenericK) return GMSX_ERR_UNSUPPORTED;
+        if (int rc = ensure_init()) return rc;
+        gmsx_stats st_k{}, st_k1{};
+        uint64_t ck = uint64_t(g->n), ck1 = 0;  // C_1 = n: an isolated vertex is a 1-clique with an empty star
+        if (k >= 2)
+            if (int rc = kclique_partial(g, k, 0, 1, &ck, &st_k)) return rc;
+        if (star_members) {
+            if (int rc = kclique_partial(g, k + 1, 0, 1, &ck1, &st_k1)) return rc;
+            *star_members = uint64_t(k + 1) * ck1;
+        }
+        *stars = ck;
+        if (stats) {
+            *stats = st_k1;
+            stats->kernel_ms += st_k.kernel_ms;
+            stats->setup_ms += st_k.setup_ms;
+            stats->launches += st_k.launches;
+            stats->units = uint64_t(g->n);
+        }
+        return GMSX_OK;
+    });
+}
+
 }  // extern "C"

@@ -206,10 +206,16 @@ __device__ __forceinline__ uint32_t tail_unit_hits_f(const uint32_t *flt, const 
 // entries [lo, hi) of the item (descriptors in LDS), one form, rows of similar length: HIT(p, j) = hits of unit j of a row.  ONE_STEP: the
 // classes of the run guarantee units <= W (one load per lane, no loop).
 #ifndef GMSX_TC_TAIL_DEPTH
-#define GMSX_TC_TAIL_DEPTH 3  // 16-byte loads a lane of the TAIL scans keeps in flight
+#define GMSX_TC_TAIL_DEPTH 1  // steps in the ring besides the one being issued: ONE is enough once the loads are counted (scale 26, tail items alone: depth 1 / 2 / 3 / 4 = 16.6 / 19.0 / 20.6 / 23.3 ms; hub items 47.9 / 49.0 / 50.2) — the registers of a deeper ring cost the eighth wave per SIMD or spill
+#endif
+#ifndef GMSX_TC_HUB_GROUP
+#define GMSX_TC_HUB_GROUP 16  // lanes per row: one width for all rows — with the step stream a group moves from row to row on its own (8-lane groups: 57 vs 51 ms
+#endif                        // for the hub rows — 128-byte requests against 256-byte ones —, no difference for the tail rows)
+#ifndef GMSX_TC_TAIL_GROUP
+#define GMSX_TC_TAIL_GROUP 16
 #endif
 #ifndef GMSX_TC_HUB_DEPTH
-#define GMSX_TC_HUB_DEPTH 2   // … of the hub scans (the decode of a byte-delta unit wants 30 registers of its own)
+#define GMSX_TC_HUB_DEPTH 1   // … of the hub scans (the decode of a byte-delta unit wants 30 registers of its own)
 #endif
 // Entries [lo, hi) of an item (descriptors in LDS), one form, rows of one width class, as a STREAM OF STEPS: a group of W lanes works on
 // one row, a step = W consecutive units of it (one 16-byte load per lane), and a lane keeps D steps in flight across row boundaries.
@@ -218,92 +224,87 @@ __device__ __forceinline__ uint32_t tail_unit_hits_f(const uint32_t *flt, const 
 // issued a moment ago, and a wave never has more than one load instruction in flight (rounds 2-3: that, times 32 waves per CU, was the
 // 3.7 TB/s of the tail items — 0.9 KB per wave and memory latency).  With counted waits the D loads overlap.
 // HIT(p, j) = hits of unit j of a row.
-template <int W, int D, class Hit>
-__device__ __forceinline__ uint32_t scan_run(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, int lo, int hi, int tid, Hit hit) {
-    constexpr int G = 256 / W;
-    const int sub = tid % W;
-    const uint4 *pool4 = reinterpret_cast<const uint4 *>(pool);
-    uint32_t cnt = 0;
+template <int W, int D>
+struct StepStream {
+    static constexpr int G = 256 / W;
+    const unsigned long long *sdesc;
+    const uint4 *pool4;
+    int hi, sub;
     // cursor of the step to ISSUE: entry e (descriptor d = first unit << 24 | form << 22 | units), unit j of this lane.  Per row: its
     // first unit's address, the index of its last unit (a lane without a unit in the step re-reads that one: same line as its
     // neighbours'), and j's bound for "the row is through"
-    int e = lo + tid / W;
-    unsigned long long d = e < hi ? sdesc[e] : 0ull;
-    const uint4 *row = pool4 + (d >> 24);
-    int units = int(uint32_t(d) & 0x3fffffu), last = max(units - 1, 0), lim = units + sub;
-    int j = sub;
-    int pending = 0;  // steps of real entries in the ring
+    int e, units, last, lim, j, form;
+    const uint4 *row;
+    int pending;  // steps of real entries in the ring
     uint4 p[D];
-    int pj[D];  // unit index of the lane in that step, -1 = none
-    auto issue = [&](int k) {
+    int pj[D];    // unit index of the lane in that step | form << 24, -1 = none
+    __device__ __forceinline__ void open_row() {
+        const unsigned long long d = e < hi ? sdesc[e] : 0ull;
+        row = pool4 + (d >> 24);
+        units = int(uint32_t(d) & 0x3fffffu);
+        form = int((uint32_t(d) >> 22) & 3u) << 24;
+        last = max(units - 1, 0);
+        lim = units + sub;
+        j = sub;
+    }
+    __device__ __forceinline__ void issue(int k) {
         p[k] = row[uint32_t(min(j, last))];
-        pj[k] = j < units ? j : -1;
+        pj[k] = j < units ? (j | form) : -1;
         pending += e < hi ? 1 : 0;
         j += W;
         if (j >= lim) {  // the row is through (uniform per group): next entry of the group
             e += G;
-            d = e < hi ? sdesc[e] : 0ull;
-            row = pool4 + (d >> 24);
-            units = int(uint32_t(d) & 0x3fffffu);
-            last = max(units - 1, 0);
-            lim = units + sub;
-            j = sub;
+            open_row();
         }
-    };
+    }
+    // entries [lo, hi_) of the item: the first D steps go out here — BEFORE the pivot's bitmap / table is rebuilt, so that they are in
+    // flight while it is (the item kernel), not after
+    __device__ __forceinline__ void start(const unsigned long long *sd, const uint32_t *__restrict__ pool, int lo, int hi_, int tid) {
+        sdesc = sd;
+        pool4 = reinterpret_cast<const uint4 *>(pool);
+        hi = hi_;
+        sub = tid % W;
+        e = lo + tid / W;
+        pending = 0;
+        open_row();
 #pragma unroll
-    for (int k = 0; k < D; ++k) issue(k);
-    while (pending > 0) {  // the groups of a wave differ by the lengths of their rows
+        for (int k = 0; k < D; ++k) issue(k);
+    }
+    // HIT(p, j, form) = hits of unit j of a row of that form.  The entries of an item are sorted by form, so the groups of a wave disagree
+    // about it only where two runs meet: ONE stream — one fill, one drain — serves the whole item (rounds 2-3: a loop per form and width).
+    template <class Hit>
+    __device__ __forceinline__ uint32_t run(Hit hit) {
+        uint32_t cnt = 0;
+        while (pending > 0) {  // the groups of a wave differ by the lengths of their rows
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const uint4 pc = p[k];
-            const int jc = pj[k];
-            pending -= 1;  // (slots of dead entries push it below zero: the loop ends at the first check after the last real step)
-            issue(k);
+            for (int k = 0; k < D; ++k) {
+                const uint4 pc = p[k];
+                const int jc = pj[k];
+                pending -= 1;  // (slots of dead entries push it below zero: the loop ends at the first check after the last real step)
+                issue(k);
 #ifdef GMSX_TC_NO_PROBE  // A/B build (WRONG counts): every unit is loaded, nothing is probed — what the memory side alone takes
-            if (jc >= 0) cnt += pc.x & 1u;
+                if (jc >= 0) cnt += pc.x & 1u;
 #else
-            if (jc >= 0) cnt += hit(pc, jc);
+                if (jc >= 0) cnt += hit(pc, jc & 0xffffff, jc >> 24);
 #endif
+            }
         }
+        return cnt;
     }
-    return cnt;
+};
+// the hub forms against the pivot bitmap / the tail forms against filter + table, dispatched per step (divergent only where two runs meet)
+__device__ __forceinline__ uint32_t hub_hits_by_form(const uint32_t *bm, uint4 p, int j, int f) {
+    if (f == kFormList) return hub_unit_hits<kFormList>(bm, p, j);
+    if (f == kFormDelta) return hub_unit_hits<kFormDelta>(bm, p, j);
+    if (f == kFormBitset) return hub_unit_hits<kFormBitset>(bm, p, j);
+    return hub_unit_hits<kFormGap12>(bm, p, j);
 }
-// One run per FORM (round 4): with the step streams a group moves from row to row on its own, so rows of unequal length side by side
-// cost nothing, and a single width serves them all — kRowGroup = 8 lanes = one 128-byte line per row and step (rows average 40 units in
-// the hub lists, 14 in the tail lists; 16 lanes left the short ones half empty).  Rounds 2-3 ran three loops per form (4 / 8 / 16 lanes):
-// every loop has a prologue and a drain, and a typical item of ~110 rows paid for eight of them.
-#ifndef GMSX_TC_HUB_GROUP
-#define GMSX_TC_HUB_GROUP 16
-#endif
-#ifndef GMSX_TC_TAIL_GROUP
-#define GMSX_TC_TAIL_GROUP 16
-#endif
-template <int W, int D, class Hit>
-__device__ __forceinline__ uint32_t scan_form(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, const unsigned short *rbeg, const unsigned short *rend,
-                                              int form, int tid, Hit hit) {
-    // the runs of a form are adjacent in the class-sorted list: [first non-empty begin, last non-empty end)
-    const int r0 = form * 3;
-    int lo = 0x7fffffff, hi = 0;
-#pragma unroll
-    for (int r = r0; r < r0 + 3; ++r)
-        if (rend[r] > rbeg[r]) {
-            lo = min(lo, int(rbeg[r]));
-            hi = max(hi, int(rend[r]));
-        }
-    return hi > lo ? scan_run<W, D>(sdesc, pool, lo, hi, tid, hit) : 0u;
+__device__ __forceinline__ uint32_t tail_hits_by_form(const uint32_t *flt, const int32_t *tbl, uint32_t mask, int shift, uint4 p, int f) {
+    return f == kFormDelta ? tail_delta_unit_hits(flt, tbl, mask, shift, p) : tail_unit_hits(flt, tbl, mask, shift, p);
 }
-// copies the item's descriptors to LDS and records, per run type, where its run begins and ends (the list is class-sorted: one run each)
-template <int NC, class ClassOf>
-__device__ __forceinline__ void stage_item(const unsigned long long *__restrict__ ent, int ne, int tid, unsigned long long *sdesc, unsigned short *cbeg,
-                                           unsigned short *cend, ClassOf class_of) {
-    if (tid < NC) cbeg[tid] = cend[tid] = 0;
+// copies the item's descriptors to LDS
+__device__ __forceinline__ void stage_item(const unsigned long long *__restrict__ ent, int ne, int tid, unsigned long long *sdesc) {
     for (int i = tid; i < ne; i += 256) sdesc[i] = ent[i];
-    __syncthreads();
-    for (int i = tid; i < ne; i += 256) {
-        const int c = class_of(sdesc[i]);
-        if (i == 0 || class_of(sdesc[i - 1]) != c) cbeg[c] = (unsigned short)i;
-        if (i == ne - 1 || class_of(sdesc[i + 1]) != c) cend[c] = (unsigned short)(i + 1);
-    }
     __syncthreads();
 }
 __device__ __forceinline__ void block_add(unsigned long long cnt, unsigned long long *red, int lane, int wave, int tid, unsigned long long *__restrict__ acc) {
@@ -322,7 +323,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                   const gmsx_tc_item *__restrict__ items, unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords + 128];  // + slack: the delta probes of unused slots read up to 104 words past the bitmap
     __shared__ unsigned long long sdesc[kTaskChunk];
-    __shared__ unsigned short cbeg[12], cend[12];  // run types
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const gmsx_tc_item &it = items[blockIdx.x];
@@ -331,22 +331,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int hl = int(hoff[u + 1] - hb);
     const int ne = int(it.bc >> 40);
     for (int i = tid; i < (kBitmapWords + 128) / 4; i += 256) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
-    stage_item<12>(htask + (it.bc & 0xffffffffffull), ne, tid, sdesc, cbeg, cend, [](unsigned long long d) { return run_type(d); });
+    stage_item(htask + (it.bc & 0xffffffffffull), ne, tid, sdesc);
     for (int i = tid; i < hl; i += 256) {
         const uint32_t id = hadj[hb + i];
         if (id != 0xFFFFu) atomicOr(&bm[id >> 5], 1u << (id & 31u));
     }
     __syncthreads();
     uint32_t cnt = 0;
-    auto run = [&](auto form_tag) {
-        constexpr int FORM = decltype(form_tag)::value;
-        cnt += scan_form<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH>(sdesc, spool, cbeg, cend, FORM, tid, [](uint4 p, int j) { return hub_unit_hits<FORM>(bm, p, j); });
-    };
 #ifndef GMSX_TC_STAGING_ONLY  // (A/B build: what the per-item fixed cost alone takes)
-    run(std::integral_constant<int, kFormList>{});
-    run(std::integral_constant<int, kFormBitset>{});
-    run(std::integral_constant<int, kFormDelta>{});
-    run(std::integral_constant<int, kFormGap12>{});
+    StepStream<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH> st;
+    st.start(sdesc, spool, 0, ne, tid);
+    cnt += st.run([](uint4 p, int j, int f) { return hub_hits_by_form(bm, p, j, f); });
 #endif
     block_add(cnt, red, lane, wave, tid, acc);
 }
@@ -357,7 +352,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ __attribute__((aligned(16))) int32_t tbl[1 << kBlockLog];
     __shared__ __attribute__((aligned(16))) uint32_t flt[kFilterWords];
     __shared__ unsigned long long sdesc[kTaskChunk];
-    __shared__ unsigned short cbeg[12], cend[12];  // run types (tail forms: list = 0, delta = 2)
     __shared__ unsigned long long red[4];
     constexpr int TILE = (1 << kBlockLog) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -366,7 +360,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int64_t tb = toff[u];
     const int tl = int(toff[u + 1] - tb);
     const int ne = int(it.bc >> 40);
-    stage_item<12>(ttask + (it.bc & 0xffffffffffull), ne, tid, sdesc, cbeg, cend, [](unsigned long long d) { return run_type(d); });
+    stage_item(ttask + (it.bc & 0xffffffffffull), ne, tid, sdesc);
     // the table sized for THIS pivot (most tail parts are a few dozen ids): 2^log slots >= 2 x keys
     int log = 6;
     while ((1 << log) < 2 * min(tl, TILE)) ++log;
@@ -385,33 +379,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             atomicOr(&flt[(uint32_t(t) >> 5) & uint32_t(kFilterWords - 1)], 1u << (uint32_t(t) & 31u));
         }
         __syncthreads();
-        auto run = [&](auto form_tag) {
-            constexpr int FORM = decltype(form_tag)::value;
-            cnt += scan_form<GMSX_TC_TAIL_GROUP, GMSX_TC_TAIL_DEPTH>(sdesc, tpool, cbeg, cend, FORM, tid, [mask, shift](uint4 p, int) { return tail_unit_hits_f<FORM>(flt, tbl, mask, shift, p); });
-        };
 #ifndef GMSX_TC_STAGING_ONLY
-        run(std::integral_constant<int, kFormList>{});
-        run(std::integral_constant<int, kFormDelta>{});
+        StepStream<GMSX_TC_TAIL_GROUP, GMSX_TC_TAIL_DEPTH> st;
+        st.start(sdesc, tpool, 0, ne, tid);
+        cnt += st.run([mask, shift](uint4 p, int, int f) { return tail_hits_by_form(flt, tbl, mask, shift, p, f); });
 #endif
     }
     block_add(cnt, red, lane, wave, tid, acc);
 }
 
 // ---------------------------------------------------------------------------------------------
-// PERSISTENT work-item kernel (round 4): what k_tc_block + k_tc_tail did with one workgroup per item — 5.4 M workgroups per pass at scale
-// 26, each opening with a chain of dependent round trips (item -> offsets -> descriptors / pivot ids -> LDS) before its first row load:
-// a third of a tail item's slot time — as ONE launch of as many workgroups as the chip holds.  A workgroup walks items off two queues
-// (hub items, tail items; tickets of kGrab consecutive items, fetched one chunk ahead) and keeps a three-deep pipeline over them:
-//   item i+2   its 64-byte record is loading (one dword per lane; fields come back out with v_readlane: the record is wave-uniform)
+// PERSISTENT work-item kernels (round 4): what k_tc_block / k_tc_tail did with one workgroup per item — 5.4 M workgroups per pass at scale
+// 26, each opening with a chain of dependent round trips (item -> offsets -> descriptors / pivot ids -> LDS) before its first row load
+// — as one launch per queue (hub items, tail items) of as many workgroups as the chip holds.  A workgroup draws tickets of kGrab
+// consecutive items (fetched one chunk ahead) and keeps a three-deep pipeline over them:
+//   item i+2   its 64-byte record is on its way into LDS (LDS-DMA, 16 lanes of wave 0)
 //   item i+1   its descriptors and the pivot's ids are on their way into the OTHER half of the LDS staging buffers by LDS-DMA
 //              (global_load_lds: no registers, no instructions at arrival)
-//   item i     is scanned.
-// Records are self-contained (device_graph.hpp: entries, the pivot's container part, run boundaries), so nothing in the chain depends on
-// a second lookup.  The pivot bitmap is MAINTAINED instead of rebuilt: consecutive items of one pivot share it; otherwise the ids of the
-// previous pivot (still in the other staging half) are XORed out and the new ones XORed in — both commute, so no barrier separates them
-// and nothing clears 8 KB per item.  Tail items alias the bitmap's LDS as filter + hash set (sized per pivot) and leave it invalid.
-// Roles: (blockIdx & 7) < tail_share starts on the tail queue, the rest on the hub queue — the latency-bound short tail rows run BESIDE
-// the bandwidth-bound hub rows for the whole pass — and a workgroup whose queue runs dry moves to the other one.
+//   item i     is scanned: ONE step stream over all its entries (StepStream above), opened before the bitmap is brought up to date.
+// Records are self-contained (device_graph.hpp: entries, the pivot's container part), so nothing in the chain depends on a second lookup.
+// The pivot bitmap is MAINTAINED instead of rebuilt: consecutive items of one pivot share it; otherwise the ids of the previous pivot (still
+// in the other staging half) are XORed out and the new ones XORed in — both commute, so no barrier separates them and nothing clears 8 KB
+// per item.  Tail items use the same LDS as hash set (sized per pivot) + 32768-bit filter.
+// Two launches, one per queue (hub items, then tail items): see k_tc_items below.
 // ---------------------------------------------------------------------------------------------
 static constexpr int kGrab = 8;        // items per queue ticket
 static constexpr int kIdStage = 256;   // dwords per id staging half: 512 hub ids / 256 tail ids; longer containers read the rest from memory
@@ -428,19 +418,6 @@ __device__ __forceinline__ void glds_dword(const uint32_t *src, uint32_t lds_byt
 __device__ __forceinline__ void stage_dwords(const uint32_t *__restrict__ src, uint32_t lds_byte_addr, int ndw, int lane, int wave) {
     for (int base = wave * 64; base < ndw; base += 256)  // uniform per wave
         if (base + lane < ndw) glds_dword(src + base + lane, lds_byte_addr + 4u * uint32_t(base));
-}
-// run boundaries of the item whose record sits in LDS (dwords 6 … 12 of the record: thirteen 16-bit positions; uniform)
-__device__ __forceinline__ int run_bound(const uint32_t *rec, int r) {
-    const uint32_t w = uni32(rec[6 + (r >> 1)]);
-    return int((r & 1) ? (w >> 16) : (w & 0xffffu));
-}
-template <int W, int D, class Hit>
-__device__ __forceinline__ uint32_t scan_form_r(const unsigned long long *sdesc, const uint32_t *__restrict__ pool, const uint32_t *rec, int form, int tid, Hit hit) {
-    uint32_t cnt = 0;
-    const int r0 = form * 3;
-    const int b0 = run_bound(rec, r0), b3 = run_bound(rec, r0 + 3);
-    if (b3 > b0) cnt += scan_run<W, D>(sdesc, pool, b0, b3, tid, hit);
-    return cnt;
 }
 // LDS of a k_tc_items workgroup (18.9 KB: eight per CU)
 struct ItemLds {
@@ -536,7 +513,13 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
         const int64_t cb = int64_t((uint64_t(c_hi & 0xffu) << 32) | c_lo);
         const int cn = int(c_hi >> 8);
         const unsigned long long *sd = L.sdesc[buf];
+        const int neA = int(uni32(recA[1]) >> 8);
         uint32_t c = 0;
+        // the item's step stream opens HERE: its first loads are in flight while the pivot's bitmap / table is brought up to date
+        StepStream<TAIL ? GMSX_TC_TAIL_GROUP : GMSX_TC_HUB_GROUP, TAIL ? GMSX_TC_TAIL_DEPTH : GMSX_TC_HUB_DEPTH> st;
+#ifndef GMSX_TC_STAGING_ONLY
+        if (!TAIL) st.start(sd, pool, 0, neA, tid);  // (the tail items open theirs behind the table build: carried across it, the stream's state spills)
+#endif
         if (!TAIL) {
             const int pivotA = int(uni32(recA[4]));
             if (!(bm_valid && bm_pivot == pivotA)) {
@@ -556,11 +539,9 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
             }
             __syncthreads();  // (2)
             if (vB) stage(L.rec[rb], buf ^ 1, lane, wave);
+            if (fetch) L.chunk[1] = pend < unsigned(n_items) ? int(pend) : -1;  // the chunk behind the one the cursor just entered (read behind the next barrier (1))
 #ifndef GMSX_TC_STAGING_ONLY
-            c += scan_form_r<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormList, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormList>(bm, p, j); });
-            c += scan_form_r<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormBitset, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormBitset>(bm, p, j); });
-            c += scan_form_r<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormDelta, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormDelta>(bm, p, j); });
-            c += scan_form_r<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH>(sd, pool, recA, kFormGap12, tid, [bm](uint4 p, int j) { return hub_unit_hits<kFormGap12>(bm, p, j); });
+            c += st.run([bm](uint4 p, int j, int f) { return hub_hits_by_form(bm, p, j, f); });
 #endif
         } else {
             int32_t *tbl = reinterpret_cast<int32_t *>(bm);
@@ -584,19 +565,29 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
                 }
                 __syncthreads();  // (2)
                 if (!staged && vB) stage(L.rec[rb], buf ^ 1, lane, wave);
+                if (!staged && fetch) L.chunk[1] = pend < unsigned(n_items) ? int(pend) : -1;
                 staged = true;
 #ifndef GMSX_TC_STAGING_ONLY
-                c += scan_form_r<GMSX_TC_TAIL_GROUP, GMSX_TC_TAIL_DEPTH>(sd, pool, recA, kFormList, tid, [=](uint4 p, int) { return tail_unit_hits_f<kFormList>(flt, tbl, mask, shift, p); });
-                c += scan_form_r<GMSX_TC_TAIL_GROUP, GMSX_TC_TAIL_DEPTH>(sd, pool, recA, kFormDelta, tid, [=](uint4 p, int) { return tail_unit_hits_f<kFormDelta>(flt, tbl, mask, shift, p); });
+                // (two forms, 32-bit list and 16-bit delta: a run each with its decode compiled in — dispatched per step, as the four hub forms
+                //  are, the tail items took 19.6 ms instead of 17.8)
+                const int nl = int(uni32(recA[8]) & 0xffffu);  // fbeg[2]: the list entries come first
+                if (nl > 0) {
+                    st.start(sd, pool, 0, nl, tid);
+                    c += st.run([=](uint4 p, int, int) { return tail_unit_hits(flt, tbl, mask, shift, p); });
+                }
+                if (neA > nl) {
+                    st.start(sd, pool, nl, neA, tid);
+                    c += st.run([=](uint4 p, int, int) { return tail_delta_unit_hits(flt, tbl, mask, shift, p); });
+                }
 #endif
             }
             if (!staged) {  // (a pivot without tail ids: nothing can match)
                 __syncthreads();
                 if (vB) stage(L.rec[rb], buf ^ 1, lane, wave);
+                if (fetch) L.chunk[1] = pend < unsigned(n_items) ? int(pend) : -1;
             }
         }
         total += c;
-        if (fetch) L.chunk[1] = pend < unsigned(n_items) ? int(pend) : -1;  // the chunk behind the one the cursor just entered
         ra = rb;
         vA = vB;
         vB = vC;
@@ -604,28 +595,25 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
     }
 }
 
-// Seven waves per SIMD (72 registers), not eight (64): the loop around the scans carries the per-lane total, the queue / pipeline state and
-// what the compiler keeps of the staging addresses; at 64 registers it spilled 42 of them to scratch — 32 KB of scratch traffic per item,
-// +24 GB beyond the L2 per pass at scale 26 — and the pass is bound by memory, not by an eighth of the wave slots (72.5 -> 71.4 ms).
-#ifndef GMSX_TC_ITEMS_MIN_WAVES
-#define GMSX_TC_ITEMS_MIN_WAVES 7
+// One kernel per queue (hub items, tail items), launched one after the other: mixed in one launch the two kinds took the SUM of their
+// times anyway (both are bound by the same memory system, §5.1 of DESIGN.md), and a kernel that holds both loops also holds both
+// argument sets and both scans' registers — it spilled at every occupancy above five waves per SIMD.
+// Waves per SIMD the two are compiled for.  With a ring of one step both fit 64 registers without a spill (eight waves); deeper rings need
+// 72 / 80 registers or spill — scratch traffic on the path of every item, and a reload is a vmcnt(0) in the middle of the stream.
+#ifndef GMSX_TC_HUB_MIN_WAVES
+#define GMSX_TC_HUB_MIN_WAVES 8
 #endif
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_TC_ITEMS_MIN_WAVES, 8))) void k_tc_items(
-    const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint32_t *__restrict__ spool, const uint32_t *__restrict__ tpool,
-    const unsigned long long *__restrict__ htask, const unsigned long long *__restrict__ ttask, const gmsx_tc_item *__restrict__ hitem, int n_hitems,
-    const gmsx_tc_item *__restrict__ titem, int n_titems, int tail_share, unsigned int *__restrict__ qhead, unsigned long long *__restrict__ acc) {
+#ifndef GMSX_TC_TAIL_MIN_WAVES
+#define GMSX_TC_TAIL_MIN_WAVES 8
+#endif
+template <bool TAIL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ? GMSX_TC_TAIL_MIN_WAVES : GMSX_TC_HUB_MIN_WAVES, 8))) void k_tc_items(
+    const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint32_t *__restrict__ pool, const unsigned long long *__restrict__ task,
+    const gmsx_tc_item *__restrict__ items, int n_items, unsigned int *__restrict__ qhead, unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) ItemLds L;
     const int tid = threadIdx.x;
-    const bool tail_first = (int(blockIdx.x) & 7) < tail_share;
     unsigned long long total = 0;
-#pragma nounroll
-    for (int phase = 0; phase < 2; ++phase) {  // a workgroup whose queue has run dry moves to the other one
-        if ((phase == 0) == tail_first) {
-            if (n_titems > 0) item_loop<true>(L, hadj, tadj, tpool, ttask, titem, n_titems, qhead + kQueueStride, total);
-        } else {
-            if (n_hitems > 0) item_loop<false>(L, hadj, tadj, spool, htask, hitem, n_hitems, qhead, total);
-        }
-    }
+    item_loop<TAIL>(L, hadj, tadj, pool, task, items, n_items, qhead, total);
     block_add(total, L.red, tid & 63, tid >> 6, tid, acc);
 }
 
@@ -761,10 +749,6 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
     unsigned long long units = 0, probes = 0, bytes = 0;
-    auto slots = [](unsigned long long d, bool tail) -> unsigned long long {
-        const unsigned long long n = d & 0x3fffffull, f = (d >> 22) & 3ull;
-        return n * (tail ? (f == kFormDelta ? 6ull : 4ull) : (f == kFormList ? 8ull : f == kFormDelta ? 14ull : f == kFormGap12 ? 10ull : 4ull));
-    };
     for (int64_t pos = wave0; pos < end; pos += nwaves) {
         if (nparts > 1 && shard_of(pos, nparts) != part) continue;
         const int32_t u = order[pos];
@@ -974,11 +958,6 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
         if (h[i]) atomicAdd(&out[i], h[i]);
 }
 
-static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
-    const int64_t span = end - first - part;
-    return span <= 0 ? 0 : (span + nparts - 1) / nparts;
-}
-
 static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, gmsx_stats *st);
 
 static int tc_oriented(const gmsx_graph *g, int part, int nparts, uint64_t *partial, gmsx_stats *st) {
@@ -1113,15 +1092,17 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
         join.armed[1] = true;
     }
     if (persist) {
-        if (n_hitems + n_titems > 0) {
-            static const int share_env = [] { const char *e = std::getenv("GMSX_TC_TAIL_SHARE"); return e ? std::atoi(e) : -1; }();
-            static const int wgs_env = [] { const char *e = std::getenv("GMSX_TC_ITEM_WGS"); return e ? std::atoi(e) : GMSX_TC_ITEMS_MIN_WAVES; }();  // workgroups per CU
-            // workgroups that START on the tail queue, of every 8 (the queues drain into each other, so this only shapes the mix)
-            const int tail_share = share_env >= 0 ? std::min(share_env, 8) : (n_titems == 0 ? 0 : n_hitems == 0 ? 8 : 2);
-            const int64_t want = (n_hitems + n_titems + kGrab - 1) / kGrab;
-            const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(want, int64_t(cus) * std::max(1, wgs_env)));
-            hipLaunchKernelGGL(k_tc_items, dim3(unsigned(blocks)), dim3(256), 0, s, g->hadj, g->tadj, g->spool, g->tpool, g->htask, g->ttask, hitem, int(n_hitems),
-                               titem, int(n_titems), tail_share, qhead, acc);
+        static const int wgs_env = [] { const char *e = std::getenv("GMSX_TC_ITEM_WGS"); return e ? std::atoi(e) : 0; }();  // workgroups per CU (0: what the kernel is compiled for)
+        auto grid = [&](int64_t n, int wgs) {
+            return unsigned(std::max<int64_t>(1, std::min<int64_t>((n + kGrab - 1) / kGrab, int64_t(cus) * (wgs_env > 0 ? wgs_env : wgs))));
+        };
+        if (n_hitems > 0) {
+            hipLaunchKernelGGL(k_tc_items<false>, dim3(grid(n_hitems, GMSX_TC_HUB_MIN_WAVES)), dim3(256), 0, s, g->hadj, g->tadj, g->spool, g->htask, hitem, int(n_hitems), qhead, acc);
+            ++launches;
+        }
+        if (n_titems > 0) {
+            hipLaunchKernelGGL(k_tc_items<true>, dim3(grid(n_titems, GMSX_TC_TAIL_MIN_WAVES)), dim3(256), 0, s, g->hadj, g->tadj, g->tpool, g->ttask, titem, int(n_titems),
+                               qhead + kQueueStride, acc);
             ++launches;
         }
     } else {

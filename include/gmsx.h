@@ -231,6 +231,15 @@ int gmsx_vertex_similarity_batch(const gmsx_graph *g, int metric, int64_t n_pair
 int gmsx_kclique_count(const gmsx_graph *g, int k, uint64_t *ordered_count, uint64_t *cliques, gmsx_stats *stats);
 int gmsx_kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint64_t *cliques_partial, gmsx_stats *stats);
 
+/* ---- k-clique-star, COUNT mode: KCliqueStar::Par::CliqueStar<SGraph, OutputMode::Count>
+ * (set_based/k_clique_star_list/parallel/recursive.h:19-35 over sequential/recursive.h:31-71).  The reference lists, for every k-clique
+ * (reached once, members ascending), the clique and its STAR — the common neighbours of all its members outside it.
+ * *stars = the number of (clique, star) pairs = C_k — what the reference prints as "total k-cliques" and what `output.size()` is;
+ * *star_members = the total cardinality of the stars = (k+1)·C_{k+1}: every (k+1)-clique puts each of its members into the star of the
+ * k-clique of the others (may be NULL: the (k+1)-clique pass is then skipped).  Both from the k-clique kernels above; the listing itself
+ * is not produced on the device.  k = 1 … 63. */
+int gmsx_kclique_star_count(const gmsx_graph *g, int k, uint64_t *stars, uint64_t *star_members, gmsx_stats *stats);
+
 /* ---- Bron–Kerbosch maximal-clique count: BkEppsteinPar::mceBench with -DBK_COUNT
  * (maximal_clique_enum/parallel/eppsteinPAR.h:18-53 over sequential/tomita.h:12-86).
  * rank: n entries in rank format (host), or NULL.  The number of maximal cliques does not depend on the order the start

@@ -18,6 +18,7 @@
 //   gmsx::count_total(g)                 -> gmsx_tc_total          (triangle_count/parallel/total.h:7-24)
 //   gmsx::vertex_count2(g, out)          -> gmsx_tc_vertex_count2  (triangle_count/parallel/vertex.h:14-49)
 //   gmsx::clique_count(g, k)             -> gmsx_kclique_count     (k_clique_count_set_based.h:19-31)
+//   gmsx::clique_star_count(g, k)        -> gmsx_kclique_star_count (k_clique_star_list/parallel/recursive.h:19-35, count mode)
 //   gmsx::maximal_clique_count(g, rank)  -> gmsx_bk_count          (maximal_clique_enum/parallel/eppsteinPAR.h:18-53)
 //   gmsx::adg_rank(g, eps, out)          -> gmsx_adg_rank          (preprocessing/parallel/degeneracy_approx_set.h:14-86)
 //   gmsx::triangle_count_ordering(g,out) -> gmsx_tc_ordering       (preprocessing/parallel/triangle_count.h:11-30)
@@ -482,6 +483,16 @@ inline size_t clique_count(const HipGraphT<S> &g, size_t k = 4) {
     detail::check(gmsx_kclique_count(g.device(), int(k), &ordered, nullptr, nullptr), "gmsx_kclique_count");
     std::printf("total %zu-cliques: %llu\n", k, static_cast<unsigned long long>(ordered));
     return size_t(ordered);
+}
+// KCliqueStar::Par::CliqueStar<SGraph, OutputMode::Count> (k_clique_star_list/parallel/recursive.h:19-35): the number of k-clique-stars —
+// what `output.size()` is in count mode — printed like the reference does (:33); *star_members (optional) = the total size of the stars a
+// listing would carry.  The listing itself (`CliqueStarList`) stays on the host: the generic template runs over the span sets.
+template <class S>
+inline int64_t clique_star_count(const HipGraphT<S> &g, int32_t k, uint64_t *star_members = nullptr) {
+    uint64_t stars = 0;
+    detail::check(gmsx_kclique_star_count(g.device(), int(k), &stars, star_members, nullptr), "gmsx_kclique_star_count");
+    std::printf("total %d-cliques: %llu\n", int(k), static_cast<unsigned long long>(stars));
+    return int64_t(stars);
 }
 // BkEppsteinPar::mceBench under -DBK_COUNT (eppsteinPAR.h:18-53): the maximal-clique count.  `rank` (rank format, any
 // random-access container of n integers) is validated to be a permutation by the library; the count does not depend on it.

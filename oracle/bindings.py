@@ -46,6 +46,7 @@ class Oracle:
         L.gmso_tc_vertex_count2_once.argtypes = [C.c_int64, _i64p, _i32p, C.c_int, _i64p]
         L.gmso_kclique.restype = C.c_uint64
         L.gmso_kclique.argtypes = [C.c_int64, _i64p, _i32p, C.c_int, C.c_int]
+        L.gmso_kclique_star_count.argtypes = [C.c_int64, _i64p, _i32p, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.gmso_bk_count.restype = C.c_uint64
         L.gmso_bk_count.argtypes = [C.c_int64, _i64p, _i32p, _i32p, C.c_int]
         L.gmso_degree_rank.argtypes = [C.c_int64, _i64p, _i32p]
@@ -110,6 +111,12 @@ class Oracle:
 
     def kclique(self, off, neigh, k, threads=0):
         return int(self.L.gmso_kclique(off.size - 1, off, neigh, k, threads))
+
+    def kclique_star_count(self, off, neigh, k, threads=0):
+        """(number of k-clique-stars = k-cliques, total cardinality of their stars)"""
+        c, m = C.c_uint64(0), C.c_uint64(0)
+        self.L.gmso_kclique_star_count(off.size - 1, off, neigh, k, threads, C.byref(c), C.byref(m))
+        return int(c.value), int(m.value)
 
     def degree_rank(self, off):
         r = np.empty(off.size - 1, dtype=np.int32)
@@ -176,6 +183,8 @@ class Reference:
         L.ref_kclique.argtypes = [vp, C.c_int, C.c_int]
         L.ref_bk_count.restype = C.c_uint64
         L.ref_bk_count.argtypes = [vp, C.c_int, C.c_int]
+        if hasattr(L, "ref_kclique_star"):
+            L.ref_kclique_star.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         if hasattr(L, "ref_kclist_count"):
             L.ref_kclist_count.restype = C.c_uint64
             L.ref_kclist_count.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -228,6 +237,12 @@ class Reference:
 
     def bk_count(self, g, set_kind=1, order=0):
         return int(self.L.ref_bk_count(g, set_kind, order))
+
+    def kclique_star(self, g, k, set_kind=1):
+        """Par::CliqueStarList<SGraph>(g, k): (number of (clique, star) pairs listed, total cardinality of the stars)"""
+        c, m = C.c_uint64(0), C.c_uint64(0)
+        self.L.ref_kclique_star(g, k, set_kind, C.byref(c), C.byref(m))
+        return int(c.value), int(m.value)
 
     def kclist_count(self, g, k, order=0, times=False):
         """TRUE k-clique count (each clique once) by the reference's kClist pipeline (ref_shim.cc: ref_kclist_count).

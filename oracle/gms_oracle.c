@@ -211,6 +211,58 @@ uint64_t gmso_kclique(int64_t n, const int64_t *off, const int32_t *neigh, int k
     return total;
 }
 
+/* ------------------------------------------------------------------ k-clique-star (count mode)
+ * GMS::KCliqueStar::Par::CliqueStar / Seq::RecursiveStepCliqueStar
+ * (gms/algorithms/set_based/k_clique_star_list/parallel/recursive.h:19-35, sequential/recursive.h:31-71):
+ * for every vertex u the recursion extends curClique = {u} by vertices vi of isect = N(u) ∩ … that are LARGER than every member
+ * (`vi <= vj` -> skip), so each k-clique is reached once, in ascending order; at k == 0 the star of the clique is
+ * ∩_{v in clique} (N(v) \ clique) and one (clique, star) pair is pushed.  Count mode: the number of pushes, and — what a listing would
+ * carry — the total cardinality of the stars. */
+static void kcstar_step(const int64_t *off, const int32_t *neigh, int k, int32_t *clique, int depth, const int32_t *isect, size_t ni,
+                        uint64_t *count, uint64_t *members) {
+    if (k == 0) {
+        /* star = the common neighbours of all members outside the clique (sequential/recursive.h:44-49) */
+        size_t cap = (size_t)(off[clique[0] + 1] - off[clique[0]]);
+        int32_t *star = (int32_t *)malloc((cap + 1) * sizeof(int32_t)), *tmp = (int32_t *)malloc((cap + 1) * sizeof(int32_t));
+        size_t ns = gmso_difference(neigh + off[clique[0]], cap, clique, (size_t)depth, star);  /* clique is ascending: a sorted set */
+        for (int i = 1; i < depth; i++) {
+            size_t di = (size_t)(off[clique[i] + 1] - off[clique[i]]);
+            int32_t *t2 = (int32_t *)malloc((di + 1) * sizeof(int32_t));
+            size_t nt = gmso_difference(neigh + off[clique[i]], di, clique, (size_t)depth, t2);
+            ns = gmso_intersect(star, ns, t2, nt, tmp);
+            memcpy(star, tmp, ns * sizeof(int32_t));
+            free(t2);
+        }
+        *count += 1;
+        *members += ns;
+        free(star);
+        free(tmp);
+        return;
+    }
+    int32_t *cur = (int32_t *)malloc((ni + 1) * sizeof(int32_t));
+    for (size_t i = 0; i < ni; i++) {
+        const int32_t vi = isect[i];
+        size_t nc = gmso_intersect(isect, ni, neigh + off[vi], (size_t)(off[vi + 1] - off[vi]), cur);
+        if (vi <= clique[depth - 1]) continue;  /* curClique is built ascending: its last member is its largest */
+        clique[depth] = vi;
+        kcstar_step(off, neigh, k - 1, clique, depth + 1, cur, nc, count, members);
+    }
+    free(cur);
+}
+void gmso_kclique_star_count(int64_t n, const int64_t *off, const int32_t *neigh, int k, int threads, uint64_t *count_out, uint64_t *members_out) {
+    uint64_t count = 0, members = 0;
+    int nt = pick_threads(threads);
+    (void)nt;
+#pragma omp parallel for reduction(+ : count, members) schedule(dynamic, 64) num_threads(nt)
+    for (int64_t u = 0; u < n; u++) {
+        int32_t clique[64];
+        clique[0] = (int32_t)u;
+        kcstar_step(off, neigh, k - 1, clique, 1, neigh + off[u], (size_t)(off[u + 1] - off[u]), &count, &members);
+    }
+    *count_out = count;
+    *members_out = members;
+}
+
 /* ------------------------------------------------------------------ Bron–Kerbosch */
 
 typedef struct { const int64_t *off; const int32_t *neigh; uint64_t count; } bk_ctx;

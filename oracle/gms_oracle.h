@@ -49,6 +49,9 @@ void gmso_tc_vertex_count2_once(int64_t n, const int64_t *off, const int32_t *ne
 /* ---- k-clique counting (gms/algorithms/set_based/k_clique_count/k_clique_count_set_based.h:5-31) ----
  * Returns the reference's value: k! * (#k-cliques) on a symmetric graph, arithmetic mod 2^64 like size_t. */
 uint64_t gmso_kclique(int64_t n, const int64_t *off, const int32_t *neigh, int k, int threads);
+/* KCliqueStar::Par::CliqueStar in count mode (k_clique_star_list/parallel/recursive.h:19-35, sequential/recursive.h:31-71): the number of
+ * (k-clique, star) pairs and the total cardinality of the stars */
+void gmso_kclique_star_count(int64_t n, const int64_t *off, const int32_t *neigh, int k, int threads, uint64_t *count_out, uint64_t *members_out);
 
 /* ---- Bron–Kerbosch maximal-clique count ----
  * BkEppsteinPar::mceBench (parallel/eppsteinPAR.h:18-53) over BkTomita::expand/findPivot

@@ -13,6 +13,7 @@
 //   BK          gms/algorithms/set_based/maximal_clique_enum/parallel/eppsteinPAR.h:18-53 (+ sequential/tomita.h:12-86)
 //   set algebra gms/representations/sets/sorted_set.h:21-272, roaring_set.h:15-229
 //   orderings   gms/algorithms/preprocessing/parallel/degeneracy_approx_set.h:14-86, degree.h:26-62, triangle_count.h:11-30
+//   k-clique-star  gms/algorithms/set_based/k_clique_star_list/parallel/recursive.h:19-43, sequential/recursive.h:31-71
 //   kClist      gms/algorithms/non_set_based/k_clique_list/bench_helper.h:16-106 (CliqueCountPipeline: Preprocess + kclisting),
 //               kernels/kclisting.h:163-188 (KcListing::count), parallelizationStrategy/parallelize.h:38-80 (node-parallel):
 //               the reference's own source of TRUE k-clique counts (each clique once) — the only reference path that reaches
@@ -27,6 +28,7 @@
 #include <gms/algorithms/set_based/maximal_clique_enum/bron_kerbosch.h>
 #include <gms/algorithms/set_based/vertex_similarity/vertex_similarity.h>
 #include <gms/algorithms/preprocessing/parallel/triangle_count.h>
+#include <gms/algorithms/set_based/k_clique_star_list/k_clique_star_list.h>
 #include <gms/algorithms/preprocessing/preprocessing.h>
 #include <gms/algorithms/non_set_based/k_clique_list/bench_helper.h>
 
@@ -321,6 +323,26 @@ uint64_t ref_kclist_count_wide(void *h, int k, double *prep_s, double *count_s) 
     if (prep_s) *prep_s = t1 - t0;
     if (count_s) *count_s = t2 - t1;
     return count;
+}
+// GMS::KCliqueStar::Par::CliqueStarList<SGraph>(g, k) (set_based/k_clique_star_list/parallel/recursive.h:37-43): the list itself, reduced to
+// what a count-mode consumer sees — the number of (clique, star) pairs and the total cardinality of the stars
+void ref_kclique_star(void *h, int k, int set_kind, uint64_t *count, uint64_t *members) {
+    Quiet q;
+    const CSRGraph &g = static_cast<RefGraph *>(h)->g;
+    auto run = [&](const auto &sg) {
+        using SG = std::decay_t<decltype(sg)>;
+        auto out = KCliqueStar::Par::CliqueStarList<SG>(sg, k);
+        uint64_t c = 0, m = 0;
+        for (const auto &pair : out) {
+            ++c;
+            m += pair[1].cardinality();
+        }
+        *count = c;
+        *members = m;
+    };
+    (void)set_kind;  // the reference's parallel variant hard-codes `RoaringSet curClique(u)` (parallel/recursive.h:28): RoaringGraph only
+    auto sg = RoaringGraph::FromCGraph(g);
+    run(sg);
 }
 int ref_omp_threads(void) { return omp_get_max_threads(); }
 }

@@ -173,3 +173,25 @@ def test_out_degrees_above_4096(gpu, oracle):
     k5h = oracle.kclique(hcsr.offsets(), hcsr.neighbors(), 5) // 120
     assert g.kclique_count(5)[1] == b * k4h + k5h
     g.free()
+
+
+def test_kclique_star_count(gpu, oracle):
+    """gmsx_kclique_star_count = KCliqueStar::Par::CliqueStar in count mode (k_clique_star_list/parallel/recursive.h:19-35): the number of
+    k-clique-stars and the total size of the stars, bit-equal to the oracle's restatement of the reference recursion (itself pinned against
+    the compiled reference's list in tests/test_oracle.py) and to the reference goldens."""
+    for kind, scale, deg in (("kronecker", 10, 16), ("uniform", 11, 16), ("kronecker", 8, 40)):
+        csr = host_graph(gpu, kind, scale, deg, True)
+        g = gpu.DeviceGraph.from_csr(csr)
+        for k in (1, 2, 3, 4, 5):
+            want = oracle.kclique_star_count(csr.offsets(), csr.neighbors(), k)
+            assert g.kclique_star_count(k) == want, (kind, scale, k)
+            assert g.kclique_star_count(k, members=False) == (want[0], None)
+        g.free()
+    csr = host_graph(gpu, "kronecker", 14)
+    g = gpu.DeviceGraph.from_csr(csr)
+    rec = GRAPHS["kronecker-14-16-relabel"]
+    assert g.kclique_star_count(3) == (rec["triangles"], 4 * (rec["kc4"] // 24))
+    assert g.kclique_star_count(2)[0] == csr.num_edges and g.kclique_star_count(2)[1] == 3 * rec["triangles"]
+    with pytest.raises(gpu.GmsxError):
+        g.kclique_star_count(0)
+    g.free()

@@ -154,6 +154,35 @@ def test_reference_kclist_agrees_with_its_set_based_count(oracle, reference, spe
         reference.free(g)
 
 
+@pytest.mark.parametrize("spec", [("kronecker", 8, 16), ("kronecker", 10, 16), ("uniform", 10, 16), ("kronecker", 7, 40)])
+def test_kclique_star_count_against_compiled_reference(oracle, reference, spec):
+    """KCliqueStar::Par::CliqueStarList (k_clique_star_list/parallel/recursive.h:19-43): the oracle's count-mode restatement equals the
+    reference's list — its length and the total size of its stars — and both equal (C_k, (k+1) C_{k+1}), the identity the device entry
+    point gmsx_kclique_star_count stands on (every (k+1)-clique puts each member into the star of the k-clique of the others)."""
+    kind, scale, deg = spec
+    g = reference.generate(kind, scale, deg, relabel=True)
+    try:
+        off, ng = reference.csr(g)
+        fact = [1, 1, 2, 6, 24, 120]
+        for k in (1, 2, 3, 4):
+            want = reference.kclique_star(g, k)
+            assert oracle.kclique_star_count(off, ng, k) == want
+            ck = off.size - 1 if k == 1 else oracle.kclique(off, ng, k) // fact[k]
+            assert want == (ck, (k + 1) * (oracle.kclique(off, ng, k + 1) // fact[k + 1]))
+    finally:
+        reference.free(g)
+
+
+def test_kclique_star_count_goldens(oracle, capi):
+    """… and against the committed goldens (the reference's own counts): scale 10: C_3 = 74 720, C_4 = 409 665, C_5 = 1 745 925."""
+    from conftest import host_graph
+    csr = host_graph(capi, "kronecker", 10)
+    off, ng = csr.offsets(), csr.neighbors()
+    assert oracle.kclique_star_count(off, ng, 3) == (74720, 4 * 409665)
+    assert oracle.kclique_star_count(off, ng, 4) == (409665, 5 * 1745925)
+    assert oracle.kclique_star_count(off, ng, 1) == (1024, 2 * 10496)
+
+
 def test_golden_kc4_true_is_kc4_over_24():
     import json
     import os
