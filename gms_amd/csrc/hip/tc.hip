@@ -626,7 +626,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ? GMSX
 // and the next edge's record and rows are in flight while this one is compared: k_tc_wave — a wave per pivot, an 8 KB bitmap per wave,
 // 16 waves per CU, one load in flight per wave behind a chain of dependent loads — took 10.6 ms for 14 GB at scale 26 (1.3 TB/s).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t ror1_in_row(uint32_t x) { return uint32_t(__builtin_amdgcn_mov_dpp(int(x), 0x121, 0xf, 0xf, false)); }  // row_ror:1
+// Does a lane of the 16-lane row hold an x equal to this lane's a?  x as the lane K places further along the row sees it (DPP row_ror:K),
+// K = 0 … 15, every rotation reading the ORIGINAL register (independent instructions; round 4's first version rotated one register fifteen
+// times: a dependent chain with a DPP hazard nop per link, 3.8 ms for the light edges of scale 26).  The ids of a row are distinct, so an
+// a meets at most ONE equal x in all of v's registers: the compares are OR-ed as lane masks (v_cmp into SGPRs + s_or on the scalar unit)
+// and counted once per a — two vector instructions per rotation instead of four.
+template <int K>
+__device__ __forceinline__ uint32_t ror_in_row(uint32_t x) {
+    if constexpr (K == 0) return x;
+    else return uint32_t(__builtin_amdgcn_mov_dpp(int(x), 0x120 + K, 0xf, 0xf, false));
+}
+__device__ __forceinline__ bool row_has(uint32_t a, uint32_t x) {
+    bool m = false;
+#define GMSX_ROT(K) m |= a == ror_in_row<K>(x);
+    GMSX_ROT(0) GMSX_ROT(1) GMSX_ROT(2) GMSX_ROT(3) GMSX_ROT(4) GMSX_ROT(5) GMSX_ROT(6) GMSX_ROT(7)
+    GMSX_ROT(8) GMSX_ROT(9) GMSX_ROT(10) GMSX_ROT(11) GMSX_ROT(12) GMSX_ROT(13) GMSX_ROT(14) GMSX_ROT(15)
+#undef GMSX_ROT
+    return m;
+}
 struct LightRows {
     uint32_t ah[4], at[4], bh[4], bt[4];  // u's hub / tail ids, v's hub / tail ids (interleaved over the 16 lanes)
 };
@@ -691,34 +708,30 @@ __global__ __launch_bounds__(256) void k_tc_light(const uint16_t *__restrict__ h
                 if (ka >= nah) break;
                 const int ia = sub + 16 * ka;
                 const uint32_t a = (ia < hlu && rows.ah[ka] != 0xFFFFu) ? rows.ah[ka] : 0xFFFFFFFFu;  // 0xFFFF = row padding
+                bool m = false;
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
                     if (kb >= nbh) break;
                     const int ib = sub + 16 * kb;
-                    uint32_t x = (ib < hlv && rows.bh[kb] != 0xFFFFu) ? rows.bh[kb] : 0xFFFFFFFEu;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        c += a == x ? 1u : 0u;
-                        x = ror1_in_row(x);
-                    }
+                    const uint32_t x = (ib < hlv && rows.bh[kb] != 0xFFFFu) ? rows.bh[kb] : 0xFFFFFFFEu;
+                    m |= row_has(a, x);
                 }
+                c += m ? 1u : 0u;
             }
 #pragma unroll
             for (int ka = 0; ka < 4; ++ka) {
                 if (ka >= nat) break;
                 const int ia = sub + 16 * ka;
                 const uint32_t a = ia < tlu ? rows.at[ka] : 0xFFFFFFFFu;
+                bool m = false;
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
                     if (kb >= nbt) break;
                     const int ib = sub + 16 * kb;
-                    uint32_t x = ib < tlv ? rows.bt[kb] : 0xFFFFFFFEu;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        c += a == x ? 1u : 0u;
-                        x = ror1_in_row(x);
-                    }
+                    const uint32_t x = ib < tlv ? rows.bt[kb] : 0xFFFFFFFEu;
+                    m |= row_has(a, x);
                 }
+                c += m ? 1u : 0u;
             }
             total += c;
             rec = rec_n;
