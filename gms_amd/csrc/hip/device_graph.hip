@@ -545,6 +545,7 @@ __global__ void k_inline_units(int64_t n, const unsigned long long *__restrict__
     units_h[v] = v < n ? int64_t((ids_h[v] + 7) / 8) : 0;
     units_t[v] = v < n ? int64_t((ids_t[v] + 3) / 4) : 0;
 }
+static constexpr int kDefaultHotWindows = 0, kDefaultHotKB = 2048, kDefaultHotMin = 16;
 // ---- receivers -----------------------------------------------------------------------------------------------------------------------------
 // A RECEIVER is a vertex that owns task lists: every heavy pivot (d+ >= kHeavy; receiver index = its position in `order`, which lists the
 // heavy pivots first) and every light vertex of rank id < inline_limit (it can only receive inline rows; index n_heavy + its rank among
@@ -573,7 +574,8 @@ template <bool FILL>
 __global__ void k_inline_entries(int64_t n, const int32_t *__restrict__ dplus, const int32_t *__restrict__ opos, const int64_t *__restrict__ lidx, int64_t n_heavy,
                                  int32_t inline_limit, const int64_t *__restrict__ ihoff, const int64_t *__restrict__ itoff, int64_t base_h, int64_t base_t,
                                  uint32_t *__restrict__ cnt, uint32_t *__restrict__ cur, const int64_t *__restrict__ hbeg, const int64_t *__restrict__ tbeg,
-                                 unsigned long long *__restrict__ htask, unsigned long long *__restrict__ ttask, unsigned long long *__restrict__ totals) {
+                                 unsigned long long *__restrict__ htask, unsigned long long *__restrict__ ttask, unsigned long long *__restrict__ totals, TcClasses cc) {
+    const int kClasses = cc.count();
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v >= n) return;
     const int64_t uh = ihoff[v + 1] - ihoff[v], ut = itoff[v + 1] - itoff[v];
@@ -584,14 +586,14 @@ __global__ void k_inline_entries(int64_t n, const int32_t *__restrict__ dplus, c
     for (int64_t o = 0; o < uh; o += kInlineChunk) {
         const unsigned long long units = (unsigned long long)min(int64_t(kInlineChunk), uh - o);
         const unsigned long long d = ((unsigned long long)(base_h + ihoff[v] + o) << 24) | ((unsigned long long)kFormList << 22) | units;
-        const int cls = hub_class(d);
+        const int cls = hub_class(cc, d);
         if (!FILL) atomicAdd(&c[cls], 1u);
         else htask[hbeg[p] + c[cls] + atomicAdd(&cur[p * kClasses + cls], 1u)] = d;
     }
     for (int64_t o = 0; o < ut; o += kInlineChunk) {
         const unsigned long long units = (unsigned long long)min(int64_t(kInlineChunk), ut - o);
         const unsigned long long d = ((unsigned long long)(base_t + itoff[v] + o) << 24) | ((unsigned long long)kFormList << 22) | units;
-        const int cls = tail_class(d);
+        const int cls = tail_class(cc, d);
         if (!FILL) atomicAdd(&c[cls], 1u);
         else ttask[tbeg[p] + c[cls] + atomicAdd(&cur[p * kClasses + cls], 1u)] = d;
     }
@@ -601,16 +603,17 @@ __global__ void k_inline_entries(int64_t n, const int32_t *__restrict__ dplus, c
     }
 }
 // per receiver: the class counters become the class offsets inside its hub list / tail list; the list lengths go to hcnt / tcnt
-__global__ void k_list_sizes(int64_t n_recv, uint32_t *__restrict__ cnt, int64_t *__restrict__ hcnt, int64_t *__restrict__ tcnt) {
+__global__ void k_list_sizes(int64_t n_recv, uint32_t *__restrict__ cnt, int64_t *__restrict__ hcnt, int64_t *__restrict__ tcnt, TcClasses cc) {
+    const int kClasses = cc.count(), hub_end = cc.tail_base();
     const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p > n_recv) return;
     if (p == n_recv) { hcnt[p] = 0; tcnt[p] = 0; return; }
     uint32_t *c = cnt + p * kClasses;
     uint32_t run = 0;
-    for (int k = 0; k < kHubClasses; ++k) { const uint32_t x = c[k]; c[k] = run; run += x; }
+    for (int k = 0; k < hub_end; ++k) { const uint32_t x = c[k]; c[k] = run; run += x; }
     hcnt[p] = run;
     run = 0;
-    for (int k = kHubClasses; k < kClasses; ++k) { const uint32_t x = c[k]; c[k] = run; run += x; }
+    for (int k = hub_end; k < kClasses; ++k) { const uint32_t x = c[k]; c[k] = run; run += x; }
     tcnt[p] = run;
 }
 
@@ -707,7 +710,8 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ cur, const int64_t *__restrict__ hbeg,
                                                     const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ htask, unsigned long long *__restrict__ ttask,
                                                     int32_t *__restrict__ tunits, unsigned long long *__restrict__ reversed, const uint32_t *__restrict__ spool,
-                                                    const uint32_t *__restrict__ tpool, int32_t inline_limit, int nparts, int part) {
+                                                    const uint32_t *__restrict__ tpool, int32_t inline_limit, int nparts, int part, TcClasses cc) {
+    const int kClasses = cc.count();
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -749,13 +753,13 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
             // tail member lie below every tail id of the pivot; a hub member has no tail part
             const unsigned long long fh = (fwd && i > 0) ? srow[v] : 0ull, fh2 = (fwd && i > 0) ? srow2[v] : 0ull, ft = (fwd && i > hl) ? trow[v] : 0ull;
             const bool fh_on = (fh & 0x3fffffull) != 0, fh2_on = (fh2 & 0x3fffffull) != 0, ft_on = (ft & 0x3fffffull) != 0;
-            const uint32_t sh = claim_by_class(FILL ? ru : cu, hub_class(fh), fh_on, lane);
-            const uint32_t sh2 = claim_by_class(FILL ? ru : cu, hub_class(fh2), fh2_on, lane);
-            const uint32_t st = claim_by_class(FILL ? ru : cu, tail_class(ft), ft_on, lane);
+            const uint32_t sh = claim_by_class(FILL ? ru : cu, hub_class(cc, fh), fh_on, lane);
+            const uint32_t sh2 = claim_by_class(FILL ? ru : cu, hub_class(cc, fh2), fh2_on, lane);
+            const uint32_t st = claim_by_class(FILL ? ru : cu, tail_class(cc, ft), ft_on, lane);
             if (FILL) {
-                if (fh_on) htask[hbeg[pos] + cu[hub_class(fh)] + sh] = fh;
-                if (fh2_on) htask[hbeg[pos] + cu[hub_class(fh2)] + sh2] = fh2;
-                if (ft_on) ttask[tbeg[pos] + cu[tail_class(ft)] + st] = ft;
+                if (fh_on) htask[hbeg[pos] + cu[hub_class(cc, fh)] + sh] = fh;
+                if (fh2_on) htask[hbeg[pos] + cu[hub_class(cc, fh2)] + sh2] = fh2;
+                if (ft_on) ttask[tbeg[pos] + cu[tail_class(cc, ft)] + st] = ft;
             }
             kept += __popcll(__ballot(fwd));
             if (v >= 0 && reverse) {  // u's rows, cut at v, against v
@@ -764,16 +768,16 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                                          rt = ct ? (du_t & ~0x3fffffull) | ct : 0ull;
                 uint32_t *cv = cnt + pv * kClasses;
                 if (!FILL) {
-                    if (rh) atomicAdd(&cv[hub_class(rh)], 1u);
-                    if (rh2) atomicAdd(&cv[hub_class(rh2)], 1u);
-                    if (rt) atomicAdd(&cv[tail_class(rt)], 1u);
+                    if (rh) atomicAdd(&cv[hub_class(cc, rh)], 1u);
+                    if (rh2) atomicAdd(&cv[hub_class(cc, rh2)], 1u);
+                    if (rt) atomicAdd(&cv[tail_class(cc, rt)], 1u);
                     atomicAdd(&tunits[v], 1);
                     ++rev;
                 } else {
                     uint32_t *rv = cur + pv * kClasses;
-                    if (rh) htask[hbeg[pv] + cv[hub_class(rh)] + atomicAdd(&rv[hub_class(rh)], 1u)] = rh;
-                    if (rh2) htask[hbeg[pv] + cv[hub_class(rh2)] + atomicAdd(&rv[hub_class(rh2)], 1u)] = rh2;
-                    if (rt) ttask[tbeg[pv] + cv[tail_class(rt)] + atomicAdd(&rv[tail_class(rt)], 1u)] = rt;
+                    if (rh) htask[hbeg[pv] + cv[hub_class(cc, rh)] + atomicAdd(&rv[hub_class(cc, rh)], 1u)] = rh;
+                    if (rh2) htask[hbeg[pv] + cv[hub_class(cc, rh2)] + atomicAdd(&rv[hub_class(cc, rh2)], 1u)] = rh2;
+                    if (rt) ttask[tbeg[pv] + cv[tail_class(cc, rt)] + atomicAdd(&rv[tail_class(cc, rt)], 1u)] = rt;
                 }
             }
         }
@@ -785,22 +789,32 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
     }
 }
 // work items: every receiver's list in chunks of kTaskChunk entries (run once for the hub lists, once for the tail lists)
-__global__ void k_item_counts(int64_t n_recv, const int64_t *__restrict__ lbeg, int64_t *__restrict__ items) {
+// (hub lists: phase by phase — TcClasses — with the items of phase 0 of ALL receivers first: slot ph * n_recv + p; the tail lists have one phase)
+__global__ void k_item_counts(int64_t n_recv, const int64_t *__restrict__ lbeg, const uint32_t *__restrict__ cnt, TcClasses cc, int phases, int64_t *__restrict__ items) {
     const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p > n_recv) return;
-    items[p] = p < n_recv ? (lbeg[p + 1] - lbeg[p] + kTaskChunk - 1) / kTaskChunk : 0;
+    if (p == n_recv) { items[int64_t(phases) * n_recv] = 0; return; }
+    for (int ph = 0; ph < phases; ++ph) {
+        int64_t b = 0, e = lbeg[p + 1] - lbeg[p];
+        if (phases > 1) hub_phase_range(cc, cnt + p * cc.count(), e, ph, &b, &e);
+        items[int64_t(ph) * n_recv + p] = (e - b + kTaskChunk - 1) / kTaskChunk;
+    }
 }
 // one thread per receiver: its list in chunks of kTaskChunk entries, each a self-contained record (device_graph.hpp); the pivot's
 // container part from coff (hoff / toff)
 __global__ void k_item_fill(int64_t n_recv, const int32_t *__restrict__ recv_v, const int32_t *__restrict__ opos, const int64_t *__restrict__ lbeg,
                             const int64_t *__restrict__ ioff, const unsigned long long *__restrict__ task, const int64_t *__restrict__ coff, int kind,
-                            gmsx_tc_item *__restrict__ items) {
+                            const uint32_t *__restrict__ cnt, TcClasses cc, int phases, gmsx_tc_item *__restrict__ items) {
     const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p >= n_recv) return;
     const int32_t w = recv_v[p];
-    const int64_t b = lbeg[p], e = lbeg[p + 1];
     const uint64_t cont = uint64_t(coff[w]) | (uint64_t(coff[w + 1] - coff[w]) << 40);
-    int64_t k = ioff[p];
+    for (int ph = 0; ph < phases; ++ph) {
+    int64_t b = 0, e = lbeg[p + 1] - lbeg[p];
+    if (phases > 1) hub_phase_range(cc, cnt + p * cc.count(), e, ph, &b, &e);
+    b += lbeg[p];
+    e += lbeg[p];
+    int64_t k = ioff[int64_t(ph) * n_recv + p];
     for (int64_t x = b; x < e; x += kTaskChunk, ++k) {
         const int ne = int(min(int64_t(kTaskChunk), e - x));
         gmsx_tc_item it{};
@@ -818,6 +832,7 @@ __global__ void k_item_fill(int64_t n_recv, const int32_t *__restrict__ recv_v, 
             it.fbeg[f] = uint16_t(lo);
         }
         items[k] = it;
+    }
     }
 }
 
@@ -1431,6 +1446,15 @@ static int build_tc_sets(gmsx_graph *g) {
         DevGuard g_rv{recv_v};
         if (std::max<int64_t>(n_heavy, L) > 0)
             hipLaunchKernelGGL(k_recv_vertices, dim3(unsigned(std::max<int64_t>(n_heavy, L) / 256 + 1)), dim3(256), 0, s, n_heavy, L, g->order, g->dplus, lidx, recv_v);
+        // hot windows of the hub lists (device_graph.hpp): GMSX_TC_HOT_WINDOWS x GMSX_TC_HOT_KB of the pool's front, GMSX_TC_HOT_MIN entries
+        {
+            auto env_int = [](const char *name, int dflt) { const char *e = std::getenv(name); return e ? std::atoi(e) : dflt; };
+            g->tc_hot_windows = std::max(0, std::min(kMaxHotWindows, env_int("GMSX_TC_HOT_WINDOWS", kDefaultHotWindows)));
+            g->tc_window_units = uint32_t(std::max(1, env_int("GMSX_TC_HOT_KB", kDefaultHotKB))) * 64u;
+            g->tc_hot_min = std::max(1, env_int("GMSX_TC_HOT_MIN", kDefaultHotMin));
+        }
+        const TcClasses cc{g->tc_hot_windows, g->tc_window_units, g->tc_hot_min};
+        const int kClasses = cc.count();
         uint32_t *cnt = nullptr, *cur = nullptr;
         if (int rc = dmalloc(&cnt, n_recv * kClasses + 1, nullptr)) return rc;
         DevGuard g_cnt{cnt};
@@ -1457,14 +1481,14 @@ static int build_tc_sets(gmsx_graph *g) {
         // COUNT
         if (n > 0)
             hipLaunchKernelGGL(k_inline_entries<false>, dim3(vb), dim3(256), 0, s, n, g->dplus, opos, lidx, n_heavy, g->inline_limit, ihoff, itoff, inline_h_base,
-                               inline_t_base, cnt, cur, hbeg, tbeg, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), totals);
+                               inline_t_base, cnt, cur, hbeg, tbeg, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), totals, cc);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->srow2, g->ksplit, g->trow,
                                two_sided, opos, cnt, cur, hbeg, tbeg, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), g->tunits,
-                               totals + 2, g->spool, g->tpool, g->inline_limit, g->shard_nparts, g->shard_part);
+                               totals + 2, g->spool, g->tpool, g->inline_limit, g->shard_nparts, g->shard_part, cc);
         pt.mark("task lists count");
         // class offsets, list offsets
-        hipLaunchKernelGGL(k_list_sizes, dim3(unsigned(n_recv / 256 + 1)), dim3(256), 0, s, n_recv, cnt, hcnt, tcnt);
+        hipLaunchKernelGGL(k_list_sizes, dim3(unsigned(n_recv / 256 + 1)), dim3(256), 0, s, n_recv, cnt, hcnt, tcnt, cc);
         if (int rc = exclusive_scan_i64(hcnt, hbeg, n_recv + 1, s)) return rc;
         if (int rc = exclusive_scan_i64(tcnt, tbeg, n_recv + 1, s)) return rc;
         unsigned long long tot[3] = {0, 0, 0};
@@ -1480,28 +1504,30 @@ static int build_tc_sets(gmsx_graph *g) {
         // FILL
         if (n > 0)
             hipLaunchKernelGGL(k_inline_entries<true>, dim3(vb), dim3(256), 0, s, n, g->dplus, opos, lidx, n_heavy, g->inline_limit, ihoff, itoff, inline_h_base,
-                               inline_t_base, cnt, cur, hbeg, tbeg, g->htask, g->ttask, totals);
+                               inline_t_base, cnt, cur, hbeg, tbeg, g->htask, g->ttask, totals, cc);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->srow2, g->ksplit, g->trow,
-                               two_sided, opos, cnt, cur, hbeg, tbeg, g->htask, g->ttask, g->tunits, totals + 2, g->spool, g->tpool, g->inline_limit, g->shard_nparts, g->shard_part);
+                               two_sided, opos, cnt, cur, hbeg, tbeg, g->htask, g->ttask, g->tunits, totals + 2, g->spool, g->tpool, g->inline_limit, g->shard_nparts, g->shard_part, cc);
         pt.mark("task lists fill");
         // work items
+        const int hub_phases = cc.hub_phases();
+        const int64_t slots = int64_t(hub_phases) * n_recv;
         int64_t *icnt = nullptr, *ioff = nullptr;
-        if (int rc = dmalloc(&icnt, n_recv + 1, nullptr)) return rc;
+        if (int rc = dmalloc(&icnt, slots + 1, nullptr)) return rc;
         DevGuard g_ic{icnt};
-        if (int rc = dmalloc(&ioff, n_recv + 1, nullptr)) return rc;
+        if (int rc = dmalloc(&ioff, slots + 1, nullptr)) return rc;
         DevGuard g_io{ioff};
         const unsigned rb = unsigned(n_recv / 256 + 1);
-        hipLaunchKernelGGL(k_item_counts, dim3(rb), dim3(256), 0, s, n_recv, hbeg, icnt);
-        if (int rc = exclusive_scan_i64(icnt, ioff, n_recv + 1, s)) return rc;
-        GMSX_HIP(hipMemcpy(&g->hitems, ioff + n_recv, sizeof(int64_t), hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(k_item_counts, dim3(rb), dim3(256), 0, s, n_recv, hbeg, cnt, cc, hub_phases, icnt);
+        if (int rc = exclusive_scan_i64(icnt, ioff, slots + 1, s)) return rc;
+        GMSX_HIP(hipMemcpy(&g->hitems, ioff + slots, sizeof(int64_t), hipMemcpyDeviceToHost));
         if (int rc = dmalloc(&g->hitem, g->hitems + 1, g)) return rc;
-        if (n_recv > 0) hipLaunchKernelGGL(k_item_fill, dim3(rb), dim3(256), 0, s, n_recv, recv_v, opos, hbeg, ioff, g->htask, g->hoff, 0, g->hitem);
-        hipLaunchKernelGGL(k_item_counts, dim3(rb), dim3(256), 0, s, n_recv, tbeg, icnt);
+        if (n_recv > 0) hipLaunchKernelGGL(k_item_fill, dim3(rb), dim3(256), 0, s, n_recv, recv_v, opos, hbeg, ioff, g->htask, g->hoff, 0, cnt, cc, hub_phases, g->hitem);
+        hipLaunchKernelGGL(k_item_counts, dim3(rb), dim3(256), 0, s, n_recv, tbeg, cnt, cc, 1, icnt);
         if (int rc = exclusive_scan_i64(icnt, ioff, n_recv + 1, s)) return rc;
         GMSX_HIP(hipMemcpy(&g->titems, ioff + n_recv, sizeof(int64_t), hipMemcpyDeviceToHost));
         if (int rc = dmalloc(&g->titem, g->titems + 1, g)) return rc;
-        if (n_recv > 0) hipLaunchKernelGGL(k_item_fill, dim3(rb), dim3(256), 0, s, n_recv, recv_v, opos, tbeg, ioff, g->ttask, g->toff, 1, g->titem);
+        if (n_recv > 0) hipLaunchKernelGGL(k_item_fill, dim3(rb), dim3(256), 0, s, n_recv, recv_v, opos, tbeg, ioff, g->ttask, g->toff, 1, cnt, cc, 1, g->titem);
         if (g->hitems >= (int64_t(1) << 31) || g->titems >= (int64_t(1) << 31)) return GMSX_ERR_DEVICE_MEM;  // 32-bit queue tickets
         GMSX_HIP(hipStreamSynchronize(s));
     }

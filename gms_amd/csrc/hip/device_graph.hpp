@@ -104,6 +104,13 @@ struct gmsx_graph {
     // independent.  Edge e of the (deterministic) list belongs to shard shard_of(e, nparts) — the pivots' rule; a sharded upload keeps its own at slot e / nparts.
     uint4 *ledge = nullptr;
     int64_t n_ledge = 0, ledge_total = 0;
+    // HOT WINDOWS (round 4): the hub-entry list of a receiver is laid out phase by phase — first the entries whose stream row starts in
+    // window 0 of the pool ([0, tc_window_units) 16-byte units: the rows of the biggest hubs, the most often streamed bytes of the graph),
+    // then window 1 … and last everything else — and the work items of phase 0 of ALL receivers come first, then phase 1 …: while a phase
+    // runs, the rows streamed fit the 4 MB L2 of every XCD instead of passing through it.  0 windows = one phase (rounds 1-3 order).
+    int tc_hot_windows = 0;
+    uint32_t tc_window_units = 1;
+    int tc_hot_min = 0;                  // a receiver with fewer entries than this in a window streams them with its next phase
     int32_t inline_limit = 0;            // light pivots hand their edges to members of rank id < inline_limit (and to heavy ones) as INLINE ROWS
     int64_t inline_units = 0;            // 16-byte units of all inline rows (inside spool / tpool)
     unsigned long long *trow = nullptr;
@@ -153,13 +160,46 @@ static constexpr int kTaskChunk = 512;   // entries per work item (4 KB of descr
 // in steps of ~sqrt(2): <= 4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192, more units — the groups of a wave work on rows of one class side
 // by side, and the wave is done when its longest row is.
 static constexpr int kLenClasses = 12;
-static constexpr int kHubClasses = 4 * kLenClasses, kTailClasses = 2 * kLenClasses, kClasses = kHubClasses + kTailClasses;
+static constexpr int kHubClasses = 4 * kLenClasses, kTailClasses = 2 * kLenClasses;
+static constexpr int kMaxHotWindows = 8;
+// hub classes exist once per PHASE of the hub lists (gmsx_graph::tc_hot_windows): phase = the window of the pool the entry's row starts in,
+// the last phase everything behind the windows
+struct TcClasses {
+    int hot_windows;        // 0 … kMaxHotWindows
+    uint32_t window_units;  // 16-byte units per window (> 0)
+    int hot_min;
+    __host__ __device__ int hub_phases() const { return hot_windows + 1; }
+    __host__ __device__ int tail_base() const { return hub_phases() * kHubClasses; }
+    __host__ __device__ int count() const { return tail_base() + kTailClasses; }
+    __host__ __device__ int phase(unsigned long long d) const {
+        if (hot_windows <= 0) return 0;
+        const unsigned long long w = (d >> 24) / window_units;
+        return w < (unsigned long long)hot_windows ? int(w) : hot_windows;
+    }
+};
 __host__ __device__ inline int length_class(uint32_t u) {
     return u <= 16 ? (u <= 4 ? 0 : u <= 8 ? 1 : u <= 12 ? 2 : 3) : u <= 64 ? (u <= 24 ? 4 : u <= 32 ? 5 : u <= 48 ? 6 : 7) : (u <= 96 ? 8 : u <= 128 ? 9 : u <= 192 ? 10 : 11);
 }
-__host__ __device__ inline int hub_class(unsigned long long d) { return int((uint32_t(d) >> 22) & 3u) * kLenClasses + length_class(uint32_t(d) & 0x3fffffu); }
-__host__ __device__ inline int tail_class(unsigned long long d) {
-    return kHubClasses + (((uint32_t(d) >> 22) & 3u) == 2u ? kLenClasses : 0) + length_class(uint32_t(d) & 0x3fffffu);
+__host__ __device__ inline int hub_class(const TcClasses &cc, unsigned long long d) {
+    return cc.phase(d) * kHubClasses + int((uint32_t(d) >> 22) & 3u) * kLenClasses + length_class(uint32_t(d) & 0x3fffffu);
+}
+__host__ __device__ inline int tail_class(const TcClasses &cc, unsigned long long d) {
+    return cc.tail_base() + (((uint32_t(d) >> 22) & 3u) == 2u ? kLenClasses : 0) + length_class(uint32_t(d) & 0x3fffffu);
+}
+// the part [*b, *e) of a receiver's hub list (len entries; c = its class offsets) that phase ph's work items cover: its window's entries
+// plus those of the windows in front that were too few (< hot_min) to be worth items of their own; the last phase takes what is left
+__host__ __device__ inline void hub_phase_range(const TcClasses &cc, const uint32_t *c, int64_t len, int ph, int64_t *b, int64_t *e) {
+    int64_t start = 0;
+    for (int q = 0;; ++q) {
+        const int64_t end = q < cc.hot_windows ? int64_t(c[(q + 1) * kHubClasses]) : len;
+        const bool own = q == cc.hot_windows || end - start >= cc.hot_min;
+        if (q == ph) {
+            *b = start;
+            *e = own ? end : start;
+            return;
+        }
+        if (own) start = end;
+    }
 }
 // which rank of a multi-GPU run owns the pivot at position `pos` of `order`: stripes of nparts positions, every other one reversed (the
 // order is by decreasing d+, so plain striding would always hand the costlier pivot of a stripe to the lower rank)
