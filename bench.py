@@ -670,9 +670,10 @@ def main():
         "achieved_is": achieved_src, "traffic_source": traffic_source,
         "memory_level": "beyond-L2 (Infinity Cache + HBM): FETCH_SIZE counts L2 misses, MALL hits included; no DRAM-side counter separates them",
         "kernel_ms": avg_kernel_ms, "kernel_hash": khash,
-        "kernel": "k_tc_items (ONE persistent launch over the work items: a pivot's row part in LDS, the stream rows its task-list entries name "
-                  "streamed through it; >98 % of the bytes and of the time) + k_tc_light (edges between two light vertices, all-pairs in registers) "
-                  "behind it on the launch stream; kernel_ms is the HIP-event wall time of the pass; traffic is summed over both",
+        "kernel": "k_tc_items<false> (hub items) + k_tc_items<true> (tail items): one PERSISTENT launch per item queue — a pivot's row part in LDS, "
+                  "the stream rows its task-list entries name streamed through it; ~95 % of the bytes and of the time — + k_tc_light (edges between two "
+                  "light vertices, all-pairs in registers), one after the other on the launch stream; kernel_ms is the HIP-event wall time of the "
+                  "whole pass; traffic is summed over the three",
         "algorithmic_bytes": stream_bytes, "algorithmic_GBps": stream_bytes / t_kernel / 1e9,
         "work_efficiency_traffic_over_algorithmic": (traffic / stream_bytes) if (traffic and stream_bytes) else None,
         "l2_hit_rate": trec.get("l2_hit_rate") if trec else None,
