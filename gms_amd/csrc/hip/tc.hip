@@ -673,18 +673,32 @@ __global__ __launch_bounds__(256) void k_tc_light(const uint16_t *__restrict__ h
         }
         return r;
     };
+    // registers a part of `len` ids needs, the maximum over the four groups of the wave (uniform)
+    auto wave_max = [](int x) {
+        return max(max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)), max(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+    };
     auto load_rows = [&](const LightRec &r) -> LightRows {
         const int64_t hu = int64_t((uint64_t(r.r0.y & 0xffu) << 32) | r.r0.x), tu = int64_t((uint64_t(r.r0.w & 0xffu) << 32) | r.r0.z);
         const int64_t hv = int64_t((uint64_t(r.r1.y & 0xffu) << 32) | r.r1.x), tv = int64_t((uint64_t(r.r1.w & 0xffu) << 32) | r.r1.z);
         const int hlu = int(r.r0.y >> 8), tlu = int(r.r0.w >> 8), hlv = int(r.r1.y >> 8), tlv = int(r.r1.w >> 8);
+        // the first register of every part unconditionally (countable loads); the second … fourth only when a group of the wave has that
+        // many ids (a scalar branch: most light rows have fewer than 16 ids per part)
+        const int more = wave_max((max(max(hlu, hlv), max(tlu, tlv)) + 15) >> 4);
         LightRows w;
+        w.ah[0] = hadj[hlu ? hu + min(sub, hlu - 1) : 0];
+        w.bh[0] = hadj[hlv ? hv + min(sub, hlv - 1) : 0];
+        w.at[0] = uint32_t(tadj[tlu ? tu + min(sub, tlu - 1) : 0]);
+        w.bt[0] = uint32_t(tadj[tlv ? tv + min(sub, tlv - 1) : 0]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = sub + 16 * k;
-            w.ah[k] = hadj[hlu ? hu + min(i, hlu - 1) : 0];
-            w.bh[k] = hadj[hlv ? hv + min(i, hlv - 1) : 0];
-            w.at[k] = uint32_t(tadj[tlu ? tu + min(i, tlu - 1) : 0]);
-            w.bt[k] = uint32_t(tadj[tlv ? tv + min(i, tlv - 1) : 0]);
+        for (int k = 1; k < 4; ++k) {
+            w.ah[k] = w.bh[k] = w.at[k] = w.bt[k] = 0;
+            if (k < more) {
+                const int i = sub + 16 * k;
+                w.ah[k] = hadj[hlu ? hu + min(i, hlu - 1) : 0];
+                w.bh[k] = hadj[hlv ? hv + min(i, hlv - 1) : 0];
+                w.at[k] = uint32_t(tadj[tlu ? tu + min(i, tlu - 1) : 0]);
+                w.bt[k] = uint32_t(tadj[tlv ? tv + min(i, tlv - 1) : 0]);
+            }
         }
         return w;
     };
@@ -698,9 +712,6 @@ __global__ __launch_bounds__(256) void k_tc_light(const uint16_t *__restrict__ h
             const LightRec rec_nn = load_rec(t + 2);
             const int hlu = int(rec.r0.y >> 8), tlu = int(rec.r0.w >> 8), hlv = int(rec.r1.y >> 8), tlv = int(rec.r1.w >> 8);
             // registers in use, the maximum over the four groups of the wave (uniform)
-            auto wave_max = [](int x) {
-                return max(max(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)), max(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
-            };
             const int nah = wave_max((hlu + 15) >> 4), nbh = wave_max((hlv + 15) >> 4), nat = wave_max((tlu + 15) >> 4), nbt = wave_max((tlv + 15) >> 4);
             uint32_t c = 0;
 #pragma unroll
