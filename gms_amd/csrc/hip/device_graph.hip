@@ -479,18 +479,22 @@ __global__ void k_count_ge(int64_t n, const int32_t *__restrict__ keys, int32_t 
 
 // ---- inline rows (build step 4c / 5b) --------------------------------------------------------------------------------------------
 static constexpr int kInlineChunk = 64;  // units of an inline row per task entry
-static constexpr int kInlineFirst = 64;  // a heavy pivot hands the edges to its first kInlineFirst members over inline too: their cut rows are 1-8 units,
-                                         // 2 bytes per id inline against 16 bytes of entry + a 128-byte line behind a pointer
+// A heavy pivot hands the edges to its first gmsx_graph::inline_first (<= 64) members over inline too: their cut rows are 1-8 units, 2 bytes
+// per id inline against 8 bytes of entry + a line behind a pointer.  The copies grow with the SQUARE of that number (member i receives i ids:
+// 2016 ids per heavy pivot at 64): scale 26, device bytes / ms per pass at 64, 48, 40, 32 = 48.6 GB / 67.2, 44.3 / 67.6, 42.7 / 67.7,
+// 41.4 / 68.0 (GMSX_TC_INLINE_FIRST; round 4 took 48: -4.2 GB for +0.6 %).
+static constexpr int kDefaultInlineFirst = 48;
+static constexpr int kInlineFirstMax = 64;
 __device__ __forceinline__ bool takes_inline(int32_t v, int32_t inline_limit, const int32_t *__restrict__ dplus) {
     return v < inline_limit || dplus[v] >= kHeavy;
 }
 // Wave per pivot u (positions [first, end) of `order`: every pivot with d+ >= 2), one lane per member (hub part — padded at its end — in
-// the low lanes, tail part behind it, both ascending; a light pivot has hl + tl <= 64, a heavy one takes part with its first 64).  COUNT: ids handed over per receiving member; FILL: copies them (cnt_* are
+// the low lanes, tail part behind it, both ascending; a light pivot has hl + tl <= 64, a heavy one takes part with its first inline_first).  COUNT: ids handed over per receiving member; FILL: copies them (cnt_* are
 // the cursors then).  (A far member that is HEAVY takes the edge over inline like a near one; k_tc_light's edge list leaves it out.)
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_inline_rows(int64_t first, int64_t end, const int32_t *__restrict__ order, const int64_t *__restrict__ hoff,
                                                      const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
-                                                     const int32_t *__restrict__ dplus, int32_t inline_limit, const int32_t *__restrict__ opos, int nparts, int part,
+                                                     const int32_t *__restrict__ dplus, int32_t inline_limit, int inline_first, const int32_t *__restrict__ opos, int nparts, int part,
                                                      unsigned long long *__restrict__ cnt_h,
                                                      unsigned long long *__restrict__ cnt_t, const int64_t *__restrict__ ihoff,
                                                      const int64_t *__restrict__ itoff, int64_t base_h, uint16_t *__restrict__ pool_h, int64_t base_t,
@@ -501,8 +505,9 @@ __global__ __launch_bounds__(256) void k_inline_rows(int64_t first, int64_t end,
     for (int64_t pos = first + wave0; pos < end; pos += nwaves) {
         const int32_t u = order[pos];
         const int64_t hb = hoff[u], tb = toff[u];
-        // a heavy pivot takes part with its first kInlineFirst members only (the low lanes of its combined list)
-        const int hl = min(int(hoff[u + 1] - hb), kInlineFirst), tl = min(int(toff[u + 1] - tb), kInlineFirst - hl);
+        // a heavy pivot takes part with its first inline_first members only (the low lanes of its combined list); a light one with all
+        const int first_u = dplus[u] >= kHeavy ? inline_first : kInlineFirstMax;
+        const int hl = min(int(hoff[u + 1] - hb), first_u), tl = min(int(toff[u + 1] - tb), first_u - hl);
         int32_t mv = 0x7fffffff;
         if (lane < hl) {
             const uint32_t x = hadj[hb + lane];
@@ -710,7 +715,7 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ cur, const int64_t *__restrict__ hbeg,
                                                     const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ htask, unsigned long long *__restrict__ ttask,
                                                     int32_t *__restrict__ tunits, unsigned long long *__restrict__ reversed, const uint32_t *__restrict__ spool,
-                                                    const uint32_t *__restrict__ tpool, int32_t inline_limit, int nparts, int part, TcClasses cc) {
+                                                    const uint32_t *__restrict__ tpool, int32_t inline_limit, int inline_first, int nparts, int part, TcClasses cc) {
     const int kClasses = cc.count();
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -732,7 +737,7 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                 const uint32_t x = hadj[hb + i];
                 if (x != 0xFFFFu) v = int32_t(x);
             } else if (i < hl + tl) v = tadj[tb + i - hl];
-            if (v >= 0 && i > 0 && i < kInlineFirst && takes_inline(v, inline_limit, dplus)) v = -1;  // handed over inline (k_inline_rows): no entry
+            if (v >= 0 && i > 0 && i < inline_first && takes_inline(v, inline_limit, dplus)) v = -1;  // handed over inline (k_inline_rows): no entry
             bool reverse = false;
             uint32_t ch = 0, ch2 = 0, ct = 0;  // units of u's rows that v would have to stream (ch2: the second slot of a hybrid row)
             if (v >= 0 && i > 0 && two_sided && dplus[v] >= kHeavy) {
@@ -1229,6 +1234,8 @@ static int build_tc_sets(gmsx_graph *g) {
         }
         if (!forced && ((flags >> 8) & 0xffffu)) want = int64_t(4) * hub_limit;  // hub-limit test hook: near AND far tail on small graphs
         g->inline_limit = int32_t(std::min<int64_t>(n, std::max<int64_t>(want, g->dense_limit)));
+        g->inline_first = kDefaultInlineFirst;
+        if (const char *e = std::getenv("GMSX_TC_INLINE_FIRST")) g->inline_first = std::max(1, std::min(kInlineFirstMax, std::atoi(e)));  // A/B knob
         if (int rc = dmalloc(&g->tsplit, n, g)) return rc;
         if (n > 0) hipLaunchKernelGGL(k_tail_split, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->toff, g->tadj, g->inline_limit, g->tsplit);
     }
@@ -1264,7 +1271,7 @@ static int build_tc_sets(gmsx_graph *g) {
         GMSX_HIP(hipMemsetAsync(inl_t, 0, size_t(n + 1) * sizeof(unsigned long long), s));
         if (n_work > 0)
             hipLaunchKernelGGL(k_inline_rows<false>, dim3(grid_for_waves(n_work)), dim3(256), 0, s, int64_t(0), n_work, g->order, g->hoff, g->hadj,
-                               g->toff, g->tadj, g->dplus, g->inline_limit, opos, g->shard_nparts, g->shard_part, inl_h, inl_t, ihoff, itoff, int64_t(0), static_cast<uint16_t *>(nullptr),
+                               g->toff, g->tadj, g->dplus, g->inline_limit, g->inline_first, opos, g->shard_nparts, g->shard_part, inl_h, inl_t, ihoff, itoff, int64_t(0), static_cast<uint16_t *>(nullptr),
                                int64_t(0), static_cast<int32_t *>(nullptr));
         int64_t *uh = nullptr, *ut = nullptr;
         if (int rc = dmalloc(&uh, n + 1, nullptr)) return rc;
@@ -1390,7 +1397,7 @@ static int build_tc_sets(gmsx_graph *g) {
         GMSX_HIP(hipMemsetAsync(inl_h, 0, size_t(n + 1) * sizeof(unsigned long long), s));  // now the fill cursors
         GMSX_HIP(hipMemsetAsync(inl_t, 0, size_t(n + 1) * sizeof(unsigned long long), s));
         hipLaunchKernelGGL(k_inline_rows<true>, dim3(grid_for_waves(n_work)), dim3(256), 0, s, int64_t(0), n_work, g->order, g->hoff, g->hadj, g->toff,
-                           g->tadj, g->dplus, g->inline_limit, opos, g->shard_nparts, g->shard_part, inl_h, inl_t, ihoff, itoff, inline_h_base, reinterpret_cast<uint16_t *>(g->spool),
+                           g->tadj, g->dplus, g->inline_limit, g->inline_first, opos, g->shard_nparts, g->shard_part, inl_h, inl_t, ihoff, itoff, inline_h_base, reinterpret_cast<uint16_t *>(g->spool),
                            inline_t_base, reinterpret_cast<int32_t *>(g->tpool));
     }
     pt.mark("inline rows fill");
@@ -1485,7 +1492,7 @@ static int build_tc_sets(gmsx_graph *g) {
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->srow2, g->ksplit, g->trow,
                                two_sided, opos, cnt, cur, hbeg, tbeg, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), g->tunits,
-                               totals + 2, g->spool, g->tpool, g->inline_limit, g->shard_nparts, g->shard_part, cc);
+                               totals + 2, g->spool, g->tpool, g->inline_limit, g->inline_first, g->shard_nparts, g->shard_part, cc);
         pt.mark("task lists count");
         // class offsets, list offsets
         hipLaunchKernelGGL(k_list_sizes, dim3(unsigned(n_recv / 256 + 1)), dim3(256), 0, s, n_recv, cnt, hcnt, tcnt, cc);
@@ -1507,7 +1514,7 @@ static int build_tc_sets(gmsx_graph *g) {
                                inline_t_base, cnt, cur, hbeg, tbeg, g->htask, g->ttask, totals, cc);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<true>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->srow2, g->ksplit, g->trow,
-                               two_sided, opos, cnt, cur, hbeg, tbeg, g->htask, g->ttask, g->tunits, totals + 2, g->spool, g->tpool, g->inline_limit, g->shard_nparts, g->shard_part, cc);
+                               two_sided, opos, cnt, cur, hbeg, tbeg, g->htask, g->ttask, g->tunits, totals + 2, g->spool, g->tpool, g->inline_limit, g->inline_first, g->shard_nparts, g->shard_part, cc);
         pt.mark("task lists fill");
         // work items
         const int hub_phases = cc.hub_phases();
@@ -1546,6 +1553,13 @@ static int build_tc_sets(gmsx_graph *g) {
         const size_t nn = size_t(n > 0 ? n : 1);
         drop(g->tsplit, nn * sizeof(int32_t));
         drop(g->srow2, nn * sizeof(unsigned long long));
+        // the first descriptors too: every task entry carries its own copy, and only gmsx_tc_row_histogram's what-if estimates read them
+        // afterwards (GMSX_TC_KEEP_ROWS=1 keeps them for tools/tc_row_hist.py)
+        const char *keep = std::getenv("GMSX_TC_KEEP_ROWS");
+        if (!(keep && std::atoi(keep) != 0)) {
+            drop(g->srow, nn * sizeof(unsigned long long));
+            drop(g->trow, nn * sizeof(unsigned long long));
+        }
         drop(g->ksplit, size_t(n + 1) * sizeof(int32_t));
     }
     return GMSX_OK;

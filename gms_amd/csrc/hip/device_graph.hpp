@@ -111,6 +111,7 @@ struct gmsx_graph {
     int tc_hot_windows = 0;
     uint32_t tc_window_units = 1;
     int tc_hot_min = 0;                  // a receiver with fewer entries than this in a window streams them with its next phase
+    int inline_first = 64;               // a HEAVY pivot hands the edges to its first inline_first members (<= 64) over inline rows as well
     int32_t inline_limit = 0;            // light pivots hand their edges to members of rank id < inline_limit (and to heavy ones) as INLINE ROWS
     int64_t inline_units = 0;            // 16-byte units of all inline rows (inside spool / tpool)
     unsigned long long *trow = nullptr;

@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
                                                   const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
-                                                  const int32_t *__restrict__ tunits, int32_t inline_limit, int64_t end, int nparts, int part,
+                                                  const int32_t *__restrict__ tunits, int32_t inline_limit, int inline_first, int64_t end, int nparts, int part,
                                                   unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
@@ -779,7 +779,7 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
         const int du = dplus[u];
         if (lane == 0) units += (unsigned long long)tunits[u];  // forward + reverse edges whose entries live here
         if (du >= kHeavy) {  // … and the edges to its first members that went inline (no entry anywhere)
-            const int hl = min(int(hoff[u + 1] - hoff[u]), 64), tl = min(int(toff[u + 1] - toff[u]), 64 - hl);
+            const int hl = min(int(hoff[u + 1] - hoff[u]), inline_first), tl = min(int(toff[u + 1] - toff[u]), inline_first - hl);
             int32_t v = -1;
             if (lane < hl) {
                 const uint32_t x = hadj[hoff[u] + lane];
@@ -953,6 +953,7 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
         }
     }
     for (int64_t pos = wave0; pos < end; pos += nwaves) {
+        if (!srow || !trow) break;  // the per-vertex descriptors are build-only unless GMSX_TC_KEEP_ROWS=1: no what-if estimates then
         const int32_t u = order[pos];
         const int du = dplus[u];
         if (du < 2) continue;
@@ -1159,7 +1160,7 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
         if (g->n > 0) {
             const int64_t blocks = std::min<int64_t>((g->n + 3) / 4, cap_blocks);
             hipLaunchKernelGGL(k_tc_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow,
-                               g->tunits, g->inline_limit, g->n, nparts, part, acc + kAccSlots * kAccStride);
+                               g->tunits, g->inline_limit, g->inline_first, g->n, nparts, part, acc + kAccSlots * kAccStride);
         }
         if (g->hitems > 0)
             hipLaunchKernelGGL(k_tc_item_stats, dim3(unsigned(std::min<int64_t>((g->hitems + 3) / 4, cap_blocks))), dim3(256), 0, s, g->hoff, 2, 0, g->htask, g->hitem,

@@ -199,7 +199,8 @@ int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21);
  * bin)*2] rows, [+1] units; cls 0..4 = hub rows as list / bitset / byte-delta, tail rows as list / delta; bin = 1 … 16 units exactly,
  * then 17-32, 33-64, … 1025+; out[240..243]: entries, inline entries, work items, bytes of the pivots' own containers;
  * out[248..251]: Σ over the oriented edges (u,v) of heavy then light pivots u of the stream units of v's rows and of min(units of
- * u's rows, units of v's rows); out[252]: the same sum for heavy u with u's rows cut at v's id (estimate).  256 values, host. */
+ * u's rows, units of v's rows); out[252]: the same sum for heavy u with u's rows cut at v's id (estimate) — out[248..252] are 0 unless the
+ * graph was built with GMSX_TC_KEEP_ROWS=1 (the per-vertex row descriptors they read are freed after the build).  256 values, host. */
 int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out256);
 /* Par::vertex_count2 / vertex_count2_once (parallel/vertex.h:14-49): counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| (= 2·triangles at u),
  * indexed by the vertex ids of the uploaded CSR.  Runs on the k = 3 bit-matrix kernels (one atomic per pivot member); graphs

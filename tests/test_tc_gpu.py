@@ -219,6 +219,7 @@ def test_inline_limit(gpu, oracle, hub_limit, inline_limit):
                                    {"GMSX_TC_ITEM_WGS": "1"}, {"GMSX_TC_ITEM_WGS": "3"}, {"GMSX_TC_GAP12": "0"}, {"GMSX_TC_GAP12": "2"},
                                    {"GMSX_TC_GAP12": "2", "GMSX_TC_DELTA": "0"}, {"GMSX_TC_HYBRID": "1"}, {"GMSX_TC_HYBRID": "2"},
                                    {"GMSX_TC_HYBRID": "2", "GMSX_TC_DELTA": "0"},
+                                   {"GMSX_TC_INLINE_FIRST": "64"}, {"GMSX_TC_INLINE_FIRST": "5"}, {"GMSX_TC_INLINE_FIRST": "1", "GMSX_TC_TWO_SIDED": "0"},
                                    {"GMSX_TC_HOT_WINDOWS": "1", "GMSX_TC_HOT_KB": "2", "GMSX_TC_HOT_MIN": "4"},
                                    {"GMSX_TC_HOT_WINDOWS": "3", "GMSX_TC_HOT_KB": "1", "GMSX_TC_HOT_MIN": "1"},
                                    {"GMSX_TC_HOT_WINDOWS": "8", "GMSX_TC_HOT_KB": "4", "GMSX_TC_HOT_MIN": "16", "GMSX_TC_PERSIST": "0"}])
@@ -227,8 +228,9 @@ def test_task_list_knobs(gpu, oracle, knobs):
     to because the member's row is the bigger one (reverse entry, cut at the member's id), or inside the member's inline rows.  With
     the hand-over off, the light-edge kernel on a side stream, the one-workgroup-per-item kernels of rounds 2-3 instead of the persistent
     one, one / three persistent workgroups per CU, or the sparse rows without / all in
-    the 12-bit-gap form, heavy rows split into a prefix bitmap + the rest (GMSX_TC_HYBRID), or the hub lists laid out and run in phases
-    by the pool window their rows start in (GMSX_TC_HOT_*), the count and the bookkeeping stay."""
+    the 12-bit-gap form, heavy rows split into a prefix bitmap + the rest (GMSX_TC_HYBRID), the hub lists laid out and run in phases
+    by the pool window their rows start in (GMSX_TC_HOT_*), or a heavy pivot handing more / fewer of its first members over inline
+    (GMSX_TC_INLINE_FIRST), the count and the bookkeeping stay."""
     old = {k: os.environ.get(k) for k in knobs}
     os.environ.update(knobs)
     try:
