@@ -1523,7 +1523,10 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     sh.pool_head = acc + kCtl + 4;
     sh.dir_count = acc + kCtl + 5;
     sh.max_stack = acc + kCtl + 6;
-    sh.budget = 512;  // nodes before a search is re-split: swept 128 … 8192 on the config-4 graph and Kronecker scale 14 after the occupancy work
+    // nodes before a search is re-split.  Round 3 swept 128 … 8192 on the config-4 graph and Kronecker scale 14 and took 512; with round 4's build
+    // pipeline the configs[3] graph takes 248.6 / 209.5 / 203.1 / 200.0 / 204.0 ms at 256 / 512 / 1024 / 2048 / 4096, RMAT 18 ef 64 (a = .45)
+    // 275.9 -> 260.1 ms at 2048, the sparse graphs (one round) are indifferent
+    sh.budget = 2048;
     sh.small_p = [] { const char *e = std::getenv("GMSX_BK_SMALL_P"); return e ? std::atoi(e) : 6; }();  // swept on the configs[3] graph: 0 (off) 316 ms, 2 304, 3 ~300, 4 295, 6 293, 8 295, 16 303
     sh.bmoff = g->bmoff;
     sh.bmpool = g->bmpool;
