@@ -230,7 +230,10 @@ struct BkShared {
     const uint32_t *bmpool;
     int32_t dense_limit;
 };
-static constexpr int kBkSplit = 8;    // records a level with pending branches is cut into when a search is split
+#ifndef GMSX_BK_SPLIT
+#define GMSX_BK_SPLIT 8
+#endif
+static constexpr int kBkSplit = GMSX_BK_SPLIT;    // records a level with pending branches is cut into when a search is split
 static constexpr int kRecHeader = 8;  // v, c, x, xf_ne, arena offset (2 words), 2 spare
 static constexpr unsigned long long kNoArena = ~0ull;
 
