@@ -130,14 +130,18 @@ __device__ __forceinline__ void set_insert(int32_t *tbl, uint32_t mask, int shif
     uint32_t h = hash_slot(w, shift);
     while (atomicCAS(&tbl[h], -1, w) != -1) h = (h + 1) & mask;
 }
+// (one exit condition per trip: with the two early returns of the obvious loop the compiler builds two nested exec-mask regions per probe,
+// ~20 scalar + vector instructions a trip; this is ~9)
 __device__ __forceinline__ uint32_t set_contains(const int32_t *tbl, uint32_t mask, int shift, int32_t w) {
-    uint32_t h = hash_slot(w, shift);
-    while (true) {
+    uint32_t h = hash_slot(w, shift), found = 0u;
+    bool go;
+    do {
         const int32_t x = tbl[h];
-        if (x == w) return 1u;
-        if (x == -1) return 0u;
+        found |= x == w ? 1u : 0u;
+        go = x != w && x != -1;
         h = (h + 1) & mask;
-    }
+    } while (go);
+    return found;
 }
 // Tail stream rows (trow / tpool: 32-bit ids, 4 per 16-byte unit, filler -2 — or 16-bit delta units, 6 ids each) against the pivot's
 // tail set; same shape as scan_srows.
@@ -154,12 +158,16 @@ static constexpr int kFilterWords = 1024;
 // SLOW PATH: which ids (bit tests, the unit's count cut off), and one exact probe per set bit, lane by lane (ffs loop: the lanes that
 // got here are few, and six exec-masked blocks — rounds 2-3 — cost 90 instructions for the wave whoever had a bit).
 __device__ __forceinline__ uint32_t flt_word(const uint32_t *flt, uint32_t id) { return flt[(id >> 5) & uint32_t(kFilterWords - 1)] >> (id & 31u); }
+// y where c (0 / 1) is set, else x — arithmetic, so that the select tree below stays free of branches (written with ?: the compiler turned
+// the six-way choice into nested exec-mask regions: ~25 instructions, most of them scalar, per probed id)
+__device__ __forceinline__ uint32_t pick(uint32_t c, uint32_t x, uint32_t y) { return x ^ ((x ^ y) & (0u - c)); }
 __device__ __forceinline__ uint32_t probe_set_bits(const int32_t *tbl, uint32_t mask, int shift, uint32_t m, const uint32_t (&id)[6]) {
     uint32_t c = 0;
     while (m) {
-        const int k = __ffs(int(m)) - 1;
+        const uint32_t k = uint32_t(__ffs(int(m)) - 1);
         m &= m - 1u;
-        const uint32_t w = k == 0 ? id[0] : k == 1 ? id[1] : k == 2 ? id[2] : k == 3 ? id[3] : k == 4 ? id[4] : id[5];
+        const uint32_t b0 = k & 1u, b1 = (k >> 1) & 1u, b2 = k >> 2;
+        const uint32_t w = pick(b2, pick(b1, pick(b0, id[0], id[1]), pick(b0, id[2], id[3])), pick(b0, id[4], id[5]));
         c += set_contains(tbl, mask, shift, int32_t(w));
     }
     return c;
