@@ -244,8 +244,11 @@ struct StepStream {
     int e, units, last, lim, j, form;
     const uint4 *row;
     int pending;  // steps of real entries in the ring
-    uint4 p[D];
-    int pj[D];    // unit index of the lane in that step | form << 24, -1 = none
+    // D == 1 keeps TWO slots and alternates between them (probe slot 0 while slot 1 loads, then the other way round): the same one step
+    // in flight, but no register-to-register copies of the unit being probed (five v_mov per step in the rotating form)
+    static constexpr int S = D == 1 ? 2 : D;
+    uint4 p[S];
+    int pj[S];    // unit index of the lane in that step | form << 24, -1 = none
     __device__ __forceinline__ void open_row() {
         const unsigned long long d = e < hi ? sdesc[e] : 0ull;
         row = pool4 + (d >> 24);
@@ -283,6 +286,23 @@ struct StepStream {
     template <class Hit>
     __device__ __forceinline__ uint32_t run(Hit hit) {
         uint32_t cnt = 0;
+        if constexpr (D == 1) {
+            auto step = [&](int cur, int nxt) {
+                pending -= 1;
+                issue(nxt);
+#ifdef GMSX_TC_NO_PROBE
+                if (pj[cur] >= 0) cnt += p[cur].x & 1u;
+#else
+                if (pj[cur] >= 0) cnt += hit(p[cur], pj[cur] & 0xffffff, pj[cur] >> 24);
+#endif
+            };
+            while (pending > 0) {
+                step(0, 1);
+                if (!(pending > 0)) break;
+                step(1, 0);
+            }
+            return cnt;
+        }
         while (pending > 0) {  // the groups of a wave differ by the lengths of their rows
 #pragma unroll
             for (int k = 0; k < D; ++k) {
