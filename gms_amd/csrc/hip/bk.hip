@@ -212,6 +212,18 @@ __device__ __forceinline__ int wave_sum(int x) {
 // inside a kernel.  If the arena or the pool is full the wave simply keeps searching (correctness never depends on it).
 #ifdef GMSX_BK_STATS
 __device__ unsigned long long g_bk_nodes;  // profiling build: nodes of the register-resident searches since the last read
+// profiling build: [0..7] entered nodes by candidate width c of the start vertex (<= 32, 64, 128, 256, 512, 1024, 2048, more); [8..15] entered nodes by
+// |P| (0, 1, 2-6, 7-16, 17-32, 33-64, 65-256, more); [16] entered with Xf non-empty; [17] branch steps; [18] leaf fast paths; [19] one-candidate-child
+// fast paths; [20] pushes; [21] pivot-scored nodes; [22] sum of |P u Xc| over them; [23] deepest level; [24] Xf words ANDed; [25] one-candidate nodes
+// [26] Xf checks of the fast paths, [27] their words, [28] cycles in Xf loops, [29] cycles in bk_search, [30] cycles in pivot scoring, [31] non-zero words of the child Xf of a push
+__device__ unsigned long long g_bk_hist[32];
+#define BK_STAT(i, v) do { if (lane == 0) atomicAdd(&g_bk_hist[i], (unsigned long long)(v)); } while (0)
+#define BK_T0() const long long t0_ = clock64()
+#define BK_T1(i) BK_STAT(i, clock64() - t0_)
+#else
+#define BK_T0() do { } while (0)
+#define BK_T1(i) do { } while (0)
+#define BK_STAT(i, v) do { } while (0)
 #endif
 struct BkShared {
     uint32_t *arena;
@@ -251,6 +263,10 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
     const int lvl = 3 * cw + xw + 1;
     unsigned budget = sh.budget, nodes = 0;
     int depth = 0;
+#ifdef GMSX_BK_STATS
+    const long long t_all_ = clock64();
+    struct TAll { long long t; int lane; __device__ ~TAll() { if (lane == 0) atomicAdd(&g_bk_hist[29], (unsigned long long)(clock64() - t)); } } t_all_guard{t_all_, lane};
+#endif
     auto any_of = [](const uint32_t (&a)[WPL]) {
         uint32_t r = a[0];
 #pragma unroll
@@ -269,6 +285,18 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
     while (true) {
         if (entering) {
             ++nodes;
+#ifdef GMSX_BK_STATS
+            {
+                int pc_ = 0;
+#pragma unroll
+                for (int h = 0; h < WPL; ++h) pc_ += __popc(P[h]);
+                pc_ = wave_sum(pc_);
+                BK_STAT(c <= 32 ? 0 : c <= 64 ? 1 : c <= 128 ? 2 : c <= 256 ? 3 : c <= 512 ? 4 : c <= 1024 ? 5 : c <= 2048 ? 6 : 7, 1);
+                BK_STAT(8 + (pc_ == 0 ? 0 : pc_ == 1 ? 1 : pc_ <= 6 ? 2 : pc_ <= 16 ? 3 : pc_ <= 32 ? 4 : pc_ <= 64 ? 5 : pc_ <= 256 ? 6 : 7), 1);
+                if (xf_ne) BK_STAT(16, 1);
+                if (lane == 0) atomicMax(&g_bk_hist[23], (unsigned long long)depth);
+            }
+#endif
             if (__ballot(any_of(P) != 0) == 0) {
                 if (__ballot(any_of(Xc) != 0) == 0 && !xf_ne) cnt++;
                 entering = false;
@@ -300,6 +328,7 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                             pw = __builtin_amdgcn_readlane(P[h], __ffsll((long long)nzl) - 1);
                         }
                     if ((pw & (pw - 1u)) == 0u) {
+                        BK_STAT(25, 1);
                         const int q = ((__ffsll((long long)nzl) - 1 + 64 * hsel) << 5) + __ffs(pw) - 1;
                         uint32_t any = 0;
 #pragma unroll
@@ -308,9 +337,12 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                             any |= w < cw ? (Xc[h] & Cadj[size_t(q) * cw + w]) : 0u;
                         }
                         if (xf_ne) {
+                            BK_T0();
+                            BK_STAT(26, 1); BK_STAT(27, xw);
                             const uint32_t *lvx = stack + size_t(depth) * lvl + 3 * cw;
                             const uint32_t *xt = XT + size_t(q) * xw;
                             for (int w = lane; w < xw; w += 64) any |= lvx[w] & xt[w];
+                            BK_T1(28);
                         }
                         if (__ballot(any != 0) == 0) cnt++;
                         entering = false;
@@ -357,6 +389,7 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
             // pivot: argmax over u in P ∪ Xc of |P ∩ N(u)|.  One LANE per candidate: P is parked in LDS, the members of
             // P ∪ Xc are expanded into an LDS list (wave prefix sum of the per-word popcounts), then every lane scores its
             // own candidates with independent row loads (64 rows in flight instead of one dependent load per candidate).
+            BK_T0();
             uint32_t U[WPL];
             int mine = 0;
 #pragma unroll
@@ -371,6 +404,8 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                 if (lane >= sft) pre += o;
             }
             const int ncand = __builtin_amdgcn_readlane(pre, 63);
+            BK_STAT(21, 1);
+            BK_STAT(22, ncand);
             {
                 int at = pre - mine;
 #pragma unroll
@@ -410,6 +445,7 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                 ext[h] = P[h] & ~prow;
             }
             entering = false;
+            BK_T1(30);
             }
         }
         // next branch vertex q of this node
@@ -534,7 +570,10 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                             ++r;
                         }
                     }
-                    if (lane == 0) atomicMax(sh.max_stack, (unsigned long long)(c + 1) * (unsigned long long)lvl);
+                    if (lane == 0) {
+                        atomicMax(sh.max_stack, (unsigned long long)(c + 1) * (unsigned long long)lvl);
+                        if (c <= 512) atomicMax(sh.max_stack + 1, (unsigned long long)(c + 1) * (unsigned long long)(128 + ((2 * xw + 3) & ~3)));  // = bk_group_slab_words: k_bk_resume4's need
+                    }
                 }
             }
 #ifdef GMSX_BK_STATS
@@ -554,6 +593,7 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
             if (h == hsel) word = __builtin_amdgcn_readlane(ext[h], L);
         const int bit = __ffs(word) - 1;
         const int q = ((L + 64 * hsel) << 5) + bit;
+        BK_STAT(17, 1);
         uint32_t Pn[WPL], Xcn[WPL];
 #pragma unroll
         for (int h = 0; h < WPL; ++h) {
@@ -568,11 +608,15 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
             // Decided right here (no level pushed, entered and popped again); the node goes on with q moved from cand to fini.
             uint32_t any = any_of(Xcn);
             if (xf_ne && __ballot(any != 0) == 0) {
+                BK_T0();
+                BK_STAT(26, 1); BK_STAT(27, xw);
                 const uint32_t *xt = XT + size_t(q) * xw;
                 for (int w = lane; w < xw; w += 64) any |= lv[3 * cw + w] & xt[w];
+                BK_T1(28);
             }
             if (__ballot(any != 0) == 0) cnt++;
             ++nodes;
+            BK_STAT(18, 1);
 #pragma unroll
             for (int h = 0; h < WPL; ++h)
                 if (h == hsel && lane == L) {
@@ -610,11 +654,15 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                         any |= w < cw ? (Xcn[h] & Cadj[size_t(q2) * cw + w]) : 0u;
                     }
                     if (xf_ne && __ballot(any != 0) == 0) {
+                        BK_T0();
+                        BK_STAT(26, 1); BK_STAT(27, xw);
                         const uint32_t *xt = XT + size_t(q) * xw, *xt2 = XT + size_t(q2) * xw;
                         for (int w = lane; w < xw; w += 64) any |= lv[3 * cw + w] & xt[w] & xt2[w];
+                        BK_T1(28);
                     }
                     if (__ballot(any != 0) == 0) cnt++;
                     nodes += 2;
+                    BK_STAT(19, 1);
 #pragma unroll
                     for (int h = 0; h < WPL; ++h)
                         if (h == hsel && lane == L) {
@@ -628,15 +676,29 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
         }
         uint32_t *nx = lv + lvl;
         int child_ne = 0;
+        BK_STAT(20, 1);
         if (xf_ne) {
+            BK_STAT(24, xw);
+            BK_T0();
             uint32_t any = 0;
             const uint32_t *xt = XT + size_t(q) * xw;
+#ifdef GMSX_BK_STATS
+            int nzw_ = 0;
+#endif
             for (int w = lane; w < xw; w += 64) {
                 const uint32_t t = lv[3 * cw + w] & xt[w];
                 nx[3 * cw + w] = t;
                 any |= t;
+#ifdef GMSX_BK_STATS
+                nzw_ += t != 0;
+#endif
             }
             child_ne = __ballot(any != 0) != 0 ? 1 : 0;
+            BK_T1(28);
+#ifdef GMSX_BK_STATS
+            nzw_ = wave_sum(nzw_);
+            BK_STAT(31, nzw_);
+#endif
         }
         // this node continues with q moved from cand to fini (tomita.h:68-70)
 #pragma unroll
@@ -1032,7 +1094,7 @@ static constexpr int kBkBlockGrab = GMSX_BK_BLOCK_GRAB;  // pieces per queue tic
 __global__ void k_bk_layout(int64_t lo, int64_t cnt, int nparts, int part, const int32_t *__restrict__ task_v, const int64_t *__restrict__ off,
                             const int32_t *__restrict__ oldid, const int32_t *__restrict__ dplus, int x_is_degree, int64_t *__restrict__ need_a,
                             int64_t *__restrict__ need_r, int64_t *__restrict__ need_p,
-                            unsigned long long *__restrict__ maxima /* [0] (c+1)*lvl  [1] global map words */) {
+                            unsigned long long *__restrict__ maxima /* [0] (c+1)*lvl  [1] global map words  [3] slab words of a 16-lane search */) {
     const int64_t qi = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (qi > cnt) return;
     if (qi == cnt) { need_a[qi] = 0; need_r[qi] = 0; need_p[qi] = 0; return; }
@@ -1044,6 +1106,7 @@ __global__ void k_bk_layout(int64_t lo, int64_t cnt, int nparts, int part, const
     need_r[qi] = kRecHeader + 3 * cw + xw;
     need_p[qi] = (c + (off[vo + 1] - off[vo]) + kBkPieceJobs - 1) / kBkPieceJobs;  // k_bk_block: pieces of kBkPieceJobs row jobs (>= 1: c > 0)
     atomicMax(&maxima[0], (unsigned long long)((c + 1) * (3 * cw + xw + 1)));
+    if (c <= 512) atomicMax(&maxima[3], (unsigned long long)((c + 1) * (128 + ((2 * xw + 3) & ~3ll))));  // = bk_group_slab_words: k_bk_resume4's need
     const unsigned long long msize = bk_map_size(int(c));
     if (msize > 1024) atomicMax(&maxima[1], 2ull * msize);
 }
@@ -1383,7 +1446,7 @@ template <int WPL>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? GMSX_BK_RESUME_WAVES : WPL == 2 ? 3 : 1))) void k_bk_resume(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in,
                                                   unsigned long long n_records, unsigned long long *__restrict__ queue, unsigned grab,
                                                   uint32_t *__restrict__ slabs, unsigned long long slab_words,
-                                                  unsigned long long *__restrict__ acc, BkShared sh) {
+                                                  unsigned long long *__restrict__ acc, BkShared sh, int min_c /* records with fewer candidates belong to k_bk_resume4 */) {
     __shared__ unsigned char xfne_stack[2052 * WPL];
     __shared__ uint32_t piv_P[64 * WPL];
     __shared__ unsigned short piv_list[2048 * WPL];
@@ -1405,7 +1468,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? G
         const uint32_t *rec = pool_in + roff;
         const int32_t v = uni32(int32_t(rec[0]));
         const int c = uni32(int(rec[1])), x = uni32(int(rec[2])), xf_ne = uni32(int(rec[3]));
+        if (c < min_c) continue;
         const bool root = uni32(rec[6]) != 0;  // written by k_bk_build: the node is entered (pivot choice), not resumed
+        const int pairs = uni32(int(rec[7]));  // Xf as a list of (word index, word) pairs (a record split off by k_bk_resume4), 0 = dense words
         const unsigned long long aoff = (unsigned long long)uni32(rec[4]) | ((unsigned long long)uni32(rec[5]) << 32);
         const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
         const uint32_t *Cadj = sh.arena + aoff;
@@ -1425,12 +1490,427 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? G
             Xc[h] = w < cw ? rec[kRecHeader + cw + w] : 0u;
             ext[h] = w < cw ? rec[kRecHeader + 2 * cw + w] : 0u;
         }
-        for (int w = lane; w < xw; w += 64) stack[3 * cw + w] = rec[kRecHeader + 3 * cw + w];
+        if (pairs == 0) {
+            for (int w = lane; w < xw; w += 64) stack[3 * cw + w] = rec[kRecHeader + 3 * cw + w];
+        } else {
+            for (int w = lane; w < xw; w += 64) stack[3 * cw + w] = 0u;
+            __threadfence();
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < pairs; i += 64) stack[3 * cw + rec[kRecHeader + 3 * cw + 2 * i]] = rec[kRecHeader + 3 * cw + 2 * i + 1];
+            __threadfence();
+        }
         __builtin_amdgcn_wave_barrier();
         bk_search<WPL>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, xf_ne, root, lane, cnt, sh, aoff, true, piv_P, piv_list);
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
+}
+
+// ---- rounds >= 1 for records with at most 512 candidates: FOUR searches per wave -------------------------------------------------------
+// k_bk_resume runs one search per wave: with c <= 512 (every record of the BASELINE configs[3] graph) at most 16 of its 64 lanes hold a
+// word of P, every search node is a chain of ~3 dependent global loads, and the node's ~100 wave-instructions are issued for those 16 lanes
+// (round 4: 61 % of the wave cycles parked, VALU 39 % busy).  Here a search is a 16-LANE GROUP (lane `sub` holds word `sub` of P / Xc / ext),
+// a wave runs four of them in lock-step, and the search is a STATE MACHINE with one step per trip of the wave's loop:
+//   * every step consumes ONE row of Cadj — the pivot's (ext = P & ~row), the branch vertex's (child P' = P & row) or the only candidate's
+//     of a one-candidate child — or one saved level of the stack (pop).  Which row the next step needs is decided at the END of a step, so
+//     the loads of all four groups are issued together, unconditionally placed at the top of the trip, and waited for once: four
+//     independent dependent-load chains per wave instead of one;
+//   * the finished in-neighbours Xf (x bits, one per CSR position of the start vertex: hundreds of words, nearly all zero below the root —
+//     measured: 2.8 non-zero words per pushed child) are a LIST of (word index, word) pairs below level 0.  A list of at most 16 pairs lives
+//     in registers, one pair per lane, and its gather XT[q][index] is one more load of the same hoisted batch: the Xf checks of the leaf fast
+//     paths and the child Xf of a push cost no extra round trip.  Longer lists and the dense level 0 of a root record are walked in memory.
+// Records are those of k_bk_resume (same pool, same header; rec[7] = pairs of a list-form Xf, 0 = dense words), so the two kernels share
+// the rounds: this one takes c <= 512, k_bk_resume the wider ones.  Tomita's recursion is unchanged (tomita.h:12-86): pivot = argmax
+// |P ∩ N(u)| over P ∪ Xc, scored by the lanes of the group; nodes with <= small_p candidates take their first candidate.
+static constexpr int kBkGroupMaxC = 512;
+static constexpr int kBkSlot = 8;                   // words per lane of a saved level: P, Xc, ext, xfn | list index, list word, -, -
+static constexpr int kBkLevelFixed = 16 * kBkSlot;  // + 2 words per possible list pair
+__host__ __device__ inline unsigned long long bk_group_level_words(long long xw) { return (unsigned long long)(kBkLevelFixed + ((2 * xw + 3) & ~3ll)); }
+__host__ __device__ inline unsigned long long bk_group_slab_words(long long c, long long xw) { return (unsigned long long)(c + 1) * bk_group_level_words(xw); }
+
+struct __attribute__((packed, aligned(4))) bk_u2 { uint32_t x, y; };
+template <int K> __device__ __forceinline__ int bkg_ror(int x) { return __builtin_amdgcn_mov_dpp(x, 0x120 + K, 0xf, 0xf, false); }  // DPP row_ror:K (rows of 16 lanes)
+__device__ __forceinline__ int bkg_sum(int x) { x += bkg_ror<8>(x); x += bkg_ror<4>(x); x += bkg_ror<2>(x); x += bkg_ror<1>(x); return x; }
+__device__ __forceinline__ int bkg_max(int x) { x = max(x, bkg_ror<8>(x)); x = max(x, bkg_ror<4>(x)); x = max(x, bkg_ror<2>(x)); x = max(x, bkg_ror<1>(x)); return x; }
+__device__ __forceinline__ uint32_t bkg_ballot(bool p, int gsh) { return uint32_t(__ballot(p) >> gsh) & 0xffffu; }  // the group's 16 bits of the wave ballot
+
+// Xf of a level held in memory — dense words (n < 0: the xw words at src) or a list of n (word index, word) pairs — against row(s) of XT.
+// MODE 0: the child list Xf ∩ N(q) -> dst, returns its length; 1: is Xf ∩ N(q) non-empty; 2: is Xf ∩ N(q) ∩ N(q2) non-empty.
+template <int MODE>
+__device__ __forceinline__ int bkg_xf_mem(const uint32_t *src, int n, int xw, const uint32_t *xt, const uint32_t *xt2, uint32_t *dst, int sub, int gsh) {
+    const uint32_t lt = (1u << sub) - 1u;
+    int out = 0;
+    if (n < 0) {
+        for (int w0 = 0; w0 < xw; w0 += 64) {
+            const int w = w0 + 4 * sub;
+            const bk_u4 a = *reinterpret_cast<const bk_u4 *>(src + w), b = *reinterpret_cast<const bk_u4 *>(xt + w);  // up to three words past the row: masked below
+            uint32_t t[4] = {a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w};
+            if (MODE == 2) {
+                const bk_u4 b2 = *reinterpret_cast<const bk_u4 *>(xt2 + w);
+                t[0] &= b2.x; t[1] &= b2.y; t[2] &= b2.z; t[3] &= b2.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (w + i >= xw) t[i] = 0u;
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t m = bkg_ballot(t[i] != 0u, gsh);
+                    if (t[i] != 0u) *reinterpret_cast<bk_u2 *>(dst + 2 * (out + __popc(m & lt))) = bk_u2{uint32_t(w + i), t[i]};
+                    out += __popc(m);
+                }
+            } else {
+                if (bkg_ballot((t[0] | t[1] | t[2] | t[3]) != 0u, gsh)) return 1;
+            }
+        }
+    } else {
+        for (int i0 = 0; i0 < n; i0 += 16) {
+            const int i = i0 + sub;
+            bk_u2 pr{0u, 0u};
+            if (i < n) pr = *reinterpret_cast<const bk_u2 *>(src + 2 * i);
+            uint32_t t = pr.y & xt[pr.x];
+            if (MODE == 2) t &= xt2[pr.x];
+            if (MODE == 0) {
+                const uint32_t m = bkg_ballot(t != 0u, gsh);
+                if (t != 0u) *reinterpret_cast<bk_u2 *>(dst + 2 * (out + __popc(m & lt))) = bk_u2{pr.x, t};
+                out += __popc(m);
+            } else {
+                if (bkg_ballot(t != 0u, gsh)) return 1;
+            }
+        }
+    }
+    return out;
+}
+
+#ifndef GMSX_BK_GROUP_WAVES
+#define GMSX_BK_GROUP_WAVES 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROUP_WAVES))) void k_bk_resume4(
+    const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in, unsigned long long n_records, unsigned long long *__restrict__ queue,
+    unsigned grab, uint32_t *__restrict__ slabs, unsigned long long slab_words /* per search */, unsigned long long *__restrict__ acc, BkShared sh) {
+    enum : int { M_REC = 0, M_ENTER, M_NEXT, M_PIVOT, M_BRANCH, M_CHILD1, M_POP, M_DONE };
+    __shared__ unsigned short piv_list[4][kBkGroupMaxC];
+    __shared__ uint32_t piv_P[4][16];
+    const int lane = threadIdx.x, sub = lane & 15, grp = lane >> 4, gsh = lane & 48;
+    const uint32_t lt = (1u << sub) - 1u;
+    uint32_t *const slab = slabs + (size_t(blockIdx.x) * 4 + grp) * slab_words;
+    unsigned long long cnt = 0;
+    // the group's search (every lane of the group holds the same value of what is not a bitmap word)
+    const uint32_t *rec = nullptr, *Cadj = pool_in, *XT = pool_in, *xf0 = pool_in;
+    int c = 0, cw = 0, xw = 0, depth = 0, mode = M_REC;
+    unsigned long long lvl = kBkLevelFixed;
+    int xfn = 0;                   // Xf of the current level: 0 empty, -1 the dense words of level 0, n > 0 a list of n pairs (n <= 16: in ridx / rval)
+    uint32_t P = 0, Xc = 0, ext = 0, Xcn = 0, ridx = 0, rval = 0, tq = 0;
+    int q = 0, rowreq = 0;
+    unsigned nodes = 0;
+    bool nosplit = false;
+    unsigned long long q_next = 0, q_end = 0;
+    auto level = [&](int l) { return slab + size_t(l) * lvl; };
+    auto xf_src = [&](int l) { return l == 0 ? xf0 : level(l) + kBkLevelFixed; };
+    while (true) {
+        bool need_pivot = false;
+        // ---- a group without a search takes the next record of its class ---------------------------------------------------------------
+        while (mode == M_REC) {
+            if (q_next == q_end) {
+                unsigned long long t0 = 0;
+                if (sub == 0) t0 = atomicAdd(queue, (unsigned long long)grab);
+                q_next = (unsigned long long)__shfl((long long)t0, gsh);
+                q_end = q_next + grab;
+            }
+            const unsigned long long qi = q_next++;
+            if (qi >= n_records) { mode = M_DONE; break; }
+            const unsigned long long roff = dir_in[qi];
+            if (roff == ~0ull) continue;  // a claimed-but-unwritten directory slot (its search was kept by the wave that claimed it)
+            rec = pool_in + roff;
+            c = int(rec[1]);
+            if (c > kBkGroupMaxC) continue;  // k_bk_resume's
+            const int x = int(rec[2]);
+            const unsigned long long aoff = (unsigned long long)rec[4] | ((unsigned long long)rec[5] << 32);
+            const uint32_t xf_ne = rec[3], root = rec[6], pairs = rec[7];
+            cw = (c + 31) >> 5;
+            xw = (x + 31) >> 5;
+            lvl = bk_group_level_words(xw);
+            Cadj = sh.arena + aoff;
+            XT = Cadj + size_t(c) * cw;
+            P = sub < cw ? rec[kRecHeader + sub] : 0u;
+            Xc = sub < cw ? rec[kRecHeader + cw + sub] : 0u;
+            ext = sub < cw ? rec[kRecHeader + 2 * cw + sub] : 0u;
+            xf0 = rec + kRecHeader + 3 * cw;
+            xfn = xf_ne == 0u ? 0 : pairs != 0u ? int(pairs) : -1;
+            ridx = rval = 0u;
+            if (xfn > 0 && xfn <= 16 && sub < xfn) {
+                const bk_u2 pr = *reinterpret_cast<const bk_u2 *>(xf0 + 2 * sub);
+                ridx = pr.x;
+                rval = pr.y;
+            }
+            depth = 0;
+            nodes = 0;
+            nosplit = false;
+            if (root != 0u) { ++nodes; need_pivot = true; mode = M_ENTER; } else mode = M_NEXT;
+        }
+        if (__ballot(mode != M_DONE) == 0) break;
+        // ---- the loads of this step, all groups together --------------------------------------------------------------------------------
+        const bool reglist = xfn > 0 && xfn <= 16;
+        uint32_t row = 0u, xtw = 0u;
+        uint4 sv{0u, 0u, 0u, 0u};
+        uint2 sl{0u, 0u};
+        if (mode == M_PIVOT || mode == M_BRANCH || mode == M_CHILD1) {
+            if (sub < cw) row = Cadj[size_t(rowreq) * cw + sub];
+            if (reglist && mode != M_PIVOT) xtw = XT[size_t(rowreq) * xw + ridx];
+        }
+        if (mode == M_POP) {
+            const uint32_t *lv = level(depth) + sub * kBkSlot;
+            sv = *reinterpret_cast<const uint4 *>(lv);
+            sl = *reinterpret_cast<const uint2 *>(lv + 4);
+        }
+        bool next = mode == M_NEXT;
+        if (mode == M_PIVOT) {
+            ext = P & ~row;
+            next = true;
+        } else if (mode == M_POP) {
+            P = sv.x; Xc = sv.y; ext = sv.z; xfn = int(sv.w);
+            ridx = sl.x; rval = sl.y;
+            next = true;
+        } else if (mode == M_CHILD1) {
+            // the child of branch q had ONE candidate q2 (its row is here): a maximal clique iff nothing finished is adjacent to q and q2
+            bool blocked = bkg_ballot((Xcn & row) != 0u, gsh) != 0u;
+            if (!blocked && xfn != 0)
+                blocked = reglist ? bkg_ballot((tq & xtw) != 0u, gsh) != 0u
+                                  : bkg_xf_mem<2>(xf_src(depth), xfn, xw, XT + size_t(q) * xw, XT + size_t(rowreq) * xw, nullptr, sub, gsh) != 0;
+            if (!blocked && sub == 0) cnt++;
+            nodes += 2;
+            next = true;
+        } else if (mode == M_BRANCH) {
+            const uint32_t Pn = P & row, Xcn_ = Xc & row;
+            if (sub == (q >> 5)) {  // this node continues with q moved from cand to fini (tomita.h:68-70)
+                const uint32_t b = 1u << (q & 31);
+                ext &= ~b; P &= ~b; Xc |= b;
+            }
+            tq = rval & xtw;  // register-list Xf ∩ N(q)
+            const uint32_t m = bkg_ballot(Pn != 0u, gsh);
+            if (m == 0u) {
+                // the child has no candidate: a leaf, decided here
+                bool blocked = bkg_ballot(Xcn_ != 0u, gsh) != 0u;
+                if (!blocked && xfn != 0)
+                    blocked = reglist ? bkg_ballot(tq != 0u, gsh) != 0u
+                                      : bkg_xf_mem<1>(xf_src(depth), xfn, xw, XT + size_t(q) * xw, nullptr, nullptr, sub, gsh) != 0;
+                if (!blocked && sub == 0) cnt++;
+                ++nodes;
+                next = true;
+            } else {
+                const int L1 = __ffs(m) - 1;
+                const uint32_t pw = uint32_t(__shfl(int(Pn), gsh + L1));
+                if ((m & (m - 1u)) == 0u && (pw & (pw - 1u)) == 0u) {
+                    // ONE candidate q2: decided by the next step from q2's row, no level pushed
+                    Xcn = Xcn_;
+                    rowreq = (L1 << 5) + __ffs(pw) - 1;
+                    mode = M_CHILD1;
+                } else {
+                    // push: save this level, enter the child
+                    uint32_t *lv = level(depth) + sub * kBkSlot;
+                    *reinterpret_cast<uint4 *>(lv) = uint4{P, Xc, ext, uint32_t(xfn)};
+                    *reinterpret_cast<uint2 *>(lv + 4) = uint2{ridx, rval};
+                    int nxf = 0;
+                    if (xfn != 0) {
+                        if (reglist) {
+                            const uint32_t mm = bkg_ballot(tq != 0u, gsh);
+                            nxf = __popc(mm);
+                            const int dst = tq != 0u ? __popc(mm & lt) : 15;  // lanes without a pair send a zero to a lane no pair goes to
+                            const uint32_t si = tq != 0u ? ridx : 0u;
+                            ridx = uint32_t(__builtin_amdgcn_ds_permute((gsh + dst) << 2, int(si)));
+                            rval = uint32_t(__builtin_amdgcn_ds_permute((gsh + dst) << 2, int(tq)));
+                            if (nxf == 16) { /* every lane sent its own pair to a distinct lane */ }
+                        } else {
+                            uint32_t *dl = level(depth + 1) + kBkLevelFixed;
+                            nxf = bkg_xf_mem<0>(xf_src(depth), xfn, xw, XT + size_t(q) * xw, nullptr, dl, sub, gsh);
+                            ridx = rval = 0u;
+                            if (nxf <= 16 && sub < nxf) {
+                                const bk_u2 pr = *reinterpret_cast<const bk_u2 *>(dl + 2 * sub);
+                                ridx = pr.x;
+                                rval = pr.y;
+                            }
+                        }
+                    }
+                    ++depth;
+                    P = Pn; Xc = Xcn_; xfn = nxf;
+                    ++nodes;
+                    need_pivot = true;
+                }
+            }
+        }
+        // ---- pivot of an entered node: argmax over u in P ∪ Xc of |P ∩ N(u)| (tomita.h:12-40); its row is the next step's ----------------
+        if (need_pivot) {
+            const uint32_t m = bkg_ballot(P != 0u, gsh);
+            const int pc = bkg_sum(__popc(P));
+            int best;
+            if (pc <= sh.small_p) {
+                const int L0 = __ffs(m) - 1;
+                best = (L0 << 5) + __ffs(uint32_t(__shfl(int(P), gsh + L0))) - 1;
+            } else {
+                const uint32_t U = P | Xc;
+                const int mine = __popc(U);
+                int incl = mine;  // inclusive prefix over the 16 lanes of the row
+                {
+                    int t;
+                    t = __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false); incl += t;  // row_shr:1
+                    t = __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false); incl += t;  // row_shr:2
+                    t = __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false); incl += t;  // row_shr:4
+                    t = __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false); incl += t;  // row_shr:8
+                }
+                const int ncand = __shfl(incl, gsh + 15);
+                piv_P[grp][sub] = P;
+                {
+                    int at = incl - mine;
+                    uint32_t bits = U;
+                    while (bits) {
+                        piv_list[grp][at++] = (unsigned short)((sub << 5) + __ffs(bits) - 1);
+                        bits &= bits - 1u;
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                int key = -1;
+                const int cw4 = (cw + 3) >> 2;
+                for (int k = sub; k < ncand; k += 16) {
+                    const int u = int(piv_list[grp][k]);
+                    const uint32_t *r = Cadj + size_t(u) * cw;
+                    int sc = 0;
+                    for (int w4 = 0; w4 < cw4; ++w4) {  // words past cw belong to the next row: P's words there are zero
+                        const bk_u4 rw = *reinterpret_cast<const bk_u4 *>(r + 4 * w4);
+                        sc += __popc(piv_P[grp][4 * w4] & rw.x) + __popc(piv_P[grp][4 * w4 + 1] & rw.y) + __popc(piv_P[grp][4 * w4 + 2] & rw.z) +
+                              __popc(piv_P[grp][4 * w4 + 3] & rw.w);
+                    }
+                    key = max(key, (sc << 16) | (0xffff - u));  // ties -> the smallest index
+                }
+                key = bkg_max(key);
+                best = 0xffff - (key & 0xffff);
+                __builtin_amdgcn_wave_barrier();
+            }
+            rowreq = best;
+            mode = M_PIVOT;
+        }
+        // ---- the next branch vertex of this node, or the way back up ----------------------------------------------------------------------
+        if (next) {
+            const uint32_t m = bkg_ballot(ext != 0u, gsh);
+            if (m == 0u) {
+                if (depth == 0) mode = M_REC;
+                else { --depth; mode = M_POP; }
+            } else {
+                bool split = false;
+                if (nodes >= sh.budget && !nosplit) {
+                    // ---- split: every level that still has branches becomes up to kBkSplit records of the next round (as in bk_search) ----
+                    uint32_t *cur = level(depth) + sub * kBkSlot;
+                    *reinterpret_cast<uint4 *>(cur) = uint4{P, Xc, ext, uint32_t(xfn)};
+                    *reinterpret_cast<uint2 *>(cur + 4) = uint2{ridx, rval};
+                    __threadfence();
+                    int nrec = 0;
+                    for (int l = 0; l <= depth; ++l) nrec += min(bkg_sum(__popc(level(l)[sub * kBkSlot + 2])), kBkSplit);
+                    const unsigned long long rec_words = (unsigned long long)(kRecHeader + 3 * cw + xw);
+                    unsigned long long p0 = 0, d0 = sh.dir_cap;
+                    if (sub == 0) {
+                        p0 = atomicAdd(sh.pool_head, rec_words * nrec);
+                        if (p0 + rec_words * nrec <= sh.pool_cap) d0 = atomicAdd(sh.dir_count, (unsigned long long)nrec);
+                    }
+                    p0 = (unsigned long long)__shfl((long long)p0, gsh);
+                    d0 = (unsigned long long)__shfl((long long)d0, gsh);
+                    if (p0 + rec_words * nrec > sh.pool_cap || d0 + nrec > sh.dir_cap) {
+                        nosplit = true;  // no room: this search is finished here (claimed directory slots keep their ~0 fill)
+                    } else {
+                        auto lowest = [](uint32_t x, int k) -> uint32_t {  // the k lowest set bits of x
+                            if (k <= 0) return 0u;
+                            if (k >= __popc(x)) return x;
+                            uint32_t r = 0;
+                            while (k--) {
+                                const uint32_t b = x & (0u - x);
+                                r |= b;
+                                x ^= b;
+                            }
+                            return r;
+                        };
+                        int r = 0;
+                        for (int l = 0; l <= depth; ++l) {
+                            const uint32_t *lv = level(l) + sub * kBkSlot;
+                            const uint32_t lP = lv[0], lXc = lv[1], e = lv[2];
+                            const int ln = int(lv[3]);
+                            const uint32_t lidx = lv[4], lval = lv[5];
+                            const int mine = __popc(e);
+                            int incl = mine;
+                            {
+                                int t;
+                                t = __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false); incl += t;
+                                t = __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false); incl += t;
+                                t = __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false); incl += t;
+                                t = __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false); incl += t;
+                            }
+                            const int nb = __shfl(incl, gsh + 15);
+                            if (nb == 0) continue;
+                            const int rank0 = incl - mine;  // rank of this word's first pending branch
+                            const int parts = min(nb, kBkSplit);
+                            for (int j = 0; j < parts; ++j) {
+                                const int a = int((long long)nb * j / parts), b = int((long long)nb * (j + 1) / parts);  // ranks [a, b) of the pending branches
+                                uint32_t *out = sh.pool + p0 + rec_words * r;
+                                // Xf of the level: level 0 as this record has it, deeper levels as a list when it fits the dense area, else scattered
+                                uint32_t o3 = 0u, o7 = 0u;
+                                uint32_t *ox = out + kRecHeader + 3 * cw;
+                                if (l == 0) {
+                                    o3 = rec[3];
+                                    o7 = rec[7];
+                                    for (int w = sub; w < xw; w += 16) ox[w] = xf0[w];
+                                } else if (ln > 0) {
+                                    o3 = 1u;
+                                    const uint32_t *src = level(l) + kBkLevelFixed;
+                                    if (2 * ln <= xw) {
+                                        o7 = uint32_t(ln);
+                                        if (ln <= 16) { if (sub < ln) *reinterpret_cast<bk_u2 *>(ox + 2 * sub) = bk_u2{lidx, lval}; }
+                                        else for (int i = sub; i < 2 * ln; i += 16) ox[i] = src[i];
+                                    } else {
+                                        for (int w = sub; w < xw; w += 16) ox[w] = 0u;
+                                        __threadfence();
+                                        if (ln <= 16) { if (sub < ln) ox[lidx] = lval; }
+                                        else for (int i = sub; i < ln; i += 16) ox[src[2 * i]] = src[2 * i + 1];
+                                    }
+                                }
+                                if (sub == 0) {
+                                    out[0] = rec[0];
+                                    out[1] = uint32_t(c);
+                                    out[2] = rec[2];
+                                    out[3] = o3;
+                                    out[4] = rec[4];
+                                    out[5] = rec[5];
+                                    out[6] = 0u;
+                                    out[7] = o7;
+                                    sh.dir[d0 + r] = p0 + rec_words * r;
+                                }
+                                if (sub < cw) {
+                                    const uint32_t before = lowest(e, a - rank0);        // branches of the runs in front of this one
+                                    const uint32_t run = lowest(e, b - rank0) & ~before;  // this run
+                                    out[kRecHeader + sub] = lP & ~before;                 // P
+                                    out[kRecHeader + cw + sub] = lXc | before;            // Xc
+                                    out[kRecHeader + 2 * cw + sub] = run;                 // ext
+                                }
+                                ++r;
+                            }
+                        }
+                        if (sub == 0) {
+                            atomicMax(sh.max_stack, (unsigned long long)(c + 1) * (unsigned long long)(3 * cw + xw + 1));
+                            atomicMax(sh.max_stack + 1, bk_group_slab_words(c, xw));
+                        }
+                        split = true;
+                    }
+                }
+                if (split) mode = M_REC;
+                else {
+                    const int L = __ffs(m) - 1;
+                    const uint32_t word = uint32_t(__shfl(int(ext), gsh + L));
+                    q = (L << 5) + __ffs(word) - 1;
+                    rowreq = q;
+                    mode = M_BRANCH;
+                }
+            }
+        }
+    }
+    if (sub == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
 }
 
 static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
@@ -1493,6 +1973,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     const int widest = std::min(g->max_dplus, max_c);  // candidates of a start vertex = its d+
     const int wpl_wide = widest <= 4096 ? 2 : widest <= 8192 ? 4 : 8;
     for (int64_t i = 0; i < n_wide; ++i) words[size_t(i)] &= ~kWideTask;
+    GMSX_HIP(hipMemsetAsync(acc + kCtl + 7, 0, 8, s));  // from here on the slot behind max_stack: the slab need of k_bk_resume4's records
 
     // ---- arena + record pools of the load balancer
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
@@ -1509,19 +1990,21 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     }
     auto alloc_arena = [&](unsigned long long want_words) -> int {
         sh.arena_cap = std::min(arena_hard_cap, std::max<unsigned long long>(want_words, (256ull << 20) / 4));
-        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&sh.arena), sh.arena_cap * 4));
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&sh.arena), sh.arena_cap * 4 + 64));  // + 64: 16-byte loads may run 12 bytes past a row
         g_arena.p = sh.arena;
         return GMSX_OK;
     };
+    // 1 = records with at most 512 candidates are searched four to a wave (k_bk_resume4, default); 0 = every record by k_bk_resume (round 4)
+    const bool use_groups = [] { const char *e = std::getenv("GMSX_BK_GROUPS"); return !e || std::atoi(e) != 0; }();
     sh.pool_cap = std::min<unsigned long long>(free_b / 16, 2ull << 30) / 4;
     sh.dir_cap = 8ull << 20;
     uint32_t *pools[2] = {nullptr, nullptr};
     unsigned long long *dirs[2] = {nullptr, nullptr};
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&pools[0]), sh.pool_cap * 4)); g_pool0.p = pools[0];
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&pools[1]), sh.pool_cap * 4)); g_pool1.p = pools[1];
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&pools[0]), sh.pool_cap * 4 + 64)); g_pool0.p = pools[0];  // + 64: 16-byte loads may run 12 bytes past a record
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&pools[1]), sh.pool_cap * 4 + 64)); g_pool1.p = pools[1];
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dirs[0]), sh.dir_cap * 8)); g_dir0.p = dirs[0];
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dirs[1]), sh.dir_cap * 8)); g_dir1.p = dirs[1];
-    unsigned long long *queue = acc + kCtl + 2;
+    unsigned long long *queue = acc + kCtl + 2, *gqueue = acc + kCtl + 13;  // tickets of k_bk_resume / k_bk_resume4
     sh.arena_head = acc + kCtl + 3;
     sh.pool_head = acc + kCtl + 4;
     sh.dir_count = acc + kCtl + 5;
@@ -1564,7 +2047,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     unsigned long long *pieces = nullptr;
     Guard g_na, g_nr, g_ao, g_ro, g_de, g_map, g_np, g_po, g_pc;
     unsigned long long *maxima = acc + kCtl + 9;  // [0] stack words, [1] global map words
-    unsigned long long mx[2] = {0, 0}, map_words = 0;
+    unsigned long long mx[4] = {0, 0, 0, 0}, map_words = 0;  // [0] stack words of k_bk_resume, [1] global map words, [3] slab words of a 16-lane search
     int64_t build_waves = 0;
     uint32_t *map_scratch = nullptr;
     if (cnt_glob > 0) {
@@ -1612,14 +2095,24 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         }
     }
     // the stack slabs of the resume kernel (grow-only, reused by every round): for the root round their size is known from the layout
-    Guard g_rslab;
-    size_t resume_cap = 0;
-    if (cnt_glob > 0 && mx[0] > 0) {
+    Guard g_rslab, g_gslab;
+    size_t resume_cap = 0, group_cap = 0;
+    const bool any_wide_records = !use_groups || widest > kBkGroupMaxC;  // k_bk_resume has records to search
+    if (cnt_glob > 0 && mx[0] > 0 && any_wide_records) {
         const unsigned long long slab_bytes = ((mx[0] + 3ull) & ~3ull) * 4ull;
         if (slab_bytes <= budget_bytes) {
             const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({cnt_glob, int64_t(cu) * 24, int64_t(budget_bytes / slab_bytes)}));
             resume_cap = size_t(waves) * slab_bytes;
             GMSX_HIP(hipMalloc(&g_rslab.p, resume_cap));
+        }
+    }
+    const int group_waves_per_cu = 4 * GMSX_BK_GROUP_WAVES;
+    if (cnt_glob > 0 && mx[3] > 0 && use_groups) {
+        const unsigned long long slab_bytes = ((mx[3] + 3ull) & ~3ull) * 4ull * 4ull;  // four searches per wave
+        if (slab_bytes <= budget_bytes) {
+            const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({(cnt_glob + 3) / 4, int64_t(cu) * group_waves_per_cu, int64_t(budget_bytes / slab_bytes)}));
+            group_cap = size_t(waves) * slab_bytes;
+            GMSX_HIP(hipMalloc(&g_gslab.p, group_cap));
         }
     }
     GMSX_HIP(hipStreamSynchronize(s));
@@ -1633,51 +2126,72 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     int rounds = 0;
     auto run_rounds = [&]() -> int {
     while (true) {
-        unsigned long long ctl[4] = {0, 0, 0, 0};  // pool_head, dir_count, max_stack
-        GMSX_HIP(hipMemcpyAsync(ctl, sh.pool_head, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        unsigned long long ctl[4] = {0, 0, 0, 0};  // pool_head, dir_count, max_stack, slab words of a 16-lane search
+        GMSX_HIP(hipMemcpyAsync(ctl, sh.pool_head, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         GMSX_HIP(hipStreamSynchronize(s));
         // a wave whose allocation overshot a capacity kept its search: only fully written records are below the caps
         const unsigned long long n_rec = std::min(ctl[1], sh.dir_cap);
         if (n_rec == 0) break;
-        const unsigned long long stack_w = (ctl[2] + 3ull) & ~3ull;
+        const unsigned long long stack_w = (ctl[2] + 3ull) & ~3ull, group_w = (ctl[3] + 3ull) & ~3ull;
         const uint32_t *pool_in = pools[cur];
         const unsigned long long *dir_in = dirs[cur];
         cur ^= 1;
         sh.pool = pools[cur];
         sh.dir = dirs[cur];
         GMSX_HIP(hipMemsetAsync(queue, 0, 8, s));
-        GMSX_HIP(hipMemsetAsync(sh.pool_head, 0, 3 * sizeof(unsigned long long), s));
+        GMSX_HIP(hipMemsetAsync(gqueue, 0, 8, s));
+        GMSX_HIP(hipMemsetAsync(sh.pool_head, 0, 4 * sizeof(unsigned long long), s));
         GMSX_HIP(hipMemsetAsync(sh.dir, 0xff, sh.dir_cap * 8, s));
-        const unsigned long long slab_bytes = std::max<unsigned long long>(stack_w * 4ull, 16);
-        if (slab_bytes > budget_bytes) return GMSX_ERR_DEVICE_MEM;
-        const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({int64_t(n_rec), int64_t(cu) * 24, int64_t(budget_bytes / slab_bytes)}));
         // few records left: split sooner so that the idle waves get work (the tail rounds are latency-, not throughput-bound)
         const int64_t full = int64_t(cu) * 24 * 2;
         sh.budget = int64_t(n_rec) >= full ? budget_resume : unsigned(std::max<int64_t>(128, int64_t(budget_resume) * int64_t(n_rec) / full));
-        if (size_t(waves) * slab_bytes > resume_cap) {  // grow-only stack slabs, reused by every round
-            (void)hipFree(g_rslab.p);
-            g_rslab.p = nullptr;
-            resume_cap = size_t(waves) * slab_bytes;
-            GMSX_HIP(hipMalloc(&g_rslab.p, resume_cap));
+        // records per queue ticket (GMSX_BK_RESUME_GRAB, default 1: eight cost 4 ms on configs[3] — the records of a round differ in cost, their queue is not the limit)
+        const unsigned grab = unsigned(std::max<int64_t>(1, std::min<int64_t>(resume_grab, int64_t(n_rec) / (int64_t(cu) * 24 * 16))));
+        if (use_groups && group_w > 0) {  // records with at most 512 candidates: four searches per wave
+            const unsigned long long slab_bytes = group_w * 4ull * 4ull;
+            if (slab_bytes > budget_bytes) return GMSX_ERR_DEVICE_MEM;
+            const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({int64_t((n_rec + 3) / 4), int64_t(cu) * group_waves_per_cu, int64_t(budget_bytes / slab_bytes)}));
+            if (size_t(waves) * slab_bytes > group_cap) {  // grow-only, reused by every round
+                (void)hipFree(g_gslab.p);
+                g_gslab.p = nullptr;
+                group_cap = size_t(waves) * slab_bytes;
+                GMSX_HIP(hipMalloc(&g_gslab.p, group_cap));
+            }
+            if (std::getenv("GMSX_BK_VERBOSE"))
+                std::fprintf(stderr, "[gmsx bk] round %d: %llu records (%llu pool words), %lld waves of four searches, %llu slab words each, budget %u\n", rounds + 1,
+                             n_rec, ctl[0], (long long)waves, group_w, sh.budget);
+            hipLaunchKernelGGL(k_bk_resume4, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, gqueue, grab, static_cast<uint32_t *>(g_gslab.p), group_w, acc,
+                               sh);
+            ++launches;
         }
-        // records per queue ticket (GMSX_BK_RESUME_GRAB, default 1): one while the waves get fewer than 16 each
-        if (std::getenv("GMSX_BK_VERBOSE"))
-            std::fprintf(stderr, "[gmsx bk] round %d: %llu records (%llu pool words), %lld waves, stack %llu words, budget %u\n", rounds + 1, n_rec, ctl[0],
-                         (long long)waves, stack_w, sh.budget);
-        const unsigned grab = unsigned(std::max<int64_t>(1, std::min<int64_t>(resume_grab, int64_t(n_rec) / (waves * 16))));
-        if (n_wide > 0 && wpl_wide == 2)  // records of wide tasks may be anywhere in the pool
-            hipLaunchKernelGGL(k_bk_resume<2>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
-                               static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
-        else if (n_wide > 0 && wpl_wide == 4)
-            hipLaunchKernelGGL(k_bk_resume<4>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
-                               static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
-        else if (n_wide > 0)
-            hipLaunchKernelGGL(k_bk_resume<8>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
-                               static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
-        else
-            hipLaunchKernelGGL(k_bk_resume<1>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
-                               static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh);
-        ++launches;
+        if (!use_groups || widest > kBkGroupMaxC) {  // the others (every record with GMSX_BK_GROUPS=0): one search per wave
+            const int min_c = use_groups ? kBkGroupMaxC + 1 : 0;
+            const unsigned long long slab_bytes = std::max<unsigned long long>(stack_w * 4ull, 16);
+            if (slab_bytes > budget_bytes) return GMSX_ERR_DEVICE_MEM;
+            const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({int64_t(n_rec), int64_t(cu) * 24, int64_t(budget_bytes / slab_bytes)}));
+            if (size_t(waves) * slab_bytes > resume_cap) {  // grow-only stack slabs, reused by every round
+                (void)hipFree(g_rslab.p);
+                g_rslab.p = nullptr;
+                resume_cap = size_t(waves) * slab_bytes;
+                GMSX_HIP(hipMalloc(&g_rslab.p, resume_cap));
+            }
+            if (std::getenv("GMSX_BK_VERBOSE"))
+                std::fprintf(stderr, "[gmsx bk] round %d: %llu records (%llu pool words), %lld waves, stack %llu words, budget %u\n", rounds + 1, n_rec, ctl[0],
+                             (long long)waves, stack_w, sh.budget);
+            if (n_wide > 0 && wpl_wide == 2)  // records of wide tasks may be anywhere in the pool
+                hipLaunchKernelGGL(k_bk_resume<2>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
+                                   static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh, min_c);
+            else if (n_wide > 0 && wpl_wide == 4)
+                hipLaunchKernelGGL(k_bk_resume<4>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
+                                   static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh, min_c);
+            else if (n_wide > 0)
+                hipLaunchKernelGGL(k_bk_resume<8>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
+                                   static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh, min_c);
+            else
+                hipLaunchKernelGGL(k_bk_resume<1>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
+                                   static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh, min_c);
+            ++launches;
+        }
         if (++rounds > 100000) return GMSX_ERR_KERNEL;
     }
     return GMSX_OK;
@@ -1740,7 +2254,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 GMSX_HIP(hipMemcpy(&span[3], roff + q1, 8, hipMemcpyDeviceToHost));
                 if (uint64_t(span[1] - span[0]) > sh.arena_cap || uint64_t(span[3] - span[2]) > sh.pool_cap) return GMSX_ERR_DEVICE_MEM;  // one start vertex beyond the arena
                 // pool_head / dir_count / max_stack as if the roots had been split off by an earlier round; arena_head behind their structures
-                const unsigned long long ctl0[3] = {(unsigned long long)(span[3] - span[2]), (unsigned long long)(q1 - q0), mx[0]};
+                const unsigned long long ctl0[4] = {(unsigned long long)(span[3] - span[2]), (unsigned long long)(q1 - q0), mx[0], mx[3]};
                 const unsigned long long ah = (unsigned long long)(span[1] - span[0]);
                 GMSX_HIP(hipMemcpyAsync(sh.pool_head, ctl0, sizeof(ctl0), hipMemcpyHostToDevice, s));
                 GMSX_HIP(hipMemcpyAsync(sh.arena_head, &ah, 8, hipMemcpyHostToDevice, s));
@@ -1771,7 +2285,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 sh.pool = pools[cur];
                 sh.dir = dirs[cur];
                 GMSX_HIP(hipMemsetAsync(sh.dir, 0xff, sh.dir_cap * 8, s));
-                GMSX_HIP(hipMemsetAsync(sh.pool_head, 0, 3 * sizeof(unsigned long long), s));
+                GMSX_HIP(hipMemsetAsync(sh.pool_head, 0, 4 * sizeof(unsigned long long), s));
                 GMSX_HIP(hipMemsetAsync(sh.arena_head, 0, 8, s));
                 q0 = q1;
             }
@@ -1875,6 +2389,17 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         (void)hipMemcpyFromSymbol(&nodes, HIP_SYMBOL(g_bk_nodes), 8);
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bk_nodes), &zero, 8);
         std::fprintf(stderr, "[gmsx bk] search nodes %llu, maximal cliques %llu\n", nodes, total);
+        unsigned long long hist[32], zeros[32] = {};
+        (void)hipMemcpyFromSymbol(hist, HIP_SYMBOL(g_bk_hist), sizeof(hist));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bk_hist), zeros, sizeof(zeros));
+        std::fprintf(stderr, "[gmsx bk] entered nodes by c <= 32/64/128/256/512/1024/2048/more:");
+        for (int i = 0; i < 8; ++i) std::fprintf(stderr, " %llu", hist[i]);
+        std::fprintf(stderr, "\n[gmsx bk] entered nodes by |P| = 0 / 1 / 2-6 / 7-16 / 17-32 / 33-64 / 65-256 / more:");
+        for (int i = 8; i < 16; ++i) std::fprintf(stderr, " %llu", hist[i]);
+        std::fprintf(stderr, "\n[gmsx bk] entered with Xf %llu, one-candidate nodes %llu, branch steps %llu, leaf fast paths %llu, one-candidate children %llu, pushes %llu (Xf words %llu), "
+                     "pivot-scored nodes %llu (sum |P u Xc| %llu), deepest level %llu\n", hist[16], hist[25], hist[17], hist[18], hist[19], hist[20], hist[24], hist[21], hist[22], hist[23]);
+        std::fprintf(stderr, "[gmsx bk] Xf checks of the fast paths %llu (%llu words), non-zero words of the pushed child Xf %llu; wave cycles: search %llu, of them Xf loops %llu, pivot scoring %llu\n",
+                     hist[26], hist[27], hist[31], hist[29], hist[28], hist[30]);
     }
     for (int b = 0; b < 7; ++b) {
         unsigned long long nrec = 0, xws = 0;

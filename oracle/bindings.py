@@ -191,6 +191,9 @@ class Reference:
         if hasattr(L, "ref_kclist_count_wide"):
             L.ref_kclist_count_wide.restype = C.c_uint64
             L.ref_kclist_count_wide.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        if hasattr(L, "ref_tc_total_sliced"):
+            L.ref_tc_total_sliced.restype = C.c_uint64
+            L.ref_tc_total_sliced.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.ref_rank.argtypes = [vp, C.c_int, _i32p]
         if hasattr(L, "ref_tc_ordering"):
             L.ref_tc_ordering.argtypes = [vp, C.c_int, _i32p]
@@ -226,6 +229,13 @@ class Reference:
 
     def tc_total(self, g, set_kind=0, seq=False):
         return int(self.L.ref_tc_total(g, set_kind, int(seq)))
+
+    def tc_total_sliced(self, g, slices, times=False):
+        """Par::count_total on RoaringSets, accumulated over `slices` id ranges of the neighbourhoods (ref_shim.cc: ref_tc_total_sliced) —
+        the reference's RoaringSet / intersect_count under a restated loop, for graphs whose whole RoaringGraph does not fit the host."""
+        b, c = C.c_double(0), C.c_double(0)
+        v = int(self.L.ref_tc_total_sliced(g, slices, C.byref(b), C.byref(c)))
+        return (v, b.value, c.value) if times else v
 
     def tc_vertex_count2(self, g, set_kind=0, variant=0):
         c = np.zeros(self.L.ref_num_nodes(g), dtype=np.int64)

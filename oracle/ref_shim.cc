@@ -150,6 +150,63 @@ uint64_t ref_tc_total(void *h, int set_kind, int variant) {
     auto sg = RoaringGraph::FromCGraph(g);
     return variant ? TriangleCount::Seq::count_total(sg) : TriangleCount::Par::count_total(sg);
 }
+// Par::count_total<RoaringGraph> for graphs whose RoaringGraph does not fit the host (RMAT scale 27: ~17 GB of CSR + ~75 GB of
+// Roaring containers against 62 GB in the build container).  |N(u) ∩ N(v)| = Σ_k |N_k(u) ∩ N_k(v)| for ANY partition of the id space
+// into ranges R_k with N_k(x) = N(x) ∩ R_k, so the total is accumulated over K column slices of the graph: per slice the reference's
+// OWN RoaringSet is built for every vertex from the slice of its (sorted) CSR row — the same constructor SetGraph::FromCGraph uses
+// (set_graph.h:160-166, roaring_set.h:49-54) — and the reference's OWN RoaringSet::intersect_count (roaring_set.h) is called for every
+// edge u < v of the FULL row, with the schedule of total.h:12.  Restated: the loop of total.h:13-20 (edges from the CSR row instead
+// of from neigh_u's iterator, K times) and the parallel build of the slice.  K = 1 is total.h verbatim on a RoaringGraph;
+// tests/test_oracle.py asserts slices = 1, 2, 5 equal to ref_tc_total on every graph both can hold.  Returns the triangle count.
+uint64_t ref_tc_total_sliced(void *h, int slices, double *build_s, double *count_s) {
+    Quiet q;
+    const CSRGraph &g = static_cast<RefGraph *>(h)->g;
+    const int64_t n = g.num_nodes();
+    if (slices < 1) slices = 1;
+    // slice boundaries: equal shares of the CSR entries by neighbour id (ids are degree-ranked: the first ranges are narrow)
+    std::vector<int64_t> hist((size_t)(n >> 10) + 2, 0);
+    for (int64_t u = 0; u < n; u++)
+        for (NodeId v : g.out_neigh(u)) hist[(size_t)(v >> 10)]++;
+    const int64_t nnz = g.num_edges_directed();
+    std::vector<int64_t> bound{0};
+    int64_t acc = 0;
+    for (size_t b = 0; b < hist.size() && (int)bound.size() < slices; b++) {
+        acc += hist[b];
+        if (acc * slices >= nnz * (int64_t)bound.size()) bound.push_back(std::min<int64_t>(n, (int64_t)(b + 1) << 10));
+    }
+    while ((int)bound.size() < slices) bound.push_back(n);
+    bound.push_back(n);
+    size_t total = 0;
+    double tb = 0, tc = 0;
+    for (int k = 0; k < slices; k++) {
+        const NodeId lo = (NodeId)bound[(size_t)k], hi = (NodeId)bound[(size_t)k + 1];
+        if (lo >= hi) continue;
+        double t0 = omp_get_wtime();
+        std::vector<RoaringSet> slice((size_t)n);
+#pragma omp parallel for schedule(dynamic, 4096)
+        for (NodeId u = 0; u < n; u++) {
+            NodeId *b = g.out_neigh(u).begin(), *e = g.out_neigh(u).end();
+            NodeId *first = std::lower_bound(b, e, lo), *last = std::lower_bound(first, e, hi);
+            if (last > first) slice[(size_t)u] = RoaringSet(first, (size_t)(last - first));
+        }
+        double t1 = omp_get_wtime();
+#pragma omp parallel for schedule(static, 17) reduction(+ : total)
+        for (NodeId u = 0; u < n; ++u) {
+            const RoaringSet &neigh_u = slice[(size_t)u];
+            if (neigh_u.cardinality() == 0) continue;
+            for (NodeId v : g.out_neigh(u)) {
+                if (u < v) total += neigh_u.intersect_count(slice[(size_t)v]);
+            }
+        }
+        tb += t1 - t0;
+        tc += omp_get_wtime() - t1;
+        fprintf(stderr, "ref_tc_total_sliced: slice %d/%d ids [%d,%d) build %.0f s count %.0f s, running 3T = %zu\n", k + 1, slices, lo, hi,
+                t1 - t0, omp_get_wtime() - t1, total);
+    }
+    if (build_s) *build_s = tb;
+    if (count_s) *count_s = tc;
+    return total / 3;
+}
 // variant: 0 Par::vertex_count2, 1 Par::vertex_count2_once, 2 Seq::vertex_count2
 void ref_tc_vertex_count2(void *h, int set_kind, int variant, int64_t *out) {
     Quiet q;

@@ -3,6 +3,9 @@
 
     make -C oracle ref
     python tools/make_golden_big.py tc 26          # Par::count_total<RoaringGraph>, ~35 min on 8 threads, ~45 GB
+    python tools/make_golden_big.py tc-sliced 27 16 5   # the same count where the whole RoaringGraph does not fit the host (scale 27: ~90 GB):
+                                                   # the reference's RoaringSet::intersect_count per edge, accumulated over 5 id-range
+                                                   # slices of the neighbourhoods (oracle/ref_shim.cc ref_tc_total_sliced)
     python tools/make_golden_big.py kc4 16|18|20   # CliqueCount<RoaringSet,RoaringGraph,RoaringSet>(g, 4)
     python tools/make_golden_big.py bk 14          # BkEppsteinPar::mceBench<RoaringGraph>, degree rank
     python tools/make_golden_big.py kclist 24|26   # TRUE 4-clique count (each clique once) by the reference's kClist pipeline
@@ -82,6 +85,14 @@ def main():
     t0 = time.time()
     if what == "tc":
         field, val, how = "triangles", R.tc_total(g, Reference.ROARING), "Par::count_total<RoaringGraph>"
+    elif what == "tc-sliced":
+        slices = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+        val, build_s, count_s = R.tc_total_sliced(g, slices, times=True)
+        field = "triangles"
+        how = ("Par::count_total on the reference's RoaringSet, accumulated over %d id-range slices of the neighbourhoods (the whole "
+               "RoaringGraph does not fit this host): RoaringSet build %.0f s + RoaringSet::intersect_count per edge %.0f s under the "
+               "loop of oracle/ref_shim.cc ref_tc_total_sliced; equal to Par::count_total<RoaringGraph> wherever that fits "
+               "(tests/test_oracle.py)" % (slices, build_s, count_s))
     elif what == "kc4":
         field, val, how = "kc4", R.kclique(g, 4, Reference.ROARING), "CliqueCount<RoaringSet,RoaringGraph,RoaringSet>(g,4)"
     elif what == "bk":
@@ -99,7 +110,7 @@ def main():
                "ref_kclist_count_wide — Par::NP_kclisting itself segfaults on this graph (uint `count*count` in SubGraphBuilder.h:49 wraps "
                "for a hub); equal to it wherever it runs (scales 10-20 checked)" % (prep_s, count_s))
     else:
-        raise SystemExit("what = tc | kc4 | bk | kclist | kclist-wide")
+        raise SystemExit("what = tc | tc-sliced | kc4 | bk | kclist | kclist-wide")
     dt = time.time() - t0
     R.free(g)
     key = "kronecker-%d-%d-relabel" % (scale, deg)
