@@ -217,6 +217,7 @@ __device__ unsigned long long g_bk_nodes;  // profiling build: nodes of the regi
 // fast paths; [20] pushes; [21] pivot-scored nodes; [22] sum of |P u Xc| over them; [23] deepest level; [24] Xf words ANDed; [25] one-candidate nodes
 // [26] Xf checks of the fast paths, [27] their words, [28] cycles in Xf loops, [29] cycles in bk_search, [30] cycles in pivot scoring, [31] non-zero words of the child Xf of a push
 __device__ unsigned long long g_bk_hist[32];
+__device__ unsigned long long g_bkg_stat[20];  // k_bk_resume4's trip statistics (see there)
 #define BK_STAT(i, v) do { if (lane == 0) atomicAdd(&g_bk_hist[i], (unsigned long long)(v)); } while (0)
 #define BK_T0() const long long t0_ = clock64()
 #define BK_T1(i) BK_STAT(i, clock64() - t0_)
@@ -1585,10 +1586,22 @@ __device__ __forceinline__ int bkg_xf_mem(const uint32_t *src, int n, int xw, co
 #ifndef GMSX_BK_GROUP_WAVES
 #define GMSX_BK_GROUP_WAVES 4
 #endif
+__device__ __forceinline__ int bkg_min(int x) { x = min(x, bkg_ror<8>(x)); x = min(x, bkg_ror<4>(x)); x = min(x, bkg_ror<2>(x)); x = min(x, bkg_ror<1>(x)); return x; }
+__device__ __forceinline__ int bkg_first(uint32_t w, int sub) { return bkg_min(w != 0u ? (sub << 5) + __ffs(w) - 1 : 0xffff); }  // lowest set bit of the group's 512-bit set
+__device__ __forceinline__ int bkg_scan(int x) {  // inclusive prefix sum over the 16 lanes of the row (DPP row_shr, lanes shifted in from outside read 0)
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    return x;
+}
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROUP_WAVES))) void k_bk_resume4(
     const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in, unsigned long long n_records, unsigned long long *__restrict__ queue,
     unsigned grab, uint32_t *__restrict__ slabs, unsigned long long slab_words /* per search */, unsigned long long *__restrict__ acc, BkShared sh) {
-    enum : int { M_REC = 0, M_ENTER, M_NEXT, M_PIVOT, M_BRANCH, M_CHILD1, M_POP, M_DONE };
+    // what the step at the top of the next trip consumes: M_PIVOT the pivot's row (ext = P & ~row), M_PIVOTB the same when the pivot is a candidate —
+    // then it is also the first branch vertex and its row serves both (a node's branches may be taken in any order) —, M_BRANCH the row of branch
+    // vertex q, M_CHILD1 the row of the only candidate of q's child, M_POP a saved level; M_ENTER / M_NEXT: a record was fetched (root / resumed)
+    enum : int { M_REC = 0, M_ENTER, M_NEXT, M_PIVOT, M_PIVOTB, M_BRANCH, M_CHILD1, M_POP, M_DONE };
     __shared__ unsigned short piv_list[4][kBkGroupMaxC];
     __shared__ uint32_t piv_P[4][16];
     const int lane = threadIdx.x, sub = lane & 15, grp = lane >> 4, gsh = lane & 48;
@@ -1596,20 +1609,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
     uint32_t *const slab = slabs + (size_t(blockIdx.x) * 4 + grp) * slab_words;
     unsigned long long cnt = 0;
     // the group's search (every lane of the group holds the same value of what is not a bitmap word)
-    const uint32_t *rec = nullptr, *Cadj = pool_in, *XT = pool_in, *xf0 = pool_in;
-    int c = 0, cw = 0, xw = 0, depth = 0, mode = M_REC;
-    unsigned long long lvl = kBkLevelFixed;
+    const uint32_t *rec = pool_in, *Cadj = pool_in, *XT = pool_in, *xf0 = pool_in;
+    uint32_t c = 0, cw = 0, xw = 0, depth = 0, lvl = kBkLevelFixed;
+    int mode = M_REC;
     int xfn = 0;                   // Xf of the current level: 0 empty, -1 the dense words of level 0, n > 0 a list of n pairs (n <= 16: in ridx / rval)
     uint32_t P = 0, Xc = 0, ext = 0, Xcn = 0, ridx = 0, rval = 0, tq = 0;
-    int q = 0, rowreq = 0;
+    uint32_t q = 0, rowreq = 0;
     unsigned nodes = 0;
     bool nosplit = false;
     unsigned long long q_next = 0, q_end = 0;
-    auto level = [&](int l) { return slab + size_t(l) * lvl; };
-    auto xf_src = [&](int l) { return l == 0 ? xf0 : level(l) + kBkLevelFixed; };
+    auto level = [&](uint32_t l) { return slab + (unsigned long long)l * lvl; };
+    auto xf_src = [&](uint32_t l) { return l == 0 ? xf0 : level(l) + kBkLevelFixed; };
+#ifdef GMSX_BK_STATS
+    // profiling build: [0] trips of the wave loop, [1] trips in which a group fetched, [2] with a memory walk of Xf, [3] with pivot scoring; group steps in
+    // [4] PIVOT [5] PIVOTB [6] BRANCH [7] CHILD1 [8] POP, [9] idle (DONE) group-trips, [10] pushes, [11] of them tail calls
+    unsigned long long st_[12] = {};
+#define BKG_ST(i, v) st_[i] += (unsigned long long)(v)
+#define BKG_GROUPS(i, pred) st_[i] += (unsigned long long)(__popcll(__ballot(pred)) >> 4)
+#else
+#define BKG_ST(i, v) do { } while (0)
+#define BKG_GROUPS(i, pred) do { } while (0)
+#endif
     while (true) {
-        bool need_pivot = false;
         // ---- a group without a search takes the next record of its class ---------------------------------------------------------------
+        BKG_ST(1, __ballot(mode == M_REC) != 0);
         while (mode == M_REC) {
             if (q_next == q_end) {
                 unsigned long long t0 = 0;
@@ -1622,14 +1645,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
             const unsigned long long roff = dir_in[qi];
             if (roff == ~0ull) continue;  // a claimed-but-unwritten directory slot (its search was kept by the wave that claimed it)
             rec = pool_in + roff;
-            c = int(rec[1]);
-            if (c > kBkGroupMaxC) continue;  // k_bk_resume's
-            const int x = int(rec[2]);
+            c = rec[1];
+            if (c > uint32_t(kBkGroupMaxC)) continue;  // k_bk_resume's
+            const uint32_t x = rec[2];
             const unsigned long long aoff = (unsigned long long)rec[4] | ((unsigned long long)rec[5] << 32);
             const uint32_t xf_ne = rec[3], root = rec[6], pairs = rec[7];
             cw = (c + 31) >> 5;
             xw = (x + 31) >> 5;
-            lvl = bk_group_level_words(xw);
+            lvl = uint32_t(bk_group_level_words(xw));
             Cadj = sh.arena + aoff;
             XT = Cadj + size_t(c) * cw;
             P = sub < cw ? rec[kRecHeader + sub] : 0u;
@@ -1638,125 +1661,125 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
             xf0 = rec + kRecHeader + 3 * cw;
             xfn = xf_ne == 0u ? 0 : pairs != 0u ? int(pairs) : -1;
             ridx = rval = 0u;
-            if (xfn > 0 && xfn <= 16 && sub < xfn) {
+            if (xfn > 0 && xfn <= 16 && sub < uint32_t(xfn)) {
                 const bk_u2 pr = *reinterpret_cast<const bk_u2 *>(xf0 + 2 * sub);
                 ridx = pr.x;
                 rval = pr.y;
             }
+            asm volatile("" : "+v"(ridx), "+v"(rval), "+v"(P), "+v"(Xc), "+v"(ext));  // waited for HERE, not by a vmcnt(0) in front of the next trip's loads
             depth = 0;
             nodes = 0;
+            rowreq = 0;
             nosplit = false;
-            if (root != 0u) { ++nodes; need_pivot = true; mode = M_ENTER; } else mode = M_NEXT;
+            if (root != 0u) { ++nodes; mode = M_ENTER; } else mode = M_NEXT;
         }
         if (__ballot(mode != M_DONE) == 0) break;
-        // ---- the loads of this step, all groups together --------------------------------------------------------------------------------
+        BKG_ST(0, 1);
+        BKG_GROUPS(4, mode == M_PIVOT); BKG_GROUPS(5, mode == M_PIVOTB); BKG_GROUPS(6, mode == M_BRANCH); BKG_GROUPS(7, mode == M_CHILD1);
+        BKG_GROUPS(8, mode == M_POP); BKG_GROUPS(9, mode == M_DONE);
+        // ---- the loads of this step: four per lane, UNCONDITIONAL (every address is valid whatever the mode: a stale row index, the slot of the
+        //      current level), issued back to back for the four groups, consumed below behind counted waits -------------------------------------
+        uint32_t *const lv = slab + (unsigned long long)depth * lvl + sub * kBkSlot;
+        const uint32_t row = Cadj[rowreq * cw + sub];  // lanes past cw read the next row: their words of P / Xc are zero
+        uint32_t xtw = XT[(unsigned long long)rowreq * xw + ridx];
+        const uint4 sv = *reinterpret_cast<const uint4 *>(lv);
+        const uint2 sl = *reinterpret_cast<const uint2 *>(lv + 4);
+        bool next = mode == M_NEXT || mode == M_POP || mode == M_PIVOT;
+        bool need_pivot = mode == M_ENTER;
+        int pc = 0, first = 0;  // of the node whose pivot is chosen below
+        {   // selects, not branches: a load whose only use sits under a branch is sunk into it by the compiler, and waited for right there
+            const bool pop = mode == M_POP, piv = mode == M_PIVOT || mode == M_PIVOTB;
+            P = pop ? sv.x : P;
+            Xc = pop ? sv.y : Xc;
+            ext = pop ? sv.z : ext;
+            xfn = pop ? int(sv.w) : xfn;
+            ridx = pop ? sl.x : ridx;
+            rval = pop ? sl.y : rval;
+            ext = piv ? P & ~row : ext;
+            asm volatile("" : "+v"(xtw));  // (used by one branch below: this keeps its load up here with the others)
+        }
         const bool reglist = xfn > 0 && xfn <= 16;
-        uint32_t row = 0u, xtw = 0u;
-        uint4 sv{0u, 0u, 0u, 0u};
-        uint2 sl{0u, 0u};
-        if (mode == M_PIVOT || mode == M_BRANCH || mode == M_CHILD1) {
-            if (sub < cw) row = Cadj[size_t(rowreq) * cw + sub];
-            if (reglist && mode != M_PIVOT) xtw = XT[size_t(rowreq) * xw + ridx];
-        }
-        if (mode == M_POP) {
-            const uint32_t *lv = level(depth) + sub * kBkSlot;
-            sv = *reinterpret_cast<const uint4 *>(lv);
-            sl = *reinterpret_cast<const uint2 *>(lv + 4);
-        }
-        bool next = mode == M_NEXT;
-        if (mode == M_PIVOT) {
-            ext = P & ~row;
-            next = true;
-        } else if (mode == M_POP) {
-            P = sv.x; Xc = sv.y; ext = sv.z; xfn = int(sv.w);
-            ridx = sl.x; rval = sl.y;
-            next = true;
-        } else if (mode == M_CHILD1) {
-            // the child of branch q had ONE candidate q2 (its row is here): a maximal clique iff nothing finished is adjacent to q and q2
-            bool blocked = bkg_ballot((Xcn & row) != 0u, gsh) != 0u;
-            if (!blocked && xfn != 0)
-                blocked = reglist ? bkg_ballot((tq & xtw) != 0u, gsh) != 0u
-                                  : bkg_xf_mem<2>(xf_src(depth), xfn, xw, XT + size_t(q) * xw, XT + size_t(rowreq) * xw, nullptr, sub, gsh) != 0;
-            if (!blocked && sub == 0) cnt++;
-            nodes += 2;
-            next = true;
-        } else if (mode == M_BRANCH) {
-            const uint32_t Pn = P & row, Xcn_ = Xc & row;
-            if (sub == (q >> 5)) {  // this node continues with q moved from cand to fini (tomita.h:68-70)
+        if (mode == M_BRANCH || mode == M_CHILD1 || mode == M_PIVOTB) {
+            // ---- the child of branch vertex q (M_CHILD1: the one-candidate child of q, through the row of its candidate) -------------------
+            const bool c1 = mode == M_CHILD1;
+            const uint32_t Pn = c1 ? 0u : P & row, Xq = (c1 ? Xcn : Xc) & row, t = (c1 ? tq : rval) & xtw;
+            if (!c1 && sub == (q >> 5)) {  // this node continues with q moved from cand to fini (tomita.h:68-70)
                 const uint32_t b = 1u << (q & 31);
                 ext &= ~b; P &= ~b; Xc |= b;
             }
-            tq = rval & xtw;  // register-list Xf ∩ N(q)
-            const uint32_t m = bkg_ballot(Pn != 0u, gsh);
-            if (m == 0u) {
-                // the child has no candidate: a leaf, decided here
-                bool blocked = bkg_ballot(Xcn_ != 0u, gsh) != 0u;
-                if (!blocked && xfn != 0)
-                    blocked = reglist ? bkg_ballot(tq != 0u, gsh) != 0u
-                                      : bkg_xf_mem<1>(xf_src(depth), xfn, xw, XT + size_t(q) * xw, nullptr, nullptr, sub, gsh) != 0;
+            const int pcn = bkg_sum(__popc(Pn));
+            const int fn = bkg_first(Pn, sub);
+            if (pcn == 0) {
+                // no candidate: a leaf, decided here — one maximal clique iff no finished vertex is adjacent to the whole clique
+                bool blocked = bkg_ballot(Xq != 0u, gsh) != 0u;
+                if (!blocked && xfn != 0) {
+                    if (reglist) blocked = bkg_ballot(t != 0u, gsh) != 0u;
+                    else {
+                        BKG_ST(2, 1);
+                        blocked = c1 ? bkg_xf_mem<2>(xf_src(depth), xfn, int(xw), XT + size_t(q) * xw, XT + size_t(rowreq) * xw, nullptr, sub, gsh) != 0
+                                     : bkg_xf_mem<1>(xf_src(depth), xfn, int(xw), XT + size_t(q) * xw, nullptr, nullptr, sub, gsh) != 0;
+                    }
+                }
                 if (!blocked && sub == 0) cnt++;
-                ++nodes;
+                nodes += c1 ? 2u : 1u;
                 next = true;
+            } else if (pcn == 1) {
+                // ONE candidate: decided by the next step from that candidate's row, no level pushed
+                Xcn = Xq;
+                tq = t;
+                rowreq = uint32_t(fn);
+                mode = M_CHILD1;
             } else {
-                const int L1 = __ffs(m) - 1;
-                const uint32_t pw = uint32_t(__shfl(int(Pn), gsh + L1));
-                if ((m & (m - 1u)) == 0u && (pw & (pw - 1u)) == 0u) {
-                    // ONE candidate q2: decided by the next step from q2's row, no level pushed
-                    Xcn = Xcn_;
-                    rowreq = (L1 << 5) + __ffs(pw) - 1;
-                    mode = M_CHILD1;
-                } else {
-                    // push: save this level, enter the child
-                    uint32_t *lv = level(depth) + sub * kBkSlot;
+                // enter the child.  The level is saved only if it has another branch left (else nothing would come back to it)
+                const bool last = bkg_ballot(ext != 0u, gsh) == 0u && (xfn == 0 || reglist);
+                BKG_GROUPS(10, true); BKG_GROUPS(11, last);
+                if (!last) {
                     *reinterpret_cast<uint4 *>(lv) = uint4{P, Xc, ext, uint32_t(xfn)};
                     *reinterpret_cast<uint2 *>(lv + 4) = uint2{ridx, rval};
-                    int nxf = 0;
-                    if (xfn != 0) {
-                        if (reglist) {
-                            const uint32_t mm = bkg_ballot(tq != 0u, gsh);
-                            nxf = __popc(mm);
-                            const int dst = tq != 0u ? __popc(mm & lt) : 15;  // lanes without a pair send a zero to a lane no pair goes to
-                            const uint32_t si = tq != 0u ? ridx : 0u;
-                            ridx = uint32_t(__builtin_amdgcn_ds_permute((gsh + dst) << 2, int(si)));
-                            rval = uint32_t(__builtin_amdgcn_ds_permute((gsh + dst) << 2, int(tq)));
-                            if (nxf == 16) { /* every lane sent its own pair to a distinct lane */ }
-                        } else {
-                            uint32_t *dl = level(depth + 1) + kBkLevelFixed;
-                            nxf = bkg_xf_mem<0>(xf_src(depth), xfn, xw, XT + size_t(q) * xw, nullptr, dl, sub, gsh);
-                            ridx = rval = 0u;
-                            if (nxf <= 16 && sub < nxf) {
-                                const bk_u2 pr = *reinterpret_cast<const bk_u2 *>(dl + 2 * sub);
-                                ridx = pr.x;
-                                rval = pr.y;
-                            }
-                        }
-                    }
-                    ++depth;
-                    P = Pn; Xc = Xcn_; xfn = nxf;
-                    ++nodes;
-                    need_pivot = true;
                 }
+                int nxf = 0;
+                if (xfn != 0) {
+                    if (reglist) {
+                        const uint32_t mm = bkg_ballot(t != 0u, gsh);
+                        nxf = __popc(mm);
+                        const int dst = t != 0u ? __popc(mm & lt) : 15;  // lanes without a pair send a zero to a lane no pair goes to
+                        const uint32_t si = t != 0u ? ridx : 0u;
+                        ridx = uint32_t(__builtin_amdgcn_ds_permute((gsh + dst) << 2, int(si)));
+                        rval = uint32_t(__builtin_amdgcn_ds_permute((gsh + dst) << 2, int(t)));
+                    } else {
+                        BKG_ST(2, 1);
+                        uint32_t *dl = level(depth + 1) + kBkLevelFixed;
+                        nxf = bkg_xf_mem<0>(xf_src(depth), xfn, int(xw), XT + size_t(q) * xw, nullptr, dl, sub, gsh);
+                        ridx = rval = 0u;
+                        if (nxf <= 16 && sub < uint32_t(nxf)) {
+                            const bk_u2 pr = *reinterpret_cast<const bk_u2 *>(dl + 2 * sub);
+                            ridx = pr.x;
+                            rval = pr.y;
+                        }
+                        asm volatile("" : "+v"(ridx), "+v"(rval));  // (as in the fetch above)
+                    }
+                }
+                if (!last) ++depth;
+                P = Pn; Xc = Xq; xfn = nxf;
+                ++nodes;
+                need_pivot = true;
+                pc = pcn;
+                first = fn;
             }
         }
         // ---- pivot of an entered node: argmax over u in P ∪ Xc of |P ∩ N(u)| (tomita.h:12-40); its row is the next step's ----------------
         if (need_pivot) {
-            const uint32_t m = bkg_ballot(P != 0u, gsh);
-            const int pc = bkg_sum(__popc(P));
-            int best;
-            if (pc <= sh.small_p) {
-                const int L0 = __ffs(m) - 1;
-                best = (L0 << 5) + __ffs(uint32_t(__shfl(int(P), gsh + L0))) - 1;
-            } else {
+            if (mode == M_ENTER) {
+                pc = bkg_sum(__popc(P));
+                first = bkg_first(P, sub);
+            }
+            int best = first;
+            bool in_p = true;
+            if (pc > sh.small_p) {
+                BKG_ST(3, 1);
                 const uint32_t U = P | Xc;
                 const int mine = __popc(U);
-                int incl = mine;  // inclusive prefix over the 16 lanes of the row
-                {
-                    int t;
-                    t = __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false); incl += t;  // row_shr:1
-                    t = __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false); incl += t;  // row_shr:2
-                    t = __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false); incl += t;  // row_shr:4
-                    t = __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false); incl += t;  // row_shr:8
-                }
+                const int incl = bkg_scan(mine);
                 const int ncand = __shfl(incl, gsh + 15);
                 piv_P[grp][sub] = P;
                 {
@@ -1771,7 +1794,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 int key = -1;
-                const int cw4 = (cw + 3) >> 2;
+                const int cw4 = int(cw + 3) >> 2;
                 for (int k = sub; k < ncand; k += 16) {
                     const int u = int(piv_list[grp][k]);
                     const uint32_t *r = Cadj + size_t(u) * cw;
@@ -1785,15 +1808,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
                 }
                 key = bkg_max(key);
                 best = 0xffff - (key & 0xffff);
+                in_p = ((piv_P[grp][best >> 5] >> (best & 31)) & 1u) != 0u;
                 __builtin_amdgcn_wave_barrier();
             }
-            rowreq = best;
-            mode = M_PIVOT;
+            rowreq = uint32_t(best);
+            q = uint32_t(best);  // (read by M_PIVOTB only)
+            mode = in_p ? M_PIVOTB : M_PIVOT;
         }
         // ---- the next branch vertex of this node, or the way back up ----------------------------------------------------------------------
         if (next) {
-            const uint32_t m = bkg_ballot(ext != 0u, gsh);
-            if (m == 0u) {
+            const int fq = bkg_first(ext, sub);
+            if (fq == 0xffff) {
                 if (depth == 0) mode = M_REC;
                 else { --depth; mode = M_POP; }
             } else {
@@ -1805,7 +1830,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
                     *reinterpret_cast<uint2 *>(cur + 4) = uint2{ridx, rval};
                     __threadfence();
                     int nrec = 0;
-                    for (int l = 0; l <= depth; ++l) nrec += min(bkg_sum(__popc(level(l)[sub * kBkSlot + 2])), kBkSplit);
+                    for (uint32_t l = 0; l <= depth; ++l) nrec += min(bkg_sum(__popc(level(l)[sub * kBkSlot + 2])), kBkSplit);
                     const unsigned long long rec_words = (unsigned long long)(kRecHeader + 3 * cw + xw);
                     unsigned long long p0 = 0, d0 = sh.dir_cap;
                     if (sub == 0) {
@@ -1829,51 +1854,44 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
                             return r;
                         };
                         int r = 0;
-                        for (int l = 0; l <= depth; ++l) {
-                            const uint32_t *lv = level(l) + sub * kBkSlot;
-                            const uint32_t lP = lv[0], lXc = lv[1], e = lv[2];
-                            const int ln = int(lv[3]);
-                            const uint32_t lidx = lv[4], lval = lv[5];
+                        for (uint32_t l = 0; l <= depth; ++l) {
+                            const uint32_t *ls = level(l) + sub * kBkSlot;
+                            const uint32_t lP = ls[0], lXc = ls[1], e = ls[2];
+                            const int ln = int(ls[3]);
+                            const uint32_t lidx = ls[4], lval = ls[5];
                             const int mine = __popc(e);
-                            int incl = mine;
-                            {
-                                int t;
-                                t = __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false); incl += t;
-                                t = __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false); incl += t;
-                                t = __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false); incl += t;
-                                t = __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false); incl += t;
-                            }
+                            const int incl = bkg_scan(mine);
                             const int nb = __shfl(incl, gsh + 15);
                             if (nb == 0) continue;
                             const int rank0 = incl - mine;  // rank of this word's first pending branch
                             const int parts = min(nb, kBkSplit);
+                            const bool in_regs = ln >= 0 && ln <= 16;  // the level's Xf: empty or a register list (saved in the slot) — else in memory
+                            const uint32_t *src = xf_src(l);            // (memory form at level 0: the Xf of the record this search came from)
                             for (int j = 0; j < parts; ++j) {
                                 const int a = int((long long)nb * j / parts), b = int((long long)nb * (j + 1) / parts);  // ranks [a, b) of the pending branches
                                 uint32_t *out = sh.pool + p0 + rec_words * r;
-                                // Xf of the level: level 0 as this record has it, deeper levels as a list when it fits the dense area, else scattered
+                                // Xf of the level: as a list when it fits the dense area of the record, else scattered into dense words
                                 uint32_t o3 = 0u, o7 = 0u;
                                 uint32_t *ox = out + kRecHeader + 3 * cw;
-                                if (l == 0) {
-                                    o3 = rec[3];
-                                    o7 = rec[7];
-                                    for (int w = sub; w < xw; w += 16) ox[w] = xf0[w];
+                                if (ln < 0) {  // the dense words of level 0
+                                    o3 = 1u;
+                                    for (uint32_t w = sub; w < xw; w += 16) ox[w] = src[w];
                                 } else if (ln > 0) {
                                     o3 = 1u;
-                                    const uint32_t *src = level(l) + kBkLevelFixed;
-                                    if (2 * ln <= xw) {
+                                    if (2u * uint32_t(ln) <= xw) {
                                         o7 = uint32_t(ln);
-                                        if (ln <= 16) { if (sub < ln) *reinterpret_cast<bk_u2 *>(ox + 2 * sub) = bk_u2{lidx, lval}; }
-                                        else for (int i = sub; i < 2 * ln; i += 16) ox[i] = src[i];
+                                        if (in_regs) { if (sub < uint32_t(ln)) *reinterpret_cast<bk_u2 *>(ox + 2 * sub) = bk_u2{lidx, lval}; }
+                                        else for (uint32_t i = sub; i < 2u * uint32_t(ln); i += 16) ox[i] = src[i];
                                     } else {
-                                        for (int w = sub; w < xw; w += 16) ox[w] = 0u;
+                                        for (uint32_t w = sub; w < xw; w += 16) ox[w] = 0u;
                                         __threadfence();
-                                        if (ln <= 16) { if (sub < ln) ox[lidx] = lval; }
-                                        else for (int i = sub; i < ln; i += 16) ox[src[2 * i]] = src[2 * i + 1];
+                                        if (in_regs) { if (sub < uint32_t(ln)) ox[lidx] = lval; }
+                                        else for (uint32_t i = sub; i < uint32_t(ln); i += 16) ox[src[2 * i]] = src[2 * i + 1];
                                     }
                                 }
                                 if (sub == 0) {
                                     out[0] = rec[0];
-                                    out[1] = uint32_t(c);
+                                    out[1] = c;
                                     out[2] = rec[2];
                                     out[3] = o3;
                                     out[4] = rec[4];
@@ -1901,9 +1919,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
                 }
                 if (split) mode = M_REC;
                 else {
-                    const int L = __ffs(m) - 1;
-                    const uint32_t word = uint32_t(__shfl(int(ext), gsh + L));
-                    q = (L << 5) + __ffs(word) - 1;
+                    q = uint32_t(fq);
                     rowreq = q;
                     mode = M_BRANCH;
                 }
@@ -1911,6 +1927,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
         }
     }
     if (sub == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
+#ifdef GMSX_BK_STATS
+    if (lane == 0)
+        for (int i = 0; i < 12; ++i) atomicAdd(&g_bkg_stat[i], st_[i]);
+#endif
 }
 
 static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
@@ -2398,6 +2418,14 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         for (int i = 8; i < 16; ++i) std::fprintf(stderr, " %llu", hist[i]);
         std::fprintf(stderr, "\n[gmsx bk] entered with Xf %llu, one-candidate nodes %llu, branch steps %llu, leaf fast paths %llu, one-candidate children %llu, pushes %llu (Xf words %llu), "
                      "pivot-scored nodes %llu (sum |P u Xc| %llu), deepest level %llu\n", hist[16], hist[25], hist[17], hist[18], hist[19], hist[20], hist[24], hist[21], hist[22], hist[23]);
+        {
+            unsigned long long gs[20], gz[20] = {};
+            (void)hipMemcpyFromSymbol(gs, HIP_SYMBOL(g_bkg_stat), sizeof(gs));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bkg_stat), gz, sizeof(gz));
+            std::fprintf(stderr, "[gmsx bk] k_bk_resume4: trips %llu (with a fetch %llu, a memory walk of Xf %llu, pivot scoring %llu); group steps PIVOT %llu PIVOT+BRANCH %llu BRANCH %llu "
+                         "CHILD1 %llu POP %llu, idle group-trips %llu; pushes %llu, of them without a saved level %llu\n",
+                         gs[0], gs[1], gs[2], gs[3], gs[4], gs[5], gs[6], gs[7], gs[8], gs[9], gs[10], gs[11]);
+        }
         std::fprintf(stderr, "[gmsx bk] Xf checks of the fast paths %llu (%llu words), non-zero words of the pushed child Xf %llu; wave cycles: search %llu, of them Xf loops %llu, pivot scoring %llu\n",
                      hist[26], hist[27], hist[31], hist[29], hist[28], hist[30]);
     }
