@@ -35,6 +35,23 @@ static constexpr unsigned long long kWideTask = 1ull << 62;  // task key flag: m
 static constexpr int kBkMaxCand = 16384;  // widest bit rows of the register-resident search kernels: eight words per lane; start
                                           // vertices with more candidates run on the memory-resident search (k_bk_wave<false, 0>)
 
+// ---- k_bk_resume4 (below): searches of 4 / 8 / 16 lanes
+static constexpr int kBkGroupMaxC = 512;
+static constexpr int kBkSlot = 8;                   // words per lane of a saved level: P, Xc, ext, xfn | list index, list word, -, -
+#ifndef GMSX_BK_PARENT_REGS
+#define GMSX_BK_PARENT_REGS 1  // the level above the current one stays in registers (k_bk_resume4): -1 … 2 ms on configs[3]
+#endif
+// lanes per search by candidate count: 16 lanes hold 512 candidates, 8 hold 256, 4 hold 128 (GMSX_BK_GROUP_MIN: the narrowest group compiled in)
+#ifndef GMSX_BK_GROUP_MIN
+#define GMSX_BK_GROUP_MIN 16  // measured on configs[3] (all records <= 512 candidates, 60 % of the nodes <= 256): 16 -> 151 ms, 8 -> 155-167, 4 -> 180-190: more searches
+                              // per wave put every block of the step machine on every trip and eight waits behind one memory walk
+#endif
+__host__ __device__ inline int bk_group_lanes(long long c) { return c <= 128 && GMSX_BK_GROUP_MIN <= 4 ? 4 : c <= 256 && GMSX_BK_GROUP_MIN <= 8 ? 8 : 16; }
+__host__ __device__ inline int bk_group_class(long long c) { const int g = bk_group_lanes(c); return g == 16 ? 0 : g == 8 ? 1 : 2; }
+// a saved level: kBkSlot words per lane of the group + 2 words per possible list pair; a search may go c levels deep
+__host__ __device__ inline unsigned long long bk_group_level_words(int lanes, long long xw) { return (unsigned long long)(lanes * kBkSlot + ((2 * xw + 3) & ~3ll)); }
+__host__ __device__ inline unsigned long long bk_group_slab_words(long long c, long long xw) { return (unsigned long long)(c + 1) * bk_group_level_words(bk_group_lanes(c), xw); }
+
 __host__ __device__ inline uint32_t bk_map_size(int c) {
     uint32_t s = 64;
     while (s < 2u * uint32_t(c)) s <<= 1;
@@ -239,6 +256,7 @@ struct BkShared {
     unsigned long long *max_stack;      // max (c+1)*lvl over the dumped records
     unsigned budget;                    // nodes per task before it is split
     int small_p;                        // nodes with at most this many candidates take their first candidate as the pivot (no scoring)
+    int small_p_groups;                 // the same for k_bk_resume4, where such a pivot costs nothing (its row is the first branch's row)
     const int64_t *bmoff;               // bitset containers of the hub rows (device_graph.hpp)
     const uint32_t *bmpool;
     int32_t dense_limit;
@@ -573,7 +591,7 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                     }
                     if (lane == 0) {
                         atomicMax(sh.max_stack, (unsigned long long)(c + 1) * (unsigned long long)lvl);
-                        if (c <= 512) atomicMax(sh.max_stack + 1, (unsigned long long)(c + 1) * (unsigned long long)(128 + ((2 * xw + 3) & ~3)));  // = bk_group_slab_words: k_bk_resume4's need
+                        if (c <= 512) atomicMax(sh.max_stack + 1 + bk_group_class(c), bk_group_slab_words(c, xw));  // k_bk_resume4's need
                     }
                 }
             }
@@ -1095,7 +1113,7 @@ static constexpr int kBkBlockGrab = GMSX_BK_BLOCK_GRAB;  // pieces per queue tic
 __global__ void k_bk_layout(int64_t lo, int64_t cnt, int nparts, int part, const int32_t *__restrict__ task_v, const int64_t *__restrict__ off,
                             const int32_t *__restrict__ oldid, const int32_t *__restrict__ dplus, int x_is_degree, int64_t *__restrict__ need_a,
                             int64_t *__restrict__ need_r, int64_t *__restrict__ need_p,
-                            unsigned long long *__restrict__ maxima /* [0] (c+1)*lvl  [1] global map words  [3] slab words of a 16-lane search */) {
+                            unsigned long long *__restrict__ maxima /* [0] (c+1)*lvl  [1] global map words  [2..4] slab words of a 16- / 8- / 4-lane search */) {
     const int64_t qi = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (qi > cnt) return;
     if (qi == cnt) { need_a[qi] = 0; need_r[qi] = 0; need_p[qi] = 0; return; }
@@ -1107,7 +1125,7 @@ __global__ void k_bk_layout(int64_t lo, int64_t cnt, int nparts, int part, const
     need_r[qi] = kRecHeader + 3 * cw + xw;
     need_p[qi] = (c + (off[vo + 1] - off[vo]) + kBkPieceJobs - 1) / kBkPieceJobs;  // k_bk_block: pieces of kBkPieceJobs row jobs (>= 1: c > 0)
     atomicMax(&maxima[0], (unsigned long long)((c + 1) * (3 * cw + xw + 1)));
-    if (c <= 512) atomicMax(&maxima[3], (unsigned long long)((c + 1) * (128 + ((2 * xw + 3) & ~3ll))));  // = bk_group_slab_words: k_bk_resume4's need
+    if (c <= 512) atomicMax(&maxima[2 + bk_group_class(c)], bk_group_slab_words(c, xw));  // k_bk_resume4's need
     const unsigned long long msize = bk_map_size(int(c));
     if (msize > 1024) atomicMax(&maxima[1], 2ull * msize);
 }
@@ -1523,26 +1541,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? G
 // Records are those of k_bk_resume (same pool, same header; rec[7] = pairs of a list-form Xf, 0 = dense words), so the two kernels share
 // the rounds: this one takes c <= 512, k_bk_resume the wider ones.  Tomita's recursion is unchanged (tomita.h:12-86): pivot = argmax
 // |P ∩ N(u)| over P ∪ Xc, scored by the lanes of the group; nodes with <= small_p candidates take their first candidate.
-static constexpr int kBkGroupMaxC = 512;
-static constexpr int kBkSlot = 8;                   // words per lane of a saved level: P, Xc, ext, xfn | list index, list word, -, -
-static constexpr int kBkLevelFixed = 16 * kBkSlot;  // + 2 words per possible list pair
-__host__ __device__ inline unsigned long long bk_group_level_words(long long xw) { return (unsigned long long)(kBkLevelFixed + ((2 * xw + 3) & ~3ll)); }
-__host__ __device__ inline unsigned long long bk_group_slab_words(long long c, long long xw) { return (unsigned long long)(c + 1) * bk_group_level_words(xw); }
-
 struct __attribute__((packed, aligned(4))) bk_u2 { uint32_t x, y; };
-template <int K> __device__ __forceinline__ int bkg_ror(int x) { return __builtin_amdgcn_mov_dpp(x, 0x120 + K, 0xf, 0xf, false); }  // DPP row_ror:K (rows of 16 lanes)
-__device__ __forceinline__ int bkg_sum(int x) { x += bkg_ror<8>(x); x += bkg_ror<4>(x); x += bkg_ror<2>(x); x += bkg_ror<1>(x); return x; }
-__device__ __forceinline__ int bkg_max(int x) { x = max(x, bkg_ror<8>(x)); x = max(x, bkg_ror<4>(x)); x = max(x, bkg_ror<2>(x)); x = max(x, bkg_ror<1>(x)); return x; }
-__device__ __forceinline__ uint32_t bkg_ballot(bool p, int gsh) { return uint32_t(__ballot(p) >> gsh) & 0xffffu; }  // the group's 16 bits of the wave ballot
+// reductions over a group of G = 4 / 8 / 16 consecutive lanes by DPP: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror — every lane ends with the result
+template <int CTRL> __device__ __forceinline__ int bkg_dpp(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, false); }
+template <int G> __device__ __forceinline__ int bkg_sum(int x) {
+    x += bkg_dpp<0xB1>(x); x += bkg_dpp<0x4E>(x);
+    if (G >= 8) x += bkg_dpp<0x141>(x);
+    if (G >= 16) x += bkg_dpp<0x140>(x);
+    return x;
+}
+template <int G> __device__ __forceinline__ int bkg_max(int x) {
+    x = max(x, bkg_dpp<0xB1>(x)); x = max(x, bkg_dpp<0x4E>(x));
+    if (G >= 8) x = max(x, bkg_dpp<0x141>(x));
+    if (G >= 16) x = max(x, bkg_dpp<0x140>(x));
+    return x;
+}
+template <int G> __device__ __forceinline__ int bkg_min(int x) {
+    x = min(x, bkg_dpp<0xB1>(x)); x = min(x, bkg_dpp<0x4E>(x));
+    if (G >= 8) x = min(x, bkg_dpp<0x141>(x));
+    if (G >= 16) x = min(x, bkg_dpp<0x140>(x));
+    return x;
+}
+template <int G> __device__ __forceinline__ int bkg_first(uint32_t w, int sub) { return bkg_min<G>(w != 0u ? (sub << 5) + __ffs(w) - 1 : 0xffff); }  // lowest set bit of the group's set
+template <int G> __device__ __forceinline__ uint32_t bkg_ballot(bool p, int gsh) { return uint32_t(__ballot(p) >> gsh) & ((1u << G) - 1u); }  // the group's bits of the wave ballot
+template <int G> __device__ __forceinline__ int bkg_scan(int x, int sub) {  // inclusive prefix sum over the lanes of the group (rare paths only)
+    for (int d = 1; d < G; d <<= 1) {
+        const int t = __shfl_up(x, d, G);
+        if (sub >= d) x += t;
+    }
+    return x;
+}
 
 // Xf of a level held in memory — dense words (n < 0: the xw words at src) or a list of n (word index, word) pairs — against row(s) of XT.
 // MODE 0: the child list Xf ∩ N(q) -> dst, returns its length; 1: is Xf ∩ N(q) non-empty; 2: is Xf ∩ N(q) ∩ N(q2) non-empty.
-template <int MODE>
+template <int MODE, int G>
 __device__ __forceinline__ int bkg_xf_mem(const uint32_t *src, int n, int xw, const uint32_t *xt, const uint32_t *xt2, uint32_t *dst, int sub, int gsh) {
     const uint32_t lt = (1u << sub) - 1u;
     int out = 0;
     if (n < 0) {
-        for (int w0 = 0; w0 < xw; w0 += 64) {
+        for (int w0 = 0; w0 < xw; w0 += 4 * G) {
             const int w = w0 + 4 * sub;
             const bk_u4 a = *reinterpret_cast<const bk_u4 *>(src + w), b = *reinterpret_cast<const bk_u4 *>(xt + w);  // up to three words past the row: masked below
             uint32_t t[4] = {a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w};
@@ -1556,80 +1593,77 @@ __device__ __forceinline__ int bkg_xf_mem(const uint32_t *src, int n, int xw, co
             if (MODE == 0) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const uint32_t m = bkg_ballot(t[i] != 0u, gsh);
+                    const uint32_t m = bkg_ballot<G>(t[i] != 0u, gsh);
                     if (t[i] != 0u) *reinterpret_cast<bk_u2 *>(dst + 2 * (out + __popc(m & lt))) = bk_u2{uint32_t(w + i), t[i]};
                     out += __popc(m);
                 }
             } else {
-                if (bkg_ballot((t[0] | t[1] | t[2] | t[3]) != 0u, gsh)) return 1;
+                if (bkg_ballot<G>((t[0] | t[1] | t[2] | t[3]) != 0u, gsh)) return 1;
             }
         }
     } else {
-        for (int i0 = 0; i0 < n; i0 += 16) {
+        for (int i0 = 0; i0 < n; i0 += G) {
             const int i = i0 + sub;
             bk_u2 pr{0u, 0u};
             if (i < n) pr = *reinterpret_cast<const bk_u2 *>(src + 2 * i);
             uint32_t t = pr.y & xt[pr.x];
             if (MODE == 2) t &= xt2[pr.x];
             if (MODE == 0) {
-                const uint32_t m = bkg_ballot(t != 0u, gsh);
+                const uint32_t m = bkg_ballot<G>(t != 0u, gsh);
                 if (t != 0u) *reinterpret_cast<bk_u2 *>(dst + 2 * (out + __popc(m & lt))) = bk_u2{pr.x, t};
                 out += __popc(m);
             } else {
-                if (bkg_ballot(t != 0u, gsh)) return 1;
+                if (bkg_ballot<G>(t != 0u, gsh)) return 1;
             }
         }
     }
     return out;
 }
 
-#ifndef GMSX_BK_GROUP_WAVES
-#define GMSX_BK_GROUP_WAVES 4
+#ifdef GMSX_BK_STATS
+#define BKG_ST(i, v) st_[i] += (unsigned long long)(v)
+#define BKG_GROUPS(i, pred) st_[i] += (unsigned long long)(__popcll(__ballot(pred)) / G)
+#else
+#define BKG_ST(i, v) do { } while (0)
+#define BKG_GROUPS(i, pred) do { } while (0)
 #endif
-__device__ __forceinline__ int bkg_min(int x) { x = min(x, bkg_ror<8>(x)); x = min(x, bkg_ror<4>(x)); x = min(x, bkg_ror<2>(x)); x = min(x, bkg_ror<1>(x)); return x; }
-__device__ __forceinline__ int bkg_first(uint32_t w, int sub) { return bkg_min(w != 0u ? (sub << 5) + __ffs(w) - 1 : 0xffff); }  // lowest set bit of the group's 512-bit set
-__device__ __forceinline__ int bkg_scan(int x) {  // inclusive prefix sum over the 16 lanes of the row (DPP row_shr, lanes shifted in from outside read 0)
-    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
-    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
-    return x;
-}
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROUP_WAVES))) void k_bk_resume4(
-    const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in, unsigned long long n_records, unsigned long long *__restrict__ queue,
-    unsigned grab, uint32_t *__restrict__ slabs, unsigned long long slab_words /* per search */, unsigned long long *__restrict__ acc, BkShared sh) {
+
+// the searches of one class of records (G lanes per search, 64 / G searches per wave) until the class's queue is empty
+template <int G>
+__device__ __forceinline__ void bk_group_searches(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in, unsigned long long n_records,
+                                                  unsigned long long *__restrict__ queue, unsigned grab, uint32_t *__restrict__ wave_slab,
+                                                  unsigned long long slab_words /* per search */, const BkShared &sh, unsigned short *piv_list /* LDS, 2048 */,
+                                                  uint32_t *piv_P /* LDS, 64 */, unsigned long long &cnt_out, unsigned long long *st_) {
     // what the step at the top of the next trip consumes: M_PIVOT the pivot's row (ext = P & ~row), M_PIVOTB the same when the pivot is a candidate —
     // then it is also the first branch vertex and its row serves both (a node's branches may be taken in any order) —, M_BRANCH the row of branch
     // vertex q, M_CHILD1 the row of the only candidate of q's child, M_POP a saved level; M_ENTER / M_NEXT: a record was fetched (root / resumed)
     enum : int { M_REC = 0, M_ENTER, M_NEXT, M_PIVOT, M_PIVOTB, M_BRANCH, M_CHILD1, M_POP, M_DONE };
-    __shared__ unsigned short piv_list[4][kBkGroupMaxC];
-    __shared__ uint32_t piv_P[4][16];
-    const int lane = threadIdx.x, sub = lane & 15, grp = lane >> 4, gsh = lane & 48;
+    constexpr int kMaxC = 32 * G, kMinC = G == GMSX_BK_GROUP_MIN ? 0 : 16 * G;  // this class: kMinC < c <= kMaxC
+    constexpr int kFixed = G * kBkSlot;
+    (void)st_;
+    const int lane = threadIdx.x, sub = lane & (G - 1), grp = lane / G, gsh = lane & ~(G - 1);
     const uint32_t lt = (1u << sub) - 1u;
-    uint32_t *const slab = slabs + (size_t(blockIdx.x) * 4 + grp) * slab_words;
+    uint32_t *const slab = wave_slab + size_t(grp) * slab_words;
+    unsigned short *const my_list = piv_list + grp * kMaxC;
+    uint32_t *const my_P = piv_P + grp * G;
     unsigned long long cnt = 0;
     // the group's search (every lane of the group holds the same value of what is not a bitmap word)
     const uint32_t *rec = pool_in, *Cadj = pool_in, *XT = pool_in, *xf0 = pool_in;
-    uint32_t c = 0, cw = 0, xw = 0, depth = 0, lvl = kBkLevelFixed;
+    uint32_t c = 0, cw = 0, xw = 0, depth = 0, lvl = kFixed;
     int mode = M_REC;
-    int xfn = 0;                   // Xf of the current level: 0 empty, -1 the dense words of level 0, n > 0 a list of n pairs (n <= 16: in ridx / rval)
+    int xfn = 0;                   // Xf of the current level: 0 empty, -1 the dense words of level 0, n > 0 a list of n pairs (n <= G: in ridx / rval)
     uint32_t P = 0, Xc = 0, ext = 0, Xcn = 0, ridx = 0, rval = 0, tq = 0;
+    // the level above the current one, while it is in registers (GMSX_BK_PARENT_REGS): a node whose children are all decided in place — most nodes — comes
+    // back to its parent without a step of its own, and the parent is written to its slot only when a grandchild is entered
+    bool has_par = false;
+    uint32_t pP = 0, pXc = 0, pext = 0, pridx = 0, prval = 0;
+    int pxfn = 0;
     uint32_t q = 0, rowreq = 0;
     unsigned nodes = 0;
     bool nosplit = false;
     unsigned long long q_next = 0, q_end = 0;
     auto level = [&](uint32_t l) { return slab + (unsigned long long)l * lvl; };
-    auto xf_src = [&](uint32_t l) { return l == 0 ? xf0 : level(l) + kBkLevelFixed; };
-#ifdef GMSX_BK_STATS
-    // profiling build: [0] trips of the wave loop, [1] trips in which a group fetched, [2] with a memory walk of Xf, [3] with pivot scoring; group steps in
-    // [4] PIVOT [5] PIVOTB [6] BRANCH [7] CHILD1 [8] POP, [9] idle (DONE) group-trips, [10] pushes, [11] of them tail calls
-    unsigned long long st_[12] = {};
-#define BKG_ST(i, v) st_[i] += (unsigned long long)(v)
-#define BKG_GROUPS(i, pred) st_[i] += (unsigned long long)(__popcll(__ballot(pred)) >> 4)
-#else
-#define BKG_ST(i, v) do { } while (0)
-#define BKG_GROUPS(i, pred) do { } while (0)
-#endif
+    auto xf_src = [&](uint32_t l) { return l == 0 ? xf0 : level(l) + kFixed; };
     while (true) {
         // ---- a group without a search takes the next record of its class ---------------------------------------------------------------
         BKG_ST(1, __ballot(mode == M_REC) != 0);
@@ -1646,13 +1680,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
             if (roff == ~0ull) continue;  // a claimed-but-unwritten directory slot (its search was kept by the wave that claimed it)
             rec = pool_in + roff;
             c = rec[1];
-            if (c > uint32_t(kBkGroupMaxC)) continue;  // k_bk_resume's
+            if (c > uint32_t(kMaxC) || c <= uint32_t(kMinC)) continue;  // another class's (beyond 512: k_bk_resume's)
             const uint32_t x = rec[2];
             const unsigned long long aoff = (unsigned long long)rec[4] | ((unsigned long long)rec[5] << 32);
             const uint32_t xf_ne = rec[3], root = rec[6], pairs = rec[7];
             cw = (c + 31) >> 5;
             xw = (x + 31) >> 5;
-            lvl = uint32_t(bk_group_level_words(xw));
+            lvl = uint32_t(bk_group_level_words(G, xw));
             Cadj = sh.arena + aoff;
             XT = Cadj + size_t(c) * cw;
             P = sub < cw ? rec[kRecHeader + sub] : 0u;
@@ -1661,7 +1695,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
             xf0 = rec + kRecHeader + 3 * cw;
             xfn = xf_ne == 0u ? 0 : pairs != 0u ? int(pairs) : -1;
             ridx = rval = 0u;
-            if (xfn > 0 && xfn <= 16 && sub < uint32_t(xfn)) {
+            if (xfn > 0 && xfn <= G && sub < uint32_t(xfn)) {
                 const bk_u2 pr = *reinterpret_cast<const bk_u2 *>(xf0 + 2 * sub);
                 ridx = pr.x;
                 rval = pr.y;
@@ -1671,6 +1705,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
             nodes = 0;
             rowreq = 0;
             nosplit = false;
+            has_par = false;
             if (root != 0u) { ++nodes; mode = M_ENTER; } else mode = M_NEXT;
         }
         if (__ballot(mode != M_DONE) == 0) break;
@@ -1678,7 +1713,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
         BKG_GROUPS(4, mode == M_PIVOT); BKG_GROUPS(5, mode == M_PIVOTB); BKG_GROUPS(6, mode == M_BRANCH); BKG_GROUPS(7, mode == M_CHILD1);
         BKG_GROUPS(8, mode == M_POP); BKG_GROUPS(9, mode == M_DONE);
         // ---- the loads of this step: four per lane, UNCONDITIONAL (every address is valid whatever the mode: a stale row index, the slot of the
-        //      current level), issued back to back for the four groups, consumed below behind counted waits -------------------------------------
+        //      current level), issued back to back for all groups, consumed below behind counted waits ------------------------------------------
         uint32_t *const lv = slab + (unsigned long long)depth * lvl + sub * kBkSlot;
         const uint32_t row = Cadj[rowreq * cw + sub];  // lanes past cw read the next row: their words of P / Xc are zero
         uint32_t xtw = XT[(unsigned long long)rowreq * xw + ridx];
@@ -1698,26 +1733,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
             ext = piv ? P & ~row : ext;
             asm volatile("" : "+v"(xtw));  // (used by one branch below: this keeps its load up here with the others)
         }
-        const bool reglist = xfn > 0 && xfn <= 16;
+        const bool reglist = xfn > 0 && xfn <= G;
         if (mode == M_BRANCH || mode == M_CHILD1 || mode == M_PIVOTB) {
             // ---- the child of branch vertex q (M_CHILD1: the one-candidate child of q, through the row of its candidate) -------------------
             const bool c1 = mode == M_CHILD1;
             const uint32_t Pn = c1 ? 0u : P & row, Xq = (c1 ? Xcn : Xc) & row, t = (c1 ? tq : rval) & xtw;
-            if (!c1 && sub == (q >> 5)) {  // this node continues with q moved from cand to fini (tomita.h:68-70)
+            if (!c1 && uint32_t(sub) == (q >> 5)) {  // this node continues with q moved from cand to fini (tomita.h:68-70)
                 const uint32_t b = 1u << (q & 31);
                 ext &= ~b; P &= ~b; Xc |= b;
             }
-            const int pcn = bkg_sum(__popc(Pn));
-            const int fn = bkg_first(Pn, sub);
+            const int pcn = bkg_sum<G>(__popc(Pn));
+            const int fn = bkg_first<G>(Pn, sub);
             if (pcn == 0) {
                 // no candidate: a leaf, decided here — one maximal clique iff no finished vertex is adjacent to the whole clique
-                bool blocked = bkg_ballot(Xq != 0u, gsh) != 0u;
+                bool blocked = bkg_ballot<G>(Xq != 0u, gsh) != 0u;
                 if (!blocked && xfn != 0) {
-                    if (reglist) blocked = bkg_ballot(t != 0u, gsh) != 0u;
+                    if (reglist) blocked = bkg_ballot<G>(t != 0u, gsh) != 0u;
                     else {
                         BKG_ST(2, 1);
-                        blocked = c1 ? bkg_xf_mem<2>(xf_src(depth), xfn, int(xw), XT + size_t(q) * xw, XT + size_t(rowreq) * xw, nullptr, sub, gsh) != 0
-                                     : bkg_xf_mem<1>(xf_src(depth), xfn, int(xw), XT + size_t(q) * xw, nullptr, nullptr, sub, gsh) != 0;
+                        blocked = c1 ? bkg_xf_mem<2, G>(xf_src(depth), xfn, int(xw), XT + size_t(q) * xw, XT + size_t(rowreq) * xw, nullptr, sub, gsh) != 0
+                                     : bkg_xf_mem<1, G>(xf_src(depth), xfn, int(xw), XT + size_t(q) * xw, nullptr, nullptr, sub, gsh) != 0;
                     }
                 }
                 if (!blocked && sub == 0) cnt++;
@@ -1730,28 +1765,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
                 rowreq = uint32_t(fn);
                 mode = M_CHILD1;
             } else {
-                // enter the child.  The level is saved only if it has another branch left (else nothing would come back to it)
-                const bool last = bkg_ballot(ext != 0u, gsh) == 0u && (xfn == 0 || reglist);
+                // enter the child.  The level is kept only if it has another branch left (else nothing would come back to it): in registers, the
+                // level those held before goes to its slot
+                const bool last = bkg_ballot<G>(ext != 0u, gsh) == 0u && (xfn == 0 || reglist);
                 BKG_GROUPS(10, true); BKG_GROUPS(11, last);
+#if GMSX_BK_PARENT_REGS
+                if (!last) {
+                    if (has_par) {
+                        uint32_t *pl = lv - lvl;  // the slot of level depth - 1
+                        *reinterpret_cast<uint4 *>(pl) = uint4{pP, pXc, pext, uint32_t(pxfn)};
+                        *reinterpret_cast<uint2 *>(pl + 4) = uint2{pridx, prval};
+                    }
+                    pP = P; pXc = Xc; pext = ext; pxfn = xfn; pridx = ridx; prval = rval;
+                    has_par = true;
+                }
+#else
                 if (!last) {
                     *reinterpret_cast<uint4 *>(lv) = uint4{P, Xc, ext, uint32_t(xfn)};
                     *reinterpret_cast<uint2 *>(lv + 4) = uint2{ridx, rval};
                 }
+#endif
                 int nxf = 0;
                 if (xfn != 0) {
                     if (reglist) {
-                        const uint32_t mm = bkg_ballot(t != 0u, gsh);
+                        const uint32_t mm = bkg_ballot<G>(t != 0u, gsh);
                         nxf = __popc(mm);
-                        const int dst = t != 0u ? __popc(mm & lt) : 15;  // lanes without a pair send a zero to a lane no pair goes to
+                        const int dst = t != 0u ? __popc(mm & lt) : G - 1;  // lanes without a pair send a zero to a lane no pair goes to
                         const uint32_t si = t != 0u ? ridx : 0u;
                         ridx = uint32_t(__builtin_amdgcn_ds_permute((gsh + dst) << 2, int(si)));
                         rval = uint32_t(__builtin_amdgcn_ds_permute((gsh + dst) << 2, int(t)));
                     } else {
                         BKG_ST(2, 1);
-                        uint32_t *dl = level(depth + 1) + kBkLevelFixed;
-                        nxf = bkg_xf_mem<0>(xf_src(depth), xfn, int(xw), XT + size_t(q) * xw, nullptr, dl, sub, gsh);
+                        uint32_t *dl = level(depth + 1) + kFixed;
+                        nxf = bkg_xf_mem<0, G>(xf_src(depth), xfn, int(xw), XT + size_t(q) * xw, nullptr, dl, sub, gsh);
                         ridx = rval = 0u;
-                        if (nxf <= 16 && sub < uint32_t(nxf)) {
+                        if (nxf <= G && sub < nxf) {
                             const bk_u2 pr = *reinterpret_cast<const bk_u2 *>(dl + 2 * sub);
                             ridx = pr.x;
                             rval = pr.y;
@@ -1770,23 +1818,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
         // ---- pivot of an entered node: argmax over u in P ∪ Xc of |P ∩ N(u)| (tomita.h:12-40); its row is the next step's ----------------
         if (need_pivot) {
             if (mode == M_ENTER) {
-                pc = bkg_sum(__popc(P));
-                first = bkg_first(P, sub);
+                pc = bkg_sum<G>(__popc(P));
+                first = bkg_first<G>(P, sub);
             }
             int best = first;
             bool in_p = true;
-            if (pc > sh.small_p) {
+            if (pc > sh.small_p_groups) {
                 BKG_ST(3, 1);
                 const uint32_t U = P | Xc;
                 const int mine = __popc(U);
-                const int incl = bkg_scan(mine);
-                const int ncand = __shfl(incl, gsh + 15);
-                piv_P[grp][sub] = P;
+                const int incl = bkg_scan<G>(mine, sub);
+                const int ncand = __shfl(incl, gsh + G - 1);
+                my_P[sub] = P;
                 {
                     int at = incl - mine;
                     uint32_t bits = U;
                     while (bits) {
-                        piv_list[grp][at++] = (unsigned short)((sub << 5) + __ffs(bits) - 1);
+                        my_list[at++] = (unsigned short)((sub << 5) + __ffs(bits) - 1);
                         bits &= bits - 1u;
                     }
                 }
@@ -1795,20 +1843,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 int key = -1;
                 const int cw4 = int(cw + 3) >> 2;
-                for (int k = sub; k < ncand; k += 16) {
-                    const int u = int(piv_list[grp][k]);
+                for (int k = sub; k < ncand; k += G) {
+                    const int u = int(my_list[k]);
                     const uint32_t *r = Cadj + size_t(u) * cw;
                     int sc = 0;
                     for (int w4 = 0; w4 < cw4; ++w4) {  // words past cw belong to the next row: P's words there are zero
                         const bk_u4 rw = *reinterpret_cast<const bk_u4 *>(r + 4 * w4);
-                        sc += __popc(piv_P[grp][4 * w4] & rw.x) + __popc(piv_P[grp][4 * w4 + 1] & rw.y) + __popc(piv_P[grp][4 * w4 + 2] & rw.z) +
-                              __popc(piv_P[grp][4 * w4 + 3] & rw.w);
+                        sc += __popc(my_P[4 * w4] & rw.x) + __popc(my_P[4 * w4 + 1] & rw.y) + __popc(my_P[4 * w4 + 2] & rw.z) + __popc(my_P[4 * w4 + 3] & rw.w);
                     }
                     key = max(key, (sc << 16) | (0xffff - u));  // ties -> the smallest index
                 }
-                key = bkg_max(key);
+                key = bkg_max<G>(key);
                 best = 0xffff - (key & 0xffff);
-                in_p = ((piv_P[grp][best >> 5] >> (best & 31)) & 1u) != 0u;
+                in_p = ((my_P[best >> 5] >> (best & 31)) & 1u) != 0u;
                 __builtin_amdgcn_wave_barrier();
             }
             rowreq = uint32_t(best);
@@ -1817,7 +1864,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
         }
         // ---- the next branch vertex of this node, or the way back up ----------------------------------------------------------------------
         if (next) {
-            const int fq = bkg_first(ext, sub);
+#if GMSX_BK_PARENT_REGS
+            {   // a finished node whose parent is in registers: the parent is the current node again, right here (it has a branch left: it was kept)
+                const bool back = has_par && bkg_ballot<G>(ext != 0u, gsh) == 0u;
+                P = back ? pP : P;
+                Xc = back ? pXc : Xc;
+                ext = back ? pext : ext;
+                xfn = back ? pxfn : xfn;
+                ridx = back ? pridx : ridx;
+                rval = back ? prval : rval;
+                depth -= back ? 1u : 0u;
+                has_par = has_par && !back;
+            }
+#endif
+            const int fq = bkg_first<G>(ext, sub);
             if (fq == 0xffff) {
                 if (depth == 0) mode = M_REC;
                 else { --depth; mode = M_POP; }
@@ -1828,9 +1888,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
                     uint32_t *cur = level(depth) + sub * kBkSlot;
                     *reinterpret_cast<uint4 *>(cur) = uint4{P, Xc, ext, uint32_t(xfn)};
                     *reinterpret_cast<uint2 *>(cur + 4) = uint2{ridx, rval};
+                    if (has_par) {
+                        uint32_t *pl = cur - lvl;
+                        *reinterpret_cast<uint4 *>(pl) = uint4{pP, pXc, pext, uint32_t(pxfn)};
+                        *reinterpret_cast<uint2 *>(pl + 4) = uint2{pridx, prval};
+                    }
                     __threadfence();
                     int nrec = 0;
-                    for (uint32_t l = 0; l <= depth; ++l) nrec += min(bkg_sum(__popc(level(l)[sub * kBkSlot + 2])), kBkSplit);
+                    for (uint32_t l = 0; l <= depth; ++l) nrec += min(bkg_sum<G>(__popc(level(l)[sub * kBkSlot + 2])), kBkSplit);
                     const unsigned long long rec_words = (unsigned long long)(kRecHeader + 3 * cw + xw);
                     unsigned long long p0 = 0, d0 = sh.dir_cap;
                     if (sub == 0) {
@@ -1860,12 +1925,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
                             const int ln = int(ls[3]);
                             const uint32_t lidx = ls[4], lval = ls[5];
                             const int mine = __popc(e);
-                            const int incl = bkg_scan(mine);
-                            const int nb = __shfl(incl, gsh + 15);
+                            const int incl = bkg_scan<G>(mine, sub);
+                            const int nb = __shfl(incl, gsh + G - 1);
                             if (nb == 0) continue;
                             const int rank0 = incl - mine;  // rank of this word's first pending branch
                             const int parts = min(nb, kBkSplit);
-                            const bool in_regs = ln >= 0 && ln <= 16;  // the level's Xf: empty or a register list (saved in the slot) — else in memory
+                            const bool in_regs = ln >= 0 && ln <= G;  // the level's Xf: empty or a register list (saved in the slot) — else in memory
                             const uint32_t *src = xf_src(l);            // (memory form at level 0: the Xf of the record this search came from)
                             for (int j = 0; j < parts; ++j) {
                                 const int a = int((long long)nb * j / parts), b = int((long long)nb * (j + 1) / parts);  // ranks [a, b) of the pending branches
@@ -1875,18 +1940,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
                                 uint32_t *ox = out + kRecHeader + 3 * cw;
                                 if (ln < 0) {  // the dense words of level 0
                                     o3 = 1u;
-                                    for (uint32_t w = sub; w < xw; w += 16) ox[w] = src[w];
+                                    for (uint32_t w = sub; w < xw; w += G) ox[w] = src[w];
                                 } else if (ln > 0) {
                                     o3 = 1u;
                                     if (2u * uint32_t(ln) <= xw) {
                                         o7 = uint32_t(ln);
-                                        if (in_regs) { if (sub < uint32_t(ln)) *reinterpret_cast<bk_u2 *>(ox + 2 * sub) = bk_u2{lidx, lval}; }
-                                        else for (uint32_t i = sub; i < 2u * uint32_t(ln); i += 16) ox[i] = src[i];
+                                        if (in_regs) { if (sub < ln) *reinterpret_cast<bk_u2 *>(ox + 2 * sub) = bk_u2{lidx, lval}; }
+                                        else for (uint32_t i = sub; i < 2u * uint32_t(ln); i += G) ox[i] = src[i];
                                     } else {
-                                        for (uint32_t w = sub; w < xw; w += 16) ox[w] = 0u;
+                                        for (uint32_t w = sub; w < xw; w += G) ox[w] = 0u;
                                         __threadfence();
-                                        if (in_regs) { if (sub < uint32_t(ln)) ox[lidx] = lval; }
-                                        else for (uint32_t i = sub; i < uint32_t(ln); i += 16) ox[src[2 * i]] = src[2 * i + 1];
+                                        if (in_regs) { if (sub < ln) ox[lidx] = lval; }
+                                        else for (uint32_t i = sub; i < uint32_t(ln); i += G) ox[src[2 * i]] = src[2 * i + 1];
                                     }
                                 }
                                 if (sub == 0) {
@@ -1900,7 +1965,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
                                     out[7] = o7;
                                     sh.dir[d0 + r] = p0 + rec_words * r;
                                 }
-                                if (sub < cw) {
+                                if (uint32_t(sub) < cw) {
                                     const uint32_t before = lowest(e, a - rank0);        // branches of the runs in front of this one
                                     const uint32_t run = lowest(e, b - rank0) & ~before;  // this run
                                     out[kRecHeader + sub] = lP & ~before;                 // P
@@ -1912,7 +1977,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
                         }
                         if (sub == 0) {
                             atomicMax(sh.max_stack, (unsigned long long)(c + 1) * (unsigned long long)(3 * cw + xw + 1));
-                            atomicMax(sh.max_stack + 1, bk_group_slab_words(c, xw));
+                            atomicMax(sh.max_stack + 1 + bk_group_class(c), bk_group_slab_words(c, xw));
                         }
                         split = true;
                     }
@@ -1926,9 +1991,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
             }
         }
     }
-    if (sub == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
+    if (sub == 0) cnt_out += cnt;
+}
+
+#ifndef GMSX_BK_GROUP_WAVES
+#define GMSX_BK_GROUP_WAVES 4  // 3 (168 VGPRs): 191-202 ms on configs[3], 5 (102, spills in the step): 265
+#endif
+// every wave drains the queues of all classes one after the other (odd workgroups the widest class first), so that no wave idles while any class has records
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROUP_WAVES))) void k_bk_resume4(
+    const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in, unsigned long long n_records, unsigned long long *__restrict__ queues /* [3] */,
+    unsigned grab, uint32_t *__restrict__ slabs, unsigned long long wave_slab_words, unsigned long long slab16, unsigned long long slab8, unsigned long long slab4,
+    unsigned long long *__restrict__ acc, BkShared sh) {
+    __shared__ unsigned short piv_list[2048];
+    __shared__ uint32_t piv_P[64];
+    uint32_t *const wave_slab = slabs + size_t(blockIdx.x) * wave_slab_words;
+    unsigned long long cnt = 0;
 #ifdef GMSX_BK_STATS
-    if (lane == 0)
+    // profiling build: [0] trips of the wave loop, [1] trips in which a group fetched, [2] with a memory walk of Xf, [3] with pivot scoring; group steps in
+    // [4] PIVOT [5] PIVOTB [6] BRANCH [7] CHILD1 [8] POP, [9] idle (DONE) group-trips, [10] pushes, [11] of them without a kept level (lane 0's groups only)
+    unsigned long long st_[12] = {};
+#else
+    unsigned long long *st_ = nullptr;
+#endif
+    (void)slab4;
+    const bool wide_first = (blockIdx.x & 1) != 0;
+    if (wide_first) bk_group_searches<16>(pool_in, dir_in, n_records, queues + 0, grab, wave_slab, slab16, sh, piv_list, piv_P, cnt, st_);
+#if GMSX_BK_GROUP_MIN <= 4
+    bk_group_searches<4>(pool_in, dir_in, n_records, queues + 2, grab, wave_slab, slab4, sh, piv_list, piv_P, cnt, st_);
+#endif
+#if GMSX_BK_GROUP_MIN <= 8
+    bk_group_searches<8>(pool_in, dir_in, n_records, queues + 1, grab, wave_slab, slab8, sh, piv_list, piv_P, cnt, st_);
+#endif
+    if (!wide_first) bk_group_searches<16>(pool_in, dir_in, n_records, queues + 0, grab, wave_slab, slab16, sh, piv_list, piv_P, cnt, st_);
+    if (cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
+#ifdef GMSX_BK_STATS
+    if (threadIdx.x == 0)
         for (int i = 0; i < 12; ++i) atomicAdd(&g_bkg_stat[i], st_[i]);
 #endif
 }
@@ -1944,10 +2041,12 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     const int64_t n = g->n;
     struct Guard { void *p = nullptr; ~Guard() { (void)hipFree(p); } } g_acc, g_ki, g_ko, g_vi, g_vo, g_tmp, g_arena, g_pool0, g_pool1, g_dir0, g_dir1;
     unsigned long long *acc = nullptr;
-    constexpr int kCtl = 64 * 16;  // control words after the 64 spread accumulators
-    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), sizeof(unsigned long long) * (kCtl + 16)));
+    // control words after the 64 spread accumulators: [0] isolated vertices [1] giant tasks [2] queue [3] arena head [4] pool head [5] directory count
+    // [6] stack words of k_bk_resume [7..9] slab words of a 16- / 8- / 4-lane search [10] build queue [11] LDS-task queue [12..14] k_bk_resume4's queues [16..20] layout maxima
+    constexpr int kCtl = 64 * 16;
+    GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&acc), sizeof(unsigned long long) * (kCtl + 32)));
     g_acc.p = acc;
-    GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * (kCtl + 16), s));
+    GMSX_HIP(hipMemsetAsync(acc, 0, sizeof(unsigned long long) * (kCtl + 32), s));
     if (n == 0) {
         *out = 0;
         if (st) *st = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
@@ -1993,7 +2092,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     const int widest = std::min(g->max_dplus, max_c);  // candidates of a start vertex = its d+
     const int wpl_wide = widest <= 4096 ? 2 : widest <= 8192 ? 4 : 8;
     for (int64_t i = 0; i < n_wide; ++i) words[size_t(i)] &= ~kWideTask;
-    GMSX_HIP(hipMemsetAsync(acc + kCtl + 7, 0, 8, s));  // from here on the slot behind max_stack: the slab need of k_bk_resume4's records
+    GMSX_HIP(hipMemsetAsync(acc + kCtl + 7, 0, 8, s));  // ([7] held the number of wide tasks until here)
 
     // ---- arena + record pools of the load balancer
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
@@ -2024,7 +2123,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&pools[1]), sh.pool_cap * 4 + 64)); g_pool1.p = pools[1];
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dirs[0]), sh.dir_cap * 8)); g_dir0.p = dirs[0];
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dirs[1]), sh.dir_cap * 8)); g_dir1.p = dirs[1];
-    unsigned long long *queue = acc + kCtl + 2, *gqueue = acc + kCtl + 13;  // tickets of k_bk_resume / k_bk_resume4
+    unsigned long long *queue = acc + kCtl + 2, *gqueue = acc + kCtl + 12;  // tickets of k_bk_resume / k_bk_resume4
     sh.arena_head = acc + kCtl + 3;
     sh.pool_head = acc + kCtl + 4;
     sh.dir_count = acc + kCtl + 5;
@@ -2034,6 +2133,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     // 275.9 -> 260.1 ms at 2048, the sparse graphs (one round) are indifferent
     sh.budget = 2048;
     sh.small_p = [] { const char *e = std::getenv("GMSX_BK_SMALL_P"); return e ? std::atoi(e) : 6; }();  // swept on the configs[3] graph: 0 (off) 316 ms, 2 304, 3 ~300, 4 295, 6 293, 8 295, 16 303
+    sh.small_p_groups = [] { const char *e = std::getenv("GMSX_BK_SMALL_P_GROUPS"); return e ? std::atoi(e) : 12; }();
     sh.bmoff = g->bmoff;
     sh.bmpool = g->bmpool;
     sh.dense_limit = g->dense_limit;
@@ -2066,8 +2166,8 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     int64_t *need_a = nullptr, *need_r = nullptr, *aoff = nullptr, *roff = nullptr, *d_end = nullptr, *need_p = nullptr, *poff = nullptr;
     unsigned long long *pieces = nullptr;
     Guard g_na, g_nr, g_ao, g_ro, g_de, g_map, g_np, g_po, g_pc;
-    unsigned long long *maxima = acc + kCtl + 9;  // [0] stack words, [1] global map words
-    unsigned long long mx[4] = {0, 0, 0, 0}, map_words = 0;  // [0] stack words of k_bk_resume, [1] global map words, [3] slab words of a 16-lane search
+    unsigned long long *maxima = acc + kCtl + 16;  // [0] stack words, [1] global map words, [2..4] slab words of a 16- / 8- / 4-lane search
+    unsigned long long mx[5] = {0, 0, 0, 0, 0}, map_words = 0;  // [0] stack words of k_bk_resume, [1] global map words, [2..4] slab words of a 16- / 8- / 4-lane search
     int64_t build_waves = 0;
     uint32_t *map_scratch = nullptr;
     if (cnt_glob > 0) {
@@ -2078,7 +2178,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&d_end), 8)); g_de.p = d_end;
         GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&need_p), size_t(cnt_glob + 1) * 8)); g_np.p = need_p;
         GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&poff), size_t(cnt_glob + 1) * 8)); g_po.p = poff;
-        GMSX_HIP(hipMemsetAsync(maxima, 0, 16, s));
+        GMSX_HIP(hipMemsetAsync(maxima, 0, 40, s));
         hipLaunchKernelGGL(k_bk_layout, dim3(unsigned(cnt_glob / 256 + 1)), dim3(256), 0, s, int64_t(0), cnt_glob, nparts, part, v_out, g->off, g->oldid, g->dplus,
                            split_build >= 2 ? 1 : 0, need_a, need_r, need_p, maxima);
         {
@@ -2127,8 +2227,12 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         }
     }
     const int group_waves_per_cu = 4 * GMSX_BK_GROUP_WAVES;
-    if (cnt_glob > 0 && mx[3] > 0 && use_groups) {
-        const unsigned long long slab_bytes = ((mx[3] + 3ull) & ~3ull) * 4ull * 4ull;  // four searches per wave
+    // words of a wave's slab area in k_bk_resume4: 4 searches of 16 lanes, 8 of 8 or 16 of 4, whichever class needs most
+    auto group_wave_words = [](unsigned long long w16, unsigned long long w8, unsigned long long w4) {
+        return std::max({4ull * ((w16 + 3ull) & ~3ull), 8ull * ((w8 + 3ull) & ~3ull), 16ull * ((w4 + 3ull) & ~3ull)});
+    };
+    if (cnt_glob > 0 && (mx[2] | mx[3] | mx[4]) != 0 && use_groups) {
+        const unsigned long long slab_bytes = group_wave_words(mx[2], mx[3], mx[4]) * 4ull;
         if (slab_bytes <= budget_bytes) {
             const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({(cnt_glob + 3) / 4, int64_t(cu) * group_waves_per_cu, int64_t(budget_bytes / slab_bytes)}));
             group_cap = size_t(waves) * slab_bytes;
@@ -2146,21 +2250,21 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     int rounds = 0;
     auto run_rounds = [&]() -> int {
     while (true) {
-        unsigned long long ctl[4] = {0, 0, 0, 0};  // pool_head, dir_count, max_stack, slab words of a 16-lane search
-        GMSX_HIP(hipMemcpyAsync(ctl, sh.pool_head, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        unsigned long long ctl[6] = {0, 0, 0, 0, 0, 0};  // pool_head, dir_count, max_stack, slab words of a 16- / 8- / 4-lane search
+        GMSX_HIP(hipMemcpyAsync(ctl, sh.pool_head, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         GMSX_HIP(hipStreamSynchronize(s));
         // a wave whose allocation overshot a capacity kept its search: only fully written records are below the caps
         const unsigned long long n_rec = std::min(ctl[1], sh.dir_cap);
         if (n_rec == 0) break;
-        const unsigned long long stack_w = (ctl[2] + 3ull) & ~3ull, group_w = (ctl[3] + 3ull) & ~3ull;
+        const unsigned long long stack_w = (ctl[2] + 3ull) & ~3ull, group_w = group_wave_words(ctl[3], ctl[4], ctl[5]);
         const uint32_t *pool_in = pools[cur];
         const unsigned long long *dir_in = dirs[cur];
         cur ^= 1;
         sh.pool = pools[cur];
         sh.dir = dirs[cur];
         GMSX_HIP(hipMemsetAsync(queue, 0, 8, s));
-        GMSX_HIP(hipMemsetAsync(gqueue, 0, 8, s));
-        GMSX_HIP(hipMemsetAsync(sh.pool_head, 0, 4 * sizeof(unsigned long long), s));
+        GMSX_HIP(hipMemsetAsync(gqueue, 0, 24, s));
+        GMSX_HIP(hipMemsetAsync(sh.pool_head, 0, 6 * sizeof(unsigned long long), s));
         GMSX_HIP(hipMemsetAsync(sh.dir, 0xff, sh.dir_cap * 8, s));
         // few records left: split sooner so that the idle waves get work (the tail rounds are latency-, not throughput-bound)
         const int64_t full = int64_t(cu) * 24 * 2;
@@ -2168,7 +2272,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         // records per queue ticket (GMSX_BK_RESUME_GRAB, default 1: eight cost 4 ms on configs[3] — the records of a round differ in cost, their queue is not the limit)
         const unsigned grab = unsigned(std::max<int64_t>(1, std::min<int64_t>(resume_grab, int64_t(n_rec) / (int64_t(cu) * 24 * 16))));
         if (use_groups && group_w > 0) {  // records with at most 512 candidates: four searches per wave
-            const unsigned long long slab_bytes = group_w * 4ull * 4ull;
+            const unsigned long long slab_bytes = group_w * 4ull;
             if (slab_bytes > budget_bytes) return GMSX_ERR_DEVICE_MEM;
             const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({int64_t((n_rec + 3) / 4), int64_t(cu) * group_waves_per_cu, int64_t(budget_bytes / slab_bytes)}));
             if (size_t(waves) * slab_bytes > group_cap) {  // grow-only, reused by every round
@@ -2178,10 +2282,10 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 GMSX_HIP(hipMalloc(&g_gslab.p, group_cap));
             }
             if (std::getenv("GMSX_BK_VERBOSE"))
-                std::fprintf(stderr, "[gmsx bk] round %d: %llu records (%llu pool words), %lld waves of four searches, %llu slab words each, budget %u\n", rounds + 1,
+                std::fprintf(stderr, "[gmsx bk] round %d: %llu records (%llu pool words), %lld waves of 4 / 8 / 16 searches, %llu slab words each, budget %u\n", rounds + 1,
                              n_rec, ctl[0], (long long)waves, group_w, sh.budget);
-            hipLaunchKernelGGL(k_bk_resume4, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, gqueue, grab, static_cast<uint32_t *>(g_gslab.p), group_w, acc,
-                               sh);
+            hipLaunchKernelGGL(k_bk_resume4, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, gqueue, grab, static_cast<uint32_t *>(g_gslab.p), group_w,
+                               (ctl[3] + 3ull) & ~3ull, (ctl[4] + 3ull) & ~3ull, (ctl[5] + 3ull) & ~3ull, acc, sh);
             ++launches;
         }
         if (!use_groups || widest > kBkGroupMaxC) {  // the others (every record with GMSX_BK_GROUPS=0): one search per wave
@@ -2260,7 +2364,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     if (split_build) {
         bool tiny_done = false;
         if (cnt_glob > 0) {
-            unsigned long long *bqueue = acc + kCtl + 8;
+            unsigned long long *bqueue = acc + kCtl + 10;
             // the roots may take at most 3/4 of the arena and half of the pool: searches of the LDS-slab tasks that split need room too
             const int64_t a_cap = int64_t(sh.arena_cap / 4 * 3), r_cap = int64_t(sh.pool_cap / 2), max_tasks = int64_t(sh.dir_cap / 2);
             for (int64_t q0 = 0; q0 < cnt_glob;) {
@@ -2274,7 +2378,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 GMSX_HIP(hipMemcpy(&span[3], roff + q1, 8, hipMemcpyDeviceToHost));
                 if (uint64_t(span[1] - span[0]) > sh.arena_cap || uint64_t(span[3] - span[2]) > sh.pool_cap) return GMSX_ERR_DEVICE_MEM;  // one start vertex beyond the arena
                 // pool_head / dir_count / max_stack as if the roots had been split off by an earlier round; arena_head behind their structures
-                const unsigned long long ctl0[4] = {(unsigned long long)(span[3] - span[2]), (unsigned long long)(q1 - q0), mx[0], mx[3]};
+                const unsigned long long ctl0[6] = {(unsigned long long)(span[3] - span[2]), (unsigned long long)(q1 - q0), mx[0], mx[2], mx[3], mx[4]};
                 const unsigned long long ah = (unsigned long long)(span[1] - span[0]);
                 GMSX_HIP(hipMemcpyAsync(sh.pool_head, ctl0, sizeof(ctl0), hipMemcpyHostToDevice, s));
                 GMSX_HIP(hipMemcpyAsync(sh.arena_head, &ah, 8, hipMemcpyHostToDevice, s));
@@ -2305,7 +2409,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 sh.pool = pools[cur];
                 sh.dir = dirs[cur];
                 GMSX_HIP(hipMemsetAsync(sh.dir, 0xff, sh.dir_cap * 8, s));
-                GMSX_HIP(hipMemsetAsync(sh.pool_head, 0, 4 * sizeof(unsigned long long), s));
+                GMSX_HIP(hipMemsetAsync(sh.pool_head, 0, 6 * sizeof(unsigned long long), s));
                 GMSX_HIP(hipMemsetAsync(sh.arena_head, 0, 8, s));
                 q0 = q1;
             }
@@ -2398,7 +2502,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     }
     GMSX_HIP(hipEventRecord(c.ev[2], s));
     GMSX_HIP(hipGetLastError());
-    unsigned long long host[kCtl + 16];
+    unsigned long long host[kCtl + 32];
     GMSX_HIP(hipMemcpyAsync(host, acc, sizeof(host), hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     unsigned long long total = 0;
