@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <new>
 #include <vector>
 
@@ -2248,8 +2249,15 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     int launches = 0;
     // ---- rounds >= 1: resume the split searches (and search the root records of k_bk_build) until no record is left
     int rounds = 0;
+    // GMSX_BK_TINY_BESIDE=2: the LDS-slab tasks run beside the FIRST RESUME ROUND (what they split off joins that round's output) instead of beside the
+    // build: hooks called around the launch of a round's kernels, and before the next round reads the counters
+    std::function<int()> round_pre, round_post, round_join;
     auto run_rounds = [&]() -> int {
     while (true) {
+        if (round_join) {
+            if (int rc = round_join()) return rc;
+            round_join = nullptr;
+        }
         unsigned long long ctl[6] = {0, 0, 0, 0, 0, 0};  // pool_head, dir_count, max_stack, slab words of a 16- / 8- / 4-lane search
         GMSX_HIP(hipMemcpyAsync(ctl, sh.pool_head, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         GMSX_HIP(hipStreamSynchronize(s));
@@ -2271,6 +2279,10 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         sh.budget = int64_t(n_rec) >= full ? budget_resume : unsigned(std::max<int64_t>(128, int64_t(budget_resume) * int64_t(n_rec) / full));
         // records per queue ticket (GMSX_BK_RESUME_GRAB, default 1: eight cost 4 ms on configs[3] — the records of a round differ in cost, their queue is not the limit)
         const unsigned grab = unsigned(std::max<int64_t>(1, std::min<int64_t>(resume_grab, int64_t(n_rec) / (int64_t(cu) * 24 * 16))));
+        if (round_pre) {
+            if (int rc = round_pre()) return rc;
+            round_pre = nullptr;
+        }
         if (use_groups && group_w > 0) {  // records with at most 512 candidates: four searches per wave
             const unsigned long long slab_bytes = group_w * 4ull;
             if (slab_bytes > budget_bytes) return GMSX_ERR_DEVICE_MEM;
@@ -2315,6 +2327,10 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 hipLaunchKernelGGL(k_bk_resume<1>, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, queue, grab,
                                    static_cast<uint32_t *>(g_rslab.p), stack_w, acc, sh, min_c);
             ++launches;
+        }
+        if (round_post) {
+            if (int rc = round_post()) return rc;
+            round_post = nullptr;
         }
         if (++rounds > 100000) return GMSX_ERR_KERNEL;
     }
@@ -2391,8 +2407,25 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 }
                 GMSX_HIP(hipStreamSynchronize(s));  // ctl0 / ah / pspan are stack variables
                 if (!tiny_done) {  // the LDS-slab tasks run beside the first chunk's build; what they split off joins its records
-                    static const bool beside = [] { const char *e = std::getenv("GMSX_BK_TINY_BESIDE"); return !e || std::atoi(e) != 0; }();  // 0: one after the other (profiling)
-                    if (int rc = launch_tiny(n_glob, n_tasks, beside)) return rc;
+                    static const int beside = [] { const char *e = std::getenv("GMSX_BK_TINY_BESIDE"); return e ? std::atoi(e) : 1; }();  // 0: one after the other (profiling)
+                    if (beside == 2 && c.side[0] && c.ev_fork && c.ev_join[0] && part_count(n_glob, n_tasks, nparts, part) > 0) {
+                        round_pre = [&]() -> int {
+                            GMSX_HIP(hipMemsetAsync(tqueue, 0, 8, s));
+                            GMSX_HIP(hipEventRecord(c.ev_fork, s));
+                            return GMSX_OK;
+                        };
+                        round_post = [&]() -> int {
+                            const int64_t cnt = part_count(n_glob, n_tasks, nparts, part);
+                            GMSX_HIP(hipStreamWaitEvent(c.side[0], c.ev_fork, 0));
+                            const int64_t waves = std::min<int64_t>(cnt, int64_t(cu) * 16);
+                            hipLaunchKernelGGL((k_bk_wave<true, 1>), dim3(unsigned(waves)), dim3(64), 0, c.side[0], g->off, g->adj, g->newid, g->oldid, g->hoff, g->hadj, g->toff,
+                                               g->tadj, g->dplus, v_out, n_glob, n_tasks, nparts, part, tqueue, static_cast<uint32_t *>(nullptr), 0ull, acc, sh);
+                            ++launches;
+                            tiny_beside = true;
+                            round_join = [&]() -> int { return join_tiny(); };
+                            return GMSX_OK;
+                        };
+                    } else if (int rc = launch_tiny(n_glob, n_tasks, beside != 0)) return rc;
                     tiny_done = true;
                 }
                 if (split_build >= 2)

@@ -205,3 +205,51 @@ def test_bk_tiny_budget_splits_everything(gpu, oracle, budget):
                 os.environ.pop(k_, None)
             else:
                 os.environ[k_] = v
+
+
+@pytest.mark.parametrize("knobs", [{"GMSX_BK_GROUPS": "0"}, {"GMSX_BK_TINY_BESIDE": "2"}, {"GMSX_BK_SMALL_P_GROUPS": "0"},
+                                   {"GMSX_BK_SMALL_P_GROUPS": "600"}, {"GMSX_BK_BUDGET": "40", "GMSX_BK_BUDGET0": "40", "GMSX_BK_SMALL_P_GROUPS": "0"},
+                                   {"GMSX_BK_BUDGET": "24", "GMSX_BK_BUDGET0": "24", "GMSX_BK_GROUPS": "0"}])
+def test_bk_search_kernel_variants(gpu, oracle, knobs):
+    """Round 5: records with at most 512 candidates are searched four to a wave (k_bk_resume4: 16-lane groups, Xf below level 0 as a list of
+    non-zero words — in registers up to 16 pairs, in memory beyond —, the pivot's row doubling as the first branch row, levels kept in
+    registers / not kept at all when no branch is left).  The knobs switch it off (every record on k_bk_resume), move the LDS-slab tasks
+    beside the first resume round, force / forbid pivot scoring, and split every search after a few dozen nodes (records written from
+    every level in list and in dense form).  Same counts as the oracle on: an R-MAT graph, a dense block (deep searches), a late hub with
+    thousands of in-neighbours (Xf far longer than 16 words at level 0, lists in memory below), and K_{4,4,4,4,4,4}."""
+    old = {k: os.environ.get(k) for k in knobs}
+    os.environ.update(knobs)
+    try:
+        rng = np.random.default_rng(11)
+        graphs = [host_graph(gpu, "kronecker", 11, 16, True)]
+        k = 200
+        iu = np.triu_indices(k, 1)
+        sel = rng.random(iu[0].size) < 0.5
+        graphs.append(gpu.HostCSR.from_edges(iu[0][sel].astype(np.int32), iu[1][sel].astype(np.int32)))
+        # a clique-rich core of 120 vertices + a hub adjacent to the whole core and to 6000 leaves, each leaf adjacent to a few core vertices:
+        # the hub comes late in the degree order of its core neighbours' searches, its in-neighbours fill hundreds of Xf words
+        core = 120
+        cu, cv = np.triu_indices(core, 1)
+        keep = rng.random(cu.size) < 0.6
+        hub = core
+        leaves = np.arange(core + 1, core + 1 + 6000, dtype=np.int32)
+        lu = np.repeat(leaves, 3)
+        lv = rng.integers(0, core, lu.size).astype(np.int32)
+        src = np.concatenate([cu[keep].astype(np.int32), np.full(core, hub, np.int32), np.full(leaves.size, hub, np.int32), lu])
+        dst = np.concatenate([cv[keep].astype(np.int32), np.arange(core, dtype=np.int32), leaves, lv])
+        graphs.append(gpu.HostCSR.from_edges(src, dst))
+        parts = [range(4 * i, 4 * i + 4) for i in range(6)]
+        edges = [(a, b) for i, pa in enumerate(parts) for pb in parts[i + 1:] for a in pa for b in pb]
+        graphs.append(gpu.HostCSR.from_edges(np.array([e[0] for e in edges], np.int32), np.array([e[1] for e in edges], np.int32)))
+        for i, csr in enumerate(graphs):
+            want = oracle.bk_count(csr.offsets(), csr.neighbors())
+            g = gpu.DeviceGraph.from_csr(csr)
+            assert g.bk_count() == want, (i, knobs)
+            assert sum(g.bk_partial(p, 2) for p in range(2)) == want, (i, knobs)
+            g.free()
+    finally:
+        for k_, v in old.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
