@@ -20,9 +20,11 @@ Par::count_total (triangle_count/parallel/total.h:7-24).  The graph is resident 
 Rank 0 prints ONE JSON line.
 
 Roofline record (all per launch = one rank's pass):
-  achieved / frac   MEASURED traffic beyond the L2 (rocprofv3 PMC: 2*FETCH_SIZE + WRITE_SIZE, separate passes, collected in
-                    this very run by short child processes BEFORE the parent touches the GPU) / kernel time / 8 TB/s.
-                    FETCH_SIZE counts L2 misses including Infinity-Cache hits, so this is beyond-L2 (MALL + HBM) bandwidth.
+  achieved / frac   MEASURED traffic beyond the L2 (rocprofv3 PMC, separate passes, collected in this very run by short child processes
+                    BEFORE the parent touches the GPU) / kernel time / 8 TB/s.  Reads = the L2's memory-side requests by size class,
+                    32 n32 + 64 n64 + 128 n128 (TCC_EA0_RDREQ_{32B,64B,128B}_sum); FETCH_SIZE — every request tallied at 64 B — is collected
+                    too and the ratio reported as `fetch_multiplier` (2.00 for these kernels: > 99 % of their requests are 128-byte ones);
+                    writes = WRITE_SIZE.  The requests include Infinity-Cache hits, so this is beyond-L2 (MALL + HBM) bandwidth.
   algorithmic_bytes device-computed bytes of THIS formulation (oriented rows in the container form the kernels read, no
                     on-chip reuse assumed: gmsx_stats.stream_bytes); work_efficiency = traffic / algorithmic_bytes.
   reference_equivalent_GBps   B_alg / t with SURVEY §8(d)'s B_alg = 4*Σ(d_u+d_v) + 8(n+1) + 4*nnz — what the reference's
@@ -267,8 +269,13 @@ def side_workload(capi, args, name, traffic, rank):
     trec = (traffic or {}).get("n1")
     if trec and "bytes" in trec:
         ach = trec["bytes"] / (best * 1e-3) / 1e9
+        alg = int(st.get("stream_bytes") or 0)
         out["roofline"] = {"bound": "hbm", "traffic": trec["bytes"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic_source": "rocprofv3 --pmc child passes of this run (2*FETCH_SIZE + WRITE_SIZE, separate passes, one call)",
+                           "algorithmic_bytes": alg or None, "algorithmic_GBps": (alg / (best * 1e-3) / 1e9) if alg else None,
+                           "work_efficiency_traffic_over_algorithmic": (trec["bytes"] / alg) if alg else None,
+                           "algorithmic_bytes_are": ALG_BYTES_ARE[name],
+                           "fetch_multiplier": trec.get("fetch_multiplier"), "multiplier_source": trec.get("multiplier_source"),
+                           "traffic_source": "rocprofv3 --pmc child passes of this run (memory-side read requests by size class + WRITE_SIZE, separate passes, one call)",
                            "memory_level": "beyond-L2 (Infinity Cache + HBM)", "kernel_ms_under_pmc": trec.get("kernel_ms_under_pmc"),
                            "kernel_hash": kernel_hash(name),
                            "per_kernel": {k: {"dispatches": v.get("dispatches"), "bytes": v.get("bytes")} for k, v in trec["kernels"].items()},
@@ -292,6 +299,16 @@ WORKLOADS = {
                 label="k=4 clique counting, RMAT scale-22 ef=16 (BASELINE.json configs[2])"),
     "bk": dict(key="config3_bk", gen=("rmat", 21, 56, 0.45, 0.22, 0.22), golden_key="rmat-21-56-a45-b22-c22", golden_field="bk", kernels="k_bk_",
                label="Bron-Kerbosch maximal cliques, com-Orkut-shaped RMAT scale-21 ef=56 A=.45 B=C=.22, |E|=117M (BASELINE.json configs[3])"),
+}
+
+
+# gmsx_stats.stream_bytes of the two side workloads (include/gmsx.h): computed on the device for the call, no cache assumed
+ALG_BYTES_ARE = {
+    "kc4": "per pivot (d+ >= 3) its own containers once + per member v the containers of N+(v) the BUILD reads (bitset words or 16-bit list, tail ids; one "
+           "4-byte gather per pair for d+ <= 32) + the slab matrices of pivots wider than 1024, written and read once; the COUNT runs on the bit-matrix in LDS",
+    "bk": "per start vertex the oriented rows of all its neighbours (what the builds walk: candidates -> Cadj, in-neighbours -> XT) + Cadj | XT of the start "
+          "vertices built in the arena, once + one Cadj row (c/32 words) per search-tree node — the operand of cand.intersect(N(q)) (tomita.h:51-70); the Xf / XT "
+          "words a node reads and the saved levels are not counted",
 }
 
 
@@ -406,11 +423,16 @@ def run_pmc_pass(args, counters, timeout, workload="tc"):
         shutil.rmtree(out, ignore_errors=True)
 
 
+RDREQ = ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]
+
+
 def measure_traffic(args, rank, workload="tc"):
     """Separate PMC passes (FETCH_SIZE needs 3 of the 4 TCC slots, WRITE_SIZE 2: never in one pass; never combined with tracing).
     Returns {"n1": {...}, "n2": …} or (None, reason)."""
     table, notes = {}, []
-    passes = (["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]) if workload == "tc" else (["FETCH_SIZE"], ["WRITE_SIZE"])
+    # the memory-side read requests of the L2 by SIZE CLASS: FETCH_SIZE tallies every request at 64 B (MI355X_MICROARCH.md "HBM": exactly half the bytes of a
+    # 16-byte-per-lane stream; "other access widths are uncalibrated") — 32 n32 + 64 n64 + 128 n128 is the byte count itself, per kernel, whatever the widths
+    passes = (RDREQ, ["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]) if workload == "tc" else (RDREQ, ["FETCH_SIZE"], ["WRITE_SIZE"])
     for counters in passes:
         t0 = time.perf_counter()
         res, err = run_pmc_pass(args, counters, timeout=args.pmc_timeout, workload=workload)
@@ -419,7 +441,7 @@ def measure_traffic(args, rank, workload="tc"):
             notes.append(f"{counters}: {err}")
             if counters[0] in ("FETCH_SIZE", "WRITE_SIZE"):
                 return None, "; ".join(notes)
-            continue
+            continue  # (without the size classes the guide's x2 stands in, and the record says so)
         for key, rec in res.items():
             t = table.setdefault(key, {"kernels": {}, "stream_bytes": rec["stream_bytes"]})
             t.update(rec["counters"])
@@ -429,13 +451,25 @@ def measure_traffic(args, rank, workload="tc"):
                 t["result"] = rec["result"]
             for k, c in rec["kernels"].items():
                 t["kernels"].setdefault(k, {}).update(c)
+    def read_bytes(rec):
+        """(bytes, multiplier on FETCH_SIZE, where it comes from) of one record holding FETCH_SIZE (KB) and, if the pass ran, the request size classes"""
+        n, n32, n64, n128 = (rec.get(c) for c in RDREQ)
+        fetch = rec["FETCH_SIZE"] * 1024.0
+        if n and n32 is not None and abs((n32 + n64 + n128) - n) <= 1e-3 * n + 8:
+            b = 32.0 * n32 + 64.0 * n64 + 128.0 * n128
+            return b, (b / fetch if fetch > 0 else None), ("TCC_EA0_RDREQ_{32B,64B,128B}_sum of this run: %.2f %% of the requests are 128-byte ones"
+                                                          % (100.0 * n128 / n))
+        return 2.0 * fetch, 2.0, "MI355X_MICROARCH.md: FETCH_SIZE tallies 128-byte requests at 64 (x2 for 16-byte-per-lane streams); size classes not collected"
     for key, t in table.items():
-        # FETCH_SIZE / WRITE_SIZE are reported in KB; gfx950 tallies the 128-B requests of 16-B-per-lane streaming loads at 64 B
-        # (MI355X_MICROARCH.md "HBM"): double the fetch figure.
-        t["bytes"] = (2.0 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024.0
+        # FETCH_SIZE / WRITE_SIZE are reported in KB
+        rb, mult, src = read_bytes(t)
+        t["read_bytes"], t["fetch_multiplier"], t["multiplier_source"] = rb, mult, src
+        t["bytes"] = rb + t["WRITE_SIZE"] * 1024.0
         for k in t["kernels"].values():
             if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
-                k["bytes"] = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+                kb, km, _ = read_bytes(k)
+                k["bytes"] = kb + k["WRITE_SIZE"] * 1024.0
+                k["fetch_multiplier"] = km
         if "TCC_HIT_sum" in t and t["TCC_HIT_sum"] + t.get("TCC_MISS_sum", 0) > 0:
             t["l2_hit_rate"] = t["TCC_HIT_sum"] / (t["TCC_HIT_sum"] + t["TCC_MISS_sum"])
     return table, "; ".join(notes) if notes else None
@@ -513,14 +547,14 @@ def main():
     if rank == 0 and world == 1 and args.pmc and os.path.exists(sg):
         traffic_table, traffic_note = measure_traffic(args, rank)
         if traffic_table:
-            traffic_source = "rocprofv3 --pmc child passes of this run (2*FETCH_SIZE + WRITE_SIZE, separate passes)"
+            traffic_source = "rocprofv3 --pmc child passes of this run (memory-side read requests by size class + WRITE_SIZE, separate passes)"
             if args.dump_traffic:
                 try:
                     with open(args.dump_traffic) as f:
                         doc = json.load(f)
                 except (OSError, ValueError):
                     doc = {}
-                doc["_comment"] = ("beyond-L2 bytes per launch of the triangle-count pass, (2*FETCH_SIZE + WRITE_SIZE) KB from separate rocprofv3 --pmc "
+                doc["_comment"] = ("beyond-L2 bytes per launch of the triangle-count pass, memory-side read requests by size class (32 n32 + 64 n64 + 128 n128) + WRITE_SIZE from separate rocprofv3 --pmc "
                                    "passes (bench.py --dump-traffic), keyed by the hash of the kernel sources they were measured on (bench.kernel_hash); "
                                    "nK = shard 0 of K on one GPU.  bench.py measures live and uses this file only as a fallback, never across hashes.")
                 doc.setdefault("by_kernel_hash", {}).setdefault(khash, {})[gkey] = traffic_table
@@ -677,6 +711,7 @@ def main():
         "algorithmic_bytes": stream_bytes, "algorithmic_GBps": stream_bytes / t_kernel / 1e9,
         "work_efficiency_traffic_over_algorithmic": (traffic / stream_bytes) if (traffic and stream_bytes) else None,
         "l2_hit_rate": trec.get("l2_hit_rate") if trec else None,
+        "fetch_multiplier": trec.get("fetch_multiplier") if trec else None, "multiplier_source": trec.get("multiplier_source") if trec else None,
         "per_kernel_traffic_bytes": {k: v.get("bytes") for k, v in trec["kernels"].items()} if trec else None,
         "reference_equivalent_bytes": b_alg / world, "reference_equivalent_GBps": b_alg / world / t_kernel / 1e9,
         "reference_equivalent_note": "B_alg = 4*sum_{u<v}(d_u+d_v) + 8(n+1) + 4*nnz (SURVEY 8(d)): what the reference's full-row merges stream; "
@@ -727,11 +762,15 @@ def main():
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         if g is not None:
             g.free()
-        out["cpu_baseline"] = cpu_baseline(csr, args.cpu_seconds)
-        if args.ref_scale > 0:
-            # the reference's own FASTEST flavour next to the SortedSet-merge port above: RoaringGraph, compiled reference, this host
-            out["cpu_baseline"]["roaring"] = reference_baseline(args.ref_scale, args.degree, golden_record(f"{args.generator}-{args.scale}-{args.degree}-relabel"))
-            out["cpu_reference"] = out["cpu_baseline"]["roaring"]  # same record under its round-2 name
+        port = cpu_baseline(csr, args.cpu_seconds)
+        ref = reference_baseline(args.ref_scale, args.degree, golden_record(f"{args.generator}-{args.scale}-{args.degree}-relabel")) if args.ref_scale > 0 else None
+        if ref and "value" in ref:
+            # the headline CPU figure is the reference's own FASTEST code on this host — the compiled reference, Par::count_total<RoaringGraph>, whole graph
+            # of the stated scale (not the flattering one) —; the SortedSet-merge port on a sample of the headline graph sits beside it
+            out["cpu_baseline"] = dict(ref, sortedset_port=port, roaring=ref)
+        else:
+            out["cpu_baseline"] = dict(port, roaring=ref)
+        out["cpu_reference"] = ref  # same record under its round-2 name
         try:  # the N = 2, 4, 8 runs that follow on this box carry it (a CPU leg per rank count would measure the same thing again)
             with open(cpu_cache, "w") as f:
                 json.dump(out["cpu_baseline"], f)

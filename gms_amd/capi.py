@@ -35,7 +35,7 @@ SYMBOLS = [
     "gmsx_init", "gmsx_set_stream", "gmsx_device_info",
     "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_upload_shard", "gmsx_graph_upload_csr_shard", "gmsx_graph_prepare", "gmsx_graph_tc_passes", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
     "gmsx_graph_device_bytes", "gmsx_graph_max_out_degree",
-    "gmsx_tc_total", "gmsx_tc_partial", "gmsx_tc_divisor", "gmsx_tc_stream_breakdown", "gmsx_tc_row_histogram", "gmsx_tc_vertex_count2",
+    "gmsx_tc_total", "gmsx_tc_partial", "gmsx_tc_divisor", "gmsx_tc_stream_breakdown", "gmsx_tc_row_histogram", "gmsx_tc_comembership", "gmsx_tc_vertex_count2",
     "gmsx_intersect_count_batch", "gmsx_vertex_similarity_batch", "gmsx_kclique_count", "gmsx_kclique_partial", "gmsx_kclique_star_count", "gmsx_bk_count", "gmsx_bk_partial",
     "gmsx_adg_rank", "gmsx_tc_ordering",
     "gmsx_comm_unique_id", "gmsx_comm_init", "gmsx_comm_allreduce_u64", "gmsx_comm_rank", "gmsx_comm_size", "gmsx_comm_finalize",
@@ -113,6 +113,7 @@ def lib():
     L.gmsx_tc_divisor.argtypes = [C.c_int]
     L.gmsx_tc_stream_breakdown.argtypes = [vp, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
     L.gmsx_tc_row_histogram.argtypes = [vp, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
+    L.gmsx_tc_comembership.argtypes = [vp, C.c_int, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
     L.gmsx_tc_vertex_count2.argtypes = [vp, _i64p, sp]
     L.gmsx_intersect_count_batch.argtypes = [vp, C.c_int64, _i32p, _i32p, _u32p, sp]
     L.gmsx_vertex_similarity_batch.argtypes = [vp, C.c_int, C.c_int64, _i32p, _i32p, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), sp]
@@ -308,6 +309,12 @@ class DeviceGraph:
         out = np.zeros(256, dtype=np.uint64)
         _check(lib().gmsx_tc_row_histogram(self._h, out), "gmsx_tc_row_histogram")
         return out[:240].reshape(5, 24, 2).astype(np.int64), out[240:].astype(np.int64)
+
+    def tc_comembership(self, batch):
+        """gmsx_tc_comembership: dict(entries, units, distinct_rows, batched_units, items) for batches of `batch` consecutive heavy pivots."""
+        out = np.zeros(8, dtype=np.uint64)
+        _check(lib().gmsx_tc_comembership(self._h, int(batch), out), "gmsx_tc_comembership")
+        return dict(entries=int(out[0]), units=int(out[1]), distinct_rows=int(out[2]), batched_units=int(out[3]), items=int(out[4]))
 
     def tc_vertex_count2(self, stats=False):
         c, st = np.zeros(self.num_nodes, dtype=np.int64), Stats()

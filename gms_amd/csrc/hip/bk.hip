@@ -278,7 +278,8 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                                           int32_t v, int c, int x, uint32_t (&P)[WPL], uint32_t (&Xc)[WPL], uint32_t (&ext)[WPL], int xf_ne,
                                           bool entering, int lane, unsigned long long &cnt, const BkShared &sh, unsigned long long arena_off,
                                           bool global_structs, uint32_t *piv_P /* LDS, 64*WPL words: the current P for all lanes */,
-                                          unsigned short *piv_list /* LDS, 2048*WPL entries: members of P ∪ Xc */) {
+                                          unsigned short *piv_list /* LDS, 2048*WPL entries: members of P ∪ Xc */,
+                                          unsigned long long &node_words /* += nodes visited x words of a Cadj row: gmsx_stats.stream_bytes */) {
     const int cw = (c + 31) >> 5, xw = (x + 31) >> 5;
     const int lvl = 3 * cw + xw + 1;
     unsigned budget = sh.budget, nodes = 0;
@@ -599,7 +600,10 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
 #ifdef GMSX_BK_STATS
             if (ok && lane == 0) atomicAdd(&g_bk_nodes, (unsigned long long)nodes);
 #endif
-            if (ok) return;          // the rest of this search belongs to the next round
+            if (ok) {                // the rest of this search belongs to the next round
+                node_words += (unsigned long long)nodes * (unsigned long long)cw;
+                return;
+            }
             budget = 0xffffffffu;    // no room: finish it here
         }
         int hsel = 0;
@@ -749,6 +753,7 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
 #ifdef GMSX_BK_STATS
     if (lane == 0) atomicAdd(&g_bk_nodes, (unsigned long long)nodes);
 #endif
+    node_words += (unsigned long long)nodes * (unsigned long long)cw;
 }
 
 // Memory-resident Tomita search for start vertices with more candidates than the register-resident kernels hold (c > 16384, or
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
     unsigned short *piv_list = reinterpret_cast<unsigned short *>(lds_work);
     const int lane = threadIdx.x;
     uint32_t *slab = LDS_SLAB ? lds_slab : slabs + size_t(blockIdx.x) * slab_words;
-    unsigned long long cnt = 0;
+    unsigned long long cnt = 0, node_words = 0;
     // the LDS tasks take kGrab consecutive start vertices per queue ticket: 1.65 M tickets on ONE address (a device-scope atomic is resolved
     // behind the L2s of the eight XCDs) were a serial resource of the kernel
     constexpr int64_t kGrab = LDS_SLAB ? GMSX_BK_GRAB : 1;
@@ -1089,11 +1094,12 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
 #if defined(GMSX_BK_AB) && GMSX_BK_AB >= 3  // A/B build (wrong counts): the LDS tasks' build without their search
             if (LDS_SLAB) { cnt += Cadj[0] & 1u; continue; }
 #endif
-            bk_search<WR>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, x > 0 ? 1 : 0, true, lane, cnt, sh, kNoArena, !LDS_SLAB, piv_P, piv_list);
+            bk_search<WR>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, x > 0 ? 1 : 0, true, lane, cnt, sh, kNoArena, !LDS_SLAB, piv_P, piv_list, node_words);
         }
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
+    if (lane == 0 && node_words) atomicAdd(&acc[(blockIdx.x & 63) * 16 + 15], node_words);
 }
 
 // ---- round 0 of the start vertices too big for an LDS slab: BUILD and SEARCH are separate kernels -------------------------------------
@@ -1472,7 +1478,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? G
     __shared__ unsigned short piv_list[2048 * WPL];
     const int lane = threadIdx.x;
     uint32_t *stack = slabs + size_t(blockIdx.x) * slab_words;
-    unsigned long long cnt = 0;
+    unsigned long long cnt = 0, node_words = 0;
     unsigned long long q_next = 0, q_end = 0;  // `grab` records per queue ticket (tickets on one address are a serial resource: ~10 ns each)
     while (true) {
         if (q_next == q_end) {
@@ -1520,10 +1526,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? G
             __threadfence();
         }
         __builtin_amdgcn_wave_barrier();
-        bk_search<WPL>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, xf_ne, root, lane, cnt, sh, aoff, true, piv_P, piv_list);
+        bk_search<WPL>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, xf_ne, root, lane, cnt, sh, aoff, true, piv_P, piv_list, node_words);
         __builtin_amdgcn_wave_barrier();
     }
     if (lane == 0 && cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
+    if (lane == 0 && node_words) atomicAdd(&acc[(blockIdx.x & 63) * 16 + 15], node_words);
 }
 
 // ---- rounds >= 1 for records with at most 512 candidates: FOUR searches per wave -------------------------------------------------------
@@ -1634,7 +1641,8 @@ template <int G>
 __device__ __forceinline__ void bk_group_searches(const uint32_t *__restrict__ pool_in, const unsigned long long *__restrict__ dir_in, unsigned long long n_records,
                                                   unsigned long long *__restrict__ queue, unsigned grab, uint32_t *__restrict__ wave_slab,
                                                   unsigned long long slab_words /* per search */, const BkShared &sh, unsigned short *piv_list /* LDS, 2048 */,
-                                                  uint32_t *piv_P /* LDS, 64 */, unsigned long long &cnt_out, unsigned long long *st_) {
+                                                  uint32_t *piv_P /* LDS, 64 */, unsigned long long &cnt_out, unsigned long long &node_words_out,
+                                                  unsigned long long *st_) {
     // what the step at the top of the next trip consumes: M_PIVOT the pivot's row (ext = P & ~row), M_PIVOTB the same when the pivot is a candidate —
     // then it is also the first branch vertex and its row serves both (a node's branches may be taken in any order) —, M_BRANCH the row of branch
     // vertex q, M_CHILD1 the row of the only candidate of q's child, M_POP a saved level; M_ENTER / M_NEXT: a record was fetched (root / resumed)
@@ -1647,7 +1655,7 @@ __device__ __forceinline__ void bk_group_searches(const uint32_t *__restrict__ p
     uint32_t *const slab = wave_slab + size_t(grp) * slab_words;
     unsigned short *const my_list = piv_list + grp * kMaxC;
     uint32_t *const my_P = piv_P + grp * G;
-    unsigned long long cnt = 0;
+    unsigned long long cnt = 0, node_words = 0;
     // the group's search (every lane of the group holds the same value of what is not a bitmap word)
     const uint32_t *rec = pool_in, *Cadj = pool_in, *XT = pool_in, *xf0 = pool_in;
     uint32_t c = 0, cw = 0, xw = 0, depth = 0, lvl = kFixed;
@@ -1717,9 +1725,16 @@ __device__ __forceinline__ void bk_group_searches(const uint32_t *__restrict__ p
         //      current level), issued back to back for all groups, consumed below behind counted waits ------------------------------------------
         uint32_t *const lv = slab + (unsigned long long)depth * lvl + sub * kBkSlot;
         const uint32_t row = Cadj[rowreq * cw + sub];  // lanes past cw read the next row: their words of P / Xc are zero
-        uint32_t xtw = XT[(unsigned long long)rowreq * xw + ridx];
-        const uint4 sv = *reinterpret_cast<const uint4 *>(lv);
-        const uint2 sl = *reinterpret_cast<const uint2 *>(lv + 4);
+        uint32_t xtw = 0u;
+        uint4 sv{0u, 0u, 0u, 0u};
+        uint2 sl{0u, 0u};
+        // (wave-uniform branches: a trip in which no group pops / no group holds a register list leaves the loads out — they were a third of the
+        //  kernel's traffic beyond the L2 as unconditional dummies — and the waits stay counted: everything is consumed at one point below)
+        if (__ballot(xfn > 0 && xfn <= G && (mode == M_BRANCH || mode == M_CHILD1 || mode == M_PIVOTB)) != 0) xtw = XT[(unsigned long long)rowreq * xw + ridx];
+        if (__ballot(mode == M_POP) != 0) {
+            sv = *reinterpret_cast<const uint4 *>(lv);
+            sl = *reinterpret_cast<const uint2 *>(lv + 4);
+        }
         bool next = mode == M_NEXT || mode == M_POP || mode == M_PIVOT;
         bool need_pivot = mode == M_ENTER;
         int pc = 0, first = 0;  // of the node whose pivot is chosen below
@@ -1880,8 +1895,10 @@ __device__ __forceinline__ void bk_group_searches(const uint32_t *__restrict__ p
 #endif
             const int fq = bkg_first<G>(ext, sub);
             if (fq == 0xffff) {
-                if (depth == 0) mode = M_REC;
-                else { --depth; mode = M_POP; }
+                if (depth == 0) {
+                    mode = M_REC;
+                    node_words += (unsigned long long)nodes * cw;  // the search is through
+                } else { --depth; mode = M_POP; }
             } else {
                 bool split = false;
                 if (nodes >= sh.budget && !nosplit) {
@@ -1983,8 +2000,10 @@ __device__ __forceinline__ void bk_group_searches(const uint32_t *__restrict__ p
                         split = true;
                     }
                 }
-                if (split) mode = M_REC;
-                else {
+                if (split) {
+                    mode = M_REC;
+                    node_words += (unsigned long long)nodes * cw;
+                } else {
                     q = uint32_t(fq);
                     rowreq = q;
                     mode = M_BRANCH;
@@ -1992,7 +2011,10 @@ __device__ __forceinline__ void bk_group_searches(const uint32_t *__restrict__ p
             }
         }
     }
-    if (sub == 0) cnt_out += cnt;
+    if (sub == 0) {
+        cnt_out += cnt;
+        node_words_out += node_words;
+    }
 }
 
 #ifndef GMSX_BK_GROUP_WAVES
@@ -2006,7 +2028,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
     __shared__ unsigned short piv_list[2048];
     __shared__ uint32_t piv_P[64];
     uint32_t *const wave_slab = slabs + size_t(blockIdx.x) * wave_slab_words;
-    unsigned long long cnt = 0;
+    unsigned long long cnt = 0, node_words = 0;
 #ifdef GMSX_BK_STATS
     // profiling build: [0] trips of the wave loop, [1] trips in which a group fetched, [2] with a memory walk of Xf, [3] with pivot scoring; group steps in
     // [4] PIVOT [5] PIVOTB [6] BRANCH [7] CHILD1 [8] POP, [9] idle (DONE) group-trips, [10] pushes, [11] of them without a kept level (lane 0's groups only)
@@ -2016,19 +2038,43 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(GMSX_BK_GROU
 #endif
     (void)slab4;
     const bool wide_first = (blockIdx.x & 1) != 0;
-    if (wide_first) bk_group_searches<16>(pool_in, dir_in, n_records, queues + 0, grab, wave_slab, slab16, sh, piv_list, piv_P, cnt, st_);
+    if (wide_first) bk_group_searches<16>(pool_in, dir_in, n_records, queues + 0, grab, wave_slab, slab16, sh, piv_list, piv_P, cnt, node_words, st_);
 #if GMSX_BK_GROUP_MIN <= 4
-    bk_group_searches<4>(pool_in, dir_in, n_records, queues + 2, grab, wave_slab, slab4, sh, piv_list, piv_P, cnt, st_);
+    bk_group_searches<4>(pool_in, dir_in, n_records, queues + 2, grab, wave_slab, slab4, sh, piv_list, piv_P, cnt, node_words, st_);
 #endif
 #if GMSX_BK_GROUP_MIN <= 8
-    bk_group_searches<8>(pool_in, dir_in, n_records, queues + 1, grab, wave_slab, slab8, sh, piv_list, piv_P, cnt, st_);
+    bk_group_searches<8>(pool_in, dir_in, n_records, queues + 1, grab, wave_slab, slab8, sh, piv_list, piv_P, cnt, node_words, st_);
 #endif
-    if (!wide_first) bk_group_searches<16>(pool_in, dir_in, n_records, queues + 0, grab, wave_slab, slab16, sh, piv_list, piv_P, cnt, st_);
+    if (!wide_first) bk_group_searches<16>(pool_in, dir_in, n_records, queues + 0, grab, wave_slab, slab16, sh, piv_list, piv_P, cnt, node_words, st_);
     if (cnt) atomicAdd(&acc[(blockIdx.x & 63) * 16], cnt);
+    if (node_words) atomicAdd(&acc[(blockIdx.x & 63) * 16 + 15], node_words);
 #ifdef GMSX_BK_STATS
     if (threadIdx.x == 0)
         for (int i = 0; i < 12; ++i) atomicAdd(&g_bkg_stat[i], st_[i]);
 #endif
+}
+
+// gmsx_stats.stream_bytes of a Bron-Kerbosch call, build part: per start vertex of the shard every row that can hold an edge into its candidate set — the
+// oriented rows of ALL its neighbours (candidates -> Cadj, in-neighbours -> XT), 2 bytes per hub id + 4 per tail id: what k_bk_block streams.  One wave
+// per start vertex (task order, the shard's stride).
+__global__ __launch_bounds__(256) void k_stat_bk_bytes(int64_t n_tasks, int nparts, int part, const int32_t *__restrict__ task_v, const int64_t *__restrict__ off,
+                                                     const int32_t *__restrict__ adj, const int32_t *__restrict__ newid, const int32_t *__restrict__ oldid,
+                                                     const int64_t *__restrict__ hoff, const int64_t *__restrict__ toff, unsigned long long *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    unsigned long long b = 0;
+    for (int64_t qi = wave0;; qi += nwaves) {
+        const int64_t pos = qi * nparts + part;
+        if (pos >= n_tasks) break;
+        const int32_t vo = oldid[task_v[pos]];
+        const int64_t ob = off[vo], oe = off[vo + 1];
+        for (int64_t j = ob + lane; j < oe; j += 64) {
+            const int32_t w = newid[adj[j]];
+            b += 2ull * (unsigned long long)(hoff[w + 1] - hoff[w]) + 4ull * (unsigned long long)(toff[w + 1] - toff[w]);
+        }
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) b += __shfl_xor(b, sft);
+    if (lane == 0 && b) atomicAdd(out, b);
 }
 
 static int64_t part_count(int64_t first, int64_t end, int nparts, int part) {
@@ -2164,6 +2210,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     // LAYOUT of the start vertices that get their own build kernel (arena and record offsets by prefix sums) and the arena itself: setup like
     // the task sort above — allocations of gigabytes now and then stall for a second, they are not part of the kernels' time
     const int64_t cnt_glob = split_build ? part_count(0, n_glob, nparts, part) : 0;
+    int64_t need_total = 0;  // arena words of the start vertices built by k_bk_block
     int64_t *need_a = nullptr, *need_r = nullptr, *aoff = nullptr, *roff = nullptr, *d_end = nullptr, *need_p = nullptr, *poff = nullptr;
     unsigned long long *pieces = nullptr;
     Guard g_na, g_nr, g_ao, g_ro, g_de, g_map, g_np, g_po, g_pc;
@@ -2201,7 +2248,6 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
             hipLaunchKernelGGL(k_bk_pieces, dim3(unsigned(cnt_glob / 256 + 1)), dim3(256), 0, s, cnt_glob, poff, pieces);
         }
         GMSX_HIP(hipMemcpy(mx, maxima, sizeof(mx), hipMemcpyDeviceToHost));
-        int64_t need_total = 0;
         GMSX_HIP(hipMemcpy(&need_total, aoff + cnt_glob, 8, hipMemcpyDeviceToHost));
         // the roots may take 3/4 of the arena (below): everything in one chunk when the device allows, + room for the LDS-slab searches that split
         if (int rc = alloc_arena((unsigned long long)need_total / 3 * 4 + (512ull << 20) / 4)) return rc;
@@ -2578,7 +2624,20 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         float ms_setup = 0.f, ms = 0.f;
         GMSX_HIP(hipEventElapsedTime(&ms_setup, c.ev[0], c.ev[1]));
         GMSX_HIP(hipEventElapsedTime(&ms, c.ev[1], c.ev[2]));
-        *st = gmsx_stats{double(ms), double(ms_setup), uint64_t(part_count(0, n, nparts, part)), 0, uint64_t(rounds), launches, 0};
+        // ALGORITHMIC bytes of this formulation (no cache assumed), outside the timed region: the rows the builds walk + Cadj | XT of the start vertices
+        // built in the arena, written once + one Cadj row (cw words) per search-tree node — the operand of the reference's cand.intersect(N(q))
+        unsigned long long node_words = 0;
+        for (int i = 0; i < 64; ++i) node_words += host[i * 16 + 15];
+        unsigned long long build_bytes = 0;
+        if (n_tasks > 0) {
+            GMSX_HIP(hipMemsetAsync(acc + kCtl + 30, 0, 8, s));
+            hipLaunchKernelGGL(k_stat_bk_bytes, dim3(unsigned(cu * 8)), dim3(256), 0, s, n_tasks, nparts, part, v_out, g->off, g->adj, g->newid, g->oldid, g->hoff, g->toff,
+                               acc + kCtl + 30);
+            GMSX_HIP(hipMemcpyAsync(&build_bytes, acc + kCtl + 30, 8, hipMemcpyDeviceToHost, s));
+            GMSX_HIP(hipStreamSynchronize(s));
+        }
+        const uint64_t alg = uint64_t(build_bytes) + 4ull * uint64_t(need_total) + 4ull * uint64_t(node_words);
+        *st = gmsx_stats{double(ms), double(ms_setup), uint64_t(part_count(0, n, nparts, part)), 0, uint64_t(rounds), launches, 0, alg};
     }
     return GMSX_OK;
 }

@@ -1234,6 +1234,45 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     return GMSX_OK;
 }
 
+// gmsx_stats.stream_bytes of a k-clique call: the ALGORITHMIC bytes of this formulation, no cache assumed — per pivot u of the shard (d+ >= k - 1; position in
+// the d+ order ≡ part mod nparts) its own containers once and, per member v, the containers of N+(v) the BUILD reads: the hub part as bitset words or
+// 16-bit list, whichever kc_use_bitset picks (nothing when the pivot has no hub member), the tail part (4 bytes per id) when v is a tail member and the pivot
+// has tail members; pivots of d+ <= 32 read a hub member's row as one 4-byte gather per lower hub member instead; a pivot wider than 1024 writes its d x d
+// bit-matrix to its global slab and reads it back once.  One wave per pivot.
+__global__ __launch_bounds__(256) void k_stat_kc_bytes(int64_t n_min, int nparts, int part, const int32_t *__restrict__ order, const int32_t *__restrict__ dplus,
+                                                     const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff,
+                                                     const int32_t *__restrict__ tadj, int32_t dense_limit, unsigned long long *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    unsigned long long b = 0;
+    for (int64_t qi = wave0;; qi += nwaves) {
+        const int64_t pos = qi * nparts + part;
+        if (pos >= n_min) break;
+        const int32_t u = order[pos];
+        const int64_t hb = hoff[u], tb = toff[u];
+        int hc = int(hoff[u + 1] - hb);
+        if (hc > 0 && hadj[hb + hc - 1] == 0xFFFFu) --hc;  // row padding
+        const int tc = int(toff[u + 1] - tb), d = hc + tc;
+        if (lane == 0) {
+            b += 2ull * (unsigned long long)hc + 4ull * (unsigned long long)tc;
+            if (d > 1024) b += 2ull * (unsigned long long)d * (unsigned long long)((d + 31) / 32) * 4ull;
+        }
+        for (int i = lane; i < d; i += 64) {
+            const bool is_hub = i < hc;
+            const int32_t v = is_hub ? int32_t(hadj[hb + i]) : tadj[tb + (i - hc)];
+            const int hl = int(hoff[v + 1] - hoff[v]), tl = int(toff[v + 1] - toff[v]);
+            if (d <= 32 && is_hub) b += 4ull * (unsigned long long)i;  // inverted gathers into v's bitset container, one per lower hub member
+            else if (is_hub && v < dense_limit && int(bitset_words(v)) * 4 + 32 < hl * 2) b += 4ull * (unsigned long long)bitset_words(v);
+            else {
+                if (hc > 0) b += 2ull * (unsigned long long)hl;
+                if (!is_hub && tc > 0) b += 4ull * (unsigned long long)tl;
+            }
+        }
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) b += __shfl_xor(b, sft);
+    if (lane == 0 && b) atomicAdd(out, b);
+}
+
 static int kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uint64_t *out, gmsx_stats *st) {
     Ctx &c = ctx();
     hipStream_t s = c.stream;
@@ -1278,7 +1317,17 @@ static int kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uin
     if (st) {
         float ms = 0.f;
         GMSX_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
-        *st = gmsx_stats{double(ms), 0.0, uint64_t(part_count(0, g->n, nparts, part)), 0, 0, launches, 0};
+        unsigned long long alg = 0;  // outside the timed region
+        int64_t n_min = 0;
+        if (g->rows_sorted && count_dplus_ge(g, std::max(k - 1, 1), &n_min) == GMSX_OK && n_min > 0) {
+            GMSX_HIP(hipMemsetAsync(acc, 0, 8, s));
+            const int cu = c.compute_units > 0 ? c.compute_units : 256;
+            hipLaunchKernelGGL(k_stat_kc_bytes, dim3(unsigned(cu * 8)), dim3(256), 0, s, n_min, nparts, part, g->order, g->dplus, g->hoff, g->hadj, g->toff, g->tadj,
+                               g->dense_limit, acc);
+            GMSX_HIP(hipMemcpyAsync(&alg, acc, 8, hipMemcpyDeviceToHost, s));
+            GMSX_HIP(hipStreamSynchronize(s));
+        }
+        *st = gmsx_stats{double(ms), 0.0, uint64_t(part_count(0, g->n, nparts, part)), 0, 0, launches, 0, uint64_t(alg)};
     }
     return GMSX_OK;
 }

@@ -35,6 +35,9 @@
 
 #include <algorithm>
 #include <type_traits>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce.hpp>
+#include <rocprim/device/device_reduce_by_key.hpp>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -944,6 +947,39 @@ __device__ __forceinline__ int hist_bin(unsigned long long units) {
     for (unsigned long long lim = 32; units > lim && b < 23; lim <<= 1) ++b;
     return b;
 }
+// Diagnostics behind gmsx_tc_comembership: one key per entry of the hub items, (position of the item's pivot in `order`) / batch << 40 | (offset of
+// the stream row the entry names) / 16, and the 16-byte units the entry streams of it — sorted and reduced by key on the host side of the call
+__global__ __launch_bounds__(256) void k_tc_comember_keys(const unsigned long long *__restrict__ htask, const gmsx_tc_item *__restrict__ hitem, int64_t hitems, int batch,
+                                                         unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals, unsigned long long *__restrict__ sums) {
+    unsigned long long ents = 0, units = 0;
+    for (int64_t i = blockIdx.x; i < hitems; i += gridDim.x) {
+        const gmsx_tc_item it = hitem[i];
+        const unsigned long long first = it.bc & 0xffffffffffull;
+        const int n = int(it.bc >> 40);
+        const unsigned long long b = (unsigned long long)(it.pos / batch) << 40;
+        for (int e = threadIdx.x; e < n; e += 256) {
+            const unsigned long long d = htask[first + e];
+            keys[first + e] = b | (d >> 24);
+            vals[first + e] = uint32_t(d & 0x3fffffull);
+            ++ents;
+            units += d & 0x3fffffull;
+        }
+    }
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        ents += __shfl_xor(ents, sft);
+        units += __shfl_xor(units, sft);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sums[0], ents);
+        atomicAdd(&sums[1], units);
+    }
+}
+__global__ __launch_bounds__(256) void k_tc_sum_u32(const uint32_t *__restrict__ v, unsigned long long n, unsigned long long *__restrict__ out) {
+    unsigned long long t = 0;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) t += v[i];
+    for (int sft = 32; sft > 0; sft >>= 1) t += __shfl_xor(t, sft);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, t);
+}
 __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                      const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                      const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
@@ -1282,6 +1318,59 @@ int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out256) {
         GMSX_HIP(hipStreamSynchronize(s));
         GMSX_HIP(hipGetLastError());
         out248[241] = uint64_t(g->inline_hentries + g->inline_tentries);
+        return GMSX_OK;
+    });
+}
+
+int gmsx_tc_comembership(const gmsx_graph *g, int batch, uint64_t *out8) {
+    return gmsx::guard([&]() -> int {
+        if (!g || !out8 || batch < 1) return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;
+        if (int rc = ensure_tc(g)) return rc;
+        hipStream_t s = ctx().stream;
+        std::memset(out8, 0, 8 * sizeof(uint64_t));
+        const int64_t ne = g->htask_entries;
+        if (g->n == 0 || ne == 0 || g->hitems == 0) return GMSX_OK;
+        struct Guard { void *p = nullptr; ~Guard() { (void)hipFree(p); } } gk0, gk1, gv0, gv1, gu, ga, gc, gt, gsum;
+        unsigned long long *k0 = nullptr, *k1 = nullptr, *uk = nullptr, *cnt = nullptr, *sum = nullptr;
+        uint32_t *v0 = nullptr, *v1 = nullptr, *agg = nullptr;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&k0), size_t(ne) * 8)); gk0.p = k0;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&k1), size_t(ne) * 8)); gk1.p = k1;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&v0), size_t(ne) * 4)); gv0.p = v0;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&v1), size_t(ne) * 4)); gv1.p = v1;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&sum), 4 * 8)); gsum.p = sum;
+        GMSX_HIP(hipMemsetAsync(k0, 0xff, size_t(ne) * 8, s));  // entries no item covers (none expected) sort to the end as one key of 0 units
+        GMSX_HIP(hipMemsetAsync(v0, 0, size_t(ne) * 4, s));
+        GMSX_HIP(hipMemsetAsync(sum, 0, 4 * 8, s));
+        hipLaunchKernelGGL(k_tc_comember_keys, dim3(unsigned(std::min<int64_t>(g->hitems, 1 << 20))), dim3(256), 0, s, g->htask, g->hitem, g->hitems, batch, k0, v0, sum);
+        size_t tb = 0;
+        GMSX_HIP(rocprim::radix_sort_pairs(nullptr, tb, k0, k1, v0, v1, size_t(ne), 0, 64, s));
+        void *tmp = nullptr;
+        GMSX_HIP(hipMalloc(&tmp, tb ? tb : 8)); gt.p = tmp;
+        GMSX_HIP(rocprim::radix_sort_pairs(tmp, tb, k0, k1, v0, v1, size_t(ne), 0, 64, s));
+        // per distinct (batch, row): the longest cut of the row any pivot of the batch streams (k0 / v0 are free again: outputs)
+        uk = k0;
+        agg = v0;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&cnt), 8)); gc.p = cnt;
+        size_t rb = 0;
+        GMSX_HIP(rocprim::reduce_by_key(nullptr, rb, k1, v1, size_t(ne), uk, agg, cnt, rocprim::maximum<uint32_t>(), rocprim::equal_to<unsigned long long>(), s));
+        void *tmp2 = nullptr;
+        Guard g2;
+        GMSX_HIP(hipMalloc(&tmp2, rb ? rb : 8)); g2.p = tmp2;
+        GMSX_HIP(rocprim::reduce_by_key(tmp2, rb, k1, v1, size_t(ne), uk, agg, cnt, rocprim::maximum<uint32_t>(), rocprim::equal_to<unsigned long long>(), s));
+        unsigned long long nuniq = 0;
+        GMSX_HIP(hipMemcpyAsync(&nuniq, cnt, 8, hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        hipLaunchKernelGGL(k_tc_sum_u32, dim3(1024), dim3(256), 0, s, agg, (unsigned long long)nuniq, sum + 2);
+        unsigned long long h[4] = {0, 0, 0, 0};
+        GMSX_HIP(hipMemcpyAsync(h, sum, sizeof(h), hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        GMSX_HIP(hipGetLastError());
+        out8[0] = uint64_t(h[0]);   // entries the hub items cover
+        out8[1] = uint64_t(h[1]);   // their 16-byte units: what the hub items stream per pass
+        out8[2] = uint64_t(nuniq);  // distinct (batch, row) pairs
+        out8[3] = uint64_t(h[2]);   // units if every row were streamed once per batch (at its longest cut)
+        out8[4] = uint64_t(g->hitems);
         return GMSX_OK;
     });
 }

@@ -124,7 +124,12 @@ typedef struct gmsx_stats {
                                   for every oriented edge (u,v) the bytes of N+(v) in the form the kernels read: its stream rows (whole
                                   16-byte units of bitset / 16-bit list / byte-delta for the hub part, 32-bit ids / 16-bit delta for the
                                   tail part) or 4 bytes per inverted gather.  No cache is assumed: the traffic a pass would cause if
-                                  nothing were ever re-used on chip.  0 for the other entry points. */
+                                  nothing were ever re-used on chip.  k-clique: every pivot's own containers once + per member the containers of
+                                  N+(v) the BUILD reads (bitset words or 16-bit list, tail ids; one 4-byte gather per pair for d+ <= 32) + the
+                                  slab matrices of pivots wider than 1024, written and read once.  Bron-Kerbosch: per start vertex the oriented
+                                  rows of all its neighbours (what the builds walk) + Cadj | XT of the start vertices built in the arena, once
+                                  + one Cadj row (c / 32 words) per search-tree node — the operand of cand.intersect(N(q)), tomita.h:51-70.
+                                  0 for the other entry points. */
 } gmsx_stats;
 
 /* Bind this process to one HIP device.  device<0 → current device.  Calling it again with the same device is a no-op (and makes
@@ -202,6 +207,12 @@ int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21);
  * u's rows, units of v's rows); out[252]: the same sum for heavy u with u's rows cut at v's id (estimate) — out[248..252] are 0 unless the
  * graph was built with GMSX_TC_KEEP_ROWS=1 (the per-vertex row descriptors they read are freed after the build).  256 values, host. */
 int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out256);
+/* Diagnostics (round 5, the "stream a row once against several staged pivots" question): if the heavy pivots were processed in batches of
+ * `batch` consecutive positions of the d+ order, each distinct stream row of a batch loaded once — out[0] entries of the hub work items,
+ * out[1] the 16-byte units they stream per pass today, out[2] distinct (batch, row) pairs, out[3] the units a batched pass would stream
+ * (every row once per batch, at the longest cut any pivot of the batch reads), out[4] hub work items.  batch = 1 shows what rows repeat
+ * inside one pivot's own list (inline chunks never do).  8 values, host. */
+int gmsx_tc_comembership(const gmsx_graph *g, int batch, uint64_t *out8);
 /* Par::vertex_count2 / vertex_count2_once (parallel/vertex.h:14-49): counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| (= 2·triangles at u),
  * indexed by the vertex ids of the uploaded CSR.  Runs on the k = 3 bit-matrix kernels (one atomic per pivot member); graphs
  * with d+ > 8192 fall back to one full-row intersect_count per CSR entry. */

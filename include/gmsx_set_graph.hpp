@@ -310,8 +310,8 @@ class HipGraphT {
             adj_own_ = std::move(o.adj_own_);
             sets_ = std::move(o.sets_);
             off_ = o.off_; adj_ = o.adj_; n_ = o.n_;
-            dev_ = o.dev_; upload_rc_ = o.upload_rc_; flags_ = o.flags_;
-            o.dev_ = nullptr; o.off_ = nullptr; o.adj_ = nullptr; o.n_ = 0;
+            dev_ = o.dev_; upload_rc_ = o.upload_rc_; flags_ = o.flags_; shard_ = o.shard_;
+            o.dev_ = nullptr; o.off_ = nullptr; o.adj_ = nullptr; o.n_ = 0; o.shard_ = {0, 1};
         }
         return *this;
     }

@@ -139,6 +139,17 @@ int main() {
         CHECK(sum == 4 && rg.out_neigh(2).intersect_count(rg.out_neigh(0)) == 1);
         gmsx::HipSetRefGraph fg = gmsx::HipSetRefGraph::FromCsr(csr);
         CHECK(fg.out_neigh(2).cardinality() == 3 && fg.out_neigh(2).intersect_count(fg.out_neigh(0)) == 1);
+        // a graph uploaded as a shard stays that shard when it is moved (count_total of a moved rank graph asked gmsx_tc_total for the
+        // WHOLE graph on a sharded upload); the moved-from object is a whole-graph placeholder again
+        gmsx::default_upload_shard() = {1, 2};
+        gmsx::HipSetGraph sharded = gmsx::HipSetGraph::FromCsr(csr);
+        gmsx::default_upload_shard() = {0, 1};
+        CHECK(sharded.upload_shard() == (std::pair<int, int>{1, 2}));
+        gmsx::HipSetGraph moved(std::move(sharded));
+        CHECK(moved.upload_shard() == (std::pair<int, int>{1, 2}) && sharded.upload_shard() == (std::pair<int, int>{0, 1}) && moved.num_nodes() == 4);
+        gmsx::HipSetGraph assigned;
+        assigned = std::move(moved);
+        CHECK(assigned.upload_shard() == (std::pair<int, int>{1, 2}) && moved.upload_shard() == (std::pair<int, int>{0, 1}));
     }
     gmsx_csr_free(csr);
 

@@ -5,8 +5,6 @@ import json
 import os
 import sys
 
-import pytest
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -17,10 +15,9 @@ def test_traffic_table_matches_kernel_sources():
         doc = json.load(f)
     khash = bench.kernel_hash()
     assert bench.committed_traffic("0" * 16, "kronecker-26-16/auto", 4) is None  # never served across kernel builds
-    if khash not in doc["by_kernel_hash"]:
-        # the live PMC passes of bench.py do not need the table; only its N>1 fallback on a box without an N=1 run does
-        pytest.skip(f"profiles/hbm_traffic.json holds no entry for the kernel sources in the tree ({khash}): re-run "
-                    "`python bench.py --dump-traffic profiles/hbm_traffic.json` on the GPU")
+    # (the live PMC passes of bench.py do not need the table; its N>1 fallback on a box without an N=1 run does — a stale table FAILS here, it is not skipped)
+    assert khash in doc["by_kernel_hash"], (f"profiles/hbm_traffic.json holds no entry for the kernel sources in the tree ({khash}): re-run "
+                                             "`python bench.py --dump-traffic profiles/hbm_traffic.json` on the GPU and commit it")
     rec = doc["by_kernel_hash"][khash]["kronecker-26-16/auto"]
     assert set(rec) >= {"n1", "n2", "n4", "n8"}
     # shards of a strong-scaling run: each about 1/N of the whole pass
