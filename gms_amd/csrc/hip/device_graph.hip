@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>  // before rocprim: its texture iterator calls the host memset
+#include <memory>
 #include <new>
 #include <random>
 
@@ -1061,6 +1062,47 @@ struct PhaseTimer {
     }
 };
 
+// Host -> device copy of a caller-owned, PAGEABLE array.  One hipMemcpyAsync of 8 GiB that the runtime touches for the first time moves at 26 GB/s on the
+// MI355X hosts (its staging pipeline runs on one thread; tools/probes/h2d_probe.hip: 0.333 s); hipHostRegister pins at the same 26 GB/s before the copy starts
+// (0.308 + 0.149 s).  Here: two pinned 64 MB staging buffers (kept for the life of the process), filled by the host substrate's threads while the other
+// one is on the wire — 0.173 s for the same 8 GiB (50 GB/s; a warm buffer copies at 56).  Small copies go the plain way.
+static int staged_h2d(void *dst, const void *src, size_t bytes, hipStream_t s) {
+    constexpr size_t kChunk = size_t(64) << 20;
+    static const bool off = [] { const char *e = std::getenv("GMSX_UPLOAD_STAGED"); return e && std::atoi(e) == 0; }();  // A/B: 0 = one hipMemcpyAsync (round 4)
+    if (bytes < 2 * kChunk || off) {
+        GMSX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+        return GMSX_OK;
+    }
+    struct Stage {
+        char *pin[2] = {nullptr, nullptr};
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        bool ok = false;
+        Stage() {
+            ok = hipHostMalloc(reinterpret_cast<void **>(&pin[0]), kChunk, hipHostMallocDefault) == hipSuccess &&
+                 hipHostMalloc(reinterpret_cast<void **>(&pin[1]), kChunk, hipHostMallocDefault) == hipSuccess &&
+                 hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess;
+            if (!ok) (void)hipGetLastError();
+        }
+    };
+    static Stage st;  // (one upload at a time per process: the library's calls are not re-entrant on one stream anyway)
+    if (!st.ok) {
+        GMSX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+        return GMSX_OK;
+    }
+    static bool used[2] = {false, false};  // across calls: the last chunks of the previous copy may still be on the wire when the next one starts filling
+    int b = 0;
+    for (size_t at = 0; at < bytes; at += kChunk, b ^= 1) {
+        const size_t n = std::min(kChunk, bytes - at);
+        if (used[b]) GMSX_HIP(hipEventSynchronize(st.ev[b]));
+        char *to = st.pin[b];
+        parallel_memcpy(to, static_cast<const char *>(src) + at, n);
+        GMSX_HIP(hipMemcpyAsync(static_cast<char *>(dst) + at, to, n, hipMemcpyHostToDevice, s));
+        GMSX_HIP(hipEventRecord(st.ev[b], s));
+        used[b] = true;
+    }
+    return GMSX_OK;
+}
+
 static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     hipStream_t s = ctx().stream;
     PhaseTimer pt(s, "base build");
@@ -1385,7 +1427,7 @@ static int build_tc_sets(gmsx_graph *g) {
         if (g->tpool_units >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;
         if (int rc = dmalloc(&g->trow, n, g)) return rc;
         if (int rc = dmalloc(&g->tpool, (g->tpool_units + kPoolSlack) * 4, g)) return rc;
-        GMSX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g->tpool), int(0xFFFFFFFEu), size_t(g->tpool_units) * 4 + 4, s));  // filler -2 (alignment gaps, inline rows)
+        GMSX_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(g->tpool), int(0xFFFFFFFEu), size_t(g->tpool_units + kPoolSlack) * 4, s));  // filler -2 (alignment gaps, inline rows, the slack the scans may load)
         if (n > 0)
             hipLaunchKernelGGL(k_trow_fill, dim3(unsigned((n + 255) / 256)), dim3(256), 0, s, n, g->toff, g->tadj, uoff, soff, real, form, g->trow, g->tpool);
         GMSX_HIP(hipStreamSynchronize(s));
@@ -1750,7 +1792,9 @@ int gmsx_graph_upload_shard(int64_t n, const int64_t *offsets, const int32_t *ne
         if (!out || n < 0 || !offsets || n > 0x7fffffffll || nparts < 1 || part < 0 || part >= nparts) return GMSX_ERR_INVALID;
         if (offsets[0] != 0 || offsets[n] < 0 || (offsets[n] > 0 && !neigh)) return GMSX_ERR_INVALID;
         if (int rc = ensure_init()) return rc;
-        gmsx_graph *g = new (std::nothrow) gmsx_graph;
+        struct Free { void operator()(gmsx_graph *p) const { free_graph(p); } };
+        std::unique_ptr<gmsx_graph, Free> owner(new (std::nothrow) gmsx_graph);  // freed on every way out, an exception in a build step included
+        gmsx_graph *g = owner.get();
         if (!g) return GMSX_ERR_NOMEM;
         g->n = n;
         g->nnz = offsets[n];
@@ -1760,12 +1804,12 @@ int gmsx_graph_upload_shard(int64_t n, const int64_t *offsets, const int32_t *ne
         if (!rc) rc = dmalloc(&g->adj, g->nnz, g);
         if (!rc) {
             hipStream_t s = ctx().stream;
-            if (hipMemcpyAsync(g->off, offsets, size_t(n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s) != hipSuccess ||
-                (g->nnz && hipMemcpyAsync(g->adj, neigh, size_t(g->nnz) * sizeof(int32_t), hipMemcpyHostToDevice, s) != hipSuccess) ||
-                hipStreamSynchronize(s) != hipSuccess) {
-                (void)hipGetLastError();
-                rc = GMSX_ERR_KERNEL;
-            }
+            PhaseTimer pt(s, "h2d");
+            rc = staged_h2d(g->off, offsets, size_t(n + 1) * sizeof(int64_t), s);
+            if (!rc && g->nnz) rc = staged_h2d(g->adj, neigh, size_t(g->nnz) * sizeof(int32_t), s);
+            if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = GMSX_ERR_KERNEL;
+            if (rc) (void)hipGetLastError();
+            pt.mark("CSR host -> device");
         }
         // offsets must be monotone before any kernel walks the rows
         if (!rc) {
@@ -1774,11 +1818,8 @@ int gmsx_graph_upload_shard(int64_t n, const int64_t *offsets, const int32_t *ne
         }
         if (!rc) rc = build_device_sets(g, flags);
         if (!rc && (flags & GMSX_UPLOAD_FOR_TC)) rc = ensure_tc(g);
-        if (rc) {
-            free_graph(g);
-            return rc;
-        }
-        *out = g;
+        if (rc) return rc;
+        *out = owner.release();
         return GMSX_OK;
     });
 }

@@ -797,7 +797,6 @@ __global__ __launch_bounds__(256) void k_tc_light(const uint16_t *__restrict__ h
 __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                   const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                   const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
-                                                  const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
                                                   const int32_t *__restrict__ tunits, int32_t inline_limit, int inline_first, int64_t end, int nparts, int part,
                                                   unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -887,7 +886,6 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
 //   out[15..20] reserved (0)
 __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict__ hoff, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                       const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
-                                                      const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
                                                       const unsigned long long *__restrict__ htask, const gmsx_tc_item *__restrict__ hitem, int64_t hitems,
                                                       const unsigned long long *__restrict__ ttask, const gmsx_tc_item *__restrict__ titem, int64_t titems,
                                                       int32_t inline_limit, int64_t first_light, int64_t end_light,
@@ -1223,7 +1221,7 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     if (need_stats) {  // untimed bookkeeping, once per shard (the graph is immutable)
         if (g->n > 0) {
             const int64_t blocks = std::min<int64_t>((g->n + 3) / 4, cap_blocks);
-            hipLaunchKernelGGL(k_tc_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow,
+            hipLaunchKernelGGL(k_tc_stats, dim3(unsigned(blocks)), dim3(256), 0, s, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->order,
                                g->tunits, g->inline_limit, g->inline_first, g->n, nparts, part, acc + kAccSlots * kAccStride);
         }
         if (g->hitems > 0)
@@ -1286,7 +1284,7 @@ int gmsx_tc_stream_breakdown(const gmsx_graph *g, uint64_t *out21) {
         struct Guard { void *p; ~Guard() { (void)hipFree(p); } } g1{acc};
         GMSX_HIP(hipMemsetAsync(acc, 0, 21 * 8, s));
         const int cus = ctx().compute_units > 0 ? ctx().compute_units : 256;
-        hipLaunchKernelGGL(k_tc_breakdown, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->hoff, g->toff, g->tadj, g->dplus, g->order, g->srow, g->trow, g->htask,
+        hipLaunchKernelGGL(k_tc_breakdown, dim3(unsigned(cus * 16)), dim3(256), 0, s, g->hoff, g->toff, g->tadj, g->dplus, g->order, g->htask,
                            g->hitem, g->hitems, g->ttask, g->titem, g->titems, g->inline_limit, n_block, n_work, acc);
         GMSX_HIP(hipMemcpyAsync(out21, acc, 21 * 8, hipMemcpyDeviceToHost, s));
         GMSX_HIP(hipStreamSynchronize(s));

@@ -8,6 +8,7 @@
 
 #include "gmsx.h"
 
+#include <cstddef>
 namespace gmsx {
 
 // No exception crosses the C ABI: every exported function that can reach an allocation of the C++ library (containers, strings, streams,
@@ -41,6 +42,10 @@ struct Csr {
 bool worth_relabelling(const Csr &g);
 int relabel_by_degree(const Csr &g, Csr &out);
 
+// threads of the host substrate (gmsx_set_host_threads / OpenMP's current maximum): what the staged upload copies with (loader.cpp)
+int host_threads();
+// memcpy by the threads of the host substrate (OpenMP's pool: no thread is started per call)
+void parallel_memcpy(void *dst, const void *src, size_t bytes);
 }  // namespace gmsx
 
 struct gmsx_csr {

@@ -657,6 +657,28 @@ static int read_sg(const std::string &path, Csr &g) {
 // ================================================================================================
 // C-ABI (include/gmsx.h, "Host graph substrate")
 // ================================================================================================
+namespace gmsx {
+int host_threads() {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+void parallel_memcpy(void *dst, const void *src, size_t bytes) {
+#ifdef _OPENMP
+#pragma omp parallel
+    {
+        const size_t nt = size_t(omp_get_num_threads()), t = size_t(omp_get_thread_num());
+        const size_t per = ((bytes + nt - 1) / nt + 4095) & ~size_t(4095), lo = std::min(bytes, per * t), hi = std::min(bytes, lo + per);
+        if (hi > lo) std::memcpy(static_cast<char *>(dst) + lo, static_cast<const char *>(src) + lo, hi - lo);
+    }
+#else
+    std::memcpy(dst, src, bytes);
+#endif
+}
+}  // namespace gmsx
+
 using namespace gmsx;
 
 extern "C" {
@@ -667,7 +689,10 @@ int gmsx_csr_generate(int generator, int scale, int degree, int relabel, int thr
         if (scale > 30) return GMSX_ERR_OVERFLOW;  // ids are int32 (generator.h:41-48 exits with -31)
         if (generator != GMSX_GEN_KRONECKER && generator != GMSX_GEN_UNIFORM) return GMSX_ERR_INVALID;
     #ifdef _OPENMP
-        const int saved = omp_get_max_threads();
+        struct Threads {  // restored on every way out, an exception included
+            int saved, set;
+            ~Threads() { if (set > 0) omp_set_num_threads(saved); }
+        } threads_guard{omp_get_max_threads(), threads};
         if (threads > 0) omp_set_num_threads(threads);
     #else
         (void)threads;
@@ -686,9 +711,6 @@ int gmsx_csr_generate(int generator, int scale, int degree, int relabel, int thr
             if (!rc) rc = finish(std::move(g), relabel, out);
             pf.lap("relabel decision + relabel");
         }
-    #ifdef _OPENMP
-        if (threads > 0) omp_set_num_threads(saved);
-    #endif
         return rc;
     });
 }
@@ -699,7 +721,10 @@ int gmsx_csr_generate_rmat(int scale, int degree, double a, double b, double c, 
         if (!(a > 0 && b >= 0 && c >= 0 && a + b + c < 1.0)) return GMSX_ERR_INVALID;
         if (scale > 30) return GMSX_ERR_OVERFLOW;
     #ifdef _OPENMP
-        const int saved = omp_get_max_threads();
+        struct Threads {  // restored on every way out, an exception included
+            int saved, set;
+            ~Threads() { if (set > 0) omp_set_num_threads(saved); }
+        } threads_guard{omp_get_max_threads(), threads};
         if (threads > 0) omp_set_num_threads(threads);
     #else
         (void)threads;
@@ -714,9 +739,6 @@ int gmsx_csr_generate_rmat(int scale, int degree, double a, double b, double c, 
             }
             if (!rc) rc = finish(std::move(g), relabel, out);
         }
-    #ifdef _OPENMP
-        if (threads > 0) omp_set_num_threads(saved);
-    #endif
         return rc;
     });
 }

@@ -144,7 +144,10 @@ enum {
     GMSX_UPLOAD_TRUSTED = 1, /* skip the device-side check of the canonical-row invariant.  The check (default): every row strictly
                                 ascending, ids in range, no self loops — exact — and the arc set equal to its transpose, decided by two
                                 keyed 64-bit multiset hashes of both (keys drawn per process): an asymmetric input passes with
-                                probability 2^-128, a symmetric one never fails */
+                                probability 2^-128, a symmetric one never fails.  With TRUSTED the caller GUARANTEES the invariant (only
+                                out-of-range ids are still refused): on a row with a repeated neighbour, a self loop or a missing reverse
+                                arc the counts are undefined — the triangle kernels, for one, maintain a pivot's LDS bitmap by XOR, so a
+                                repeated id cancels itself */
     GMSX_UPLOAD_FOR_TC = 2   /* also build the triangle-count containers (stream rows, inline rows, task lists: ~5x the CSR) now, inside the
                                 upload — what a triangle-count harness wants in its untimed "GraphExec buildTime" (common/benchmark.h:
                                 105-109).  Without it they are built by gmsx_graph_prepare or by the first gmsx_tc_* call, and a k-clique /
