@@ -582,6 +582,8 @@ def main():
     # test hook for 1-GPU boxes: GMSX_SHARE_GPU=1 lets several ranks share cuda:0 (then over gloo, RCCL refuses duplicates)
     share = os.environ.get("GMSX_SHARE_GPU") == "1"
     rank, local_rank, world = dist.init_process_group(backend="gloo" if share else None)
+    if os.environ.get("GMSX_BENCH_TEST_DIE_RANK") == str(rank) and world > 1:
+        os._exit(5)  # test hook (tests/test_multi_gpu_readiness_gpu.py): this rank dies before the communicator id reaches it
     if world != args.gpus:
         log(rank, f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE")
     if share:
@@ -626,8 +628,15 @@ def main():
         if rank == 0:
             idt.copy_(torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8))
         torch.distributed.broadcast(idt, 0)
-        comm = capi.Comm.init(rank, world, bytes(idt.cpu().numpy().tobytes()))
-        collective = "gmsx_comm_allreduce_u64 = ncclAllReduce(count=1, ncclUint64, ncclSum) over RCCL (native, librccl)"
+        try:
+            comm = capi.Comm.init(rank, world, bytes(idt.cpu().numpy().tobytes()))  # bounded: GMSX_COMM_TIMEOUT_S (a peer that never arrives)
+        except capi.GmsxError as e:
+            log(0, f"rank {rank}: {e}: leaving (the launcher takes the other ranks down)")
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(3)  # not sys.exit: after a timeout a helper thread is parked inside RCCL, and no exec — a fresh exit status is all the launcher needs
+        assert (comm.rank, comm.size) == (rank, world), (comm.rank, comm.size, rank, world)
+        collective = "gmsx_comm_allreduce_u64 = ncclAllReduce(count=1, ncclUint64, ncclSum) over RCCL (native, librccl), %d ranks" % comm.size
     elif world > 1:
         collective = "torch.distributed gloo all-reduce (GMSX_SHARE_GPU test hook: ranks share one GPU, RCCL refuses duplicates)"
     else:

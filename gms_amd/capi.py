@@ -22,7 +22,7 @@ TC_AUTO, TC_ORIENTED, TC_FULL = 0, 1, 2
 UPLOAD_DEFAULT, UPLOAD_TRUSTED, UPLOAD_FOR_TC = 0, 1, 2
 PREPARE_TC = 1
 OK, ERR_INVALID, ERR_NOMEM, ERR_IO, ERR_FORMAT, ERR_DIRECTED, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
-ERR_DEVICE_MEM, ERR_NOT_CANONICAL, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_KERNEL, ERR_COMM = -7, -8, -9, -10, -11, -12
+ERR_DEVICE_MEM, ERR_NOT_CANONICAL, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_KERNEL, ERR_COMM, ERR_TIMEOUT = -7, -8, -9, -10, -11, -12, -13
 COMM_ID_BYTES = 128
 
 # every symbol include/gmsx.h declares (tests/test_capi_symbols.py checks the header against this list)

@@ -369,7 +369,12 @@ int main(int argc, char **argv) {
             if (!f || std::fread(id, 1, sizeof(id), f) != sizeof(id)) return 5;
             std::fclose(f);
         }
-        if ((rc = gmsx_comm_init(rank, nranks, id, &comm)) != GMSX_OK) { std::fprintf(stderr, "gmsx_comm_init: %s\n", gmsx_strerror(rc)); return 5; }
+        if ((rc = gmsx_comm_init(rank, nranks, id, &comm)) != GMSX_OK) {
+            std::fprintf(stderr, "gmsx_comm_init: %s\n", gmsx_strerror(rc));
+            std::fflush(nullptr);
+            if (rc == GMSX_ERR_TIMEOUT) _exit(5);  // a helper thread is parked inside RCCL: leave without the exit handlers (the supervisor reaps)
+            return 5;
+        }
         std::printf("RCCL communicator: %d rank(s), one per GPU; partial counts meet in one u64 all-reduce\n", nranks);
     }
     auto reduce = [&](uint64_t v) {

@@ -10,8 +10,14 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 
 namespace {
 
@@ -47,6 +53,25 @@ Rccl &rccl() {
     }();
     return r;
 }
+
+double comm_timeout_s() {
+    const char *e = std::getenv("GMSX_COMM_TIMEOUT_S");
+    const double v = e ? std::atof(e) : 180.0;
+    return v > 0 ? v : 180.0;
+}
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// ncclCommInitRank on a helper thread, so that the caller's wait can be bounded.  (The non-blocking creation NCCL offers for this —
+// ncclCommInitRankConfig with blocking = 0, polled by ncclCommGetAsyncError — was tried first: on RCCL 2.27.7 the call itself does not return
+// while a peer is missing, tools/probes/comm_timeout_probe.py.)  A job whose wait ran out stays behind with its parked thread: the caller is
+// expected to leave the process (gmsx.h), and neither is touched again.
+struct InitJob {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false;
+    int result = -1, device = 0, nranks = 1, rank = 0;
+    ncclUniqueId id;
+    ncclComm_t comm = nullptr;
+};
 
 }  // namespace
 
@@ -87,10 +112,32 @@ int gmsx_comm_init(int rank, int nranks, const void *id, gmsx_comm **out) {
         }
         ncclUniqueId u;
         std::memcpy(&u, id, sizeof(u));
-        if (rccl().CommInitRank(&c->comm, nranks, u, rank) != kNcclSuccess) {
+        int rc = GMSX_OK;
+        {
+            auto job = std::make_shared<InitJob>();
+            job->device = ctx().device;
+            job->nranks = nranks;
+            job->rank = rank;
+            job->id = u;
+            std::thread([job] {
+                (void)hipSetDevice(job->device);
+                ncclComm_t comm = nullptr;
+                const int r = rccl().CommInitRank(&comm, job->nranks, job->id, job->rank);
+                std::lock_guard<std::mutex> lock(job->m);
+                job->comm = comm;
+                job->result = r;
+                job->done = true;
+                job->cv.notify_all();
+            }).detach();
+            std::unique_lock<std::mutex> lock(job->m);
+            if (!job->cv.wait_for(lock, std::chrono::duration<double>(comm_timeout_s()), [&] { return job->done; })) rc = GMSX_ERR_TIMEOUT;
+            else if (job->result != kNcclSuccess) rc = GMSX_ERR_COMM;
+            else c->comm = job->comm;
+        }
+        if (rc != GMSX_OK) {
             (void)hipFree(c->buf);
             delete c;
-            return GMSX_ERR_COMM;
+            return rc;
         }
         *out = c;
         return GMSX_OK;
@@ -104,7 +151,20 @@ int gmsx_comm_allreduce_u64(gmsx_comm *c, uint64_t *value) {
         GMSX_HIP(hipMemcpyAsync(c->buf, value, sizeof(uint64_t), hipMemcpyHostToDevice, s));
         if (rccl().AllReduce(c->buf, c->buf, 1, kNcclUint64, kNcclSum, c->comm, s) != kNcclSuccess) return GMSX_ERR_COMM;
         GMSX_HIP(hipMemcpyAsync(value, c->buf, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-        GMSX_HIP(hipStreamSynchronize(s));
+        // the wait for the result is bounded too: a peer that died between init and the reduction must not park this rank
+        hipEvent_t done = nullptr;
+        GMSX_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+        struct Ev { hipEvent_t e; ~Ev() { (void)hipEventDestroy(e); } } ev{done};
+        GMSX_HIP(hipEventRecord(done, s));
+        const double t0 = now_s(), limit = comm_timeout_s();
+        for (unsigned spins = 0;; ++spins) {
+            const hipError_t q = hipEventQuery(done);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) { (void)hipGetLastError(); return GMSX_ERR_KERNEL; }
+            if (spins < 20000) continue;  // an 8-byte reduction is through in tens of microseconds: no sleep on the timed path
+            if (now_s() - t0 > limit) return GMSX_ERR_TIMEOUT;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
         return GMSX_OK;
     });
 }

@@ -1875,6 +1875,7 @@ const char *gmsx_strerror(int status) {
         case GMSX_ERR_UNSUPPORTED: return "request not supported by this build";
         case GMSX_ERR_KERNEL: return "HIP kernel launch or synchronisation failed";
         case GMSX_ERR_COMM: return "librccl could not be loaded or an RCCL call failed";
+        case GMSX_ERR_TIMEOUT: return "a peer of the communicator did not arrive in time (GMSX_COMM_TIMEOUT_S)";
         default: return "unknown gmsx status";
     }
 }

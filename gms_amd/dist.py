@@ -22,6 +22,12 @@ def init_process_group(backend=None):
         kw = {}
         if backend == "nccl":
             kw["device_id"] = torch.device("cuda", local_rank)
+        # the control plane waits no longer for a dead peer than the library's own communicator does (include/gmsx.h: GMSX_COMM_TIMEOUT_S, default 180 s)
+        try:
+            import datetime
+            kw["timeout"] = datetime.timedelta(seconds=max(10.0, float(os.environ.get("GMSX_COMM_TIMEOUT_S", "180")) * 2))
+        except ValueError:
+            pass
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 

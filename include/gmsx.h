@@ -45,7 +45,8 @@ enum {
     GMSX_ERR_OVERFLOW = -9,     /* ids do not fit int32 (reference: exit(-31), generator.h:41-48) */
     GMSX_ERR_UNSUPPORTED = -10, /* valid request outside what this build implements */
     GMSX_ERR_KERNEL = -11,      /* a kernel launch or device synchronisation failed */
-    GMSX_ERR_COMM = -12         /* librccl missing or an RCCL call failed */
+    GMSX_ERR_COMM = -12,        /* librccl missing or an RCCL call failed */
+    GMSX_ERR_TIMEOUT = -13      /* a peer of the communicator did not arrive within GMSX_COMM_TIMEOUT_S seconds (gmsx_comm_init / gmsx_comm_allreduce_u64) */
 };
 const char *gmsx_strerror(int status);
 int gmsx_version(void);
@@ -293,7 +294,11 @@ int gmsx_tc_ordering(const gmsx_graph *g, int32_t *ordering /* n, host */, gmsx_
 typedef struct gmsx_comm gmsx_comm;
 #define GMSX_COMM_ID_BYTES 128
 int gmsx_comm_unique_id(void *id /* GMSX_COMM_ID_BYTES, out */);
-int gmsx_comm_init(int rank, int nranks, const void *id /* GMSX_COMM_ID_BYTES */, gmsx_comm **out); /* ncclCommInitRank on the bound device */
+/* ncclCommInitRank on the bound device, with a BOUNDED wait: the call runs on a helper thread and the caller waits at most GMSX_COMM_TIMEOUT_S
+ * seconds (environment, default 180) for it — a peer that died or never started makes ncclCommInitRank wait for good.  GMSX_ERR_TIMEOUT then:
+ * the helper thread stays parked inside RCCL, so the caller should report the failure and LEAVE THE PROCESS (its launcher — torch.distributed.run,
+ * gmsx_driver's supervisor — takes the other ranks down).  The wait for the result of every gmsx_comm_allreduce_u64 is bounded the same way. */
+int gmsx_comm_init(int rank, int nranks, const void *id /* GMSX_COMM_ID_BYTES */, gmsx_comm **out);
 int gmsx_comm_allreduce_u64(gmsx_comm *c, uint64_t *value /* in: this rank's partial, out: the sum */); /* ncclAllReduce(count=1, ncclUint64, ncclSum) */
 int gmsx_comm_rank(const gmsx_comm *c);
 int gmsx_comm_size(const gmsx_comm *c);

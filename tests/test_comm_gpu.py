@@ -29,3 +29,28 @@ def test_driver_gpus_1_runs_through_rccl(gpu):
         r = subprocess.run([exe, kernel, "-g", "kronecker", "12", "-n", "1", "-v", "--gpus", "1"], capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout + r.stderr
         assert needle in r.stdout and "RCCL communicator: 1 rank(s)" in r.stdout and " PASS " in r.stdout, r.stdout
+
+
+def test_comm_init_gives_up_on_a_peer_that_never_arrives(gpu):
+    """rank 0 of a TWO-rank communicator whose peer never calls in — a rank that died before the id reached it — must not
+    park in ncclCommInitRank for good.  The library runs it on a helper thread and waits GMSX_COMM_TIMEOUT_S seconds at most, then returns
+    GMSX_ERR_TIMEOUT.  Run in a child process (the parked helper thread is not something the test session should keep), which leaves with its own
+    status: no re-exec anywhere."""
+    import sys
+    import time
+    code = ("import os, sys, time\n"
+            "sys.path.insert(0, %r)\n"
+            "from gms_amd import capi\n"
+            "capi.init(0)\n"
+            "uid = capi.Comm.unique_id()\n"
+            "t0 = time.time()\n"
+            "try:\n"
+            "    capi.Comm.init(0, 2, uid)\n"
+            "except capi.GmsxError as e:\n"
+            "    print('status', e.status, 'after', round(time.time() - t0, 1), flush=True)\n"
+            "    os._exit(7 if e.status == capi.ERR_TIMEOUT else 8)  # (the helper thread is parked inside RCCL: leave without the exit handlers)\n"
+            "sys.exit(0)\n") % ROOT
+    t0 = time.time()
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GMSX_COMM_TIMEOUT_S="5"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 7, (r.returncode, r.stdout, r.stderr[-600:])
+    assert time.time() - t0 < 60

@@ -57,3 +57,19 @@ def test_driver_two_ranks_one_device_fails_cleanly(gpu):
     assert "a rank ended with status" in r.stderr, r.stderr[-1500:]
     assert dt < 120, dt                                              # not a hang: rank 0 was stopped, not left in a collective
     assert set(glob.glob("/tmp/gmsx_driver_id_*")) == before         # the id file is gone
+
+
+def test_bench_rank_that_dies_before_the_id_broadcast_takes_the_job_down(gpu, tmp_path):
+    """rank 1 of a two-rank `bench.py` dies right after the process group is up — before the communicator id is broadcast, before any
+    collective.  Rank 0 must not be left waiting: the job ends non-zero within a minute, and nothing re-execs (every process that initialised the GPU
+    either finishes or exits; the launcher reaps).  GMSX_COMM_TIMEOUT_S bounds both the library's communicator and the control plane's waits."""
+    env = dict(os.environ, GMSX_SHARE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", GMSX_BENCH_TEST_DIE_RANK="1", GMSX_COMM_TIMEOUT_S="10")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "16", "--steps", "1", "--warmup", "1", "--cache-dir",
+           str(tmp_path / "cache")]
+    t0 = time.time()
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    dt = time.time() - t0
+    assert r.returncode != 0, r.stdout[-1000:]
+    assert dt < 60, dt
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]   # no result line from a job that lost a rank
