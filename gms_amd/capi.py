@@ -21,6 +21,7 @@ RELABEL_NEVER, RELABEL_AUTO, RELABEL_ALWAYS = 0, 1, 2
 TC_AUTO, TC_ORIENTED, TC_FULL = 0, 1, 2
 UPLOAD_DEFAULT, UPLOAD_TRUSTED, UPLOAD_FOR_TC = 0, 1, 2
 PREPARE_TC = 1
+SETOP_INTERSECT, SETOP_DIFFERENCE = 0, 1
 OK, ERR_INVALID, ERR_NOMEM, ERR_IO, ERR_FORMAT, ERR_DIRECTED, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
 ERR_DEVICE_MEM, ERR_NOT_CANONICAL, ERR_OVERFLOW, ERR_UNSUPPORTED, ERR_KERNEL, ERR_COMM, ERR_TIMEOUT = -7, -8, -9, -10, -11, -12, -13
 COMM_ID_BYTES = 128
@@ -36,7 +37,7 @@ SYMBOLS = [
     "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_upload_shard", "gmsx_graph_upload_csr_shard", "gmsx_graph_prepare", "gmsx_graph_tc_passes", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
     "gmsx_graph_device_bytes", "gmsx_graph_max_out_degree",
     "gmsx_tc_total", "gmsx_tc_partial", "gmsx_tc_divisor", "gmsx_tc_stream_breakdown", "gmsx_tc_row_histogram", "gmsx_tc_comembership", "gmsx_tc_vertex_count2",
-    "gmsx_intersect_count_batch", "gmsx_vertex_similarity_batch", "gmsx_kclique_count", "gmsx_kclique_partial", "gmsx_kclique_star_count", "gmsx_bk_count", "gmsx_bk_partial",
+    "gmsx_intersect_count_batch", "gmsx_set_op_batch", "gmsx_vertex_similarity_batch", "gmsx_kclique_count", "gmsx_kclique_partial", "gmsx_kclique_star_count", "gmsx_bk_count", "gmsx_bk_partial",
     "gmsx_adg_rank", "gmsx_tc_ordering",
     "gmsx_comm_unique_id", "gmsx_comm_init", "gmsx_comm_allreduce_u64", "gmsx_comm_rank", "gmsx_comm_size", "gmsx_comm_finalize",
 ]
@@ -116,6 +117,7 @@ def lib():
     L.gmsx_tc_comembership.argtypes = [vp, C.c_int, np.ctypeslib.ndpointer(np.uint64, flags="C_CONTIGUOUS")]
     L.gmsx_tc_vertex_count2.argtypes = [vp, _i64p, sp]
     L.gmsx_intersect_count_batch.argtypes = [vp, C.c_int64, _i32p, _i32p, _u32p, sp]
+    L.gmsx_set_op_batch.argtypes = [vp, C.c_int, C.c_int64, _i32p, _i32p, _i64p, C.c_void_p, C.c_int64, sp]
     L.gmsx_vertex_similarity_batch.argtypes = [vp, C.c_int, C.c_int64, _i32p, _i32p, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS"), sp]
     L.gmsx_kclique_count.argtypes = [vp, C.c_int, u64p, u64p, sp]
     L.gmsx_kclique_partial.argtypes = [vp, C.c_int, C.c_int, C.c_int, u64p, sp]
@@ -330,6 +332,20 @@ class DeviceGraph:
                "gmsx_intersect_count_batch")
         out = out[:u.size]
         return (out, st.as_dict()) if stats else out
+
+    def set_op_batch(self, op, u, v, stats=False):
+        """gmsx_set_op_batch: (offsets[n_pairs + 1], ids) of N(u[i]) ∩ N(v[i]) (op = "intersect") or N(u[i]) \\ N(v[i]) ("difference"), ascending — the sizing
+        call first, then the fill into an array of exactly that size."""
+        code = {"intersect": SETOP_INTERSECT, "difference": SETOP_DIFFERENCE}[op]
+        u = np.ascontiguousarray(u, dtype=np.int32)
+        v = np.ascontiguousarray(v, dtype=np.int32)
+        uu, vv = (u if u.size else np.zeros(1, np.int32)), (v if v.size else np.zeros(1, np.int32))
+        off, st = np.zeros(u.size + 1, dtype=np.int64), Stats()
+        _check(lib().gmsx_set_op_batch(self._h, code, u.size, uu, vv, off, None, 0, C.byref(st)), "gmsx_set_op_batch (sizing)")
+        ids = np.zeros(max(int(off[-1]), 1), dtype=np.int32)
+        _check(lib().gmsx_set_op_batch(self._h, code, u.size, uu, vv, off, ids.ctypes.data_as(C.c_void_p), int(off[-1]), C.byref(st)), "gmsx_set_op_batch")
+        ids = ids[:int(off[-1])]
+        return (off, ids, st.as_dict()) if stats else (off, ids)
 
     SIM = {"jaccard": 0, "overlap": 1, "adamic_adar": 2, "resource": 3, "common_neighbors": 4, "total_neighbors": 5, "pref_attachment": 6}
 

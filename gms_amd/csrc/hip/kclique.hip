@@ -50,9 +50,17 @@ __device__ __forceinline__ uint32_t kc_bit_hi(const uint32_t *bm, uint32_t p) {
     return __builtin_amdgcn_ubfe(bm[q >> 5], q, 1u);
 }
 __device__ __forceinline__ void kc_probe8(const uint32_t *bm, const unsigned short *pre, uint32_t *orow, kc_u4u p) {
+#ifdef GMSX_KC_NO_PROBE  // A/B build (wrong counts): the row loads without their probes
+    if ((p.x ^ p.y ^ p.z ^ p.w) == 0x12345678u) orow[0] = 1u;
+    return;
+#endif
     uint32_t mask = kc_bit_lo(bm, p.x) | (kc_bit_hi(bm, p.x) << 1) | (kc_bit_lo(bm, p.y) << 2) | (kc_bit_hi(bm, p.y) << 3) |
                     (kc_bit_lo(bm, p.z) << 4) | (kc_bit_hi(bm, p.z) << 5) | (kc_bit_lo(bm, p.w) << 6) | (kc_bit_hi(bm, p.w) << 7);
     const unsigned long long lo = (unsigned long long)p.x | ((unsigned long long)p.y << 32), hi = (unsigned long long)p.z | ((unsigned long long)p.w << 32);
+#ifdef GMSX_KC_NO_HITS  // A/B build (wrong counts): the probes without the resolution of their hits
+    if (mask == 0xdeadu) orow[0] = 1u;
+    mask = 0;
+#endif
     while (mask) {
         const int s = __ffs(mask) - 1;
         mask &= mask - 1;
@@ -112,6 +120,10 @@ __device__ __forceinline__ void kc_stream_list(const uint16_t *__restrict__ row,
 }
 
 __device__ __forceinline__ void kc_and_word(uint32_t x, uint32_t pivot_word, int k, const unsigned short *pre, uint32_t *orow) {
+#if defined(GMSX_KC_NO_HITS) || defined(GMSX_KC_NO_PROBE)
+    if (x == 0xdeadbeefu) orow[0] = 1u;
+    x = 0;
+#endif
     while (x) {
         const int b = __ffs(x) - 1;
         x &= x - 1;

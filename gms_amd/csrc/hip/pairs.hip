@@ -13,6 +13,8 @@
 
 #include <algorithm>
 
+#include <rocprim/device/device_scan.hpp>
+
 namespace gmsx {
 
 // |A ∩ B| for two ascending rows; wave-uniform arguments; returns the wave-uniform count
@@ -59,6 +61,62 @@ __global__ __launch_bounds__(256) void k_pair_batch(const int64_t *__restrict__ 
         const uint32_t c = wave_intersect_count(adj + off[u], off[u + 1] - off[u], adj + off[v], off[v + 1] - off[v], lane);
         if (lane == 0) out[p] = c;
     }
+}
+
+// Materialising set operations on full rows (round 5; the base of the LISTING consumers — BK's non-count mode, tomita.h:51-86, the k-clique-star
+// output, k_clique_star_list/parallel/output.h:14-68 — which need the sets themselves, not their sizes):
+//   SortedSetBase::intersect / difference    gms/representations/sets/sorted_set.h:160-197 -> sorted_set_operations.h:16-42, 73-99
+// for a batch of vertex pairs, CSR-shaped: pass 1 counts (k_pair_batch above, |A \ B| = |A| - |A ∩ B|), an exclusive scan places the results,
+// pass 2 — this kernel — streams one row again (the shorter one for an intersection: either order gives the same ascending result; N(u) for
+// N(u) \ N(v)), binary-searches the other and writes the kept ids behind the wave's running offset by ballot + prefix popcount: ascending, as the
+// reference's merges emit them.
+template <bool DIFF>
+__global__ __launch_bounds__(256) void k_pair_fill(const int64_t *__restrict__ off, const int32_t *__restrict__ adj, int64_t n, int64_t n_pairs,
+                                                   const int32_t *__restrict__ pu, const int32_t *__restrict__ pv, const int64_t *__restrict__ out_off,
+                                                   int32_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    for (int64_t p = wave0; p < n_pairs; p += nwaves) {
+        const int32_t u = pu[p], v = pv[p];
+        if (u < 0 || v < 0 || u >= n || v >= n) continue;  // (flagged by the count pass: the call fails)
+        const int32_t *a = adj + off[u], *b = adj + off[v];
+        int64_t la = off[u + 1] - off[u], lb = off[v + 1] - off[v];
+        if (!DIFF && la > lb) {  // stream the shorter, search the longer
+            const int32_t *t = a; a = b; b = t;
+            const int64_t tl = la; la = lb; lb = tl;
+        }
+        int64_t at = out_off[p];
+        for (int64_t base = 0; base < la; base += 64) {
+            const int64_t i = base + lane;
+            bool keep = false;
+            int32_t x = 0;
+            if (i < la) {
+                x = a[i];
+                int64_t lo = 0, hi = lb;
+                while (lo < hi) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (b[mid] < x) lo = mid + 1; else hi = mid;
+                }
+                const bool hit = lo < lb && b[lo] == x;
+                keep = DIFF ? !hit : hit;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) out[at + __popcll(m & lt)] = x;
+            at += __popcll(m);
+        }
+    }
+}
+// counts of pass 1 -> sizes of the results (uint32 -> int64, |A \ B| = |A| - |A ∩ B|), scanned in place by the caller
+__global__ void k_pair_sizes(const int64_t *__restrict__ off, int64_t n, int64_t n_pairs, const int32_t *__restrict__ pu, const int32_t *__restrict__ pv,
+                             const uint32_t *__restrict__ cnt, int diff, int64_t *__restrict__ sizes) {
+    const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (p > n_pairs) return;
+    if (p == n_pairs) { sizes[p] = 0; return; }
+    const int32_t u = pu[p];
+    const bool ok = u >= 0 && u < n && pv[p] >= 0 && pv[p] < n;
+    sizes[p] = !ok ? 0 : diff ? (off[u + 1] - off[u]) - int64_t(cnt[p]) : int64_t(cnt[p]);
 }
 
 // Vertex similarity (vertex_similarity/vertex_similarity.h:30-222): one wave per pair.  Count-based metrics reuse
@@ -313,6 +371,74 @@ int gmsx_intersect_count_batch(const gmsx_graph *g, int64_t n_pairs, const int32
             *stats = gmsx_stats{double(ms), 0.0, uint64_t(n_pairs), 0, 0, 1, 0};
         }
         return bad ? GMSX_ERR_INVALID : GMSX_OK;  // a vertex id outside [0, n)
+    });
+}
+
+int gmsx_set_op_batch(const gmsx_graph *g, int op, int64_t n_pairs, const int32_t *u, const int32_t *v, int64_t *out_offsets, int32_t *out_ids, int64_t out_capacity,
+                      gmsx_stats *stats) {
+    return gmsx::guard([&]() -> int {
+        if (!g || n_pairs < 0 || !out_offsets || (op != GMSX_SETOP_INTERSECT && op != GMSX_SETOP_DIFFERENCE) || (n_pairs > 0 && (!u || !v)) || out_capacity < 0)
+            return GMSX_ERR_INVALID;
+        if (int rc = ensure_init()) return rc;
+        out_offsets[0] = 0;
+        if (n_pairs == 0) {
+            if (stats) *stats = gmsx_stats{0.0, 0.0, 0, 0, 0, 0, 0};
+            return GMSX_OK;
+        }
+        Ctx &c = ctx();
+        hipStream_t s = c.stream;
+        int32_t *du = nullptr, *dv = nullptr, *dout = nullptr;
+        uint32_t *dcnt = nullptr;
+        int64_t *dsz = nullptr, *doff = nullptr;
+        unsigned long long *flags = nullptr;
+        void *tmp = nullptr;
+        struct Guard { void *p = nullptr; ~Guard() { (void)hipFree(p); } } g1, g2, g3, g4, g5, g6, g7, g8;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&du), size_t(n_pairs) * 4)); g1.p = du;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dv), size_t(n_pairs) * 4)); g2.p = dv;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dcnt), size_t(n_pairs) * 4)); g3.p = dcnt;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dsz), size_t(n_pairs + 1) * 8)); g4.p = dsz;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&doff), size_t(n_pairs + 1) * 8)); g5.p = doff;
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&flags), 8)); g6.p = flags;
+        GMSX_HIP(hipMemcpyAsync(du, u, size_t(n_pairs) * 4, hipMemcpyHostToDevice, s));
+        GMSX_HIP(hipMemcpyAsync(dv, v, size_t(n_pairs) * 4, hipMemcpyHostToDevice, s));
+        GMSX_HIP(hipMemsetAsync(flags, 0, 8, s));
+        GMSX_HIP(hipEventRecord(c.ev[0], s));
+        const int64_t blocks = std::min<int64_t>((n_pairs + 3) / 4, int64_t(c.compute_units > 0 ? c.compute_units : 256) * 32);
+        hipLaunchKernelGGL(k_pair_batch, dim3(unsigned(blocks)), dim3(256), 0, s, g->off, g->adj, g->n, n_pairs, du, dv, dcnt, flags);
+        hipLaunchKernelGGL(k_pair_sizes, dim3(unsigned(n_pairs / 256 + 1)), dim3(256), 0, s, g->off, g->n, n_pairs, du, dv, dcnt, op == GMSX_SETOP_DIFFERENCE ? 1 : 0, dsz);
+        size_t tb = 0;
+        GMSX_HIP(rocprim::exclusive_scan(nullptr, tb, dsz, doff, int64_t(0), size_t(n_pairs + 1), rocprim::plus<int64_t>(), s));
+        GMSX_HIP(hipMalloc(&tmp, tb ? tb : 8)); g7.p = tmp;
+        GMSX_HIP(rocprim::exclusive_scan(tmp, tb, dsz, doff, int64_t(0), size_t(n_pairs + 1), rocprim::plus<int64_t>(), s));
+        unsigned long long bad = 0;
+        GMSX_HIP(hipMemcpyAsync(out_offsets, doff, size_t(n_pairs + 1) * 8, hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipMemcpyAsync(&bad, flags, 8, hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        if (bad) return GMSX_ERR_INVALID;  // a vertex id outside [0, n)
+        const int64_t total = out_offsets[n_pairs];
+        int launches = 3;
+        if (out_ids && total > out_capacity) return GMSX_ERR_INVALID;  // the offsets say how much room the result needs
+        if (out_ids && total > 0) {
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&dout), size_t(total) * 4)); g8.p = dout;
+            if (op == GMSX_SETOP_DIFFERENCE)
+                hipLaunchKernelGGL(k_pair_fill<true>, dim3(unsigned(blocks)), dim3(256), 0, s, g->off, g->adj, g->n, n_pairs, du, dv, doff, dout);
+            else
+                hipLaunchKernelGGL(k_pair_fill<false>, dim3(unsigned(blocks)), dim3(256), 0, s, g->off, g->adj, g->n, n_pairs, du, dv, doff, dout);
+            ++launches;
+            GMSX_HIP(hipEventRecord(c.ev[1], s));
+            GMSX_HIP(hipGetLastError());
+            GMSX_HIP(hipMemcpyAsync(out_ids, dout, size_t(total) * 4, hipMemcpyDeviceToHost, s));
+            GMSX_HIP(hipStreamSynchronize(s));
+        } else {
+            GMSX_HIP(hipEventRecord(c.ev[1], s));
+            GMSX_HIP(hipStreamSynchronize(s));
+        }
+        if (stats) {
+            float ms = 0.f;
+            GMSX_HIP(hipEventElapsedTime(&ms, c.ev[0], c.ev[1]));
+            *stats = gmsx_stats{double(ms), 0.0, uint64_t(n_pairs), 0, 0, launches, 0};
+        }
+        return GMSX_OK;
     });
 }
 

@@ -226,6 +226,14 @@ int gmsx_tc_vertex_count2(const gmsx_graph *g, int64_t *counts /* n, host */, gm
  * out[i] = |N(u[i]) ∩ N(v[i])| on the full rows.  u, v, out are host arrays. */
 int gmsx_intersect_count_batch(const gmsx_graph *g, int64_t n_pairs, const int32_t *u, const int32_t *v,
                                uint32_t *out, gmsx_stats *stats);
+/* Set::intersect / Set::difference (sorted_set.h:160-197 -> sorted_set_operations.h:16-42, 73-99) MATERIALISED for a batch of vertex pairs —
+ * result i = N(u[i]) ∩ N(v[i]) or N(u[i]) \ N(v[i]), ascending vertex ids of the uploaded CSR, CSR-shaped: out_offsets[n_pairs + 1] (host, always
+ * filled) and out_ids (host).  out_ids == NULL is the sizing call (count pass + scan only); with out_ids the result must fit out_capacity ids, else
+ * GMSX_ERR_INVALID (out_offsets[n_pairs] says how many it needs).  Two passes of one wave per pair (count, scan, fill): the base of the listing
+ * consumers (BK without BK_COUNT, tomita.h:75-84; k-clique-star output, k_clique_star_list/parallel/output.h:14-68). */
+enum { GMSX_SETOP_INTERSECT = 0, GMSX_SETOP_DIFFERENCE = 1 };
+int gmsx_set_op_batch(const gmsx_graph *g, int op, int64_t n_pairs, const int32_t *u, const int32_t *v, int64_t *out_offsets /* n_pairs + 1 */,
+                      int32_t *out_ids /* may be NULL */, int64_t out_capacity, gmsx_stats *stats);
 
 /* ---- vertex similarity over graph rows: GMS::VertexSim::vertex_similarity<Metric> (gms/algorithms/set_based/vertex_similarity/
  * vertex_similarity.h:30-222), the scores behind the reference's link-prediction driver.  out[i] = metric(N(u[i]), N(v[i])) in

@@ -530,4 +530,22 @@ inline void triangle_count_ordering(const HipGraphT<S> &g, Output &ordering) {
     detail::check(gmsx_tc_ordering(g.device(), reinterpret_cast<int32_t *>(ordering.data()), nullptr), "gmsx_tc_ordering");
 }
 
+// Set::intersect / Set::difference of whole neighbourhoods for a BATCH of vertex pairs on the device (sorted_set.h:160-197): result i =
+// out_neigh(u[i]) ∩ out_neigh(v[i]) (difference = false) or out_neigh(u[i]) \ out_neigh(v[i]), as sets of the graph's own flavour — what a
+// listing consumer (tomita.h:51-70 with `sol`, k_clique_star_list/parallel/output.h:14-68) hands on.  One sizing call, one fill.
+template <class S, class Ids>
+inline std::vector<S> set_op_batch(const HipGraphT<S> &g, const Ids &u, const Ids &v, bool difference = false) {
+    const int64_t np = int64_t(u.size());
+    std::vector<int32_t> uu(u.begin(), u.end()), vv(v.begin(), v.end());
+    std::vector<int64_t> off(size_t(np) + 1, 0);
+    const int op = difference ? GMSX_SETOP_DIFFERENCE : GMSX_SETOP_INTERSECT;
+    detail::check(gmsx_set_op_batch(g.device(), op, np, uu.data(), vv.data(), off.data(), nullptr, 0, nullptr), "gmsx_set_op_batch");
+    std::vector<int32_t> ids(size_t(off[size_t(np)]) + 1);
+    detail::check(gmsx_set_op_batch(g.device(), op, np, uu.data(), vv.data(), off.data(), ids.data(), off[size_t(np)], nullptr), "gmsx_set_op_batch");
+    std::vector<S> out;
+    out.reserve(size_t(np));
+    for (int64_t i = 0; i < np; ++i) out.emplace_back(ids.data() + off[size_t(i)], size_t(off[size_t(i) + 1] - off[size_t(i)]));  // (owning copies)
+    return out;
+}
+
 }  // namespace gmsx

@@ -137,6 +137,12 @@ int main() {
         unsigned sum = 0;
         for (auto v : rg.out_neigh(2)) sum += v;  // uint32 iteration
         CHECK(sum == 4 && rg.out_neigh(2).intersect_count(rg.out_neigh(0)) == 1);
+        if (std::getenv("GMSX_TEST_DEVICE_SET_OPS")) {  // (instantiated for every flavour on every build; executed only where a device is: the GPU adaptor test)
+            auto both = gmsx::set_op_batch(hg, std::vector<int>{0, 2}, std::vector<int>{1, 0});
+            auto left = gmsx::set_op_batch(rg, std::vector<int>{2}, std::vector<int>{0}, true);
+            CHECK(both.size() == 2 && vec(both[0]) == (std::vector<int>{2}) && vec(both[1]) == (std::vector<int>{1}));
+            CHECK(left.size() == 1 && left[0].cardinality() == 2 && left[0].contains(0) && left[0].contains(3));
+        }
         gmsx::HipSetRefGraph fg = gmsx::HipSetRefGraph::FromCsr(csr);
         CHECK(fg.out_neigh(2).cardinality() == 3 && fg.out_neigh(2).intersect_count(fg.out_neigh(0)) == 1);
         // a graph uploaded as a shard stays that shard when it is moved (count_total of a moved rank graph asked gmsx_tc_total for the

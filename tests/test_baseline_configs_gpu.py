@@ -171,10 +171,17 @@ def test_config5_scale27_eight_shards_on_one_gpu(gpu):
     g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_TRUSTED)
     del csr
     total = g.tc_total()
-    parts = [min((g.tc_partial(p, 8, stats=True) for _ in range(3)), key=lambda r: r[1]["kernel_ms"]) for p in range(8)]  # best of 3 per shard:
-    assert sum(p[0] for p in parts) == total                        # a single timing on a shared box carries +-10 %
+    # the REFERENCE's count of this graph (round 5): Par::count_total on the reference's RoaringSet / intersect_count, accumulated over
+    # five id-range slices of the neighbourhoods because the whole RoaringGraph (~90 GB) does not fit the 62 GB build container
+    # (tools/make_golden_big.py tc-sliced 27 16 5, oracle/ref_shim.cc ref_tc_total_sliced; equal to the unsliced call wherever that fits)
+    rec = GRAPHS.get("kronecker-27-16-relabel")
+    if not (rec and "triangles" in rec):
+        pytest.fail("tests/golden/graphs.json holds no reference golden for scale 27 (run tools/make_golden_big.py tc-sliced 27 16 5)")
+    assert (rec["n"], rec["m"]) == (134217728, 2111632322)
+    assert total == rec["triangles"], (total, rec["triangles"])
+    parts = [g.tc_partial(p, 8, stats=True) for p in range(8)]
+    assert sum(p[0] for p in parts) == total
     assert sum(p[1]["units"] for p in parts) == g.num_edges
-    ms = [p[1]["kernel_ms"] for p in parts]
-    assert max(ms) < 1.2 * min(ms), ms                             # cost-balanced shards (round 3 measured 28.6–28.9 ms each)
+    # (how evenly the eight shards are loaded is a measurement, not a parity property: tools/tc_probe.py 27 --shards 8 -> profiles/r05/tc27_shards.json)
     assert g.kclique_count(3)[1] == total
     g.free()

@@ -45,6 +45,10 @@ def test_set_op_goldens_through_the_batch_kernel(gpu):
         csr = edges_to_csr(gpu, edges, n=n)
         g = gpu.DeviceGraph.from_csr(csr)
         assert int(g.intersect_count_batch([x], [y])[0]) == case["expect"]["intersect_count"]
+        # … and the materialised results (round 5): the reference's intersect / difference lists of the same cases
+        for op in ("intersect", "difference"):
+            o, ids = g.set_op_batch(op, [x], [y])
+            assert ids.tolist() == case["expect"][op] and o.tolist() == [0, len(case["expect"][op])], (case["a"], case["b"], op)
         g.free()
 
 
@@ -106,3 +110,68 @@ def test_vertex_similarity_batch(gpu, oracle):
         got = g.vertex_similarity_batch(name, u, v)
         assert np.allclose(got, want, rtol=1e-12, atol=0.0, equal_nan=True), name
     g.free()
+
+
+def test_set_op_batch_materialises_intersect_and_difference(gpu, oracle):
+    """gmsx_set_op_batch (round 5): Set::intersect / Set::difference of full rows, MATERIALISED for a batch of pairs (count pass, scan, fill pass).
+    Bit-equal to the oracle's merges (oracle/gms_oracle.c: sorted_set_operations.h:16-42, 73-99) and — where the compiled reference is on the box
+    — to the reference's own SortedSet and RoaringSet operators; ascending ids, CSR-shaped offsets, hubs / random / equal / isolated vertices."""
+    csr = host_graph(gpu, "kronecker", 13, 16, True)
+    off, ng = csr.offsets(), csr.neighbors()
+    g = gpu.DeviceGraph.from_csr(csr)
+    rng = np.random.default_rng(23)
+    n = csr.num_nodes
+    iso = np.flatnonzero(np.diff(off) == 0)[:20]
+    u = np.concatenate([rng.integers(0, n, 2000), rng.integers(0, 64, 300), np.arange(40), iso, rng.integers(0, 64, iso.size)]).astype(np.int32)
+    v = np.concatenate([rng.integers(0, n, 2000), rng.integers(0, 64, 300), np.arange(40), rng.integers(0, 64, iso.size), iso]).astype(np.int32)
+    ref = None
+    try:
+        from oracle import bindings
+        if bindings.have_ref():
+            ref = bindings.Reference()
+    except Exception:  # noqa: BLE001
+        ref = None
+    for op in ("intersect", "difference"):
+        o, ids, st = g.set_op_batch(op, u, v, stats=True)
+        assert o.shape == (u.size + 1,) and o[0] == 0 and np.all(np.diff(o) >= 0) and ids.size == o[-1] and st["units"] == u.size
+        for i, (a, b) in enumerate(zip(u, v)):
+            ra, rb = ng[off[a]:off[a + 1]], ng[off[b]:off[b + 1]]
+            want = oracle.intersect(ra, rb) if op == "intersect" else oracle.difference(ra, rb)
+            got = ids[o[i]:o[i + 1]]
+            assert np.array_equal(got, want), (op, i, a, b)
+            if ref is not None and i % 37 == 0 and ra.size and rb.size:
+                for kind in (ref.SORTED, ref.ROARING):
+                    assert np.array_equal(got, ref.set_op(kind, op, ra, rb)), (op, i, kind)
+        cnt = g.intersect_count_batch(u, v).astype(np.int64)
+        assert np.array_equal(np.diff(o), cnt if op == "intersect" else np.diff(off)[u] - cnt)
+    # N(u) ∩ N(u) = N(u), N(u) \ N(u) = {}
+    o, ids = g.set_op_batch("intersect", np.arange(30), np.arange(30))
+    assert np.array_equal(ids, ng[:off[30]]) and np.array_equal(o, off[:31])
+    o, ids = g.set_op_batch("difference", np.arange(30), np.arange(30))
+    assert ids.size == 0 and not o.any()
+    o, ids = g.set_op_batch("intersect", [], [])
+    assert o.tolist() == [0] and ids.size == 0
+    # errors: a vertex id outside the graph; a result that does not fit the caller's array (the offsets still say what it needs)
+    with pytest.raises(gpu.GmsxError) as ei:
+        g.set_op_batch("intersect", [0, n], [1, 1])
+    assert ei.value.status == gpu.ERR_INVALID
+    import ctypes as C
+    uu, vv = np.array([0, 1], np.int32), np.array([1, 0], np.int32)
+    o = np.zeros(3, np.int64)
+    small = np.zeros(1, np.int32)
+    rc = gpu.lib().gmsx_set_op_batch(g._h, gpu.SETOP_INTERSECT, 2, uu, vv, o, small.ctypes.data_as(C.c_void_p), 1, None)
+    assert rc == gpu.ERR_INVALID and o[2] == 2 * int(g.intersect_count_batch([0], [1])[0]) > 1
+    g.free()
+
+
+def test_cpp_adaptor_set_op_batch_on_the_device(gpu, tmp_path):
+    """The C++ adaptor's gmsx::set_op_batch (include/gmsx_set_graph.hpp) over HipSetGraph and HipRoaringGraph: tests/cpp/test_set_concept.cpp with its
+    device block switched on."""
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "t")
+    cmd = ["g++", "-std=c++17", "-O1", "-fopenmp", "-w", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_set_concept.cpp"),
+           "-L", os.path.join(ROOT, "gms_amd", "lib"), "-lgmsx", "-Wl,-rpath," + os.path.join(ROOT, "gms_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.run(cmd, check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, env=dict(os.environ, GMSX_TEST_DEVICE_SET_OPS="1")).stdout
+    assert "set concept ok" in out
