@@ -431,10 +431,91 @@ __device__ __forceinline__ unsigned long long kc4_row(const uint32_t (&wt)[WPL],
             const int tmax = __builtin_amdgcn_readlane(tj, min(63, nb - c0 - 1));  // ranks ascend with the lane: the last active lane has the largest word index
             const uint32_t *rj = band + size_t(j - j0) * BS;
             uint32_t acc = 0;
+#ifdef GMSX_KC_NO_INNER  // A/B build (wrong counts): the k = 4 count without its AND + popcount loops (what finding the neighbours alone takes)
+            acc = uint32_t(rj[0] & 1u) + uint32_t(tmax);
+#else
 #pragma unroll
             for (int g = 0; g < WPL; ++g)
                 if (tmax >= 64 * g) acc += kc4_and_popc(wt[g], rj + 64 * g, min(tmax - 64 * g, 63) + 1);
+#endif
             if (act) total += acc;
+        }
+    }
+    return total;
+}
+
+// k = 4 count of a whole LDS bit-matrix, by PAIR LISTS (round 5):  Σ_i Σ_{j ∈ rows[i]} popc(rows[i] & rows[j]).
+// Measured on round 4's kernels (k = 4, scale 22): with the AND + popcount loops compiled out of kc4_row the call still took 20.9 of 22.6 ms — finding
+// the neighbours j of a row (a 64-lane prefix scan, a six-step binary search and a five-step select per row, for 33 neighbours on average) cost five
+// times what the intersections did; the narrower matrices' lane-per-word loop idled behind its longest lane.  Here a wave takes 64 matrix cells of ONE
+// COLUMN WORD w — rows 64 b … 64 b + 63 — writes their set bits (i, j) into its own LDS pair buffer behind one wave prefix sum, and then every lane
+// intersects one pair: all pairs of the task have j in word w, so every lane walks exactly the words 0 … w of its two rows (row j has no bit at or
+// above j) — full lanes, one trip count, no search.  A task with more pairs than the buffer holds is taken in runs of lanes.
+__device__ __forceinline__ unsigned long long kc4_count_pairs(const uint32_t *rows, int WS, int d, int W, uint32_t *wbuf, int cap, int *next_task, int lane) {
+    unsigned long long total = 0;
+    d = uni32(d);
+    const int nblk = (d + 63) >> 6, ntask = W * nblk;
+    while (true) {
+        // tasks from a workgroup-wide ticket counter in LDS (zeroed before the barrier in front of the count), the long ones first: the waves of a
+        // workgroup end together.  The ticket is pinned to a scalar register: the task, its column word w and the trip count of the intersections below
+        // are then scalar — a loop the compiler unrolls and waits for once, not an exec-masked one
+        int task = 0;
+        if (lane == 0) task = atomicAdd(next_task, 1);
+        task = uni32(task);
+        if (task >= ntask) break;
+        const int w = W - 1 - task / nblk, blk = task % nblk;  // the long tasks (high column words) first
+        const int i = blk * 64 + lane;
+        uint32_t bits = (i < d && (w << 5) < i) ? rows[size_t(i) * WS + w] : 0u;
+#ifdef GMSX_KC_CELLS_ONLY  // A/B build (wrong counts): the count phase reads the matrix cells and nothing else
+        total += __popc(bits);
+        bits = 0u;
+#endif
+        while (__ballot(bits != 0u) != 0) {  // wave-uniform
+            const int pc = __popc(bits);
+            // inclusive prefix over the 64 lanes without an LDS round trip (six dependent ds_bpermutes per task were a third of the phase): DPP row_shr
+            // scans inside the four rows of 16, then the totals of the rows in front through three v_readlanes
+            int incl = pc;
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);
+            {
+                const int t0 = __builtin_amdgcn_readlane(incl, 15), t1 = __builtin_amdgcn_readlane(incl, 31), t2 = __builtin_amdgcn_readlane(incl, 47);
+                incl += (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+            }
+            const bool fits = incl <= cap;  // a run of lanes from lane 0 on (a cell has at most 32 pairs <= cap: at least one lane)
+            const int nfit = __popcll(__ballot(fits));
+            const int npairs = __builtin_amdgcn_readlane(incl, uni32(nfit - 1));
+            if (fits) {
+                int at = incl - pc;
+                while (bits) {
+                    wbuf[at++] = (uint32_t(i) << 16) | uint32_t((w << 5) + __ffs(bits) - 1);
+                    bits &= bits - 1u;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int c0 = 0; c0 < npairs; c0 += 64) {
+                const int r = c0 + lane;
+                const bool act = r < npairs;
+                const uint32_t pr = wbuf[act ? r : 0];
+                const uint32_t *ri = rows + size_t(pr >> 16) * WS, *rj = rows + size_t(pr & 0xffffu) * WS;
+                uint32_t acc = 0;
+                int q = 0;
+#ifdef GMSX_KC_NO_INNER
+                acc = (ri[0] ^ rj[0]) & 1u;
+                q = w + 1;
+#endif
+                for (; q + 4 <= w + 1; q += 4) {
+                    const uint32_t a0 = ri[q], a1 = ri[q + 1], a2 = ri[q + 2], a3 = ri[q + 3];
+                    const uint32_t b0 = rj[q], b1 = rj[q + 1], b2 = rj[q + 2], b3 = rj[q + 3];
+                    acc += uint32_t(__popc(a0 & b0) + __popc(a1 & b1)) + uint32_t(__popc(a2 & b2) + __popc(a3 & b3));
+                }
+                for (; q <= w; ++q) acc += uint32_t(__popc(ri[q] & rj[q]));
+                if (act) total += acc;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     return total;
@@ -654,6 +735,11 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ unsigned long long red[16];
     __shared__ int wave_tot[16];
+#ifdef GMSX_KC_NO_PAIRS  // A/B build: round 4's k = 4 counts (kc4_row for wide matrices, one lane per matrix word for the others)
+    constexpr bool kc4_pairs_enabled = false;
+#else
+    constexpr bool kc4_pairs_enabled = !GLOBAL_ROWS;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nthreads = int(blockDim.x), nwaves = nthreads >> 6;  // 256 … 1024 threads: big LDS bit-matrices leave one workgroup per CU
     // WS = row stride in words: W for the wave-cooperative recursion (lane = word index), W + 1 for the lane-per-pair
@@ -774,6 +860,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop L1 lines of the slab cached for an earlier pivot
         } else {
+            if (tid == 0) wave_tot[0] = 0;  // the ticket counter of kc4_count_pairs (the prefix phase is long done with wave_tot)
             __syncthreads();
         }
 #ifdef GMSX_KC_BUILD_ONLY  // A/B build: what the BUILD phase alone takes (k = 4, scale 22: 12.4 of 22.6 ms)
@@ -867,6 +954,10 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                 if constexpr (WPL > 1) cand[1] = 64 + lane < W ? rows[size_t(i) * WS + 64 + lane] : 0u;
                 cnt += wave_cliques<LV, WPL>(rows, WS, cand, lane);
             }
+        } else if (LV == 2 && kc4_pairs_enabled) {
+            // k = 4 on an LDS matrix: pair lists in the dead bitmap / prefix area (12 KB), a share per wave (kc4_count_pairs)
+            uint32_t *wbuf = bm + size_t(wave) * size_t((kBitmapWords + kBitmapWords / 2) / nwaves);
+            cnt += kc4_count_pairs(rows, WS, d, W, wbuf, (kBitmapWords + kBitmapWords / 2) / nwaves, &wave_tot[0], lane);
         } else if (LV == 2 && W >= 22) {
             // k = 4, wide matrix in LDS: a single band (the whole matrix), one row per wave and trip.  (Below ~700 vertices
             // the per-row prefix / select overhead of kc4_row exceeds what its divergence-free inner loop saves.)
