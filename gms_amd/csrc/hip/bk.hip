@@ -1018,7 +1018,12 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
                                                 const int32_t *__restrict__ dplus, const int32_t *__restrict__ task_v,
                                                 int64_t first, int64_t end, int nparts, int part,
                                                 unsigned long long *__restrict__ queue, uint32_t *__restrict__ slabs,
-                                                unsigned long long slab_words, unsigned long long *__restrict__ acc, BkShared sh) {
+                                                unsigned long long slab_words, unsigned long long *__restrict__ acc, BkShared sh,
+                                                // LDS-slab tasks only (round 5, GMSX_BK_TINY_ROOTS): not searched here — Cadj | XT go to the arena and a ROOT
+                                                // RECORD to the pool, at offsets the layout scans computed per task, and k_bk_resume4 searches them four to a
+                                                // wave (a search of at most ~90 candidates keeps three of this kernel's 64 lanes busy)
+                                                const int64_t *__restrict__ emit_aoff = nullptr, const int64_t *__restrict__ emit_roff = nullptr,
+                                                unsigned long long emit_abase = 0, unsigned long long emit_rbase = 0, unsigned long long emit_dbase = 0) {
     __shared__ __attribute__((aligned(16))) uint32_t lds_slab[LDS_SLAB ? kLdsSlabWords : 4];
     // per level: is Xf non-empty (written by one lane, read by all); an LDS-slab task has < 256 candidates (its slab would not fit otherwise)
     constexpr int WR = WPL > 0 ? WPL : 1;  // WPL = 0: the memory-resident search keeps nothing of the search in LDS
@@ -1094,6 +1099,36 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
 #if defined(GMSX_BK_AB) && GMSX_BK_AB >= 3  // A/B build (wrong counts): the LDS tasks' build without their search
             if (LDS_SLAB) { cnt += Cadj[0] & 1u; continue; }
 #endif
+            if (LDS_SLAB && emit_aoff) {
+                const unsigned long long a0 = emit_abase + (unsigned long long)emit_aoff[qi], r0 = emit_rbase + (unsigned long long)emit_roff[qi];
+                const int words = c * cw + c * xw;  // Cadj, then XT: contiguous in the slab
+                uint32_t *dst = sh.arena + a0;
+                for (int i = lane; i < words; i += 64) dst[i] = Cadj[i];
+                uint32_t *rec = sh.pool + r0;
+                if (lane == 0) {
+                    rec[0] = uint32_t(v);
+                    rec[1] = uint32_t(c);
+                    rec[2] = uint32_t(x);
+                    rec[3] = x > 0 ? 1u : 0u;
+                    rec[4] = uint32_t(a0 & 0xffffffffull);
+                    rec[5] = uint32_t(a0 >> 32);
+                    rec[6] = 1u;  // root: enter the node
+                    rec[7] = 0u;
+                    sh.dir[emit_dbase + (unsigned long long)qi] = r0;
+                }
+                for (int w = lane; w < cw; w += 64) {
+                    const int bits = c - w * 32;
+                    rec[kRecHeader + w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);  // P = every candidate
+                    rec[kRecHeader + cw + w] = 0u;                                          // Xc
+                    rec[kRecHeader + 2 * cw + w] = 0u;                                      // ext (set by the pivot step)
+                }
+                for (int w = lane; w < xw; w += 64) {
+                    const int bits = x - w * 32;
+                    rec[kRecHeader + 3 * cw + w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);  // Xf = every in-neighbour
+                }
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
             bk_search<WR>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, x > 0 ? 1 : 0, true, lane, cnt, sh, kNoArena, !LDS_SLAB, piv_P, piv_list, node_words);
         }
         __builtin_amdgcn_wave_barrier();
@@ -2211,6 +2246,10 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     // the task sort above — allocations of gigabytes now and then stall for a second, they are not part of the kernels' time
     const int64_t cnt_glob = split_build ? part_count(0, n_glob, nparts, part) : 0;
     int64_t need_total = 0;  // arena words of the start vertices built by k_bk_block
+    const int64_t cnt_tiny = part_count(n_glob, n_tasks, nparts, part);
+    const bool tiny_roots = use_groups && split_build >= 2 && cnt_glob > 0 && [] { const char *e = std::getenv("GMSX_BK_TINY_ROOTS"); return e && std::atoi(e) != 0; }();
+    int64_t *t_need_a = nullptr, *t_need_r = nullptr, *t_need_p = nullptr, *t_aoff = nullptr, *t_roff = nullptr, tiny_a = 0, tiny_r = 0;
+    Guard g_tna, g_tnr, g_tnp, g_tao, g_tro;
     int64_t *need_a = nullptr, *need_r = nullptr, *aoff = nullptr, *roff = nullptr, *d_end = nullptr, *need_p = nullptr, *poff = nullptr;
     unsigned long long *pieces = nullptr;
     Guard g_na, g_nr, g_ao, g_ro, g_de, g_map, g_np, g_po, g_pc;
@@ -2247,10 +2286,34 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
             GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&pieces), size_t(n_pieces + 1) * 8)); g_pc.p = pieces;
             hipLaunchKernelGGL(k_bk_pieces, dim3(unsigned(cnt_glob / 256 + 1)), dim3(256), 0, s, cnt_glob, poff, pieces);
         }
+        // GMSX_BK_TINY_ROOTS=1 (off by default): the LDS-slab tasks are BUILT by k_bk_wave<true> and SEARCHED by k_bk_resume4 — they leave Cadj | XT in the arena
+        // and a root record in the pool, at offsets from the same kind of layout scans (their x = in-neighbours only: the wave build compacts them).  Measured
+        // on configs[3]: round 0 62 -> 55 ms (the build alone beside k_bk_block), round 1 32.8 -> 48.8 ms (1.65 M searches of ~33 nodes: a record fetch and a
+        // root pivot each) — 156 against 147.4 ms: their search in LDS, hidden beside the build, is the cheaper place
+        if (tiny_roots && cnt_tiny > 0) {
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&t_need_a), size_t(cnt_tiny + 1) * 8)); g_tna.p = t_need_a;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&t_need_r), size_t(cnt_tiny + 1) * 8)); g_tnr.p = t_need_r;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&t_need_p), size_t(cnt_tiny + 1) * 8)); g_tnp.p = t_need_p;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&t_aoff), size_t(cnt_tiny + 1) * 8)); g_tao.p = t_aoff;
+            GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&t_roff), size_t(cnt_tiny + 1) * 8)); g_tro.p = t_roff;
+            hipLaunchKernelGGL(k_bk_layout, dim3(unsigned(cnt_tiny / 256 + 1)), dim3(256), 0, s, n_glob, cnt_tiny, nparts, part, v_out, g->off, g->oldid, g->dplus, 0,
+                               t_need_a, t_need_r, t_need_p, maxima);
+            size_t scan_bytes = 0;
+            GMSX_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, t_need_a, t_aoff, int64_t(0), size_t(cnt_tiny + 1), rocprim::plus<int64_t>(), s));
+            void *scan_tmp = nullptr;
+            GMSX_HIP(hipMalloc(&scan_tmp, scan_bytes ? scan_bytes : 8));
+            Guard g_scan;
+            g_scan.p = scan_tmp;
+            GMSX_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, t_need_a, t_aoff, int64_t(0), size_t(cnt_tiny + 1), rocprim::plus<int64_t>(), s));
+            GMSX_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, t_need_r, t_roff, int64_t(0), size_t(cnt_tiny + 1), rocprim::plus<int64_t>(), s));
+            GMSX_HIP(hipStreamSynchronize(s));
+            GMSX_HIP(hipMemcpy(&tiny_a, t_aoff + cnt_tiny, 8, hipMemcpyDeviceToHost));
+            GMSX_HIP(hipMemcpy(&tiny_r, t_roff + cnt_tiny, 8, hipMemcpyDeviceToHost));
+        }
         GMSX_HIP(hipMemcpy(mx, maxima, sizeof(mx), hipMemcpyDeviceToHost));
         GMSX_HIP(hipMemcpy(&need_total, aoff + cnt_glob, 8, hipMemcpyDeviceToHost));
         // the roots may take 3/4 of the arena (below): everything in one chunk when the device allows, + room for the LDS-slab searches that split
-        if (int rc = alloc_arena((unsigned long long)need_total / 3 * 4 + (512ull << 20) / 4)) return rc;
+        if (int rc = alloc_arena((unsigned long long)need_total / 3 * 4 + (unsigned long long)tiny_a + (512ull << 20) / 4)) return rc;
         if (std::getenv("GMSX_BK_VERBOSE"))
             std::fprintf(stderr, "[gmsx bk] start vertices %lld: %lld built in the arena (%lld words), %lld in LDS slabs\n", (long long)n_tasks, (long long)cnt_glob,
                          (long long)need_total, (long long)(n_tasks - n_glob));
@@ -2281,7 +2344,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     if (cnt_glob > 0 && (mx[2] | mx[3] | mx[4]) != 0 && use_groups) {
         const unsigned long long slab_bytes = group_wave_words(mx[2], mx[3], mx[4]) * 4ull;
         if (slab_bytes <= budget_bytes) {
-            const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({(cnt_glob + 3) / 4, int64_t(cu) * group_waves_per_cu, int64_t(budget_bytes / slab_bytes)}));
+            const int64_t waves = std::max<int64_t>(1, std::min<int64_t>({(cnt_glob + (tiny_roots ? cnt_tiny : 0) + 3) / 4, int64_t(cu) * group_waves_per_cu, int64_t(budget_bytes / slab_bytes)}));
             group_cap = size_t(waves) * slab_bytes;
             GMSX_HIP(hipMalloc(&g_gslab.p, group_cap));
         }
@@ -2398,6 +2461,8 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
             }
         }
     } tiny_join{c, s, tiny_beside};
+    unsigned long long emit_abase = 0, emit_rbase = 0, emit_dbase = 0;
+    bool emit = false;  // set by the first chunk when the LDS-slab tasks' roots fit behind its own
     auto launch_tiny = [&](int64_t lo, int64_t hi, bool beside) -> int {
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (cnt <= 0) return GMSX_OK;
@@ -2410,7 +2475,8 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         }
         const int64_t waves = std::min<int64_t>(cnt, int64_t(cu) * 16);
         hipLaunchKernelGGL((k_bk_wave<true, 1>), dim3(unsigned(waves)), dim3(64), 0, st, g->off, g->adj, g->newid, g->oldid, g->hoff, g->hadj, g->toff, g->tadj,
-                           g->dplus, v_out, lo, hi, nparts, part, tqueue, static_cast<uint32_t *>(nullptr), 0ull, acc, sh);
+                           g->dplus, v_out, lo, hi, nparts, part, tqueue, static_cast<uint32_t *>(nullptr), 0ull, acc, sh,
+                           emit ? t_aoff : static_cast<const int64_t *>(nullptr), emit ? t_roff : static_cast<const int64_t *>(nullptr), emit_abase, emit_rbase, emit_dbase);
         ++launches;
         tiny_beside = st != s;
         return GMSX_OK;
@@ -2440,14 +2506,26 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 GMSX_HIP(hipMemcpy(&span[3], roff + q1, 8, hipMemcpyDeviceToHost));
                 if (uint64_t(span[1] - span[0]) > sh.arena_cap || uint64_t(span[3] - span[2]) > sh.pool_cap) return GMSX_ERR_DEVICE_MEM;  // one start vertex beyond the arena
                 // pool_head / dir_count / max_stack as if the roots had been split off by an earlier round; arena_head behind their structures
-                const unsigned long long ctl0[6] = {(unsigned long long)(span[3] - span[2]), (unsigned long long)(q1 - q0), mx[0], mx[2], mx[3], mx[4]};
-                const unsigned long long ah = (unsigned long long)(span[1] - span[0]);
+                unsigned long long ctl0[6] = {(unsigned long long)(span[3] - span[2]), (unsigned long long)(q1 - q0), mx[0], mx[2], mx[3], mx[4]};
+                unsigned long long ah = (unsigned long long)(span[1] - span[0]);
+                static const int tiny_mode = [] { const char *e = std::getenv("GMSX_BK_TINY_BESIDE"); return e ? std::atoi(e) : 1; }();
+                if (!tiny_done && tiny_roots && cnt_tiny > 0 && tiny_mode != 2 && ah + (unsigned long long)tiny_a + (64ull << 20) / 4 <= sh.arena_cap &&
+                    ctl0[0] + (unsigned long long)tiny_r <= sh.pool_cap / 4 * 3 && ctl0[1] + (unsigned long long)cnt_tiny <= sh.dir_cap) {
+                    emit = true;  // the LDS-slab tasks' structures and root records go behind this chunk's: round 1 searches both
+                    emit_abase = ah;
+                    emit_rbase = ctl0[0];
+                    emit_dbase = ctl0[1];
+                    ah += (unsigned long long)tiny_a;
+                    ctl0[0] += (unsigned long long)tiny_r;
+                    ctl0[1] += (unsigned long long)cnt_tiny;
+                }
+                const unsigned long long zero_words = (unsigned long long)(span[1] - span[0]);  // Cadj | XT the pieces of k_bk_block OR into
                 GMSX_HIP(hipMemcpyAsync(sh.pool_head, ctl0, sizeof(ctl0), hipMemcpyHostToDevice, s));
                 GMSX_HIP(hipMemcpyAsync(sh.arena_head, &ah, 8, hipMemcpyHostToDevice, s));
                 GMSX_HIP(hipMemsetAsync(bqueue, 0, 8, s));
                 int64_t pspan[2] = {0, 0};
                 if (split_build >= 2) {  // Cadj | XT of the chunk start empty: the pieces of a start vertex only OR into them
-                    GMSX_HIP(hipMemsetAsync(sh.arena, 0, size_t(ah) * 4, s));
+                    GMSX_HIP(hipMemsetAsync(sh.arena, 0, size_t(zero_words) * 4, s));
                     GMSX_HIP(hipMemcpyAsync(&pspan[0], poff + q0, 8, hipMemcpyDeviceToHost, s));
                     GMSX_HIP(hipMemcpyAsync(&pspan[1], poff + q1, 8, hipMemcpyDeviceToHost, s));
                 }

@@ -207,7 +207,7 @@ def test_bk_tiny_budget_splits_everything(gpu, oracle, budget):
                 os.environ[k_] = v
 
 
-@pytest.mark.parametrize("knobs", [{"GMSX_BK_GROUPS": "0"}, {"GMSX_BK_TINY_BESIDE": "2"}, {"GMSX_BK_SMALL_P_GROUPS": "0"},
+@pytest.mark.parametrize("knobs", [{"GMSX_BK_GROUPS": "0"}, {"GMSX_BK_TINY_BESIDE": "2"}, {"GMSX_BK_TINY_ROOTS": "1"}, {"GMSX_BK_SMALL_P_GROUPS": "0"},
                                    {"GMSX_BK_SMALL_P_GROUPS": "600"}, {"GMSX_BK_BUDGET": "40", "GMSX_BK_BUDGET0": "40", "GMSX_BK_SMALL_P_GROUPS": "0"},
                                    {"GMSX_BK_BUDGET": "24", "GMSX_BK_BUDGET0": "24", "GMSX_BK_GROUPS": "0"}])
 def test_bk_search_kernel_variants(gpu, oracle, knobs):
