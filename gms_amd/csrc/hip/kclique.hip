@@ -454,7 +454,9 @@ __device__ __forceinline__ unsigned long long kc4_row(const uint32_t (&wt)[WPL],
 __device__ __forceinline__ unsigned long long kc4_count_pairs(const uint32_t *rows, int WS, int d, int W, uint32_t *wbuf, int cap, int *next_task, int lane) {
     unsigned long long total = 0;
     d = uni32(d);
-    const int nblk = (d + 63) >> 6, ntask = W * nblk;
+    // tasks = (column word w, block of 64 rows b) with rows beyond column 32 w, i.e. b >= w / 2 (the matrix is strictly lower triangular: the blocks
+    // above the diagonal are empty and get no ticket): the pairs (k, b), k <= b < nblk, of a triangular enumeration, two column words 2k, 2k + 1 each
+    const int nblk = (d + 63) >> 6, ntri = nblk * (nblk + 1) / 2, ntask = 2 * ntri;
     while (true) {
         // tasks from a workgroup-wide ticket counter in LDS (zeroed before the barrier in front of the count), the long ones first: the waves of a
         // workgroup end together.  The ticket is pinned to a scalar register: the task, its column word w and the trip count of the intersections below
@@ -463,7 +465,12 @@ __device__ __forceinline__ unsigned long long kc4_count_pairs(const uint32_t *ro
         if (lane == 0) task = atomicAdd(next_task, 1);
         task = uni32(task);
         if (task >= ntask) break;
-        const int w = W - 1 - task / nblk, blk = task % nblk;  // the long tasks (high column words) first
+        const int tt = ntri - 1 - (task >> 1);  // the far blocks of the high column words first: the long tasks
+        int blk = int((__builtin_sqrtf(8.0f * float(tt) + 1.0f) - 1.0f) * 0.5f);
+        while (blk * (blk + 1) / 2 > tt) --blk;
+        while ((blk + 1) * (blk + 2) / 2 <= tt) ++blk;
+        const int w = 2 * (tt - blk * (blk + 1) / 2) + (task & 1);
+        if (w >= W) continue;  // (an odd number of column words)
         const int i = blk * 64 + lane;
         uint32_t bits = (i < d && (w << 5) < i) ? rows[size_t(i) * WS + w] : 0u;
 #ifdef GMSX_KC_CELLS_ONLY  // A/B build (wrong counts): the count phase reads the matrix cells and nothing else
