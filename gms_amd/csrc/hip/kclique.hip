@@ -772,31 +772,14 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         if (!GLOBAL_ROWS)
             for (int i = tid; i < d * WS; i += nthreads) rows[i] = 0;  // the slab variant writes every row word at its flush
         __syncthreads();
+        // the bitmap, and for every word that holds a member the local index of its first one — the exclusive prefix popcount a hit adds its rank
+        // inside the word to.  The hub list is ascending, so that index is the position of the first member whose id falls into the word: written by
+        // that member (round 5; rounds 1-4 counted the bits of all 2 048 words and scanned them per pivot: a barrier and 24 LDS operations per thread
+        // that the pivots of a few dozen members paid as dearly as the wide ones).  Words without a member keep stale values: no hit reads them.
         for (int i = tid; i < hc; i += nthreads) {
             const uint32_t w = hub_list[i];
             atomicOr(&bm[w >> 5], 1u << (w & 31u));
-        }
-        __syncthreads();
-        // prefix popcounts of the bitmap words (exclusive): 8 words per thread over the first 256 threads
-        {
-            int local = 0;
-            if (tid < 256)
-                for (int k = 0; k < 8; ++k) local += __popc(bm[tid * 8 + k]);
-            int incl = local;
-            for (int sft = 1; sft < 64; sft <<= 1) {
-                const int o = __shfl_up(incl, sft);
-                if (lane >= sft) incl += o;
-            }
-            if (lane == 63 && wave < 4) wave_tot[wave] = incl;
-            __syncthreads();
-            if (tid < 256) {
-                int base = incl - local;
-                for (int w2 = 0; w2 < wave; ++w2) base += wave_tot[w2];
-                for (int k = 0; k < 8; ++k) {
-                    pre[tid * 8 + k] = (unsigned short)base;
-                    base += __popc(bm[tid * 8 + k]);
-                }
-            }
+            if (i == 0 || (uint32_t(hub_list[i - 1]) >> 5) != (w >> 5)) pre[w >> 5] = (unsigned short)i;
         }
         __syncthreads();
         // four rows per wave and trip, one per 16-lane group; the global-slab variant builds them in an LDS stage and
