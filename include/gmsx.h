@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GMSX_VERSION 300
+#define GMSX_VERSION 310
 
 /* ---- status codes ---- */
 enum {

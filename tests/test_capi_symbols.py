@@ -23,7 +23,7 @@ def test_header_and_library_agree(capi):
     for name in names:
         assert hasattr(L, name), f"{name} declared in include/gmsx.h but not exported by libgmsx.so"
     assert sorted(capi.SYMBOLS) == names
-    assert capi.lib().gmsx_version() == 300
+    assert capi.lib().gmsx_version() == 310
     assert capi.lib().gmsx_strerror(-6).decode().startswith("no HIP device")
 
 
