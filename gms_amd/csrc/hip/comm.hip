@@ -79,6 +79,7 @@ struct gmsx_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     unsigned long long *buf = nullptr;  // device: the value being reduced
+    hipEvent_t done = nullptr;          // recorded behind every reduction: its wait is a bounded poll
 };
 
 using namespace gmsx;
@@ -152,9 +153,8 @@ int gmsx_comm_allreduce_u64(gmsx_comm *c, uint64_t *value) {
         if (rccl().AllReduce(c->buf, c->buf, 1, kNcclUint64, kNcclSum, c->comm, s) != kNcclSuccess) return GMSX_ERR_COMM;
         GMSX_HIP(hipMemcpyAsync(value, c->buf, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         // the wait for the result is bounded too: a peer that died between init and the reduction must not park this rank
-        hipEvent_t done = nullptr;
-        GMSX_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        struct Ev { hipEvent_t e; ~Ev() { (void)hipEventDestroy(e); } } ev{done};
+        if (!c->done) GMSX_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+        hipEvent_t done = c->done;
         GMSX_HIP(hipEventRecord(done, s));
         const double t0 = now_s(), limit = comm_timeout_s();
         for (unsigned spins = 0;; ++spins) {
@@ -178,6 +178,7 @@ int gmsx_comm_finalize(gmsx_comm *c) {
         int rc = GMSX_OK;
         if (c->comm && rccl().ok && rccl().CommDestroy(c->comm) != kNcclSuccess) rc = GMSX_ERR_COMM;
         (void)hipFree(c->buf);
+        if (c->done) (void)hipEventDestroy(c->done);
         delete c;
         return rc;
     });
