@@ -1164,6 +1164,11 @@ static int launch_generic(const gmsx_graph *g, int k, int64_t first, int64_t end
     return GMSX_OK;
 }
 
+static bool pipe_all_default(const gmsx_graph *g) {
+    (void)g;
+    return false;
+}
+
 template <int LV, bool VTX = false>
 static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long long *acc, int *launches, uint32_t **slab_out,
                       unsigned long long *vcounts = nullptr) {
@@ -1287,6 +1292,12 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr_set[VTX ? kMaxK : LV] = true;
     }
+    // the pipelined BUILD (member id -> extents -> first units, three members deep) in the narrower bins too: GMSX_KC_PIPE_ALL = 1 always, 0 never, unset =
+    // when the oriented containers outgrow the 256 MB Infinity Cache (a member's row then costs HBM round trips, not cache hits — see DESIGN.md §5.2)
+    const bool pipe_all = [&] {
+        if (const char *e = std::getenv("GMSX_KC_PIPE_ALL")) return std::atoi(e) != 0;
+        return pipe_all_default(g);
+    }();
     const int m_dmax[] = {1024, 704, 512, 384, 256, 192, 128, 96, 64, 32};  // last entry = lower end of the last bin
     for (int b = 0; b + 1 < int(sizeof(m_dmax) / sizeof(int)); ++b) {
         const int dmax = m_dmax[b], W = dmax / 32, WS = W | 1;  // odd stride: rows of one column spread over the LDS banks
@@ -1298,7 +1309,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
             const int threads = dmax >= 704 ? 1024 : dmax >= 384 ? 512 : 256;
             // (one 1024-thread workgroup per CU from d+ = 513 on: four waves per SIMD whatever the registers — the pipelined BUILD pays there)
-            if (threads == 1024)
+            if (threads == 1024 || pipe_all)
                 hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, true>), dim3(unsigned(blocks)), dim3(threads), lds, n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
                                    g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts);
             else
