@@ -84,6 +84,9 @@ __device__ __forceinline__ kc_u4u kc_load8(const uint16_t *row, int j, int l) {
 // A ring of kKcDepth loads per lane, refilled before the oldest one is probed; the loads are UNCONDITIONAL (an index past the row is
 // clamped to its last pair: in bounds, probed never) so that the waits are counted — under a branch every wait is vmcnt(0) and the
 // group has ONE load in flight: long member rows (the pivots of the big bins have members of d+ up to 3000) were a chain of round trips.
+#ifndef GMSX_KC_STREAM_DEPTH
+#define GMSX_KC_STREAM_DEPTH 2  // steps in flight per lane of the step-stream BUILD (mode 2)
+#endif
 #ifndef GMSX_KC_DEPTH
 #define GMSX_KC_DEPTH 2  // (measured, k = 4 at scale 22 / 24: depth 2 22.6 / 143.4 ms, depth 3 24.9 / 154.5, depth 4 25.1 / 155.2 — the registers of a deeper ring cost a wave per SIMD, and the BUILD waits on its LDS probes, not on the row loads)
 #endif
@@ -171,9 +174,18 @@ __device__ __forceinline__ int sorted_find(const int32_t *__restrict__ lst, int 
     return (lo < len && lst[lo] == w) ? lo : -1;
 }
 
+// … behind a FILTER (round 5): 32 768 bits in LDS, bit (id mod 32768) set for every tail member of the pivot.  The tail list itself is in global memory
+// and the search a chain of ~log2(tc) dependent loads; almost every streamed tail id is a miss (as in the triangle kernels, tc.hip), and from scale 24
+// on — where most vertices are tail vertices — those searches, not the rows, were what the BUILD waited for.
+static constexpr int kKcFilterWords = 1024;
+__device__ __forceinline__ int kc_tail_find(const uint32_t *flt, const int32_t *__restrict__ lst, int len, int32_t w) {
+    if (((flt[(uint32_t(w) >> 5) & uint32_t(kKcFilterWords - 1)] >> (uint32_t(w) & 31u)) & 1u) == 0u) return -1;
+    return sorted_find(lst, len, w);
+}
+
 // 32-bit tail container [row, row + l) of one tail member against the pivot's ascending tail list (local index hc + position)
 __device__ __forceinline__ void kc_stream_tail_from(const int32_t *__restrict__ row, int l, int j0, const int32_t *__restrict__ tail_list, int tc, int hc,
-                                                    uint32_t *orow) {
+                                                    uint32_t *orow, const uint32_t *flt) {
     if (l <= 0) return;
     int32_t p[kKcDepth];
 #pragma unroll
@@ -185,7 +197,7 @@ __device__ __forceinline__ void kc_stream_tail_from(const int32_t *__restrict__ 
             const int jc = j + 16 * k;
             p[k] = row[min(jc + 16 * kKcDepth, l - 1)];
             if (jc < l) {
-                const int t = sorted_find(tail_list, tc, cur);
+                const int t = kc_tail_find(flt, tail_list, tc, cur);
                 if (t >= 0) {
                     const int idx = hc + t;
                     atomicOr(&orow[idx >> 5], 1u << (idx & 31));
@@ -196,8 +208,8 @@ __device__ __forceinline__ void kc_stream_tail_from(const int32_t *__restrict__ 
 }
 
 __device__ __forceinline__ void kc_stream_tail(const int32_t *__restrict__ row, int l, int sub, const int32_t *__restrict__ tail_list, int tc, int hc,
-                                               uint32_t *orow) {
-    kc_stream_tail_from(row, l, sub, tail_list, tc, hc, orow);
+                                               uint32_t *orow, const uint32_t *flt) {
+    kc_stream_tail_from(row, l, sub, tail_list, tc, hc, orow, flt);
 }
 
 // ---- the BUILD as a pipeline over the members of a lane group (round 4) ---------------------------------------------------------------
@@ -243,7 +255,7 @@ __device__ __forceinline__ KcFirst kc_load_first(const uint16_t *__restrict__ ha
 __device__ __forceinline__ void kc_build_member_first(const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint32_t *__restrict__ bmpool,
                                                       const KcExt &e, const KcFirst &f, bool bitset, int nw, bool is_hub, int hc,
                                                       const int32_t *__restrict__ tail_list, int tc, const uint32_t *bm, const unsigned short *pre,
-                                                      uint32_t *orow, int sub) {
+                                                      uint32_t *orow, int sub, const uint32_t *flt) {
     if (bitset) {
         const int j = sub * 4;
         if (j < nw) kc_and4(f.h, *reinterpret_cast<const uint4 *>(bm + j), j, pre, orow);
@@ -257,10 +269,10 @@ __device__ __forceinline__ void kc_build_member_first(const uint16_t *__restrict
     }
     if (!is_hub && tc > 0) {
         if (sub < e.tl) {
-            const int t = sorted_find(tail_list, tc, f.t);
+            const int t = kc_tail_find(flt, tail_list, tc, f.t);
             if (t >= 0) atomicOr(&orow[(hc + t) >> 5], 1u << ((hc + t) & 31));
         }
-        kc_stream_tail_from(tadj + e.tb, e.tl, sub + 16, tail_list, tc, hc, orow);
+        kc_stream_tail_from(tadj + e.tb, e.tl, sub + 16, tail_list, tc, hc, orow, flt);
     }
 }
 
@@ -270,7 +282,7 @@ __device__ __forceinline__ void kc_build_member(const int64_t *__restrict__ hoff
                                                 const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                 const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool, int32_t dense_limit,
                                                 int32_t v, bool is_hub, int hc, const int32_t *__restrict__ tail_list, int tc,
-                                                const uint32_t *bm, const unsigned short *pre, uint32_t *orow, int sub) {
+                                                const uint32_t *bm, const unsigned short *pre, uint32_t *orow, int sub, const uint32_t *flt) {
     const int64_t hb = hoff[v];
     const int hl = int(hoff[v + 1] - hb);
     if (is_hub && v < dense_limit) {
@@ -283,9 +295,100 @@ __device__ __forceinline__ void kc_build_member(const int64_t *__restrict__ hoff
     if (hc > 0) kc_stream_list(hadj + hb, hl, sub, bm, pre, orow);
     if (!is_hub && tc > 0) {
         const int64_t tb = toff[v];
-        kc_stream_tail(tadj + tb, int(toff[v + 1] - tb), sub, tail_list, tc, hc, orow);
+        kc_stream_tail(tadj + tb, int(toff[v + 1] - tb), sub, tail_list, tc, hc, orow, flt);
     }
 }
+
+// ---- the BUILD as ONE STREAM OF STEPS per 16-lane group (round 5; mode 2 of k_kc_block) ---------------------------------------------------
+// Member by member (mode 0) a group pays, per member, the chain member id -> extents -> first units of the row before it streams it; from scale 24 on
+// the oriented containers no longer sit in the Infinity Cache and every link is an HBM round trip: the BUILD of k = 4 at scale 26 moved its 1.6 TB of
+// member rows at 2.1 TB/s.  Here, as in the triangle kernels' StepStream (tc.hip): the extents of up to 256 members are fetched by
+// 256 threads AT ONCE into LDS descriptors, and a group then walks its members' rows as one stream of steps (16 consecutive 16-byte units, one per
+// lane) with D steps in flight per lane ACROSS member boundaries — every load unconditional (a lane without a unit in the step re-reads the row's last
+// unit, a group past its last member the fallback address) so that the waits are counted.  A member's row = its hub part (bitset words or 16-bit list)
+// followed by its tail part (32-bit ids); a step carries its member's index, the probe reads what else it needs from the descriptor.
+struct __attribute__((aligned(16))) KcDesc {
+    unsigned long long ph, pt;  // byte addresses of the hub part (list or bitset container) and of the tail part
+    uint32_t hu, tu;            // 16-byte units of the two parts; bit 31 of hu: the hub part is a bitset container
+    uint32_t hl, tl;            // ids of the list / tail part (the last unit of a part is cut there)
+};
+template <int D>
+struct KcStream {
+    static constexpr int S = D == 1 ? 2 : D;
+    const KcDesc *desc;
+    const char *fallback;
+    int hi, sub, G;
+    int e, units, hu, last, lim, j;
+    const char *ph, *pt;
+    int pending;
+    kc_u4u p[S];
+    int pj[S], pe[S];
+    __device__ __forceinline__ void open_row() {
+        if (e < hi) {
+            const KcDesc d = desc[e];
+            ph = reinterpret_cast<const char *>(d.ph);
+            pt = reinterpret_cast<const char *>(d.pt);
+            hu = int(d.hu & 0x7fffffffu);
+            units = hu + int(d.tu);
+        } else {
+            ph = pt = fallback;
+            hu = units = 0;
+        }
+        last = max(units - 1, 0);
+        lim = units + sub;
+        j = sub;
+    }
+    __device__ __forceinline__ void issue(int k) {
+        const int jj = min(j, last);
+        const char *a = jj < hu ? ph + 16 * size_t(jj) : pt + 16 * size_t(jj - hu);
+        p[k] = *reinterpret_cast<const kc_u4u *>(units > 0 ? a : fallback);
+        pj[k] = j < units ? j : -1;
+        pe[k] = e;
+        pending += e < hi ? 1 : 0;
+        j += 16;
+        if (j >= lim) {  // the member's row is through (uniform per group): the group's next member
+            e += G;
+            open_row();
+        }
+    }
+    __device__ __forceinline__ void start(const KcDesc *d, const void *fb, int n, int tid, int nthreads) {
+        desc = d;
+        fallback = static_cast<const char *>(fb);
+        hi = n;
+        sub = tid & 15;
+        G = nthreads >> 4;
+        e = tid >> 4;
+        pending = 0;
+        open_row();
+#pragma unroll
+        for (int k = 0; k < S - (D == 1 ? 1 : 0); ++k) issue(k);
+    }
+    template <class Probe>
+    __device__ __forceinline__ void run(Probe probe) {
+        if constexpr (D == 1) {
+            while (pending > 0) {
+                pending -= 1;
+                issue(1);
+                if (pj[0] >= 0) probe(p[0], pj[0], pe[0]);
+                if (!(pending > 0)) break;
+                pending -= 1;
+                issue(0);
+                if (pj[1] >= 0) probe(p[1], pj[1], pe[1]);
+            }
+        } else {
+            while (pending > 0) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const kc_u4u pc = p[k];
+                    const int jc = pj[k], ec = pe[k];
+                    pending -= 1;
+                    issue(k);
+                    if (jc >= 0) probe(pc, jc, ec);
+                }
+            }
+        }
+    }
+};
 
 // ---- counting ------------------------------------------------------------------------------------------------
 // Per-lane recursion for local graphs of <= 32 vertices (one 32-bit word per set).  Number of LV-cliques inside cand.
@@ -731,7 +834,7 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
 // (d <= 1024); true: in a per-workgroup global slab (d up to 64*32*WPL), workgroups walk their pivots with a grid stride.
 // dynamic LDS layout: [rows: dmax*WS u32 (LDS variant only)] [bm: 2048 u32] [pre: 2048 u16] [row stage: nwaves*4*W u32 (slab variant only)]
 // ---------------------------------------------------------------------------------------------
-template <int LV, int WPL, bool GLOBAL_ROWS, bool VTX, bool PIPE = GLOBAL_ROWS>
+template <int LV, int WPL, bool GLOBAL_ROWS, bool VTX, int PIPE = GLOBAL_ROWS ? 1 : 0 /* the BUILD: 0 member by member, 1 three-stage member pipeline, 2 step stream */>
 __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                    const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                    const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
@@ -742,6 +845,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ unsigned long long red[16];
     __shared__ int wave_tot[16];
+    __shared__ uint32_t flt[kKcFilterWords];  // the pivot's tail members, one bit per (id mod 32768): kc_tail_find
 #ifdef GMSX_KC_NO_PAIRS  // A/B build: round 4's k = 4 counts (kc4_row for wide matrices, one lane per matrix word for the others)
     constexpr bool kc4_pairs_enabled = false;
 #else
@@ -756,6 +860,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
     unsigned short *pre = reinterpret_cast<unsigned short *>(bm + kBitmapWords);
 
     unsigned long long cnt = 0;
+    bool flt_dirty = true;
     for (int64_t q = blockIdx.x;; q += gridDim.x) {
         const int64_t pos = first + q * nparts + part;
         if (pos >= end) break;  // uniform per block
@@ -769,6 +874,9 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         const int32_t *tail_list = tadj + tb;
         __syncthreads();  // previous pivot's counting is done
         for (int i = tid; i < kBitmapWords; i += nthreads) bm[i] = 0;
+        if (flt_dirty)  // (uniform: the previous pivot of this workgroup had tail members, or this is its first)
+            for (int i = tid; i < kKcFilterWords; i += nthreads) flt[i] = 0;
+        flt_dirty = tc > 0;
         if (!GLOBAL_ROWS)
             for (int i = tid; i < d * WS; i += nthreads) rows[i] = 0;  // the slab variant writes every row word at its flush
         __syncthreads();
@@ -781,13 +889,60 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
             atomicOr(&bm[w >> 5], 1u << (w & 31u));
             if (i == 0 || (uint32_t(hub_list[i - 1]) >> 5) != (w >> 5)) pre[w >> 5] = (unsigned short)i;
         }
+        for (int i = tid; i < tc; i += nthreads) {
+            const uint32_t w = uint32_t(tail_list[i]);
+            atomicOr(&flt[(w >> 5) & uint32_t(kKcFilterWords - 1)], 1u << (w & 31u));
+        }
         __syncthreads();
         // four rows per wave and trip, one per 16-lane group; the global-slab variant builds them in an LDS stage and
         // writes finished rows out with coalesced stores (no global atomics)
         {
             const int grp = lane >> 4, sub = lane & 15;
             uint32_t *stage = GLOBAL_ROWS ? reinterpret_cast<uint32_t *>(pre + kBitmapWords) + size_t(wave) * 4 * W : nullptr;
-            if constexpr (PIPE) {
+            if constexpr (PIPE == 2) {
+                // ---- mode 2: descriptors of up to 256 members at a time, then one step stream per group (KcStream above) ----
+                KcDesc *desc = reinterpret_cast<KcDesc *>(smem + size_t(dmax) * WS + kBitmapWords + kBitmapWords / 2 + (VTX ? dmax : 0));
+                for (int base = 0; base < d; base += 256) {
+                    const int nb = min(256, d - base);
+                    if (tid < nb) {
+                        const int i = base + tid;
+                        const bool is_hub = i < hc;
+                        const int32_t v = is_hub ? int32_t(hub_list[i]) : tail_list[i - hc];
+                        const KcExt e = kc_load_ext(hoff, toff, bmoff, dense_limit, v);
+                        const bool bs = kc_use_bitset(v, is_hub, dense_limit, e.hl);
+                        KcDesc dd;
+                        dd.ph = bs ? reinterpret_cast<unsigned long long>(bmpool + e.bo) : reinterpret_cast<unsigned long long>(hadj + e.hb);
+                        dd.pt = reinterpret_cast<unsigned long long>(tadj + e.tb);
+                        dd.hu = bs ? (uint32_t(bitset_words(v) / 4) | 0x80000000u) : (hc > 0 ? uint32_t((e.hl + 7) / 8) : 0u);
+                        dd.tu = (!is_hub && tc > 0) ? uint32_t((e.tl + 3) / 4) : 0u;
+                        dd.hl = uint32_t(e.hl);
+                        dd.tl = uint32_t(e.tl);
+                        desc[tid] = dd;
+                    }
+                    __syncthreads();
+                    KcStream<GMSX_KC_STREAM_DEPTH> st;
+                    st.start(desc, hadj, nb, tid, nthreads);
+                    st.run([&](kc_u4u pu, int ju, int eu) {
+                        const KcDesc dd = desc[eu];
+                        uint32_t *orow = rows + size_t(base + eu) * WS;
+                        const int hu = int(dd.hu & 0x7fffffffu);
+                        if (ju < hu) {
+                            if (dd.hu & 0x80000000u) kc_and4(make_uint4(pu.x, pu.y, pu.z, pu.w), *reinterpret_cast<const uint4 *>(bm + 4 * ju), 4 * ju, pre, orow);
+                            else kc_probe8(bm, pre, orow, kc_cut8(pu, int(dd.hl) - 8 * ju));
+                        } else {
+                            const int t0 = 4 * (ju - hu), nt = int(dd.tl) - t0;  // 1 … 4 ids of this unit are the row's
+                            const int32_t ids[4] = {int32_t(pu.x), int32_t(pu.y), int32_t(pu.z), int32_t(pu.w)};
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4)
+                                if (q4 < nt) {
+                                    const int t = kc_tail_find(flt, tail_list, tc, ids[q4]);
+                                    if (t >= 0) atomicOr(&orow[(hc + t) >> 5], 1u << ((hc + t) & 31));
+                                }
+                        }
+                    });
+                    __syncthreads();  // the descriptors are rewritten by the next batch
+                }
+            } else if constexpr (PIPE == 1) {
                 const int istep = nwaves * 4;
                 // member i of the pivot: its rank id (an index past the row: vertex 0 — loaded, never used)
                 auto member = [&](int i) -> int32_t { return i < hc ? int32_t(hub_list[i]) : tail_list[i < d ? i - hc : 0]; };
@@ -814,7 +969,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
 #ifdef GMSX_KC_NO_ROWS  // A/B build (wrong counts): the BUILD phase without its row streams
                         if (v0 == -7) orow[0] = 1;
 #else
-                        kc_build_member_first(hadj, tadj, bmpool, e0, f0, b0, b0 ? int(bitset_words(v0)) : 0, is_hub, hc, tail_list, tc, bm, pre, orow, sub);
+                        kc_build_member_first(hadj, tadj, bmpool, e0, f0, b0, b0 ? int(bitset_words(v0)) : 0, is_hub, hc, tail_list, tc, bm, pre, orow, sub, flt);
 #endif
                     }
                     if (GLOBAL_ROWS) {
@@ -839,7 +994,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
 #ifdef GMSX_KC_NO_ROWS
                         if (v == -7) rows[size_t(i) * WS] = 1;
 #else
-                        kc_build_member(hoff, hadj, toff, tadj, bmoff, bmpool, dense_limit, v, is_hub, hc, tail_list, tc, bm, pre, rows + size_t(i) * WS, sub);
+                        kc_build_member(hoff, hadj, toff, tadj, bmoff, bmpool, dense_limit, v, is_hub, hc, tail_list, tc, bm, pre, rows + size_t(i) * WS, sub, flt);
 #endif
                     }
                 }
@@ -1164,6 +1319,10 @@ static int launch_generic(const gmsx_graph *g, int k, int64_t first, int64_t end
     return GMSX_OK;
 }
 
+static bool stream_build_default(const gmsx_graph *g) {
+    (void)g;
+    return false;
+}
 static bool pipe_all_default(const gmsx_graph *g) {
     (void)g;
     return false;
@@ -1256,10 +1415,10 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         *slab_out = slabs;
         static bool l_attr[kMaxK + 1] = {false};
         if (!l_attr[VTX ? kMaxK : LV]) {
-            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, true, VTX>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 2, true, VTX>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, true, VTX>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 2, true, VTX>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
             if constexpr (LV <= 2)
-                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 4, true, VTX>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 4, true, VTX>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
             l_attr[VTX ? kMaxK : LV] = true;
         }
         for (int b = 0; b < NL; ++b) {
@@ -1286,10 +1445,11 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     // M: 32 < d+ <= 1024, bit-matrix in LDS; one launch per bin — the bins are cut where another workgroup fits a CU
     static bool attr_set[kMaxK + 1] = {false};
     if (!attr_set[VTX ? kMaxK : LV]) {
-        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, false>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, true>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 0>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         attr_set[VTX ? kMaxK : LV] = true;
     }
     // the pipelined BUILD (member id -> extents -> first units, three members deep) in the narrower bins too: GMSX_KC_PIPE_ALL = 1 always, 0 never, unset =
@@ -1297,6 +1457,11 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     const bool pipe_all = [&] {
         if (const char *e = std::getenv("GMSX_KC_PIPE_ALL")) return std::atoi(e) != 0;
         return pipe_all_default(g);
+    }();
+    // the step-stream BUILD (mode 2): GMSX_KC_STREAM_BUILD = 1 always, 0 never, unset = by graph size (stream_build_default)
+    const bool stream_build = [&] {
+        if (const char *e = std::getenv("GMSX_KC_STREAM_BUILD")) return std::atoi(e) != 0;
+        return stream_build_default(g);
     }();
     const int m_dmax[] = {1024, 704, 512, 384, 256, 192, 128, 96, 64, 32};  // last entry = lower end of the last bin
     for (int b = 0; b + 1 < int(sizeof(m_dmax) / sizeof(int)); ++b) {
@@ -1309,11 +1474,14 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
             const int threads = dmax >= 704 ? 1024 : dmax >= 384 ? 512 : 256;
             // (one 1024-thread workgroup per CU from d+ = 513 on: four waves per SIMD whatever the registers — the pipelined BUILD pays there)
-            if (threads == 1024 || pipe_all)
-                hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, true>), dim3(unsigned(blocks)), dim3(threads), lds, n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
+            if (stream_build)
+                hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 2>), dim3(unsigned(blocks)), dim3(threads), lds + 256 * sizeof(KcDesc), n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
+                                   g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts);
+            else if (threads == 1024 || pipe_all)
+                hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 1>), dim3(unsigned(blocks)), dim3(threads), lds, n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
                                    g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts);
             else
-                hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, false>), dim3(unsigned(blocks)), dim3(threads), lds, n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
+                hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 0>), dim3(unsigned(blocks)), dim3(threads), lds, n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
                                    g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts);
             ++*launches;
         }
