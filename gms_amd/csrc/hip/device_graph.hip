@@ -468,23 +468,32 @@ __global__ void k_order_keys(int64_t n, const int32_t *__restrict__ dplus, int32
     }
 }
 
-// keys are descending; out[0] = number of keys >= thr
-__global__ void k_count_ge(int64_t n, const int32_t *__restrict__ keys, int32_t thr, int64_t *__restrict__ out) {
+// d+ descends along `order`; out[0] = number of vertices with d+ >= thr
+__global__ void k_count_ge(int64_t n, const int32_t *__restrict__ order, const int32_t *__restrict__ dplus, int32_t thr, int64_t *__restrict__ out) {
     int64_t lo = 0, hi = n;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] >= thr) lo = mid + 1; else hi = mid;
+        if (dplus[order[mid]] >= thr) lo = mid + 1; else hi = mid;
     }
     out[0] = lo;
+}
+// the task entries' fields (device_graph.hpp, TaskList): out[0] |= 1 when a stream row is longer than its list can say
+__global__ void k_task_limits(int64_t n, const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ srow2,
+                              const unsigned long long *__restrict__ trow, unsigned long long *__restrict__ out) {
+    const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    if ((srow[v] & 0x3fffffull) > kTaskHubUnitsMax || (srow2[v] & 0x3fffffull) > kTaskHubUnitsMax || (trow[v] & 0x3fffffull) > kTaskTailUnitsMax) atomicOr(out, 1ull);
 }
 
 // ---- inline rows (build step 4c / 5b) --------------------------------------------------------------------------------------------
 static constexpr int kInlineChunk = 64;  // units of an inline row per task entry
 // A heavy pivot hands the edges to its first gmsx_graph::inline_first (<= 64) members over inline too: their cut rows are 1-8 units, 2 bytes
-// per id inline against 8 bytes of entry + a line behind a pointer.  The copies grow with the SQUARE of that number (member i receives i ids:
+// per id inline against 6 bytes of entry + a line behind a pointer.  The copies grow with the SQUARE of that number (member i receives i ids:
 // 2016 ids per heavy pivot at 64): scale 26, device bytes / ms per pass at 64, 48, 40, 32 = 48.6 GB / 67.2, 44.3 / 67.6, 42.7 / 67.7,
-// 41.4 / 68.0 (GMSX_TC_INLINE_FIRST; round 4 took 48: -4.2 GB for +0.6 %).
-static constexpr int kDefaultInlineFirst = 48;
+// 41.4 / 68.0 (GMSX_TC_INLINE_FIRST; round 4 took 48: -4.2 GB for +0.6 %).  Round 5, with 6-byte task entries: 48 / 36 / 32 / 28 =
+// 40.9 GB / 66.4 ms, 38.5 / 66.9, 37.9 / 67.1, 37.3 / 67.1 — member 28 receives 56 bytes of ids inline, and its cut row would be 6 bytes
+// of entry + four 16-byte units: from there on the copy is no smaller than what it replaces.  Round 5 takes 28.
+static constexpr int kDefaultInlineFirst = 28;
 static constexpr int kInlineFirstMax = 64;
 __device__ __forceinline__ bool takes_inline(int32_t v, int32_t inline_limit, const int32_t *__restrict__ dplus) {
     return v < inline_limit || dplus[v] >= kHeavy;
@@ -580,7 +589,7 @@ template <bool FILL>
 __global__ void k_inline_entries(int64_t n, const int32_t *__restrict__ dplus, const int32_t *__restrict__ opos, const int64_t *__restrict__ lidx, int64_t n_heavy,
                                  int32_t inline_limit, const int64_t *__restrict__ ihoff, const int64_t *__restrict__ itoff, int64_t base_h, int64_t base_t,
                                  uint32_t *__restrict__ cnt, uint32_t *__restrict__ cur, const int64_t *__restrict__ hbeg, const int64_t *__restrict__ tbeg,
-                                 unsigned long long *__restrict__ htask, unsigned long long *__restrict__ ttask, unsigned long long *__restrict__ totals, TcClasses cc) {
+                                 TaskList htask, TaskList ttask, unsigned long long *__restrict__ totals, TcClasses cc) {
     const int kClasses = cc.count();
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v >= n) return;
@@ -594,14 +603,14 @@ __global__ void k_inline_entries(int64_t n, const int32_t *__restrict__ dplus, c
         const unsigned long long d = ((unsigned long long)(base_h + ihoff[v] + o) << 24) | ((unsigned long long)kFormList << 22) | units;
         const int cls = hub_class(cc, d);
         if (!FILL) atomicAdd(&c[cls], 1u);
-        else htask[hbeg[p] + c[cls] + atomicAdd(&cur[p * kClasses + cls], 1u)] = d;
+        else htask.put(hbeg[p] + c[cls] + atomicAdd(&cur[p * kClasses + cls], 1u), d);
     }
     for (int64_t o = 0; o < ut; o += kInlineChunk) {
         const unsigned long long units = (unsigned long long)min(int64_t(kInlineChunk), ut - o);
         const unsigned long long d = ((unsigned long long)(base_t + itoff[v] + o) << 24) | ((unsigned long long)kFormList << 22) | units;
         const int cls = tail_class(cc, d);
         if (!FILL) atomicAdd(&c[cls], 1u);
-        else ttask[tbeg[p] + c[cls] + atomicAdd(&cur[p * kClasses + cls], 1u)] = d;
+        else ttask.put(tbeg[p] + c[cls] + atomicAdd(&cur[p * kClasses + cls], 1u), d);
     }
     if (!FILL) {
         atomicAdd(&totals[0], (unsigned long long)((uh + kInlineChunk - 1) / kInlineChunk));
@@ -714,7 +723,7 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                                                     const unsigned long long *__restrict__ srow2, const int32_t *__restrict__ ksplit,
                                                     const unsigned long long *__restrict__ trow, int two_sided, const int32_t *__restrict__ opos,
                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ cur, const int64_t *__restrict__ hbeg,
-                                                    const int64_t *__restrict__ tbeg, unsigned long long *__restrict__ htask, unsigned long long *__restrict__ ttask,
+                                                    const int64_t *__restrict__ tbeg, TaskList htask, TaskList ttask,
                                                     int32_t *__restrict__ tunits, unsigned long long *__restrict__ reversed, const uint32_t *__restrict__ spool,
                                                     const uint32_t *__restrict__ tpool, int32_t inline_limit, int inline_first, int nparts, int part, TcClasses cc) {
     const int kClasses = cc.count();
@@ -763,9 +772,9 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
             const uint32_t sh2 = claim_by_class(FILL ? ru : cu, hub_class(cc, fh2), fh2_on, lane);
             const uint32_t st = claim_by_class(FILL ? ru : cu, tail_class(cc, ft), ft_on, lane);
             if (FILL) {
-                if (fh_on) htask[hbeg[pos] + cu[hub_class(cc, fh)] + sh] = fh;
-                if (fh2_on) htask[hbeg[pos] + cu[hub_class(cc, fh2)] + sh2] = fh2;
-                if (ft_on) ttask[tbeg[pos] + cu[tail_class(cc, ft)] + st] = ft;
+                if (fh_on) htask.put(hbeg[pos] + cu[hub_class(cc, fh)] + sh, fh);
+                if (fh2_on) htask.put(hbeg[pos] + cu[hub_class(cc, fh2)] + sh2, fh2);
+                if (ft_on) ttask.put(tbeg[pos] + cu[tail_class(cc, ft)] + st, ft);
             }
             kept += __popcll(__ballot(fwd));
             if (v >= 0 && reverse) {  // u's rows, cut at v, against v
@@ -777,17 +786,17 @@ __global__ __launch_bounds__(256) void k_task_lists(int64_t n_heavy, const int32
                     if (rh) atomicAdd(&cv[hub_class(cc, rh)], 1u);
                     if (rh2) atomicAdd(&cv[hub_class(cc, rh2)], 1u);
                     if (rt) atomicAdd(&cv[tail_class(cc, rt)], 1u);
-                    atomicAdd(&tunits[v], 1);
+                    atomicAdd(&tunits[pv], 1);
                     ++rev;
                 } else {
                     uint32_t *rv = cur + pv * kClasses;
-                    if (rh) htask[hbeg[pv] + cv[hub_class(cc, rh)] + atomicAdd(&rv[hub_class(cc, rh)], 1u)] = rh;
-                    if (rh2) htask[hbeg[pv] + cv[hub_class(cc, rh2)] + atomicAdd(&rv[hub_class(cc, rh2)], 1u)] = rh2;
-                    if (rt) ttask[tbeg[pv] + cv[tail_class(cc, rt)] + atomicAdd(&rv[tail_class(cc, rt)], 1u)] = rt;
+                    if (rh) htask.put(hbeg[pv] + cv[hub_class(cc, rh)] + atomicAdd(&rv[hub_class(cc, rh)], 1u), rh);
+                    if (rh2) htask.put(hbeg[pv] + cv[hub_class(cc, rh2)] + atomicAdd(&rv[hub_class(cc, rh2)], 1u), rh2);
+                    if (rt) ttask.put(tbeg[pv] + cv[tail_class(cc, rt)] + atomicAdd(&rv[tail_class(cc, rt)], 1u), rt);
                 }
             }
         }
-        if (!FILL && lane == 0 && kept) atomicAdd(&tunits[u], kept);
+        if (!FILL && lane == 0 && kept) atomicAdd(&tunits[pos], kept);
     }
     if (!FILL) {
         for (int s = 32; s > 0; s >>= 1) rev += __shfl_down(rev, s);
@@ -809,7 +818,7 @@ __global__ void k_item_counts(int64_t n_recv, const int64_t *__restrict__ lbeg, 
 // one thread per receiver: its list in chunks of kTaskChunk entries, each a self-contained record (device_graph.hpp); the pivot's
 // container part from coff (hoff / toff)
 __global__ void k_item_fill(int64_t n_recv, const int32_t *__restrict__ recv_v, const int32_t *__restrict__ opos, const int64_t *__restrict__ lbeg,
-                            const int64_t *__restrict__ ioff, const unsigned long long *__restrict__ task, const int64_t *__restrict__ coff, int kind,
+                            const int64_t *__restrict__ ioff, TaskList task, const int64_t *__restrict__ coff, int kind,
                             const uint32_t *__restrict__ cnt, TcClasses cc, int phases, gmsx_tc_item *__restrict__ items) {
     const int64_t p = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (p >= n_recv) return;
@@ -833,7 +842,7 @@ __global__ void k_item_fill(int64_t n_recv, const int32_t *__restrict__ recv_v, 
             int lo = 0, hi = ne;
             while (lo < hi) {
                 const int mid = (lo + hi) >> 1;
-                if (int((uint32_t(task[x + mid]) >> 22) & 3u) < f) lo = mid + 1; else hi = mid;
+                if (int((uint32_t(task.get(x + mid)) >> 22) & 3u) < f) lo = mid + 1; else hi = mid;
             }
             it.fbeg[f] = uint16_t(lo);
         }
@@ -850,8 +859,10 @@ static int grid_for_waves(int64_t rows) {
 }
 
 template <class T>
-static int dmalloc(T **p, int64_t count, gmsx_graph *g) {
+static int dmalloc(T **p, int64_t count, gmsx_graph *g, int line = __builtin_LINE()) {
     const size_t bytes = size_t(count > 0 ? count : 1) * sizeof(T);
+    static const bool trace = std::getenv("GMSX_MEM_TRACE") != nullptr;  // where the device bytes go: one line per allocation that stays with the graph
+    if (trace && g && bytes >= (1u << 20)) std::fprintf(stderr, "gmsx mem: device_graph.hip:%d %.3f GB (elements of %zu B)\n", line, double(bytes) * 1e-9, sizeof(T));
     if (g && g->tc_building && g->tc_limit_bytes > 0 && g->device_bytes + int64_t(bytes) - g->tc_base_bytes > g->tc_limit_bytes) {
         *p = nullptr;  // test hook: pretend the device is this small
         return GMSX_ERR_DEVICE_MEM;
@@ -876,7 +887,7 @@ static void free_tc(gmsx_graph *g) {
         (void)hipFree(p);
         p = nullptr;
     };
-    drop(g->tsplit); drop(g->srow); drop(g->srow2); drop(g->ksplit); drop(g->spool); drop(g->trow); drop(g->htask); drop(g->ttask); drop(g->hitem); drop(g->titem); drop(g->tunits);
+    drop(g->tsplit); drop(g->srow); drop(g->srow2); drop(g->ksplit); drop(g->spool); drop(g->trow); drop(g->htask.lo); drop(g->htask.hi); drop(g->ttask.lo); drop(g->ttask.hi); drop(g->hitem); drop(g->titem); drop(g->tunits);
     drop(g->ledge); drop(g->tpool); drop(g->shard_hitem); drop(g->shard_titem);
     g->shard_idx_part = g->shard_idx_nparts = -1;
     g->device_bytes -= g->tc_bytes;
@@ -906,8 +917,10 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->ksplit);
     (void)hipFree(g->spool);
     (void)hipFree(g->trow);
-    (void)hipFree(g->htask);
-    (void)hipFree(g->ttask);
+    (void)hipFree(g->htask.lo);
+    (void)hipFree(g->htask.hi);
+    (void)hipFree(g->ttask.lo);
+    (void)hipFree(g->ttask.hi);
     (void)hipFree(g->hitem);
     (void)hipFree(g->titem);
     (void)hipFree(g->tunits);
@@ -917,7 +930,6 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->tpool);
     (void)hipFree(g->dplus);
     (void)hipFree(g->order);
-    (void)hipFree(g->sorted_dplus);
     (void)hipFree(g->scratch);
     (void)hipFree(g->acc);
     delete g;
@@ -1219,22 +1231,23 @@ static int build_device_sets(gmsx_graph *g, uint32_t flags) {
     pt.mark("bitsets");
     // 5. work-sorted launch order: rank ids by decreasing d+
     if (int rc = dmalloc(&g->order, n, g)) return rc;
-    if (int rc = dmalloc(&g->sorted_dplus, n, g)) return rc;
     if (n > 0) {
-        int32_t *keys_in = nullptr, *vals_in = nullptr;
+        int32_t *keys_in = nullptr, *vals_in = nullptr, *keys_out = nullptr;  // (the sorted keys are dplus[order[i]]: not kept)
+        if (int rc = dmalloc(&keys_out, n, nullptr)) return rc;
+        DevGuard g_ko{keys_out};
         if (int rc = dmalloc(&keys_in, n, nullptr)) return rc;
         DevGuard g_ki{keys_in};
         if (int rc = dmalloc(&vals_in, n, nullptr)) return rc;
         DevGuard g_vi{vals_in};
         hipLaunchKernelGGL(k_order_keys, dim3(tb), dim3(256), 0, s, n, g->dplus, keys_in, vals_in);
         size_t tmp_bytes = 0;
-        GMSX_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, keys_in, g->sorted_dplus, vals_in, g->order, size_t(n), 0, 32, s));
+        GMSX_HIP(rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, keys_in, keys_out, vals_in, g->order, size_t(n), 0, 32, s));
         void *tmp = nullptr;
         GMSX_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 8));
         DevGuard g_tmp{tmp};
-        GMSX_HIP(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, g->sorted_dplus, vals_in, g->order, size_t(n), 0, 32, s));
+        GMSX_HIP(rocprim::radix_sort_pairs_desc(tmp, tmp_bytes, keys_in, keys_out, vals_in, g->order, size_t(n), 0, 32, s));
         int32_t top = 0;
-        GMSX_HIP(hipMemcpyAsync(&top, g->sorted_dplus, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipMemcpyAsync(&top, keys_out, sizeof(int32_t), hipMemcpyDeviceToHost, s));
         GMSX_HIP(hipStreamSynchronize(s));
         g->max_dplus = top;
     }
@@ -1301,8 +1314,8 @@ static int build_tc_sets(gmsx_graph *g) {
             int64_t *d_cnt = nullptr;
             if (int rc = dmalloc(&d_cnt, 2, nullptr)) return rc;
             DevGuard g_c{d_cnt};
-            hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, n, g->sorted_dplus, int32_t(kHeavy), d_cnt);
-            hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, n, g->sorted_dplus, int32_t(2), d_cnt + 1);
+            hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, n, g->order, g->dplus, int32_t(kHeavy), d_cnt);
+            hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, n, g->order, g->dplus, int32_t(2), d_cnt + 1);
             GMSX_HIP(hipStreamSynchronize(s));
             int64_t h[2] = {0, 0};
             GMSX_HIP(hipMemcpy(h, d_cnt, sizeof(h), hipMemcpyDeviceToHost));
@@ -1511,9 +1524,9 @@ static int build_tc_sets(gmsx_graph *g) {
         DevGuard g_cur{cur};
         GMSX_HIP(hipMemsetAsync(cnt, 0, size_t(n_recv * kClasses + 1) * sizeof(uint32_t), s));
         GMSX_HIP(hipMemsetAsync(cur, 0, size_t(n_recv * kClasses + 1) * sizeof(uint32_t), s));
-        if (int rc = dmalloc(&g->tunits, n + 1, g)) return rc;
-        GMSX_HIP(hipMemsetAsync(g->tunits, 0, size_t(n + 1) * sizeof(int32_t), s));
-        unsigned long long *totals = nullptr;  // [0] hub inline entries [1] tail inline entries [2] reversed edges
+        if (int rc = dmalloc(&g->tunits, n_heavy + 1, g)) return rc;  // only heavy pivots keep or receive entries of edges: by position in `order`
+        GMSX_HIP(hipMemsetAsync(g->tunits, 0, size_t(n_heavy + 1) * sizeof(int32_t), s));
+        unsigned long long *totals = nullptr;  // [0] hub inline entries [1] tail inline entries [2] reversed edges [3] rows too long for a task entry
         if (int rc = dmalloc(&totals, 4, nullptr)) return rc;
         DevGuard g_tot{totals};
         GMSX_HIP(hipMemsetAsync(totals, 0, 4 * sizeof(unsigned long long), s));
@@ -1527,29 +1540,35 @@ static int build_tc_sets(gmsx_graph *g) {
         if (int rc = dmalloc(&tbeg, n_recv + 1, nullptr)) return rc;
         DevGuard g_tb{tbeg};
         const int grid = grid_for_waves(n_heavy);
+        // a task entry has 32 bits for the first unit of its row and 14 / 15 for the row's units (TaskList)
+        if (g->spool_units + kPoolSlack >= (int64_t(1) << 32) || g->tpool_units + kPoolSlack >= (int64_t(1) << 32)) return GMSX_ERR_DEVICE_MEM;
+        if (n > 0) hipLaunchKernelGGL(k_task_limits, dim3(vb), dim3(256), 0, s, n, g->srow, g->srow2, g->trow, totals + 3);
         // COUNT
         if (n > 0)
             hipLaunchKernelGGL(k_inline_entries<false>, dim3(vb), dim3(256), 0, s, n, g->dplus, opos, lidx, n_heavy, g->inline_limit, ihoff, itoff, inline_h_base,
-                               inline_t_base, cnt, cur, hbeg, tbeg, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), totals, cc);
+                               inline_t_base, cnt, cur, hbeg, tbeg, TaskList{}, TaskList{}, totals, cc);
         if (n_heavy > 0)
             hipLaunchKernelGGL(k_task_lists<false>, dim3(grid), dim3(256), 0, s, n_heavy, g->order, g->hoff, g->hadj, g->toff, g->tadj, g->dplus, g->srow, g->srow2, g->ksplit, g->trow,
-                               two_sided, opos, cnt, cur, hbeg, tbeg, static_cast<unsigned long long *>(nullptr), static_cast<unsigned long long *>(nullptr), g->tunits,
+                               two_sided, opos, cnt, cur, hbeg, tbeg, TaskList{}, TaskList{}, g->tunits,
                                totals + 2, g->spool, g->tpool, g->inline_limit, g->inline_first, g->shard_nparts, g->shard_part, cc);
         pt.mark("task lists count");
         // class offsets, list offsets
         hipLaunchKernelGGL(k_list_sizes, dim3(unsigned(n_recv / 256 + 1)), dim3(256), 0, s, n_recv, cnt, hcnt, tcnt, cc);
         if (int rc = exclusive_scan_i64(hcnt, hbeg, n_recv + 1, s)) return rc;
         if (int rc = exclusive_scan_i64(tcnt, tbeg, n_recv + 1, s)) return rc;
-        unsigned long long tot[3] = {0, 0, 0};
+        unsigned long long tot[4] = {0, 0, 0, 0};
         GMSX_HIP(hipMemcpy(&g->htask_entries, hbeg + n_recv, sizeof(int64_t), hipMemcpyDeviceToHost));
         GMSX_HIP(hipMemcpy(&g->ttask_entries, tbeg + n_recv, sizeof(int64_t), hipMemcpyDeviceToHost));
         GMSX_HIP(hipMemcpy(tot, totals, sizeof(tot), hipMemcpyDeviceToHost));
+        if (tot[3]) return GMSX_ERR_DEVICE_MEM;  // a row of > 16 383 hub / 32 767 tail units: no graph that fits the device has one
         g->inline_hentries = int64_t(tot[0]);
         g->inline_tentries = int64_t(tot[1]);
         g->task_reverse = int64_t(tot[2]);
         if (g->htask_entries >= (int64_t(1) << 40) || g->ttask_entries >= (int64_t(1) << 40)) return GMSX_ERR_DEVICE_MEM;  // 40 position bits in a work item
-        if (int rc = dmalloc(&g->htask, g->htask_entries + 2, g)) return rc;
-        if (int rc = dmalloc(&g->ttask, g->ttask_entries + 2, g)) return rc;
+        if (int rc = dmalloc(&g->htask.lo, g->htask_entries + 2, g)) return rc;
+        if (int rc = dmalloc(&g->htask.hi, g->htask_entries + 2, g)) return rc;
+        if (int rc = dmalloc(&g->ttask.lo, g->ttask_entries + 2, g)) return rc;
+        if (int rc = dmalloc(&g->ttask.hi, g->ttask_entries + 2, g)) return rc;
         // FILL
         if (n > 0)
             hipLaunchKernelGGL(k_inline_entries<true>, dim3(vb), dim3(256), 0, s, n, g->dplus, opos, lidx, n_heavy, g->inline_limit, ihoff, itoff, inline_h_base,
@@ -1706,7 +1725,7 @@ int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out) {
             return GMSX_OK;
         }
     hipStream_t s = ctx().stream;
-    hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, g->n, g->sorted_dplus, threshold, reinterpret_cast<int64_t *>(g->scratch + 8));
+    hipLaunchKernelGGL(k_count_ge, dim3(1), dim3(1), 0, s, g->n, g->order, g->dplus, threshold, reinterpret_cast<int64_t *>(g->scratch + 8));
     GMSX_HIP(hipMemcpyAsync(out, g->scratch + 8, sizeof(int64_t), hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
     if (g->ge_used < 40) {

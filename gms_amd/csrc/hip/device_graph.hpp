@@ -28,7 +28,6 @@
 //
 //   dplus int32[n]                     true out-degree (hub + tail) per rank id
 //   order int32[n]                     rank ids by decreasing d+ (work-sorted launch order, heavy first);
-//   sorted_dplus int32[n]              dplus[order[i]] (for bin boundaries)
 // WORK ITEM of the triangle kernels: up to kTaskChunk consecutive entries of ONE pivot's hub-entry list (htask) or tail-entry list
 // (ttask).  A self-contained 64-byte record — everything a persistent workgroup needs to stage the item without a dependent lookup:
 // bc = first entry (40 bits) | entries << 40; cont = where the pivot's own container part lies (first id in hadj / tadj, 40 bits) | its
@@ -45,6 +44,30 @@ struct __attribute__((aligned(64))) gmsx_tc_item {
     uint32_t reserved[7];
 };
 static_assert(sizeof(gmsx_tc_item) == 64, "work item record = one 64-byte line");
+// TASK LIST: the stream-row descriptors of all receivers, 6 bytes per entry in two arrays (round 5; 8-byte words before: −1.9 GB at scale
+// 26).  An entry is the 64-bit descriptor first unit << 24 | form << 22 | units squeezed into 48 bits — lo = (first unit & 0xffff) << 16 |
+// form | units, hi = first unit >> 16 — and expanded again when a workgroup stages its item in LDS (two coalesced loads per entry instead of
+// one; the scan path reads the 8-byte LDS copy as before).  Hub lists: 2 form bits + 14 unit bits (a hub row is <= 65 535 ids = 8 192
+// list units, and another form is only taken when it is shorter); tail lists: 1 form bit (list / 16-bit delta) + 15 unit bits (131 068
+// ids in the 32-bit form).  The build refuses a graph whose rows or pools exceed the fields (k_task_limits: GMSX_ERR_DEVICE_MEM).
+constexpr uint32_t kTaskHubUnitsMax = (1u << 14) - 1, kTaskTailUnitsMax = (1u << 15) - 1;
+struct TaskList {
+    uint32_t *lo = nullptr;
+    uint16_t *hi = nullptr;
+    bool tail = false;
+    __host__ __device__ TaskList at(int64_t first) const { return TaskList{lo + first, hi + first, tail}; }
+    __device__ __forceinline__ unsigned long long get(int64_t i) const {
+        const uint32_t l = lo[i], h = hi[i];
+        const unsigned long long first = ((unsigned long long)h << 16) | (l >> 16);
+        const uint32_t form = tail ? ((l >> 15) & 1u) << 1 : (l >> 14) & 3u, units = tail ? l & kTaskTailUnitsMax : l & kTaskHubUnitsMax;
+        return (first << 24) | ((unsigned long long)form << 22) | units;
+    }
+    __device__ __forceinline__ void put(int64_t i, unsigned long long d) const {
+        const uint32_t first = uint32_t(d >> 24), form = (uint32_t(d) >> 22) & 3u, units = uint32_t(d) & 0x3fffffu;
+        lo[i] = (first << 16) | (tail ? (form >> 1) << 15 : form << 14) | units;
+        hi[i] = uint16_t(first >> 16);
+    }
+};
 struct gmsx_graph {
     int64_t n = 0, nnz = 0, m = 0;
     int64_t *off = nullptr;
@@ -77,15 +100,15 @@ struct gmsx_graph {
     // pivot's tail set); form 2 = 16-bit delta: 32-bit base, count, five 16-bit gaps — 6 ids per unit, 2.67 B/id against 4 B/id
     // TASK LISTS (tc.hip).  |N+(u) ∩ N+(v)| of an oriented edge (u,v) can be counted with either endpoint as the pivot (its row as bitmap +
     // tail set in LDS) and the other one streamed; the pass streams the SMALLER row (fewer 16-byte units).  So every receiving vertex w
-    // owns two lists of 8-byte stream-row descriptors — HUB entries (rows probed against w's bitmap) and TAIL entries (rows probed against
+    // owns two lists of stream-row descriptors (6 bytes each: TaskList) — HUB entries (rows probed against w's bitmap) and TAIL entries (rows probed against
     // w's tail set) — one descriptor per non-empty row part of every edge it is the pivot of: members v of its own row whose rows are the
     // smaller ones ("forward"), in-neighbours u that hand their edge over because the part of their row below w is smaller ("reverse", cut
     // at w's id; only towards heavy w), and the 64-unit chunks of w's inline rows.  Each list is laid out CLASS BY CLASS — class = (form,
     // ceil(log2 units)) — by counting and bucketing at build time (no sort), so the kernels run compile-time-shaped loops over runs of
     // equally formed, similarly long rows: 4-, 8- or 16-lane groups for rows of <= 4, <= 8, more units.  The order INSIDE a class is the
     // arrival order of atomic cursors — it differs from process to process, which is why a multi-GPU shard is a set of whole PIVOTS.
-    unsigned long long *htask = nullptr;  // hub entries of all receivers, receiver by receiver (in `order`), class by class
-    unsigned long long *ttask = nullptr;  // tail entries likewise
+    TaskList htask{nullptr, nullptr, false};  // hub entries of all receivers, receiver by receiver (in `order`), class by class
+    TaskList ttask{nullptr, nullptr, true};   // tail entries likewise
     int64_t htask_entries = 0, ttask_entries = 0;
     struct gmsx_tc_item *hitem = nullptr, *titem = nullptr;  // work items over htask / ttask
     int64_t hitems = 0, titems = 0;
@@ -95,7 +118,7 @@ struct gmsx_graph {
     mutable struct gmsx_tc_item *shard_hitem = nullptr, *shard_titem = nullptr;
     mutable int64_t shard_hitems = 0, shard_titems = 0;
     mutable int shard_idx_part = -1, shard_idx_nparts = -1;
-    int32_t *tunits = nullptr;           // [n] oriented edges whose entries live at this vertex (forward + reverse): the bookkeeping of gmsx_stats.units
+    int32_t *tunits = nullptr;           // [heavy pivots, by position in `order`] oriented edges whose entries live at this pivot (forward + reverse): the bookkeeping of gmsx_stats.units
     int64_t task_reverse = 0;            // edges handed over to the other endpoint
     // LIGHT EDGES (round 4, k_tc_light): the oriented edges (u, v) no work item covers — u light (2 <= d+ < kHeavy), v a FAR LIGHT member of it
     // (rank id >= inline_limit, d+ < kHeavy) — as self-contained 32-byte records: where the hub part and the tail part of u's row and of
@@ -122,7 +145,6 @@ struct gmsx_graph {
     bool rows_sorted = false;   // both containers of every row ascending (always: sorted in vertex ranges at upload)
     int32_t *dplus = nullptr;
     int32_t *order = nullptr;
-    int32_t *sorted_dplus = nullptr;
     int64_t hub_entries = 0, tail_entries = 0;
     int32_t max_dplus = 0;
     int32_t max_deg = 0;

@@ -196,7 +196,7 @@ __device__ __forceinline__ uint32_t tail_delta_unit_hits(const uint32_t *flt, co
 // ---------------------------------------------------------------------------------------------
 // Work items (device_graph.hpp): one workgroup per item = up to kTaskChunk consecutive entries of ONE pivot's hub-entry list (k_tc_block:
 // the pivot's hub part staged as the 65536-bit bitmap, 8 KB) or tail-entry list (k_tc_tail: the pivot's tail part as filter + hash set,
-// tiled if longer than half the table).  An entry is one 8-byte stream-row descriptor — a member's row, the cut row of an in-neighbour
+// tiled if longer than half the table).  An entry is one stream-row descriptor (6 bytes, TaskList) — a member's row, the cut row of an in-neighbour
 // that handed its edge over, a 64-unit chunk of an inline row: the kernels cannot tell and need not.
 // ---------------------------------------------------------------------------------------------
 static constexpr int kBlockLog = 10;
@@ -235,13 +235,20 @@ __device__ __forceinline__ uint32_t tail_unit_hits_f(const uint32_t *flt, const 
 // issued a moment ago, and a wave never has more than one load instruction in flight (rounds 2-3: that, times 32 waves per CU, was the
 // 3.7 TB/s of the tail items — 0.9 KB per wave and memory latency).  With counted waits the D loads overlap.
 // HIT(p, j) = hits of unit j of a row.
-template <int W, int D>
+// An item's task entries as they lie in LDS: the two halves of the 6-byte entries (TaskList) as they come from HBM — the entry is taken
+// apart when a group opens its row (one ds_read_b32 + one ds_read_u16 and an alignbit instead of one ds_read_b64 and a 64-bit shift).
+struct StagedTasks {
+    uint32_t lo[kTaskChunk];
+    uint32_t hi[kTaskChunk / 2 + 2];  // 16 bits per entry; the direct-to-LDS copy moves whole dwords: an item that begins at an odd entry has one foreign half in front
+};
+template <int W, int D, bool TAIL>
 struct StepStream {
     static constexpr int G = 256 / W;
-    const unsigned long long *sdesc;
+    const uint32_t *slo;
+    const uint16_t *shi;
     const uint4 *pool4;
     int hi, sub;
-    // cursor of the step to ISSUE: entry e (descriptor d = first unit << 24 | form << 22 | units), unit j of this lane.  Per row: its
+    // cursor of the step to ISSUE: entry e (first unit of its row, form, units), unit j of this lane.  Per row: its
     // first unit's address, the index of its last unit (a lane without a unit in the step re-reads that one: same line as its
     // neighbours'), and j's bound for "the row is through"
     int e, units, last, lim, j, form;
@@ -253,10 +260,12 @@ struct StepStream {
     uint4 p[S];
     int pj[S];    // unit index of the lane in that step | form << 24, -1 = none
     __device__ __forceinline__ void open_row() {
-        const unsigned long long d = e < hi ? sdesc[e] : 0ull;
-        row = pool4 + (d >> 24);
-        units = int(uint32_t(d) & 0x3fffffu);
-        form = int((uint32_t(d) >> 22) & 3u) << 24;
+        int ee = e;
+        asm volatile("" : "+v"(ee));  // (both LDS addresses from the entry index each time: as two running addresses they cost two registers for the whole item)
+        const uint32_t l = e < hi ? slo[ee] : 0u, h = e < hi ? uint32_t(shi[ee]) : 0u;
+        row = pool4 + __builtin_amdgcn_alignbit(h, l, 16);  // first unit = hi << 16 | lo >> 16
+        units = int(l & (TAIL ? kTaskTailUnitsMax : kTaskHubUnitsMax));
+        form = TAIL ? int((l >> 15) & 1u) << 25 : int((l >> 14) & 3u) << 24;  // (tail lists keep one form bit: list 0 / delta 2)
         last = max(units - 1, 0);
         lim = units + sub;
         j = sub;
@@ -273,8 +282,9 @@ struct StepStream {
     }
     // entries [lo, hi_) of the item: the first D steps go out here — BEFORE the pivot's bitmap / table is rebuilt, so that they are in
     // flight while it is (the item kernel), not after
-    __device__ __forceinline__ void start(const unsigned long long *sd, const uint32_t *__restrict__ pool, int lo, int hi_, int tid) {
-        sdesc = sd;
+    __device__ __forceinline__ void start(const StagedTasks &sd, int odd, const uint32_t *__restrict__ pool, int lo, int hi_, int tid) {
+        slo = sd.lo;
+        shi = reinterpret_cast<const uint16_t *>(sd.hi) + odd;
         pool4 = reinterpret_cast<const uint4 *>(pool);
         hi = hi_;
         sub = tid % W;
@@ -334,8 +344,11 @@ __device__ __forceinline__ uint32_t tail_hits_by_form(const uint32_t *flt, const
     return f == kFormDelta ? tail_delta_unit_hits(flt, tbl, mask, shift, p) : tail_unit_hits(flt, tbl, mask, shift, p);
 }
 // copies the item's descriptors to LDS
-__device__ __forceinline__ void stage_item(const unsigned long long *__restrict__ ent, int ne, int tid, unsigned long long *sdesc) {
-    for (int i = tid; i < ne; i += 256) sdesc[i] = ent[i];
+__device__ __forceinline__ void stage_item(const TaskList ent, int ne, int tid, StagedTasks &sd) {
+    for (int i = tid; i < ne; i += 256) {
+        sd.lo[i] = ent.lo[i];
+        reinterpret_cast<uint16_t *>(sd.hi)[i] = ent.hi[i];
+    }
     __syncthreads();
 }
 __device__ __forceinline__ void block_add(unsigned long long cnt, unsigned long long *red, int lane, int wave, int tid, unsigned long long *__restrict__ acc) {
@@ -350,10 +363,10 @@ __device__ __forceinline__ void block_add(unsigned long long cnt, unsigned long 
 
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                  const uint32_t *__restrict__ spool, const unsigned long long *__restrict__ htask,
+                                                  const uint32_t *__restrict__ spool, const TaskList htask,
                                                   const gmsx_tc_item *__restrict__ items, unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords + 128];  // + slack: the delta probes of unused slots read up to 104 words past the bitmap
-    __shared__ unsigned long long sdesc[kTaskChunk];
+    __shared__ StagedTasks sdesc;
     __shared__ unsigned long long red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const gmsx_tc_item &it = items[blockIdx.x];
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int hl = int(hoff[u + 1] - hb);
     const int ne = int(it.bc >> 40);
     for (int i = tid; i < (kBitmapWords + 128) / 4; i += 256) reinterpret_cast<uint4 *>(bm)[i] = make_uint4(0u, 0u, 0u, 0u);
-    stage_item(htask + (it.bc & 0xffffffffffull), ne, tid, sdesc);
+    stage_item(htask.at(int64_t(it.bc & 0xffffffffffull)), ne, tid, sdesc);
     for (int i = tid; i < hl; i += 256) {
         const uint32_t id = hadj[hb + i];
         if (id != 0xFFFFu) atomicOr(&bm[id >> 5], 1u << (id & 31u));
@@ -370,19 +383,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __syncthreads();
     uint32_t cnt = 0;
 #ifndef GMSX_TC_STAGING_ONLY  // (A/B build: what the per-item fixed cost alone takes)
-    StepStream<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH> st;
-    st.start(sdesc, spool, 0, ne, tid);
+    StepStream<GMSX_TC_HUB_GROUP, GMSX_TC_HUB_DEPTH, false> st;
+    st.start(sdesc, 0, spool, 0, ne, tid);
     cnt += st.run([](uint4 p, int j, int f) { return hub_hits_by_form(bm, p, j, f); });
 #endif
     block_add(cnt, red, lane, wave, tid, acc);
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_tc_tail(const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
-                                                 const uint32_t *__restrict__ tpool, const unsigned long long *__restrict__ ttask,
+                                                 const uint32_t *__restrict__ tpool, const TaskList ttask,
                                                  const gmsx_tc_item *__restrict__ items, unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) int32_t tbl[1 << kBlockLog];
     __shared__ __attribute__((aligned(16))) uint32_t flt[kFilterWords];
-    __shared__ unsigned long long sdesc[kTaskChunk];
+    __shared__ StagedTasks sdesc;
     __shared__ unsigned long long red[4];
     constexpr int TILE = (1 << kBlockLog) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -391,7 +404,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     const int64_t tb = toff[u];
     const int tl = int(toff[u + 1] - tb);
     const int ne = int(it.bc >> 40);
-    stage_item(ttask + (it.bc & 0xffffffffffull), ne, tid, sdesc);
+    stage_item(ttask.at(int64_t(it.bc & 0xffffffffffull)), ne, tid, sdesc);
     // the table sized for THIS pivot (most tail parts are a few dozen ids): 2^log slots >= 2 x keys
     int log = 6;
     while ((1 << log) < 2 * min(tl, TILE)) ++log;
@@ -411,8 +424,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         }
         __syncthreads();
 #ifndef GMSX_TC_STAGING_ONLY
-        StepStream<GMSX_TC_TAIL_GROUP, GMSX_TC_TAIL_DEPTH> st;
-        st.start(sdesc, tpool, 0, ne, tid);
+        StepStream<GMSX_TC_TAIL_GROUP, GMSX_TC_TAIL_DEPTH, true> st;
+        st.start(sdesc, 0, tpool, 0, ne, tid);
         cnt += st.run([mask, shift](uint4 p, int, int f) { return tail_hits_by_form(flt, tbl, mask, shift, p, f); });
 #endif
     }
@@ -447,13 +460,14 @@ __device__ __forceinline__ void glds_dword(const uint32_t *src, uint32_t lds_byt
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
 }
 __device__ __forceinline__ void stage_dwords(const uint32_t *__restrict__ src, uint32_t lds_byte_addr, int ndw, int lane, int wave) {
+    asm volatile("" : "+v"(lane));  // (the per-lane source address is formed here, not at the top of the item and carried — or spilled — across its scans)
     for (int base = wave * 64; base < ndw; base += 256)  // uniform per wave
         if (base + lane < ndw) glds_dword(src + base + lane, lds_byte_addr + 4u * uint32_t(base));
 }
 // LDS of a k_tc_items workgroup (18.9 KB: eight per CU)
 struct ItemLds {
     uint32_t bm[kBitmapWords + 128];  // hub items: the pivot bitmap (+ slack: the delta probes of unused slots read up to 104 words past it); tail items: table | filter
-    unsigned long long sdesc[2][kTaskChunk];
+    StagedTasks sdesc[2];
     uint32_t idst[2][kIdStage];
     uint32_t rec[3][16];  // records of the items A (scanned), B (staging), C (arriving)
     unsigned long long red[4];
@@ -462,12 +476,12 @@ struct ItemLds {
 // One queue (hub items or tail items) until it is dry.
 template <bool TAIL>
 __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint32_t *__restrict__ pool,
-                                          const unsigned long long *__restrict__ task, const gmsx_tc_item *__restrict__ items, int n_items,
+                                          const TaskList task, const gmsx_tc_item *__restrict__ items, int n_items,
                                           unsigned int *__restrict__ qhead, unsigned long long &total) {
     constexpr int TILE = (1 << kBlockLog) / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *bm = L.bm;
-    const uint32_t a_sdesc = lds_addr(&L.sdesc[0][0]), a_idst = lds_addr(&L.idst[0][0]), a_rec = lds_addr(&L.rec[0][0]);
+    const uint32_t a_slo = lds_addr(&L.sdesc[0].lo[0]), a_shi = lds_addr(&L.sdesc[0].hi[0]), a_idst = lds_addr(&L.idst[0][0]), a_rec = lds_addr(&L.rec[0][0]);
     __syncthreads();  // the previous phase is over: its LDS is free
     if (tid == 0) {
         const unsigned a = atomicAdd(qhead, unsigned(kGrab));
@@ -495,7 +509,8 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
         const uint32_t bc_lo = uni32(rec[0]), bc_hi = uni32(rec[1]), c_lo = uni32(rec[2]), c_hi = uni32(rec[3]);
         const uint64_t first = (uint64_t(bc_hi & 0xffu) << 32) | bc_lo, cb = (uint64_t(c_hi & 0xffu) << 32) | c_lo;
         const int ne = int(bc_hi >> 8), cn = int(c_hi >> 8);
-        stage_dwords(reinterpret_cast<const uint32_t *>(task + first), a_sdesc + uint32_t(b) * uint32_t(sizeof(L.sdesc[0])), 2 * ne, lane, wave);
+        stage_dwords(task.lo + first, a_slo + uint32_t(b) * uint32_t(sizeof(StagedTasks)), ne, lane, wave);
+        stage_dwords(reinterpret_cast<const uint32_t *>(task.hi + (first & ~uint64_t(1))), a_shi + uint32_t(b) * uint32_t(sizeof(StagedTasks)), (int(first & 1u) + ne + 1) / 2, lane, wave);
         if (TAIL) stage_dwords(reinterpret_cast<const uint32_t *>(tadj + cb), a_idst + uint32_t(b) * uint32_t(sizeof(L.idst[0])), min(cn, kIdStage), lane, wave);
         else stage_dwords(reinterpret_cast<const uint32_t *>(hadj + cb), a_idst + uint32_t(b) * uint32_t(sizeof(L.idst[0])), min(cn, 2 * kIdStage) / 2, lane, wave);
     };
@@ -543,13 +558,13 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
         const uint32_t c_lo = uni32(recA[2]), c_hi = uni32(recA[3]);
         const int64_t cb = int64_t((uint64_t(c_hi & 0xffu) << 32) | c_lo);
         const int cn = int(c_hi >> 8);
-        const unsigned long long *sd = L.sdesc[buf];
-        const int neA = int(uni32(recA[1]) >> 8);
+        const StagedTasks &sd = L.sdesc[buf];
+        const int neA = int(uni32(recA[1]) >> 8), oddA = int(uni32(recA[0]) & 1u);  // (an odd first entry: its 16-bit half is the second of the first dword staged)
         uint32_t c = 0;
         // the item's step stream opens HERE: its first loads are in flight while the pivot's bitmap / table is brought up to date
-        StepStream<TAIL ? GMSX_TC_TAIL_GROUP : GMSX_TC_HUB_GROUP, TAIL ? GMSX_TC_TAIL_DEPTH : GMSX_TC_HUB_DEPTH> st;
+        StepStream<TAIL ? GMSX_TC_TAIL_GROUP : GMSX_TC_HUB_GROUP, TAIL ? GMSX_TC_TAIL_DEPTH : GMSX_TC_HUB_DEPTH, TAIL> st;
 #ifndef GMSX_TC_STAGING_ONLY
-        if (!TAIL) st.start(sd, pool, 0, neA, tid);  // (the tail items open theirs behind the table build: carried across it, the stream's state spills)
+        if (!TAIL) st.start(sd, oddA, pool, 0, neA, tid);  // (the tail items open theirs behind the table build: carried across it, the stream's state spills)
 #endif
         if (!TAIL) {
             const int pivotA = int(uni32(recA[4]));
@@ -589,7 +604,9 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
                 for (int i = tid; i < size; i += 256) tbl[i] = -1;
                 reinterpret_cast<uint4 *>(flt)[tid] = make_uint4(0u, 0u, 0u, 0u);  // kFilterWords = 4 x 256
                 __syncthreads();
-                for (int i = tid; i < tn; i += 256) {
+                int tin = tid0;
+                asm volatile("" : "+v"(tin));  // (per-lane addresses of this loop stay inside the tile: held across the scans they spill)
+                for (int i = tin; i < tn; i += 256) {
                     const int32_t t = t0 + i < kIdStage ? int32_t(L.idst[buf][t0 + i]) : tadj[cb + t0 + i];
                     set_insert(tbl, mask, shift, t);
                     atomicOr(&flt[(uint32_t(t) >> 5) & uint32_t(kFilterWords - 1)], 1u << (uint32_t(t) & 31u));
@@ -603,11 +620,11 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
                 //  are, the tail items took 19.6 ms instead of 17.8)
                 const int nl = int(uni32(recA[8]) & 0xffffu);  // fbeg[2]: the list entries come first
                 if (nl > 0) {
-                    st.start(sd, pool, 0, nl, tid);
+                    st.start(sd, oddA, pool, 0, nl, tid);
                     c += st.run([=](uint4 p, int, int) { return tail_unit_hits(flt, tbl, mask, shift, p); });
                 }
                 if (neA > nl) {
-                    st.start(sd, pool, nl, neA, tid);
+                    st.start(sd, oddA, pool, nl, neA, tid);
                     c += st.run([=](uint4 p, int, int) { return tail_delta_unit_hits(flt, tbl, mask, shift, p); });
                 }
 #endif
@@ -639,7 +656,7 @@ __device__ __forceinline__ void item_loop(ItemLds &L, const uint16_t *__restrict
 #endif
 template <bool TAIL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TAIL ? GMSX_TC_TAIL_MIN_WAVES : GMSX_TC_HUB_MIN_WAVES, 8))) void k_tc_items(
-    const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint32_t *__restrict__ pool, const unsigned long long *__restrict__ task,
+    const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint32_t *__restrict__ pool, const TaskList task,
     const gmsx_tc_item *__restrict__ items, int n_items, unsigned int *__restrict__ qhead, unsigned long long *__restrict__ acc) {
     __shared__ __attribute__((aligned(16))) ItemLds L;
     const int tid = threadIdx.x;
@@ -789,7 +806,7 @@ __global__ __launch_bounds__(256) void k_tc_light(const uint16_t *__restrict__ h
 //   light pivot u (2 <= d+ < 64; k_tc_stats, wave per pivot position): per far light member v (rank id >= inline_limit, d+ < 64) the
 //       32-byte edge record and the hub / tail parts of both rows as k_tc_light reads them (u's tail part up to v);
 //   work item (k_tc_item_stats, wave per item): the pivot's container (hub part for a hub item, tail part for a tail item) once; per
-//       entry 8 bytes of descriptor and the stream row it describes (whole 16-byte units) — members' rows, cut rows and inline chunks alike.
+//       entry 6 bytes of descriptor and the stream row it describes (whole 16-byte units) — members' rows, cut rows and inline chunks alike.
 // out[0] = oriented edges counted by the shard: every edge of a light or idle pivot at the pivot, the edges a heavy pivot handed to its
 // first members over inline at the pivot, every other edge of a heavy pivot where its entries live (tunits, written by the build);
 // out[1] = id slots probed (per unit: 8 list, 14 byte-delta, 10 gap-12, 4 bitset words; 4 / 6 tail ids).  A shard = the pivots at the
@@ -807,8 +824,9 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
         if (nparts > 1 && shard_of(pos, nparts) != part) continue;
         const int32_t u = order[pos];
         const int du = dplus[u];
-        if (lane == 0) units += (unsigned long long)tunits[u];  // forward + reverse edges whose entries live here
-        if (du >= kHeavy) {  // … and the edges to its first members that went inline (no entry anywhere)
+        if (du >= kHeavy) {  // forward + reverse edges whose entries live here (the heavy pivots are the first of `order`) …
+            if (lane == 0) units += (unsigned long long)tunits[pos];
+            // … and the edges to its first members that went inline (no entry anywhere)
             const int hl = min(int(hoff[u + 1] - hoff[u]), inline_first), tl = min(int(toff[u + 1] - toff[u]), inline_first - hl);
             int32_t v = -1;
             if (lane < hl) {
@@ -842,7 +860,7 @@ __global__ __launch_bounds__(256) void k_tc_stats(const int64_t *__restrict__ ho
     }
 }
 // one list of work items (hub or tail)
-__global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict__ coff, int bytes_per_id, int tail, const unsigned long long *__restrict__ task,
+__global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict__ coff, int bytes_per_id, int tail, const TaskList task,
                                                        const gmsx_tc_item *__restrict__ items, int64_t n_items, int nparts, int part,
                                                        unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -860,8 +878,8 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
         const int64_t b = int64_t(it.bc & 0xffffffffffull);
         if (lane == 0) bytes += (unsigned long long)bytes_per_id * (unsigned long long)(coff[it.pivot + 1] - coff[it.pivot]);
         for (int i = lane; i < ne; i += 64) {
-            const unsigned long long d = task[b + i];
-            bytes += 8ull + 16ull * (d & 0x3fffffull);
+            const unsigned long long d = task.get(b + i);
+            bytes += 6ull + 16ull * (d & 0x3fffffull);
             probes += slots(d);
         }
     }
@@ -878,7 +896,7 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
 // Diagnostics (gmsx_tc_stream_breakdown): the algorithmic stream bytes of one pass (= gmsx_stats.stream_bytes) by what is read.
 //   out[0..2]  hub stream rows named by the work items' entries, by form (16-bit list, bitset, byte-delta)
 //   out[3..4]  tail stream rows named by the entries (32-bit list, 16-bit delta)
-//   out[5]     the entries themselves (8 bytes each)          out[6]  the pivots' own containers (hub part per hub item, tail part per tail item)
+//   out[5]     the entries themselves (6 bytes each)          out[6]  the pivots' own containers (hub part per hub item, tail part per tail item)
 //   out[7]     of out[0] + out[3]: inline rows (ids handed over by light pivots; filled in by the host from the build's figures)
 //   out[8..9]  light edges (k_tc_light): hub / tail parts of the far light members' rows
 //   out[10]    light edges: the 32-byte records + the pivots' own hub / tail parts (once per edge)
@@ -886,8 +904,8 @@ __global__ __launch_bounds__(256) void k_tc_item_stats(const int64_t *__restrict
 //   out[15..20] reserved (0)
 __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict__ hoff, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                       const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
-                                                      const unsigned long long *__restrict__ htask, const gmsx_tc_item *__restrict__ hitem, int64_t hitems,
-                                                      const unsigned long long *__restrict__ ttask, const gmsx_tc_item *__restrict__ titem, int64_t titems,
+                                                      const TaskList htask, const gmsx_tc_item *__restrict__ hitem, int64_t hitems,
+                                                      const TaskList ttask, const gmsx_tc_item *__restrict__ titem, int64_t titems,
                                                       int32_t inline_limit, int64_t first_light, int64_t end_light,
                                                       unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
@@ -897,7 +915,7 @@ __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict_
     for (int64_t q = wave0; q < hitems + titems; q += nwaves) {
         const bool tail = q >= hitems;
         const gmsx_tc_item &it = tail ? titem[q - hitems] : hitem[q];
-        const unsigned long long *task = tail ? ttask : htask;
+        const TaskList task = tail ? ttask : htask;
         const int ne = int(it.bc >> 40);
         const int64_t b0 = int64_t(it.bc & 0xffffffffffull);
         if (lane == 0) {
@@ -906,12 +924,12 @@ __global__ __launch_bounds__(256) void k_tc_breakdown(const int64_t *__restrict_
             c[13] += 1;
         }
         for (int i = lane; i < ne; i += 64) {
-            const unsigned long long d = task[b0 + i];
+            const unsigned long long d = task.get(b0 + i);
             const unsigned long long db = 16ull * (d & 0x3fffffull);
             const int fd = int((d >> 22) & 3);
             if (tail) c[fd == kFormDelta ? 4 : 3] += db;
             else c[fd == kFormList ? 0 : fd == kFormBitset ? 1 : 2] += db;
-            c[5] += 8;
+            c[5] += 6;
         }
     }
     for (int64_t pos = first_light + wave0; pos < end_light; pos += nwaves) {
@@ -947,7 +965,7 @@ __device__ __forceinline__ int hist_bin(unsigned long long units) {
 }
 // Diagnostics behind gmsx_tc_comembership: one key per entry of the hub items, (position of the item's pivot in `order`) / batch << 40 | (offset of
 // the stream row the entry names) / 16, and the 16-byte units the entry streams of it — sorted and reduced by key on the host side of the call
-__global__ __launch_bounds__(256) void k_tc_comember_keys(const unsigned long long *__restrict__ htask, const gmsx_tc_item *__restrict__ hitem, int64_t hitems, int batch,
+__global__ __launch_bounds__(256) void k_tc_comember_keys(const TaskList htask, const gmsx_tc_item *__restrict__ hitem, int64_t hitems, int batch,
                                                          unsigned long long *__restrict__ keys, uint32_t *__restrict__ vals, unsigned long long *__restrict__ sums) {
     unsigned long long ents = 0, units = 0;
     for (int64_t i = blockIdx.x; i < hitems; i += gridDim.x) {
@@ -956,7 +974,7 @@ __global__ __launch_bounds__(256) void k_tc_comember_keys(const unsigned long lo
         const int n = int(it.bc >> 40);
         const unsigned long long b = (unsigned long long)(it.pos / batch) << 40;
         for (int e = threadIdx.x; e < n; e += 256) {
-            const unsigned long long d = htask[first + e];
+            const unsigned long long d = htask.get(int64_t(first + e));
             keys[first + e] = b | (d >> 24);
             vals[first + e] = uint32_t(d & 0x3fffffull);
             ++ents;
@@ -982,8 +1000,8 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
                                                      const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                      const int32_t *__restrict__ dplus, const int32_t *__restrict__ order,
                                                      const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ trow,
-                                                     const unsigned long long *__restrict__ htask, const gmsx_tc_item *__restrict__ hitem, int64_t hitems,
-                                                     const unsigned long long *__restrict__ ttask, const gmsx_tc_item *__restrict__ titem, int64_t titems,
+                                                     const TaskList htask, const gmsx_tc_item *__restrict__ hitem, int64_t hitems,
+                                                     const TaskList ttask, const gmsx_tc_item *__restrict__ titem, int64_t titems,
                                                      int64_t end, unsigned long long *__restrict__ out) {
     __shared__ unsigned long long h[256];
     for (int i = threadIdx.x; i < 256; i += 256) h[i] = 0;
@@ -1000,7 +1018,7 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
     for (int64_t q = wave0; q < hitems + titems; q += nwaves) {
         const bool tail = q >= hitems;
         const gmsx_tc_item &it = tail ? titem[q - hitems] : hitem[q];
-        const unsigned long long *task = tail ? ttask : htask;
+        const TaskList task = tail ? ttask : htask;
         const int ne = int(it.bc >> 40);
         const int64_t b0 = int64_t(it.bc & 0xffffffffffull);
         if (lane == 0) {
@@ -1009,7 +1027,7 @@ __global__ __launch_bounds__(256) void k_tc_row_hist(const int64_t *__restrict__
             atomicAdd(&h[243], tail ? 4ull * (unsigned long long)(toff[it.pivot + 1] - toff[it.pivot]) : 2ull * (unsigned long long)(hoff[it.pivot + 1] - hoff[it.pivot]));
         }
         for (int i = lane; i < ne; i += 64) {
-            const unsigned long long d = task[b0 + i];
+            const unsigned long long d = task.get(b0 + i);
             if (tail) add(((d >> 22) & 3) == kFormDelta ? 4 : 3, d & 0x3fffffull);
             else add(min(int((d >> 22) & 3), 2), d & 0x3fffffull);  // 12-bit-gap rows are counted with the byte-delta ones
         }

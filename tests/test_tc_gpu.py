@@ -219,7 +219,7 @@ def test_inline_limit(gpu, oracle, hub_limit, inline_limit):
                                    {"GMSX_TC_ITEM_WGS": "1"}, {"GMSX_TC_ITEM_WGS": "3"}, {"GMSX_TC_GAP12": "0"}, {"GMSX_TC_GAP12": "2"},
                                    {"GMSX_TC_GAP12": "2", "GMSX_TC_DELTA": "0"}, {"GMSX_TC_HYBRID": "1"}, {"GMSX_TC_HYBRID": "2"},
                                    {"GMSX_TC_HYBRID": "2", "GMSX_TC_DELTA": "0"},
-                                   {"GMSX_TC_INLINE_FIRST": "64"}, {"GMSX_TC_INLINE_FIRST": "5"}, {"GMSX_TC_INLINE_FIRST": "1", "GMSX_TC_TWO_SIDED": "0"},
+                                   {"GMSX_TC_INLINE_FIRST": "64"}, {"GMSX_TC_INLINE_FIRST": "48"}, {"GMSX_TC_INLINE_FIRST": "5"}, {"GMSX_TC_INLINE_FIRST": "1", "GMSX_TC_TWO_SIDED": "0"},
                                    {"GMSX_TC_HOT_WINDOWS": "1", "GMSX_TC_HOT_KB": "2", "GMSX_TC_HOT_MIN": "4"},
                                    {"GMSX_TC_HOT_WINDOWS": "3", "GMSX_TC_HOT_KB": "1", "GMSX_TC_HOT_MIN": "1"},
                                    {"GMSX_TC_HOT_WINDOWS": "8", "GMSX_TC_HOT_KB": "4", "GMSX_TC_HOT_MIN": "16", "GMSX_TC_PERSIST": "0"}])
@@ -305,13 +305,13 @@ def test_shards_of_separate_processes_add_up(gpu):
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
     assert rec["ok"] and rec["total"] == rec["sum_of_process_shards"] == rec["sum_of_sharded_uploads"] and rec["units"] == rec["m"], rec
-    assert max(rec["bytes_sharded"]) < 0.85 * rec["bytes_full"], rec  # a third of the task lists and inline rows each (scale 19: 0.75; scale 26: 0.45)
+    assert max(rec["bytes_sharded"]) < 0.9 * rec["bytes_full"], rec  # a third of the task lists and inline rows each; the base layout and the stream rows are whole (scale 19: 0.85 — 0.75 before round 5 shrank what is sharded)
 
 
 def test_containers_that_do_not_fit_fall_back_to_passes(gpu, oracle):
     """When the triangle-count containers of the whole graph do not fit the device, the library builds them for 1/k of the pivots at a time
     and walks k passes instead of returning GMSX_ERR_DEVICE_MEM.  GMSX_TC_MEM_LIMIT_MB (test hook) pretends the device is small: RMAT scale
-    18 needs ~0.3 GB of containers; with a 96 MB budget the count, the units, the shard sums and the per-vertex path stay exact."""
+    18 needs 83 MB of containers (round 5; passes at a budget of 96 / 64 / 40 / 24 / 16 MB: 1 / 2 / 4 / 16 / refused — tools/probes/tc_passes_probe.py); with a 64 MB budget the count, the units, the shard sums and the per-vertex path stay exact."""
     csr = host_graph(gpu, "kronecker", 18)
     want = oracle.tc_total(csr.offsets(), csr.neighbors())
     g0 = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_FOR_TC)
@@ -320,7 +320,7 @@ def test_containers_that_do_not_fit_fall_back_to_passes(gpu, oracle):
     t0, st0 = g0.tc_total(stats=True)
     g0.free()
     old = os.environ.get("GMSX_TC_MEM_LIMIT_MB")
-    os.environ["GMSX_TC_MEM_LIMIT_MB"] = "96"
+    os.environ["GMSX_TC_MEM_LIMIT_MB"] = "64"
     try:
         g = gpu.DeviceGraph.from_csr(csr)
         assert g.tc_passes == 0                      # lazy: nothing built yet
@@ -339,7 +339,7 @@ def test_containers_that_do_not_fit_fall_back_to_passes(gpu, oracle):
         assert sum(p[0] for p in parts) == want and sum(p[1]["units"] for p in parts) == csr.num_edges
         assert g2.tc_partial(0, 1) == want and g2.tc_total() == want and g2.tc_passes >= 4
         g2.free()
-        os.environ["GMSX_TC_MEM_LIMIT_MB"] = "96"
+        os.environ["GMSX_TC_MEM_LIMIT_MB"] = "64"
         assert g.kclique_count(3)[1] == want         # the base layout is untouched
         g.free()
         os.environ["GMSX_TC_MEM_LIMIT_MB"] = "1"     # nothing fits, not even 1/4096 of the pivots: the one refusal left
