@@ -174,42 +174,65 @@ __device__ __forceinline__ int sorted_find(const int32_t *__restrict__ lst, int 
     return (lo < len && lst[lo] == w) ? lo : -1;
 }
 
-// … behind a FILTER (round 5): 32 768 bits in LDS, bit (id mod 32768) set for every tail member of the pivot.  The tail list itself is in global memory
+// … behind a FILTER (round 5): 32 768 (8 192) bits in LDS, bit (id mod that) set for every tail member of the pivot.  The tail list itself is in global memory
 // and the search a chain of ~log2(tc) dependent loads; almost every streamed tail id is a miss (as in the triangle kernels, tc.hip), and from scale 24
 // on — where most vertices are tail vertices — those searches, not the rows, were what the BUILD waited for.
-static constexpr int kKcFilterWords = 1024;
-__device__ __forceinline__ int kc_tail_find(const uint32_t *flt, const int32_t *__restrict__ lst, int len, int32_t w) {
-    if (((flt[(uint32_t(w) >> 5) & uint32_t(kKcFilterWords - 1)] >> (uint32_t(w) & 31u)) & 1u) == 0u) return -1;
+// (A filter of 8 192 bits in the bins of d+ <= 704 — a workgroup more per CU — measured: scale 24 116.2 instead of 112.6 ms, the 512-thread bin at scale 26
+//  214 instead of < 149 ms: every false positive is a chain of global loads.  Hence also the SECOND bit per id, GMSX_KC_FILTER_BITS.)
+#ifndef GMSX_KC_FILTER_BITS
+#define GMSX_KC_FILTER_BITS 2
+#endif
+struct KcFilter {
+    const uint32_t *w;
+    uint32_t mask;  // words - 1
+};
+__device__ __forceinline__ uint32_t kc_filter_bit2(uint32_t w, uint32_t mask) { return (w * 0x9E3779B1u) >> 12 & (32u * mask + 31u); }  // bit index of the second hash
+__device__ __forceinline__ int kc_tail_find(const KcFilter flt, const int32_t *__restrict__ lst, int len, int32_t w) {
+    if (((flt.w[(uint32_t(w) >> 5) & flt.mask] >> (uint32_t(w) & 31u)) & 1u) == 0u) return -1;
+    if (GMSX_KC_FILTER_BITS > 1) {
+        const uint32_t b = kc_filter_bit2(uint32_t(w), flt.mask);
+        if (((flt.w[b >> 5] >> (b & 31u)) & 1u) == 0u) return -1;
+    }
     return sorted_find(lst, len, w);
 }
 
-// 32-bit tail container [row, row + l) of one tail member against the pivot's ascending tail list (local index hc + position)
-__device__ __forceinline__ void kc_stream_tail_from(const int32_t *__restrict__ row, int l, int j0, const int32_t *__restrict__ tail_list, int tc, int hc,
-                                                    uint32_t *orow, const uint32_t *flt) {
-    if (l <= 0) return;
-    int32_t p[kKcDepth];
+// 32-bit tail container [row, row + l) of one tail member against the pivot's ascending tail list (local index hc + position), from id `base` on:
+// lane `sub` of the group takes FOUR consecutive ids per step (one 16-byte load at a 4-byte-aligned address; tadj carries four ids of slack behind
+// its last row) — round 5: one id per lane and step, 64 bytes per group and load, made the tail parts 114 of the 330 ms the LDS bins' BUILD took at
+// scale 26 (44 % of the oriented edges are tail entries there).  Same ring of unconditional, counted loads as the hub lists.
+__device__ __forceinline__ void kc_stream_tail_from(const int32_t *__restrict__ row, int l, int base, int sub, const int32_t *__restrict__ tail_list, int tc, int hc,
+                                                    uint32_t *orow, const KcFilter flt) {
+    if (l <= base) return;  // uniform per group
+#ifdef GMSX_KC_NO_TAIL  // A/B build (wrong counts): the BUILD without the tail parts of its member rows
+    return;
+#endif
+    kc_u4u p[kKcDepth];
+    const int j0 = base + 4 * sub;
 #pragma unroll
-    for (int k = 0; k < kKcDepth; ++k) p[k] = row[min(j0 + 16 * k, l - 1)];
-    for (int j = j0; j < l; j += 16 * kKcDepth) {
+    for (int k = 0; k < kKcDepth; ++k) p[k] = *reinterpret_cast<const kc_u4u *>(row + (j0 + 64 * k < l ? j0 + 64 * k : 0));
+    for (int j = j0; j < l; j += 64 * kKcDepth) {  // the lanes of a group differ by at most one step
 #pragma unroll
         for (int k = 0; k < kKcDepth; ++k) {
-            const int32_t cur = p[k];
-            const int jc = j + 16 * k;
-            p[k] = row[min(jc + 16 * kKcDepth, l - 1)];
-            if (jc < l) {
-                const int t = kc_tail_find(flt, tail_list, tc, cur);
-                if (t >= 0) {
-                    const int idx = hc + t;
-                    atomicOr(&orow[idx >> 5], 1u << (idx & 31));
+            const kc_u4u cur = p[k];
+            const int jc = j + 64 * k, jn = jc + 64 * kKcDepth;
+            p[k] = *reinterpret_cast<const kc_u4u *>(row + (jn < l ? jn : 0));
+            const int32_t ids[4] = {int32_t(cur.x), int32_t(cur.y), int32_t(cur.z), int32_t(cur.w)};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (jc + q < l) {
+                    const int t = kc_tail_find(flt, tail_list, tc, ids[q]);
+                    if (t >= 0) {
+                        const int idx = hc + t;
+                        atomicOr(&orow[idx >> 5], 1u << (idx & 31));
+                    }
                 }
-            }
         }
     }
 }
 
 __device__ __forceinline__ void kc_stream_tail(const int32_t *__restrict__ row, int l, int sub, const int32_t *__restrict__ tail_list, int tc, int hc,
-                                               uint32_t *orow, const uint32_t *flt) {
-    kc_stream_tail_from(row, l, sub, tail_list, tc, hc, orow, flt);
+                                               uint32_t *orow, const KcFilter flt) {
+    kc_stream_tail_from(row, l, 0, sub, tail_list, tc, hc, orow, flt);
 }
 
 // ---- the BUILD as a pipeline over the members of a lane group (round 4) ---------------------------------------------------------------
@@ -255,7 +278,7 @@ __device__ __forceinline__ KcFirst kc_load_first(const uint16_t *__restrict__ ha
 __device__ __forceinline__ void kc_build_member_first(const uint16_t *__restrict__ hadj, const int32_t *__restrict__ tadj, const uint32_t *__restrict__ bmpool,
                                                       const KcExt &e, const KcFirst &f, bool bitset, int nw, bool is_hub, int hc,
                                                       const int32_t *__restrict__ tail_list, int tc, const uint32_t *bm, const unsigned short *pre,
-                                                      uint32_t *orow, int sub, const uint32_t *flt) {
+                                                      uint32_t *orow, int sub, const KcFilter flt) {
     if (bitset) {
         const int j = sub * 4;
         if (j < nw) kc_and4(f.h, *reinterpret_cast<const uint4 *>(bm + j), j, pre, orow);
@@ -272,7 +295,7 @@ __device__ __forceinline__ void kc_build_member_first(const uint16_t *__restrict
             const int t = kc_tail_find(flt, tail_list, tc, f.t);
             if (t >= 0) atomicOr(&orow[(hc + t) >> 5], 1u << ((hc + t) & 31));
         }
-        kc_stream_tail_from(tadj + e.tb, e.tl, sub + 16, tail_list, tc, hc, orow, flt);
+        kc_stream_tail_from(tadj + e.tb, e.tl, 16, sub, tail_list, tc, hc, orow, flt);
     }
 }
 
@@ -282,7 +305,7 @@ __device__ __forceinline__ void kc_build_member(const int64_t *__restrict__ hoff
                                                 const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                 const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool, int32_t dense_limit,
                                                 int32_t v, bool is_hub, int hc, const int32_t *__restrict__ tail_list, int tc,
-                                                const uint32_t *bm, const unsigned short *pre, uint32_t *orow, int sub, const uint32_t *flt) {
+                                                const uint32_t *bm, const unsigned short *pre, uint32_t *orow, int sub, const KcFilter flt) {
     const int64_t hb = hoff[v];
     const int hl = int(hoff[v + 1] - hb);
     if (is_hub && v < dense_limit) {
@@ -542,6 +565,64 @@ __device__ __forceinline__ unsigned long long kc4_row(const uint32_t (&wt)[WPL],
                 if (tmax >= 64 * g) acc += kc4_and_popc(wt[g], rj + 64 * g, min(tmax - 64 * g, 63) + 1);
 #endif
             if (act) total += acc;
+        }
+    }
+    return total;
+}
+
+// … the same sum with the neighbours of the row found WITHOUT the 64-lane shuffle scan, the six-step search and the five-step select (round 5, the
+// slab matrices: 0.16 s of the 0.39 s their bins took at scale 26 were those, 0.12 s the AND + popcount loops): only the band's column words
+// [jw0, jw1) of row i can hold neighbours, so the lanes that hold them write their set bits j - j0 into the wave's LDS list behind a DPP prefix sum,
+// and lane r of a chunk reads entry r.  (Tried and dropped: the lanes on the WORDS of the two rows, the neighbours walked by scalar code — no scan,
+// no list, one ds_read_b32 + v_and + v_bcnt per neighbour: 2.5 times SLOWER, 0.92 s for the slab bins: one LDS round trip per neighbour and wave
+// instead of 64 neighbours in flight.)
+static constexpr int kKcRowList = 256;  // entries of a wave's neighbour list (2 bytes each)
+template <int WPL>
+__device__ __forceinline__ unsigned long long kc4_row_list(const uint32_t (&wt)[WPL], const uint32_t *band, int BS, int j0, int jw0, int jw1, int lane,
+                                                           unsigned short *wbuf, int cap) {
+    unsigned long long total = 0;
+#pragma unroll
+    for (int h = 0; h < WPL; ++h) {
+        if (jw1 <= 64 * h || jw0 >= 64 * (h + 1)) continue;  // (uniform: the band's columns lie in one half, rarely in two)
+        const int t_me = lane + 64 * h;
+        uint32_t bits = (t_me >= jw0 && t_me < jw1) ? wt[h] : 0u;
+        while (__ballot(bits != 0u) != 0) {  // (one trip unless the row has more neighbours in the band than the list holds)
+            const int pc = __popc(bits);
+            int incl = pc;
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);
+            incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);
+            {
+                const int t0 = __builtin_amdgcn_readlane(incl, 15), t1 = __builtin_amdgcn_readlane(incl, 31), t2 = __builtin_amdgcn_readlane(incl, 47);
+                incl += (lane >= 16 ? t0 : 0) + (lane >= 32 ? t1 : 0) + (lane >= 48 ? t2 : 0);
+            }
+            const bool fits = incl <= cap;  // a run of lanes from lane 0 on (a word has at most 32 bits <= cap)
+            const int nfit = __popcll(__ballot(fits));
+            const int nb = __builtin_amdgcn_readlane(incl, uni32(nfit - 1));
+            if (fits) {
+                int at = incl - pc;
+                const int jb = (t_me << 5) - j0;
+                while (bits) {
+                    wbuf[at++] = (unsigned short)(jb + __ffs(bits) - 1);
+                    bits &= bits - 1u;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int c0 = 0; c0 < nb; c0 += 64) {
+                const bool act = c0 + lane < nb;
+                const int jr = wbuf[act ? c0 + lane : nb - 1];  // j - j0, ascending with the lane
+                const int tmax = (__builtin_amdgcn_readlane(jr, min(63, nb - c0 - 1)) + j0) >> 5;  // the last active lane has the largest j
+                const uint32_t *rj = band + size_t(jr) * BS;
+                uint32_t acc = 0;
+#pragma unroll
+                for (int g = 0; g < WPL; ++g)
+                    if (tmax >= 64 * g) acc += kc4_and_popc(wt[g], rj + 64 * g, min(tmax - 64 * g, 63) + 1);
+                if (act) total += acc;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     return total;
@@ -845,7 +926,9 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ unsigned long long red[16];
     __shared__ int wave_tot[16];
-    __shared__ uint32_t flt[kKcFilterWords];  // the pivot's tail members, one bit per (id mod 32768): kc_tail_find
+    constexpr int kKcFilterWords = 1024;
+    __shared__ __attribute__((aligned(16))) uint32_t fltw[kKcFilterWords];  // the pivot's tail members, one bit per (id mod 32 x words): kc_tail_find
+    const KcFilter flt{fltw, uint32_t(kKcFilterWords - 1)};
 #ifdef GMSX_KC_NO_PAIRS  // A/B build: round 4's k = 4 counts (kc4_row for wide matrices, one lane per matrix word for the others)
     constexpr bool kc4_pairs_enabled = false;
 #else
@@ -873,12 +956,14 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         const uint16_t *hub_list = hadj + hb;
         const int32_t *tail_list = tadj + tb;
         __syncthreads();  // previous pivot's counting is done
-        for (int i = tid; i < kBitmapWords; i += nthreads) bm[i] = 0;
+        // (16-byte stores: the clears are a quarter of the LDS instructions of a pivot of a few dozen members)
+        const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = tid; i < kBitmapWords / 4; i += nthreads) reinterpret_cast<uint4 *>(bm)[i] = zero4;
         if (flt_dirty)  // (uniform: the previous pivot of this workgroup had tail members, or this is its first)
-            for (int i = tid; i < kKcFilterWords; i += nthreads) flt[i] = 0;
+            for (int i = tid; i < kKcFilterWords / 4; i += nthreads) reinterpret_cast<uint4 *>(fltw)[i] = zero4;
         flt_dirty = tc > 0;
-        if (!GLOBAL_ROWS)
-            for (int i = tid; i < d * WS; i += nthreads) rows[i] = 0;  // the slab variant writes every row word at its flush
+        if (!GLOBAL_ROWS)  // the slab variant writes every row word at its flush.  (Rounded up to 16 bytes: at most into the first words of the bitmap behind the rows — zero as well.)
+            for (int i = tid; i < (d * WS + 3) / 4; i += nthreads) reinterpret_cast<uint4 *>(rows)[i] = zero4;
         __syncthreads();
         // the bitmap, and for every word that holds a member the local index of its first one — the exclusive prefix popcount a hit adds its rank
         // inside the word to.  The hub list is ascending, so that index is the position of the first member whose id falls into the word: written by
@@ -891,7 +976,11 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         }
         for (int i = tid; i < tc; i += nthreads) {
             const uint32_t w = uint32_t(tail_list[i]);
-            atomicOr(&flt[(w >> 5) & uint32_t(kKcFilterWords - 1)], 1u << (w & 31u));
+            atomicOr(&fltw[(w >> 5) & uint32_t(kKcFilterWords - 1)], 1u << (w & 31u));
+            if (GMSX_KC_FILTER_BITS > 1) {
+                const uint32_t b2 = kc_filter_bit2(w, uint32_t(kKcFilterWords - 1));
+                atomicOr(&fltw[b2 >> 5], 1u << (b2 & 31u));
+            }
         }
         __syncthreads();
         // four rows per wave and trip, one per 16-lane group; the global-slab variant builds them in an LDS stage and
@@ -1065,6 +1154,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
             // neighbours inside the band.  JB = WT here (host-chosen so that JB x (W+1) words fit the LDS).
             uint32_t *band = smem;
             const int JB = WT, BS = W + 1;
+            unsigned short *wlist = reinterpret_cast<unsigned short *>(band + size_t(JB) * BS) + size_t(wave) * kKcRowList;  // (behind the band: the host adds nwaves x kKcRowList x 2 bytes)
             for (int j0 = 0; j0 + 1 < d; j0 += JB) {
                 const int j1 = min(j0 + JB, d);
                 __syncthreads();
@@ -1074,15 +1164,27 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                     band[r * BS + cw] = rows[size_t(j0 + r) * WS + cw];
                 }
                 __syncthreads();
-                const int jw0 = j0 >> 5, jwn = ((j1 + 31) >> 5) - jw0;  // the band's columns: at most JB / 32 <= 18 words
-                for (int i = j0 + 1 + wave; i < d; i += nwaves) {
-                    // a row without a neighbour inside the band is skipped after one short load (sparse matrices of large d)
-                    const uint32_t probe = lane < jwn ? rows[size_t(i) * WS + jw0 + lane] : 0u;
-                    if (__ballot(probe != 0) == 0) continue;
-                    uint32_t wt[WPL];
+                const int jw0 = j0 >> 5, jw1 = (j1 + 31) >> 5;  // the band's columns
+                // the rows come from the slab in global memory, one per wave and trip — with the NEXT row of the wave on its way while this one meets
+                // the band (round 5: a short probe load, a ballot, then the row's load, then the count — two dependent round trips per row with four
+                // waves per SIMD — were 0.16 of the 0.39 s the slab bins took at scale 26)
+                uint32_t wt[WPL], wn[WPL];
+                int i = j0 + 1 + wave;
 #pragma unroll
-                    for (int h = 0; h < WPL; ++h) wt[h] = 64 * h + lane < W ? rows[size_t(i) * WS + 64 * h + lane] : 0u;
-                    cnt += kc4_row<WPL>(wt, band, BS, j0, j0 >> 5, (j1 + 31) >> 5, lane);
+                for (int h = 0; h < WPL; ++h) wt[h] = 64 * h + lane < W ? rows[size_t(min(i, d - 1)) * WS + 64 * h + lane] : 0u;
+                for (; i < d; i += nwaves) {
+#pragma unroll
+                    for (int h = 0; h < WPL; ++h) wn[h] = 64 * h + lane < W ? rows[size_t(min(i + nwaves, d - 1)) * WS + 64 * h + lane] : 0u;
+                    bool any = false;  // a row without a neighbour inside the band is skipped (sparse matrices of large d)
+#pragma unroll
+                    for (int h = 0; h < WPL; ++h) any |= 64 * h + lane >= jw0 && 64 * h + lane < jw1 && wt[h] != 0u;
+#ifdef GMSX_KC_SLAB_ROW_SCAN  // A/B build: rounds 1-4's neighbour search (shuffle scan + binary search + select)
+                    if (__ballot(any) != 0) cnt += kc4_row<WPL>(wt, band, BS, j0, jw0, jw1, lane);
+#else
+                    if (__ballot(any) != 0) cnt += kc4_row_list<WPL>(wt, band, BS, j0, jw0, jw1, lane, wlist, kKcRowList);
+#endif
+#pragma unroll
+                    for (int h = 0; h < WPL; ++h) wt[h] = wn[h];
                 }
             }
         } else if constexpr (LV == 1) {
@@ -1427,7 +1529,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             const int threads = LV == 2 ? 1024 : 512;
             const int WT = dmax == 8192 ? 128 : dmax == 4096 ? 288 : 576;  // k = 4 row band: WT rows x (W+1) words of LDS (multiple of 32)
             size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(threads / 64) * 4 * W * 4;  // bitmap + prefix + row stage
-            if (LV == 2) lds = std::max(lds, size_t(WT) * (W + 1) * 4);
+            if (LV == 2) lds = std::max(lds, size_t(WT) * (W + 1) * 4 + size_t(threads / 64) * kKcRowList * sizeof(unsigned short));  // + the waves' neighbour lists (kc4_row_list)
             if (VTX) lds += size_t(dmax) * 4;  // column counters
             if (b == 2) {
                 if constexpr (LV <= 2)
