@@ -754,19 +754,30 @@ __device__ __forceinline__ void kcs_tail_rows(const int64_t *__restrict__ hoff, 
                                               const int32_t *__restrict__ tadj, const int32_t *keys, const unsigned char *vals, uint32_t *rows,
                                               int32_t my, int hc, int d, int lane) {
     const int grp = lane >> 4, sub = lane & 15;
+    // the extents of the NEXT trip's rows are on their way while this trip's rows are streamed (round 5: extents, then rows — two dependent round trips
+    // per trip of four members — were most of what a pivot of a dozen tail members waited for)
+    int32_t vn = __shfl(my, min(hc + grp, d - 1));
+    int64_t n_hb = hoff[vn], n_he = hoff[vn + 1], n_tb = toff[vn], n_te = toff[vn + 1];
     for (int i0 = hc; i0 < d; i0 += 4) {
-        const int32_t v0 = __builtin_amdgcn_readlane(my, i0 & 63), v1 = __builtin_amdgcn_readlane(my, (i0 + 1) & 63),
-                      v2 = __builtin_amdgcn_readlane(my, (i0 + 2) & 63), v3 = __builtin_amdgcn_readlane(my, (i0 + 3) & 63);
         const int i = i0 + grp;
+        const int64_t hb = n_hb, tb = n_tb;
+        const int hl = int(n_he - n_hb), tl = int(n_te - n_tb);
+        const int32_t m_max = __shfl(my, max(i - 1, 0));  // member i - 1
+        vn = __shfl(my, min(i + 4, d - 1));
+        n_hb = hoff[vn];
+        n_he = hoff[vn + 1];
+        n_tb = toff[vn];
+        n_te = toff[vn + 1];
         if (i >= d) continue;  // per group
-        const int32_t v = grp == 0 ? v0 : grp == 1 ? v1 : grp == 2 ? v2 : v3;
         uint32_t bits = 0;
-        {
-            const int64_t hb = hoff[v];
-            const int hl = int(hoff[v + 1] - hb);
+        // (round 5) both parts of the row ascend, and only the members BELOW v can be in it: the hub part is of use up to the pivot's largest hub
+        // member — not at all without hub members —, the tail part up to the tail member in front of v — not at all for the first tail member
+        if (hc > 0) {
+            const uint32_t h_max = uint32_t(__builtin_amdgcn_readlane(my, (hc - 1) & 63));
             const uint16_t *row = hadj + hb;
             for (int j = sub * 8; j < hl; j += 128) {
                 const kc_u4u p = kc_load8(row, j, hl);
+                if ((p.x & 0xffffu) > h_max) break;  // (the pad 0xFFFF included)
                 const uint32_t pw[4] = {p.x, p.y, p.z, p.w};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -778,12 +789,12 @@ __device__ __forceinline__ void kcs_tail_rows(const int64_t *__restrict__ hoff, 
                 }
             }
         }
-        if (d > hc) {
-            const int64_t tb = toff[v];
-            const int tl = int(toff[v + 1] - tb);
+        if (i > hc) {
             const int32_t *row = tadj + tb;
             for (int j = sub; j < tl; j += 16) {
-                const int a = kcs_find<BUCKET>(keys, vals, row[j]);
+                const int32_t x = row[j];
+                if (x > m_max) break;
+                const int a = kcs_find<BUCKET>(keys, vals, x);
                 if (a >= 0) bits |= 1u << a;
             }
         }
@@ -810,6 +821,8 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
     const int64_t nwaves = int64_t(gridDim.x) * 4;
     const int half = lane >> 5, jl = lane & 31;
     unsigned long long cnt = 0;
+    // (Software-pipelining the pivots of a wave — the extents of pivot k + 1 and the id of pivot k + 2 loaded under pivot k — was measured SLOWER,
+    // 73 against 59 ms at scale 26: the grid gives a wave one or two pivots, and the staged prologue is two more round trips for each.)
     for (int64_t q = int64_t(blockIdx.x) * 4 + wave;; q += nwaves) {
         const int64_t pos = first + q * nparts + part;
         if (pos >= end) break;  // uniform per wave
