@@ -617,9 +617,13 @@ __device__ __forceinline__ unsigned long long kc4_row_list(const uint32_t (&wt)[
                 const int tmax = (__builtin_amdgcn_readlane(jr, min(63, nb - c0 - 1)) + j0) >> 5;  // the last active lane has the largest j
                 const uint32_t *rj = band + size_t(jr) * BS;
                 uint32_t acc = 0;
+#ifdef GMSX_KC_NO_INNER  // A/B build (wrong counts): the count without its AND + popcount loops
+                acc = uint32_t(rj[0] & 1u) + uint32_t(tmax);
+#else
 #pragma unroll
                 for (int g = 0; g < WPL; ++g)
                     if (tmax >= 64 * g) acc += kc4_and_popc(wt[g], rj + 64 * g, min(tmax - 64 * g, 63) + 1);
+#endif
                 if (act) total += acc;
             }
             __builtin_amdgcn_wave_barrier();
@@ -1181,23 +1185,38 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                 // the rows come from the slab in global memory, one per wave and trip — with the NEXT row of the wave on its way while this one meets
                 // the band (round 5: a short probe load, a ballot, then the row's load, then the count — two dependent round trips per row with four
                 // waves per SIMD — were 0.16 of the 0.39 s the slab bins took at scale 26)
-                uint32_t wt[WPL], wn[WPL];
-                int i = j0 + 1 + wave;
+                constexpr int R = 4;  // rows of the wave in flight (one ahead: the trip took as long as the load, 1.2 us; the count of a row is shorter)
+                uint32_t ring[R][WPL];
+                const int i_first = j0 + 1 + wave;
 #pragma unroll
-                for (int h = 0; h < WPL; ++h) wt[h] = 64 * h + lane < W ? rows[size_t(min(i, d - 1)) * WS + 64 * h + lane] : 0u;
-                for (; i < d; i += nwaves) {
+                for (int r = 0; r < R; ++r)
 #pragma unroll
-                    for (int h = 0; h < WPL; ++h) wn[h] = 64 * h + lane < W ? rows[size_t(min(i + nwaves, d - 1)) * WS + 64 * h + lane] : 0u;
-                    bool any = false;  // a row without a neighbour inside the band is skipped (sparse matrices of large d)
+                    for (int h = 0; h < WPL; ++h) ring[r][h] = 64 * h + lane < W ? rows[size_t(min(i_first + r * nwaves, d - 1)) * WS + 64 * h + lane] : 0u;
+                for (int i = i_first; i < d; i += R * nwaves) {
 #pragma unroll
-                    for (int h = 0; h < WPL; ++h) any |= 64 * h + lane >= jw0 && 64 * h + lane < jw1 && wt[h] != 0u;
-#ifdef GMSX_KC_SLAB_ROW_SCAN  // A/B build: rounds 1-4's neighbour search (shuffle scan + binary search + select)
-                    if (__ballot(any) != 0) cnt += kc4_row<WPL>(wt, band, BS, j0, jw0, jw1, lane);
-#else
-                    if (__ballot(any) != 0) cnt += kc4_row_list<WPL>(wt, band, BS, j0, jw0, jw1, lane, wlist, kKcRowList);
+                    for (int r = 0; r < R; ++r) {
+                        const int ii = i + r * nwaves;
+                        uint32_t wt[WPL];
+#pragma unroll
+                        for (int h = 0; h < WPL; ++h) {
+                            wt[h] = ring[r][h];
+                            ring[r][h] = 64 * h + lane < W ? rows[size_t(min(ii + R * nwaves, d - 1)) * WS + 64 * h + lane] : 0u;
+                        }
+                        if (ii >= d) continue;  // (uniform)
+                        bool any = false;  // a row without a neighbour inside the band is skipped (sparse matrices of large d)
+#pragma unroll
+                        for (int h = 0; h < WPL; ++h) any |= 64 * h + lane >= jw0 && 64 * h + lane < jw1 && wt[h] != 0u;
+                        if (__ballot(any) == 0) continue;
+#ifdef GMSX_KC_NO_SLAB_CALL  // A/B build (wrong counts): the slab count's bands and row loads without the per-row work
+                        cnt += any;
+                        continue;
 #endif
-#pragma unroll
-                    for (int h = 0; h < WPL; ++h) wt[h] = wn[h];
+#ifdef GMSX_KC_SLAB_ROW_SCAN  // A/B build: rounds 1-4's neighbour search (shuffle scan + binary search + select)
+                        cnt += kc4_row<WPL>(wt, band, BS, j0, jw0, jw1, lane);
+#else
+                        cnt += kc4_row_list<WPL>(wt, band, BS, j0, jw0, jw1, lane, wlist, kKcRowList);
+#endif
+                    }
                 }
             }
         } else if constexpr (LV == 1) {
@@ -1513,6 +1532,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
                 if (hipEventRecord(evs[i], sides[i]) == hipSuccess) (void)hipStreamWaitEvent(main, evs[i], 0);
         }
     } join{s, sides, ev_joins};
+    static const bool timing = std::getenv("GMSX_TIMING") != nullptr;  // the bins' pivot counts on stderr
     // L: 1024 < d+ <= 4096 (8192 for k <= 4), bit-matrix in a global slab per workgroup; one launch per row width (one / two / four words per lane)
     constexpr int NL = (LV <= 2) ? 3 : 2;
     size_t slab_bytes[3] = {0, 0, 0};
@@ -1522,6 +1542,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         if (int rc = range(l_dmax[b] / 2, l_dmax[b], &l_lo[b], &l_hi[b])) return rc;
         l_cnt[b] = part_count(l_lo[b], l_hi[b], nparts, part);
         l_blocks[b] = std::min<int64_t>(l_cnt[b], cu);  // one workgroup per CU: the LDS tile / stage fills it
+        if (timing && l_cnt[b] > 0) std::fprintf(stderr, "[gmsx kclique] slab bin d+ <= %d: %lld pivots\n", l_dmax[b], (long long)l_cnt[b]);
         if (l_cnt[b] > 0) slab_bytes[b] = size_t(l_blocks[b]) * l_dmax[b] * (l_dmax[b] / 32 + 1) * sizeof(uint32_t);
     }
     if (slab_bytes[0] + slab_bytes[1] + slab_bytes[2] > 0) {
@@ -1584,6 +1605,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         int64_t lo = 0, hi = 0;
         if (int rc = range(m_dmax[b + 1], dmax, &lo, &hi)) return rc;
         const int64_t cnt = part_count(lo, hi, nparts, part);
+        if (timing && cnt > 0) std::fprintf(stderr, "[gmsx kclique] LDS bin d+ <= %d: %lld pivots\n", dmax, (long long)cnt);
         if (cnt > 0) {
             const size_t lds = size_t(dmax) * WS * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + (VTX ? size_t(dmax) * 4 : 0);
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
