@@ -592,9 +592,9 @@ def main():
         raise SystemExit(f"rank {rank}: cuda:{local_rank} does not exist ({torch.cuda.device_count()} devices visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    t0 = time.perf_counter()
+    t_i0 = time.perf_counter()
     capi.init(local_rank)  # binds the device, loads the library's code object, pins the upload's two staging buffers: once per process
-    t_init = time.perf_counter() - t0
+    t_init = time.perf_counter() - t_i0
     capi.set_stream(torch.cuda.current_stream().cuda_stream)
     info = capi.device_info()
     algo = {"auto": capi.TC_AUTO, "oriented": capi.TC_ORIENTED, "full": capi.TC_FULL}[args.algo]

@@ -482,10 +482,10 @@ __global__ void k_count_ge(int64_t n, const int32_t *__restrict__ order, const i
 }
 // the task entries' fields (device_graph.hpp, TaskList): out[0] |= 1 when a stream row is longer than its list can say
 __global__ void k_task_limits(int64_t n, const unsigned long long *__restrict__ srow, const unsigned long long *__restrict__ srow2,
-                              const unsigned long long *__restrict__ trow, unsigned long long *__restrict__ out) {
+                              const unsigned long long *__restrict__ trow, uint32_t hub_max, uint32_t tail_max, unsigned long long *__restrict__ out) {
     const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (v >= n) return;
-    if ((srow[v] & 0x3fffffull) > kTaskHubUnitsMax || (srow2[v] & 0x3fffffull) > kTaskHubUnitsMax || (trow[v] & 0x3fffffull) > kTaskTailUnitsMax) atomicOr(out, 1ull);
+    if ((srow[v] & 0x3fffffull) > hub_max || (srow2[v] & 0x3fffffull) > hub_max || (trow[v] & 0x3fffffull) > tail_max) atomicOr(out, 1ull);
 }
 
 // ---- inline rows (build step 4c / 5b) --------------------------------------------------------------------------------------------
@@ -1557,7 +1557,11 @@ static int build_tc_sets(gmsx_graph *g) {
         const int grid = grid_for_waves(n_heavy);
         // a task entry has 32 bits for the first unit of its row and 14 / 15 for the row's units (TaskList)
         if (g->spool_units + kPoolSlack >= (int64_t(1) << 32) || g->tpool_units + kPoolSlack >= (int64_t(1) << 32)) return GMSX_ERR_DEVICE_MEM;
-        if (n > 0) hipLaunchKernelGGL(k_task_limits, dim3(vb), dim3(256), 0, s, n, g->srow, g->srow2, g->trow, totals + 3);
+        {
+            uint32_t hub_max = kTaskHubUnitsMax, tail_max = kTaskTailUnitsMax;
+            if (const char *e = std::getenv("GMSX_TC_TEST_MAX_UNITS")) hub_max = tail_max = uint32_t(std::max(1, std::atoi(e)));  // test hook: pretend the fields are this narrow
+            if (n > 0) hipLaunchKernelGGL(k_task_limits, dim3(vb), dim3(256), 0, s, n, g->srow, g->srow2, g->trow, hub_max, tail_max, totals + 3);
+        }
         // COUNT
         if (n > 0)
             hipLaunchKernelGGL(k_inline_entries<false>, dim3(vb), dim3(256), 0, s, n, g->dplus, opos, lidx, n_heavy, g->inline_limit, ihoff, itoff, inline_h_base,
@@ -1575,7 +1579,7 @@ static int build_tc_sets(gmsx_graph *g) {
         GMSX_HIP(hipMemcpy(&g->htask_entries, hbeg + n_recv, sizeof(int64_t), hipMemcpyDeviceToHost));
         GMSX_HIP(hipMemcpy(&g->ttask_entries, tbeg + n_recv, sizeof(int64_t), hipMemcpyDeviceToHost));
         GMSX_HIP(hipMemcpy(tot, totals, sizeof(tot), hipMemcpyDeviceToHost));
-        if (tot[3]) return GMSX_ERR_DEVICE_MEM;  // a row of > 16 383 hub / 32 767 tail units: no graph that fits the device has one
+        if (tot[3]) return GMSX_ERR_UNSUPPORTED;  // a row of > 16 383 hub / 32 767 tail units (no graph that fits the device has one): not a matter of memory — building a share of the pivots at a time would not help
         g->inline_hentries = int64_t(tot[0]);
         g->inline_tentries = int64_t(tot[1]);
         g->task_reverse = int64_t(tot[2]);

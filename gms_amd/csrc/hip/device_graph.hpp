@@ -49,7 +49,7 @@ static_assert(sizeof(gmsx_tc_item) == 64, "work item record = one 64-byte line")
 // form | units, hi = first unit >> 16 — and expanded again when a workgroup stages its item in LDS (two coalesced loads per entry instead of
 // one; the scan path reads the 8-byte LDS copy as before).  Hub lists: 2 form bits + 14 unit bits (a hub row is <= 65 535 ids = 8 192
 // list units, and another form is only taken when it is shorter); tail lists: 1 form bit (list / 16-bit delta) + 15 unit bits (131 068
-// ids in the 32-bit form).  The build refuses a graph whose rows or pools exceed the fields (k_task_limits: GMSX_ERR_DEVICE_MEM).
+// ids in the 32-bit form).  The build refuses a graph whose rows exceed the fields (k_task_limits: GMSX_ERR_UNSUPPORTED; pools of >= 2^32 units: GMSX_ERR_DEVICE_MEM, i.e. built a share of the pivots at a time).
 constexpr uint32_t kTaskHubUnitsMax = (1u << 14) - 1, kTaskTailUnitsMax = (1u << 15) - 1;
 struct TaskList {
     uint32_t *lo = nullptr;

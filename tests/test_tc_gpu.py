@@ -308,6 +308,32 @@ def test_shards_of_separate_processes_add_up(gpu):
     assert max(rec["bytes_sharded"]) < 0.9 * rec["bytes_full"], rec  # a third of the task lists and inline rows each; the base layout and the stream rows are whole (scale 19: 0.85 — 0.75 before round 5 shrank what is sharded)
 
 
+def test_rows_too_long_for_a_task_entry_are_refused_not_miscounted(gpu, oracle):
+    """A task entry (6 bytes, device_graph.hpp TaskList) has 14 / 15 bits for the units of the stream row it names.  A graph with a longer row is
+    REFUSED when the triangle-count containers are built (GMSX_ERR_UNSUPPORTED — not the memory fallback: a share of the pivots would have the same
+    rows), the base layout stays usable, and the same graph counts right without the hook.  GMSX_TC_TEST_MAX_UNITS (test hook) narrows the fields."""
+    csr = host_graph(gpu, "kronecker", 14)
+    want = oracle.tc_total(csr.offsets(), csr.neighbors())
+    old = os.environ.get("GMSX_TC_TEST_MAX_UNITS")
+    os.environ["GMSX_TC_TEST_MAX_UNITS"] = "2"
+    try:
+        g = gpu.DeviceGraph.from_csr(csr)
+        with pytest.raises(gpu.GmsxError) as ei:
+            g.tc_total()
+        assert ei.value.status == gpu.ERR_UNSUPPORTED
+        assert g.kclique_count(3)[1] == want         # the base layout is untouched
+        with pytest.raises(gpu.GmsxError):
+            gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_FOR_TC)
+        os.environ["GMSX_TC_TEST_MAX_UNITS"] = "100000"
+        assert g.tc_total() == want                  # the handle recovers once the rows fit
+        g.free()
+    finally:
+        if old is None:
+            os.environ.pop("GMSX_TC_TEST_MAX_UNITS", None)
+        else:
+            os.environ["GMSX_TC_TEST_MAX_UNITS"] = old
+
+
 def test_containers_that_do_not_fit_fall_back_to_passes(gpu, oracle):
     """When the triangle-count containers of the whole graph do not fit the device, the library builds them for 1/k of the pivots at a time
     and walks k passes instead of returning GMSX_ERR_DEVICE_MEM.  GMSX_TC_MEM_LIMIT_MB (test hook) pretends the device is small: RMAT scale
