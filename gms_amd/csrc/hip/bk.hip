@@ -1191,7 +1191,7 @@ __global__ void k_bk_pieces(int64_t cnt, const int64_t *__restrict__ poff, unsig
 // k_bk_block: the same build by a WORKGROUP per start vertex, shaped like the triangle kernels — the candidates C = N+(v) staged in LDS as
 // the 65536-bit hub bitmap + the index of the first candidate of every bitmap word (candidates ascend, so local index = that + popcount
 // of the lower bits) and a 32768-bit filter in front of the ascending tail-candidate list; then every row that can hold an edge into C
-// is STREAMED with 16-byte loads by a 16-lane group: the rows N+(a_i) of the candidates (hits -> Cadj, both directions) and the rows
+// is STREAMED with 16-byte loads by a group of GMSX_BK_BLOCK_GROUP lanes (8; 16 in rounds 3-4): the rows N+(a_i) of the candidates (hits -> Cadj, both directions) and the rows
 // N+(t) of the in-neighbours t (hits -> XT).  A streamed id costs a bitmap probe (one LDS read + bit test) instead of a hash-table walk,
 // sixteen rows are in flight per workgroup with the ids and extents of the next two batches already loading, and no wave idles behind a
 // dependent chain.  XT has one column per CSR POSITION of v's row (x = degree; the positions of out-neighbours stay empty), so no
@@ -1206,6 +1206,9 @@ struct BkRowJob {
 };
 #ifndef GMSX_BK_BLOCK_WAVES
 #define GMSX_BK_BLOCK_WAVES 5
+#endif
+#ifndef GMSX_BK_BLOCK_GROUP
+#define GMSX_BK_BLOCK_GROUP 8  // lanes per row job of k_bk_block (round 5; 16 before).  configs[3]: 16 / 8 / 4 lanes = 62.9 / 58.1 / 56.9 ms for the kernel, 147.7 / 142.8 / 141.5 for the call — most rows of a start vertex's neighbours are a unit or two, and a group has ONE row in flight; 8: the long rows of hub candidates still move 128 bytes per step
 #endif
 #ifndef GMSX_BK_ROWSCAN
 #define GMSX_BK_ROWSCAN 0  // 0: one 16-byte load in flight per lane and row part; 1: two.  configs[3]: alone 37.6 / 36.7 ms, the whole call 212.3 / 214.0 ms
@@ -1226,7 +1229,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
                                           // through, and a binary search in GLOBAL memory behind it stalled the whole wave for ~8 dependent round trips
     __shared__ long long s_task;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int grp = tid >> 4, sub = tid & 15;  // 16 groups of 16 lanes
+    constexpr int GL = GMSX_BK_BLOCK_GROUP, NG = 256 / GL;  // lanes per row job, row jobs in flight per workgroup
+    const int grp = tid / GL, sub = tid % GL;
     long long t_next = 0;
     int t_have = 0;  // pieces left of this workgroup's queue ticket (kBkBlockGrab per ticket)
     while (true) {
@@ -1308,7 +1312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
         //     sinks the load into the branch): a load under a branch cannot be counted, and every later wait becomes vmcnt(0);
         //   * a loaded value is first TOUCHED one trip later (the stage registers hold raw loaded words; the selects that turn them into a
         //     job id / an extent run at the top of the next trip): a use right behind the load is a wait right behind the load.
-        const int j0 = piece_i * kBkPieceJobs + grp;  // this group's jobs: j0, j0 + 16, … < njobs
+        const int j0 = piece_i * kBkPieceJobs + grp;  // this group's jobs: j0, j0 + NG, … < njobs
         struct RawLoad { int32_t xh, xt, xa; };
         struct ExtLoad { int64_t hs, he, ts, te; };
         auto load_raw = [&](int j) -> RawLoad {
@@ -1332,17 +1336,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
             const int32_t aa = max(a, 0);
             return ExtLoad{hoff[aa], hoff[aa + 1], toff[aa], toff[aa + 1]};
         };
-        RawLoad l_raw = load_raw(j0 - 16);        // (jobs in front of j0 do not exist: fin_raw drops them)
+        RawLoad l_raw = load_raw(j0 - NG);        // (jobs in front of j0 do not exist: fin_raw drops them)
         int32_t raw_n = -1, l_nw = 0;             // the raw job whose newid is in flight, and that word
         int32_t id_e = -1;                        // the job id whose extents are in flight
         ExtLoad l_ext = load_ext(-1);
-        for (int j = j0 - 48; j < njobs; j += 16) {
+        for (int j = j0 - 3 * NG; j < njobs; j += NG) {
             // top of the trip: what the previous trip loaded becomes values
-            const int32_t raw2 = fin_raw(l_raw, j + 32);
+            const int32_t raw2 = fin_raw(l_raw, j + 2 * NG);
             const int32_t id1 = fin_id(l_nw, raw_n);
             const BkRowJob cur{id_e, id_e >= 0 ? l_ext.hs : 0, id_e >= 0 ? l_ext.he : 0, id_e >= 0 ? l_ext.ts : 0, id_e >= 0 ? l_ext.te : 0};
             // … and the next round of fetches goes out before this trip's rows
-            l_raw = load_raw(j + 48);
+            l_raw = load_raw(j + 3 * NG);
             l_nw = newid[max(raw2, 0)];
             raw_n = raw2;
             l_ext = load_ext(id1);
@@ -1416,8 +1420,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
                 };
                 const int64_t te = tc > 0 ? cur.te : cur.ts;  // no tail candidates: the tail part of the row cannot hit
 #if GMSX_BK_ROWSCAN == 0
-                for (int64_t q = cur.hs + sub * 8; q < cur.he; q += 128) probe_hub(*reinterpret_cast<const bk_u4 *>(hadj + q), int(min(int64_t(8), cur.he - q)));
-                for (int64_t q = cur.ts + sub * 4; q < te; q += 64) probe_tail(*reinterpret_cast<const bk_u4 *>(tadj + q), int(min(int64_t(4), te - q)));
+                for (int64_t q = cur.hs + sub * 8; q < cur.he; q += 8 * GL) probe_hub(*reinterpret_cast<const bk_u4 *>(hadj + q), int(min(int64_t(8), cur.he - q)));
+                for (int64_t q = cur.ts + sub * 4; q < te; q += 4 * GL) probe_tail(*reinterpret_cast<const bk_u4 *>(tadj + q), int(min(int64_t(4), te - q)));
 #else
                 // two loads in flight per lane and part; a probe is issued only where a load was (most rows of a late start vertex have no hub
                 // part at all: probing the zeros of an absent load cost a third of the kernel's VALU instructions)
