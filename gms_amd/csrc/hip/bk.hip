@@ -1425,21 +1425,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GMSX_BK_BLO
 #else
                 // two loads in flight per lane and part; a probe is issued only where a load was (most rows of a late start vertex have no hub
                 // part at all: probing the zeros of an absent load cost a third of the kernel's VALU instructions)
-                for (int64_t q = cur.hs + sub * 8; q < cur.he; q += 256) {
+                for (int64_t q = cur.hs + sub * 8; q < cur.he; q += 16 * GL) {
                     const bk_u4 h0 = *reinterpret_cast<const bk_u4 *>(hadj + q);
-                    const bool two = q + 128 < cur.he;
+                    const bool two = q + 8 * GL < cur.he;
                     bk_u4 h1{0u, 0u, 0u, 0u};
-                    if (two) h1 = *reinterpret_cast<const bk_u4 *>(hadj + q + 128);
+                    if (two) h1 = *reinterpret_cast<const bk_u4 *>(hadj + q + 8 * GL);
                     probe_hub(h0, int(min(int64_t(8), cur.he - q)));
-                    if (two) probe_hub(h1, int(min(int64_t(8), cur.he - q - 128)));
+                    if (two) probe_hub(h1, int(min(int64_t(8), cur.he - q - 8 * GL)));
                 }
-                for (int64_t q = cur.ts + sub * 4; q < te; q += 128) {
+                for (int64_t q = cur.ts + sub * 4; q < te; q += 8 * GL) {
                     const bk_u4 t0 = *reinterpret_cast<const bk_u4 *>(tadj + q);  // tadj is padded by four ids
-                    const bool two = q + 64 < te;
+                    const bool two = q + 4 * GL < te;
                     bk_u4 t1{0u, 0u, 0u, 0u};
-                    if (two) t1 = *reinterpret_cast<const bk_u4 *>(tadj + q + 64);
+                    if (two) t1 = *reinterpret_cast<const bk_u4 *>(tadj + q + 4 * GL);
                     probe_tail(t0, int(min(int64_t(4), te - q)));
-                    if (two) probe_tail(t1, int(min(int64_t(4), te - q - 64)));
+                    if (two) probe_tail(t1, int(min(int64_t(4), te - q - 4 * GL)));
                 }
 #endif
             }
