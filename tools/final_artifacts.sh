@@ -1,6 +1,13 @@
+#!/bin/bash
+# the artifacts a round ends with (run on the GPU box: gpurun -- 'bash tools/final_artifacts.sh'); everything lands in gpurun_out/ and is copied to profiles/ by hand
 timeout 1700 python -m pytest tests -q -m gpu 2>&1 | grep -v "^RCCL\|^HIP version\|^ROCm version\|^Hostname\|^Librccl" > gpurun_out/gpu_tests.log; tail -2 gpurun_out/gpu_tests.log
 cp profiles/hbm_traffic.json gpurun_out/hbm_traffic.json
 python bench.py --dump-traffic gpurun_out/hbm_traffic.json 2>gpurun_out/bench_final.err | tail -1 > gpurun_out/bench_final.json; wc -c gpurun_out/bench_final.json
+if [ "${1:-}" = "bk" ]; then
+  bash tools/profile_pmc.sh bk_r5final tools/bk_probe.py --default-only > gpurun_out/prof_bk_r5final.log 2>&1; tail -2 gpurun_out/prof_bk_r5final.log
+  (python tools/bk_probe.py --default-only | tail -1; bash tools/probes/bk_trace.sh; python tools/bk_probe.py 18 64 --default-only | tail -1) > gpurun_out/bk_r5final.txt 2>&1
+  exit 0
+fi
 bash tools/profile_bench.sh s26_r5final > gpurun_out/prof_s26_r5final.log 2>&1; tail -3 gpurun_out/prof_s26_r5final.log
 bash tools/profile_pmc.sh kc22_r5final tools/kc_probe.py 22 > gpurun_out/prof_kc22_r5final.log 2>&1; tail -2 gpurun_out/prof_kc22_r5final.log
 python tools/kc_probe.py 24 2>&1 | tail -1 > gpurun_out/kc24_r5.json
