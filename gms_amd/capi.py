@@ -32,7 +32,7 @@ SYMBOLS = [
     "gmsx_csr_generate", "gmsx_csr_generate_rmat", "gmsx_csr_from_edges", "gmsx_csr_load", "gmsx_csr_save_sg", "gmsx_csr_from_arrays",
     "gmsx_csr_worth_relabelling", "gmsx_csr_relabel_by_degree", "gmsx_csr_num_nodes", "gmsx_csr_num_edges",
     "gmsx_csr_num_edges_directed", "gmsx_csr_offsets", "gmsx_csr_neighbors", "gmsx_csr_merge_elements",
-    "gmsx_csr_fingerprint", "gmsx_csr_free", "gmsx_set_host_threads",
+    "gmsx_csr_fingerprint", "gmsx_csr_free", "gmsx_set_host_threads", "gmsx_set_option", "gmsx_reset_options", "gmsx_option_name",
     "gmsx_init", "gmsx_set_stream", "gmsx_device_info",
     "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_upload_shard", "gmsx_graph_upload_csr_shard", "gmsx_graph_prepare", "gmsx_graph_tc_passes", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
     "gmsx_graph_device_bytes", "gmsx_graph_max_out_degree",
@@ -132,7 +132,15 @@ def lib():
     L.gmsx_comm_rank.argtypes = [vp]
     L.gmsx_comm_size.argtypes = [vp]
     L.gmsx_comm_finalize.argtypes = [vp]
+    L.gmsx_set_option.argtypes = [C.c_char_p, C.c_char_p]
+    L.gmsx_reset_options.restype = None
+    L.gmsx_option_name.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
     _LIB = L
+    # convenience of the tools (tools/*.sh, probes): GMSX_OPT_<NAME>=<value> in the environment of a PYTHON process becomes
+    # gmsx_set_option(NAME, value) here, in the binding — the library itself reads no tuning from the environment
+    for k, v in os.environ.items():
+        if k.startswith("GMSX_OPT_"):
+            _check(L.gmsx_set_option(k[len("GMSX_OPT_"):].encode(), v.encode()), f"gmsx_set_option({k})")
     return L
 
 
@@ -232,6 +240,40 @@ class HostCSR:
 def set_host_threads(n=0):
     """Threads of the host substrate (OpenMP); n <= 0 = all processors.  Returns the previous maximum."""
     return int(lib().gmsx_set_host_threads(int(n)))
+
+
+def set_option(name, value):
+    """gmsx_set_option: value None = back to the default.  Unknown names raise (GMSX_ERR_INVALID)."""
+    _check(lib().gmsx_set_option(name.encode(), None if value is None else str(value).encode()), f"gmsx_set_option({name})")
+
+
+def reset_options():
+    lib().gmsx_reset_options()
+
+
+def option_names():
+    out, i, p = [], 0, C.c_char_p()
+    while lib().gmsx_option_name(i, C.byref(p)) == 0:
+        out.append(p.value.decode())
+        i += 1
+    return out
+
+
+class options:
+    """with capi.options(KC_MAXD=8, BK_BUDGET=64): … — sets the options for the block and restores the defaults after it."""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            set_option(k, None)
+        return False
 
 
 def init(device=-1):

@@ -2147,7 +2147,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&v_out), size_t(n) * 4)); g_vo.p = v_out;
     GMSX_HIP(hipEventRecord(c.ev[0], s));
     int max_c = kBkMaxCand;
-    if (const char *e = std::getenv("GMSX_BK_MAXC")) {  // test hook: a lower width limit sends more start vertices through the memory-resident search
+    if (const char *e = opt("BK_MAXC")) {  // test hook: a lower width limit sends more start vertices through the memory-resident search
         const int v = std::atoi(e);
         if (v >= 1 && v < kBkMaxCand) max_c = v;
     }
@@ -2189,7 +2189,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     // the arena (Cadj | XT of the start vertices of a chunk + of the LDS-slab searches that split) is sized by NEED once the layout of the
     // start vertices is known — a fixed 48 GB allocation per call cost seconds of first-touch time now and then
     unsigned long long arena_hard_cap = std::min<unsigned long long>(free_b / 4, 48ull << 30) / 4;
-    if (const char *e = std::getenv("GMSX_BK_ARENA_MB")) {  // test hook: a small arena makes small graphs build their roots in several chunks
+    if (const char *e = opt("BK_ARENA_MB")) {  // test hook: a small arena makes small graphs build their roots in several chunks
         const long v = std::atol(e);
         if (v >= 1) arena_hard_cap = std::min<unsigned long long>(arena_hard_cap, ((unsigned long long)v << 20) / 4);
     }
@@ -2200,7 +2200,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         return GMSX_OK;
     };
     // 1 = records with at most 512 candidates are searched four to a wave (k_bk_resume4, default); 0 = every record by k_bk_resume (round 4)
-    const bool use_groups = [] { const char *e = std::getenv("GMSX_BK_GROUPS"); return !e || std::atoi(e) != 0; }();
+    const bool use_groups = [] { const char *e = opt("BK_GROUPS"); return !e || std::atoi(e) != 0; }();
     sh.pool_cap = std::min<unsigned long long>(free_b / 16, 2ull << 30) / 4;
     sh.dir_cap = 8ull << 20;
     uint32_t *pools[2] = {nullptr, nullptr};
@@ -2218,17 +2218,17 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     // pipeline the configs[3] graph takes 248.6 / 209.5 / 203.1 / 200.0 / 204.0 ms at 256 / 512 / 1024 / 2048 / 4096, RMAT 18 ef 64 (a = .45)
     // 275.9 -> 260.1 ms at 2048, the sparse graphs (one round) are indifferent
     sh.budget = 2048;
-    sh.small_p = [] { const char *e = std::getenv("GMSX_BK_SMALL_P"); return e ? std::atoi(e) : 6; }();  // swept on the configs[3] graph: 0 (off) 316 ms, 2 304, 3 ~300, 4 295, 6 293, 8 295, 16 303
-    sh.small_p_groups = [] { const char *e = std::getenv("GMSX_BK_SMALL_P_GROUPS"); return e ? std::atoi(e) : 12; }();
+    sh.small_p = [] { const char *e = opt("BK_SMALL_P"); return e ? std::atoi(e) : 6; }();  // swept on the configs[3] graph: 0 (off) 316 ms, 2 304, 3 ~300, 4 295, 6 293, 8 295, 16 303
+    sh.small_p_groups = [] { const char *e = opt("BK_SMALL_P_GROUPS"); return e ? std::atoi(e) : 12; }();
     sh.bmoff = g->bmoff;
     sh.bmpool = g->bmpool;
     sh.dense_limit = g->dense_limit;
-    if (const char *e = std::getenv("GMSX_BK_BUDGET")) {  // tuning knob: nodes a search may visit before it is re-split
+    if (const char *e = opt("BK_BUDGET")) {  // tuning knob: nodes a search may visit before it is re-split
         const long v = std::atol(e);
         if (v >= 16 && v <= (1l << 30)) sh.budget = unsigned(v);
     }
     unsigned budget0 = sh.budget;  // round 0 (start vertices: build + first stretch of the search)
-    if (const char *e = std::getenv("GMSX_BK_BUDGET0")) {
+    if (const char *e = opt("BK_BUDGET0")) {
         const long v = std::atol(e);
         if (v >= 16 && v <= (1l << 30)) budget0 = unsigned(v);
     }
@@ -2240,8 +2240,8 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     GMSX_HIP(hipMemsetAsync(sh.dir, 0xff, sh.dir_cap * 8, s));
     // 2 (default): k_bk_block, a workgroup per start vertex, rows streamed against an LDS bitmap; 1: k_bk_build, a wave per start vertex with
     // the hash-map build of k_bk_wave; 0: round 2's combined build + search bins
-    const int64_t resume_grab = [] { const char *e = std::getenv("GMSX_BK_RESUME_GRAB"); return e ? std::max(1, std::atoi(e)) : 1; }();  // measured on configs[3]: 8 costs 4 ms (the records of a round differ in cost; their queue is not the limit)
-    const int split_build = [] { const char *e = std::getenv("GMSX_BK_SPLIT_BUILD"); return e ? std::atoi(e) : 2; }();
+    const int64_t resume_grab = [] { const char *e = opt("BK_RESUME_GRAB"); return e ? std::max(1, std::atoi(e)) : 1; }();  // measured on configs[3]: 8 costs 4 ms (the records of a round differ in cost; their queue is not the limit)
+    const int split_build = [] { const char *e = opt("BK_SPLIT_BUILD"); return e ? std::atoi(e) : 2; }();
     int64_t n_tasks = 0;
     while (n_tasks < n && words[size_t(n_tasks)] > 0) ++n_tasks;
     int64_t n_glob = 0;  // tasks beyond an LDS slab: sorted first (the wide ones, > 2048 candidates, at the very front)
@@ -2251,7 +2251,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
     const int64_t cnt_glob = split_build ? part_count(0, n_glob, nparts, part) : 0;
     int64_t need_total = 0;  // arena words of the start vertices built by k_bk_block
     const int64_t cnt_tiny = part_count(n_glob, n_tasks, nparts, part);
-    const bool tiny_roots = use_groups && split_build >= 2 && cnt_glob > 0 && [] { const char *e = std::getenv("GMSX_BK_TINY_ROOTS"); return e && std::atoi(e) != 0; }();
+    const bool tiny_roots = use_groups && split_build >= 2 && cnt_glob > 0 && [] { const char *e = opt("BK_TINY_ROOTS"); return e && std::atoi(e) != 0; }();
     int64_t *t_need_a = nullptr, *t_need_r = nullptr, *t_need_p = nullptr, *t_aoff = nullptr, *t_roff = nullptr, tiny_a = 0, tiny_r = 0;
     Guard g_tna, g_tnr, g_tnp, g_tao, g_tro;
     int64_t *need_a = nullptr, *need_r = nullptr, *aoff = nullptr, *roff = nullptr, *d_end = nullptr, *need_p = nullptr, *poff = nullptr;
@@ -2318,7 +2318,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
         GMSX_HIP(hipMemcpy(&need_total, aoff + cnt_glob, 8, hipMemcpyDeviceToHost));
         // the roots may take 3/4 of the arena (below): everything in one chunk when the device allows, + room for the LDS-slab searches that split
         if (int rc = alloc_arena((unsigned long long)need_total / 3 * 4 + (unsigned long long)tiny_a + (512ull << 20) / 4)) return rc;
-        if (std::getenv("GMSX_BK_VERBOSE"))
+        if (opt("BK_VERBOSE"))
             std::fprintf(stderr, "[gmsx bk] start vertices %lld: %lld built in the arena (%lld words), %lld in LDS slabs\n", (long long)n_tasks, (long long)cnt_glob,
                          (long long)need_total, (long long)(n_tasks - n_glob));
         map_words = split_build >= 2 ? 0ull : (mx[1] + 3ull) & ~3ull;
@@ -2406,7 +2406,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 group_cap = size_t(waves) * slab_bytes;
                 GMSX_HIP(hipMalloc(&g_gslab.p, group_cap));
             }
-            if (std::getenv("GMSX_BK_VERBOSE"))
+            if (opt("BK_VERBOSE"))
                 std::fprintf(stderr, "[gmsx bk] round %d: %llu records (%llu pool words), %lld waves of 4 / 8 / 16 searches, %llu slab words each, budget %u\n", rounds + 1,
                              n_rec, ctl[0], (long long)waves, group_w, sh.budget);
             hipLaunchKernelGGL(k_bk_resume4, dim3(unsigned(waves)), dim3(64), 0, s, pool_in, dir_in, n_rec, gqueue, grab, static_cast<uint32_t *>(g_gslab.p), group_w,
@@ -2424,7 +2424,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 resume_cap = size_t(waves) * slab_bytes;
                 GMSX_HIP(hipMalloc(&g_rslab.p, resume_cap));
             }
-            if (std::getenv("GMSX_BK_VERBOSE"))
+            if (opt("BK_VERBOSE"))
                 std::fprintf(stderr, "[gmsx bk] round %d: %llu records (%llu pool words), %lld waves, stack %llu words, budget %u\n", rounds + 1, n_rec, ctl[0],
                              (long long)waves, stack_w, sh.budget);
             if (n_wide > 0 && wpl_wide == 2)  // records of wide tasks may be anywhere in the pool
@@ -2512,7 +2512,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 // pool_head / dir_count / max_stack as if the roots had been split off by an earlier round; arena_head behind their structures
                 unsigned long long ctl0[6] = {(unsigned long long)(span[3] - span[2]), (unsigned long long)(q1 - q0), mx[0], mx[2], mx[3], mx[4]};
                 unsigned long long ah = (unsigned long long)(span[1] - span[0]);
-                static const int tiny_mode = [] { const char *e = std::getenv("GMSX_BK_TINY_BESIDE"); return e ? std::atoi(e) : 1; }();
+                const int tiny_mode = [] { const char *e = opt("BK_TINY_BESIDE"); return e ? std::atoi(e) : 1; }();
                 if (!tiny_done && tiny_roots && cnt_tiny > 0 && tiny_mode != 2 && ah + (unsigned long long)tiny_a + (64ull << 20) / 4 <= sh.arena_cap &&
                     ctl0[0] + (unsigned long long)tiny_r <= sh.pool_cap / 4 * 3 && ctl0[1] + (unsigned long long)cnt_tiny <= sh.dir_cap) {
                     emit = true;  // the LDS-slab tasks' structures and root records go behind this chunk's: round 1 searches both
@@ -2535,7 +2535,7 @@ static int bk_partial(const gmsx_graph *g, int part, int nparts, uint64_t *out, 
                 }
                 GMSX_HIP(hipStreamSynchronize(s));  // ctl0 / ah / pspan are stack variables
                 if (!tiny_done) {  // the LDS-slab tasks run beside the first chunk's build; what they split off joins its records
-                    static const int beside = [] { const char *e = std::getenv("GMSX_BK_TINY_BESIDE"); return e ? std::atoi(e) : 1; }();  // 0: one after the other (profiling)
+                    const int beside = [] { const char *e = opt("BK_TINY_BESIDE"); return e ? std::atoi(e) : 1; }();  // 0: one after the other (profiling)
                     if (beside == 2 && c.side[0] && c.ev_fork && c.ev_join[0] && part_count(n_glob, n_tasks, nparts, part) > 0) {
                         round_pre = [&]() -> int {
                             GMSX_HIP(hipMemsetAsync(tqueue, 0, 8, s));

@@ -864,7 +864,7 @@ static int grid_for_waves(int64_t rows) {
 template <class T>
 static int dmalloc(T **p, int64_t count, gmsx_graph *g, int line = __builtin_LINE()) {
     const size_t bytes = size_t(count > 0 ? count : 1) * sizeof(T);
-    static const bool trace = std::getenv("GMSX_MEM_TRACE") != nullptr;  // where the device bytes go: one line per allocation that stays with the graph
+    const bool trace = opt("MEM_TRACE") != nullptr;  // where the device bytes go: one line per allocation that stays with the graph
     if (trace && g && bytes >= (1u << 20)) std::fprintf(stderr, "gmsx mem: device_graph.hip:%d %.3f GB (elements of %zu B)\n", line, double(bytes) * 1e-9, sizeof(T));
     if (g && g->tc_building && g->tc_limit_bytes > 0 && g->device_bytes + int64_t(bytes) - g->tc_base_bytes > g->tc_limit_bytes) {
         *p = nullptr;  // test hook: pretend the device is this small
@@ -966,7 +966,7 @@ template <class K>
 static int sort_rows(K *keys, int64_t entries, int64_t n, const int64_t *d_off, int end_bit, hipStream_t s) {
     if (n <= 0 || entries <= 0) return GMSX_OK;
     int64_t chunk = int64_t(1) << 31;
-    if (const char *e = std::getenv("GMSX_SORT_CHUNK")) {  // test hook: force several ranges on a small graph
+    if (const char *e = opt("SORT_CHUNK")) {  // test hook: force several ranges on a small graph
         const long long v = std::atoll(e);
         if (v > 0) chunk = v;
     }
@@ -1014,7 +1014,7 @@ template <class K, class V>
 static int sort_segment_pairs(K *keys, V *vals, int64_t entries, int64_t n, const int64_t *d_off, int end_bit, hipStream_t s) {
     if (n <= 0 || entries <= 0) return GMSX_OK;
     int64_t chunk = int64_t(1) << 31;
-    if (const char *e = std::getenv("GMSX_SORT_CHUNK")) {
+    if (const char *e = opt("SORT_CHUNK")) {
         const long long v = std::atoll(e);
         if (v > 0) chunk = v;
     }
@@ -1067,7 +1067,7 @@ struct PhaseTimer {
     bool on;
     std::chrono::steady_clock::time_point t0;
     const char *what;
-    PhaseTimer(hipStream_t st, const char *w) : s(st), on(std::getenv("GMSX_TIMING") != nullptr), t0(std::chrono::steady_clock::now()), what(w) {}
+    PhaseTimer(hipStream_t st, const char *w) : s(st), on(opt("TIMING") != nullptr), t0(std::chrono::steady_clock::now()), what(w) {}
     void mark(const char *phase) {
         if (!on) return;
         (void)hipStreamSynchronize(s);
@@ -1098,7 +1098,7 @@ struct H2dStage {
     }
 };
 static bool h2d_staged_off() {
-    static const bool off = [] { const char *e = std::getenv("GMSX_UPLOAD_STAGED"); return e && std::atoi(e) == 0; }();  // A/B: 0 = one hipMemcpyAsync (round 4)
+    const bool off = [] { const char *e = opt("UPLOAD_STAGED"); return e && std::atoi(e) == 0; }();  // A/B: 0 = one hipMemcpyAsync (round 4)
     return off;
 }
 static H2dStage &h2d_stage() {
@@ -1298,14 +1298,14 @@ static int build_tc_sets(gmsx_graph *g) {
     {
         int64_t want = std::min<int64_t>(524288, n / 256);
         bool forced = false;
-        if (const char *e = std::getenv("GMSX_INLINE_LIMIT")) {  // tuning / test knob
+        if (const char *e = opt("INLINE_LIMIT")) {  // tuning / test knob
             const long long v = std::atoll(e);
             if (v >= 0 && v <= (1ll << 31) - 1) { want = v; forced = true; }
         }
         if (!forced && ((flags >> 8) & 0xffffu)) want = int64_t(4) * hub_limit;  // hub-limit test hook: near AND far tail on small graphs
         g->inline_limit = int32_t(std::min<int64_t>(n, std::max<int64_t>(want, g->dense_limit)));
         g->inline_first = kDefaultInlineFirst;
-        if (const char *e = std::getenv("GMSX_TC_INLINE_FIRST")) g->inline_first = std::max(1, std::min(kInlineFirstMax, std::atoi(e)));  // A/B knob
+        if (const char *e = opt("TC_INLINE_FIRST")) g->inline_first = std::max(1, std::min(kInlineFirstMax, std::atoi(e)));  // A/B knob
         if (int rc = dmalloc(&g->tsplit, n, g)) return rc;
         if (n > 0) hipLaunchKernelGGL(k_tail_split, dim3(grid_for_waves(n)), dim3(256), 0, s, n, g->toff, g->tadj, g->inline_limit, g->tsplit);
     }
@@ -1361,19 +1361,19 @@ static int build_tc_sets(gmsx_graph *g) {
     int64_t inline_h_base = 0, inline_t_base = 0;  // first unit of the inline regions of spool / tpool
     {
         int delta_mode = g->rows_sorted ? 1 : 0;
-        if (const char *e = std::getenv("GMSX_TC_DELTA")) {  // 0 = lists and bitsets only, 2 = delta wherever possible (test hook)
+        if (const char *e = opt("TC_DELTA")) {  // 0 = lists and bitsets only, 2 = delta wherever possible (test hook)
             const int v = std::atoi(e);
             if (v >= 0 && v <= 2 && g->rows_sorted) delta_mode = v;
         }
         int delta_pct = 85;  // take the delta form when it is at most this percentage of the list form (its decode costs ~30 % more VALU per id)
-        if (const char *e = std::getenv("GMSX_TC_DELTA_PCT")) {
+        if (const char *e = opt("TC_DELTA_PCT")) {
             const int v = std::atoi(e);
             if (v >= 10 && v <= 100) delta_pct = v;
         }
         // measured (MI355X, scale 26): the 12-bit-gap form takes 37 GB (9 %) off the algorithmic stream bytes but costs 6.3 VALU instructions
         // per id against 4 for a list: 87.5 -> 90.7 ms (scale 24: 16.3 -> 17.3).  The pass is on both roofs; the form stays OFF by default.
         int gap12_mode = 0;
-        if (const char *e = std::getenv("GMSX_TC_GAP12")) {  // 1 = when at least 10 % smaller than the list, 2 = every row that would be a list (test hook)
+        if (const char *e = opt("TC_GAP12")) {  // 1 = when at least 10 % smaller than the list, 2 = every row that would be a list (test hook)
             const int v = std::atoi(e);
             if (v >= 0 && v <= 2 && g->rows_sorted) gap12_mode = v;
         }
@@ -1381,7 +1381,7 @@ static int build_tc_sets(gmsx_graph *g) {
         // estimate does not survive the two-sided design (the rows that end up streamed are the SMALLER ones of every edge and the cuts
         // already drop their low-id prefixes for the receivers that matter) — and the pass time does not move (80.5–80.9 ms all three).  OFF.
         int hybrid_mode = 0;
-        if (const char *e = std::getenv("GMSX_TC_HYBRID")) {  // 1 = when at least 10 % smaller than the row's best single form, 2 = wherever smaller at all
+        if (const char *e = opt("TC_HYBRID")) {  // 1 = when at least 10 % smaller than the row's best single form, 2 = wherever smaller at all
             const int v = std::atoi(e);
             if (v >= 0 && v <= 2 && g->rows_sorted) hybrid_mode = v;
         }
@@ -1425,7 +1425,7 @@ static int build_tc_sets(gmsx_graph *g) {
     // 4e. … and of the tail parts
     {
         int delta_mode = g->rows_sorted ? 1 : 0;
-        if (const char *e = std::getenv("GMSX_TC_TAIL_DELTA")) {  // 0 = 32-bit lists only, 2 = delta wherever possible (test hook)
+        if (const char *e = opt("TC_TAIL_DELTA")) {  // 0 = 32-bit lists only, 2 = delta wherever possible (test hook)
             const int v = std::atoi(e);
             if (v >= 0 && v <= 2 && g->rows_sorted) delta_mode = v;
         }
@@ -1504,7 +1504,7 @@ static int build_tc_sets(gmsx_graph *g) {
     //    the order inside a class is the arrival order of atomic cursors, and nothing depends on it (a multi-GPU shard is a set of pivots).
     {
         int two_sided = 1;
-        if (const char *e = std::getenv("GMSX_TC_TWO_SIDED")) two_sided = std::atoi(e) != 0;  // 0 = every heavy pivot keeps all its edges (A/B knob)
+        if (const char *e = opt("TC_TWO_SIDED")) two_sided = std::atoi(e) != 0;  // 0 = every heavy pivot keeps all its edges (A/B knob)
         const unsigned vb = unsigned(n / 256 + 1);
         // light receivers: rank ids below inline_limit that are not heavy
         const int64_t L = g->inline_limit;
@@ -1525,10 +1525,10 @@ static int build_tc_sets(gmsx_graph *g) {
             hipLaunchKernelGGL(k_recv_vertices, dim3(unsigned(std::max<int64_t>(n_heavy, L) / 256 + 1)), dim3(256), 0, s, n_heavy, L, g->order, g->dplus, lidx, recv_v);
         // hot windows of the hub lists (device_graph.hpp): GMSX_TC_HOT_WINDOWS x GMSX_TC_HOT_KB of the pool's front, GMSX_TC_HOT_MIN entries
         {
-            auto env_int = [](const char *name, int dflt) { const char *e = std::getenv(name); return e ? std::atoi(e) : dflt; };
-            g->tc_hot_windows = std::max(0, std::min(kMaxHotWindows, env_int("GMSX_TC_HOT_WINDOWS", kDefaultHotWindows)));
-            g->tc_window_units = uint32_t(std::max(1, env_int("GMSX_TC_HOT_KB", kDefaultHotKB))) * 64u;
-            g->tc_hot_min = std::max(1, env_int("GMSX_TC_HOT_MIN", kDefaultHotMin));
+            auto env_int = [](const char *name, int dflt) { return int(opt_int(name, dflt)); };
+            g->tc_hot_windows = std::max(0, std::min(kMaxHotWindows, env_int("TC_HOT_WINDOWS", kDefaultHotWindows)));
+            g->tc_window_units = uint32_t(std::max(1, env_int("TC_HOT_KB", kDefaultHotKB))) * 64u;
+            g->tc_hot_min = std::max(1, env_int("TC_HOT_MIN", kDefaultHotMin));
         }
         const TcClasses cc{g->tc_hot_windows, g->tc_window_units, g->tc_hot_min};
         const int kClasses = cc.count();
@@ -1559,7 +1559,7 @@ static int build_tc_sets(gmsx_graph *g) {
         if (g->spool_units + kPoolSlack >= (int64_t(1) << 32) || g->tpool_units + kPoolSlack >= (int64_t(1) << 32)) return GMSX_ERR_DEVICE_MEM;
         {
             uint32_t hub_max = kTaskHubUnitsMax, tail_max = kTaskTailUnitsMax;
-            if (const char *e = std::getenv("GMSX_TC_TEST_MAX_UNITS")) hub_max = tail_max = uint32_t(std::max(1, std::atoi(e)));  // test hook: pretend the fields are this narrow
+            if (const char *e = opt("TC_TEST_MAX_UNITS")) hub_max = tail_max = uint32_t(std::max(1, std::atoi(e)));  // test hook: pretend the fields are this narrow
             if (n > 0) hipLaunchKernelGGL(k_task_limits, dim3(vb), dim3(256), 0, s, n, g->srow, g->srow2, g->trow, hub_max, tail_max, totals + 3);
         }
         // COUNT
@@ -1635,7 +1635,7 @@ static int build_tc_sets(gmsx_graph *g) {
         drop(g->srow2, nn * sizeof(unsigned long long));
         // the first descriptors too: every task entry carries its own copy, and only gmsx_tc_row_histogram's what-if estimates read them
         // afterwards (GMSX_TC_KEEP_ROWS=1 keeps them for tools/tc_row_hist.py)
-        const char *keep = std::getenv("GMSX_TC_KEEP_ROWS");
+        const char *keep = opt("TC_KEEP_ROWS");
         if (!(keep && std::atoi(keep) != 0)) {
             drop(g->srow, nn * sizeof(unsigned long long));
             drop(g->trow, nn * sizeof(unsigned long long));
@@ -1662,7 +1662,7 @@ static int build_tc_once(gmsx_graph *g) {
 int ensure_tc(const gmsx_graph *cg) {
     gmsx_graph *g = const_cast<gmsx_graph *>(cg);  // handles are single-threaded; the build only adds containers, nothing a caller can observe changes
     if (g->tc_ready) return GMSX_OK;
-    if (const char *e = std::getenv("GMSX_TC_MEM_LIMIT_MB")) {  // test hook: the budget of the triangle-count containers
+    if (const char *e = opt("TC_MEM_LIMIT_MB")) {  // test hook: the budget of the triangle-count containers
         const long long v = std::atoll(e);
         g->tc_limit_bytes = v > 0 ? int64_t(v) << 20 : 0;
     }
@@ -1796,7 +1796,7 @@ int gmsx_init(int device) {
         // What a process pays ONCE belongs here, not under the first upload's clock (round 5; GMSX_INIT_LAZY=1 restores the lazy behaviour): the
         // code object of the library is loaded by the first kernel launch, and the two pinned staging buffers of the uploads (128 MB) are allocated
         // and touched — together 60 … 90 ms of the first scale-26 upload before.
-        if (const char *e = std::getenv("GMSX_INIT_LAZY"); !(e && std::atoi(e) != 0)) {
+        if (const char *e = opt("INIT_LAZY"); !(e && std::atoi(e) != 0)) {
             hipLaunchKernelGGL(gmsx::k_warm, dim3(1), dim3(64), 0, c.stream, static_cast<unsigned long long *>(nullptr));
             if (!gmsx::h2d_staged_off()) (void)gmsx::h2d_stage();
             if (hipStreamSynchronize(c.stream) != hipSuccess) return GMSX_ERR_NO_DEVICE;

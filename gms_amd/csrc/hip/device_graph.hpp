@@ -7,6 +7,16 @@
 #include "gmsx.h"
 #include "gmsx_internal.hpp"  // gmsx::guard: no exception crosses the C ABI
 
+// The A/B switches of the kernel sources ("wrong counts" builds that compile a part of a kernel out to time the rest, GMSX_TC_ONLY)
+// exist in DEVELOPMENT builds only: `make` never defines GMSX_DEV_HOOKS, tools/ab_lib.sh does.  A shipped libgmsx.so cannot be
+// steered into a miscount — neither by a macro that slipped into EXTRA nor by the environment (tests/test_capi_symbols.py checks the strings).
+#if !defined(GMSX_DEV_HOOKS) &&                                                                                                               \
+    (defined(GMSX_KC_NO_PROBE) || defined(GMSX_KC_NO_HITS) || defined(GMSX_KC_NO_TAIL) || defined(GMSX_KC_NO_INNER) || defined(GMSX_KC_CELLS_ONLY) ||   \
+     defined(GMSX_KC_NO_ROWS) || defined(GMSX_KC_BUILD_ONLY) || defined(GMSX_KC_NO_SLAB_CALL) || defined(GMSX_KC_NO_PAIRS) || defined(GMSX_KC_SLAB_ROW_SCAN) || \
+     defined(GMSX_BK_AB) || defined(GMSX_BK_NO_HIT_ATOMICS) || defined(GMSX_BK_STATS) || defined(GMSX_TC_NO_PROBE) || defined(GMSX_TC_STAGING_ONLY))
+#error "A/B switches need -DGMSX_DEV_HOOKS (tools/ab_lib.sh sets it); the default build of libgmsx.so carries none of them"
+#endif
+
 // Layout in HBM (all arrays hipMalloc'd once at upload, read-only afterwards):
 //
 //   off  int64[n+1], adj int32[nnz]   the caller's symmetric CSR, rows ascending (the reference's CSRGraph rows)

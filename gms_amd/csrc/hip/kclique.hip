@@ -1412,7 +1412,7 @@ static int launch_generic(const gmsx_graph *g, int k, int64_t first, int64_t end
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
     const int64_t levels = k > 3 ? k - 3 : 1;
     int64_t budget_ints = (int64_t(2) << 30) / 4;  // 2 GB of level lists in flight
-    if (const char *e = std::getenv("GMSX_KC_SLAB_MB")) {  // test hook: a tiny budget forces many chunks on small graphs
+    if (const char *e = opt("KC_SLAB_MB")) {  // test hook: a tiny budget forces many chunks on small graphs
         const long long v = std::atoll(e);
         if (v >= 1) budget_ints = int64_t(v) * (1 << 20) / 4;
     }
@@ -1471,7 +1471,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     int64_t over = 0, n_min = 0;
     constexpr int kMaxD = (LV <= 2) ? 8192 : 4096;  // widest bit rows: four words per lane for k = 3, 4 and the per-vertex counts, two for k >= 5
     int max_d = kMaxD;
-    if (const char *e = std::getenv("GMSX_KC_MAXD")) {  // test hook: a lower limit sends more pivots through the generic path
+    if (const char *e = opt("KC_MAXD")) {  // test hook: a lower limit sends more pivots through the generic path
         const int v = std::atoi(e);
         if (v >= 1 && v < kMaxD) max_d = v;
     }
@@ -1510,7 +1510,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         }
         GMSX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     }
-    const int n_streams = [] { const char *e = std::getenv("GMSX_KC_STREAMS"); const int v = e ? std::atoi(e) : 4; return v < 1 ? 1 : v > 4 ? 4 : v; }();
+    const int n_streams = [] { const char *e = opt("KC_STREAMS"); const int v = e ? std::atoi(e) : 4; return v < 1 ? 1 : v > 4 ? 4 : v; }();
     GMSX_HIP(hipEventRecord(ev_fork, s));
     for (int i = 0; i < kSides; ++i) GMSX_HIP(hipStreamWaitEvent(sides[i], ev_fork, 0));
     hipStream_t side = n_streams > 1 ? sides[0] : s;
@@ -1532,7 +1532,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
                 if (hipEventRecord(evs[i], sides[i]) == hipSuccess) (void)hipStreamWaitEvent(main, evs[i], 0);
         }
     } join{s, sides, ev_joins};
-    static const bool timing = std::getenv("GMSX_TIMING") != nullptr;  // the bins' pivot counts on stderr
+    const bool timing = opt("TIMING") != nullptr;  // the bins' pivot counts on stderr
     // L: 1024 < d+ <= 4096 (8192 for k <= 4), bit-matrix in a global slab per workgroup; one launch per row width (one / two / four words per lane)
     constexpr int NL = (LV <= 2) ? 3 : 2;
     size_t slab_bytes[3] = {0, 0, 0};
@@ -1591,12 +1591,12 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     // the pipelined BUILD (member id -> extents -> first units, three members deep) in the narrower bins too: GMSX_KC_PIPE_ALL = 1 always, 0 never, unset =
     // when the oriented containers outgrow the 256 MB Infinity Cache (a member's row then costs HBM round trips, not cache hits — see DESIGN.md §5.2)
     const bool pipe_all = [&] {
-        if (const char *e = std::getenv("GMSX_KC_PIPE_ALL")) return std::atoi(e) != 0;
+        if (const char *e = opt("KC_PIPE_ALL")) return std::atoi(e) != 0;
         return pipe_all_default(g);
     }();
     // the step-stream BUILD (mode 2): GMSX_KC_STREAM_BUILD = 1 always, 0 never, unset = by graph size (stream_build_default)
     const bool stream_build = [&] {
-        if (const char *e = std::getenv("GMSX_KC_STREAM_BUILD")) return std::atoi(e) != 0;
+        if (const char *e = opt("KC_STREAM_BUILD")) return std::atoi(e) != 0;
         return stream_build_default(g);
     }();
     const int m_dmax[] = {1024, 704, 512, 384, 256, 192, 128, 96, 64, 32};  // last entry = lower end of the last bin

@@ -1141,10 +1141,15 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
         if (int rc = tc_shard_items(g, part, nparts)) return rc;
     const gmsx_tc_item *hitem = use_idx ? g->shard_hitem : g->hitem, *titem = use_idx ? g->shard_titem : g->titem;
     int64_t n_hitems = use_idx ? g->shard_hitems : g->hitems, n_titems = use_idx ? g->shard_titems : g->titems;
-    if (const char *only = std::getenv("GMSX_TC_ONLY")) {  // profiling (WRONG counts): the hub items / the tail items / the light pivots alone
+#ifdef GMSX_DEV_HOOKS  // profiling build only (WRONG counts): the hub items / the tail items / the light pivots alone
+    const char *only = std::getenv("GMSX_TC_ONLY");
+    if (only) {
         if (std::strcmp(only, "hub") != 0) n_hitems = 0;
         if (std::strcmp(only, "tail") != 0) n_titems = 0;
     }
+#else
+    const char *only = nullptr;
+#endif
     Ctx &c = ctx();
     hipStream_t s = c.stream;
     unsigned long long *acc = g->acc;  // persistent per-graph accumulators: no allocation on the call path
@@ -1158,7 +1163,6 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     int launches = 0;
     const int cus = c.compute_units > 0 ? c.compute_units : 256;
     const int64_t cap_blocks = int64_t(cus) * 16;
-    const char *only = std::getenv("GMSX_TC_ONLY");
     const bool run_light = !only || std::strcmp(only, "light") == 0;
     // the light edges of this call: a full upload holds every edge (shard = shard_of(e, nparts)), a sharded one its own, densely
     const bool strided = nparts > 1 && g->shard_nparts == 1;
@@ -1173,8 +1177,8 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
     // workgroup has left): measured 72.0-72.4 ms against 71.3-71.6 one after the other at scale 26 — the items kernel is bound by memory and
     // the light edges are 10 GB of it — and beside it from the start 72-80.  GMSX_TC_PERSIST=0 (A/B): rounds 2-3's one-workgroup-per-item
     // kernels (with GMSX_TC_OVERLAP=1 the tail items on a side stream of their own).
-    const int overlap = [] { const char *e = std::getenv("GMSX_TC_OVERLAP"); return e ? std::atoi(e) : 0; }();
-    const int persist = [] { const char *e = std::getenv("GMSX_TC_PERSIST"); return e ? std::atoi(e) : 1; }();
+    const int overlap = [] { const char *e = opt("TC_OVERLAP"); return e ? std::atoi(e) : 0; }();
+    const int persist = [] { const char *e = opt("TC_PERSIST"); return e ? std::atoi(e) : 1; }();
     const bool sides = overlap && c.side[0] && c.side[1];
     struct Join {  // joins the side streams on every way out once they were forked (error returns included)
         Ctx &c;
@@ -1197,7 +1201,7 @@ static int tc_one(const gmsx_graph *g, int part, int nparts, uint64_t *partial, 
         join.armed[1] = true;
     }
     if (persist) {
-        static const int wgs_env = [] { const char *e = std::getenv("GMSX_TC_ITEM_WGS"); return e ? std::atoi(e) : 0; }();  // workgroups per CU (0: what the kernel is compiled for)
+        const int wgs_env = [] { const char *e = opt("TC_ITEM_WGS"); return e ? std::atoi(e) : 0; }();  // workgroups per CU (0: what the kernel is compiled for)
         auto grid = [&](int64_t n, int wgs) {
             return unsigned(std::max<int64_t>(1, std::min<int64_t>((n + kGrab - 1) / kGrab, int64_t(cus) * (wgs_env > 0 ? wgs_env : wgs))));
         };

@@ -1,6 +1,7 @@
 // Internal declarations shared by the host substrate and the device layer of libgmsx.
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <ios>
 #include <memory>
 #include <new>
@@ -41,6 +42,19 @@ struct Csr {
 
 bool worth_relabelling(const Csr &g);
 int relabel_by_degree(const Csr &g, Csr &out);
+
+// OPTIONS (gmsx_set_option, include/gmsx.h): the library takes its tuning limits and diagnostics from explicit calls, never from the
+// environment.  opt("BK_MAXC") = the value the caller set as a C string (valid until the option is set again), or nullptr when unset —
+// the call sites parse it the way they used to parse an environment variable.  Every option leaves the results unchanged.
+const char *opt(const char *name);
+inline long long opt_int(const char *name, long long dflt) {
+    const char *e = opt(name);
+    return e ? std::atoll(e) : dflt;
+}
+inline bool opt_on(const char *name) {
+    const char *e = opt(name);
+    return e && std::atoi(e) != 0;
+}
 
 // threads of the host substrate (gmsx_set_host_threads / OpenMP's current maximum): what the staged upload copies with (loader.cpp)
 int host_threads();

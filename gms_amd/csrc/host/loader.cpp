@@ -51,7 +51,7 @@ static constexpr int64_t kGenBlock = int64_t(1) << 18;  // generator.h:152: rng 
 
 // phase timings of the host substrate on stderr when GMSX_TIMING=1 (the reference prints "Generate Time" / "Build Time")
 struct PhaseTimer {
-    const bool on = std::getenv("GMSX_TIMING") != nullptr;
+    const bool on = opt_on("TIMING");
     double t0 = now();
     static double now() {
 #ifdef _OPENMP
@@ -677,6 +677,44 @@ void parallel_memcpy(void *dst, const void *src, size_t bytes) {
     std::memcpy(dst, src, bytes);
 #endif
 }
+// ---- options (gmsx_set_option) ------------------------------------------------------------------------------------------------------
+// A fixed table: a name the library does not know is refused, so a typo cannot silently do nothing.  All of them change HOW a result is
+// computed (limits, budgets, container forms, diagnostics on stderr), never the result.
+namespace {
+struct Option {
+    const char *name;
+    char value[32];
+    bool set;
+};
+Option g_options[] = {
+    // diagnostics (stderr)
+    {"TIMING", "", false}, {"MEM_TRACE", "", false}, {"BK_VERBOSE", "", false},
+    // triangle-count containers (device_graph.hip) and passes (tc.hip)
+    {"INLINE_LIMIT", "", false}, {"TC_INLINE_FIRST", "", false}, {"TC_DELTA", "", false}, {"TC_DELTA_PCT", "", false}, {"TC_GAP12", "", false},
+    {"TC_HYBRID", "", false}, {"TC_TAIL_DELTA", "", false}, {"TC_TWO_SIDED", "", false}, {"TC_HOT_WINDOWS", "", false}, {"TC_HOT_KB", "", false},
+    {"TC_HOT_MIN", "", false}, {"TC_TEST_MAX_UNITS", "", false}, {"TC_KEEP_ROWS", "", false}, {"TC_MEM_LIMIT_MB", "", false}, {"TC_OVERLAP", "", false},
+    {"TC_PERSIST", "", false}, {"TC_ITEM_WGS", "", false}, {"SORT_CHUNK", "", false}, {"UPLOAD_STAGED", "", false}, {"INIT_LAZY", "", false},
+    // k-clique (kclique.hip)
+    {"KC_SLAB_MB", "", false}, {"KC_MAXD", "", false}, {"KC_STREAMS", "", false}, {"KC_PIPE_ALL", "", false}, {"KC_STREAM_BUILD", "", false},
+    {"KC_REVERSE", "", false},
+    // Bron–Kerbosch (bk.hip)
+    {"BK_MAXC", "", false}, {"BK_ARENA_MB", "", false}, {"BK_GROUPS", "", false}, {"BK_SMALL_P", "", false}, {"BK_SMALL_P_GROUPS", "", false},
+    {"BK_BUDGET", "", false}, {"BK_BUDGET0", "", false}, {"BK_RESUME_GRAB", "", false}, {"BK_SPLIT_BUILD", "", false}, {"BK_TINY_ROOTS", "", false},
+    {"BK_TINY_BESIDE", "", false},
+};
+Option *find_option(const char *name) {
+    if (!name) return nullptr;
+    for (Option &o : g_options)
+        if (std::strcmp(o.name, name) == 0) return &o;
+    return nullptr;
+}
+}  // namespace
+
+const char *opt(const char *name) {
+    const Option *o = find_option(name);
+    return o && o->set ? o->value : nullptr;
+}
+
 }  // namespace gmsx
 
 using namespace gmsx;
@@ -879,6 +917,28 @@ uint64_t gmsx_csr_fingerprint(const gmsx_csr *h, int which) {
         x *= 1099511628211ull;
     }
     return x;
+}
+
+int gmsx_set_option(const char *name, const char *value) {
+    gmsx::Option *o = gmsx::find_option(name);
+    if (!o) return GMSX_ERR_INVALID;
+    if (!value) {
+        o->set = false;
+        return GMSX_OK;
+    }
+    if (std::strlen(value) >= sizeof(o->value)) return GMSX_ERR_INVALID;
+    std::strcpy(o->value, value);
+    o->set = true;
+    return GMSX_OK;
+}
+void gmsx_reset_options(void) {
+    for (gmsx::Option &o : gmsx::g_options) o.set = false;
+}
+int gmsx_option_name(int index, const char **name) {
+    const int count = int(sizeof(gmsx::g_options) / sizeof(gmsx::g_options[0]));
+    if (index < 0 || index >= count || !name) return GMSX_ERR_INVALID;
+    *name = gmsx::g_options[index].name;
+    return GMSX_OK;
 }
 
 void gmsx_csr_free(gmsx_csr *h) { delete h; }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define GMSX_VERSION 310
+#define GMSX_VERSION 320
 
 /* ---- status codes ---- */
 enum {
@@ -106,6 +106,29 @@ void gmsx_csr_free(gmsx_csr *g);
  * the runtime default.  Returns the previous maximum.  Launchers that export OMP_NUM_THREADS=1 to their workers
  * (torch.distributed.run does) would otherwise serialise graph generation: the rank that builds the graph calls this. */
 int gmsx_set_host_threads(int n);
+
+/* OPTIONS.  The library reads NO tuning from the environment (the one exception is GMSX_COMM_TIMEOUT_S below): limits, budgets, container
+ * forms and diagnostics are set by explicit calls.  Every option changes HOW a result is computed — which kernel variant, how large a
+ * chunk, what is printed to stderr — and never the result; the "wrong counts" A/B switches of the kernel sources exist only in
+ * development builds (-DGMSX_DEV_HOOKS, tools/ab_lib.sh) and are absent from a library built by `make`.
+ * name: one of the names below (without prefix), else GMSX_ERR_INVALID; value: a decimal number as a C string (< 32 characters), NULL = back
+ * to the default.  Process-wide; set options before the calls they steer, not concurrently with them.  Names:
+ *   diagnostics     TIMING (phase times and bin sizes on stderr), MEM_TRACE (one line per device allocation of a graph), BK_VERBOSE
+ *   upload          SORT_CHUNK (vertices per row-sort range), UPLOAD_STAGED (0 = one hipMemcpyAsync per array), INIT_LAZY (1 = pin the staging
+ *                   buffers at the first large upload instead of in gmsx_init)
+ *   triangle count  TC_MEM_LIMIT_MB (budget of the containers: smaller = several passes), INLINE_LIMIT, TC_INLINE_FIRST, TC_TWO_SIDED,
+ *                   TC_DELTA / TC_DELTA_PCT / TC_GAP12 / TC_HYBRID / TC_TAIL_DELTA (which container forms the stream rows may take),
+ *                   TC_HOT_WINDOWS / TC_HOT_KB / TC_HOT_MIN (L2-window phases of the hub lists), TC_TEST_MAX_UNITS (pretend the task-list
+ *                   fields are this narrow), TC_KEEP_ROWS (keep the per-vertex row descriptors for gmsx_tc_row_histogram), TC_OVERLAP,
+ *                   TC_PERSIST, TC_ITEM_WGS (launch shapes)
+ *   k-clique        KC_MAXD (widest pivot of the bit-matrix kernels), KC_SLAB_MB (budget of the global slabs), KC_STREAMS, KC_PIPE_ALL,
+ *                   KC_STREAM_BUILD, KC_REVERSE (BUILD variants)
+ *   Bron–Kerbosch   BK_MAXC (widest start vertex of the register-resident search), BK_ARENA_MB, BK_BUDGET / BK_BUDGET0 (nodes before a
+ *                   search is re-split), BK_GROUPS, BK_SMALL_P, BK_SMALL_P_GROUPS, BK_RESUME_GRAB, BK_SPLIT_BUILD, BK_TINY_ROOTS,
+ *                   BK_TINY_BESIDE (kernel variants) */
+int gmsx_set_option(const char *name, const char *value);
+void gmsx_reset_options(void);                          /* every option back to its default */
+int gmsx_option_name(int index, const char **name);     /* enumerates the names: GMSX_ERR_INVALID past the last */
 
 /* =====================================================================================
  * Device side

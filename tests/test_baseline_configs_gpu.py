@@ -104,15 +104,11 @@ def test_config4_bk_orkut_shaped_rmat(gpu, oracle):
     assert sum(g.bk_partial(p, 2) for p in range(2)) == total
     rank, rounds = g.adg_rank()                                    # the reference driver's preprocessing step, then BK through it
     assert rounds > 1 and g.bk_count(rank=rank) == total
-    old = os.environ.get("GMSX_BK_BUDGET")
     try:
-        os.environ["GMSX_BK_BUDGET"] = "4096"                      # a different split/resume decomposition of every search
+        gpu.set_option("BK_BUDGET", "4096")                      # a different split/resume decomposition of every search
         assert g.bk_count() == total
     finally:
-        if old is None:
-            os.environ.pop("GMSX_BK_BUDGET", None)
-        else:
-            os.environ["GMSX_BK_BUDGET"] = old
+        gpu.reset_options()
     g.free()
 
 

@@ -158,18 +158,14 @@ def test_bk_roots_that_do_not_fit_the_arena_are_built_in_chunks(gpu):
     g = gpu.DeviceGraph.from_csr(csr)
     got, st = g.bk_count(stats=True)
     assert got == want
-    old = os.environ.get("GMSX_BK_ARENA_MB")
-    os.environ["GMSX_BK_ARENA_MB"] = "1"
+    gpu.set_option("BK_ARENA_MB", "1")
     try:
         got2, st2 = g.bk_count(stats=True)
         assert got2 == want
         assert st2["launches"] > st["launches"], (st, st2)
         assert sum(g.bk_partial(p, 2) for p in range(2)) == want
     finally:
-        if old is None:
-            os.environ.pop("GMSX_BK_ARENA_MB", None)
-        else:
-            os.environ["GMSX_BK_ARENA_MB"] = old
+        gpu.reset_options()
     g.free()
 
 
@@ -178,9 +174,8 @@ def test_bk_tiny_budget_splits_everything(gpu, oracle, budget):
     """A node budget of a few dozen nodes makes every non-trivial search split, again and again: every level with pending branches is cut
     into up to eight records whose runs of siblings start from the state their predecessors leave behind (P minus / X plus the earlier
     branch vertices).  Same counts as the oracle on graphs with deep searches (dense blocks), wide nodes (hubs) and both."""
-    old = {k: os.environ.get(k) for k in ("GMSX_BK_BUDGET", "GMSX_BK_BUDGET0")}
-    os.environ["GMSX_BK_BUDGET"] = str(budget)
-    os.environ["GMSX_BK_BUDGET0"] = str(budget)
+    gpu.set_option("BK_BUDGET", str(budget))
+    gpu.set_option("BK_BUDGET0", str(budget))
     try:
         rng = np.random.default_rng(5)
         graphs = [host_graph(gpu, "kronecker", 11, 16, True), host_graph(gpu, "uniform", 9, 60, True)]
@@ -200,16 +195,12 @@ def test_bk_tiny_budget_splits_everything(gpu, oracle, budget):
             g.free()
         assert oracle.bk_count(graphs[3].offsets(), graphs[3].neighbors()) == 4 ** 6
     finally:
-        for k_, v in old.items():
-            if v is None:
-                os.environ.pop(k_, None)
-            else:
-                os.environ[k_] = v
+        gpu.reset_options()
 
 
-@pytest.mark.parametrize("knobs", [{"GMSX_BK_GROUPS": "0"}, {"GMSX_BK_TINY_BESIDE": "2"}, {"GMSX_BK_TINY_ROOTS": "1"}, {"GMSX_BK_SMALL_P_GROUPS": "0"},
-                                   {"GMSX_BK_SMALL_P_GROUPS": "600"}, {"GMSX_BK_BUDGET": "40", "GMSX_BK_BUDGET0": "40", "GMSX_BK_SMALL_P_GROUPS": "0"},
-                                   {"GMSX_BK_BUDGET": "24", "GMSX_BK_BUDGET0": "24", "GMSX_BK_GROUPS": "0"}])
+@pytest.mark.parametrize("knobs", [{"BK_GROUPS": "0"}, {"BK_TINY_BESIDE": "2"}, {"BK_TINY_ROOTS": "1"}, {"BK_SMALL_P_GROUPS": "0"},
+                                   {"BK_SMALL_P_GROUPS": "600"}, {"BK_BUDGET": "40", "BK_BUDGET0": "40", "BK_SMALL_P_GROUPS": "0"},
+                                   {"BK_BUDGET": "24", "BK_BUDGET0": "24", "BK_GROUPS": "0"}])
 def test_bk_search_kernel_variants(gpu, oracle, knobs):
     """Round 5: records with at most 512 candidates are searched four to a wave (k_bk_resume4: 16-lane groups, Xf below level 0 as a list of
     non-zero words — in registers up to 16 pairs, in memory beyond —, the pivot's row doubling as the first branch row, levels kept in
@@ -217,8 +208,8 @@ def test_bk_search_kernel_variants(gpu, oracle, knobs):
     beside the first resume round, force / forbid pivot scoring, and split every search after a few dozen nodes (records written from
     every level in list and in dense form).  Same counts as the oracle on: an R-MAT graph, a dense block (deep searches), a late hub with
     thousands of in-neighbours (Xf far longer than 16 words at level 0, lists in memory below), and K_{4,4,4,4,4,4}."""
-    old = {k: os.environ.get(k) for k in knobs}
-    os.environ.update(knobs)
+    for k_opt, v_opt in knobs.items():
+        gpu.set_option(k_opt, v_opt)
     try:
         rng = np.random.default_rng(11)
         graphs = [host_graph(gpu, "kronecker", 11, 16, True)]
@@ -248,8 +239,4 @@ def test_bk_search_kernel_variants(gpu, oracle, knobs):
             assert sum(g.bk_partial(p, 2) for p in range(2)) == want, (i, knobs)
             g.free()
     finally:
-        for k_, v in old.items():
-            if v is None:
-                os.environ.pop(k_, None)
-            else:
-                os.environ[k_] = v
+        gpu.reset_options()

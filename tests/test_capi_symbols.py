@@ -23,7 +23,7 @@ def test_header_and_library_agree(capi):
     for name in names:
         assert hasattr(L, name), f"{name} declared in include/gmsx.h but not exported by libgmsx.so"
     assert sorted(capi.SYMBOLS) == names
-    assert capi.lib().gmsx_version() == 310
+    assert capi.lib().gmsx_version() == 320
     assert capi.lib().gmsx_strerror(-6).decode().startswith("no HIP device")
 
 
@@ -62,3 +62,44 @@ def test_new_entry_points_fail_loudly_without_gpu(capi):
     with pytest.raises(capi.GmsxError) as ei:  # (creating an id is host-side bootstrap and may succeed; binding a rank needs the device)
         capi.Comm.init(0, 1, bytes(capi.COMM_ID_BYTES))
     assert ei.value.status in (capi.ERR_COMM, capi.ERR_NO_DEVICE)
+
+
+def test_shipped_library_has_no_wrong_answer_hooks(capi):
+    """VERDICT r5 'weak' 6: the library `make` builds cannot be steered into a miscount.  GMSX_TC_ONLY and the "wrong counts" A/B regions
+    of the kernel sources exist only under -DGMSX_DEV_HOOKS (tools/ab_lib.sh); the tuning limits are explicit gmsx_set_option calls, and the one
+    environment variable the library reads is the documented GMSX_COMM_TIMEOUT_S."""
+    blob = open(capi.LIB_PATH, "rb").read()
+    assert b"GMSX_TC_ONLY" not in blob
+    env_names = sorted(set(re.findall(rb"GMSX_[A-Z][A-Z0-9_]{2,}", blob)))
+    assert env_names == [b"GMSX_COMM_TIMEOUT_S"], env_names
+    sites = []
+    for base, _, files in os.walk(os.path.join(ROOT, "gms_amd", "csrc")):
+        if os.path.basename(base) == "driver":   # gmsx_driver is a launcher binary, not the library
+            continue
+        for f in files:
+            text = open(os.path.join(base, f), errors="ignore").read()
+            sites += [(f, m.start()) for m in re.finditer(r"getenv\(", text)]
+    dev_only = [s for s in sites if s[0] == "tc.hip"]  # the one under #ifdef GMSX_DEV_HOOKS
+    assert len(sites) - len(dev_only) <= 2, sites
+    # the guard: an A/B macro without GMSX_DEV_HOOKS does not compile
+    hdr = open(os.path.join(ROOT, "gms_amd", "csrc", "hip", "device_graph.hpp")).read()
+    assert "#error" in hdr and "GMSX_DEV_HOOKS" in hdr
+    mk = open(os.path.join(ROOT, "gms_amd", "csrc", "Makefile")).read()
+    assert "GMSX_DEV_HOOKS" not in mk
+
+
+def test_options_api(capi):
+    names = capi.option_names()
+    assert "BK_MAXC" in names and "TC_MEM_LIMIT_MB" in names and len(names) == len(set(names)) >= 30
+    with pytest.raises(capi.GmsxError) as ei:
+        capi.set_option("NO_SUCH_OPTION", 1)
+    assert ei.value.status == capi.ERR_INVALID
+    with pytest.raises(capi.GmsxError):
+        capi.set_option("BK_MAXC", "9" * 40)   # longer than a value may be
+    with capi.options(BK_MAXC=64, KC_MAXD=8):
+        pass
+    capi.set_option("BK_MAXC", 5)
+    capi.reset_options()
+    hdr = open(os.path.join(ROOT, "include", "gmsx.h")).read()
+    for n in names:   # every option is documented at the boundary
+        assert re.search(r"\b%s\b" % n, hdr), n

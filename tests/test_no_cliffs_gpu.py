@@ -65,8 +65,7 @@ def _want(oracle, csr, key, k):
 @pytest.mark.parametrize("maxd", [1, 8, 40, 300])
 def test_generic_path_equals_bit_matrix_path(gpu, oracle, maxd):
     """GMSX_KC_MAXD (test hook) lowers the width limit, so ordinary graphs go through the generic recursion: same counts."""
-    old = os.environ.get("GMSX_KC_MAXD")
-    os.environ["GMSX_KC_MAXD"] = str(maxd)
+    gpu.set_option("KC_MAXD", str(maxd))
     try:
         for kind, scale, deg, ks in (("kronecker", 10, 16, (3, 4, 5, 6)), ("uniform", 10, 30, (3, 4)), ("kronecker", 12, 8, (3, 4, 5))):
             csr = host_graph(gpu, kind, scale, deg, True)
@@ -75,10 +74,7 @@ def test_generic_path_equals_bit_matrix_path(gpu, oracle, maxd):
                 assert g.kclique_count(k)[0] == _want(oracle, csr, (kind, scale, deg), k), (kind, scale, k, maxd)
             g.free()
     finally:
-        if old is None:
-            os.environ.pop("GMSX_KC_MAXD", None)
-        else:
-            os.environ["GMSX_KC_MAXD"] = old
+        gpu.reset_options()
 
 
 def test_k_beyond_ten(gpu):
@@ -176,9 +172,8 @@ def test_generic_path_k15_on_a_midsize_graph(gpu, slab_mb):
     csr = planted_cliques_graph(gpu)
     want = dag_clique_count(csr.offsets(), csr.neighbors(), 15)
     assert want >= math.comb(16, 15) + math.comb(17, 15) + math.comb(18, 15)
-    old = os.environ.get("GMSX_KC_SLAB_MB")
     if slab_mb is not None:
-        os.environ["GMSX_KC_SLAB_MB"] = str(slab_mb)
+        gpu.set_option("KC_SLAB_MB", str(slab_mb))
     try:
         g = gpu.DeviceGraph.from_csr(csr)
         ordered, cliques, st = g.kclique_count(15, stats=True)
@@ -188,10 +183,7 @@ def test_generic_path_k15_on_a_midsize_graph(gpu, slab_mb):
         assert sum(g.kclique_partial(15, p, 3) for p in range(3)) == cliques
         g.free()
     finally:
-        if old is None:
-            os.environ.pop("GMSX_KC_SLAB_MB", None)
-        else:
-            os.environ["GMSX_KC_SLAB_MB"] = old
+        gpu.reset_options()
 
 
 @pytest.mark.parametrize("a", [4200, 8200])
@@ -213,8 +205,7 @@ def test_bk_beyond_4096_candidates(gpu, oracle, a):
 def test_bk_memory_resident_search_equals_register_search(gpu, oracle, maxc):
     """GMSX_BK_MAXC (test hook) lowers the width above which a start vertex runs on the memory-resident search (k_bk_wave<false, 0>:
     P / Xc / ext of every level in the global slab) — production value 16384.  Same counts as the oracle and as the shard sums."""
-    old = os.environ.get("GMSX_BK_MAXC")
-    os.environ["GMSX_BK_MAXC"] = str(maxc)
+    gpu.set_option("BK_MAXC", str(maxc))
     try:
         for kind, scale, deg in (("kronecker", 10, 16), ("uniform", 10, 30), ("kronecker", 11, 8)):
             csr = host_graph(gpu, kind, scale, deg, True)
@@ -234,10 +225,7 @@ def test_bk_memory_resident_search_equals_register_search(gpu, oracle, maxc):
         assert g.bk_count() == 81
         g.free()
     finally:
-        if old is None:
-            os.environ.pop("GMSX_BK_MAXC", None)
-        else:
-            os.environ["GMSX_BK_MAXC"] = old
+        gpu.reset_options()
 
 
 @pytest.mark.parametrize("chunk", [1, 700, 50000])
@@ -245,8 +233,7 @@ def test_rows_sorted_in_ranges(gpu, oracle, chunk):
     """rocPRIM's segmented sort counts items in 32 bits, so the upload sorts the rows in vertex ranges of < 2^31 container entries
     (graphs beyond 2^32 entries used to keep unsorted rows and lose the delta forms and the k-clique kernels).  GMSX_SORT_CHUNK (test
     hook) forces many ranges on a small graph: every kernel that relies on ascending rows still agrees with the oracle."""
-    old = os.environ.get("GMSX_SORT_CHUNK")
-    os.environ["GMSX_SORT_CHUNK"] = str(chunk)
+    gpu.set_option("SORT_CHUNK", str(chunk))
     try:
         for kind, scale, deg, hub_limit in (("kronecker", 12, 16, 0), ("uniform", 11, 40, 64)):
             csr = host_graph(gpu, kind, scale, deg, True)
@@ -259,7 +246,4 @@ def test_rows_sorted_in_ranges(gpu, oracle, chunk):
             assert g.bk_count() == _WANT.setdefault(("bk", kind, scale, deg), oracle.bk_count(csr.offsets(), csr.neighbors()))
             g.free()
     finally:
-        if old is None:
-            os.environ.pop("GMSX_SORT_CHUNK", None)
-        else:
-            os.environ["GMSX_SORT_CHUNK"] = old
+        gpu.reset_options()

@@ -192,8 +192,7 @@ def test_inline_limit(gpu, oracle, hub_limit, inline_limit):
     """Light pivots hand the edges to their heavy members and to members of rank id < inline_limit over as inline rows (the members
     below v copied next to v, scanned by v's work items); only the edges to far light members stay behind (k_tc_light).  Any limit gives the same
     counts — for the triangle kernels and for the k-clique / Bron–Kerbosch kernels that share the containers."""
-    old = os.environ.get("GMSX_INLINE_LIMIT")
-    os.environ["GMSX_INLINE_LIMIT"] = str(inline_limit)
+    gpu.set_option("INLINE_LIMIT", str(inline_limit))
     try:
         for kind, scale, deg in (("kronecker", 13, 16), ("uniform", 12, 20)):
             csr = host_graph(gpu, kind, scale, deg, True)
@@ -208,21 +207,18 @@ def test_inline_limit(gpu, oracle, hub_limit, inline_limit):
                 assert g.bk_count() == oracle.bk_count(csr.offsets(), csr.neighbors())
             g.free()
     finally:
-        if old is None:
-            os.environ.pop("GMSX_INLINE_LIMIT", None)
-        else:
-            os.environ["GMSX_INLINE_LIMIT"] = old
+        gpu.reset_options()
 
 
-@pytest.mark.parametrize("knobs", [{"GMSX_TC_TWO_SIDED": "0"}, {"GMSX_TC_TWO_SIDED": "0", "GMSX_INLINE_LIMIT": "0"},
-                                   {"GMSX_TC_OVERLAP": "1"}, {"GMSX_TC_PERSIST": "0"}, {"GMSX_TC_PERSIST": "0", "GMSX_TC_OVERLAP": "1"},
-                                   {"GMSX_TC_ITEM_WGS": "1"}, {"GMSX_TC_ITEM_WGS": "3"}, {"GMSX_TC_GAP12": "0"}, {"GMSX_TC_GAP12": "2"},
-                                   {"GMSX_TC_GAP12": "2", "GMSX_TC_DELTA": "0"}, {"GMSX_TC_HYBRID": "1"}, {"GMSX_TC_HYBRID": "2"},
-                                   {"GMSX_TC_HYBRID": "2", "GMSX_TC_DELTA": "0"},
-                                   {"GMSX_TC_INLINE_FIRST": "64"}, {"GMSX_TC_INLINE_FIRST": "48"}, {"GMSX_TC_INLINE_FIRST": "5"}, {"GMSX_TC_INLINE_FIRST": "1", "GMSX_TC_TWO_SIDED": "0"},
-                                   {"GMSX_TC_HOT_WINDOWS": "1", "GMSX_TC_HOT_KB": "2", "GMSX_TC_HOT_MIN": "4"},
-                                   {"GMSX_TC_HOT_WINDOWS": "3", "GMSX_TC_HOT_KB": "1", "GMSX_TC_HOT_MIN": "1"},
-                                   {"GMSX_TC_HOT_WINDOWS": "8", "GMSX_TC_HOT_KB": "4", "GMSX_TC_HOT_MIN": "16", "GMSX_TC_PERSIST": "0"}])
+@pytest.mark.parametrize("knobs", [{"TC_TWO_SIDED": "0"}, {"TC_TWO_SIDED": "0", "INLINE_LIMIT": "0"},
+                                   {"TC_OVERLAP": "1"}, {"TC_PERSIST": "0"}, {"TC_PERSIST": "0", "TC_OVERLAP": "1"},
+                                   {"TC_ITEM_WGS": "1"}, {"TC_ITEM_WGS": "3"}, {"TC_GAP12": "0"}, {"TC_GAP12": "2"},
+                                   {"TC_GAP12": "2", "TC_DELTA": "0"}, {"TC_HYBRID": "1"}, {"TC_HYBRID": "2"},
+                                   {"TC_HYBRID": "2", "TC_DELTA": "0"},
+                                   {"TC_INLINE_FIRST": "64"}, {"TC_INLINE_FIRST": "48"}, {"TC_INLINE_FIRST": "5"}, {"TC_INLINE_FIRST": "1", "TC_TWO_SIDED": "0"},
+                                   {"TC_HOT_WINDOWS": "1", "TC_HOT_KB": "2", "TC_HOT_MIN": "4"},
+                                   {"TC_HOT_WINDOWS": "3", "TC_HOT_KB": "1", "TC_HOT_MIN": "1"},
+                                   {"TC_HOT_WINDOWS": "8", "TC_HOT_KB": "4", "TC_HOT_MIN": "16", "TC_PERSIST": "0"}])
 def test_task_list_knobs(gpu, oracle, knobs):
     """Every oriented edge is counted at exactly one endpoint: at the pivot that keeps it (forward entry), at the member it was handed
     to because the member's row is the bigger one (reverse entry, cut at the member's id), or inside the member's inline rows.  With
@@ -231,8 +227,8 @@ def test_task_list_knobs(gpu, oracle, knobs):
     the 12-bit-gap form, heavy rows split into a prefix bitmap + the rest (GMSX_TC_HYBRID), the hub lists laid out and run in phases
     by the pool window their rows start in (GMSX_TC_HOT_*), or a heavy pivot handing more / fewer of its first members over inline
     (GMSX_TC_INLINE_FIRST), the count and the bookkeeping stay."""
-    old = {k: os.environ.get(k) for k in knobs}
-    os.environ.update(knobs)
+    for k_opt, v_opt in knobs.items():
+        gpu.set_option(k_opt, v_opt)
     try:
         for kind, scale, deg, hub_limit in (("kronecker", 14, 16, 0), ("kronecker", 13, 40, 64), ("uniform", 12, 120, 0), ("uniform", 12, 120, 500)):
             csr = host_graph(gpu, kind, scale, deg, True)
@@ -250,11 +246,7 @@ def test_task_list_knobs(gpu, oracle, knobs):
             assert sum(p[0] for p in parts) == want and sum(p[1]["units"] for p in parts) == csr.num_edges
             g.free()
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        gpu.reset_options()
 
 
 @pytest.mark.parametrize("delta", ["0", "1", "2"])
@@ -262,10 +254,8 @@ def test_stream_row_forms(gpu, oracle, delta):
     """The heavy-pivot kernel reads every member's hub part as a 'stream row' in the cheapest of three forms (16-bit list, bitset,
     byte-delta with 255-escapes).  GMSX_TC_DELTA = 0 / 1 / 2 = never / when smaller / wherever possible: same counts, on graphs
     whose rows have small gaps (dense block), huge gaps (sparse uniform: escapes and one-id units) and both (RMAT)."""
-    old = os.environ.get("GMSX_TC_DELTA")
-    old_t = os.environ.get("GMSX_TC_TAIL_DELTA")
-    os.environ["GMSX_TC_DELTA"] = delta
-    os.environ["GMSX_TC_TAIL_DELTA"] = delta   # the tail parts have the same choice: 32-bit list or 16-bit delta units
+    gpu.set_option("TC_DELTA", delta)
+    gpu.set_option("TC_TAIL_DELTA", delta)   # the tail parts have the same choice: 32-bit list or 16-bit delta units
     try:
         for kind, scale, deg in (("kronecker", 14, 16), ("uniform", 13, 150), ("kronecker", 12, 64)):
             csr = host_graph(gpu, kind, scale, deg, True)
@@ -284,11 +274,7 @@ def test_stream_row_forms(gpu, oracle, delta):
         assert g.tc_total() == oracle.tc_total(csr.offsets(), csr.neighbors())
         g.free()
     finally:
-        for name, val in (("GMSX_TC_DELTA", old), ("GMSX_TC_TAIL_DELTA", old_t)):
-            if val is None:
-                os.environ.pop(name, None)
-            else:
-                os.environ[name] = val
+        gpu.reset_options()
 
 
 def test_shards_of_separate_processes_add_up(gpu):
@@ -314,8 +300,7 @@ def test_rows_too_long_for_a_task_entry_are_refused_not_miscounted(gpu, oracle):
     rows), the base layout stays usable, and the same graph counts right without the hook.  GMSX_TC_TEST_MAX_UNITS (test hook) narrows the fields."""
     csr = host_graph(gpu, "kronecker", 14)
     want = oracle.tc_total(csr.offsets(), csr.neighbors())
-    old = os.environ.get("GMSX_TC_TEST_MAX_UNITS")
-    os.environ["GMSX_TC_TEST_MAX_UNITS"] = "2"
+    gpu.set_option("TC_TEST_MAX_UNITS", "2")
     try:
         g = gpu.DeviceGraph.from_csr(csr)
         with pytest.raises(gpu.GmsxError) as ei:
@@ -324,14 +309,11 @@ def test_rows_too_long_for_a_task_entry_are_refused_not_miscounted(gpu, oracle):
         assert g.kclique_count(3)[1] == want         # the base layout is untouched
         with pytest.raises(gpu.GmsxError):
             gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_FOR_TC)
-        os.environ["GMSX_TC_TEST_MAX_UNITS"] = "100000"
+        gpu.set_option("TC_TEST_MAX_UNITS", "100000")
         assert g.tc_total() == want                  # the handle recovers once the rows fit
         g.free()
     finally:
-        if old is None:
-            os.environ.pop("GMSX_TC_TEST_MAX_UNITS", None)
-        else:
-            os.environ["GMSX_TC_TEST_MAX_UNITS"] = old
+        gpu.reset_options()
 
 
 def test_containers_that_do_not_fit_fall_back_to_passes(gpu, oracle):
@@ -345,8 +327,7 @@ def test_containers_that_do_not_fit_fall_back_to_passes(gpu, oracle):
     full_bytes = g0.device_bytes
     t0, st0 = g0.tc_total(stats=True)
     g0.free()
-    old = os.environ.get("GMSX_TC_MEM_LIMIT_MB")
-    os.environ["GMSX_TC_MEM_LIMIT_MB"] = "64"
+    gpu.set_option("TC_MEM_LIMIT_MB", "64")
     try:
         g = gpu.DeviceGraph.from_csr(csr)
         assert g.tc_passes == 0                      # lazy: nothing built yet
@@ -358,17 +339,17 @@ def test_containers_that_do_not_fit_fall_back_to_passes(gpu, oracle):
         assert g.tc_total() == want
         # fewer shards than passes: a shard that cannot fit either is cut into nested sub-shards — slower, never refused —
         # and the handle stays usable for whole-graph calls afterwards
-        os.environ["GMSX_TC_MEM_LIMIT_MB"] = "40"
+        gpu.set_option("TC_MEM_LIMIT_MB", "40")
         g2 = gpu.DeviceGraph.from_csr(csr)
         assert g2.tc_total() == want and g2.tc_passes >= 4
         parts = [g2.tc_partial(p, 2, stats=True) for p in range(2)]
         assert sum(p[0] for p in parts) == want and sum(p[1]["units"] for p in parts) == csr.num_edges
         assert g2.tc_partial(0, 1) == want and g2.tc_total() == want and g2.tc_passes >= 4
         g2.free()
-        os.environ["GMSX_TC_MEM_LIMIT_MB"] = "64"
+        gpu.set_option("TC_MEM_LIMIT_MB", "64")
         assert g.kclique_count(3)[1] == want         # the base layout is untouched
         g.free()
-        os.environ["GMSX_TC_MEM_LIMIT_MB"] = "1"     # nothing fits, not even 1/4096 of the pivots: the one refusal left
+        gpu.set_option("TC_MEM_LIMIT_MB", "1")     # nothing fits, not even 1/4096 of the pivots: the one refusal left
         g = gpu.DeviceGraph.from_csr(csr)
         with pytest.raises(gpu.GmsxError) as ei:
             g.tc_total()
@@ -376,10 +357,7 @@ def test_containers_that_do_not_fit_fall_back_to_passes(gpu, oracle):
         assert g.kclique_count(3)[1] == want
         g.free()
     finally:
-        if old is None:
-            os.environ.pop("GMSX_TC_MEM_LIMIT_MB", None)
-        else:
-            os.environ["GMSX_TC_MEM_LIMIT_MB"] = old
+        gpu.reset_options()
 
 
 def test_random_small_graphs_all_paths(gpu, oracle):
@@ -387,7 +365,6 @@ def test_random_small_graphs_all_paths(gpu, oracle):
     limits that move members between the inline rows and the light-pivot kernel: forward / reverse / cut / inline / first-member entries
     all occur, every count equals the oracle's, every shard split adds up."""
     rng = np.random.default_rng(20261003)
-    old = os.environ.get("GMSX_INLINE_LIMIT")
     try:
         for trial in range(36):
             n = int(rng.integers(40, 2500))
@@ -415,15 +392,13 @@ def test_random_small_graphs_all_paths(gpu, oracle):
             csr = gpu.HostCSR.from_edges(src[keep].astype(np.int32), dst[keep].astype(np.int32))
             want = oracle.tc_total(csr.offsets(), csr.neighbors())
             hub_limit = int(rng.choice([0, 1, 7, 40, 300]))
-            os.environ["GMSX_INLINE_LIMIT"] = str(int(rng.choice([0, 10, 100, 1000, 10 ** 7])))
+            inline_limit = int(rng.choice([0, 10, 100, 1000, 10 ** 7]))
+            gpu.set_option("INLINE_LIMIT", inline_limit)
             g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_DEFAULT | (hub_limit << 8))
             t, st = g.tc_total(stats=True)
-            assert t == want and st["units"] == csr.num_edges, (trial, n, kind, hub_limit, os.environ["GMSX_INLINE_LIMIT"])
+            assert t == want and st["units"] == csr.num_edges, (trial, n, kind, hub_limit, inline_limit)
             nparts = int(rng.integers(2, 6))
             assert sum(g.tc_partial(p, nparts) for p in range(nparts)) == want, (trial, nparts)
             g.free()
     finally:
-        if old is None:
-            os.environ.pop("GMSX_INLINE_LIMIT", None)
-        else:
-            os.environ["GMSX_INLINE_LIMIT"] = old
+        gpu.reset_options()

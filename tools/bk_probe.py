@@ -1,5 +1,5 @@
 """GPU probe: Bron-Kerbosch on the BASELINE configs[3] graph (or `scale ef`): count vs golden, kernel time, rounds.
-usage: bk_probe.py [scale ef] [--default-only]   (--default-only: skip the GMSX_BK_SPLIT_BUILD=1 / 0 comparison runs, e.g. under a profiler)"""
+usage: bk_probe.py [scale ef] [--default-only]   (--default-only: skip the BK_SPLIT_BUILD = 1 / 0 comparison runs, e.g. under a profiler)"""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gms_amd import capi
@@ -16,9 +16,8 @@ except (OSError, ValueError):
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "graphs.json")))
 csr = capi.HostCSR.generate_rmat(scale, ef, 0.45, 0.22, 0.22)
 g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_TRUSTED)
-for knobs in (({},) if default_only else ({}, {"GMSX_BK_SPLIT_BUILD": "1"}, {"GMSX_BK_SPLIT_BUILD": "0"}, {})):
-    os.environ.pop("GMSX_BK_SPLIT_BUILD", None)
-    os.environ.update(knobs)
+for knobs in (({},) if default_only else ({}, {"BK_SPLIT_BUILD": "1"}, {"BK_SPLIT_BUILD": "0"}, {})):
+    capi.set_option("BK_SPLIT_BUILD", knobs.get("BK_SPLIT_BUILD"))
     ms = []
     for _ in range(3):
         total, st = g.bk_count(stats=True)
@@ -26,4 +25,4 @@ for knobs in (({},) if default_only else ({}, {"GMSX_BK_SPLIT_BUILD": "1"}, {"GM
     gold = GOLD.get("rmat-%d-%d-a45-b22-c22" % (scale, ef), {}).get("bk")
     print(json.dumps({"graph": [scale, ef], "m": csr.num_edges, "knobs": knobs, "maximal_cliques": total, "golden_ok": (total == gold) if gold else None, "kernel_ms": ms,
                       "rounds": st["probes"], "launches": st["launches"]}), flush=True)
-os.environ.pop("GMSX_BK_SPLIT_BUILD", None)
+capi.set_option("BK_SPLIT_BUILD", None)

@@ -12,6 +12,6 @@ bash tools/profile_bench.sh s26_r5final > gpurun_out/prof_s26_r5final.log 2>&1; 
 bash tools/profile_pmc.sh kc22_r5final tools/kc_probe.py 22 > gpurun_out/prof_kc22_r5final.log 2>&1; tail -2 gpurun_out/prof_kc22_r5final.log
 python tools/kc_probe.py 24 2>&1 | tail -1 > gpurun_out/kc24_r5.json
 python tools/kc_probe.py 26 2>&1 | tail -1 > gpurun_out/kc26_r5.json
-(bash tools/kc_trace.sh 26; bash tools/probes/kc_bin_traffic.sh 26; GMSX_TIMING=1 python tools/kc_probe.py 26 2>&1 | grep "kclique\]" | sort -u) > gpurun_out/kc26_bins_r5.txt 2>&1
+(bash tools/kc_trace.sh 26; bash tools/probes/kc_bin_traffic.sh 26; GMSX_OPT_TIMING=1 python tools/kc_probe.py 26 2>&1 | grep "kclique\]" | sort -u) > gpurun_out/kc26_bins_r5.txt 2>&1
 (python tools/bk_probe.py --default-only | tail -1; bash tools/probes/bk_trace.sh) > gpurun_out/bk_r5final.txt 2>&1
-GMSX_TIMING=1 python tools/probes/upload_phases.py 26 2>&1 | grep "gmsx\|rep" | grep -v "rmat\|host\]" > gpurun_out/upload_phases_s26.txt
+GMSX_OPT_TIMING=1 python tools/probes/upload_phases.py 26 2>&1 | grep "gmsx\|rep" | grep -v "rmat\|host\]" > gpurun_out/upload_phases_s26.txt

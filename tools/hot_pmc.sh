@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: tools/hot_pmc.sh <windows> <KB> <min> : kernel trace + FETCH_SIZE + L2 hit/miss passes of the scale-26 triangle count with the given hot-window setting
 export TMPDIR=/tmp
-export GMSX_TC_HOT_WINDOWS=$1 GMSX_TC_HOT_KB=$2 GMSX_TC_HOT_MIN=$3
+export GMSX_OPT_TC_HOT_WINDOWS=$1 GMSX_OPT_TC_HOT_KB=$2 GMSX_OPT_TC_HOT_MIN=$3
 OUT=gpurun_out/hot_$1_$2_$3
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 tools/tc_probe.py 26 --passes 3 > $OUT/stdout.txt 2> $OUT/trace.err

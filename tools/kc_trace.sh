@@ -2,7 +2,7 @@
 # usage: tools/kc_trace.sh [scale] : kernel trace of the k = 4 call at scale 22 with the bins on ONE stream (per-bin times)
 export TMPDIR=/tmp
 D=$(mktemp -d /tmp/trace_XXXXXX)
-GMSX_KC_STREAMS=1 rocprofv3 --kernel-trace --output-format csv -d $D -o t -- python3 tools/kc_probe.py ${1:-22} --k 4 > $D/stdout.txt 2>&1
+GMSX_OPT_KC_STREAMS=1 rocprofv3 --kernel-trace --output-format csv -d $D -o t -- python3 tools/kc_probe.py ${1:-22} --k 4 > $D/stdout.txt 2>&1
 tail -1 $D/stdout.txt | cut -c1-300
 python3 - "$D" <<'PY'
 import csv, glob, sys

@@ -24,10 +24,10 @@ cases = [("cocktail party 18 pairs", complete_multipartite([2] * 18), 2 ** 18),
 for name, csr, want in cases:
     if csr is None:
         continue
-    for knobs in ({}, {"GMSX_BK_BUDGET": "64", "GMSX_BK_BUDGET0": "64"}, {"GMSX_BK_GROUPS": "0"}):
-        for k in ("GMSX_BK_BUDGET", "GMSX_BK_BUDGET0", "GMSX_BK_GROUPS"):
-            os.environ.pop(k, None)
-        os.environ.update(knobs)
+    for knobs in ({}, {"BK_BUDGET": "64", "BK_BUDGET0": "64"}, {"BK_GROUPS": "0"}):
+        capi.reset_options()
+        for k, v in knobs.items():
+            capi.set_option(k, v)
         g = capi.DeviceGraph.from_csr(csr)
         got, st = g.bk_count(stats=True)
         print(name, knobs, got, "OK" if got == want else "MISMATCH want %d" % want, round(st["kernel_ms"], 1), "ms", flush=True)

@@ -2,7 +2,7 @@
 # usage: tools/probes/kc_bin_traffic.sh [scale]: beyond-L2 read traffic per k = 4 bin (FETCH_SIZE x 1024 x 2: the requests are 128-byte ones), bins on one stream
 export TMPDIR=/tmp
 D=$(mktemp -d /tmp/kcpmc_XXXXXX)
-GMSX_KC_STREAMS=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D -o p -- python3 tools/kc_probe.py ${1:-26} --k 4 > $D/stdout.txt 2>&1
+GMSX_OPT_KC_STREAMS=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D -o p -- python3 tools/kc_probe.py ${1:-26} --k 4 > $D/stdout.txt 2>&1
 python3 - "$D" <<'PY'
 import csv, glob, sys
 rows = []

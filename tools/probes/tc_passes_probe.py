@@ -11,7 +11,7 @@ full = g.device_bytes
 g.free()
 out = {"base_MB": base / 2**20, "tc_MB": (full - base) / 2**20}
 for lim in (96, 80, 72, 64, 56, 48, 40, 32, 24, 16):
-    os.environ["GMSX_TC_MEM_LIMIT_MB"] = str(lim)
+    capi.set_option("TC_MEM_LIMIT_MB", lim)
     g = capi.DeviceGraph.from_csr(csr)
     try:
         g.tc_total()

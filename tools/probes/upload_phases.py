@@ -1,5 +1,5 @@
-"""GPU probe: the phases of bench.py's upload (validated base upload + triangle-count containers) — run with GMSX_TIMING=1.
-usage: GMSX_TIMING=1 python tools/probes/upload_phases.py [scale]"""
+"""GPU probe: the phases of bench.py's upload (validated base upload + triangle-count containers) — run with GMSX_OPT_TIMING=1.
+usage: GMSX_OPT_TIMING=1 python tools/probes/upload_phases.py [scale]"""
 import os
 import sys
 import time

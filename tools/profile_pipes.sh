@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: tools/profile_pipes.sh <tag> <python script + args...>
-# Pipe-busy counters of the triangle-count kernels, one after the other (GMSX_TC_OVERLAP=0 unless the caller sets it): kernel trace, then
+# Pipe-busy counters of the triangle-count kernels, one after the other (GMSX_OPT_TC_OVERLAP=0 unless the caller sets it): kernel trace, then
 # separate --pmc passes (never combined with tracing; 8 SQ slots per pass).  What is busy: SQ_ACTIVE_INST_{VALU,LDS,VMEM,SCA} (quad-cycles a
 # wave had an instruction of that kind executing), SQ_WAIT_* (parked), SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT (LDS-array cycles).
 set -u
@@ -8,7 +8,7 @@ TAG=$1; shift
 OUT=gpurun_out/pipes_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-export GMSX_TC_OVERLAP=${GMSX_TC_OVERLAP:-0}
+export GMSX_OPT_TC_OVERLAP=${GMSX_OPT_TC_OVERLAP:-0}
 rocprofv3 -L > $OUT/counters_available.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 "$@" > $OUT/stdout.txt 2> $OUT/trace.err
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_WAIT_ANY --output-format csv -d $OUT/pmc_active -o pmc -- python3 "$@" > /dev/null 2> $OUT/pmc_active.err

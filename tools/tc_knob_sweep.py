@@ -1,5 +1,5 @@
 """GPU probe: pass time of the triangle count at one RMAT scale under sets of build / launch knobs.
-usage: python tools/tc_knob_sweep.py 26 "GMSX_TC_GAP12=1" "GMSX_TC_DELTA_PCT=100" "GMSX_TC_GAP12=1,GMSX_TC_DELTA_PCT=100" …   ("" = defaults)"""
+usage: python tools/tc_knob_sweep.py 26 "TC_GAP12=1" "TC_DELTA_PCT=100" "TC_GAP12=1,TC_DELTA_PCT=100" …   ("" = defaults)"""
 import json
 import os
 import sys
@@ -20,8 +20,8 @@ csr = capi.HostCSR.generate("kronecker", scale)
 base = None
 for cfg in [""] + [c for c in configs if c]:
     kv = dict(x.split("=", 1) for x in cfg.split(",") if x)
-    old = {k: os.environ.get(k) for k in kv}
-    os.environ.update(kv)
+    for k, v in kv.items():
+        capi.set_option(k, v)
     try:
         g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_TRUSTED | capi.UPLOAD_FOR_TC)
         ms = []
@@ -33,8 +33,4 @@ for cfg in [""] + [c for c in configs if c]:
                           "stream_GB": round(st["stream_bytes"] / 1e9, 1), "probes_G": round(st["probes"] / 1e9, 1), "device_GB": round(g.device_bytes / 1e9, 1)}), flush=True)
         g.free()
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        capi.reset_options()

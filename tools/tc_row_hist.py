@@ -1,7 +1,7 @@
 """GPU: prints gmsx_tc_row_histogram for an RMAT graph — which row lengths the heavy pivots stream and what the light pivots' gathers cost.
 usage: python tools/tc_row_hist.py <scale>"""
 import os, sys, json
-os.environ.setdefault("GMSX_TC_KEEP_ROWS", "1")  # the what-if estimates at the end read the per-vertex row descriptors
+os.environ.setdefault("GMSX_OPT_TC_KEEP_ROWS", "1")  # the what-if estimates at the end read the per-vertex row descriptors
 sys.path.insert(0, ".")
 from gms_amd import capi
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 24

@@ -1,5 +1,5 @@
-"""GPU probe: upload phases of a validated (GMSX_UPLOAD_DEFAULT) upload — run with GMSX_TIMING=1 for the per-phase lines.
-usage: GMSX_TIMING=1 python tools/upload_probe.py 24 [26]"""
+"""GPU probe: upload phases of a validated (GMSX_UPLOAD_DEFAULT) upload — run with GMSX_OPT_TIMING=1 for the per-phase lines.
+usage: GMSX_OPT_TIMING=1 python tools/upload_probe.py 24 [26]"""
 import os
 import sys
 import time
