@@ -165,14 +165,22 @@ def reference_baseline(scale, degree, headline_golden=None):
         for name, kind, sc in (("RoaringGraph", 1, scale), ("SortedSetGraph", 0, max(scale - 2, 10))):
             g = R.generate("kronecker", sc, degree, relabel=True)
             m = R.L.ref_nnz(g) // 2
-            t0 = time.perf_counter()
-            tri = R.tc_total(g, kind)  # includes SetGraph::FromCGraph (the shim cannot time it separately)
-            dt = time.perf_counter() - t0
+            # the reference harness times kernel(sgraph) alone — SetGraph::FromCGraph is its untimed "GraphExec buildTime"
+            # (common/benchmark.h:105-116) —, so the shim clocks the two phases apart and the baseline is m / count_s
+            if hasattr(R.L, "ref_tc_total_timed"):
+                tri, build_s, count_s = R.tc_total_timed(g, kind)
+            else:  # a prebuilt shim of an older round
+                t0 = time.perf_counter()
+                tri = R.tc_total(g, kind)
+                build_s, count_s = 0.0, time.perf_counter() - t0
             R.free(g)
-            out[name] = {"graph": f"RMAT scale-{sc} ef={degree} (reference loader)", "m": int(m), "seconds_incl_setgraph_build": dt,
-                         "edges_per_s": m / dt, "triangles": int(tri)}
+            out[name] = {"graph": f"RMAT scale-{sc} ef={degree} (reference loader)", "m": int(m), "setgraph_build_s": build_s, "count_s": count_s,
+                         "edges_per_s": m / count_s, "edges_per_s_incl_setgraph_build": m / (build_s + count_s), "triangles": int(tri)}
         out["value"], out["unit"], out["cores"] = out["RoaringGraph"]["edges_per_s"], "edges/s", out["threads"]
-        out["sample"] = "Par::count_total<RoaringGraph> of the compiled reference on the whole " + out["RoaringGraph"]["graph"]
+        out["value_incl_setgraph_build"] = out["RoaringGraph"]["edges_per_s_incl_setgraph_build"]
+        out["sample"] = ("Par::count_total<RoaringGraph> of the compiled reference on the whole " + out["RoaringGraph"]["graph"] +
+                         ": m / seconds of kernel(sgraph) alone, as the reference harness times it (common/benchmark.h:111-116); the figure with "
+                         "SetGraph::FromCGraph inside the clock is value_incl_setgraph_build")
         src = ((headline_golden or {}).get("sources") or {}).get("triangles", "")
         mt = re.search(r"(\d+) threads, (\d+) s", src)
         if headline_golden and mt:

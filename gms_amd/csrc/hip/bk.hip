@@ -1628,10 +1628,11 @@ __device__ __forceinline__ int bkg_xf_mem(const uint32_t *src, int n, int xw, co
     if (n < 0) {
         for (int w0 = 0; w0 < xw; w0 += 4 * G) {
             const int w = w0 + 4 * sub;
-            const bk_u4 a = *reinterpret_cast<const bk_u4 *>(src + w), b = *reinterpret_cast<const bk_u4 *>(xt + w);  // up to three words past the row: masked below
+            const int wl = min(w, (xw - 1) & ~3);  // lanes behind the row load its last unit again (unclamped they read up to 4 G - 1 words past a record or the last XT row — the arena and the pools carry 64 bytes of slack)
+            const bk_u4 a = *reinterpret_cast<const bk_u4 *>(src + wl), b = *reinterpret_cast<const bk_u4 *>(xt + wl);  // at most three words past the row: masked below
             uint32_t t[4] = {a.x & b.x, a.y & b.y, a.z & b.z, a.w & b.w};
             if (MODE == 2) {
-                const bk_u4 b2 = *reinterpret_cast<const bk_u4 *>(xt2 + w);
+                const bk_u4 b2 = *reinterpret_cast<const bk_u4 *>(xt2 + wl);
                 t[0] &= b2.x; t[1] &= b2.y; t[2] &= b2.z; t[3] &= b2.w;
             }
 #pragma unroll

@@ -79,6 +79,11 @@ struct gmsx_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
     unsigned long long *buf = nullptr;  // device: the value being reduced
+    unsigned long long *pin = nullptr;  // PINNED host words owned by the communicator: [0] the partial on its way in, [1] the sum on its way out.  The caller's
+                                        // `value` is pageable (a stack word, a ctypes object): a copy queued to it behind ncclAllReduce would block the host
+                                        // inside hipMemcpyAsync when a peer is dead — before the bounded poll is reached — or, if asynchronous, still be
+                                        // pending into freed memory after GMSX_ERR_TIMEOUT.  With pinned words both copies are plain queue
+                                        // entries, and a late DMA lands in memory that lives as long as the communicator.
     hipEvent_t done = nullptr;          // recorded behind every reduction: its wait is a bounded poll
 };
 
@@ -111,6 +116,12 @@ int gmsx_comm_init(int rank, int nranks, const void *id, gmsx_comm **out) {
             delete c;
             return GMSX_ERR_DEVICE_MEM;
         }
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->pin), 16, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(c->buf);
+            delete c;
+            return GMSX_ERR_NOMEM;
+        }
         ncclUniqueId u;
         std::memcpy(&u, id, sizeof(u));
         int rc = GMSX_OK;
@@ -137,6 +148,7 @@ int gmsx_comm_init(int rank, int nranks, const void *id, gmsx_comm **out) {
         }
         if (rc != GMSX_OK) {
             (void)hipFree(c->buf);
+            (void)hipHostFree(c->pin);
             delete c;
             return rc;
         }
@@ -149,9 +161,10 @@ int gmsx_comm_allreduce_u64(gmsx_comm *c, uint64_t *value) {
     return gmsx::guard([&]() -> int {
         if (!c || !value) return GMSX_ERR_INVALID;
         hipStream_t s = ctx().stream;
-        GMSX_HIP(hipMemcpyAsync(c->buf, value, sizeof(uint64_t), hipMemcpyHostToDevice, s));
+        c->pin[0] = *value;
+        GMSX_HIP(hipMemcpyAsync(c->buf, &c->pin[0], sizeof(uint64_t), hipMemcpyHostToDevice, s));
         if (rccl().AllReduce(c->buf, c->buf, 1, kNcclUint64, kNcclSum, c->comm, s) != kNcclSuccess) return GMSX_ERR_COMM;
-        GMSX_HIP(hipMemcpyAsync(value, c->buf, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipMemcpyAsync(&c->pin[1], c->buf, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
         // the wait for the result is bounded too: a peer that died between init and the reduction must not park this rank
         if (!c->done) GMSX_HIP(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
         hipEvent_t done = c->done;
@@ -165,6 +178,7 @@ int gmsx_comm_allreduce_u64(gmsx_comm *c, uint64_t *value) {
             if (now_s() - t0 > limit) return GMSX_ERR_TIMEOUT;
             std::this_thread::sleep_for(std::chrono::microseconds(50));
         }
+        *value = c->pin[1];  // only now: the caller's word is written by the host, after the reduction is known to be through
         return GMSX_OK;
     });
 }
@@ -178,6 +192,7 @@ int gmsx_comm_finalize(gmsx_comm *c) {
         int rc = GMSX_OK;
         if (c->comm && rccl().ok && rccl().CommDestroy(c->comm) != kNcclSuccess) rc = GMSX_ERR_COMM;
         (void)hipFree(c->buf);
+        (void)hipHostFree(c->pin);
         if (c->done) (void)hipEventDestroy(c->done);
         delete c;
         return rc;

@@ -4,6 +4,7 @@
 #include "device_graph.hpp"
 
 #include <algorithm>
+#include <mutex>
 #include <array>
 #include <chrono>
 #include <cstdio>
@@ -1116,6 +1117,8 @@ static int staged_h2d(void *dst, const void *src, size_t bytes, hipStream_t s) {
         GMSX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
         return GMSX_OK;
     }
+    static std::mutex stage_mutex;          // the two pinned buffers, their events and `used` are process-wide: two host threads uploading different graphs
+    std::lock_guard<std::mutex> lock(stage_mutex);  // take turns here instead of overwriting each other's chunks
     static bool used[2] = {false, false};  // across calls: the last chunks of the previous copy may still be on the wire when the next one starts filling
     int b = 0;
     for (size_t at = 0; at < bytes; at += kChunk, b ^= 1) {

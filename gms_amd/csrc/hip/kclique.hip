@@ -1611,7 +1611,9 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
             const int threads = dmax >= 704 ? 1024 : dmax >= 384 ? 512 : 256;
             // (one 1024-thread workgroup per CU from d+ = 513 on: four waves per SIMD whatever the registers — the pipelined BUILD pays there)
-            if (stream_build)
+            // (the step-stream BUILD adds 256 descriptors to the dynamic LDS: where they no longer fit beside the matrix and the 4 KB static filter —
+            // the d+ <= 1024 bin with per-vertex counts — the bin keeps its default BUILD instead of failing its launch: ADVICE r5)
+            if (stream_build && lds + 256 * sizeof(KcDesc) + 4096 <= size_t(155) * 1024)
                 hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 2>), dim3(unsigned(blocks)), dim3(threads), lds + 256 * sizeof(KcDesc), n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
                                    g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts);
             else if (threads == 1024 || pipe_all)

@@ -191,6 +191,9 @@ class Reference:
         if hasattr(L, "ref_kclist_count_wide"):
             L.ref_kclist_count_wide.restype = C.c_uint64
             L.ref_kclist_count_wide.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        if hasattr(L, "ref_tc_total_timed"):
+            L.ref_tc_total_timed.restype = C.c_uint64
+            L.ref_tc_total_timed.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         if hasattr(L, "ref_tc_total_sliced"):
             L.ref_tc_total_sliced.restype = C.c_uint64
             L.ref_tc_total_sliced.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -229,6 +232,13 @@ class Reference:
 
     def tc_total(self, g, set_kind=0, seq=False):
         return int(self.L.ref_tc_total(g, set_kind, int(seq)))
+
+    def tc_total_timed(self, g, set_kind=0):
+        """(triangles, SetGraph build seconds, count seconds): Par::count_total with the phases the reference harness separates
+        (common/benchmark.h:105-116: FromCGraph untimed, the trial clock around kernel(sgraph) alone)."""
+        b, c = C.c_double(0), C.c_double(0)
+        v = int(self.L.ref_tc_total_timed(g, set_kind, C.byref(b), C.byref(c)))
+        return v, b.value, c.value
 
     def tc_total_sliced(self, g, slices, times=False):
         """Par::count_total on RoaringSets, accumulated over `slices` id ranges of the neighbourhoods (ref_shim.cc: ref_tc_total_sliced) —

@@ -148,6 +148,9 @@ def test_reference_sliced_triangle_count_equals_the_unsliced_call(oracle, refere
         assert want == reference.tc_total(g, 0)
         for k in (1, 2, 3, 5, 8):
             assert reference.tc_total_sliced(g, k) == want, k
+        for kind_ in (0, 1):  # bench.py's cpu_baseline leg: the same call with SetGraph::FromCGraph and kernel(sgraph) clocked apart (common/benchmark.h:105-116)
+            tri, build_s, count_s = reference.tc_total_timed(g, kind_)
+            assert tri == want and build_s >= 0 and count_s > 0
         if scale <= 12:
             off, ng = reference.csr(g)
             assert oracle.tc_total(off, ng) == want
