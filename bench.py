@@ -55,6 +55,7 @@ KERNEL_SOURCES = {
     "kc4": ["gms_amd/csrc/hip/kclique.hip", "gms_amd/csrc/hip/device_graph.hip", "gms_amd/csrc/hip/device_graph.hpp"],
     "bk": ["gms_amd/csrc/hip/bk.hip", "gms_amd/csrc/hip/device_graph.hip", "gms_amd/csrc/hip/device_graph.hpp"],
 }
+KERNEL_SOURCES["kc26"] = KERNEL_SOURCES["kc4"]
 SHARD_COUNTS = (1, 2, 4, 8)
 
 
@@ -97,6 +98,20 @@ def host_cores():
     if quota:
         ncores = max(1, min(ncores, int(quota + 0.999)))
     return ncores
+
+
+def host_memory():
+    """RssAnon / RssFile / VmHWM of this process in bytes (/proc/self/status)."""
+    out = {"RssAnon": 0, "RssFile": 0, "VmHWM": 0}
+    try:
+        with open("/proc/self/status") as f:
+            for line in f:
+                k = line.split(":")[0]
+                if k in out:
+                    out[k] = int(line.split()[1]) * 1024
+    except (OSError, ValueError, IndexError):
+        pass
+    return out
 
 
 def set_gomp_threads(n):
@@ -229,7 +244,7 @@ def golden_record(key):
         return None
 
 
-def side_workload(capi, args, name, traffic, rank):
+def side_workload(capi, args, name, traffic, rank, cus, ceiling):
     """BASELINE.json configs[2] / configs[3] on this GPU: lean upload (no triangle-count containers), five timed calls (the best is reported, all are listed), the count asserted
     against the golden the COMPILED REFERENCE produced (tools/make_golden_big.py), traffic from the PMC child passes of this run."""
     w = WORKLOADS[name]
@@ -252,7 +267,8 @@ def side_workload(capi, args, name, traffic, rank):
     golden = rec_g.get(w["golden_field"])
     if golden is not None:
         assert (rec_g.get("n"), rec_g.get("m")) == (n, m), (rec_g.get("n"), rec_g.get("m"), n, m)
-        assert values[0] == golden, f"PARITY FAILURE ({w['key']}): {values[0]} != reference golden {golden}"
+        got = values[0] // 24 if w["golden_field"] == "kc4_true" else values[0]  # kc4_true = C_4 itself (the reference's kClist), kc4 = 4!·C_4 (its set-based CliqueCount)
+        assert got == golden and (w["golden_field"] != "kc4_true" or values[0] == 24 * golden), f"PARITY FAILURE ({w['key']}): {got} != reference golden {golden}"
         parity = "== reference golden (%s)" % ((rec_g.get("sources") or {}).get(w["golden_field"], "tests/golden/graphs.json"))
     else:
         parity = "no reference golden in tests/golden/graphs.json (self-consistency only)"
@@ -260,7 +276,7 @@ def side_workload(capi, args, name, traffic, rank):
     out = {"workload": w["label"], "n": int(n), "m": int(m), "parity": parity, "kernel_ms": best, "kernel_ms_all": ms, "launches": st["launches"],
            "roots_per_s": n / (best * 1e-3), "upload_s_lean": t_upload, "graph_device_bytes": int(dev_bytes), "load_or_generate_s": t_load,
            "one_shot_s_upload_plus_first_call": t_upload + ms[0] * 1e-3}
-    if name == "kc4":
+    if name in ("kc4", "kc26"):
         out["ordered_count"] = int(values[0])
         out["cliques"] = int(values[0]) // 24
         out["cliques_per_s"] = out["cliques"] / (best * 1e-3)
@@ -275,36 +291,96 @@ def side_workload(capi, args, name, traffic, rank):
         out["maximal_cliques_per_s"] = values[0] / (best * 1e-3)
         out["resume_rounds"] = int(st["probes"])
     trec = (traffic or {}).get("n1")
-    if trec and "bytes" in trec:
-        ach = trec["bytes"] / (best * 1e-3) / 1e9
-        alg = int(st.get("stream_bytes") or 0)
-        out["roofline"] = {"bound": "hbm", "traffic": trec["bytes"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "algorithmic_bytes": alg or None, "algorithmic_GBps": (alg / (best * 1e-3) / 1e9) if alg else None,
-                           "work_efficiency_traffic_over_algorithmic": (trec["bytes"] / alg) if alg else None,
-                           "algorithmic_bytes_are": ALG_BYTES_ARE[name],
-                           "fetch_multiplier": trec.get("fetch_multiplier"), "multiplier_source": trec.get("multiplier_source"),
-                           "traffic_source": "rocprofv3 --pmc child passes of this run (memory-side read requests by size class + WRITE_SIZE, separate passes, one call)",
-                           "memory_level": "beyond-L2 (Infinity Cache + HBM)", "kernel_ms_under_pmc": trec.get("kernel_ms_under_pmc"),
-                           "kernel_hash": kernel_hash(name),
-                           "per_kernel": {k: {"dispatches": v.get("dispatches"), "bytes": v.get("bytes")} for k, v in trec["kernels"].items()},
-                           "note": "latency/issue-bound kernels (build of bit matrices + bitmap recursion): frac says how far from the HBM roof, "
-                                   "not how much work is left"}
-    else:
-        out["roofline"] = None
+    alg = int(st.get("stream_bytes") or 0)
+    out["roofline"] = make_roofline(alg, best * 1e-3, trec if (trec and "bytes" in trec) else None, cus, ceiling, extra={
+        "algorithmic_bytes_are": ALG_BYTES_ARE[name], "kernel_hash": kernel_hash(name),
+        "traffic_source": "rocprofv3 --pmc child passes of this run (memory-side read requests by size class + WRITE_SIZE, SQ_* and GRBM_GUI_ACTIVE: separate passes, one call each)"})
     log(rank, f"{w['key']}: {best:.2f} ms ({parity[:40]}…), upload {t_upload:.2f}s")
     return out
+
+
+def vertex_count2_record(capi, args, rank):
+    """SURVEY §8(f) row 1 on the configs[2] graph: Par::vertex_count2 (parallel/vertex.h:14-27) — counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| = 2 x the triangles at u,
+    so Σ_u counts[u] = 6 T, asserted against the reference golden of that graph."""
+    csr = workload_csr(capi, args, "kc4")
+    g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_DEFAULT)
+    ms, total = [], None
+    for _ in range(3):
+        c, st = g.tc_vertex_count2(stats=True)
+        ms.append(st["kernel_ms"])
+        total = int(c.sum(dtype="int64"))
+    g.free()
+    tri = (golden_record(WORKLOADS["kc4"]["golden_key"]) or {}).get("triangles")
+    if tri is not None:
+        assert total == 6 * tri, f"PARITY FAILURE (vertex_count2): sum {total} != 6 x {tri}"
+    best = min(ms)
+    log(rank, f"vertex_count2_s22: {best:.2f} ms")
+    return {"workload": "per-vertex triangle counts (Par::vertex_count2), RMAT scale-22 ef=16", "n": int(csr.num_nodes), "m": int(csr.num_edges),
+            "kernel_ms": best, "kernel_ms_all": ms, "sum_counts": total, "parity": "sum == 6 x the reference golden's triangles" if tri is not None else "no golden",
+            "edges_per_s": csr.num_edges / (best * 1e-3), "launches": st["launches"]}
+
+
+def tc_s27_record(capi, args, algo, divisor, rank, t_start):
+    """BASELINE.json configs[4]'s graph (RMAT scale 27, 2.1 G edges) on ONE GPU: the whole pass, then each of the eight shards a rank of the 8-GPU run
+    would count (gmsx_tc_partial(p, 8) on the full upload: the shard's own work items, compacted) — their times are what an 8-GPU step costs besides the
+    8-byte all-reduce.  Count asserted against the reference golden (ref_tc_total_sliced, tests/golden/graphs.json)."""
+    age = time.perf_counter() - t_start
+    if age > args.big_budget_s:
+        return {"skipped": f"the run was already {age:.0f} s old (--big-budget-s {args.big_budget_s:.0f}): generating the scale-27 graph on the host takes ~2 min more"}
+    t0 = time.perf_counter()
+    csr = capi.HostCSR.generate("kronecker", 27, 16, capi.RELABEL_AUTO)
+    t_gen = time.perf_counter() - t0
+    n, m = csr.num_nodes, csr.num_edges
+    t0 = time.perf_counter()
+    g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_DEFAULT)
+    t_up = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    g.prepare(capi.PREPARE_TC)
+    t_build = time.perf_counter() - t0
+    ms, whole, st = [], None, None
+    for _ in range(3):
+        whole, st = g.tc_partial(0, 1, algo, stats=True)
+        ms.append(st["kernel_ms"])
+    stream_bytes, dev_bytes = int(st["stream_bytes"]), int(g.device_bytes)
+    shard_ms, shard_sum = [], 0
+    for p in range(8):
+        part, t = None, []
+        for _ in range(2):
+            part, sst = g.tc_partial(p, 8, algo, stats=True)
+            t.append(sst["kernel_ms"])
+        shard_ms.append(min(t))
+        shard_sum += part
+    g.free()
+    tri = whole // divisor
+    golden, src = golden_triangles("kronecker", 27, 16)
+    assert shard_sum == whole, f"PARITY FAILURE (tc_s27): shards add up to {shard_sum}, the whole pass counted {whole}"
+    if golden is not None:
+        assert (n, m) == (134217728, 2111632322) and tri == golden, f"PARITY FAILURE (tc_s27): {tri} != reference golden {golden}"
+    best = min(ms)
+    log(rank, f"tc_s27: {best:.1f} ms whole, shards {min(shard_ms):.2f} … {max(shard_ms):.2f} ms, generate {t_gen:.0f}s")
+    return {"workload": "triangle count, RMAT scale-27 ef=16 on ONE GPU + its eight shards one after the other (BASELINE.json configs[4]'s graph; the 8-GPU run itself is unmeasured: no node)",
+            "n": int(n), "m": int(m), "triangles": int(tri), "parity": f"== reference golden ({src})" if golden is not None else "no golden",
+            "kernel_ms": best, "kernel_ms_all": ms, "edges_per_s": m / (best * 1e-3), "shard_kernel_ms": shard_ms, "shard_ms_max": max(shard_ms), "shard_ms_min": min(shard_ms),
+            "shards_sum_over_whole": sum(shard_ms) / best, "eight_gpu_step_estimate_edges_per_s": m / (max(shard_ms) * 1e-3),
+            "eight_gpu_step_estimate_note": "m / the slowest shard's kernel time: what eight GPUs would reach if the 8-byte all-reduce were free — an estimate from one GPU, NOT a measurement",
+            "algorithmic_bytes": stream_bytes, "algorithmic_GBps": stream_bytes / (best * 1e-3) / 1e9, "frac": stream_bytes / (best * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "graph_device_bytes": dev_bytes, "generate_s": t_gen, "upload_s": t_up, "build_tc_containers_s": t_build}
 
 
 # ---- rocprofv3 PMC passes, live --------------------------------------------------------------------------------------
 
 def sg_cache_path(args):
-    return os.path.join(args.cache_dir, f"{args.generator}-{args.scale}-{args.degree}.sg")
+    return os.path.join(args.cache_dir, f"{args.generator}-{args.scale}-{args.degree}.sgx")  # mapped, not read: the ranks / PMC children share one page-cache copy
 
 
 # the single-GPU perf configs of BASELINE.json besides the triangle count (configs[2], configs[3])
 WORKLOADS = {
     "kc4": dict(key="config2_kclique4_s22", gen=("kronecker", 22, 16), golden_key="kronecker-22-16-relabel", golden_field="kc4", kernels="k_kc_",
                 label="k=4 clique counting, RMAT scale-22 ef=16 (BASELINE.json configs[2])"),
+    # the NORTH-STAR k-clique workload (BASELINE.json north_star: "bit-exact triangle and k-clique counts on RMAT scale-26"): k = 4 on the headline graph;
+    # the golden is the reference's kClist count (tests/golden/graphs.json kc4_true: the set-based CliqueCount cannot reach this size)
+    "kc26": dict(key="kclique4_s26", gen=("kronecker", 26, 16), golden_key="kronecker-26-16-relabel", golden_field="kc4_true", kernels="k_kc_",
+                 label="k=4 clique counting, RMAT scale-26 ef=16 (BASELINE.json north_star: k-clique counts on the headline graph)"),
     "bk": dict(key="config3_bk", gen=("rmat", 21, 56, 0.45, 0.22, 0.22), golden_key="rmat-21-56-a45-b22-c22", golden_field="bk", kernels="k_bk_",
                label="Bron-Kerbosch maximal cliques, com-Orkut-shaped RMAT scale-21 ef=56 A=.45 B=C=.22, |E|=117M (BASELINE.json configs[3])"),
 }
@@ -312,6 +388,7 @@ WORKLOADS = {
 
 # gmsx_stats.stream_bytes of the two side workloads (include/gmsx.h): computed on the device for the call, no cache assumed
 ALG_BYTES_ARE = {
+    "kc26": None,  # = kc4, set below
     "kc4": "per pivot (d+ >= 3) its own containers once + per member v the containers of N+(v) the BUILD reads (bitset words or 16-bit list, tail ids; one "
            "4-byte gather per pair for d+ <= 32) + the slab matrices of pivots wider than 1024, written and read once; the COUNT runs on the bit-matrix in LDS",
     "bk": "per start vertex the oriented rows of all its neighbours (what the builds walk: candidates -> Cadj, in-neighbours -> XT) + Cadj | XT of the start "
@@ -320,13 +397,24 @@ ALG_BYTES_ARE = {
 }
 
 
+ALG_BYTES_ARE["kc26"] = ALG_BYTES_ARE["kc4"]
+
+
+def side_names(args):
+    """The side records of an N = 1 run, in the order they run."""
+    names = ["bk", "kc4"] if args.side else []
+    if args.big and args.scale == 26 and args.generator == "kronecker" and args.degree == 16:
+        names.append("kc26")  # k = 4 on the headline graph itself: shares its cache file
+    return names
+
+
 def workload_cache_path(args, name):
     gen = WORKLOADS[name]["gen"]
-    return os.path.join(args.cache_dir, "-".join(str(x) for x in gen) + ".sg")
+    return os.path.join(args.cache_dir, "-".join(str(x) for x in gen) + ".sgx")
 
 
 def workload_csr(capi, args, name):
-    """The host CSR of a side workload: from the .sg cache of this box when present, else generated (and cached for the PMC children)."""
+    """The host CSR of a side workload: from the .sgx cache of this box when present, else generated (and cached for the PMC children)."""
     path = workload_cache_path(args, name)
     if os.path.exists(path):
         try:
@@ -339,7 +427,7 @@ def workload_csr(capi, args, name):
         os.makedirs(args.cache_dir, mode=0o700, exist_ok=True)
         fd, tmp = tempfile.mkstemp(prefix=".sg_", dir=args.cache_dir)
         os.close(fd)
-        csr.save_sg(tmp)
+        csr.save_sgx(tmp)
         os.replace(tmp, path)
     except (OSError, capi.GmsxError):
         pass
@@ -347,7 +435,7 @@ def workload_csr(capi, args, name):
 
 
 def run_workload(g, name):
-    if name == "kc4":
+    if name in ("kc4", "kc26"):
         ordered, cliques, st = g.kclique_count(4, stats=True)
         return ordered, st
     total, st = g.bk_count(stats=True)
@@ -385,10 +473,12 @@ def run_pmc_pass(args, counters, timeout, workload="tc"):
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found"
     out = tempfile.mkdtemp(prefix="gmsx_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
-    cmd = [rocprof, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "-o", "pmc", "--",
+    cmd = [rocprof, "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out, "-o", "pmc", "--",
                                             sys.executable, os.path.abspath(__file__), "--pmc-child", "--workload", workload, "--scale", str(args.scale),
                                             "--degree", str(args.degree), "--generator", args.generator, "--algo", args.algo, "--cache-dir", args.cache_dir]
     prefix = "k_tc_" if workload == "tc" else WORKLOADS[workload]["kernels"]
+    dur_key = "dur_ns:" + counters[0]
+    counters = list(counters) + [dur_key]  # summed and carried like a counter
     try:
         env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
         r = subprocess.run(cmd, cwd=out, env=env, capture_output=True, text=True, timeout=timeout)
@@ -405,6 +495,10 @@ def run_pmc_pass(args, counters, timeout, workload="tc"):
         for x in rows:
             d = by_dispatch.setdefault(int(x["Dispatch_Id"]), {"kernel": x["Kernel_Name"].split("(")[0].replace("gmsx::", "").replace("void ", "")})
             d[x["Counter_Name"]] = d.get(x["Counter_Name"], 0.0) + float(x["Counter_Value"])
+            try:  # the dispatch's own duration under this pass (the cycle base of the compute-side fractions comes from the same dispatches)
+                d[dur_key] = float(x["End_Timestamp"]) - float(x["Start_Timestamp"])
+            except (KeyError, ValueError):
+                pass
         order = [by_dispatch[k] for k in sorted(by_dispatch)]
         if workload != "tc":  # one call: every dispatch of the workload's kernels belongs to it (helper kernels have other prefixes)
             kernels = {}
@@ -432,6 +526,90 @@ def run_pmc_pass(args, counters, timeout, workload="tc"):
 
 
 RDREQ = ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"]
+# the compute side of the roofline: what the SIMDs and the LDS arrays did while the kernels ran, from two more child passes
+SQ_PASS = ["SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES"]
+GRBM_PASS = ["GRBM_GUI_ACTIVE"]
+N_XCD = 8                      # MI355X: 8 XCDs x 32 CUs; GRBM_GUI_ACTIVE comes back summed over the XCDs (profiles/r05/s26_r5: 797 M per 48.5 ms launch = 8 x 2.05 GHz)
+VALU_CYCLES_PER_INST = 3.0     # SIMD cycles per wave64 VALU instruction for the mix of these kernels: tools/probes/valu_rate.hip measures 2.2-2.5 for the
+VALU_CYCLES_RANGE = (2.3, 4.3)  # add / and / shift class and 4.2-4.3 for v_bfe_u32 / v_lshl_or_b32 / v_mul_lo_u32 / v_bcnt_u32_b32 (profiles/r04/valu_rate.txt)
+
+
+def compute_side(rec, cus):
+    """VALU and LDS utilisation of the dispatches whose counter sums are in `rec` (one kernel, or a whole call).  Under the profiler the dispatches
+    of a call run one after the other, so the cycle base is the sum of their own busy cycles.
+      valu_frac = SQ_INSTS_VALU x cycles-per-instruction / (SIMDs x cycles)     (cycles = GRBM_GUI_ACTIVE / XCDs: one XCD clock's cycles while busy)
+      lds_frac  = SQ_LDS_IDX_ACTIVE / (CUs x cycles)                            (cycles the LDS arrays were indexing; bank conflicts are part of it)"""
+    gui, insts = rec.get("GRBM_GUI_ACTIVE"), rec.get("SQ_INSTS_VALU")
+    if not gui or insts is None:
+        return None
+    cycles = gui / N_XCD
+    out = {"valu_frac": insts * VALU_CYCLES_PER_INST / (4 * cus * cycles),
+           "valu_frac_range": [insts * c / (4 * cus * cycles) for c in VALU_CYCLES_RANGE],
+           "valu_instructions": insts, "busy_cycles_per_xcd": cycles}
+    lds = rec.get("SQ_LDS_IDX_ACTIVE")
+    if lds is not None:
+        out["lds_frac"] = lds / (cus * cycles)
+        out["lds_bank_conflict_share"] = (rec.get("SQ_LDS_BANK_CONFLICT", 0.0) / lds) if lds else 0.0
+    if rec.get("SQ_WAVE_CYCLES"):
+        out["waves_waiting_share"] = rec.get("SQ_WAIT_ANY", 0.0) / rec["SQ_WAVE_CYCLES"]
+    dur = rec.get("dur_ns:GRBM_GUI_ACTIVE")
+    if dur:
+        out["clock_GHz"] = cycles / dur
+    return out
+
+
+def make_roofline(alg_bytes, kernel_s, trec, cus, ceiling_gbs, extra=None):
+    """The `roofline` object of one record.  achieved / frac follow the contract: ALGORITHMIC bytes of the formulation per launch / the launch's
+    duration / the 8 TB/s specification peak; `traffic` = the bytes the L2 requested from memory (PMC, beyond-L2 = Infinity Cache + HBM), with its own
+    rate and fraction beside it; valu_frac / lds_frac from the SQ / GRBM child passes; `bound` = whichever of the three fractions (memory by traffic,
+    VALU, LDS) is highest."""
+    ach = alg_bytes / kernel_s / 1e9 if alg_bytes else None
+    traffic = trec["bytes"] if trec and "bytes" in trec else None
+    r = {"bound": None, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic,
+         "achieved_is": "algorithmic bytes of this formulation (gmsx_stats.stream_bytes: computed on the device for the call, no on-chip reuse assumed) / kernel time",
+         "algorithmic_bytes": int(alg_bytes) if alg_bytes else None,
+         "traffic_GBps": (traffic / kernel_s / 1e9) if traffic else None, "frac_traffic": (traffic / kernel_s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+         "work_efficiency_traffic_over_algorithmic": (traffic / alg_bytes) if (traffic and alg_bytes) else None,
+         "memory_level": "beyond-L2 (Infinity Cache + HBM): the counters tally the L2's memory-side requests, MALL hits included; no DRAM-side counter separates them",
+         "measured_stream_ceiling_GBps": ceiling_gbs,
+         "frac_of_measured_stream_ceiling": (ach / ceiling_gbs) if (ach and ceiling_gbs) else None,
+         "frac_traffic_of_measured_stream_ceiling": (traffic / kernel_s / 1e9 / ceiling_gbs) if (traffic and ceiling_gbs) else None,
+         "measured_stream_ceiling_is": "gmsx_hbm_read_probe of this run: a read-only in-order sweep of an 8 GiB buffer (far beyond the 256 MB Infinity Cache), "
+                                       "16-byte loads, HIP events — what HBM delivers to a pure stream on this box; a kernel whose beyond-L2 rate lies above it "
+                                       "is being served from the Infinity Cache in part",
+         "contract_bound": "hbm"}
+    cs = compute_side(trec, cus) if trec else None
+    fr = {"memory_by_traffic": r["frac_traffic"] if traffic else r["frac"]}
+    if cs:
+        r.update({k: cs[k] for k in ("valu_frac", "valu_frac_range", "lds_frac", "lds_bank_conflict_share", "waves_waiting_share", "clock_GHz") if k in cs})
+        r["valu_frac_is"] = ("SQ_INSTS_VALU x %.1f SIMD cycles per wave64 instruction (tools/probes/valu_rate.hip: %.1f for the add / and / shift class, %.1f for "
+                             "v_bfe / v_lshl_or / v_mul_lo / v_bcnt; valu_frac_range = at those two) / (4 SIMDs x %d CUs x GRBM_GUI_ACTIVE / %d XCDs), "
+                             "dispatches serialised by the profiler" % (VALU_CYCLES_PER_INST, VALU_CYCLES_RANGE[0], VALU_CYCLES_RANGE[1], cus, N_XCD))
+        r["lds_frac_is"] = "SQ_LDS_IDX_ACTIVE / (%d CUs x GRBM_GUI_ACTIVE / %d XCDs)" % (cus, N_XCD)
+        fr["valu"] = cs["valu_frac"]
+        if "lds_frac" in cs:
+            fr["lds"] = cs["lds_frac"]
+    fr = {k: v for k, v in fr.items() if v is not None}
+    if fr:
+        top = max(fr, key=fr.get)
+        r["bound"] = {"memory_by_traffic": "beyond-L2", "valu": "valu", "lds": "lds"}[top]
+    r["fractions"] = fr
+    if trec:
+        r.update({"fetch_multiplier": trec.get("fetch_multiplier"), "multiplier_source": trec.get("multiplier_source"),
+                  "kernel_ms_under_pmc": trec.get("kernel_ms_under_pmc"), "l2_hit_rate": trec.get("l2_hit_rate")})
+        pk = {}
+        for k, v in (trec.get("kernels") or {}).items():
+            e = {"dispatches": v.get("dispatches", 1), "bytes": v.get("bytes")}
+            kc = compute_side(v, cus)
+            if kc:
+                e.update({a: kc[a] for a in ("valu_frac", "lds_frac", "lds_bank_conflict_share", "waves_waiting_share", "clock_GHz") if a in kc})
+                if v.get("dur_ns:GRBM_GUI_ACTIVE"):
+                    e["ms_under_pmc"] = v["dur_ns:GRBM_GUI_ACTIVE"] * 1e-6
+            pk[k] = e
+        r["per_kernel"] = pk
+    if extra:
+        r.update(extra)
+    return r
 
 
 def measure_traffic(args, rank, workload="tc"):
@@ -440,7 +618,7 @@ def measure_traffic(args, rank, workload="tc"):
     table, notes = {}, []
     # the memory-side read requests of the L2 by SIZE CLASS: FETCH_SIZE tallies every request at 64 B (MI355X_MICROARCH.md "HBM": exactly half the bytes of a
     # 16-byte-per-lane stream; "other access widths are uncalibrated") — 32 n32 + 64 n64 + 128 n128 is the byte count itself, per kernel, whatever the widths
-    passes = (RDREQ, ["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]) if workload == "tc" else (RDREQ, ["FETCH_SIZE"], ["WRITE_SIZE"])
+    passes = ((RDREQ, ["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]) if workload == "tc" else (RDREQ, ["FETCH_SIZE"], ["WRITE_SIZE"])) + (SQ_PASS, GRBM_PASS)
     for counters in passes:
         t0 = time.perf_counter()
         res, err = run_pmc_pass(args, counters, timeout=args.pmc_timeout, workload=workload)
@@ -494,6 +672,9 @@ def committed_traffic(khash, key, world):
         return None
 
 
+T_START = time.perf_counter()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -514,6 +695,9 @@ def main():
                                                        "(the committed fallback profiles/hbm_traffic.json is produced this way)")
     ap.add_argument("--side", type=int, default=1, help="N=1: also run BASELINE configs[2] (k=4 cliques, scale 22) and configs[3] (Bron-Kerbosch, 117M-edge RMAT); 0 disables")
     ap.add_argument("--workload", default="tc", choices=["tc"] + sorted(WORKLOADS), help=argparse.SUPPRESS)
+    ap.add_argument("--big", type=int, default=1, help="N=1: also the two north-star-size records — kclique4_s26 (k = 4 on the headline graph, count == the reference's kClist golden) "
+                                                      "and tc_s27 (BASELINE configs[4]'s graph on ONE GPU: whole pass + its eight shards); 0 disables")
+    ap.add_argument("--big-budget-s", type=float, default=330.0, help="tc_s27 (≈ 2 min of host-side graph generation) is skipped when the run is already older than this")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -545,8 +729,11 @@ def main():
                 try:
                     fd, tmp = tempfile.mkstemp(prefix=".sg_", dir=args.cache_dir)
                     os.close(fd)
-                    csr.save_sg(tmp)
+                    csr.save_sgx(tmp)
                     os.replace(tmp, sg)
+                    if world > 1:  # rank 0 drops its private copy and maps the cache like the other ranks: ONE copy of the CSR in host memory
+                        csr = None
+                        csr = capi.HostCSR.load(sg, relabel=capi.RELABEL_NEVER)
                 except (OSError, capi.GmsxError) as e:  # a full or read-only cache directory is not an error of the benchmark
                     log(rank, f"cache not written: {e}")
 
@@ -575,8 +762,8 @@ def main():
                 pass
 
     side_traffic = {}
-    if rank == 0 and world == 1 and args.side:
-        for name in sorted(WORKLOADS):
+    if rank == 0 and world == 1:
+        for name in side_names(args):
             try:
                 workload_csr(capi, args, name)  # generated on the host and cached for the children (and for the leg below)
                 if args.pmc:
@@ -605,6 +792,13 @@ def main():
     t_init = time.perf_counter() - t_i0
     capi.set_stream(torch.cuda.current_stream().cuda_stream)
     info = capi.device_info()
+    ceiling = None
+    if rank == 0 and not share:
+        try:  # the box's own read-stream ceiling, before the graph takes the memory: 8 GiB swept 40 times, ~60 ms
+            ceiling = capi.hbm_read_probe(8 << 30, 40)
+            log(rank, f"read-only stream ceiling of this device: {ceiling:.0f} GB/s")
+        except capi.GmsxError as e:
+            log(rank, f"stream ceiling probe failed: {e}")
     algo = {"auto": capi.TC_AUTO, "oriented": capi.TC_ORIENTED, "full": capi.TC_FULL}[args.algo]
     divisor = capi.lib().gmsx_tc_divisor(algo)
 
@@ -712,31 +906,19 @@ def main():
             if trec is not None:
                 traffic_source = "profiles/hbm_traffic.json (measured on this kernel build: hash %s)" % khash
     traffic = trec["bytes"] if trec else None
-    if traffic is not None:
-        achieved, achieved_src = traffic / t_kernel / 1e9, "measured traffic / kernel time"
-    else:
-        traffic_source = None
-        achieved, achieved_src = stream_bytes / t_kernel / 1e9, ("ALGORITHMIC bytes of the oriented formulation / kernel time (no PMC measurement "
-                                                                 "for this kernel build: " + str(traffic_note or "none available") + ")")
-    roofline = {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-        "achieved_is": achieved_src, "traffic_source": traffic_source,
-        "memory_level": "beyond-L2 (Infinity Cache + HBM): FETCH_SIZE counts L2 misses, MALL hits included; no DRAM-side counter separates them",
-        "kernel_ms": avg_kernel_ms, "kernel_hash": khash,
+    if traffic is None:
+        traffic_source = "none for this kernel build (" + str(traffic_note or "no PMC pass, no cached table") + "): traffic is null"
+    roofline = make_roofline(stream_bytes, t_kernel, trec, info["compute_units"], ceiling, extra={
+        "traffic_source": traffic_source, "kernel_ms": avg_kernel_ms, "kernel_hash": khash,
         "kernel": "k_tc_items<false> (hub items) + k_tc_items<true> (tail items): one PERSISTENT launch per item queue — a pivot's row part in LDS, "
                   "the stream rows its task-list entries name streamed through it; ~95 % of the bytes and of the time — + k_tc_light (edges between two "
                   "light vertices, all-pairs in registers), one after the other on the launch stream; kernel_ms is the HIP-event wall time of the "
-                  "whole pass; traffic is summed over the three",
-        "algorithmic_bytes": stream_bytes, "algorithmic_GBps": stream_bytes / t_kernel / 1e9,
-        "work_efficiency_traffic_over_algorithmic": (traffic / stream_bytes) if (traffic and stream_bytes) else None,
-        "l2_hit_rate": trec.get("l2_hit_rate") if trec else None,
-        "fetch_multiplier": trec.get("fetch_multiplier") if trec else None, "multiplier_source": trec.get("multiplier_source") if trec else None,
-        "per_kernel_traffic_bytes": {k: v.get("bytes") for k, v in trec["kernels"].items()} if trec else None,
+                  "whole pass; traffic and the compute-side counters are summed over the three (per_kernel splits them)",
+        "algorithmic_GBps": stream_bytes / t_kernel / 1e9,
         "reference_equivalent_bytes": b_alg / world, "reference_equivalent_GBps": b_alg / world / t_kernel / 1e9,
         "reference_equivalent_note": "B_alg = 4*sum_{u<v}(d_u+d_v) + 8(n+1) + 4*nnz (SURVEY 8(d)): what the reference's full-row merges stream; "
                                      "not a hardware utilisation — the oriented kernels probe far fewer ids",
-        "probes_per_launch": st["probes"], "graph_device_bytes": g.device_bytes,
-    }
+        "probes_per_launch": st["probes"], "graph_device_bytes": g.device_bytes})
 
     out = {
         "metric": METRIC if args.scale == 26 else METRIC.replace("RMAT-26", f"RMAT-{args.scale}"), "value": value, "unit": "edges/s",
@@ -760,23 +942,38 @@ def main():
         # N > 1: every rank builds the triangle-count containers of ITS pivots only (gmsx_graph_upload_csr_shard); rank 0's figures above
         "upload": {"sharded": world > 1, "shard": [rank, world] if world > 1 else None},
     }
+    # host memory of the ranks: the CSR every rank uploads from is a MAPPING of the one cache file for N > 1 (gmsx_csr_load of
+    # ".sgx"), i.e. file pages shared through the page cache (RssFile), not N private copies (RssAnon)
+    hm = host_memory()
+    out["host_memory"] = {"csr_mapped": bool(csr.is_mapped), "csr_bytes": int(8 * (n + 1) + 4 * nnz),
+                          "rss_anon_bytes_max_over_ranks": int(dist.allreduce_max(float(hm["RssAnon"]), None if share else dev)),
+                          "rss_file_bytes_max_over_ranks": int(dist.allreduce_max(float(hm["RssFile"]), None if share else dev)),
+                          "peak_rss_bytes_max_over_ranks": int(dist.allreduce_max(float(hm["VmHWM"]), None if share else dev)),
+                          "rank0": hm, "note": "RssAnon = private memory of a rank; RssFile = mapped file pages (the shared CSR cache, libraries)"}
     if comm is not None:
         comm.finalize()
     if rank == 0 and world == 1 and args.check_scale > 0 and args.check_scale != args.scale:
         g.free()
         g = None
         out["config1_check"] = config1_check(capi, args.generator, args.check_scale, args.degree, algo, divisor)
-    if rank == 0 and world == 1 and args.side:
+    if rank == 0 and world == 1:
         if g is not None:
             g.free()
             g = None
-        for name in sorted(WORKLOADS):
+        for name in side_names(args):
             try:
-                out[WORKLOADS[name]["key"]] = side_workload(capi, args, name, side_traffic.get(name), rank)
+                out[WORKLOADS[name]["key"]] = side_workload(capi, args, name, side_traffic.get(name), rank, info["compute_units"], ceiling)
             except AssertionError:
                 raise
             except Exception as e:  # noqa: BLE001
                 out[WORKLOADS[name]["key"]] = {"error": repr(e)}
+    if rank == 0 and world == 1 and args.side:
+        try:
+            out["vertex_count2_s22"] = vertex_count2_record(capi, args, rank)
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001
+            out["vertex_count2_s22"] = {"error": repr(e)}
     cpu_cache = os.path.join(args.cache_dir, f"cpu_baseline_{args.generator}-{args.scale}-{args.degree}.json")
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         if g is not None:
@@ -795,6 +992,16 @@ def main():
                 json.dump(out["cpu_baseline"], f)
         except OSError:
             pass
+    if rank == 0 and world == 1 and args.big:
+        csr = None  # the headline graph's host copy goes before the scale-27 one is generated
+        try:
+            out["tc_s27"] = tc_s27_record(capi, args, algo, divisor, rank, T_START)
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001
+            out["tc_s27"] = {"error": repr(e)}
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        pass
     elif rank == 0:
         out["cpu_baseline"] = None
         try:

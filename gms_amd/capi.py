@@ -29,11 +29,11 @@ COMM_ID_BYTES = 128
 # every symbol include/gmsx.h declares (tests/test_capi_symbols.py checks the header against this list)
 SYMBOLS = [
     "gmsx_strerror", "gmsx_version",
-    "gmsx_csr_generate", "gmsx_csr_generate_rmat", "gmsx_csr_from_edges", "gmsx_csr_load", "gmsx_csr_save_sg", "gmsx_csr_from_arrays",
+    "gmsx_csr_generate", "gmsx_csr_generate_rmat", "gmsx_csr_from_edges", "gmsx_csr_load", "gmsx_csr_save_sg", "gmsx_csr_save_sgx", "gmsx_csr_is_mapped", "gmsx_csr_from_arrays",
     "gmsx_csr_worth_relabelling", "gmsx_csr_relabel_by_degree", "gmsx_csr_num_nodes", "gmsx_csr_num_edges",
     "gmsx_csr_num_edges_directed", "gmsx_csr_offsets", "gmsx_csr_neighbors", "gmsx_csr_merge_elements",
     "gmsx_csr_fingerprint", "gmsx_csr_free", "gmsx_set_host_threads", "gmsx_set_option", "gmsx_reset_options", "gmsx_option_name",
-    "gmsx_init", "gmsx_set_stream", "gmsx_device_info",
+    "gmsx_init", "gmsx_set_stream", "gmsx_device_info", "gmsx_hbm_read_probe",
     "gmsx_graph_upload", "gmsx_graph_upload_csr", "gmsx_graph_upload_shard", "gmsx_graph_upload_csr_shard", "gmsx_graph_prepare", "gmsx_graph_tc_passes", "gmsx_graph_free", "gmsx_graph_num_nodes", "gmsx_graph_num_edges",
     "gmsx_graph_device_bytes", "gmsx_graph_max_out_degree",
     "gmsx_tc_total", "gmsx_tc_partial", "gmsx_tc_divisor", "gmsx_tc_stream_breakdown", "gmsx_tc_row_histogram", "gmsx_tc_comembership", "gmsx_tc_vertex_count2",
@@ -77,6 +77,8 @@ def lib():
     L.gmsx_csr_from_edges.argtypes = [C.c_int64, C.c_int64, _i32p, _i32p, C.c_int, C.c_int, vpp]
     L.gmsx_csr_load.argtypes = [C.c_char_p, C.c_int, C.c_int, vpp]
     L.gmsx_csr_save_sg.argtypes = [vp, C.c_char_p]
+    L.gmsx_csr_save_sgx.argtypes = [vp, C.c_char_p]
+    L.gmsx_csr_is_mapped.argtypes = [vp]
     L.gmsx_csr_from_arrays.argtypes = [C.c_int64, _i64p, _i32p, vpp]
     L.gmsx_csr_worth_relabelling.argtypes = [vp]
     L.gmsx_csr_relabel_by_degree.argtypes = [vp, vpp]
@@ -132,6 +134,7 @@ def lib():
     L.gmsx_comm_rank.argtypes = [vp]
     L.gmsx_comm_size.argtypes = [vp]
     L.gmsx_comm_finalize.argtypes = [vp]
+    L.gmsx_hbm_read_probe.argtypes = [C.c_int64, C.c_int, C.POINTER(C.c_double)]
     L.gmsx_set_option.argtypes = [C.c_char_p, C.c_char_p]
     L.gmsx_reset_options.restype = None
     L.gmsx_option_name.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
@@ -194,6 +197,14 @@ class HostCSR:
 
     def save_sg(self, path):
         _check(lib().gmsx_csr_save_sg(self._h, os.fsencode(path)), "gmsx_csr_save_sg")
+
+    def save_sgx(self, path):
+        """The mappable cache form (gmsx_csr_save_sgx); HostCSR.load of a ".sgx" maps it instead of reading it."""
+        _check(lib().gmsx_csr_save_sgx(self._h, os.fsencode(path)), "gmsx_csr_save_sgx")
+
+    @property
+    def is_mapped(self):
+        return bool(lib().gmsx_csr_is_mapped(self._h))
 
     def relabel_by_degree(self):
         h = C.c_void_p()
@@ -282,6 +293,13 @@ def init(device=-1):
 
 def set_stream(stream_ptr):
     _check(lib().gmsx_set_stream(C.c_void_p(stream_ptr)), "gmsx_set_stream")
+
+
+def hbm_read_probe(nbytes=4 << 30, iterations=20):
+    """GB/s of a read-only stream over a buffer of `nbytes` (gmsx_hbm_read_probe)."""
+    v = C.c_double(0)
+    _check(lib().gmsx_hbm_read_probe(int(nbytes), int(iterations), C.byref(v)), "gmsx_hbm_read_probe")
+    return v.value
 
 
 def device_info():

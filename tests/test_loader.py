@@ -247,3 +247,62 @@ def test_sg_reader_rejects_corrupt_files(capi, tmp_path):
         assert ei.value.status == capi.ERR_FORMAT, name
     again = capi.HostCSR.load(good, relabel=capi.RELABEL_NEVER)
     assert again.fingerprint() == csr.fingerprint()
+
+
+def test_sgx_cache_is_mapped_shared_and_validated(capi, tmp_path):
+    """the cache the ranks of a multi-GPU run load is MAPPED (gmsx_csr_load of ".sgx"), so N processes share one page-cache
+    copy instead of fread-ing N private ones; it holds the same arrays as the reference-format .sg, is refused when corrupt exactly like .sg, and
+    a mapped handle behaves like any other (relabel, save, numpy views)."""
+    import struct
+    import subprocess
+    import sys
+    csr = capi.HostCSR.generate("kronecker", 10, 16)
+    n, nnz = csr.num_nodes, csr.nnz
+    p = str(tmp_path / "k10.sgx")
+    csr.save_sgx(p)
+    raw = bytearray(open(p, "rb").read())
+    assert raw[:8] == b"GMSXCSR1" and struct.unpack_from("<qqq", raw, 8) == (0, n, nnz)
+    adj0 = (64 + 8 * (n + 1) + 63) // 64 * 64
+    assert len(raw) == adj0 + 4 * nnz
+    m = capi.HostCSR.load(p, relabel=capi.RELABEL_NEVER)
+    assert m.is_mapped and not csr.is_mapped
+    assert m.fingerprint() == csr.fingerprint() and m.merge_elements() == csr.merge_elements()
+    assert np.array_equal(m.offsets(), csr.offsets()) and np.array_equal(m.neighbors(), csr.neighbors())
+    assert m.offsets().ctypes.data % 64 == 0 and m.neighbors().ctypes.data % 64 == 0
+    # a mapped graph goes through everything a read one does: .sg out, relabel (a new, owned CSR)
+    m.save_sg(str(tmp_path / "back.sg"))
+    assert capi.HostCSR.load(str(tmp_path / "back.sg"), relabel=capi.RELABEL_NEVER).fingerprint() == csr.fingerprint()
+    r = m.relabel_by_degree()
+    assert not r.is_mapped and r.num_edges == csr.num_edges
+    # private anonymous memory of a process that maps the cache stays far below the arrays' size (they are file pages, shared)
+    big = capi.HostCSR.generate("kronecker", 18, 16)
+    pb = str(tmp_path / "k18.sgx")
+    big.save_sgx(pb)
+    arrays = 8 * (big.num_nodes + 1) + 4 * big.nnz
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from gms_amd import capi\n"
+            "def anon():\n"
+            "    return next(int(l.split()[1]) for l in open('/proc/self/status') if l.startswith('RssAnon')) * 1024\n"
+            "a0 = anon(); g = capi.HostCSR.load(%r, relabel=capi.RELABEL_NEVER); s = int(g.neighbors().sum()); print(anon() - a0, g.is_mapped, s)\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), pb)
+    out = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True).stdout.split()
+    assert out[1] == "True" and int(out[0]) < arrays // 4 and int(out[2]) == int(big.neighbors().sum(dtype=np.int64)), (out, arrays)
+    # corrupt caches are refused, not walked
+    def variant(name, mutate):
+        b = bytearray(raw)
+        mutate(b)
+        q = str(tmp_path / name)
+        open(q, "wb").write(b)
+        return q
+    cases = {
+        "magic.sgx": lambda b: b.__setitem__(0, ord("X")),
+        "nonmono.sgx": lambda b: struct.pack_into("<q", b, 64 + 8 * 5, nnz + 7),
+        "negid.sgx": lambda b: struct.pack_into("<i", b, adj0 + 4 * 3, -1),
+        "bigid.sgx": lambda b: struct.pack_into("<i", b, adj0 + 4 * 3, n),
+        "trunc.sgx": lambda b: b.__delitem__(slice(len(b) - 10, len(b))),
+        "badend.sgx": lambda b: struct.pack_into("<q", b, 64 + 8 * n, nnz - 1),
+        "hugennz.sgx": lambda b: struct.pack_into("<q", b, 24, 1 << 61),
+    }
+    for name, mut in cases.items():
+        with pytest.raises(capi.GmsxError) as ei:
+            capi.HostCSR.load(variant(name, mut), relabel=capi.RELABEL_NEVER)
+        assert ei.value.status == capi.ERR_FORMAT, name

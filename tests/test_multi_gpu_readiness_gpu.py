@@ -47,6 +47,38 @@ def test_bench_two_ranks_on_one_gpu_json_line(gpu, tmp_path):
     assert out["upload"]["sharded"] is True and out["upload"]["shard"] == [0, 2]
 
 
+def test_bench_eight_ranks_on_one_gpu(gpu, tmp_path):
+    """VERDICT r5 item 6 — first-contact readiness for an 8-GPU node, as far as one GPU goes: the N = 1 run of bench.py on the box (live PMC passes,
+    shard traffic cached), then `bench.py --gpus 8` exactly as the driver launches it, eight ranks sharing cuda:0 (GMSX_SHARE_GPU=1, gloo carries the
+    all-reduce).  One JSON line; eight sharded uploads whose partials add up to the reference golden; the ranks MAP the one cache file (no private CSR
+    copies: RssAnon of the fattest rank stays below the CSR's size); the roofline of the N = 8 line comes from the traffic the N = 1 run measured for
+    shard 0 of 8 on this kernel build.  UNMEASURED on real multi-GPU hardware: no 8-GPU node has been available to any round."""
+    cache = str(tmp_path / "cache")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "22", "--steps", "2", "--warmup", "1", "--cache-dir", cache, "--side", "0",
+                         "--cpu-seconds", "0", "--check-scale", "0", "--big", "0"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r1.returncode == 0, r1.stderr[-3000:]
+    one = json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][0])
+    assert one["n_gpus"] == 1 and one["roofline"]["traffic"]
+    env["GMSX_SHARE_GPU"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port",
+           str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--scale", "22", "--steps", "2", "--warmup", "1", "--cache-dir", cache]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["triangles"] == 2111140967   # the reference golden of scale 22
+    assert out["upload"]["sharded"] is True and out["upload"]["shard"] == [0, 8]
+    assert "gloo" in out["config"]["collective"]
+    roof = out["roofline"]
+    assert roof["traffic"] and "N=1 run on this box" in roof["traffic_source"], roof.get("traffic_source")
+    assert 0.05 < roof["traffic"] / one["roofline"]["traffic"] < 0.25                                        # shard 0 of 8: about an eighth of the pass
+    hm = out["host_memory"]
+    assert hm["csr_mapped"] is True and hm["rss_anon_bytes_max_over_ranks"] < hm["csr_bytes"], hm
+    assert hm["peak_rss_bytes_max_over_ranks"] > 0
+
+
 def test_driver_two_ranks_one_device_fails_cleanly(gpu):
     exe = os.path.join(ROOT, "gms_amd", "lib", "gmsx_driver")
     before = set(glob.glob("/tmp/gmsx_driver_id_*"))
