@@ -934,12 +934,17 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->tpool);
     (void)hipFree(g->dplus);
     (void)hipFree(g->order);
+    (void)hipFree(g->kc_rel);
+    (void)hipFree(g->kc_aoff);
+    (void)hipFree(g->kc_arena);
+    (void)hipFree(g->kc_rec);
+    (void)hipFree(g->kc_item);
     (void)hipFree(g->scratch);
     (void)hipFree(g->acc);
     delete g;
 }
 
-static int exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t count, hipStream_t s) {
+int exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t count, hipStream_t s) {
     size_t tmp_bytes = 0;
     GMSX_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, int64_t(0), size_t(count), rocprim::plus<int64_t>(), s));
     void *tmp = nullptr;

@@ -158,6 +158,21 @@ struct gmsx_graph {
     int64_t hub_entries = 0, tail_entries = 0;
     int32_t max_dplus = 0;
     int32_t max_deg = 0;
+    // k-clique REVERSE ROWS (round 6; kclique.hip, ensure_kc_reverse — built at the first k-clique call, like the triangle-count task lists).  The BUILD
+    // needs rows[i] = N+(v_i) ∩ N+(u) for every member v_i of every pivot u.  Forward it streams N+(v_i) against u's bitmap; but nothing of N+(v_i)
+    // above v_i's predecessors can hit, and for a HUB member w = v_i the same bits come from the other side: the i members below w — a prefix of u's
+    // own hub list, 2 i bytes — probed against w's bitset container.  An edge is handed to its receiver w when that is at least twice cheaper; the
+    // receivers then run first (k_kc_reverse: w's bitset staged in LDS, the prefixes of all its in-neighbours streamed through it, hit bits written
+    // as finished matrix rows into an arena) and the pivots copy those rows instead of streaming the member.
+    mutable bool kc_rev_tried = false;       // built (or found not worth building) already
+    mutable uint32_t *kc_rel = nullptr;      // [hoff[n]] per hub-entry position: word offset of that member's row inside its pivot's arena span; ~0u = streamed forward
+    mutable int64_t *kc_aoff = nullptr;      // [n + 1] word offset of a pivot's span in the arena (by rank id)
+    mutable uint32_t *kc_arena = nullptr;    // the reverse rows of one call
+    mutable ulonglong2 *kc_rec = nullptr;    // [kc_recs] one record per reverse edge, receiver by receiver: x = first id of the pivot's hub list in hadj (40 bits) | i << 40,
+                                             //           y = arena word of the row (36 bits) | position of the pivot in `order` << 36 (what a shard is decided on)
+    mutable uint4 *kc_item = nullptr;        // [kc_items] work items: x = receiver, y = entries, z | w << 32 = first record
+    mutable int64_t kc_recs = 0, kc_items = 0, kc_arena_words = 0, kc_rev_bytes = 0;
+    mutable double kc_rev_build_ms = 0.0;    // what building the lists took (reported once, in gmsx_stats.setup_ms of the call that built them)
     unsigned long long *scratch = nullptr;  // device: a few u64 accumulators
     unsigned long long *acc = nullptr;      // device: 64 spread u64 accumulators (128 B apart) + a few control words, reused by every call
     // host-side memo of read-only facts about the immutable graph (filled lazily; handles are single-threaded)
@@ -260,6 +275,7 @@ int ensure_init();
 // number of vertices with d+ >= threshold (= position in `order` where d+ drops below it)
 int kclique_vertex_counts(const gmsx_graph *g, unsigned long long *d_counts, gmsx_stats *st);  // kclique.hip
 int count_dplus_ge(const gmsx_graph *g, int32_t threshold, int64_t *out);
+int exclusive_scan_i64(const int64_t *in, int64_t *out, int64_t count, hipStream_t s);  // device_graph.hip (rocPRIM)
 // builds the triangle-count containers of the (otherwise immutable) graph if they are not there yet (device_graph.hip)
 int ensure_tc(const gmsx_graph *g);
 // … for one shard / pass (frees and rebuilds when another one is resident)

@@ -129,7 +129,8 @@ int gmsx_set_host_threads(int n);
  *                   fields are this narrow), TC_KEEP_ROWS (keep the per-vertex row descriptors for gmsx_tc_row_histogram), TC_OVERLAP,
  *                   TC_PERSIST, TC_ITEM_WGS (launch shapes)
  *   k-clique        KC_MAXD (widest pivot of the bit-matrix kernels), KC_SLAB_MB (budget of the global slabs), KC_STREAMS, KC_PIPE_ALL,
- *                   KC_STREAM_BUILD, KC_REVERSE (BUILD variants)
+ *                   KC_STREAM_BUILD (BUILD variants), KC_REVERSE (0 = every member row streamed forward: no reverse rows), KC_REV_MIN (edges a hub
+ *                   receiver must get to take them, default 64)
  *   Bron–Kerbosch   BK_MAXC (widest start vertex of the register-resident search), BK_ARENA_MB, BK_BUDGET / BK_BUDGET0 (nodes before a
  *                   search is re-split), BK_GROUPS, BK_SMALL_P, BK_SMALL_P_GROUPS, BK_RESUME_GRAB, BK_SPLIT_BUILD, BK_TINY_ROOTS,
  *                   BK_TINY_BESIDE (kernel variants) */
@@ -252,8 +253,8 @@ int gmsx_tc_row_histogram(const gmsx_graph *g, uint64_t *out256);
  * inside one pivot's own list (inline chunks never do).  8 values, host. */
 int gmsx_tc_comembership(const gmsx_graph *g, int batch, uint64_t *out8);
 /* Par::vertex_count2 / vertex_count2_once (parallel/vertex.h:14-49): counts[u] = Σ_{v∈N(u)} |N(u)∩N(v)| (= 2·triangles at u),
- * indexed by the vertex ids of the uploaded CSR.  Runs on the k = 3 bit-matrix kernels (one atomic per pivot member); graphs
- * with d+ > 8192 fall back to one full-row intersect_count per CSR entry. */
+ * indexed by the vertex ids of the uploaded CSR.  Runs on the k = 3 bit-matrix kernels (one atomic per pivot member); pivots with
+ * d+ > 8192 — none on RMAT up to scale 27 (max d+ = 3855) — run on the generic list recursion (one atomic per triangle, those pivots only). */
 int gmsx_tc_vertex_count2(const gmsx_graph *g, int64_t *counts /* n, host */, gmsx_stats *stats);
 
 /* ---- generic batched Set::intersect_count (sorted_set.h:176-182 / roaring_set.h:144-152) over graph rows:

@@ -195,3 +195,39 @@ def test_kclique_star_count(gpu, oracle):
     with pytest.raises(gpu.GmsxError):
         g.kclique_star_count(0)
     g.free()
+
+
+@pytest.mark.parametrize("rev_min", [1, 8, 64])
+def test_reverse_rows_equal_forward_rows(gpu, oracle, rev_min):
+    """Round 6: the BUILD takes rows[i] = N+(v_i) ∩ N+(u) from the cheaper end of the edge — streamed forward (N+(v_i) against u's bitmap)
+    or, for hub members whose receiver takes enough edges, copied from the arena k_kc_reverse filled (u's prefix below v_i against v_i's bitset container).
+    Same matrix either way: counts for k = 3 … 6, the per-vertex counts and the shards' partial sums with the reverse rows at several receiver thresholds
+    (KC_REV_MIN; 1 = every cheaper edge is handed over) equal those with KC_REVERSE = 0, the oracle's and the reference goldens; small hub ranges
+    (GMSX_UPLOAD_HUB_LIMIT) move the hub / tail boundary through the pivots' rows."""
+    specs = (("kronecker", 14, 16, 0), ("kronecker", 16, 16, 0), ("kronecker", 13, 40, 0), ("kronecker", 14, 16, 3000), ("uniform", 12, 120, 0), ("kronecker", 12, 64, 500))
+    for kind, scale, deg, hub_limit in specs:
+        csr = host_graph(gpu, kind, scale, deg, True)
+        flags = gpu.UPLOAD_DEFAULT | (hub_limit << 8)
+        with gpu.options(KC_REVERSE=0):
+            g0 = gpu.DeviceGraph.from_csr(csr, flags=flags)
+            want = {k: g0.kclique_count(k, stats=True) for k in (3, 4, 5, 6)}
+            vc0 = g0.tc_vertex_count2()
+            g0.free()
+        with gpu.options(KC_REV_MIN=rev_min):
+            g = gpu.DeviceGraph.from_csr(csr, flags=flags)
+            base = g.device_bytes
+            for k in (4, 3, 5, 6):
+                ordered, cliques, st = g.kclique_count(k, stats=True)
+                assert (ordered, cliques) == want[k][:2], (kind, scale, deg, hub_limit, k, rev_min)
+                assert st["stream_bytes"] <= want[k][2]["stream_bytes"], (kind, scale, k)   # handing an edge over never costs more bytes than streaming it
+            assert np.array_equal(g.tc_vertex_count2(), vc0)
+            parts = [g.kclique_partial(4, p, 3) for p in range(3)]
+            assert sum(parts) == want[4][1]
+            if (kind, scale, deg, hub_limit) == ("kronecker", 16, 16, 0) and rev_min <= 8:
+                assert g.device_bytes > base      # this graph does hand edges over: the lists and the arena stay with the graph
+            g.free()
+        key = f"{kind}-{scale}-{deg}-relabel"
+        if key in GRAPHS and "kc4" in GRAPHS[key]:
+            assert want[4][0] == GRAPHS[key]["kc4"]
+    csr = host_graph(gpu, "kronecker", 12, 16, True)
+    assert gpu.DeviceGraph.from_csr(csr).kclique_count(4)[0] == oracle.kclique(csr.offsets(), csr.neighbors(), 4)

@@ -83,6 +83,21 @@ def test_vertex_count2_vs_goldens_and_oracle(gpu, oracle):
     e.free()
 
 
+@pytest.mark.parametrize("maxd", [1, 8, 40, 300])
+def test_vertex_count2_on_pivots_wider_than_the_bit_matrix(gpu, oracle, maxd):
+    """per-vertex counts of pivots wider than the bit-matrix kernels hold run on the generic list recursion (k_kc_generic, one atomic per
+    triangle) — those pivots only; the rest of the graph stays on the bit-matrix kernels.  KC_MAXD lowers the width limit so that ordinary graphs split
+    between the two paths at different points: the counts are those of the oracle's Par::vertex_count2 (parallel/vertex.h:14-27) every time."""
+    with gpu.options(KC_MAXD=maxd):
+        for kind, scale, deg in (("kronecker", 10, 16), ("uniform", 10, 30), ("kronecker", 12, 8)):
+            csr = host_graph(gpu, kind, scale, deg, True)
+            g = gpu.DeviceGraph.from_csr(csr)
+            got, st = g.tc_vertex_count2(stats=True)
+            want = oracle.tc_vertex_count2(csr.offsets(), csr.neighbors())
+            assert np.array_equal(got, want), (kind, scale, maxd)
+            g.free()
+
+
 def test_vertex_similarity_batch(gpu, oracle):
     """gmsx_vertex_similarity_batch vs the reference goldens: count-based metrics bit-identical (NaN positions included);
     Adamic-Adar / resource allocation within 1e-12 relative (different summation order, device log())."""

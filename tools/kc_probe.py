@@ -1,5 +1,5 @@
 """GPU probe: k-clique count on RMAT scale(s) — count vs the reference golden, best-of-3 kernel time, lean upload time.
-usage: python tools/kc_probe.py 22 24 [--k 4]"""
+usage: python tools/kc_probe.py 22 24 [--k 4] [--ab]     (--ab: every scale also with KC_REVERSE = 0, the forward-only BUILD of rounds 1-5)"""
 import json
 import os
 import sys
@@ -20,14 +20,20 @@ except (OSError, ValueError):
     pass
 for s in scales:
     csr = capi.HostCSR.generate("kronecker", s)
-    t0 = time.perf_counter()
-    g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_TRUSTED)
-    t_up = time.perf_counter() - t0
-    ms = []
-    for _ in range(3):
-        ordered, cliques, st = g.kclique_count(k, stats=True)
-        ms.append(round(st["kernel_ms"], 2))
-    gold = GOLD.get("kronecker-%d-16-relabel" % s, {}).get("kc%d" % k)
-    print(json.dumps({"scale": s, "k": k, "ordered": ordered, "cliques": cliques, "golden_ok": (ordered == gold) if gold is not None else None, "kernel_ms": ms,
-                      "upload_s": round(t_up, 3), "launches": st["launches"], "device_GB": round(g.device_bytes / 1e9, 2)}), flush=True)
-    g.free()
+    for reverse in ((1, 0) if "--ab" in sys.argv else (1,)):
+        capi.set_option("KC_REVERSE", None if reverse else 0)
+        t0 = time.perf_counter()
+        g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_TRUSTED)
+        t_up = time.perf_counter() - t0
+        ms, setup = [], []
+        for _ in range(3):
+            ordered, cliques, st = g.kclique_count(k, stats=True)
+            ms.append(round(st["kernel_ms"], 2))
+            setup.append(round(st["setup_ms"], 1))
+        rec = GOLD.get("kronecker-%d-16-relabel" % s, {})
+        gold = rec.get("kc%d" % k) if ("kc%d" % k) in rec else (24 * rec["kc4_true"] if k == 4 and "kc4_true" in rec else None)
+        print(json.dumps({"scale": s, "k": k, "reverse_rows": bool(reverse), "ordered": ordered, "cliques": cliques, "golden_ok": (ordered == gold) if gold is not None else None,
+                          "kernel_ms": ms, "setup_ms": setup, "stream_GB": round(st["stream_bytes"] / 1e9, 1), "upload_s": round(t_up, 3), "launches": st["launches"],
+                          "device_GB": round(g.device_bytes / 1e9, 2)}), flush=True)
+        g.free()
+    capi.set_option("KC_REVERSE", None)
