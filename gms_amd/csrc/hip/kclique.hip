@@ -1514,18 +1514,18 @@ static constexpr int kRevMinD = 33;          // narrower pivots run on k_kc_smal
 static constexpr uint32_t kRelForward = 0xffffffffu;
 __device__ __forceinline__ int rev_row_words(int i) { return (i + 31) >> 5; }
 // bytes the forward BUILD streams for hub member w (kc_use_bitset's choice) — and what handing the edge over costs: the prefix, the record, the row written and read back
-__device__ __forceinline__ bool rev_is_cheaper(const int64_t *__restrict__ hoff, int32_t dense_limit, int32_t w, int i) {
+__device__ __forceinline__ bool rev_is_cheaper(const int64_t *__restrict__ hoff, int32_t dense_limit, int32_t w, int i, int factor10) {
     const int hl = int(hoff[w + 1] - hoff[w]);
     const int bw = int(bitset_words(w)) * 4;
     const int fwd = (w < dense_limit && bw + 32 < hl * 2) ? bw : hl * 2;
     const int rev = 2 * i + 16 + 8 * rev_row_words(i) + 32;
-    return 2 * rev < fwd;
+    return factor10 * rev < 10 * fwd;  // (factor10 = 20: handed over when at least twice cheaper)
 }
 // pass 1 (MODE 0): mark the candidate edges (kc_rel = 0 / ~0) and count them per receiver.  pass 2 (MODE 1): the arena words of every pivot (the edges whose
 // receiver takes them).  pass 3 (MODE 2): relative offsets into kc_rel, records to the receivers.  One 16-lane group per pivot position of the d+ order.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_kcr_edges(int64_t n_piv, const int32_t *__restrict__ order, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
-                                                   int32_t dense_limit, int min_edges, uint32_t *__restrict__ rel, uint32_t *__restrict__ rcnt,
+                                                   int32_t dense_limit, int min_edges, int factor10, uint32_t *__restrict__ rel, uint32_t *__restrict__ rcnt,
                                                    int64_t *__restrict__ words /* by rank id */, const int64_t *__restrict__ aoff, const int64_t *__restrict__ roff,
                                                    uint32_t *__restrict__ rcur, ulonglong2 *__restrict__ rec) {
     const int sub = threadIdx.x & 15;
@@ -1543,7 +1543,7 @@ __global__ __launch_bounds__(256) void k_kcr_edges(int64_t n_piv, const int32_t 
             if (i < hc) {
                 w = int32_t(hadj[hb + i]);
                 if (MODE == 0) {
-                    take = i >= 1 && rev_is_cheaper(hoff, dense_limit, w, i);
+                    take = i >= 1 && rev_is_cheaper(hoff, dense_limit, w, i, factor10);
                     rel[hb + i] = take ? 0u : kRelForward;
                     if (take) atomicAdd(&rcnt[w], 1u);
                 } else {
@@ -1607,22 +1607,39 @@ __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ it
         const uint4 *src = reinterpret_cast<const uint4 *>(bmpool + bmoff[w]);
         for (int t = tid; t < nw4; t += 256) reinterpret_cast<uint4 *>(bm)[t] = src[t];
         __syncthreads();
-        for (int e = grp; e < cnt; e += 16) {
-            const ulonglong2 r = rec[first + e];
-            if (nparts > 1 && shard_of(int64_t(r.y >> 36), nparts) != part) continue;  // another rank's pivot
+        // three records in flight per group: the record of entry e + 32, the first unit of the row of entry e + 16, the probes of entry e — every load
+        // unconditional (an entry past the item re-reads its last record: in bounds, skipped below), so the waits are counted and a group does not sit out the
+        // record -> row chain of every entry (first version, one entry at a time: 32.8 ms at scale 26 for 288 M records)
+        const int e_last = cnt - 1;
+        auto unit_of = [&](const ulonglong2 &r) -> kc_u4u {
             const int i = int(r.x >> 40);
-            const uint16_t *row = hadj + (r.x & ((1ull << 40) - 1ull));
-            unsigned char *out = reinterpret_cast<unsigned char *>(arena + (r.y & ((1ull << 36) - 1ull)));
-            const int nbytes = rev_row_words(i) * 4, last = (i - 1) & ~7;  // i >= 1
-            for (int b = sub; b < nbytes; b += 16) {
-                const int p0 = b * 8;
-                const kc_u4u p = *reinterpret_cast<const kc_u4u *>(row + min(p0, last));  // (clamped: in bounds, its bits masked below)
-                uint32_t m = kc_bit_lo(bm, p.x) | (kc_bit_hi(bm, p.x) << 1) | (kc_bit_lo(bm, p.y) << 2) | (kc_bit_hi(bm, p.y) << 3) | (kc_bit_lo(bm, p.z) << 4) |
-                             (kc_bit_hi(bm, p.z) << 5) | (kc_bit_lo(bm, p.w) << 6) | (kc_bit_hi(bm, p.w) << 7);
-                const int valid = i - p0;  // ids of this unit that belong to the prefix (<= 0: a byte of the row's last word behind the prefix)
-                m = valid >= 8 ? m : valid > 0 ? (m & ((1u << valid) - 1u)) : 0u;
-                out[b] = (unsigned char)m;
+            return *reinterpret_cast<const kc_u4u *>(hadj + (r.x & ((1ull << 40) - 1ull)) + min(sub * 8, (i - 1) & ~7));
+        };
+        ulonglong2 r0 = rec[first + min(grp, e_last)], r1 = rec[first + min(grp + 16, e_last)];
+        kc_u4u u0 = unit_of(r0);
+        for (int e = grp; e < cnt; e += 16) {
+            const ulonglong2 r2 = rec[first + min(e + 32, e_last)];
+            const kc_u4u u1 = unit_of(r1);
+            const ulonglong2 r = r0;
+            const bool mine = !(nparts > 1 && shard_of(int64_t(r.y >> 36), nparts) != part);  // (another rank's pivot: skipped)
+            if (mine) {
+                const int i = int(r.x >> 40);
+                const uint16_t *row = hadj + (r.x & ((1ull << 40) - 1ull));
+                unsigned char *out = reinterpret_cast<unsigned char *>(arena + (r.y & ((1ull << 36) - 1ull)));
+                const int nbytes = rev_row_words(i) * 4, last = (i - 1) & ~7;  // i >= 1
+                for (int b = sub; b < nbytes; b += 16) {
+                    const int p0 = b * 8;
+                    const kc_u4u p = b == sub ? u0 : *reinterpret_cast<const kc_u4u *>(row + min(p0, last));  // (clamped: in bounds, its bits masked below)
+                    uint32_t m = kc_bit_lo(bm, p.x) | (kc_bit_hi(bm, p.x) << 1) | (kc_bit_lo(bm, p.y) << 2) | (kc_bit_hi(bm, p.y) << 3) | (kc_bit_lo(bm, p.z) << 4) |
+                                 (kc_bit_hi(bm, p.z) << 5) | (kc_bit_lo(bm, p.w) << 6) | (kc_bit_hi(bm, p.w) << 7);
+                    const int valid = i - p0;  // ids of this unit that belong to the prefix (<= 0: a byte of the row's last word behind the prefix)
+                    m = valid >= 8 ? m : valid > 0 ? (m & ((1u << valid) - 1u)) : 0u;
+                    out[b] = (unsigned char)m;
+                }
             }
+            r0 = r1;
+            r1 = r2;
+            u0 = u1;
         }
     }
 }
@@ -1661,9 +1678,10 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     GMSX_HIP(hipMemsetAsync(words, 0, size_t(g->n + 1) * 8, s));
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
     const int min_edges = int(std::max<long long>(1, opt_int("KC_REV_MIN", kRevMinEdges)));  // (option: a lower threshold lets small test graphs hand edges over)
+    const int factor10 = int(std::max<long long>(1, opt_int("KC_REV_FACTOR", 20)));  // (option: 10 x how much cheaper the reverse side must be)
     const unsigned blocks = unsigned(std::min<int64_t>((n_piv + 15) / 16, int64_t(cu) * 32));
-    hipLaunchKernelGGL(k_kcr_edges<0>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, rel, rcnt, words, nullptr, nullptr, rcur, nullptr);
-    hipLaunchKernelGGL(k_kcr_edges<1>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, rel, rcnt, words, nullptr, nullptr, rcur, nullptr);
+    hipLaunchKernelGGL(k_kcr_edges<0>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, nullptr, nullptr, rcur, nullptr);
+    hipLaunchKernelGGL(k_kcr_edges<1>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, nullptr, nullptr, rcur, nullptr);
     GMSX_HIP(hipGetLastError());
     if (int rc = exclusive_scan_i64(words, aoff, g->n + 1, s)) return rc;
     // the receivers' side on the host: at most 65 535 counters
@@ -1699,7 +1717,7 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     int64_t *roff = static_cast<int64_t *>(d_roff.p), *ioff = static_cast<int64_t *>(d_ioff.p);
     GMSX_HIP(hipMemcpyAsync(roff, h_roff.data(), size_t(H + 1) * 8, hipMemcpyHostToDevice, s));
     GMSX_HIP(hipMemcpyAsync(ioff, h_ioff.data(), size_t(H + 1) * 8, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_kcr_edges<2>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, rel, rcnt, words, aoff, roff, rcur,
+    hipLaunchKernelGGL(k_kcr_edges<2>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, aoff, roff, rcur,
                        static_cast<ulonglong2 *>(d_rec.p));
     hipLaunchKernelGGL(k_kcr_items, dim3(unsigned((H + 255) / 256)), dim3(256), 0, s, H, roff, ioff, static_cast<uint4 *>(d_item.p));
     GMSX_HIP(hipGetLastError());

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gms_amd import capi  # noqa: E402
 
 k = int(sys.argv[sys.argv.index("--k") + 1]) if "--k" in sys.argv else 4
-scales = [int(a) for a in sys.argv[1:] if a.isdigit() and (sys.argv[sys.argv.index(a) - 1] != "--k")]
+scales = [int(a) for a in sys.argv[1:] if a.isdigit() and (sys.argv[sys.argv.index(a) - 1] not in ("--k", "--opts"))]
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "graphs.json")))
 capi.init(0)
 try:
@@ -19,9 +19,24 @@ try:
 except (OSError, ValueError):
     pass
 for s in scales:
-    csr = capi.HostCSR.generate("kronecker", s)
-    for reverse in ((1, 0) if "--ab" in sys.argv else (1,)):
-        capi.set_option("KC_REVERSE", None if reverse else 0)
+    cache = "/tmp/gmsx_probe_cache/kronecker-%d-16.sgx" % s  # (a second probe process on the same box maps it instead of generating again)
+    if os.path.exists(cache):
+        csr = capi.HostCSR.load(cache, relabel=capi.RELABEL_NEVER)
+    else:
+        csr = capi.HostCSR.generate("kronecker", s)
+        try:
+            os.makedirs(os.path.dirname(cache), exist_ok=True)
+            csr.save_sgx(cache + ".tmp")
+            os.replace(cache + ".tmp", cache)
+        except (OSError, capi.GmsxError):
+            pass
+    variants = [{}] + ([{"KC_REVERSE": 0}] if "--ab" in sys.argv else [])
+    if "--opts" in sys.argv:  # --opts "KC_REV_FACTOR=10;KC_REV_FACTOR=30,KC_REV_MIN=16": one more run per ';'-separated option set
+        variants += [dict(kv.split("=") for kv in v.split(",") if kv) for v in sys.argv[sys.argv.index("--opts") + 1].split(";")]
+    for opts in variants:
+        for kk, vv in opts.items():
+            capi.set_option(kk, vv)
+        reverse = str(opts.get("KC_REVERSE", 1)) != "0"
         t0 = time.perf_counter()
         g = capi.DeviceGraph.from_csr(csr, flags=capi.UPLOAD_TRUSTED)
         t_up = time.perf_counter() - t0
@@ -32,8 +47,9 @@ for s in scales:
             setup.append(round(st["setup_ms"], 1))
         rec = GOLD.get("kronecker-%d-16-relabel" % s, {})
         gold = rec.get("kc%d" % k) if ("kc%d" % k) in rec else (24 * rec["kc4_true"] if k == 4 and "kc4_true" in rec else None)
-        print(json.dumps({"scale": s, "k": k, "reverse_rows": bool(reverse), "ordered": ordered, "cliques": cliques, "golden_ok": (ordered == gold) if gold is not None else None,
+        print(json.dumps({"scale": s, "k": k, "reverse_rows": bool(reverse), "options": opts, "ordered": ordered, "cliques": cliques, "golden_ok": (ordered == gold) if gold is not None else None,
                           "kernel_ms": ms, "setup_ms": setup, "stream_GB": round(st["stream_bytes"] / 1e9, 1), "upload_s": round(t_up, 3), "launches": st["launches"],
                           "device_GB": round(g.device_bytes / 1e9, 2)}), flush=True)
         g.free()
-    capi.set_option("KC_REVERSE", None)
+        for kk in opts:
+            capi.set_option(kk, None)  # (not reset_options: the GMSX_OPT_* of the environment stay)
