@@ -802,11 +802,14 @@ def main():
     algo = {"auto": capi.TC_AUTO, "oriented": capi.TC_ORIENTED, "full": capi.TC_FULL}[args.algo]
     divisor = capi.lib().gmsx_tc_divisor(algo)
 
+    anon_delta = 0
     if world > 1:
         dist.barrier()  # rank 0 has written the cache
         if csr is None:
             capi.set_host_threads(max(1, ncores // world))  # every rank: its share of the cores for the host-side bookkeeping
+            a0 = host_memory()["RssAnon"]
             csr = capi.HostCSR.load(sg, relabel=capi.RELABEL_NEVER)
+            anon_delta = host_memory()["RssAnon"] - a0  # what holding the CSR adds to this rank's PRIVATE memory: ~0 for a mapped cache
     t_gen = time.perf_counter() - t0
     n, m, nnz = csr.num_nodes, csr.num_edges, csr.nnz
     elems = csr.merge_elements()
@@ -949,6 +952,7 @@ def main():
                           "rss_anon_bytes_max_over_ranks": int(dist.allreduce_max(float(hm["RssAnon"]), None if share else dev)),
                           "rss_file_bytes_max_over_ranks": int(dist.allreduce_max(float(hm["RssFile"]), None if share else dev)),
                           "peak_rss_bytes_max_over_ranks": int(dist.allreduce_max(float(hm["VmHWM"]), None if share else dev)),
+                          "csr_load_rss_anon_delta_max_over_ranks": int(dist.allreduce_max(float(anon_delta), None if share else dev)),
                           "rank0": hm, "note": "RssAnon = private memory of a rank; RssFile = mapped file pages (the shared CSR cache, libraries)"}
     if comm is not None:
         comm.finalize()

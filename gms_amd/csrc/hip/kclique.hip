@@ -1584,12 +1584,25 @@ __global__ void k_kcr_items(int32_t H, const int64_t *__restrict__ roff, const i
         items[i0 + t] = make_uint4(uint32_t(w), uint32_t(min<int64_t>(kRevItem, cnt - t * kRevItem)), uint32_t(f), uint32_t(f >> 32));
     }
 }
+// Which shard a pivot belongs to: the pivots' kernels stride over the positions of THEIR BIN — position lo + q * nparts + part of the d+ order, lo = where the
+// bin starts (launch_all) — so the rule needs the bins' starts: lo[] ascending, 0 for "not yet reached".
+struct KcBins {
+    static constexpr int kN = 13;
+    int64_t lo[kN];
+    __device__ __forceinline__ int part_of(int64_t pos, int nparts) const {
+        int64_t l = 0;
+#pragma unroll
+        for (int b = 0; b < kN; ++b)
+            if (lo[b] <= pos) l = max(l, lo[b]);
+        return int((pos - l) % nparts);
+    }
+};
 // the receivers' kernel: persistent workgroups take work items (<= 512 records of one receiver w) from a queue; w's bitset container over [0, w) goes to LDS
 // with 16-byte copies; a 16-lane group per record streams the pivot's prefix (16-byte loads, 8 ids per lane and step), tests every id's bit, and each lane
 // stores its 8 hit bits as ONE BYTE of the row — byte b of a row = local indices 8 b … 8 b + 7, i.e. exactly the little-endian words the BUILD copies.
 __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ items, int64_t n_items, const ulonglong2 *__restrict__ rec, const int64_t *__restrict__ bmoff,
                                                     const uint32_t *__restrict__ bmpool, const uint16_t *__restrict__ hadj, uint32_t *__restrict__ arena, int nparts,
-                                                    int part, unsigned int *__restrict__ queue) {
+                                                    int part, KcBins bins, unsigned int *__restrict__ queue) {
     __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords];
     __shared__ unsigned int s_item;
     const int tid = threadIdx.x, grp = tid >> 4, sub = tid & 15;
@@ -1621,7 +1634,7 @@ __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ it
             const ulonglong2 r2 = rec[first + min(e + 32, e_last)];
             const kc_u4u u1 = unit_of(r1);
             const ulonglong2 r = r0;
-            const bool mine = !(nparts > 1 && shard_of(int64_t(r.y >> 36), nparts) != part);  // (another rank's pivot: skipped)
+            const bool mine = nparts <= 1 || bins.part_of(int64_t(r.y >> 36), nparts) == part;  // (another rank's pivot: skipped)
             if (mine) {
                 const int i = int(r.x >> 40);
                 const uint16_t *row = hadj + (r.x & ((1ull << 40) - 1ull));
@@ -1739,14 +1752,23 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     return GMSX_OK;
 }
 // the receivers' pass of one call (inside the timed region, ahead of the pivots' kernels)
-static int launch_kc_reverse(const gmsx_graph *g, int part, int nparts, unsigned long long *acc, int *launches) {
+static int launch_kc_reverse(const gmsx_graph *g, int part, int nparts, int64_t over, unsigned long long *acc, int *launches) {
     if (!g->kc_rel || g->kc_items <= 0) return GMSX_OK;
     Ctx &c = ctx();
     hipStream_t s = c.stream;
+    KcBins bins;  // where the bins of launch_all start (its `range`): the first position whose d+ is <= the bin's width, not below the generic path's share
+    {
+        const int widths[KcBins::kN] = {8192, 4096, 2048, 1024, 704, 512, 384, 256, 192, 128, 96, 64, 32};
+        for (int b = 0; b < KcBins::kN; ++b) {
+            int64_t lo = 0;
+            if (int rc = count_dplus_ge(g, widths[b] + 1, &lo)) return rc;
+            bins.lo[b] = std::max(lo, over);
+        }
+    }
     unsigned int *queue = reinterpret_cast<unsigned int *>(acc + (kAccSlots - 1) * kAccStride + 8);  // a spare word of the accumulator array (zeroed by the caller)
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
     const unsigned blocks = unsigned(std::min<int64_t>(g->kc_items, int64_t(cu) * 8));
-    hipLaunchKernelGGL(k_kc_reverse, dim3(blocks), dim3(256), 0, s, g->kc_item, g->kc_items, g->kc_rec, g->bmoff, g->bmpool, g->hadj, g->kc_arena, nparts, part, queue);
+    hipLaunchKernelGGL(k_kc_reverse, dim3(blocks), dim3(256), 0, s, g->kc_item, g->kc_items, g->kc_rec, g->bmoff, g->bmpool, g->hadj, g->kc_arena, nparts, part, bins, queue);
     ++*launches;
     return GMSX_OK;
 }
@@ -1811,7 +1833,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     }
     const int n_streams = [] { const char *e = opt("KC_STREAMS"); const int v = e ? std::atoi(e) : 4; return v < 1 ? 1 : v > 4 ? 4 : v; }();
     // the receivers' pass first (on the launch stream, ahead of the fork): the rows the pivots below copy instead of streaming their member
-    if (int rc = launch_kc_reverse(g, part, nparts, acc, launches)) return rc;
+    if (int rc = launch_kc_reverse(g, part, nparts, over, acc, launches)) return rc;
     const KcRev rv{g->kc_rel, g->kc_aoff, g->kc_arena};
     GMSX_HIP(hipEventRecord(ev_fork, s));
     for (int i = 0; i < kSides; ++i) GMSX_HIP(hipStreamWaitEvent(sides[i], ev_fork, 0));
@@ -1863,6 +1885,10 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             if (l_cnt[b] <= 0) continue;
             const int dmax = l_dmax[b], W = dmax / 32, WS = W + 1;
             const int threads = LV == 2 ? 1024 : 512;
+            // (Round 6 tried the other cut of a slab matrix — a CHUNK of 16 / 8 column words of every row in LDS and one lane per pair (i, j) as on the LDS
+            //  matrices, pairs enumerated from the slab into per-wave lists: bit-exact, and SLOWER — 270.7 against 249.5 ms for the d+ <= 2048 bin, 171.6 against
+            //  98.7 for d+ <= 4096 at scale 26 (profiles/r06/kc26_slab_chunks.txt).  The slab matrices are dense enough that the count is the AND + popcount
+            //  words themselves, and a lane-per-pair loop reads BOTH rows from LDS for every word where the band loop below holds row i in registers.)
             const int WT = dmax == 8192 ? 128 : dmax == 4096 ? 288 : 576;  // k = 4 row band: WT rows x (W+1) words of LDS (multiple of 32)
             size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(threads / 64) * 4 * W * 4;  // bitmap + prefix + row stage
             if (LV == 2) lds = std::max(lds, size_t(WT) * (W + 1) * 4 + size_t(threads / 64) * kKcRowList * sizeof(unsigned short));  // + the waves' neighbour lists (kc4_row_list)

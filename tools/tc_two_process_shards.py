@@ -20,9 +20,10 @@ if len(sys.argv) > 2:
         gs.tc_partial((p + 1) % n, n)
     except capi.GmsxError as e:
         refused = e.status == capi.ERR_INVALID
+    sharded_bytes = gs.device_bytes  # (before the k-clique call: its reverse-row lists join the graph's device bytes on first use)
     kc = gs.kclique_partial(4, (p + 1) % n, n)  # the base containers of a sharded upload are complete: any k-clique shard works
     print(json.dumps({"partial": part, "units": st["units"], "partial_sharded_upload": part_s, "units_sharded_upload": st_s["units"],
-                      "bytes_full": full_bytes, "bytes_sharded": gs.device_bytes, "other_shard_refused": refused, "kc4_other_shard": kc}))
+                      "bytes_full": full_bytes, "bytes_sharded": sharded_bytes, "other_shard_refused": refused, "kc4_other_shard": kc}))
     sys.exit(0)
 scale, nparts = int(sys.argv[1]), 3
 outs = [json.loads(subprocess.run([sys.executable, __file__, str(scale), str(p), str(nparts)], capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
