@@ -1752,10 +1752,9 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     return GMSX_OK;
 }
 // the receivers' pass of one call (inside the timed region, ahead of the pivots' kernels)
-static int launch_kc_reverse(const gmsx_graph *g, int part, int nparts, int64_t over, unsigned long long *acc, int *launches) {
+static int launch_kc_reverse(const gmsx_graph *g, int part, int nparts, int64_t over, unsigned long long *acc, int *launches, hipStream_t s) {
     if (!g->kc_rel || g->kc_items <= 0) return GMSX_OK;
     Ctx &c = ctx();
-    hipStream_t s = c.stream;
     KcBins bins;  // where the bins of launch_all start (its `range`): the first position whose d+ is <= the bin's width, not below the generic path's share
     {
         const int widths[KcBins::kN] = {8192, 4096, 2048, 1024, 704, 512, 384, 256, 192, 128, 96, 64, 32};
@@ -1821,9 +1820,9 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     // FOUR streams (round 3; two before): the bins differ in workgroup size and LDS footprint (one workgroup per CU for the 1024-wide
     // matrices … sixteen for the narrow ones), each leaves wave slots and LDS the others can use, and a bin's last workgroups no longer hold
     // up the next bin of the same stream.  GMSX_KC_STREAMS=1 … 4 (A/B).
-    constexpr int kSides = 3;
-    static hipStream_t sides[kSides] = {nullptr, nullptr, nullptr};
-    static hipEvent_t ev_fork = nullptr, ev_joins[kSides] = {nullptr, nullptr, nullptr};
+    constexpr int kSides = 4;  // three for the bins (round robin with the launch stream), the last for the wave kernel of d+ <= 32
+    static hipStream_t sides[kSides] = {nullptr, nullptr, nullptr, nullptr};
+    static hipEvent_t ev_fork = nullptr, ev_joins[kSides] = {nullptr, nullptr, nullptr, nullptr};
     if (!sides[0]) {
         for (int i = 0; i < kSides; ++i) {
             GMSX_HIP(hipStreamCreateWithFlags(&sides[i], hipStreamNonBlocking));
@@ -1832,12 +1831,22 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         GMSX_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     }
     const int n_streams = [] { const char *e = opt("KC_STREAMS"); const int v = e ? std::atoi(e) : 4; return v < 1 ? 1 : v > 4 ? 4 : v; }();
-    // the receivers' pass first (on the launch stream, ahead of the fork): the rows the pivots below copy instead of streaming their member
-    if (int rc = launch_kc_reverse(g, part, nparts, over, acc, launches)) return rc;
-    const KcRev rv{g->kc_rel, g->kc_aoff, g->kc_arena};
     GMSX_HIP(hipEventRecord(ev_fork, s));
     for (int i = 0; i < kSides; ++i) GMSX_HIP(hipStreamWaitEvent(sides[i], ev_fork, 0));
     hipStream_t side = n_streams > 1 ? sides[0] : s;
+    // The receivers' pass (the rows the pivots copy instead of streaming their member) and the wave kernel of d+ <= 32 — which reads none of those rows —
+    // start TOGETHER, each on a side stream of its own: both are latency-bound (60 - 70 % of their wave cycles waiting, 9 / 6 KB of LDS per workgroup),
+    // so they share the CUs instead of queueing (28.5 + 58 ms one after the other at scale 26).  Every other bin waits for the rows (ev_rev).
+    static hipEvent_t ev_rev = nullptr;
+    if (!ev_rev) GMSX_HIP(hipEventCreateWithFlags(&ev_rev, hipEventDisableTiming));
+    hipStream_t rev_stream = n_streams > 1 ? sides[kSides - 2] : s, small_stream = n_streams > 1 ? sides[kSides - 1] : s;
+    if (int rc = launch_kc_reverse(g, part, nparts, over, acc, launches, rev_stream)) return rc;
+    const KcRev rv{g->kc_rel, g->kc_aoff, g->kc_arena};
+    if (g->kc_rel && g->kc_items > 0 && n_streams > 1) {
+        GMSX_HIP(hipEventRecord(ev_rev, rev_stream));
+        GMSX_HIP(hipStreamWaitEvent(s, ev_rev, 0));
+        for (int i = 0; i + 2 < kSides; ++i) GMSX_HIP(hipStreamWaitEvent(sides[i], ev_rev, 0));
+    }
     int next_stream = 0;
     auto pick = [&]() -> hipStream_t {  // round robin over the launch stream and the side streams in use
         const int i = next_stream++ % n_streams;
@@ -1856,6 +1865,18 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
                 if (hipEventRecord(evs[i], sides[i]) == hipSuccess) (void)hipStreamWaitEvent(main, evs[i], 0);
         }
     } join{s, sides, ev_joins};
+    // S: k-1 <= d+ <= 32 — launched first, beside the receivers' pass (see above)
+    {
+        int64_t lo = 0, hi = 0;
+        if (int rc = range(0, 32, &lo, &hi)) return rc;
+        const int64_t cnt = part_count(lo, hi, nparts, part);
+        if (cnt > 0) {
+            const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, int64_t(cu) * 32);
+            hipLaunchKernelGGL((k_kc_small<LV, VTX>), dim3(unsigned(blocks)), dim3(256), 0, small_stream, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                               g->order, lo, hi, nparts, part, acc, g->oldid, vcounts);
+            ++*launches;
+        }
+    }
     const bool timing = opt("TIMING") != nullptr;  // the bins' pivot counts on stderr
     // L: 1024 < d+ <= 4096 (8192 for k <= 4), bit-matrix in a global slab per workgroup; one launch per row width (one / two / four words per lane)
     constexpr int NL = (LV <= 2) ? 3 : 2;
@@ -1950,18 +1971,6 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             else
                 hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 0>), dim3(unsigned(blocks)), dim3(threads), lds, n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
                                    g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv);
-            ++*launches;
-        }
-    }
-    // S: k-1 <= d+ <= 32
-    {
-        int64_t lo = 0, hi = 0;
-        if (int rc = range(0, 32, &lo, &hi)) return rc;
-        const int64_t cnt = part_count(lo, hi, nparts, part);
-        if (cnt > 0) {
-            const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, int64_t(cu) * 32);
-            hipLaunchKernelGGL((k_kc_small<LV, VTX>), dim3(unsigned(blocks)), dim3(256), 0, side, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
-                               g->order, lo, hi, nparts, part, acc, g->oldid, vcounts);
             ++*launches;
         }
     }
