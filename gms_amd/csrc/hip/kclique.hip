@@ -957,6 +957,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ unsigned long long red[16];
     __shared__ int wave_tot[16];
+    __shared__ int s_nfwd;  // members of the current pivot that are streamed forward (the list `fwd` below; LDS matrices only)
     constexpr int kKcFilterWords = 1024;
     __shared__ __attribute__((aligned(16))) uint32_t fltw[kKcFilterWords];  // the pivot's tail members, one bit per (id mod 32 x words): kc_tail_find
     const KcFilter flt{fltw, uint32_t(kKcFilterWords - 1)};
@@ -996,6 +997,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         if (flt_dirty)  // (uniform: the previous pivot of this workgroup had tail members, or this is its first)
             for (int i = tid; i < kKcFilterWords / 4; i += nthreads) reinterpret_cast<uint4 *>(fltw)[i] = zero4;
         flt_dirty = tc > 0;
+        if (tid == 0) s_nfwd = 0;
         if (!GLOBAL_ROWS)  // the slab variant writes every row word at its flush.  (Rounded up to 16 bytes: at most into the first words of the bitmap behind the rows — zero as well.)
             for (int i = tid; i < (d * WS + 3) / 4; i += nthreads) reinterpret_cast<uint4 *>(rows)[i] = zero4;
         __syncthreads();
@@ -1017,6 +1019,36 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
             }
         }
         __syncthreads();
+        // LDS matrices (round 6): FIRST the rows that need no stream — one THREAD per member copies its finished row from the reverse-row arena (a
+        // contiguous ⌈i / 32⌉ words; neighbouring members' rows are neighbours in the arena), all members of the pivot at once: one dependent chain
+        // rel -> row per pivot instead of one per trip of four members — and the members that ARE streamed are compacted into `fwd` (ballot + one
+        // LDS atomic per wave), so that the group loops below walk forward members only: a trip no longer idles three groups behind one stream, and a
+        // pivot whose hub edges were all handed over has no trips at all.  (The slab variant keeps deciding per trip: its rows pass through the stage.)
+        unsigned short *fwd = reinterpret_cast<unsigned short *>(smem + size_t(dmax) * WS + kBitmapWords + kBitmapWords / 2 + (VTX ? dmax : 0));
+        int nfwd = d;
+        if constexpr (!GLOBAL_ROWS && PIPE != 2) {
+            for (int i0 = 0; i0 < d; i0 += nthreads) {
+                const int i = i0 + tid;
+                bool fw = false;
+                if (i < d && i > 0) {  // (row 0 is empty: nobody is below the first member)
+                    const uint32_t r = (rel_u && i < hc) ? rel_u[i] : kKcRelForward;
+                    if (r != kKcRelForward) {
+                        const uint32_t *src = arow + r;
+                        uint32_t *dst = rows + size_t(i) * WS;
+                        for (int t = 0; t < ((i + 31) >> 5); ++t) dst[t] = src[t];
+                    } else {
+                        fw = true;
+                    }
+                }
+                const unsigned long long m = __ballot(fw);
+                int base = 0;
+                if (lane == 0 && m) base = atomicAdd(&s_nfwd, __popcll(m));
+                base = __shfl(base, 0);
+                if (fw) fwd[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+            }
+            __syncthreads();
+            nfwd = s_nfwd;
+        }
         // four rows per wave and trip, one per 16-lane group; the global-slab variant builds them in an LDS stage and
         // writes finished rows out with coalesced stores (no global atomics)
         {
@@ -1074,30 +1106,36 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                 const int istep = nwaves * 4;
                 // member i of the pivot: its rank id (an index past the row: vertex 0 — loaded, never used)
                 auto member = [&](int i) -> int32_t { return i < hc ? int32_t(hub_list[i]) : tail_list[i < d ? i - hc : 0]; };
-                // … and where its row comes from: a member whose row lies in the arena (or member 0: no row) walks the pipeline as rank id 0 — the top hub, d+ = 0:
-                // its extents are two cached loads and its "row" is empty, so every stage below is a no-op for it
-                auto relof = [&](int i) -> uint32_t { return (rel_u && i < hc) ? rel_u[i] : kKcRelForward; };
+                // SLAB matrices walk ALL members, four consecutive ones per trip (their rows leave through the stage together), and decide per member where the
+                // row comes from — a member whose row lies in the arena (or member 0: no row) walks the pipeline as rank id 0, the top hub, d+ = 0: its extents
+                // are two cached loads and its "row" is empty, so every stage is a no-op for it.  LDS matrices walk the forward list only (pass 1 above).
+                const int K = GLOBAL_ROWS ? d : nfwd;  // positions to walk
+                auto at = [&](int k) -> int { return GLOBAL_ROWS ? min(k, d - 1) : (nfwd > 0 ? int(fwd[min(k, nfwd - 1)]) : 0); };  // position -> member index (clamped)
+                auto relof = [&](int i) -> uint32_t { return (GLOBAL_ROWS && rel_u && i < hc) ? rel_u[i] : kKcRelForward; };
                 auto piped = [&](int i, uint32_t r) -> int32_t { return (r != kKcRelForward || i == 0) ? 0 : member(i); };
                 // the pipeline (kc_load_ext / kc_load_first above): ids three members ahead, extents two, first units one
-                const int ig = wave * 4 + grp;
-                uint32_t r0 = relof(min(ig, d - 1)), r1 = relof(min(ig + istep, d - 1)), r2 = relof(min(ig + 2 * istep, d - 1));
-                int32_t v0 = piped(min(ig, d - 1), r0), v1 = piped(min(ig + istep, d - 1), r1), v2 = piped(min(ig + 2 * istep, d - 1), r2);
+                const int kg = wave * 4 + grp;
+                int i_0 = at(kg), i_1 = at(kg + istep), i_2 = at(kg + 2 * istep);
+                uint32_t r0 = relof(i_0), r1 = relof(i_1), r2 = relof(i_2);
+                int32_t v0 = piped(i_0, r0), v1 = piped(i_1, r1), v2 = piped(i_2, r2);
                 KcExt e0 = kc_load_ext(hoff, toff, bmoff, dense_limit, v0), e1 = kc_load_ext(hoff, toff, bmoff, dense_limit, v1);
-                bool b0 = kc_use_bitset(v0, ig < hc, dense_limit, e0.hl);
+                bool b0 = kc_use_bitset(v0, i_0 < hc, dense_limit, e0.hl);
                 KcFirst f0 = kc_load_first(hadj, tadj, bmpool, e0, b0, b0 ? int(bitset_words(v0)) : 0, sub);
-                for (int i0 = wave * 4; i0 < d; i0 += istep) {
-                    const int i = i0 + grp;
+                for (int k0 = wave * 4; k0 < K; k0 += istep) {
+                    const int kf = k0 + grp;
+                    const int i = i_0;
                     // later stages first: they complete while member i is probed
-                    const uint32_t r3 = relof(min(i + 3 * istep, d - 1));
-                    const int32_t v3 = piped(min(i + 3 * istep, d - 1), r3);
+                    const int i_3 = at(kf + 3 * istep);
+                    const uint32_t r3 = relof(i_3);
+                    const int32_t v3 = piped(i_3, r3);
                     const KcExt e2 = kc_load_ext(hoff, toff, bmoff, dense_limit, v2);
-                    const bool b1 = kc_use_bitset(v1, i + istep < hc, dense_limit, e1.hl);
+                    const bool b1 = kc_use_bitset(v1, i_1 < hc, dense_limit, e1.hl);
                     const KcFirst f1 = kc_load_first(hadj, tadj, bmpool, e1, b1, b1 ? int(bitset_words(v1)) : 0, sub);
                     if (GLOBAL_ROWS) {
                         for (int t = lane; t < 4 * W; t += 64) stage[t] = 0;
                         __builtin_amdgcn_wave_barrier();
                     }
-                    if (i < d) {
+                    if (kf < K) {
                         const bool is_hub = i < hc;
                         uint32_t *orow = GLOBAL_ROWS ? stage + grp * W : rows + size_t(i) * WS;
 #ifdef GMSX_KC_NO_ROWS  // A/B build (wrong counts): the BUILD phase without its row streams
@@ -1109,12 +1147,13 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                     }
                     if (GLOBAL_ROWS) {
                         __builtin_amdgcn_wave_barrier();
-                        const int nr = min(4, d - i0);
-                        for (int t = lane; t < nr * W; t += 64) rows[size_t(i0 + t / W) * WS + t % W] = stage[t];
+                        const int nr = min(4, d - k0);
+                        for (int t = lane; t < nr * W; t += 64) rows[size_t(k0 + t / W) * WS + t % W] = stage[t];
                         __builtin_amdgcn_wave_barrier();
                     }
                     v0 = v1; v1 = v2; v2 = v3;
                     r0 = r1; r1 = r2; r2 = r3;
+                    i_0 = i_1; i_1 = i_2; i_2 = i_3;
                     e0 = e1; e1 = e2;
                     b0 = b1;
                     f0 = f1;
@@ -1122,17 +1161,16 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
             } else {
                 // small matrices, several workgroups per CU: the 30 registers of the pipeline would cost a third of the waves (80 -> 110
                 // VGPRs: 6 -> 4 per SIMD; measured 22.6 -> 25.9 ms at scale 22 with the pipeline everywhere) — member by member
-                for (int i0 = wave * 4; i0 < d; i0 += nwaves * 4) {
-                    const int i = i0 + grp;
-                    if (i < d && i > 0) {  // (nothing of N+(v_0) can be a member: row 0 is empty)
+                for (int k0 = wave * 4; k0 < nfwd; k0 += nwaves * 4) {
+                    const int kf = k0 + grp;
+                    if (kf < nfwd) {
+                        const int i = fwd[kf];
                         const bool is_hub = i < hc;
                         const int32_t v = is_hub ? int32_t(hub_list[i]) : tail_list[i - hc];
-                        const uint32_t r = (rel_u && is_hub) ? rel_u[i] : kKcRelForward;
 #ifdef GMSX_KC_NO_ROWS
                         if (v == -7) rows[size_t(i) * WS] = 1;
 #else
-                        if (r != kKcRelForward) kc_copy_row(arow + r, (i + 31) >> 5, rows + size_t(i) * WS, sub);
-                        else kc_build_member(hoff, hadj, toff, tadj, bmoff, bmpool, dense_limit, v, is_hub, hc, tail_list, tc, bm, pre, rows + size_t(i) * WS, sub, flt);
+                        kc_build_member(hoff, hadj, toff, tadj, bmoff, bmpool, dense_limit, v, is_hub, hc, tail_list, tc, bm, pre, rows + size_t(i) * WS, sub, flt);
 #endif
                     }
                 }
@@ -1956,7 +1994,8 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (timing && cnt > 0) std::fprintf(stderr, "[gmsx kclique] LDS bin d+ <= %d: %lld pivots\n", dmax, (long long)cnt);
         if (cnt > 0) {
-            const size_t lds = size_t(dmax) * WS * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + (VTX ? size_t(dmax) * 4 : 0);
+            const size_t lds = size_t(dmax) * WS * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + (VTX ? size_t(dmax) * 4 : 0) +
+                               ((size_t(dmax) * 2 + 15) & ~size_t(15));  // + the list of the members streamed forward (2 bytes each; no bin loses a workgroup per CU to it)
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
             const int threads = dmax >= 704 ? 1024 : dmax >= 384 ? 512 : 256;
             // (one 1024-thread workgroup per CU from d+ = 513 on: four waves per SIMD whatever the registers — the pipelined BUILD pays there)

@@ -6,7 +6,7 @@ TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --cpu-seconds 0 --check-scale 0 --ref-scale 0 --pmc 0 --side 0 $*"   # --pmc 0: no nested rocprofv3 children under the profiler
+ARGS="--steps 3 --warmup 1 --cpu-seconds 0 --check-scale 0 --ref-scale 0 --pmc 0 --side 0 --big 0 $*"   # --pmc 0: no nested rocprofv3 children under the profiler
 # the first pass leaves the generated graph as a .sg cache (bench.py default), the PMC passes load it
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc_fetch.err
