@@ -394,7 +394,9 @@ WORKLOADS = {
 ALG_BYTES_ARE = {
     "kc26": None,  # = kc4, set below
     "kc4": "per pivot (d+ >= 3) its own containers once + per member v the containers of N+(v) the BUILD reads (bitset words or 16-bit list, tail ids; one "
-           "4-byte gather per pair for d+ <= 32) + the slab matrices of pivots wider than 1024, written and read once; the COUNT runs on the bit-matrix in LDS",
+           "4-byte gather per pair for d+ <= 32) — or, for a hub member handed to its receiver (reverse rows), the 2 i bytes of the pivot's prefix below it + a "
+           "16-byte record + the row's ceil(i/32) words written and read back — + the slab matrices of pivots wider than 1024, written and read once; the COUNT "
+           "runs on the bit-matrix in LDS",
     "bk": "per start vertex the oriented rows of all its neighbours (what the builds walk: candidates -> Cadj, in-neighbours -> XT) + Cadj | XT of the start "
           "vertices built in the arena, once + one Cadj row (c/32 words) per search-tree node — the operand of cand.intersect(N(q)) (tomita.h:51-70); the Xf / XT "
           "words a node reads and the saved levels are not counted",

@@ -157,7 +157,9 @@ typedef struct gmsx_stats {
                                   16-byte units of bitset / 16-bit list / byte-delta for the hub part, 32-bit ids / 16-bit delta for the
                                   tail part) or 4 bytes per inverted gather.  No cache is assumed: the traffic a pass would cause if
                                   nothing were ever re-used on chip.  k-clique: every pivot's own containers once + per member the containers of
-                                  N+(v) the BUILD reads (bitset words or 16-bit list, tail ids; one 4-byte gather per pair for d+ <= 32) + the
+                                  N+(v) the BUILD reads (bitset words or 16-bit list, tail ids; one 4-byte gather per pair for d+ <= 32) — or, for a
+                                  hub member whose row the receivers' pass produced (round 6, kclique.hip: reverse rows), the 2 i bytes of the pivot's
+                                  prefix below it + its 16-byte record + its row of ceil(i/32) words written and read back — + the
                                   slab matrices of pivots wider than 1024, written and read once.  Bron-Kerbosch: per start vertex the oriented
                                   rows of all its neighbours (what the builds walk) + Cadj | XT of the start vertices built in the arena, once
                                   + one Cadj row (c / 32 words) per search-tree node — the operand of cand.intersect(N(q)), tomita.h:51-70.

@@ -1,5 +1,10 @@
 """GPU: the native RCCL path under the C-ABI (gmsx_comm_*) and the C++ driver's --gpus mode, on the one GPU a test box has:
-a 1-rank communicator runs the real ncclCommInitRank / ncclAllReduce(count=1, ncclUint64) code path."""
+a 1-rank communicator runs the real ncclCommInitRank / ncclAllReduce(count=1, ncclUint64) code path.
+
+(ADVICE r5 asked for a two-rank test whose peer dies BETWEEN init and the all-reduce.  It cannot run on a 1-GPU box: RCCL refuses a communicator with two
+ranks on one device, and gloo does not go through gmsx_comm_*.  What round 6 changed there — the all-reduce's host copies go through pinned words owned by
+the communicator, so neither copy can block before the bounded poll nor land in a caller's freed word after GMSX_ERR_TIMEOUT — is exercised by the 1-rank
+test below on every value pattern; the dead-peer path of the INIT, which needs no second device, is the third test.)"""
 import os
 import subprocess
 
