@@ -68,7 +68,15 @@ Args parse(int argc, char **argv) {
         else if (f == "-g" || f == "--gen") { if (!need(2)) break; a.gen = argv[++i]; a.scale = std::atoi(argv[++i]); }
         else if (f == "--deg") { if (!need(1)) break; a.deg = std::atoi(argv[++i]); }
         else if (f == "--gpus") { if (!need(1)) break; a.gpus = std::atoi(argv[++i]); if (a.gpus < 1 || a.gpus > 64) a.error = 100; }
-        else if (f == "-p" || f == "--param") {
+        else if (f == "--opt") {  // --opt NAME=VALUE -> gmsx_set_option (limits, kernel variants, diagnostics: include/gmsx.h); unknown names are refused
+            if (!need(1)) break;
+            const std::string kv = argv[++i];
+            const size_t eq = kv.find('=');
+            if (eq == std::string::npos || gmsx_set_option(kv.substr(0, eq).c_str(), kv.substr(eq + 1).c_str()) != GMSX_OK) {
+                std::fprintf(stderr, "gmsx_driver: --opt %s: not an option of this library (names: include/gmsx.h)\n", kv.c_str());
+                a.error = 100;
+            }
+        } else if (f == "-p" || f == "--param") {
             if (!need(1)) break;
             const std::string kv = argv[++i];
             if (kv.rfind("clique-size=", 0) == 0) a.clique_size = std::atoi(kv.c_str() + 12);
@@ -83,7 +91,7 @@ Args parse(int argc, char **argv) {
 
 void usage(const char *argv0) {
     std::printf("usage: %s <tc|vertex|kclique|bk> (-g kronecker|uniform <scale> [--deg d] | -f file.{el,sg}) [-v] [-n trials] [-t threads] "
-                "[-p clique-size=k] [--gpus N]\n", argv0);
+                "[-p clique-size=k] [--gpus N] [--opt NAME=VALUE ...]\n", argv0);
 }
 
 // ---- host-side verifiers: this driver's own plain loops over the host CSR (independent of the device kernels) ----------

@@ -30,6 +30,11 @@ def test_driver_builds_and_rejects_bad_usage(capi):
     assert os.path.exists(exe), "make -C gms_amd/csrc builds the driver"
     assert subprocess.run([exe]).returncode == 101                      # no graph given (cli/cli.h:131-133)
     assert subprocess.run([exe, "tc", "--bogus"]).returncode == 100     # unparsable flags (cli/cli.h:122-127)
+    # --opt NAME=VALUE is gmsx_set_option: the library takes no tuning from the environment, and a name it does not know is refused, not ignored
+    r = subprocess.run([exe, "tc", "-g", "kronecker", "6", "--opt", "NO_SUCH_OPTION=1"], capture_output=True, text=True)
+    assert r.returncode == 100 and "not an option" in r.stderr
+    r = subprocess.run([exe, "tc", "-g", "kronecker", "6", "--opt", "KC_REVERSE=0", "--opt", "TIMING=1"], capture_output=True, text=True)
+    assert r.returncode != 100, r.stderr   # accepted: the run itself then needs a device (or fails loudly without one)
 
 
 def _have_gpu():
