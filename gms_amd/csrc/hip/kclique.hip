@@ -45,6 +45,14 @@ struct KcRev {
     const uint32_t *arena;  // rows written by k_kc_reverse earlier in the same call
 };
 static constexpr uint32_t kKcRelForward = 0xffffffffu;
+// TRIANGULAR LDS matrix (round 6; k = 4, the bins of 512 < d+ <= 1472): row i is strictly below the diagonal, so it is stored with (i >> 5) + 1 words —
+// every word that can hold a column below i, and word j >> 5 of row j exists for the pair loops — at word offset Σ_{t<i} ((t >> 5) + 1).  Half the
+// LDS of the rectangular layout: two 1024-thread workgroups per CU up to d+ = 960, and a matrix in LDS (pair-list count) instead of a global slab
+// (row-band count) up to d+ = 1472.
+__device__ __host__ __forceinline__ uint32_t kc_tri_off(int i) {
+    const int q = i >> 5, r = i & 31;
+    return uint32_t((q + 1) * (16 * q + r));
+}
 // a finished row of `nwords` words from the arena into the (zeroed) matrix row, by the 16 lanes of a group
 __device__ __forceinline__ void kc_copy_row(const uint32_t *__restrict__ src, int nwords, uint32_t *orow, int sub) {
     for (int t = sub; t < nwords; t += 16) orow[t] = src[t];
@@ -653,7 +661,9 @@ __device__ __forceinline__ unsigned long long kc4_row_list(const uint32_t (&wt)[
 // COLUMN WORD w — rows 64 b … 64 b + 63 — writes their set bits (i, j) into its own LDS pair buffer behind one wave prefix sum, and then every lane
 // intersects one pair: all pairs of the task have j in word w, so every lane walks exactly the words 0 … w of its two rows (row j has no bit at or
 // above j) — full lanes, one trip count, no search.  A task with more pairs than the buffer holds is taken in runs of lanes.
+template <bool TRI = false>
 __device__ __forceinline__ unsigned long long kc4_count_pairs(const uint32_t *rows, int WS, int d, int W, uint32_t *wbuf, int cap, int *next_task, int lane) {
+    auto rowp = [&](int i) -> const uint32_t * { return TRI ? rows + kc_tri_off(i) : rows + size_t(i) * WS; };
     unsigned long long total = 0;
     d = uni32(d);
     // tasks = (column word w, block of 64 rows b) with rows beyond column 32 w, i.e. b >= w / 2 (the matrix is strictly lower triangular: the blocks
@@ -674,7 +684,7 @@ __device__ __forceinline__ unsigned long long kc4_count_pairs(const uint32_t *ro
         const int w = 2 * (tt - blk * (blk + 1) / 2) + (task & 1);
         if (w >= W) continue;  // (an odd number of column words)
         const int i = blk * 64 + lane;
-        uint32_t bits = (i < d && (w << 5) < i) ? rows[size_t(i) * WS + w] : 0u;
+        uint32_t bits = (i < d && (w << 5) < i) ? rowp(i)[w] : 0u;
 #ifdef GMSX_KC_CELLS_ONLY  // A/B build (wrong counts): the count phase reads the matrix cells and nothing else
         total += __popc(bits);
         bits = 0u;
@@ -709,7 +719,7 @@ __device__ __forceinline__ unsigned long long kc4_count_pairs(const uint32_t *ro
                 const int r = c0 + lane;
                 const bool act = r < npairs;
                 const uint32_t pr = wbuf[act ? r : 0];
-                const uint32_t *ri = rows + size_t(pr >> 16) * WS, *rj = rows + size_t(pr & 0xffffu) * WS;
+                const uint32_t *ri = rowp(int(pr >> 16)), *rj = rowp(int(pr & 0xffffu));
                 uint32_t acc = 0;
                 int q = 0;
 #ifdef GMSX_KC_NO_INNER
@@ -946,7 +956,8 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
 // (d <= 1024); true: in a per-workgroup global slab (d up to 64*32*WPL), workgroups walk their pivots with a grid stride.
 // dynamic LDS layout: [rows: dmax*WS u32 (LDS variant only)] [bm: 2048 u32] [pre: 2048 u16] [row stage: nwaves*4*W u32 (slab variant only)]
 // ---------------------------------------------------------------------------------------------
-template <int LV, int WPL, bool GLOBAL_ROWS, bool VTX, int PIPE = GLOBAL_ROWS ? 1 : 0 /* the BUILD: 0 member by member, 1 three-stage member pipeline, 2 step stream */>
+template <int LV, int WPL, bool GLOBAL_ROWS, bool VTX, int PIPE = GLOBAL_ROWS ? 1 : 0 /* the BUILD: 0 member by member, 1 three-stage member pipeline, 2 step stream */,
+          bool TRI = false /* LDS matrix stored triangularly (kc_tri_off; k = 4 only) */>
 __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                    const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                    const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
@@ -970,8 +981,11 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
     const int nthreads = int(blockDim.x), nwaves = nthreads >> 6;  // 256 … 1024 threads: big LDS bit-matrices leave one workgroup per CU
     // WS = row stride in words: W for the wave-cooperative recursion (lane = word index), W + 1 for the lane-per-pair
     // k = 4 count (random rows per lane: an odd stride spreads them over the LDS banks)
+    static_assert(!TRI || (LV == 2 && !GLOBAL_ROWS && !VTX && PIPE != 2), "the triangular layout serves the k = 4 count on LDS matrices");
+    const size_t mat_words = TRI ? size_t(kc_tri_off(dmax)) : size_t(dmax) * WS;  // words of the LDS matrix of this bin
     uint32_t *rows = GLOBAL_ROWS ? slabs + size_t(blockIdx.x) * size_t(dmax) * size_t(WS) : smem;
-    uint32_t *bm = GLOBAL_ROWS ? smem : smem + size_t(dmax) * WS;
+    uint32_t *bm = GLOBAL_ROWS ? smem : smem + mat_words;
+    auto rowp = [&](int i) -> uint32_t * { return TRI ? rows + kc_tri_off(i) : rows + size_t(i) * WS; };
     unsigned short *pre = reinterpret_cast<unsigned short *>(bm + kBitmapWords);
 
     unsigned long long cnt = 0;
@@ -999,7 +1013,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         flt_dirty = tc > 0;
         if (tid == 0) s_nfwd = 0;
         if (!GLOBAL_ROWS)  // the slab variant writes every row word at its flush.  (Rounded up to 16 bytes: at most into the first words of the bitmap behind the rows — zero as well.)
-            for (int i = tid; i < (d * WS + 3) / 4; i += nthreads) reinterpret_cast<uint4 *>(rows)[i] = zero4;
+            for (int i = tid; i < (int(TRI ? kc_tri_off(d) : uint32_t(d * WS)) + 3) / 4; i += nthreads) reinterpret_cast<uint4 *>(rows)[i] = zero4;
         __syncthreads();
         // the bitmap, and for every word that holds a member the local index of its first one — the exclusive prefix popcount a hit adds its rank
         // inside the word to.  The hub list is ascending, so that index is the position of the first member whose id falls into the word: written by
@@ -1024,7 +1038,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         // rel -> row per pivot instead of one per trip of four members — and the members that ARE streamed are compacted into `fwd` (ballot + one
         // LDS atomic per wave), so that the group loops below walk forward members only: a trip no longer idles three groups behind one stream, and a
         // pivot whose hub edges were all handed over has no trips at all.  (The slab variant keeps deciding per trip: its rows pass through the stage.)
-        unsigned short *fwd = reinterpret_cast<unsigned short *>(smem + size_t(dmax) * WS + kBitmapWords + kBitmapWords / 2 + (VTX ? dmax : 0));
+        unsigned short *fwd = reinterpret_cast<unsigned short *>(smem + mat_words + kBitmapWords + kBitmapWords / 2 + (VTX ? dmax : 0));
         int nfwd = d;
         if constexpr (!GLOBAL_ROWS && PIPE != 2) {
             for (int i0 = 0; i0 < d; i0 += nthreads) {
@@ -1034,7 +1048,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                     const uint32_t r = (rel_u && i < hc) ? rel_u[i] : kKcRelForward;
                     if (r != kKcRelForward) {
                         const uint32_t *src = arow + r;
-                        uint32_t *dst = rows + size_t(i) * WS;
+                        uint32_t *dst = rowp(i);
                         for (int t = 0; t < ((i + 31) >> 5); ++t) dst[t] = src[t];
                     } else {
                         fw = true;
@@ -1137,7 +1151,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                     }
                     if (kf < K) {
                         const bool is_hub = i < hc;
-                        uint32_t *orow = GLOBAL_ROWS ? stage + grp * W : rows + size_t(i) * WS;
+                        uint32_t *orow = GLOBAL_ROWS ? stage + grp * W : rowp(i);
 #ifdef GMSX_KC_NO_ROWS  // A/B build (wrong counts): the BUILD phase without its row streams
                         if (v0 == -7) orow[0] = 1;
 #else
@@ -1170,7 +1184,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
 #ifdef GMSX_KC_NO_ROWS
                         if (v == -7) rows[size_t(i) * WS] = 1;
 #else
-                        kc_build_member(hoff, hadj, toff, tadj, bmoff, bmpool, dense_limit, v, is_hub, hc, tail_list, tc, bm, pre, rows + size_t(i) * WS, sub, flt);
+                        kc_build_member(hoff, hadj, toff, tadj, bmoff, bmpool, dense_limit, v, is_hub, hc, tail_list, tc, bm, pre, rowp(i), sub, flt);
 #endif
                     }
                 }
@@ -1306,7 +1320,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         } else if (LV == 2 && kc4_pairs_enabled) {
             // k = 4 on an LDS matrix: pair lists in the dead bitmap / prefix area (12 KB), a share per wave (kc4_count_pairs)
             uint32_t *wbuf = bm + size_t(wave) * size_t((kBitmapWords + kBitmapWords / 2) / nwaves);
-            cnt += kc4_count_pairs(rows, WS, d, W, wbuf, (kBitmapWords + kBitmapWords / 2) / nwaves, &wave_tot[0], lane);
+            cnt += kc4_count_pairs<TRI>(rows, WS, d, W, wbuf, (kBitmapWords + kBitmapWords / 2) / nwaves, &wave_tot[0], lane);
         } else if (LV == 2 && W >= 22) {
             // k = 4, wide matrix in LDS: a single band (the whole matrix), one row per wave and trip.  (Below ~700 vertices
             // the per-row prefix / select overhead of kc4_row exceeds what its divergence-free inner loop saves.)
@@ -1625,8 +1639,8 @@ __global__ void k_kcr_items(int32_t H, const int64_t *__restrict__ roff, const i
 // Which shard a pivot belongs to: the pivots' kernels stride over the positions of THEIR BIN — position lo + q * nparts + part of the d+ order, lo = where the
 // bin starts (launch_all) — so the rule needs the bins' starts: lo[] ascending, 0 for "not yet reached".
 struct KcBins {
-    static constexpr int kN = 13;
-    int64_t lo[kN];
+    static constexpr int kN = 16;
+    int64_t lo[kN];  // unused slots: 0
     __device__ __forceinline__ int part_of(int64_t pos, int nparts) const {
         int64_t l = 0;
 #pragma unroll
@@ -1790,18 +1804,9 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     return GMSX_OK;
 }
 // the receivers' pass of one call (inside the timed region, ahead of the pivots' kernels)
-static int launch_kc_reverse(const gmsx_graph *g, int part, int nparts, int64_t over, unsigned long long *acc, int *launches, hipStream_t s) {
+static int launch_kc_reverse(const gmsx_graph *g, int part, int nparts, const KcBins &bins, unsigned long long *acc, int *launches, hipStream_t s) {
     if (!g->kc_rel || g->kc_items <= 0) return GMSX_OK;
     Ctx &c = ctx();
-    KcBins bins;  // where the bins of launch_all start (its `range`): the first position whose d+ is <= the bin's width, not below the generic path's share
-    {
-        const int widths[KcBins::kN] = {8192, 4096, 2048, 1024, 704, 512, 384, 256, 192, 128, 96, 64, 32};
-        for (int b = 0; b < KcBins::kN; ++b) {
-            int64_t lo = 0;
-            if (int rc = count_dplus_ge(g, widths[b] + 1, &lo)) return rc;
-            bins.lo[b] = std::max(lo, over);
-        }
-    }
     unsigned int *queue = reinterpret_cast<unsigned int *>(acc + (kAccSlots - 1) * kAccStride + 8);  // a spare word of the accumulator array (zeroed by the caller)
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
     const unsigned blocks = unsigned(std::min<int64_t>(g->kc_items, int64_t(cu) * 8));
@@ -1810,6 +1815,13 @@ static int launch_kc_reverse(const gmsx_graph *g, int part, int nparts, int64_t 
     return GMSX_OK;
 }
 
+// widths of the two triangular LDS bins (k = 4): the matrix of d+ <= 1472 and its bitmap / prefix / forward list fill one CU's LDS (153.6 of the 155 KB a
+// launch may ask for); two matrices of d+ <= 960 fit it together (2 x 78.0 KB with the static 4.3 KB each)
+static constexpr int kKcTriTop = 1472, kKcTriTwo = 960;  // (multiples of 32: W = dmax / 32 words)
+static bool kc_tri_enabled() {
+    const char *e = opt("KC_TRI");  // option: 0 = rectangular LDS matrices up to 1024 and the slab beyond, as in rounds 1-5 (A/B)
+    return !(e && std::atoi(e) == 0);
+}
 static bool stream_build_default(const gmsx_graph *g) {
     (void)g;
     return false;
@@ -1878,7 +1890,31 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     static hipEvent_t ev_rev = nullptr;
     if (!ev_rev) GMSX_HIP(hipEventCreateWithFlags(&ev_rev, hipEventDisableTiming));
     hipStream_t rev_stream = n_streams > 1 ? sides[kSides - 2] : s, small_stream = n_streams > 1 ? sides[kSides - 1] : s;
-    if (int rc = launch_kc_reverse(g, part, nparts, over, acc, launches, rev_stream)) return rc;
+    // the bins of this call: slab widths (each from half its width on), then the LDS-matrix widths, each from the next one on — and, for the receivers'
+    // pass, where each starts in the d+ order (`range` below): the shards of a bin are strides of ITS positions
+    // k = 4 (count only): the LDS matrices of 512 < d+ <= 1472 are stored TRIANGULARLY (kc_tri_off) — two 1024-thread workgroups per CU up to 960, and
+    // the pivots of 1024 < d+ <= 1472 (most of what used to be the first slab bin) count by pair lists in LDS instead of row bands over a global slab
+    const bool tri = LV == 2 && !VTX && kc_tri_enabled();
+    const int l_dmax[3] = {4096, 2048, 8192}, l_from[3] = {2048, tri ? kKcTriTop : 1024, 4096};  // slab bins: (from, dmax]
+    const int m_rect[] = {1024, 704, 640, 512, 384, 256, 192, 128, 96, 64, 32}, m_tri[] = {kKcTriTop, kKcTriTwo, 512, 384, 256, 192, 128, 96, 64, 32};
+    const int *m_dmax = tri ? m_tri : m_rect;  // LDS bins: (next entry, entry]; the last entry = lower end of the last bin
+    const int n_m = tri ? int(sizeof(m_tri) / sizeof(int)) : int(sizeof(m_rect) / sizeof(int));
+    KcBins bins;
+    {
+        int nb = 0;
+        for (int64_t &x : bins.lo) x = 0;
+        auto add = [&](int width) -> int {
+            int64_t lo = 0;
+            if (int rc = count_dplus_ge(g, width + 1, &lo)) return rc;
+            if (nb < KcBins::kN) bins.lo[nb++] = std::max(lo, over);
+            return GMSX_OK;
+        };
+        for (int w : l_dmax)
+            if (int rc = add(w)) return rc;
+        for (int b = 0; b < n_m; ++b)
+            if (int rc = add(m_dmax[b])) return rc;
+    }
+    if (int rc = launch_kc_reverse(g, part, nparts, bins, acc, launches, rev_stream)) return rc;
     const KcRev rv{g->kc_rel, g->kc_aoff, g->kc_arena};
     if (g->kc_rel && g->kc_items > 0 && n_streams > 1) {
         GMSX_HIP(hipEventRecord(ev_rev, rev_stream));
@@ -1920,9 +1956,8 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     constexpr int NL = (LV <= 2) ? 3 : 2;
     size_t slab_bytes[3] = {0, 0, 0};
     int64_t l_lo[3], l_hi[3], l_cnt[3] = {0, 0, 0}, l_blocks[3];
-    const int l_dmax[3] = {4096, 2048, 8192};
     for (int b = 0; b < NL; ++b) {
-        if (int rc = range(l_dmax[b] / 2, l_dmax[b], &l_lo[b], &l_hi[b])) return rc;
+        if (int rc = range(l_from[b], l_dmax[b], &l_lo[b], &l_hi[b])) return rc;
         l_cnt[b] = part_count(l_lo[b], l_hi[b], nparts, part);
         l_blocks[b] = std::min<int64_t>(l_cnt[b], cu);  // one workgroup per CU: the LDS tile / stage fills it
         if (timing && l_cnt[b] > 0) std::fprintf(stderr, "[gmsx kclique] slab bin d+ <= %d: %lld pivots\n", l_dmax[b], (long long)l_cnt[b]);
@@ -1969,6 +2004,8 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     static bool attr_set[kMaxK + 1] = {false};
     if (!attr_set[VTX ? kMaxK : LV]) {
         GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        if constexpr (LV == 2 && !VTX)
+            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 0>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
         GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 1>),
@@ -1986,22 +2023,26 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         if (const char *e = opt("KC_STREAM_BUILD")) return std::atoi(e) != 0;
         return stream_build_default(g);
     }();
-    const int m_dmax[] = {1024, 704, 512, 384, 256, 192, 128, 96, 64, 32};  // last entry = lower end of the last bin
-    for (int b = 0; b + 1 < int(sizeof(m_dmax) / sizeof(int)); ++b) {
+    for (int b = 0; b + 1 < n_m; ++b) {
         const int dmax = m_dmax[b], W = dmax / 32, WS = W | 1;  // odd stride: rows of one column spread over the LDS banks
+        const bool tri_bin = tri && dmax > 512;
         int64_t lo = 0, hi = 0;
         if (int rc = range(m_dmax[b + 1], dmax, &lo, &hi)) return rc;
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (timing && cnt > 0) std::fprintf(stderr, "[gmsx kclique] LDS bin d+ <= %d: %lld pivots\n", dmax, (long long)cnt);
         if (cnt > 0) {
-            const size_t lds = size_t(dmax) * WS * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + (VTX ? size_t(dmax) * 4 : 0) +
+            const size_t lds = (tri_bin ? size_t(kc_tri_off(dmax)) : size_t(dmax) * WS) * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + (VTX ? size_t(dmax) * 4 : 0) +
                                ((size_t(dmax) * 2 + 15) & ~size_t(15));  // + the list of the members streamed forward (2 bytes each; no bin loses a workgroup per CU to it)
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
-            const int threads = dmax >= 704 ? 1024 : dmax >= 384 ? 512 : 256;
+            const int threads = dmax >= 640 ? 1024 : dmax >= 384 ? 512 : 256;  // (d+ <= 640: TWO 1024-thread workgroups fit a CU — 53.8 KB of matrix each)
             // (one 1024-thread workgroup per CU from d+ = 513 on: four waves per SIMD whatever the registers — the pipelined BUILD pays there)
             // (the step-stream BUILD adds 256 descriptors to the dynamic LDS: where they no longer fit beside the matrix and the 4 KB static filter —
             // the d+ <= 1024 bin with per-vertex counts — the bin keeps its default BUILD instead of failing its launch: ADVICE r5)
-            if (stream_build && lds + 256 * sizeof(KcDesc) + 4096 <= size_t(155) * 1024)
+            if (tri_bin) {
+                if constexpr (LV == 2 && !VTX)
+                    hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 1, true>), dim3(unsigned(blocks)), dim3(1024), lds, n_streams > 2 ? pick() : s, g->hoff, g->hadj,
+                                       g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv);
+            } else if (stream_build && lds + 256 * sizeof(KcDesc) + 4096 <= size_t(155) * 1024)
                 hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 2>), dim3(unsigned(blocks)), dim3(threads), lds + 256 * sizeof(KcDesc), n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
                                    g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv);
             else if (threads == 1024 || pipe_all)
@@ -2028,7 +2069,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
 // bit-matrix to its global slab and reads it back once.  One wave per pivot.
 __global__ __launch_bounds__(256) void k_stat_kc_bytes(int64_t n_min, int nparts, int part, const int32_t *__restrict__ order, const int32_t *__restrict__ dplus,
                                                      const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff,
-                                                     const int32_t *__restrict__ tadj, int32_t dense_limit, const uint32_t *__restrict__ rel,
+                                                     const int32_t *__restrict__ tadj, int32_t dense_limit, const uint32_t *__restrict__ rel, int slab_from,
                                                      unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
@@ -2043,7 +2084,7 @@ __global__ __launch_bounds__(256) void k_stat_kc_bytes(int64_t n_min, int nparts
         const int tc = int(toff[u + 1] - tb), d = hc + tc;
         if (lane == 0) {
             b += 2ull * (unsigned long long)hc + 4ull * (unsigned long long)tc;
-            if (d > 1024) b += 2ull * (unsigned long long)d * (unsigned long long)((d + 31) / 32) * 4ull;
+            if (d > slab_from) b += 2ull * (unsigned long long)d * (unsigned long long)((d + 31) / 32) * 4ull;
         }
         for (int i = lane; i < d; i += 64) {
             const bool is_hub = i < hc;
@@ -2120,7 +2161,7 @@ static int kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uin
             GMSX_HIP(hipMemsetAsync(acc, 0, 8, s));
             const int cu = c.compute_units > 0 ? c.compute_units : 256;
             hipLaunchKernelGGL(k_stat_kc_bytes, dim3(unsigned(cu * 8)), dim3(256), 0, s, n_min, nparts, part, g->order, g->dplus, g->hoff, g->hadj, g->toff, g->tadj,
-                               g->dense_limit, g->kc_rel, acc);
+                               g->dense_limit, g->kc_rel, (k == 4 && kc_tri_enabled()) ? kKcTriTop : 1024, acc);
             GMSX_HIP(hipMemcpyAsync(&alg, acc, 8, hipMemcpyDeviceToHost, s));
             GMSX_HIP(hipStreamSynchronize(s));
         }

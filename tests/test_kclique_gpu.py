@@ -70,14 +70,24 @@ def test_partials_sum_to_total(gpu):
 def test_complete_graphs_exercise_every_bin(gpu):
     # K_n: C_k = C(n,k); d+ runs 0..n-1, so n = 40 / 300 / 1100 / 2300 cover the wave kernel, the LDS bit-matrix bins,
     # the global-slab kernel and its two-words-per-lane variant.  k! * C_k wraps mod 2^64 like the reference's size_t.
-    for n, ks in [(5, (3, 4, 5, 6)), (40, (3, 4, 5, 8, 10)), (300, (3, 4, 5)), (1100, (3, 4)), (2300, (3, 4))]:
+    # (round 6: for k = 4 the LDS matrices of 512 < d+ <= 1472 are triangular — n = 1100, 1600, 2300 put a pivot on every width of both triangular bins
+    #  and of the slab bins behind them; KC_TRI = 0 keeps the rectangular / slab split of rounds 1-5 covered)
+    for n, ks in [(5, (3, 4, 5, 6)), (40, (3, 4, 5, 8, 10)), (300, (3, 4, 5)), (1100, (3, 4)), (1600, (4,)), (2300, (3, 4))]:
         iu = np.triu_indices(n, 1)
-        g = gpu.DeviceGraph.from_csr(gpu.HostCSR.from_edges(iu[0].astype(np.int32), iu[1].astype(np.int32)))
-        for k in ks:
-            ordered, cliques = g.kclique_count(k)
-            assert cliques == math.comb(n, k), (n, k)
-            assert ordered == (math.comb(n, k) * math.factorial(k)) & U64
-        g.free()
+        csr = gpu.HostCSR.from_edges(iu[0].astype(np.int32), iu[1].astype(np.int32))
+        for tri in ((None, 0) if n >= 1100 else (None,)):
+            gpu.set_option("KC_TRI", tri)
+            try:
+                g = gpu.DeviceGraph.from_csr(csr)
+                for k in ks:
+                    ordered, cliques = g.kclique_count(k)
+                    assert cliques == math.comb(n, k), (n, k, tri)
+                    assert ordered == (math.comb(n, k) * math.factorial(k)) & U64
+                if n >= 1100:
+                    assert sum(g.kclique_partial(4, q, 3) for q in range(3)) == math.comb(n, 4)
+                g.free()
+            finally:
+                gpu.set_option("KC_TRI", None)
 
 
 def test_edge_cases_and_errors(gpu):
@@ -119,7 +129,8 @@ def test_dense_random_graph_large_out_degrees(gpu):
             continue
         S = Af[np.ix_(nb, nb)]
         k4 += int(round(float(np.einsum("ij,ij->", S @ S, S, dtype=np.float64)))) // 6  # triangles among the later neighbours of a
-    for hub_limit in (0, 900):
+    for hub_limit, tri_opt in ((0, None), (900, None), (900, 0)):
+        gpu.set_option("KC_TRI", tri_opt)
         g = gpu.DeviceGraph.from_csr(csr, flags=gpu.UPLOAD_DEFAULT | (hub_limit << 8))
         assert g.max_out_degree > 1024
         assert g.tc_total() == tri
@@ -129,6 +140,7 @@ def test_dense_random_graph_large_out_degrees(gpu):
         # per-vertex counts run on the same bit-matrices (row popcounts + column sums): counts[u] = Σ_v A²[u,v]·A[u,v]
         assert np.array_equal(g.tc_vertex_count2(), per_vertex)
         g.free()
+    gpu.set_option("KC_TRI", None)
 
 
 def test_out_degrees_above_4096(gpu, oracle):
