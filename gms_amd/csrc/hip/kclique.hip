@@ -238,16 +238,35 @@ __device__ __forceinline__ void kc_stream_tail_from(const int32_t *__restrict__ 
             const kc_u4u cur = p[k];
             const int jc = j + 64 * k, jn = jc + 64 * kKcDepth;
             p[k] = *reinterpret_cast<const kc_u4u *>(row + (jn < l ? jn : 0));
-            const int32_t ids[4] = {int32_t(cur.x), int32_t(cur.y), int32_t(cur.z), int32_t(cur.w)};
+            // the first filter bit of the unit's four ids TOGETHER (four LDS reads in flight, one wait), then only the ids that pass — well under 1 % —
+            // go on to the second bit and the search.  (Rounds 4-5 ran kc_tail_find id by id: four exec-masked blocks per unit, each with its own
+            // LDS round trip in front of a branch — the tail members' rows were the BUILD's most expensive bytes.)
+            const uint32_t ids[4] = {cur.x, cur.y, cur.z, cur.w};
+            uint32_t fw[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (jc + q < l) {
-                    const int t = kc_tail_find(flt, tail_list, tc, ids[q]);
+            for (int q = 0; q < 4; ++q) fw[q] = flt.w[(ids[q] >> 5) & flt.mask];
+            uint32_t pass = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pass |= ((fw[q] >> (ids[q] & 31u)) & 1u) << q;
+            const int nv = l - jc;  // ids of this unit that belong to the row (>= 1 here when jc < l)
+            pass = jc < l ? (nv >= 4 ? pass : (pass & ((1u << nv) - 1u))) : 0u;
+            while (pass) {
+                const int q = __ffs(pass) - 1;
+                pass &= pass - 1u;
+                const uint32_t id = q == 0 ? ids[0] : q == 1 ? ids[1] : q == 2 ? ids[2] : ids[3];
+                bool ok = true;
+                if (GMSX_KC_FILTER_BITS > 1) {
+                    const uint32_t b = kc_filter_bit2(id, flt.mask);
+                    ok = ((flt.w[b >> 5] >> (b & 31u)) & 1u) != 0u;
+                }
+                if (ok) {
+                    const int t = sorted_find(tail_list, tc, int32_t(id));
                     if (t >= 0) {
                         const int idx = hc + t;
                         atomicOr(&orow[idx >> 5], 1u << (idx & 31));
                     }
                 }
+            }
         }
     }
 }
@@ -521,18 +540,39 @@ __device__ __forceinline__ unsigned long long lane_enum(const uint32_t *rows, in
     return s;
 }
 
+// popc(x) + acc in ONE instruction: v_bcnt_u32_b32 has an accumulate operand, but the compiler re-associates a sum of popcounts into bcnt(x, 0) plus
+// v_add3 — a quarter more VALU instructions in the k = 4 count loops, which are bound by exactly those (round 6: and + bcnt per word, two chains)
+__device__ __forceinline__ uint32_t kc_popc_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
 // Σ_{q < nq} popc(word q of the row held one-word-per-lane in `wl`  &  rj[q]); nq is wave-uniform, four LDS reads in flight
 __device__ __forceinline__ uint32_t kc4_and_popc(uint32_t wl, const uint32_t *rj, int nq) {
-    uint32_t acc = 0;
+    uint32_t acc = 0, acc1 = 0;
     int q = 0;
+    for (; q + 8 <= nq; q += 8) {
+        const uint32_t b0 = rj[q], b1 = rj[q + 1], b2 = rj[q + 2], b3 = rj[q + 3], b4 = rj[q + 4], b5 = rj[q + 5], b6 = rj[q + 6], b7 = rj[q + 7];
+        acc = kc_popc_acc(uint32_t(__builtin_amdgcn_readlane(int(wl), q)) & b0, acc);
+        acc1 = kc_popc_acc(uint32_t(__builtin_amdgcn_readlane(int(wl), q + 1)) & b1, acc1);
+        acc = kc_popc_acc(uint32_t(__builtin_amdgcn_readlane(int(wl), q + 2)) & b2, acc);
+        acc1 = kc_popc_acc(uint32_t(__builtin_amdgcn_readlane(int(wl), q + 3)) & b3, acc1);
+        acc = kc_popc_acc(uint32_t(__builtin_amdgcn_readlane(int(wl), q + 4)) & b4, acc);
+        acc1 = kc_popc_acc(uint32_t(__builtin_amdgcn_readlane(int(wl), q + 5)) & b5, acc1);
+        acc = kc_popc_acc(uint32_t(__builtin_amdgcn_readlane(int(wl), q + 6)) & b6, acc);
+        acc1 = kc_popc_acc(uint32_t(__builtin_amdgcn_readlane(int(wl), q + 7)) & b7, acc1);
+    }
     for (; q + 4 <= nq; q += 4) {
         const uint32_t b0 = rj[q], b1 = rj[q + 1], b2 = rj[q + 2], b3 = rj[q + 3];
         const uint32_t a0 = uint32_t(__builtin_amdgcn_readlane(int(wl), q)), a1 = uint32_t(__builtin_amdgcn_readlane(int(wl), q + 1)),
                        a2 = uint32_t(__builtin_amdgcn_readlane(int(wl), q + 2)), a3 = uint32_t(__builtin_amdgcn_readlane(int(wl), q + 3));
-        acc += uint32_t(__popc(a0 & b0) + __popc(a1 & b1)) + uint32_t(__popc(a2 & b2) + __popc(a3 & b3));
+        acc = kc_popc_acc(a0 & b0, acc);
+        acc1 = kc_popc_acc(a1 & b1, acc1);
+        acc = kc_popc_acc(a2 & b2, acc);
+        acc1 = kc_popc_acc(a3 & b3, acc1);
     }
-    for (; q < nq; ++q) acc += uint32_t(__popc(uint32_t(__builtin_amdgcn_readlane(int(wl), q)) & rj[q]));
-    return acc;
+    for (; q < nq; ++q) acc = kc_popc_acc(uint32_t(__builtin_amdgcn_readlane(int(wl), q)) & rj[q], acc);
+    return acc + acc1;
 }
 
 // k = 4 count of one matrix row i, wave-cooperative:  Σ_{j ∈ rows[i], j in the band} popc(rows[i] & rows[j]).
@@ -726,13 +766,29 @@ __device__ __forceinline__ unsigned long long kc4_count_pairs(const uint32_t *ro
                 acc = (ri[0] ^ rj[0]) & 1u;
                 q = w + 1;
 #endif
+                uint32_t acc1 = 0;  // two chains of kc_popc_acc (and + bcnt per word: no separate adds)
+                for (; q + 8 <= w + 1; q += 8) {  // eight words per trip: the two address increments and the loop control once per 16 LDS words
+                    const uint32_t a0 = ri[q], a1 = ri[q + 1], a2 = ri[q + 2], a3 = ri[q + 3], a4 = ri[q + 4], a5 = ri[q + 5], a6 = ri[q + 6], a7 = ri[q + 7];
+                    const uint32_t b0 = rj[q], b1 = rj[q + 1], b2 = rj[q + 2], b3 = rj[q + 3], b4 = rj[q + 4], b5 = rj[q + 5], b6 = rj[q + 6], b7 = rj[q + 7];
+                    acc = kc_popc_acc(a0 & b0, acc);
+                    acc1 = kc_popc_acc(a1 & b1, acc1);
+                    acc = kc_popc_acc(a2 & b2, acc);
+                    acc1 = kc_popc_acc(a3 & b3, acc1);
+                    acc = kc_popc_acc(a4 & b4, acc);
+                    acc1 = kc_popc_acc(a5 & b5, acc1);
+                    acc = kc_popc_acc(a6 & b6, acc);
+                    acc1 = kc_popc_acc(a7 & b7, acc1);
+                }
                 for (; q + 4 <= w + 1; q += 4) {
                     const uint32_t a0 = ri[q], a1 = ri[q + 1], a2 = ri[q + 2], a3 = ri[q + 3];
                     const uint32_t b0 = rj[q], b1 = rj[q + 1], b2 = rj[q + 2], b3 = rj[q + 3];
-                    acc += uint32_t(__popc(a0 & b0) + __popc(a1 & b1)) + uint32_t(__popc(a2 & b2) + __popc(a3 & b3));
+                    acc = kc_popc_acc(a0 & b0, acc);
+                    acc1 = kc_popc_acc(a1 & b1, acc1);
+                    acc = kc_popc_acc(a2 & b2, acc);
+                    acc1 = kc_popc_acc(a3 & b3, acc1);
                 }
-                for (; q <= w; ++q) acc += uint32_t(__popc(ri[q] & rj[q]));
-                if (act) total += acc;
+                for (; q <= w; ++q) acc = kc_popc_acc(ri[q] & rj[q], acc);
+                if (act) total += acc + acc1;
             }
             __builtin_amdgcn_wave_barrier();
         }
