@@ -1010,7 +1010,8 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
 // ---------------------------------------------------------------------------------------------
 // M / L: workgroup per pivot.  W = words per bit row, WS = row stride.  GLOBAL_ROWS=false: bit-matrix in dynamic LDS
 // (d <= 1024); true: in a per-workgroup global slab (d up to 64*32*WPL), workgroups walk their pivots with a grid stride.
-// dynamic LDS layout: [rows: dmax*WS u32 (LDS variant only)] [bm: 2048 u32] [pre: 2048 u16] [row stage: nwaves*4*W u32 (slab variant only)]
+// LDS layout: LDS variants — static [bm: 2048 u32][pre: 2048 u16][filter: 1024 u32] at LDS address 0, dynamic [rows][col][fwd]; slab variants — static filter,
+// dynamic [bm: 2048 u32] [pre: 2048 u16] [row stage: nwaves*4*W u32]
 // ---------------------------------------------------------------------------------------------
 template <int LV, int WPL, bool GLOBAL_ROWS, bool VTX, int PIPE = GLOBAL_ROWS ? 1 : 0 /* the BUILD: 0 member by member, 1 three-stage member pipeline, 2 step stream */,
           bool TRI = false /* LDS matrix stored triangularly (kc_tri_off; k = 4 only) */>
@@ -1026,7 +1027,13 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
     __shared__ int wave_tot[16];
     __shared__ int s_nfwd;  // members of the current pivot that are streamed forward (the list `fwd` below; LDS matrices only)
     constexpr int kKcFilterWords = 1024;
-    __shared__ __attribute__((aligned(16))) uint32_t fltw[kKcFilterWords];  // the pivot's tail members, one bit per (id mod 32 x words): kc_tail_find
+    // LDS-matrix variants (round 6): bitmap, prefix counts and tail filter as ONE STATIC array — the only 16-byte aligned static of the kernel, so it is laid out
+    // at LDS address 0 and every probe's word address IS its ds_read address (the triangle kernels have always had this); as part of the dynamic LDS the
+    // bitmap's base had to be added to each of the eight word addresses of a streamed unit.  The slab variants keep the bitmap in the dynamic part: their
+    // k = 4 count reuses everything from the first dynamic word on as its row band, and 16 KB of static LDS beside that would not fit the CU.
+    constexpr int kStaticWords = GLOBAL_ROWS ? kKcFilterWords : kBitmapWords + kBitmapWords / 2 + kKcFilterWords;
+    __shared__ __attribute__((aligned(16))) uint32_t kc_fixed[kStaticWords];
+    uint32_t *fltw = GLOBAL_ROWS ? kc_fixed : kc_fixed + kBitmapWords + kBitmapWords / 2;  // the pivot's tail members, one bit per (id mod 32 x words): kc_tail_find
     const KcFilter flt{fltw, uint32_t(kKcFilterWords - 1)};
 #ifdef GMSX_KC_NO_PAIRS  // A/B build: round 4's k = 4 counts (kc4_row for wide matrices, one lane per matrix word for the others)
     constexpr bool kc4_pairs_enabled = false;
@@ -1040,7 +1047,8 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
     static_assert(!TRI || (LV == 2 && !GLOBAL_ROWS && !VTX && PIPE != 2), "the triangular layout serves the k = 4 count on LDS matrices");
     const size_t mat_words = TRI ? size_t(kc_tri_off(dmax)) : size_t(dmax) * WS;  // words of the LDS matrix of this bin
     uint32_t *rows = GLOBAL_ROWS ? slabs + size_t(blockIdx.x) * size_t(dmax) * size_t(WS) : smem;
-    uint32_t *bm = GLOBAL_ROWS ? smem : smem + mat_words;
+    uint32_t *bm = GLOBAL_ROWS ? smem : kc_fixed;
+    // dynamic LDS of the LDS-matrix variants: [rows: mat_words][column counters (VTX)][forward list / step-stream descriptors]
     auto rowp = [&](int i) -> uint32_t * { return TRI ? rows + kc_tri_off(i) : rows + size_t(i) * WS; };
     unsigned short *pre = reinterpret_cast<unsigned short *>(bm + kBitmapWords);
 
@@ -1094,7 +1102,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         // rel -> row per pivot instead of one per trip of four members — and the members that ARE streamed are compacted into `fwd` (ballot + one
         // LDS atomic per wave), so that the group loops below walk forward members only: a trip no longer idles three groups behind one stream, and a
         // pivot whose hub edges were all handed over has no trips at all.  (The slab variant keeps deciding per trip: its rows pass through the stage.)
-        unsigned short *fwd = reinterpret_cast<unsigned short *>(smem + mat_words + kBitmapWords + kBitmapWords / 2 + (VTX ? dmax : 0));
+        unsigned short *fwd = reinterpret_cast<unsigned short *>(smem + mat_words + (VTX ? dmax : 0));
         int nfwd = d;
         if constexpr (!GLOBAL_ROWS && PIPE != 2) {
             for (int i0 = 0; i0 < d; i0 += nthreads) {
@@ -1126,7 +1134,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
             uint32_t *stage = GLOBAL_ROWS ? reinterpret_cast<uint32_t *>(pre + kBitmapWords) + size_t(wave) * 4 * W : nullptr;
             if constexpr (PIPE == 2) {
                 // ---- mode 2: descriptors of up to 256 members at a time, then one step stream per group (KcStream above) ----
-                KcDesc *desc = reinterpret_cast<KcDesc *>(smem + size_t(dmax) * WS + kBitmapWords + kBitmapWords / 2 + (VTX ? dmax : 0));
+                KcDesc *desc = reinterpret_cast<KcDesc *>(smem + size_t(dmax) * WS + (VTX ? dmax : 0));
                 for (int base = 0; base < d; base += 256) {
                     const int nb = min(256, d - base);
                     if (tid < nb) {
@@ -1263,8 +1271,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
             // (u, v_i, v_j).  Column sums with byte-sliced counters: lane = word (32 columns), eight registers of four 8-bit
             // counters each, the rows split over the waves, flushed to LDS counters every 255 rows; then member t adds
             // its row popcount and its column sum to counts[v_t] (one global atomic), the pivot gets the number of bits.
-            uint32_t *col = GLOBAL_ROWS ? reinterpret_cast<uint32_t *>(pre + kBitmapWords) + size_t(nwaves) * 4 * W
-                                        : reinterpret_cast<uint32_t *>(pre + kBitmapWords);
+            uint32_t *col = GLOBAL_ROWS ? reinterpret_cast<uint32_t *>(pre + kBitmapWords) + size_t(nwaves) * 4 * W : smem + mat_words;
             __shared__ uint32_t piv_sum;
             for (int t = tid; t < d; t += nthreads) col[t] = 0;
             if (tid == 0) piv_sum = 0;
@@ -1873,6 +1880,8 @@ static int launch_kc_reverse(const gmsx_graph *g, int part, int nparts, const Kc
 
 // widths of the two triangular LDS bins (k = 4): the matrix of d+ <= 1472 and its bitmap / prefix / forward list fill one CU's LDS (153.6 of the 155 KB a
 // launch may ask for); two matrices of d+ <= 960 fit it together (2 x 78.0 KB with the static 4.3 KB each)
+// dynamic LDS the LDS-matrix variants may ask for: the CU's 160 KB minus their 16.2 KB of static LDS (bitmap + prefix counts + tail filter + reduction slots)
+static constexpr int kKcLdsDynMax = 143 * 1024;
 static constexpr int kKcTriTop = 1472, kKcTriTwo = 960;  // (multiples of 32: W = dmax / 32 words)
 static bool kc_tri_enabled() {
     const char *e = opt("KC_TRI");  // option: 0 = rectangular LDS matrices up to 1024 and the slab beyond, as in rounds 1-5 (A/B)
@@ -2059,13 +2068,13 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     // M: 32 < d+ <= 1024, bit-matrix in LDS; one launch per bin — the bins are cut where another workgroup fits a CU
     static bool attr_set[kMaxK + 1] = {false};
     if (!attr_set[VTX ? kMaxK : LV]) {
-        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+        GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kKcLdsDynMax));
         if constexpr (LV == 2 && !VTX)
-            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+            GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kKcLdsDynMax));
         GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 0>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kKcLdsDynMax));
         GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<LV, 1, false, VTX, 1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, kKcLdsDynMax));
         attr_set[VTX ? kMaxK : LV] = true;
     }
     // the pipelined BUILD (member id -> extents -> first units, three members deep) in the narrower bins too: GMSX_KC_PIPE_ALL = 1 always, 0 never, unset =
@@ -2087,7 +2096,8 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         const int64_t cnt = part_count(lo, hi, nparts, part);
         if (timing && cnt > 0) std::fprintf(stderr, "[gmsx kclique] LDS bin d+ <= %d: %lld pivots\n", dmax, (long long)cnt);
         if (cnt > 0) {
-            const size_t lds = (tri_bin ? size_t(kc_tri_off(dmax)) : size_t(dmax) * WS) * 4 + size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + (VTX ? size_t(dmax) * 4 : 0) +
+            // (the bitmap, the prefix counts and the tail filter — 16 KB — are static LDS of the LDS-matrix variants)
+            const size_t lds = (tri_bin ? size_t(kc_tri_off(dmax)) : size_t(dmax) * WS) * 4 + (VTX ? size_t(dmax) * 4 : 0) +
                                ((size_t(dmax) * 2 + 15) & ~size_t(15));  // + the list of the members streamed forward (2 bytes each; no bin loses a workgroup per CU to it)
             const int64_t blocks = std::min<int64_t>(cnt, int64_t(cu) * 64);
             const int threads = dmax >= 640 ? 1024 : dmax >= 384 ? 512 : 256;  // (d+ <= 640: TWO 1024-thread workgroups fit a CU — 53.8 KB of matrix each)
@@ -2098,7 +2108,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
                 if constexpr (LV == 2 && !VTX)
                     hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 1, true>), dim3(unsigned(blocks)), dim3(1024), lds, n_streams > 2 ? pick() : s, g->hoff, g->hadj,
                                        g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv);
-            } else if (stream_build && lds + 256 * sizeof(KcDesc) + 4096 <= size_t(155) * 1024)
+            } else if (stream_build && lds + 256 * sizeof(KcDesc) <= size_t(kKcLdsDynMax))
                 hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 2>), dim3(unsigned(blocks)), dim3(threads), lds + 256 * sizeof(KcDesc), n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
                                    g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv);
             else if (threads == 1024 || pipe_all)
