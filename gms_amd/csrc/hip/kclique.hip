@@ -15,6 +15,7 @@
 //      level — the reference's `isect.intersect(N(vi))` recursion with sets as d-bit vectors.  k = 4 on wide matrices
 //      runs wave-cooperatively with one neighbour j per lane (kc4_row), slab matrices band by band through LDS.
 #include "device_graph.hpp"
+#include "kc4_mfma.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -45,6 +46,13 @@ struct KcRev {
     const uint32_t *arena;  // rows written by k_kc_reverse earlier in the same call
 };
 static constexpr uint32_t kKcRelForward = 0xffffffffu;
+// EXPORT (round 6; k = 4): the BUILD leaves the finished matrix of the pivot at position q of its launch in a pool (slot q, row stride kc4m_stride(d) words,
+// d in dpool[q]) instead of counting it — the count of the launch's matrices is one k_kc4_mfma launch on the matrix cores (kc4_mfma.hpp).  pool == nullptr: off.
+struct KcExport {
+    uint32_t *pool;
+    int32_t *dpool;
+    unsigned long long slot_words;
+};
 // TRIANGULAR LDS matrix (round 6; k = 4, the bins of 512 < d+ <= 1472): row i is strictly below the diagonal, so it is stored with (i >> 5) + 1 words —
 // every word that can hold a column below i, and word j >> 5 of row j exists for the pair loops — at word offset Σ_{t<i} ((t >> 5) + 1).  Half the
 // LDS of the rectangular layout: two 1024-thread workgroups per CU up to d+ = 960, and a matrix in LDS (pair-list count) instead of a global slab
@@ -1021,7 +1029,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                                                    int32_t dense_limit, const int32_t *__restrict__ order, int64_t first, int64_t end,
                                                    int nparts, int part, int dmax, int W, int WS, int WT, uint32_t *__restrict__ slabs,
                                                    unsigned long long *__restrict__ acc, const int32_t *__restrict__ oldid,
-                                                   unsigned long long *__restrict__ vcounts, KcRev rv) {
+                                                   unsigned long long *__restrict__ vcounts, KcRev rv, KcExport ex) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     __shared__ unsigned long long red[16];
     __shared__ int wave_tot[16];
@@ -1046,6 +1054,8 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
     // k = 4 count (random rows per lane: an odd stride spreads them over the LDS banks)
     static_assert(!TRI || (LV == 2 && !GLOBAL_ROWS && !VTX && PIPE != 2), "the triangular layout serves the k = 4 count on LDS matrices");
     const size_t mat_words = TRI ? size_t(kc_tri_off(dmax)) : size_t(dmax) * WS;  // words of the LDS matrix of this bin
+    constexpr bool kCanExport = LV == 2 && !VTX && (GLOBAL_ROWS || TRI) && PIPE == 1;  // the variants whose k = 4 count can run on the matrix cores
+    const bool exporting = kCanExport && ex.pool != nullptr;  // (uniform)
     uint32_t *rows = GLOBAL_ROWS ? slabs + size_t(blockIdx.x) * size_t(dmax) * size_t(WS) : smem;
     uint32_t *bm = GLOBAL_ROWS ? smem : kc_fixed;
     // dynamic LDS of the LDS-matrix variants: [rows: mat_words][column counters (VTX)][forward list / step-stream descriptors]
@@ -1068,6 +1078,13 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         // reverse rows of this pivot's hub members (nullptr: none; ~0u per member: streamed forward)
         const uint32_t *rel_u = rv.rel ? rv.rel + hb : nullptr;
         const uint32_t *arow = rv.rel ? rv.arena + rv.aoff[u] : nullptr;
+        // slab rows: stride WSr, Wr words written per row.  EXPORT: the slab is slot q of the pool in the layout k_kc4_mfma reads (stride kc4m_stride(d) <= W)
+        int WSr = WS, Wr = W;
+        if constexpr (kCanExport && GLOBAL_ROWS)
+            if (exporting) {
+                WSr = Wr = kc4m_stride(d);
+                rows = ex.pool + size_t(q) * size_t(ex.slot_words);
+            }
         __syncthreads();  // previous pivot's counting is done
         // (16-byte stores: the clears are a quarter of the LDS instructions of a pivot of a few dozen members)
         const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
@@ -1226,7 +1243,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                     if (GLOBAL_ROWS) {
                         __builtin_amdgcn_wave_barrier();
                         const int nr = min(4, d - k0);
-                        for (int t = lane; t < nr * W; t += 64) rows[size_t(k0 + t / W) * WS + t % W] = stage[t];
+                        for (int t = lane; t < nr * Wr; t += 64) rows[size_t(k0 + t / Wr) * WSr + t % Wr] = stage[(t / Wr) * W + t % Wr];
                         __builtin_amdgcn_wave_barrier();
                     }
                     v0 = v1; v1 = v2; v2 = v3;
@@ -1262,6 +1279,28 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
             if (tid == 0) wave_tot[0] = 0;  // the ticket counter of kc4_count_pairs (the prefix phase is long done with wave_tot)
             __syncthreads();
         }
+        if constexpr (kCanExport)
+            if (exporting) {
+                // the count of this matrix is k_kc4_mfma's: an LDS matrix leaves for its pool slot (triangular -> rectangular rows of kc4m_stride(d) words,
+                // zero-filled, 16-byte stores); a slab matrix was built there
+                if constexpr (!GLOBAL_ROWS) {
+                    const int q4 = kc4m_stride(d) >> 2;  // 16-byte units per row
+                    uint4 *dst = reinterpret_cast<uint4 *>(ex.pool + size_t(q) * size_t(ex.slot_words));
+                    for (int x = tid; x < d * q4; x += nthreads) {
+                        const int i = x / q4, c = (x - i * q4) << 2;
+                        const uint32_t *src = rows + kc_tri_off(i);
+                        const int nw = (i >> 5) + 1;
+                        uint4 v;
+                        v.x = c < nw ? src[c] : 0u;
+                        v.y = c + 1 < nw ? src[c + 1] : 0u;
+                        v.z = c + 2 < nw ? src[c + 2] : 0u;
+                        v.w = c + 3 < nw ? src[c + 3] : 0u;
+                        dst[x] = v;
+                    }
+                }
+                if (tid == 0) ex.dpool[q] = d;
+                continue;
+            }
 #ifdef GMSX_KC_BUILD_ONLY  // A/B build: what the BUILD phase alone takes (k = 4, scale 22: 12.4 of 22.6 ms)
         if (true) {
         } else
@@ -1896,6 +1935,54 @@ static bool pipe_all_default(const gmsx_graph *g) {
     return false;
 }
 
+// The pool the exporting BUILD kernels leave their matrices in (KcExport) — allocated at the first k = 4 call and kept (option KC_POOL_MB, default 6 144: a
+// region per stream; a region is reused by the next chunk of the same stream, so stream order alone protects it), with the d's of a chunk's slots and the
+// tickets of the count launches behind it.
+struct KcPool {
+    uint32_t *base = nullptr;
+    size_t bytes = 0;
+    int32_t *dpool = nullptr;
+    int *tickets = nullptr;
+};
+static constexpr int kKcPoolRegions = 3, kKcChunkMax = 65536, kKcTickets = 8192;
+static KcPool &kc_pool() {
+    static KcPool p;
+    return p;
+}
+static int ensure_kc_pool() {
+    KcPool &p = kc_pool();
+    size_t want = size_t(6144) << 20;
+    if (const char *e = opt("KC_POOL_MB")) {
+        const long long v = std::atoll(e);
+        if (v >= 0) want = size_t(v) << 20;
+    }
+    if (p.base && p.bytes == want) return GMSX_OK;
+    if (p.base) {
+        GMSX_HIP(hipDeviceSynchronize());
+        (void)hipFree(p.base);
+        p.base = nullptr;
+        p.bytes = 0;
+    }
+    if (!p.dpool) {
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&p.dpool), sizeof(int32_t) * kKcPoolRegions * kKcChunkMax));
+        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&p.tickets), sizeof(int) * kKcTickets));
+    }
+    for (size_t b = want; b >= (size_t(96) << 20); b >>= 1) {  // (a smaller pool = more chunks; below 96 MB the bins keep their in-kernel counts)
+        void *q = nullptr;
+        if (hipMalloc(&q, b) == hipSuccess) {
+            p.base = static_cast<uint32_t *>(q);
+            p.bytes = b;
+            break;
+        }
+        (void)hipGetLastError();
+    }
+    return GMSX_OK;
+}
+static bool kc_mfma_enabled() {
+    const char *e = opt("KC_MFMA");  // option: 0 = the k = 4 count of every bin by AND + popcount inside the BUILD kernels, as before the matrix-core count (A/B)
+    return !(e && std::atoi(e) == 0);
+}
+
 template <int LV, bool VTX = false>
 static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long long *acc, int *launches, uint32_t **slab_out,
                       unsigned long long *vcounts = nullptr) {
@@ -2017,11 +2104,94 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         }
     }
     const bool timing = opt("TIMING") != nullptr;  // the bins' pivot counts on stderr
+    // k = 4 on the MATRIX CORES (round 6): the bins of d+ > 512 BUILD their matrices into a pool — chunk by chunk, a pool region and a stream per chunk in
+    // turn — and each chunk's count is one k_kc4_mfma launch behind its BUILD on the same stream (kc4_mfma.hpp): the BUILD of the next chunk (rows streamed
+    // from HBM: latency and bandwidth) runs beside the count of this one (matrix cores and VALU, operands from the L2).
+    bool exported_slab[3] = {false, false, false}, exported_tri = false;
+    if constexpr (LV == 2 && !VTX) {
+        if (kc_mfma_enabled()) {
+            if (int rc = ensure_kc_pool()) return rc;
+            KcPool &pool = kc_pool();
+            const int n_regions = std::min(n_streams, kKcPoolRegions);
+            const size_t region_words = pool.bytes / 4 / size_t(n_regions) & ~size_t(63);
+            static bool x_attr = false;
+            if (!x_attr) {
+                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 2, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 1, false, false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kKcLdsDynMax));
+                x_attr = true;
+            }
+            if (pool.base) GMSX_HIP(hipMemsetAsync(pool.tickets, 0, sizeof(int) * kKcTickets, s));
+            GMSX_HIP(hipEventRecord(ev_fork, s));  // (again: the side streams start behind the cleared tickets)
+            for (int i = 0; i < kSides; ++i) GMSX_HIP(hipStreamWaitEvent(sides[i], ev_fork, 0));
+            int chunk_seq = 0, n_tickets = 0;
+            const int mfma_grid = [] { const char *e = opt("KC_MFMA_GRID"); const int v = e ? std::atoi(e) : 1; return v < 1 ? 1 : v > 8 ? 8 : v; }();
+            // one bin (from, dmax]: slab variant WPL = 1 / 2 / 4 (dmax 2048 / 4096 / 8192) or the triangular LDS variant (WPL = 0)
+            auto export_bin = [&](int from, int dmax, int wpl, bool *done) -> int {
+                *done = false;
+                if (!pool.base) return GMSX_OK;
+                const size_t slot_words = size_t(dmax) * size_t(kc4m_stride(dmax));
+                const int64_t cap = std::min<int64_t>(int64_t(region_words / slot_words), kKcChunkMax);
+                if (cap < 1) return GMSX_OK;  // the pool cannot hold one matrix of this bin: it keeps its in-kernel count
+                int64_t lo = 0, hi = 0;
+                if (int rc = range(from, dmax, &lo, &hi)) return rc;
+                const int64_t cnt = part_count(lo, hi, nparts, part);
+                *done = true;
+                if (timing && cnt > 0) std::fprintf(stderr, "[gmsx kclique] matrix-core bin d+ <= %d: %lld pivots, %lld per chunk\n", dmax, (long long)cnt, (long long)cap);
+                const int W = dmax / 32;
+                for (int64_t q0 = 0; q0 < cnt; q0 += cap) {
+                    if (n_tickets >= kKcTickets) return GMSX_ERR_UNSUPPORTED;
+                    const int64_t nq = std::min(cap, cnt - q0);
+                    const int r = chunk_seq++ % n_regions;
+                    hipStream_t st = r == 0 ? s : sides[r - 1];
+                    const KcExport ex{pool.base + size_t(r) * region_words, pool.dpool + size_t(r) * kKcChunkMax, (unsigned long long)slot_words};
+                    const int64_t first = lo + q0 * nparts, end = std::min(hi, lo + (q0 + nq) * nparts);
+                    if (wpl > 0) {
+                        const size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(1024 / 64) * 4 * W * 4;  // bitmap + prefix + row stage
+                        const unsigned blocks = unsigned(std::min<int64_t>(nq, int64_t(cu)));  // (128 registers x 1024 threads: one workgroup per CU)
+                        if (wpl == 1)
+                            hipLaunchKernelGGL((k_kc_block<2, 1, true, false>), dim3(blocks), dim3(1024), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                                               g->dense_limit, g->order, first, end, nparts, part, dmax, W, W, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, ex);
+                        else if (wpl == 2)
+                            hipLaunchKernelGGL((k_kc_block<2, 2, true, false>), dim3(blocks), dim3(1024), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                                               g->dense_limit, g->order, first, end, nparts, part, dmax, W, W, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, ex);
+                        else
+                            hipLaunchKernelGGL((k_kc_block<2, 4, true, false>), dim3(blocks), dim3(1024), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                                               g->dense_limit, g->order, first, end, nparts, part, dmax, W, W, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, ex);
+                    } else {
+                        const size_t lds = size_t(kc_tri_off(dmax)) * 4 + ((size_t(dmax) * 2 + 15) & ~size_t(15));
+                        const unsigned blocks = unsigned(std::min<int64_t>(nq, int64_t(cu) * 64));
+                        hipLaunchKernelGGL((k_kc_block<2, 1, false, false, 1, true>), dim3(blocks), dim3(1024), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff,
+                                           g->bmpool, g->dense_limit, g->order, first, end, nparts, part, dmax, W, W | 1, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid,
+                                           vcounts, rv, ex);
+                    }
+                    const unsigned cgrid = unsigned(std::min<int64_t>(nq, int64_t(cu) * mfma_grid));
+                    hipLaunchKernelGGL((k_kc4_mfma<2, 512>), dim3(cgrid), dim3(512), 0, st, ex.pool, slot_words, ex.dpool, int(nq), pool.tickets + n_tickets, acc, kAccSlots,
+                                       kAccStride);
+                    ++n_tickets;
+                    *launches += 2;
+                }
+                return GMSX_OK;
+            };
+            if (int rc = export_bin(4096, 8192, 4, &exported_slab[2])) return rc;
+            if (int rc = export_bin(2048, 4096, 2, &exported_slab[0])) return rc;
+            if (int rc = export_bin(tri ? kKcTriTop : 1024, 2048, 1, &exported_slab[1])) return rc;
+            if (tri) {
+                bool a = false, b = false;
+                if (int rc = export_bin(kKcTriTwo, kKcTriTop, 0, &a)) return rc;
+                if (int rc = export_bin(512, kKcTriTwo, 0, &b)) return rc;
+                exported_tri = a && b;
+                if (a != b) return GMSX_ERR_KERNEL;  // (both bins have slots of at most 283 KB: a pool that holds one holds the other)
+            }
+        }
+    }
     // L: 1024 < d+ <= 4096 (8192 for k <= 4), bit-matrix in a global slab per workgroup; one launch per row width (one / two / four words per lane)
     constexpr int NL = (LV <= 2) ? 3 : 2;
     size_t slab_bytes[3] = {0, 0, 0};
     int64_t l_lo[3], l_hi[3], l_cnt[3] = {0, 0, 0}, l_blocks[3];
     for (int b = 0; b < NL; ++b) {
+        if (exported_slab[b]) continue;
         if (int rc = range(l_from[b], l_dmax[b], &l_lo[b], &l_hi[b])) return rc;
         l_cnt[b] = part_count(l_lo[b], l_hi[b], nparts, part);
         l_blocks[b] = std::min<int64_t>(l_cnt[b], cu);  // one workgroup per CU: the LDS tile / stage fills it
@@ -2055,13 +2225,13 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             if (b == 2) {
                 if constexpr (LV <= 2)
                     hipLaunchKernelGGL((k_kc_block<LV, 4, true, VTX>), dim3(unsigned(l_blocks[b])), dim3(threads), lds, s, g->hoff, g->hadj, g->toff, g->tadj,
-                                       g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc, g->oldid, vcounts, rv);
+                                       g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc, g->oldid, vcounts, rv, KcExport{nullptr, nullptr, 0ull});
             } else if (b == 0)
                 hipLaunchKernelGGL((k_kc_block<LV, 2, true, VTX>), dim3(unsigned(l_blocks[b])), dim3(threads), lds, s, g->hoff, g->hadj, g->toff, g->tadj,
-                                   g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc, g->oldid, vcounts, rv);
+                                   g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc, g->oldid, vcounts, rv, KcExport{nullptr, nullptr, 0ull});
             else
                 hipLaunchKernelGGL((k_kc_block<LV, 1, true, VTX>), dim3(unsigned(l_blocks[b])), dim3(threads), lds, s, g->hoff, g->hadj, g->toff, g->tadj,
-                                   g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc, g->oldid, vcounts, rv);
+                                   g->bmoff, g->bmpool, g->dense_limit, g->order, l_lo[b], l_hi[b], nparts, part, dmax, W, WS, WT, slabs, acc, g->oldid, vcounts, rv, KcExport{nullptr, nullptr, 0ull});
             ++*launches;
         }
     }
@@ -2091,6 +2261,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     for (int b = 0; b + 1 < n_m; ++b) {
         const int dmax = m_dmax[b], W = dmax / 32, WS = W | 1;  // odd stride: rows of one column spread over the LDS banks
         const bool tri_bin = tri && dmax > 512;
+        if (tri_bin && exported_tri) continue;
         int64_t lo = 0, hi = 0;
         if (int rc = range(m_dmax[b + 1], dmax, &lo, &hi)) return rc;
         const int64_t cnt = part_count(lo, hi, nparts, part);
@@ -2107,16 +2278,16 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             if (tri_bin) {
                 if constexpr (LV == 2 && !VTX)
                     hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 1, true>), dim3(unsigned(blocks)), dim3(1024), lds, n_streams > 2 ? pick() : s, g->hoff, g->hadj,
-                                       g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv);
+                                       g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, KcExport{nullptr, nullptr, 0ull});
             } else if (stream_build && lds + 256 * sizeof(KcDesc) <= size_t(kKcLdsDynMax))
                 hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 2>), dim3(unsigned(blocks)), dim3(threads), lds + 256 * sizeof(KcDesc), n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
-                                   g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv);
+                                   g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, KcExport{nullptr, nullptr, 0ull});
             else if (threads == 1024 || pipe_all)
                 hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 1>), dim3(unsigned(blocks)), dim3(threads), lds, n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
-                                   g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv);
+                                   g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, KcExport{nullptr, nullptr, 0ull});
             else
                 hipLaunchKernelGGL((k_kc_block<LV, 1, false, VTX, 0>), dim3(unsigned(blocks)), dim3(threads), lds, n_streams > 2 ? pick() : (dmax >= 704 ? s : side), g->hoff, g->hadj,
-                                   g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv);
+                                   g->toff, g->tadj, g->bmoff, g->bmpool, g->dense_limit, g->order, lo, hi, nparts, part, dmax, W, WS, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, KcExport{nullptr, nullptr, 0ull});
             ++*launches;
         }
     }
@@ -2131,8 +2302,8 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
 // gmsx_stats.stream_bytes of a k-clique call: the ALGORITHMIC bytes of this formulation, no cache assumed — per pivot u of the shard (d+ >= k - 1; position in
 // the d+ order ≡ part mod nparts) its own containers once and, per member v, the containers of N+(v) the BUILD reads: the hub part as bitset words or
 // 16-bit list, whichever kc_use_bitset picks (nothing when the pivot has no hub member), the tail part (4 bytes per id) when v is a tail member and the pivot
-// has tail members; pivots of d+ <= 32 read a hub member's row as one 4-byte gather per lower hub member instead; a pivot wider than 1024 writes its d x d
-// bit-matrix to its global slab and reads it back once.  One wave per pivot.
+// has tail members; pivots of d+ <= 32 read a hub member's row as one 4-byte gather per lower hub member instead; a pivot wider than `slab_from` (1024; k = 4: 1472,
+// or 512 when the count runs on the matrix cores) writes its d x d bit-matrix to global memory and reads it back once.  One wave per pivot.
 __global__ __launch_bounds__(256) void k_stat_kc_bytes(int64_t n_min, int nparts, int part, const int32_t *__restrict__ order, const int32_t *__restrict__ dplus,
                                                      const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff,
                                                      const int32_t *__restrict__ tadj, int32_t dense_limit, const uint32_t *__restrict__ rel, int slab_from,
@@ -2227,7 +2398,7 @@ static int kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uin
             GMSX_HIP(hipMemsetAsync(acc, 0, 8, s));
             const int cu = c.compute_units > 0 ? c.compute_units : 256;
             hipLaunchKernelGGL(k_stat_kc_bytes, dim3(unsigned(cu * 8)), dim3(256), 0, s, n_min, nparts, part, g->order, g->dplus, g->hoff, g->hadj, g->toff, g->tadj,
-                               g->dense_limit, g->kc_rel, (k == 4 && kc_tri_enabled()) ? kKcTriTop : 1024, acc);
+                               g->dense_limit, g->kc_rel, (k == 4 && kc_tri_enabled()) ? ((kc_mfma_enabled() && kc_pool().base) ? 512 : kKcTriTop) : 1024, acc);
             GMSX_HIP(hipMemcpyAsync(&alg, acc, 8, hipMemcpyDeviceToHost, s));
             GMSX_HIP(hipStreamSynchronize(s));
         }
