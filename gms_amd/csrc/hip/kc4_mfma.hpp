@@ -99,21 +99,21 @@ struct Kc4mBlock {
                 }
         };
         // the short tail's words are on their way from the start
-        const uint32_t tb = uint32_t(nfull) * 8u - 4u * h;  // (offJ / offI carry + 4 h for the 16-byte chunks)
+        const uint32_t tb = uint32_t(nfull) * 8u - 4u * h;  // (offJ / offI carry + 4 h for the 16-byte chunks; the sums below wrap in 32 bits BEFORE they meet the pointer)
         uint2 t2j[T], t2i[T];
         uint32_t t1j[T], t1i[T];
         if (nw & 4) {
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                t2j[t] = *reinterpret_cast<const uint2 *>(m + offJ[t] + tb + 2u * h);
-                t2i[t] = *reinterpret_cast<const uint2 *>(m + offI[t] + tb + 2u * h);
+                t2j[t] = *reinterpret_cast<const uint2 *>(m + (offJ[t] + tb + 2u * h));
+                t2i[t] = *reinterpret_cast<const uint2 *>(m + (offI[t] + tb + 2u * h));
             }
         }
         if (nw & 2) {
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                t1j[t] = m[offJ[t] + tb + (nw & 4) + h];
-                t1i[t] = m[offI[t] + tb + (nw & 4) + h];
+                t1j[t] = m[uint32_t(offJ[t] + tb + uint32_t(nw & 4) + h)];
+                t1i[t] = m[uint32_t(offI[t] + tb + uint32_t(nw & 4) + h)];
             }
         }
         if (nfull > 0) {
@@ -205,7 +205,12 @@ struct Kc4mBlock {
     }
 };
 
-// One workgroup (NT / 64 waves) per matrix at a time, matrices from a global ticket, the blocks of a matrix from a ticket in LDS (far blocks first: the long ones).
+// One workgroup per matrix at a time, matrices from a global ticket, the blocks of a matrix from a ticket in LDS (far blocks first: the long ones).  NT = 1 024
+// (four waves per SIMD at 128 registers): the block loop waits on its fragment loads — without the mask epilogue or without the expansions it takes the same
+// time (tools/probes/kc4_mfma_probe.hip) — and more waves hide more of that; 512 threads: +5 … 10 %.
+// (Measured and dropped: the waves of an XCD on ONE matrix — group = HW_REG_XCC_ID, tasks (matrix, block) as tickets of a per-group counter over prefix sums of
+// the matrices' block counts, so that an XCD's L2 holds the matrix all its waves re-read — 0.93 against 0.81 ms for 1 024 matrices of d+ = 1 800 even with eight
+// tickets per atomic: a returning atomic on one address completes every ~11 ns chip-wide, and the fragment loads were no faster from the nearer cache.)
 template <int T, int NT, int DBG = 0>
 __global__ __launch_bounds__(NT) void k_kc4_mfma(const uint32_t *__restrict__ pool, size_t slot_words, const int32_t *__restrict__ dpool, int nmat,
                                                 int *__restrict__ ticket, unsigned long long *__restrict__ acc, int acc_slots, int acc_stride) {

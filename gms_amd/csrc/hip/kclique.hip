@@ -1949,14 +1949,19 @@ static KcPool &kc_pool() {
     static KcPool p;
     return p;
 }
-static int ensure_kc_pool() {
+// `needed`: what this call's matrices would take in one piece; the pool is min(needed, default) — or exactly KC_POOL_MB — and only ever grows
+static int ensure_kc_pool(size_t needed) {
     KcPool &p = kc_pool();
-    size_t want = size_t(6144) << 20;
+    size_t want = std::min(size_t(6144) << 20, std::max(needed, size_t(96) << 20));
+    bool exact = false;
     if (const char *e = opt("KC_POOL_MB")) {
         const long long v = std::atoll(e);
-        if (v >= 0) want = size_t(v) << 20;
+        if (v >= 0) {
+            want = size_t(v) << 20;
+            exact = true;
+        }
     }
-    if (p.base && p.bytes == want) return GMSX_OK;
+    if (p.base && (exact ? p.bytes == want : p.bytes >= want)) return GMSX_OK;
     if (p.base) {
         GMSX_HIP(hipDeviceSynchronize());
         (void)hipFree(p.base);
@@ -2109,8 +2114,18 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
     // from HBM: latency and bandwidth) runs beside the count of this one (matrix cores and VALU, operands from the L2).
     bool exported_slab[3] = {false, false, false}, exported_tri = false;
     if constexpr (LV == 2 && !VTX) {
+        // (a graph without a pivot wider than 512 allocates nothing)
+        size_t needed = 0;
         if (kc_mfma_enabled()) {
-            if (int rc = ensure_kc_pool()) return rc;
+            const int froms[5] = {4096, 2048, tri ? kKcTriTop : 1024, kKcTriTwo, 512}, tos[5] = {8192, 4096, 2048, kKcTriTop, kKcTriTwo};
+            for (int b = 0; b < (tri ? 5 : 3); ++b) {
+                int64_t lo = 0, hi = 0;
+                if (int rc = range(froms[b], tos[b], &lo, &hi)) return rc;
+                needed += size_t(part_count(lo, hi, nparts, part)) * size_t(tos[b]) * size_t(kc4m_stride(tos[b])) * 4;
+            }
+        }
+        if (needed > 0) {
+            if (int rc = ensure_kc_pool(needed + (size_t(1) << 20))) return rc;
             KcPool &pool = kc_pool();
             const int n_regions = std::min(n_streams, kKcPoolRegions);
             const size_t region_words = pool.bytes / 4 / size_t(n_regions) & ~size_t(63);
@@ -2148,27 +2163,34 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
                     const KcExport ex{pool.base + size_t(r) * region_words, pool.dpool + size_t(r) * kKcChunkMax, (unsigned long long)slot_words};
                     const int64_t first = lo + q0 * nparts, end = std::min(hi, lo + (q0 + nq) * nparts);
                     if (wpl > 0) {
-                        const size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(1024 / 64) * 4 * W * 4;  // bitmap + prefix + row stage
+                        const int slab_threads = [] { const char *e = opt("KC_SLAB_THREADS"); const int v = e ? std::atoi(e) : 1024; return (v == 512 || v == 768) ? v : 1024; }();
+                        const size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(slab_threads / 64) * 4 * W * 4;  // bitmap + prefix + row stage
                         const unsigned blocks = unsigned(std::min<int64_t>(nq, int64_t(cu)));  // (128 registers x 1024 threads: one workgroup per CU)
                         if (wpl == 1)
-                            hipLaunchKernelGGL((k_kc_block<2, 1, true, false>), dim3(blocks), dim3(1024), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                            hipLaunchKernelGGL((k_kc_block<2, 1, true, false>), dim3(blocks), dim3(slab_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
                                                g->dense_limit, g->order, first, end, nparts, part, dmax, W, W, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, ex);
                         else if (wpl == 2)
-                            hipLaunchKernelGGL((k_kc_block<2, 2, true, false>), dim3(blocks), dim3(1024), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                            hipLaunchKernelGGL((k_kc_block<2, 2, true, false>), dim3(blocks), dim3(slab_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
                                                g->dense_limit, g->order, first, end, nparts, part, dmax, W, W, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, ex);
                         else
-                            hipLaunchKernelGGL((k_kc_block<2, 4, true, false>), dim3(blocks), dim3(1024), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                            hipLaunchKernelGGL((k_kc_block<2, 4, true, false>), dim3(blocks), dim3(slab_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
                                                g->dense_limit, g->order, first, end, nparts, part, dmax, W, W, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, ex);
                     } else {
                         const size_t lds = size_t(kc_tri_off(dmax)) * 4 + ((size_t(dmax) * 2 + 15) & ~size_t(15));
                         const unsigned blocks = unsigned(std::min<int64_t>(nq, int64_t(cu) * 64));
-                        hipLaunchKernelGGL((k_kc_block<2, 1, false, false, 1, true>), dim3(blocks), dim3(1024), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff,
+                        const int tri_threads = [&] { const char *e = opt("KC_TRI_THREADS"); const int v = e ? std::atoi(e) : 1024; return (v == 256 || v == 512) && dmax <= kKcTriTwo ? v : 1024; }();
+                        hipLaunchKernelGGL((k_kc_block<2, 1, false, false, 1, true>), dim3(blocks), dim3(tri_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff,
                                            g->bmpool, g->dense_limit, g->order, first, end, nparts, part, dmax, W, W | 1, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid,
                                            vcounts, rv, ex);
                     }
                     const unsigned cgrid = unsigned(std::min<int64_t>(nq, int64_t(cu) * mfma_grid));
-                    hipLaunchKernelGGL((k_kc4_mfma<2, 512>), dim3(cgrid), dim3(512), 0, st, ex.pool, slot_words, ex.dpool, int(nq), pool.tickets + n_tickets, acc, kAccSlots,
-                                       kAccStride);
+                    const int mfma_nt = [] { const char *e = opt("KC_MFMA_NT"); return e ? std::atoi(e) : 1024; }();
+                    if (mfma_nt == 256)
+                        hipLaunchKernelGGL((k_kc4_mfma<2, 256>), dim3(cgrid), dim3(256), 0, st, ex.pool, slot_words, ex.dpool, int(nq), pool.tickets + n_tickets, acc, kAccSlots, kAccStride);
+                    else if (mfma_nt == 512)
+                        hipLaunchKernelGGL((k_kc4_mfma<2, 512>), dim3(cgrid), dim3(512), 0, st, ex.pool, slot_words, ex.dpool, int(nq), pool.tickets + n_tickets, acc, kAccSlots, kAccStride);
+                    else
+                        hipLaunchKernelGGL((k_kc4_mfma<2, 1024>), dim3(cgrid), dim3(1024), 0, st, ex.pool, slot_words, ex.dpool, int(nq), pool.tickets + n_tickets, acc, kAccSlots, kAccStride);
                     ++n_tickets;
                     *launches += 2;
                 }

@@ -143,6 +143,51 @@ def test_dense_random_graph_large_out_degrees(gpu):
     gpu.set_option("KC_TRI", None)
 
 
+def test_matrix_core_count_equals_popcount_count(gpu):
+    """k = 4 on the matrix cores (round 6, kc4_mfma.hpp: the pivots of d+ > 512 leave their bit matrices in a pool, k_kc4_mfma counts them as a masked
+    bit-GEMM) against the AND + popcount count inside the BUILD kernels (KC_MFMA = 0), against a closed form, with a pool so small that every bin is cut
+    into many chunks, on one stream, and shard by shard.  Complete multipartite graph: a 4-clique takes one vertex from each of four parts, so
+    C_4 = e_4(part sizes); the members of a pivot are NOT a clique (no edges inside a part), d+ runs up to n - |largest part| = 2 500: both triangular
+    LDS bins and the slab bins of 2 048 and 4 096.  G(n, 0.6) adds irregular rows."""
+    import itertools
+    parts = [800, 700, 600, 500, 400, 300]
+    starts = np.concatenate([[0], np.cumsum(parts)])
+    n = int(starts[-1])
+    part_of = np.repeat(np.arange(len(parts)), parts)
+    iu = np.triu_indices(n, 1)
+    keep = part_of[iu[0]] != part_of[iu[1]]
+    csr_mp = gpu.HostCSR.from_edges(iu[0][keep].astype(np.int32), iu[1][keep].astype(np.int32))
+    e4 = sum(a * b * c * d for a, b, c, d in itertools.combinations(parts, 4))
+    rng = np.random.default_rng(11)
+    n2 = 3800
+    A = np.triu(rng.random((n2, n2)) < 0.6, 1)
+    ju = np.nonzero(A)
+    csr_gnp = gpu.HostCSR.from_edges(ju[0].astype(np.int32), ju[1].astype(np.int32))
+    for csr, closed in ((csr_mp, e4), (csr_gnp, None)):
+        got = {}
+        for name, opts in (("default", {}), ("popcount", {"KC_MFMA": 0}), ("small_pool", {"KC_POOL_MB": 96}), ("one_stream", {"KC_STREAMS": 1})):
+            for kk, vv in opts.items():
+                gpu.set_option(kk, vv)
+            try:
+                g = gpu.DeviceGraph.from_csr(csr)
+                assert g.max_out_degree > 2048
+                ordered, cliques, st = g.kclique_count(4, stats=True)
+                assert ordered == (cliques * 24) & U64
+                got[name] = (cliques, st["launches"])
+                if name in ("default", "small_pool"):
+                    assert sum(g.kclique_partial(4, q, 3) for q in range(3)) == cliques
+                g.free()
+            finally:
+                for kk in opts:
+                    gpu.set_option(kk, None)
+        assert len({v[0] for v in got.values()}) == 1, got
+        if closed is not None:
+            assert got["default"][0] == closed
+        assert got["default"][1] > got["popcount"][1]       # a BUILD and a count launch per chunk
+        assert got["small_pool"][1] > got["default"][1]     # more, shorter chunks
+    gpu.set_option("KC_POOL_MB", None)
+
+
 def test_out_degrees_above_4096(gpu, oracle):
     """Pivots with 4096 < d+ <= 8192 (four-words-per-lane slab kernel, k <= 4 and the per-vertex counts).  K_{a,b} plus a sparse
     random graph H inside side A: every B vertex sees all of A as higher-ranked neighbours (d+ = a > 4096), triangles are

@@ -41,8 +41,8 @@ static void run(const char *name, const uint32_t *dpoolm, size_t slot_words, con
     float best = 1e30f;
     unsigned long long got = 0;
     for (int it = 0; it < 3; ++it) {
-        CK(hipMemset(ticket, 0, 4));
         CK(hipMemset(acc, 0, 64 * 16 * 8));
+        CK(hipMemset(ticket, 0, 4));
         CK(hipEventRecord(e0));
         k_kc4_mfma<T, NT, DBG><<<256 * gridmul, NT>>>(dpoolm, slot_words, dd, nmat, ticket, acc, 64, 16);
         CK(hipEventRecord(e1));
@@ -96,15 +96,13 @@ static void shape(int d, double dens, int nmat) {
     CK(hipMemcpy(dd, hd.data(), size_t(nmat) * 4, hipMemcpyHostToDevice));
     printf("d = %d density %.2f, %d matrices (%.1f MB each)\n", d, dens, nmat, slot_words * 4 / 1e6);
     run<4, 256>("4x4 wg256", pool, slot_words, dd, nmat, want, macs);
-    run<2, 256>("2x2 wg256", pool, slot_words, dd, nmat, want, macs);
     run<2, 256>("2x2 wg256 x2", pool, slot_words, dd, nmat, want, macs, 2);
     run<2, 256>("2x2 wg256 x4", pool, slot_words, dd, nmat, want, macs, 4);
     run<2, 512>("2x2 wg512", pool, slot_words, dd, nmat, want, macs);
-    run<2, 512>("2x2 wg512 x2", pool, slot_words, dd, nmat, want, macs, 2);
     run<2, 1024>("2x2 wg1024", pool, slot_words, dd, nmat, want, macs);
-    run<2, 512, 1>("2x2 wg512 x2 noepi", pool, slot_words, dd, nmat, want, macs, 2);
-    run<2, 512, 2>("2x2 wg512 x2 chunk0", pool, slot_words, dd, nmat, want, macs, 2);
-    run<2, 512, 3>("2x2 wg512 x2 noexp", pool, slot_words, dd, nmat, want, macs, 2);
+    run<2, 1024, 1>("2x2 wg1024 noepi", pool, slot_words, dd, nmat, want, macs);
+    run<2, 1024, 2>("2x2 wg1024 chunk0", pool, slot_words, dd, nmat, want, macs);
+    run<2, 1024, 3>("2x2 wg1024 noexp", pool, slot_words, dd, nmat, want, macs);
     CK(hipFree(pool));
     CK(hipFree(dd));
 }
