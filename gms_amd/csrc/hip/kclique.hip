@@ -1022,7 +1022,8 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
 // dynamic [bm: 2048 u32] [pre: 2048 u16] [row stage: nwaves*4*W u32]
 // ---------------------------------------------------------------------------------------------
 template <int LV, int WPL, bool GLOBAL_ROWS, bool VTX, int PIPE = GLOBAL_ROWS ? 1 : 0 /* the BUILD: 0 member by member, 1 three-stage member pipeline, 2 step stream */,
-          bool TRI = false /* LDS matrix stored triangularly (kc_tri_off; k = 4 only) */>
+          bool TRI = false /* LDS matrix stored triangularly (kc_tri_off; k = 4 only) */,
+          bool EXPORT = false /* BUILD only: the finished matrix leaves for the pool (KcExport), k_kc4_mfma counts it */>
 __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                    const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                    const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
@@ -1054,8 +1055,8 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
     // k = 4 count (random rows per lane: an odd stride spreads them over the LDS banks)
     static_assert(!TRI || (LV == 2 && !GLOBAL_ROWS && !VTX && PIPE != 2), "the triangular layout serves the k = 4 count on LDS matrices");
     const size_t mat_words = TRI ? size_t(kc_tri_off(dmax)) : size_t(dmax) * WS;  // words of the LDS matrix of this bin
-    constexpr bool kCanExport = LV == 2 && !VTX && (GLOBAL_ROWS || TRI) && PIPE == 1;  // the variants whose k = 4 count can run on the matrix cores
-    const bool exporting = kCanExport && ex.pool != nullptr;  // (uniform)
+    static_assert(!EXPORT || (LV == 2 && !VTX && (GLOBAL_ROWS || TRI) && PIPE == 1), "the variants whose k = 4 count can run on the matrix cores");
+    constexpr bool kCanExport = EXPORT, exporting = EXPORT;  // (compile-time: the BUILD-only kernels carry none of the count phases' registers)
     uint32_t *rows = GLOBAL_ROWS ? slabs + size_t(blockIdx.x) * size_t(dmax) * size_t(WS) : smem;
     uint32_t *bm = GLOBAL_ROWS ? smem : kc_fixed;
     // dynamic LDS of the LDS-matrix variants: [rows: mat_words][column counters (VTX)][forward list / step-stream descriptors]
@@ -2131,17 +2132,16 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             const size_t region_words = pool.bytes / 4 / size_t(n_regions) & ~size_t(63);
             static bool x_attr = false;
             if (!x_attr) {
-                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 1, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 2, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 4, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
-                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 1, false, false, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kKcLdsDynMax));
+                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 1, true, false, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 2, true, false, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 4, true, false, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024));
+                GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 1, false, false, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kKcLdsDynMax));
                 x_attr = true;
             }
             if (pool.base) GMSX_HIP(hipMemsetAsync(pool.tickets, 0, sizeof(int) * kKcTickets, s));
             GMSX_HIP(hipEventRecord(ev_fork, s));  // (again: the side streams start behind the cleared tickets)
             for (int i = 0; i < kSides; ++i) GMSX_HIP(hipStreamWaitEvent(sides[i], ev_fork, 0));
             int chunk_seq = 0, n_tickets = 0;
-            const int mfma_grid = [] { const char *e = opt("KC_MFMA_GRID"); const int v = e ? std::atoi(e) : 1; return v < 1 ? 1 : v > 8 ? 8 : v; }();
             // one bin (from, dmax]: slab variant WPL = 1 / 2 / 4 (dmax 2048 / 4096 / 8192) or the triangular LDS variant (WPL = 0)
             auto export_bin = [&](int from, int dmax, int wpl, bool *done) -> int {
                 *done = false;
@@ -2163,34 +2163,30 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
                     const KcExport ex{pool.base + size_t(r) * region_words, pool.dpool + size_t(r) * kKcChunkMax, (unsigned long long)slot_words};
                     const int64_t first = lo + q0 * nparts, end = std::min(hi, lo + (q0 + nq) * nparts);
                     if (wpl > 0) {
-                        const int slab_threads = [] { const char *e = opt("KC_SLAB_THREADS"); const int v = e ? std::atoi(e) : 1024; return (v == 512 || v == 768) ? v : 1024; }();
+                        constexpr int slab_threads = 1024;
                         const size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(slab_threads / 64) * 4 * W * 4;  // bitmap + prefix + row stage
                         const unsigned blocks = unsigned(std::min<int64_t>(nq, int64_t(cu)));  // (128 registers x 1024 threads: one workgroup per CU)
                         if (wpl == 1)
-                            hipLaunchKernelGGL((k_kc_block<2, 1, true, false>), dim3(blocks), dim3(slab_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                            hipLaunchKernelGGL((k_kc_block<2, 1, true, false, 1, false, true>), dim3(blocks), dim3(slab_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
                                                g->dense_limit, g->order, first, end, nparts, part, dmax, W, W, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, ex);
                         else if (wpl == 2)
-                            hipLaunchKernelGGL((k_kc_block<2, 2, true, false>), dim3(blocks), dim3(slab_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                            hipLaunchKernelGGL((k_kc_block<2, 2, true, false, 1, false, true>), dim3(blocks), dim3(slab_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
                                                g->dense_limit, g->order, first, end, nparts, part, dmax, W, W, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, ex);
                         else
-                            hipLaunchKernelGGL((k_kc_block<2, 4, true, false>), dim3(blocks), dim3(slab_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
+                            hipLaunchKernelGGL((k_kc_block<2, 4, true, false, 1, false, true>), dim3(blocks), dim3(slab_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
                                                g->dense_limit, g->order, first, end, nparts, part, dmax, W, W, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid, vcounts, rv, ex);
                     } else {
                         const size_t lds = size_t(kc_tri_off(dmax)) * 4 + ((size_t(dmax) * 2 + 15) & ~size_t(15));
                         const unsigned blocks = unsigned(std::min<int64_t>(nq, int64_t(cu) * 64));
-                        const int tri_threads = [&] { const char *e = opt("KC_TRI_THREADS"); const int v = e ? std::atoi(e) : 1024; return (v == 256 || v == 512) && dmax <= kKcTriTwo ? v : 1024; }();
-                        hipLaunchKernelGGL((k_kc_block<2, 1, false, false, 1, true>), dim3(blocks), dim3(tri_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff,
+                        constexpr int tri_threads = 1024;
+                        hipLaunchKernelGGL((k_kc_block<2, 1, false, false, 1, true, true>), dim3(blocks), dim3(tri_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff,
                                            g->bmpool, g->dense_limit, g->order, first, end, nparts, part, dmax, W, W | 1, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid,
                                            vcounts, rv, ex);
                     }
-                    const unsigned cgrid = unsigned(std::min<int64_t>(nq, int64_t(cu) * mfma_grid));
-                    const int mfma_nt = [] { const char *e = opt("KC_MFMA_NT"); return e ? std::atoi(e) : 1024; }();
-                    if (mfma_nt == 256)
-                        hipLaunchKernelGGL((k_kc4_mfma<2, 256>), dim3(cgrid), dim3(256), 0, st, ex.pool, slot_words, ex.dpool, int(nq), pool.tickets + n_tickets, acc, kAccSlots, kAccStride);
-                    else if (mfma_nt == 512)
-                        hipLaunchKernelGGL((k_kc4_mfma<2, 512>), dim3(cgrid), dim3(512), 0, st, ex.pool, slot_words, ex.dpool, int(nq), pool.tickets + n_tickets, acc, kAccSlots, kAccStride);
-                    else
-                        hipLaunchKernelGGL((k_kc4_mfma<2, 1024>), dim3(cgrid), dim3(1024), 0, st, ex.pool, slot_words, ex.dpool, int(nq), pool.tickets + n_tickets, acc, kAccSlots, kAccStride);
+                    const unsigned cgrid = unsigned(std::min<int64_t>(nq, int64_t(cu)));
+                    // (Measured at scale 26 and dropped: 256- / 512-thread count workgroups, two or four per CU, with 512- / 768-thread BUILD workgroups beside them, so
+                    //  that a count wave per SIMD fits next to the BUILD's — 504 … 545 against 489 ms: the two kernels slow each other more than the overlap gains.)
+                    hipLaunchKernelGGL((k_kc4_mfma<2, 1024>), dim3(cgrid), dim3(1024), 0, st, ex.pool, slot_words, ex.dpool, int(nq), pool.tickets + n_tickets, acc, kAccSlots, kAccStride);
                     ++n_tickets;
                     *launches += 2;
                 }

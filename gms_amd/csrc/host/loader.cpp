@@ -768,7 +768,6 @@ Option g_options[] = {
     // k-clique (kclique.hip)
     {"KC_SLAB_MB", "", false}, {"KC_MAXD", "", false}, {"KC_STREAMS", "", false}, {"KC_PIPE_ALL", "", false}, {"KC_STREAM_BUILD", "", false},
     {"KC_REVERSE", "", false}, {"KC_REV_MIN", "", false}, {"KC_REV_FACTOR", "", false}, {"KC_TRI", "", false}, {"KC_MFMA", "", false}, {"KC_POOL_MB", "", false},
-    {"KC_MFMA_GRID", "", false}, {"KC_TRI_THREADS", "", false}, {"KC_SLAB_THREADS", "", false}, {"KC_MFMA_NT", "", false},
     // Bron–Kerbosch (bk.hip)
     {"BK_MAXC", "", false}, {"BK_ARENA_MB", "", false}, {"BK_GROUPS", "", false}, {"BK_SMALL_P", "", false}, {"BK_SMALL_P_GROUPS", "", false},
     {"BK_BUDGET", "", false}, {"BK_BUDGET0", "", false}, {"BK_RESUME_GRAB", "", false}, {"BK_SPLIT_BUILD", "", false}, {"BK_TINY_ROOTS", "", false},

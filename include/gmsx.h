@@ -133,7 +133,7 @@ int gmsx_set_host_threads(int n);
  *                   receiver must get to take them, default 64), KC_REV_FACTOR (10 x how much cheaper in bytes the reverse side must be, default 20),
  *                   KC_TRI (0 = k = 4 keeps rectangular LDS matrices up to d+ = 1024 and the global slab beyond, instead of triangular ones up to 1472),
  *                   KC_MFMA (0 = the k = 4 count of the pivots of d+ > 512 by AND + popcount inside their BUILD kernels instead of on the matrix cores),
- *                   KC_POOL_MB (the pool those pivots' matrices pass through, default 6144: smaller = more, shorter chunks), KC_MFMA_GRID (launch shape)
+ *                   KC_POOL_MB (the pool those pivots' matrices pass through, default min(what the call needs, 6144): smaller = more, shorter chunks)
  *   Bron–Kerbosch   BK_MAXC (widest start vertex of the register-resident search), BK_ARENA_MB, BK_BUDGET / BK_BUDGET0 (nodes before a
  *                   search is re-split), BK_GROUPS, BK_SMALL_P, BK_SMALL_P_GROUPS, BK_RESUME_GRAB, BK_SPLIT_BUILD, BK_TINY_ROOTS,
  *                   BK_TINY_BESIDE (kernel variants) */
