@@ -379,11 +379,11 @@ def sg_cache_path(args):
 
 # the single-GPU perf configs of BASELINE.json besides the triangle count (configs[2], configs[3])
 WORKLOADS = {
-    "kc4": dict(key="config2_kclique4_s22", gen=("kronecker", 22, 16), golden_key="kronecker-22-16-relabel", golden_field="kc4", kernels="k_kc_",
+    "kc4": dict(key="config2_kclique4_s22", gen=("kronecker", 22, 16), golden_key="kronecker-22-16-relabel", golden_field="kc4", kernels="k_kc",
                 label="k=4 clique counting, RMAT scale-22 ef=16 (BASELINE.json configs[2])"),
     # the NORTH-STAR k-clique workload (BASELINE.json north_star: "bit-exact triangle and k-clique counts on RMAT scale-26"): k = 4 on the headline graph;
     # the golden is the reference's kClist count (tests/golden/graphs.json kc4_true: the set-based CliqueCount cannot reach this size)
-    "kc26": dict(key="kclique4_s26", gen=("kronecker", 26, 16), golden_key="kronecker-26-16-relabel", golden_field="kc4_true", kernels="k_kc_",
+    "kc26": dict(key="kclique4_s26", gen=("kronecker", 26, 16), golden_key="kronecker-26-16-relabel", golden_field="kc4_true", kernels="k_kc",
                  label="k=4 clique counting, RMAT scale-26 ef=16 (BASELINE.json north_star: k-clique counts on the headline graph)"),
     "bk": dict(key="config3_bk", gen=("rmat", 21, 56, 0.45, 0.22, 0.22), golden_key="rmat-21-56-a45-b22-c22", golden_field="bk", kernels="k_bk_",
                label="Bron-Kerbosch maximal cliques, com-Orkut-shaped RMAT scale-21 ef=56 A=.45 B=C=.22, |E|=117M (BASELINE.json configs[3])"),
@@ -395,8 +395,8 @@ ALG_BYTES_ARE = {
     "kc26": None,  # = kc4, set below
     "kc4": "per pivot (d+ >= 3) its own containers once + per member v the containers of N+(v) the BUILD reads (bitset words or 16-bit list, tail ids; one "
            "4-byte gather per pair for d+ <= 32) — or, for a hub member handed to its receiver (reverse rows), the 2 i bytes of the pivot's prefix below it + a "
-           "16-byte record + the row's ceil(i/32) words written and read back — + the slab matrices of pivots wider than 1024, written and read once; the COUNT "
-           "runs on the bit-matrix in LDS",
+           "16-byte record + the row's ceil(i/32) words written and read back — + the bit matrices of the pivots wider than 512 (k = 4: they pass through a pool "
+           "in global memory to the matrix-core count, k_kc4_mfma), written and read once; the narrower pivots' COUNT runs on the bit-matrix in LDS",
     "bk": "per start vertex the oriented rows of all its neighbours (what the builds walk: candidates -> Cadj, in-neighbours -> XT) + Cadj | XT of the start "
           "vertices built in the arena, once + one Cadj row (c/32 words) per search-tree node — the operand of cand.intersect(N(q)) (tomita.h:51-70); the Xf / XT "
           "words a node reads and the saved levels are not counted",
@@ -535,6 +535,7 @@ RDREQ = ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", 
 # the compute side of the roofline: what the SIMDs and the LDS arrays did while the kernels ran, from two more child passes
 SQ_PASS = ["SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES"]
 GRBM_PASS = ["GRBM_GUI_ACTIVE"]
+MFMA_PASS = ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_MFMA"]  # the matrix cores (round 6: the k = 4 count of the wide pivots, kc4_mfma.hpp); not collected for the triangle count
 N_XCD = 8                      # MI355X: 8 XCDs x 32 CUs; GRBM_GUI_ACTIVE comes back summed over the XCDs (profiles/r05/s26_r5: 797 M per 48.5 ms launch = 8 x 2.05 GHz)
 VALU_CYCLES_PER_INST = 3.0     # SIMD cycles per wave64 VALU instruction for the mix of these kernels: tools/probes/valu_rate.hip measures 2.2-2.5 for the
 VALU_CYCLES_RANGE = (2.3, 4.3)  # add / and / shift class and 4.2-4.3 for v_bfe_u32 / v_lshl_or_b32 / v_mul_lo_u32 / v_bcnt_u32_b32 (profiles/r04/valu_rate.txt)
@@ -556,6 +557,9 @@ def compute_side(rec, cus):
     if lds is not None:
         out["lds_frac"] = lds / (cus * cycles)
         out["lds_bank_conflict_share"] = (rec.get("SQ_LDS_BANK_CONFLICT", 0.0) / lds) if lds else 0.0
+    if rec.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None:  # rocprofiler's MfmaUtil: busy cycles of the matrix pipes, summed over the SIMDs, / (SIMDs x cycles)
+        out["mfma_frac"] = rec["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * cus * cycles)
+        out["mfma_instructions"] = rec.get("SQ_INSTS_MFMA")
     if rec.get("SQ_WAVE_CYCLES"):
         out["waves_waiting_share"] = rec.get("SQ_WAIT_ANY", 0.0) / rec["SQ_WAVE_CYCLES"]
     dur = rec.get("dur_ns:GRBM_GUI_ACTIVE")
@@ -587,7 +591,10 @@ def make_roofline(alg_bytes, kernel_s, trec, cus, ceiling_gbs, extra=None):
     cs = compute_side(trec, cus) if trec else None
     fr = {"memory_by_traffic": r["frac_traffic"] if traffic else r["frac"]}
     if cs:
-        r.update({k: cs[k] for k in ("valu_frac", "valu_frac_range", "lds_frac", "lds_bank_conflict_share", "waves_waiting_share", "clock_GHz") if k in cs})
+        r.update({k: cs[k] for k in ("valu_frac", "valu_frac_range", "lds_frac", "lds_bank_conflict_share", "waves_waiting_share", "clock_GHz", "mfma_frac", "mfma_instructions") if k in cs})
+        if "mfma_frac" in cs:
+            r["mfma_frac_is"] = "SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x %d CUs x GRBM_GUI_ACTIVE / %d XCDs) — rocprofiler's MfmaUtil over the whole call" % (cus, N_XCD)
+            fr["mfma"] = cs["mfma_frac"]
         r["valu_frac_is"] = ("SQ_INSTS_VALU x %.1f SIMD cycles per wave64 instruction (tools/probes/valu_rate.hip: %.1f for the add / and / shift class, %.1f for "
                              "v_bfe / v_lshl_or / v_mul_lo / v_bcnt; valu_frac_range = at those two) / (4 SIMDs x %d CUs x GRBM_GUI_ACTIVE / %d XCDs), "
                              "dispatches serialised by the profiler" % (VALU_CYCLES_PER_INST, VALU_CYCLES_RANGE[0], VALU_CYCLES_RANGE[1], cus, N_XCD))
@@ -598,7 +605,7 @@ def make_roofline(alg_bytes, kernel_s, trec, cus, ceiling_gbs, extra=None):
     fr = {k: v for k, v in fr.items() if v is not None}
     if fr:
         top = max(fr, key=fr.get)
-        r["bound"] = {"memory_by_traffic": "beyond-L2", "valu": "valu", "lds": "lds"}[top]
+        r["bound"] = {"memory_by_traffic": "beyond-L2", "valu": "valu", "lds": "lds", "mfma": "mfma"}[top]
     r["fractions"] = fr
     if trec:
         r.update({"fetch_multiplier": trec.get("fetch_multiplier"), "multiplier_source": trec.get("multiplier_source"),
@@ -608,7 +615,7 @@ def make_roofline(alg_bytes, kernel_s, trec, cus, ceiling_gbs, extra=None):
             e = {"dispatches": v.get("dispatches", 1), "bytes": v.get("bytes")}
             kc = compute_side(v, cus)
             if kc:
-                e.update({a: kc[a] for a in ("valu_frac", "lds_frac", "lds_bank_conflict_share", "waves_waiting_share", "clock_GHz") if a in kc})
+                e.update({a: kc[a] for a in ("valu_frac", "lds_frac", "lds_bank_conflict_share", "waves_waiting_share", "clock_GHz", "mfma_frac") if a in kc})
                 if v.get("dur_ns:GRBM_GUI_ACTIVE"):
                     e["ms_under_pmc"] = v["dur_ns:GRBM_GUI_ACTIVE"] * 1e-6
             pk[k] = e
@@ -624,7 +631,7 @@ def measure_traffic(args, rank, workload="tc"):
     table, notes = {}, []
     # the memory-side read requests of the L2 by SIZE CLASS: FETCH_SIZE tallies every request at 64 B (MI355X_MICROARCH.md "HBM": exactly half the bytes of a
     # 16-byte-per-lane stream; "other access widths are uncalibrated") — 32 n32 + 64 n64 + 128 n128 is the byte count itself, per kernel, whatever the widths
-    passes = ((RDREQ, ["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]) if workload == "tc" else (RDREQ, ["FETCH_SIZE"], ["WRITE_SIZE"])) + (SQ_PASS, GRBM_PASS)
+    passes = ((RDREQ, ["FETCH_SIZE"], ["WRITE_SIZE"], ["TCC_HIT_sum", "TCC_MISS_sum"]) if workload == "tc" else (RDREQ, ["FETCH_SIZE"], ["WRITE_SIZE"])) + (SQ_PASS, GRBM_PASS) + ((MFMA_PASS,) if workload.startswith("kc") else ())
     for counters in passes:
         t0 = time.perf_counter()
         res, err = run_pmc_pass(args, counters, timeout=args.pmc_timeout, workload=workload)
