@@ -495,7 +495,7 @@ def run_pmc_pass(args, counters, timeout, workload="tc"):
         rows = []
         for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
             with open(f) as fh:
-                rows += [x for x in csv.DictReader(fh) if prefix in x["Kernel_Name"] and "stats" not in x["Kernel_Name"]]
+                rows += [x for x in csv.DictReader(fh) if prefix in x["Kernel_Name"] and "stats" not in x["Kernel_Name"] and "k_kcr_" not in x["Kernel_Name"]]  # (k_kcr_*: the one-off list build of a graph's first k-clique call)
         # dispatches in issue order -> passes (each pass = st["launches"] dispatches)
         by_dispatch = {}
         for x in rows:
