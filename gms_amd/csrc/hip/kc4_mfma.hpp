@@ -53,7 +53,25 @@ __device__ __forceinline__ kc4m_v8i kc4m_exp_b(uint32_t w) {
 }
 
 // DBG (tools/probes/kc4_mfma_probe.hip only; wrong sums): 1 = no mask epilogue, 2 = every chunk re-reads the first one (L1 / TA side), 3 = no expansion (raw words as fragments)
-template <int T, int DBG = 0>  // tiles per block side: block = (32 T) x (32 T)
+// Full 16-byte chunks: the four words a lane holds feed four K-steps, and K-step S takes bit class S of ALL four words (nibble position S of every nibble) —
+// one weight per instruction (0.5 / 1 / 2 / 2), the same expansion on both sides (one AND per dword; class 3 a shift more), and the instruction's block scales
+// (E8M0: 2^(byte - 127), one byte per lane) put the product back to 1: 2 x 2 for the 0.5s, 1 x 1, 0.5 x 0.5 for the 2s.  20 VALU per tile role and chunk
+// against 4 x (5 + 7) / 2 = 24 with the mixed-weight expansions above, which the short tails keep.
+template <int S>
+__device__ __forceinline__ kc4m_v8i kc4m_class(uint4 w) {
+    kc4m_v8i r = {};
+    if constexpr (S < 3) {
+        constexpr uint32_t M = 0x11111111u << S;
+        r[0] = int(w.x & M); r[1] = int(w.y & M); r[2] = int(w.z & M); r[3] = int(w.w & M);
+    } else {
+        r[0] = int((w.x >> 1) & 0x44444444u); r[1] = int((w.y >> 1) & 0x44444444u); r[2] = int((w.z >> 1) & 0x44444444u); r[3] = int((w.w >> 1) & 0x44444444u);
+    }
+    return r;
+}
+template <int S>
+__device__ __forceinline__ int kc4m_class_scale() { return S == 0 ? int(0x80808080u) : S == 1 ? 0x7f7f7f7f : 0x7e7e7e7e; }
+
+template <int T, int DBG = 0, int PF = 1>  // tiles per block side: block = (32 T) x (32 T); PF: chunks of fragment loads in flight behind the one being multiplied
 struct Kc4mBlock {
     // one block (bi >= bj) of matrix `m` (row stride WS words, d rows); returns Σ L_ij (L Lᵀ)_ij over the block
     static __device__ __forceinline__ uint32_t run(const uint32_t *__restrict__ m, int WS, int d, int bi, int bj, int lane) {
@@ -98,6 +116,36 @@ struct Kc4mBlock {
                     acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[b], fb[a], c0, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
                 }
         };
+        // one K-step of a full chunk: bit class S of the four words of every lane (kc4m_class)
+        auto cstep = [&](auto zero_tag, auto s_tag, const uint4 (&cj)[T], const uint4 (&ci)[T]) {
+            constexpr bool ZERO = decltype(zero_tag)::value;
+            constexpr int S = decltype(s_tag)::value;
+            kc4m_v8i fa[T], fb[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if constexpr (DBG == 3) {
+                    fa[t] = kc4m_v8i{int(cj[t].x), int(cj[t].y), int(cj[t].z), int(cj[t].w), 0, 0, 0, 0};
+                    fb[t] = kc4m_v8i{int(ci[t].x), int(ci[t].y), int(ci[t].z), int(ci[t].w), 0, 0, 0, 0};
+                } else {
+                    fa[t] = kc4m_class<S>(cj[t]);
+                    fb[t] = kc4m_class<S>(ci[t]);
+                }
+            }
+            const int sc = kc4m_class_scale<S>();
+#pragma unroll
+            for (int a = 0; a < T; ++a)
+#pragma unroll
+                for (int b = 0; b < T; ++b) {
+                    kc4m_v16f c0;
+                    if constexpr (ZERO) {
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) c0[g] = 0.f;
+                    } else {
+                        c0 = acc[a][b];
+                    }
+                    acc[a][b] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[b], fb[a], c0, 4, 4, 0, sc, 0, sc);
+                }
+        };
         // the short tail's words are on their way from the start
         const uint32_t tb = uint32_t(nfull) * 8u - 4u * h;  // (offJ / offI carry + 4 h for the 16-byte chunks; the sums below wrap in 32 bits BEFORE they meet the pointer)
         uint2 t2j[T], t2i[T];
@@ -117,38 +165,47 @@ struct Kc4mBlock {
             }
         }
         if (nfull > 0) {
-            uint4 wj[T], wi[T];
+            uint4 wj[T], wi[T], mj[T], mi[T];  // the chunk being multiplied; PF = 2: the one behind it
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 wj[t] = *reinterpret_cast<const uint4 *>(m + offJ[t]);
                 wi[t] = *reinterpret_cast<const uint4 *>(m + offI[t]);
             }
+            if constexpr (PF == 2) {
+                const uint32_t c1 = uint32_t(min(1, nfull - 1)) * 8u;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    mj[t] = *reinterpret_cast<const uint4 *>(m + offJ[t] + c1);
+                    mi[t] = *reinterpret_cast<const uint4 *>(m + offI[t] + c1);
+                }
+            }
             for (int c = 0; c < nfull; ++c) {
                 uint4 nj[T], ni[T];
-                const uint32_t cn = DBG == 2 ? 0u : uint32_t(min(c + 1, nfull - 1)) * 8u;  // (the last trip reloads its own chunk: no branch around the loads)
+                const uint32_t cn = DBG == 2 ? 0u : uint32_t(min(c + PF, nfull - 1)) * 8u;  // (the last trips reload the last chunk: no branch around the loads)
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
                     nj[t] = *reinterpret_cast<const uint4 *>(m + offJ[t] + cn);
                     ni[t] = *reinterpret_cast<const uint4 *>(m + offI[t] + cn);
                 }
-                uint32_t xj[T], xi[T];
-#pragma unroll
-                for (int t = 0; t < T; ++t) { xj[t] = wj[t].x; xi[t] = wi[t].x; }
-                if (c == 0) kstep(std::true_type{}, xj, xi);
-                else kstep(std::false_type{}, xj, xi);
-#pragma unroll
-                for (int t = 0; t < T; ++t) { xj[t] = wj[t].y; xi[t] = wi[t].y; }
-                kstep(std::false_type{}, xj, xi);
-#pragma unroll
-                for (int t = 0; t < T; ++t) { xj[t] = wj[t].z; xi[t] = wi[t].z; }
-                kstep(std::false_type{}, xj, xi);
-#pragma unroll
-                for (int t = 0; t < T; ++t) { xj[t] = wj[t].w; xi[t] = wi[t].w; }
-                kstep(std::false_type{}, xj, xi);
+                // (the scheduler sinks these loads to the end of the trip — their results are only copied there — so a chunk waits for its own loads; pinning
+                //  them here with a sched_barrier, one or two chunks ahead, was SLOWER (0.96 against 0.81 ms, 1 024 matrices of d+ = 1 800): the loop is bound by
+                //  the bytes its fragment loads pull through the fabric, not by their latency — see the teams below)
+                if (c == 0) cstep(std::true_type{}, std::integral_constant<int, 0>{}, wj, wi);
+                else cstep(std::false_type{}, std::integral_constant<int, 0>{}, wj, wi);
+                cstep(std::false_type{}, std::integral_constant<int, 1>{}, wj, wi);
+                cstep(std::false_type{}, std::integral_constant<int, 2>{}, wj, wi);
+                cstep(std::false_type{}, std::integral_constant<int, 3>{}, wj, wi);
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
-                    wj[t] = nj[t];
-                    wi[t] = ni[t];
+                    if constexpr (PF == 2) {
+                        wj[t] = mj[t];
+                        wi[t] = mi[t];
+                        mj[t] = nj[t];
+                        mi[t] = ni[t];
+                    } else {
+                        wj[t] = nj[t];
+                        wi[t] = ni[t];
+                    }
                 }
             }
         } else {
@@ -205,27 +262,25 @@ struct Kc4mBlock {
     }
 };
 
-// One workgroup per matrix at a time, matrices from a global ticket, the blocks of a matrix from a ticket in LDS (far blocks first: the long ones).  NT = 1 024
-// (four waves per SIMD at 128 registers): the block loop waits on its fragment loads — without the mask epilogue or without the expansions it takes the same
-// time (tools/probes/kc4_mfma_probe.hip) — and more waves hide more of that; 512 threads: +5 … 10 %.
-// (Measured and dropped: the waves of an XCD on ONE matrix — group = HW_REG_XCC_ID, tasks (matrix, block) as tickets of a per-group counter over prefix sums of
-// the matrices' block counts, so that an XCD's L2 holds the matrix all its waves re-read — 0.93 against 0.81 ms for 1 024 matrices of d+ = 1 800 even with eight
-// tickets per atomic: a returning atomic on one address completes every ~11 ns chip-wide, and the fragment loads were no faster from the nearer cache.)
-template <int T, int NT, int DBG = 0>
-__global__ __launch_bounds__(NT) void k_kc4_mfma(const uint32_t *__restrict__ pool, size_t slot_words, const int32_t *__restrict__ dpool, int nmat,
-                                                int *__restrict__ ticket, unsigned long long *__restrict__ acc, int acc_slots, int acc_stride) {
-    __shared__ int s_mat, s_blk;
+// TEAMS.  A block re-reads its 2 x 32 T rows once per K-chunk and a matrix is re-read ~nb / 2 times in all.  With one matrix per workgroup the 32 CUs of an XCD
+// are on 32 matrices at once — 16 MB at d+ = 1 800 against 4 MB of L2 — and the fragment loads run at what the fabric behind the L2 delivers (5.8 TB/s; with
+// every chunk re-reading the first one the kernel was a third faster).  So G workgroups that share an XCD — the dispatcher deals consecutive workgroup ids
+// round the XCDs, blockIdx mod 8 labels the ones that share one; a wrong guess costs speed, never the count — form a team on ONE matrix: team k takes the
+// matrices k, k + nteams, … of the launch (they are sorted by width: equal shares), member g the blocks g, g + G, … of each, its 16 waves through a ticket in
+// LDS.  No global atomic (a returning atomic on one address completes every ~11 ns chip-wide: per-XCD block tickets were tried and cost more than the loads).
+// NT = 1 024: four waves per SIMD at 128 registers hide the most of the loads (512 threads: + 5 … 10 %).
+template <int T, int NT, int DBG = 0, int PF = 1>
+__global__ __launch_bounds__(NT) void k_kc4_mfma(const uint32_t *__restrict__ pool, size_t slot_words, const int32_t *__restrict__ dpool, int nmat, int G,
+                                                unsigned long long *__restrict__ acc, int acc_slots, int acc_stride) {
+    __shared__ int s_blk;
     __shared__ unsigned long long red[NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // gridDim.x is a multiple of 8 G (host): teams = gridDim.x / G
+    const int x = blockIdx.x & 7, y = blockIdx.x >> 3, g = y % G, team = x + 8 * (y / G), nteams = int(gridDim.x) / G;
     unsigned long long total = 0;
-    while (true) {
-        if (tid == 0) {
-            s_mat = atomicAdd(ticket, 1);
-            s_blk = 0;
-        }
+    for (int q = team; q < nmat; q += nteams) {
+        if (tid == 0) s_blk = 0;
         __syncthreads();
-        const int q = s_mat;
-        if (q >= nmat) break;
         const int d = dpool[q];
         const uint32_t *m = pool + size_t(q) * slot_words;
         const int WS = kc4m_stride(d);
@@ -233,16 +288,16 @@ __global__ __launch_bounds__(NT) void k_kc4_mfma(const uint32_t *__restrict__ po
         while (true) {
             int task = 0;
             if (lane == 0) task = atomicAdd(&s_blk, 1);
-            task = __builtin_amdgcn_readfirstlane(task);
+            task = __builtin_amdgcn_readfirstlane(task) * G + g;
             if (task >= ntri) break;
-            const int tt = ntri - 1 - task;
+            const int tt = ntri - 1 - task;  // far blocks first: the long ones
             int bi = int((__builtin_sqrtf(8.0f * float(tt) + 1.0f) - 1.0f) * 0.5f);
             while (bi * (bi + 1) / 2 > tt) --bi;
             while ((bi + 1) * (bi + 2) / 2 <= tt) ++bi;
             const int bj = tt - bi * (bi + 1) / 2;
-            total += Kc4mBlock<T, DBG>::run(m, WS, d, bi, bj, lane);
+            total += Kc4mBlock<T, DBG, PF>::run(m, WS, d, bi, bj, lane);
         }
-        __syncthreads();  // every wave is done with s_mat / s_blk
+        __syncthreads();  // every wave is done with s_blk
     }
     for (int s = 32; s > 0; s >>= 1) total += __shfl_down(total, s);
     if (lane == 0) red[wave] = total;

@@ -1120,18 +1120,25 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         // rel -> row per pivot instead of one per trip of four members — and the members that ARE streamed are compacted into `fwd` (ballot + one
         // LDS atomic per wave), so that the group loops below walk forward members only: a trip no longer idles three groups behind one stream, and a
         // pivot whose hub edges were all handed over has no trips at all.  (The slab variant keeps deciding per trip: its rows pass through the stage.)
-        unsigned short *fwd = reinterpret_cast<unsigned short *>(smem + mat_words + (VTX ? dmax : 0));
+        // EXPORT (the matrix leaves for the pool): rows that lie in the arena never pass through LDS or the stage — they are copied arena -> pool in bulk below
+        // (slab variant: here; LDS variant: by the copy-out) — and BOTH variants walk the forward list only.  (With every hub edge handed to its receiver the
+        // slab BUILD spent 40 ms at scale 26 copying finished rows four per wave and trip through its stage.)
+        constexpr bool kUseFwd = (!GLOBAL_ROWS && PIPE != 2) || EXPORT;
+        unsigned short *fwd = GLOBAL_ROWS ? reinterpret_cast<unsigned short *>(reinterpret_cast<uint32_t *>(pre + kBitmapWords) + size_t(nwaves) * 4 * W)  // (slab: behind the stage)
+                                          : reinterpret_cast<unsigned short *>(smem + mat_words + (VTX ? dmax : 0));
         int nfwd = d;
-        if constexpr (!GLOBAL_ROWS && PIPE != 2) {
+        if constexpr (kUseFwd) {
             for (int i0 = 0; i0 < d; i0 += nthreads) {
                 const int i = i0 + tid;
                 bool fw = false;
                 if (i < d && i > 0) {  // (row 0 is empty: nobody is below the first member)
                     const uint32_t r = (rel_u && i < hc) ? rel_u[i] : kKcRelForward;
                     if (r != kKcRelForward) {
-                        const uint32_t *src = arow + r;
-                        uint32_t *dst = rowp(i);
-                        for (int t = 0; t < ((i + 31) >> 5); ++t) dst[t] = src[t];
+                        if constexpr (!EXPORT) {
+                            const uint32_t *src = arow + r;
+                            uint32_t *dst = rowp(i);
+                            for (int t = 0; t < ((i + 31) >> 5); ++t) dst[t] = src[t];
+                        }
                     } else {
                         fw = true;
                     }
@@ -1141,6 +1148,24 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                 if (lane == 0 && m) base = atomicAdd(&s_nfwd, __popcll(m));
                 base = __shfl(base, 0);
                 if (fw) fwd[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)i;
+            }
+            if constexpr (EXPORT && GLOBAL_ROWS) {
+                // slab: the arena rows (and the empty row 0) go straight to the pool slot, 16 bytes per thread and step; the forward rows are written by the flushes
+                const int q4 = WSr >> 2;
+                uint4 *dst = reinterpret_cast<uint4 *>(rows);
+                for (int x = tid; x < d * q4; x += nthreads) {
+                    const int i = x / q4, c = (x - i * q4) << 2;
+                    const uint32_t r = (rel_u && i < hc && i > 0) ? rel_u[i] : kKcRelForward;
+                    if (r == kKcRelForward && i > 0) continue;
+                    const uint32_t *src = arow + r;
+                    const int nw = i > 0 ? (i + 31) >> 5 : 0;
+                    uint4 v;
+                    v.x = c < nw ? src[c] : 0u;
+                    v.y = c + 1 < nw ? src[c + 1] : 0u;
+                    v.z = c + 2 < nw ? src[c + 2] : 0u;
+                    v.w = c + 3 < nw ? src[c + 3] : 0u;
+                    dst[x] = v;
+                }
             }
             __syncthreads();
             nfwd = s_nfwd;
@@ -1205,9 +1230,9 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                 // SLAB matrices walk ALL members, four consecutive ones per trip (their rows leave through the stage together), and decide per member where the
                 // row comes from — a member whose row lies in the arena (or member 0: no row) walks the pipeline as rank id 0, the top hub, d+ = 0: its extents
                 // are two cached loads and its "row" is empty, so every stage is a no-op for it.  LDS matrices walk the forward list only (pass 1 above).
-                const int K = GLOBAL_ROWS ? d : nfwd;  // positions to walk
-                auto at = [&](int k) -> int { return GLOBAL_ROWS ? min(k, d - 1) : (nfwd > 0 ? int(fwd[min(k, nfwd - 1)]) : 0); };  // position -> member index (clamped)
-                auto relof = [&](int i) -> uint32_t { return (GLOBAL_ROWS && rel_u && i < hc) ? rel_u[i] : kKcRelForward; };
+                const int K = kUseFwd ? nfwd : d;  // positions to walk
+                auto at = [&](int k) -> int { return !kUseFwd ? min(k, d - 1) : (nfwd > 0 ? int(fwd[min(k, nfwd - 1)]) : 0); };  // position -> member index (clamped)
+                auto relof = [&](int i) -> uint32_t { return (!kUseFwd && rel_u && i < hc) ? rel_u[i] : kKcRelForward; };
                 auto piped = [&](int i, uint32_t r) -> int32_t { return (r != kKcRelForward || i == 0) ? 0 : member(i); };
                 // the pipeline (kc_load_ext / kc_load_first above): ids three members ahead, extents two, first units one
                 const int kg = wave * 4 + grp;
@@ -1243,8 +1268,12 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                     }
                     if (GLOBAL_ROWS) {
                         __builtin_amdgcn_wave_barrier();
-                        const int nr = min(4, d - k0);
-                        for (int t = lane; t < nr * Wr; t += 64) rows[size_t(k0 + t / Wr) * WSr + t % Wr] = stage[(t / Wr) * W + t % Wr];
+                        const int nr = min(4, K - k0);
+                        if constexpr (kUseFwd) {  // (EXPORT: the trip's rows are four members of the forward list)
+                            for (int t = lane; t < nr * Wr; t += 64) rows[size_t(fwd[k0 + t / Wr]) * WSr + t % Wr] = stage[(t / Wr) * W + t % Wr];
+                        } else {
+                            for (int t = lane; t < nr * Wr; t += 64) rows[size_t(k0 + t / Wr) * WSr + t % Wr] = stage[(t / Wr) * W + t % Wr];
+                        }
                         __builtin_amdgcn_wave_barrier();
                     }
                     v0 = v1; v1 = v2; v2 = v3;
@@ -1289,8 +1318,9 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                     uint4 *dst = reinterpret_cast<uint4 *>(ex.pool + size_t(q) * size_t(ex.slot_words));
                     for (int x = tid; x < d * q4; x += nthreads) {
                         const int i = x / q4, c = (x - i * q4) << 2;
-                        const uint32_t *src = rows + kc_tri_off(i);
-                        const int nw = (i >> 5) + 1;
+                        const uint32_t r = (rel_u && i < hc && i > 0) ? rel_u[i] : kKcRelForward;  // (a row of the arena never went through LDS)
+                        const uint32_t *src = r != kKcRelForward ? arow + r : rows + kc_tri_off(i);
+                        const int nw = r != kKcRelForward ? (i + 31) >> 5 : (i >> 5) + 1;
                         uint4 v;
                         v.x = c < nw ? src[c] : 0u;
                         v.y = c + 1 < nw ? src[c + 1] : 0u;
@@ -1674,7 +1704,7 @@ __device__ __forceinline__ bool rev_is_cheaper(const int64_t *__restrict__ hoff,
     const int bw = int(bitset_words(w)) * 4;
     const int fwd = (w < dense_limit && bw + 32 < hl * 2) ? bw : hl * 2;
     const int rev = 2 * i + 16 + 8 * rev_row_words(i) + 32;
-    return factor10 * rev < 10 * fwd;  // (factor10 = 20: handed over when at least twice cheaper)
+    return factor10 * rev < 10 * fwd;  // (factor10 = 20: handed over when at least twice cheaper; 1, the default: unless ten times dearer)
 }
 // pass 1 (MODE 0): mark the candidate edges (kc_rel = 0 / ~0) and count them per receiver.  pass 2 (MODE 1): the arena words of every pivot (the edges whose
 // receiver takes them).  pass 3 (MODE 2): relative offsets into kc_rel, records to the receivers.  One 16-lane group per pivot position of the d+ order.
@@ -1846,7 +1876,11 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     GMSX_HIP(hipMemsetAsync(words, 0, size_t(g->n + 1) * 8, s));
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
     const int min_edges = int(std::max<long long>(1, opt_int("KC_REV_MIN", kRevMinEdges)));  // (option: a lower threshold lets small test graphs hand edges over)
-    const int factor10 = int(std::max<long long>(1, opt_int("KC_REV_FACTOR", 20)));  // (option: 10 x how much cheaper the reverse side must be)
+    // (option: 10 x how much cheaper in BYTES the reverse side must be.  Default 1 — handed over unless it moves ten times the bytes — since the matrix-core count:
+    //  a forward row's hits are resolved bit by bit (prefix popcount + LDS atomic, divergent per lane), a reverse row costs one LDS probe per prefix id, and
+    //  with the count off the clock the BUILD is what a call waits for.  20 -> 1 at scales 22 / 24 / 26: 13.6 -> 11.3, 70.0 -> 59.3, 496 -> 470 ms, for lists + arena
+    //  of 31.3 instead of 13.4 GB at scale 26 and 69 instead of 34 ms of one-off list build)
+    const int factor10 = int(std::max<long long>(1, opt_int("KC_REV_FACTOR", 1)));
     const unsigned blocks = unsigned(std::min<int64_t>((n_piv + 15) / 16, int64_t(cu) * 32));
     hipLaunchKernelGGL(k_kcr_edges<0>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, nullptr, nullptr, rcur, nullptr);
     hipLaunchKernelGGL(k_kcr_edges<1>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, nullptr, nullptr, rcur, nullptr);
@@ -1937,15 +1971,13 @@ static bool pipe_all_default(const gmsx_graph *g) {
 }
 
 // The pool the exporting BUILD kernels leave their matrices in (KcExport) — allocated at the first k = 4 call and kept (option KC_POOL_MB, default 6 144: a
-// region per stream; a region is reused by the next chunk of the same stream, so stream order alone protects it), with the d's of a chunk's slots and the
-// tickets of the count launches behind it.
+// region per stream; a region is reused by the next chunk of the same stream, so stream order alone protects it), with the d's of a chunk's slots behind it.
 struct KcPool {
     uint32_t *base = nullptr;
     size_t bytes = 0;
     int32_t *dpool = nullptr;
-    int *tickets = nullptr;
 };
-static constexpr int kKcPoolRegions = 3, kKcChunkMax = 65536, kKcTickets = 8192;
+static constexpr int kKcPoolRegions = 3, kKcChunkMax = 65536;
 static KcPool &kc_pool() {
     static KcPool p;
     return p;
@@ -1971,7 +2003,6 @@ static int ensure_kc_pool(size_t needed) {
     }
     if (!p.dpool) {
         GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&p.dpool), sizeof(int32_t) * kKcPoolRegions * kKcChunkMax));
-        GMSX_HIP(hipMalloc(reinterpret_cast<void **>(&p.tickets), sizeof(int) * kKcTickets));
     }
     for (size_t b = want; b >= (size_t(96) << 20); b >>= 1) {  // (a smaller pool = more chunks; below 96 MB the bins keep their in-kernel counts)
         void *q = nullptr;
@@ -2138,10 +2169,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
                 GMSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_kc_block<2, 1, false, false, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kKcLdsDynMax));
                 x_attr = true;
             }
-            if (pool.base) GMSX_HIP(hipMemsetAsync(pool.tickets, 0, sizeof(int) * kKcTickets, s));
-            GMSX_HIP(hipEventRecord(ev_fork, s));  // (again: the side streams start behind the cleared tickets)
-            for (int i = 0; i < kSides; ++i) GMSX_HIP(hipStreamWaitEvent(sides[i], ev_fork, 0));
-            int chunk_seq = 0, n_tickets = 0;
+            int chunk_seq = 0;
             // one bin (from, dmax]: slab variant WPL = 1 / 2 / 4 (dmax 2048 / 4096 / 8192) or the triangular LDS variant (WPL = 0)
             auto export_bin = [&](int from, int dmax, int wpl, bool *done) -> int {
                 *done = false;
@@ -2156,7 +2184,6 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
                 if (timing && cnt > 0) std::fprintf(stderr, "[gmsx kclique] matrix-core bin d+ <= %d: %lld pivots, %lld per chunk\n", dmax, (long long)cnt, (long long)cap);
                 const int W = dmax / 32;
                 for (int64_t q0 = 0; q0 < cnt; q0 += cap) {
-                    if (n_tickets >= kKcTickets) return GMSX_ERR_UNSUPPORTED;
                     const int64_t nq = std::min(cap, cnt - q0);
                     const int r = chunk_seq++ % n_regions;
                     hipStream_t st = r == 0 ? s : sides[r - 1];
@@ -2164,7 +2191,8 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
                     const int64_t first = lo + q0 * nparts, end = std::min(hi, lo + (q0 + nq) * nparts);
                     if (wpl > 0) {
                         constexpr int slab_threads = 1024;
-                        const size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(slab_threads / 64) * 4 * W * 4;  // bitmap + prefix + row stage
+                        const size_t lds = size_t(kBitmapWords) * 4 + size_t(kBitmapWords) * 2 + size_t(slab_threads / 64) * 4 * W * 4 +  // bitmap + prefix + row stage
+                                           ((size_t(dmax) * 2 + 15) & ~size_t(15));                                                            // + the forward list
                         const unsigned blocks = unsigned(std::min<int64_t>(nq, int64_t(cu)));  // (128 registers x 1024 threads: one workgroup per CU)
                         if (wpl == 1)
                             hipLaunchKernelGGL((k_kc_block<2, 1, true, false, 1, false, true>), dim3(blocks), dim3(slab_threads), lds, st, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
@@ -2183,11 +2211,13 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
                                            g->bmpool, g->dense_limit, g->order, first, end, nparts, part, dmax, W, W | 1, 0, static_cast<uint32_t *>(nullptr), acc, g->oldid,
                                            vcounts, rv, ex);
                     }
-                    const unsigned cgrid = unsigned(std::min<int64_t>(nq, int64_t(cu)));
+                    // teams of G workgroups of one XCD per matrix (kc4_mfma.hpp): the wider the matrices, the more of an XCD's CUs share one — measured on 1 024
+                    // matrices of d+ = 600 / 1 200 / 1 800 / 3 000: G = 1 / 2 / 4 / 8 are the fastest (0.092 / 0.220 / 0.717 / 1.46 ms; G = 1: 0.092 / 0.244 / 0.822 / 1.87)
+                    const int G = dmax <= kKcTriTwo ? 1 : dmax <= kKcTriTop ? 2 : dmax <= 2048 ? 4 : 8;
+                    const unsigned cgrid = unsigned(std::max(cu / (8 * G), 1) * 8 * G);  // (a multiple of 8 G; teams beyond the chunk's matrices leave at once)
                     // (Measured at scale 26 and dropped: 256- / 512-thread count workgroups, two or four per CU, with 512- / 768-thread BUILD workgroups beside them, so
                     //  that a count wave per SIMD fits next to the BUILD's — 504 … 545 against 489 ms: the two kernels slow each other more than the overlap gains.)
-                    hipLaunchKernelGGL((k_kc4_mfma<2, 1024>), dim3(cgrid), dim3(1024), 0, st, ex.pool, slot_words, ex.dpool, int(nq), pool.tickets + n_tickets, acc, kAccSlots, kAccStride);
-                    ++n_tickets;
+                    hipLaunchKernelGGL((k_kc4_mfma<2, 1024>), dim3(cgrid), dim3(1024), 0, st, ex.pool, slot_words, ex.dpool, int(nq), G, acc, kAccSlots, kAccStride);
                     *launches += 2;
                 }
                 return GMSX_OK;

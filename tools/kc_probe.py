@@ -1,5 +1,6 @@
 """GPU probe: k-clique count on RMAT scale(s) — count vs the reference golden, best-of-3 kernel time, lean upload time.
-usage: python tools/kc_probe.py 22 24 [--k 4] [--ab]     (--ab: every scale also with KC_REVERSE = 0, the forward-only BUILD of rounds 1-5)"""
+usage: python tools/kc_probe.py 22 24 [--k 4] [--ab]     (--ab: every scale also with KC_MFMA = 0, the k = 4 count by AND + popcount inside the BUILD kernels, and
+with KC_REVERSE = 0, the forward-only BUILD of rounds 1-5)"""
 import json
 import os
 import sys
@@ -30,7 +31,7 @@ for s in scales:
             os.replace(cache + ".tmp", cache)
         except (OSError, capi.GmsxError):
             pass
-    variants = [{}] + ([{"KC_REVERSE": 0}] if "--ab" in sys.argv else [])
+    variants = [{}] + ([{"KC_MFMA": 0}, {"KC_REVERSE": 0}] if "--ab" in sys.argv else [])
     if "--opts" in sys.argv:  # --opts "KC_REV_FACTOR=10;KC_REV_FACTOR=30,KC_REV_MIN=16": one more run per ';'-separated option set
         variants += [dict(kv.split("=") for kv in v.split(",") if kv) for v in sys.argv[sys.argv.index("--opts") + 1].split(";")]
     for opts in variants:

@@ -29,11 +29,9 @@ static unsigned long long host_count(const std::vector<uint32_t> &m, int d, int 
     return t;
 }
 
-template <int T, int NT, int DBG = 0>
-static void run(const char *name, const uint32_t *dpoolm, size_t slot_words, const int32_t *dd, int nmat, unsigned long long want, double macs, int gridmul = 1) {
-    int *ticket;
+template <int T, int NT, int DBG = 0, int PF = 1>
+static void run(const char *name, const uint32_t *dpoolm, size_t slot_words, const int32_t *dd, int nmat, unsigned long long want, double macs, int G = 1, int gridmul = 1) {
     unsigned long long *acc;
-    CK(hipMalloc(&ticket, 4));
     CK(hipMalloc(&acc, 64 * 16 * 8));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0));
@@ -42,9 +40,8 @@ static void run(const char *name, const uint32_t *dpoolm, size_t slot_words, con
     unsigned long long got = 0;
     for (int it = 0; it < 3; ++it) {
         CK(hipMemset(acc, 0, 64 * 16 * 8));
-        CK(hipMemset(ticket, 0, 4));
         CK(hipEventRecord(e0));
-        k_kc4_mfma<T, NT, DBG><<<256 * gridmul, NT>>>(dpoolm, slot_words, dd, nmat, ticket, acc, 64, 16);
+        k_kc4_mfma<T, NT, DBG, PF><<<256 * gridmul, NT>>>(dpoolm, slot_words, dd, nmat, G, acc, 64, 16);
         CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
         float ms;
@@ -55,8 +52,7 @@ static void run(const char *name, const uint32_t *dpoolm, size_t slot_words, con
         got = 0;
         for (auto x : h) got += x;
     }
-    printf("  %-22s %8.3f ms   sum %llu %s   %.0f T useful bit-MAC/s\n", name, best, got, got == want ? "OK" : "WRONG", macs / best / 1e9);
-    CK(hipFree(ticket));
+    printf("  %-18s G %2d %8.3f ms   sum %llu %s   %.0f T useful bit-MAC/s\n", name, G, best, got, got == want ? "OK" : "WRONG", macs / best / 1e9);
     CK(hipFree(acc));
 }
 
@@ -95,14 +91,12 @@ static void shape(int d, double dens, int nmat) {
     }
     CK(hipMemcpy(dd, hd.data(), size_t(nmat) * 4, hipMemcpyHostToDevice));
     printf("d = %d density %.2f, %d matrices (%.1f MB each)\n", d, dens, nmat, slot_words * 4 / 1e6);
-    run<4, 256>("4x4 wg256", pool, slot_words, dd, nmat, want, macs);
-    run<2, 256>("2x2 wg256 x2", pool, slot_words, dd, nmat, want, macs, 2);
-    run<2, 256>("2x2 wg256 x4", pool, slot_words, dd, nmat, want, macs, 4);
-    run<2, 512>("2x2 wg512", pool, slot_words, dd, nmat, want, macs);
-    run<2, 1024>("2x2 wg1024", pool, slot_words, dd, nmat, want, macs);
-    run<2, 1024, 1>("2x2 wg1024 noepi", pool, slot_words, dd, nmat, want, macs);
-    run<2, 1024, 2>("2x2 wg1024 chunk0", pool, slot_words, dd, nmat, want, macs);
-    run<2, 1024, 3>("2x2 wg1024 noexp", pool, slot_words, dd, nmat, want, macs);
+    for (int G : {1, 2, 4, 8, 16, 32}) run<2, 1024>("2x2 wg1024", pool, slot_words, dd, nmat, want, macs, G);
+    for (int G : {1, 8}) run<2, 512>("2x2 wg512", pool, slot_words, dd, nmat, want, macs, G);
+    for (int G : {1, 8}) run<2, 512>("2x2 wg512 x2", pool, slot_words, dd, nmat, want, macs, G, 2);
+    for (int G : {1, 8}) run<4, 256>("4x4 wg256", pool, slot_words, dd, nmat, want, macs, G);
+    run<2, 1024, 1>("2x2 wg1024 noepi", pool, slot_words, dd, nmat, want, macs, 8);
+    run<2, 1024, 3>("2x2 wg1024 noexp", pool, slot_words, dd, nmat, want, macs, 8);
     CK(hipFree(pool));
     CK(hipFree(dd));
 }
