@@ -1825,6 +1825,8 @@ __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ it
                 const uint16_t *row = hadj + (r.x & ((1ull << 40) - 1ull));
                 unsigned char *out = reinterpret_cast<unsigned char *>(arena + (r.y & ((1ull << 36) - 1ull)));
                 const int nbytes = rev_row_words(i) * 4, last = (i - 1) & ~7;  // i >= 1
+                // (round 6b, measured and dropped: two more units of a long prefix in flight behind the one being probed — 81.6 / 88.2 against 72.8 ms at scale 26,
+                //  always or only for prefixes beyond 128 ids: the kernel waits on its LDS probes, not on these loads)
                 for (int b = sub; b < nbytes; b += 16) {
                     const int p0 = b * 8;
                     const kc_u4u p = b == sub ? u0 : *reinterpret_cast<const kc_u4u *>(row + min(p0, last));  // (clamped: in bounds, its bits masked below)
