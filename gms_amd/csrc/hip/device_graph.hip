@@ -939,6 +939,9 @@ static void free_graph(gmsx_graph *g) {
     (void)hipFree(g->kc_arena);
     (void)hipFree(g->kc_rec);
     (void)hipFree(g->kc_item);
+    (void)hipFree(g->kc_relt);
+    (void)hipFree(g->kc_rect);
+    (void)hipFree(g->kc_itemt);
     (void)hipFree(g->scratch);
     (void)hipFree(g->acc);
     delete g;

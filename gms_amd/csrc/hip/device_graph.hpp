@@ -171,6 +171,13 @@ struct gmsx_graph {
     mutable ulonglong2 *kc_rec = nullptr;    // [kc_recs] one record per reverse edge, receiver by receiver: x = first id of the pivot's hub list in hadj (40 bits) | i << 40,
                                              //           y = arena word of the row (36 bits) | position of the pivot in `order` << 36 (what a shard is decided on)
     mutable uint4 *kc_item = nullptr;        // [kc_items] work items: x = receiver, y = entries, z | w << 32 = first record
+    // TAIL receivers (round 6b): a tail member w (rank id >= 65 535: no bitset container) takes its edges too — k_kc_reverse_tail builds w's bitmap and tail set
+    // in LDS from its two lists and streams the pivot's whole hub list and its tail members below w through them.  (With the matrix-core count the forward
+    // rows of the tail members were 206 of the 470 ms of a k = 4 call at scale 26.)
+    mutable uint32_t *kc_relt = nullptr;     // [toff[n]] per tail-entry position, as kc_rel
+    mutable ulonglong2 *kc_rect = nullptr;   // [2 kc_recst] two 16-byte halves per record: {hadj offset | i << 40, arena word | position << 36}, {tadj offset | hc << 40, 0}
+    mutable uint4 *kc_itemt = nullptr;       // [kc_itemst] work items of tail receivers
+    mutable int64_t kc_recst = 0, kc_itemst = 0;
     mutable int64_t kc_recs = 0, kc_items = 0, kc_arena_words = 0, kc_rev_bytes = 0;
     mutable double kc_rev_build_ms = 0.0;    // what building the lists took (reported once, in gmsx_stats.setup_ms of the call that built them)
     unsigned long long *scratch = nullptr;  // device: a few u64 accumulators

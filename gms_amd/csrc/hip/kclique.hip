@@ -43,7 +43,8 @@ struct __attribute__((packed, aligned(4))) kc_u4u { uint32_t x, y, z, w; };
 struct KcRev {
     const uint32_t *rel;    // per hub-entry position of hadj: word offset of the member's row inside its pivot's span, ~0u = forward
     const int64_t *aoff;    // per rank id: the pivot's span in the arena
-    const uint32_t *arena;  // rows written by k_kc_reverse earlier in the same call
+    const uint32_t *arena;  // rows written by k_kc_reverse / k_kc_reverse_tail earlier in the same call
+    const uint32_t *relt;   // the same per tail-entry position of tadj (TAIL receivers, round 6b); nullptr: every tail member is streamed forward
 };
 static constexpr uint32_t kKcRelForward = 0xffffffffu;
 // EXPORT (round 6; k = 4): the BUILD leaves the finished matrix of the pivot at position q of its launch in a pool (slot q, row stride kc4m_stride(d) words,
@@ -1078,7 +1079,10 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
         const int32_t *tail_list = tadj + tb;
         // reverse rows of this pivot's hub members (nullptr: none; ~0u per member: streamed forward)
         const uint32_t *rel_u = rv.rel ? rv.rel + hb : nullptr;
+        const uint32_t *relt_u = (rv.rel && rv.relt) ? rv.relt + tb : nullptr;
         const uint32_t *arow = rv.rel ? rv.arena + rv.aoff[u] : nullptr;
+        // where member i's finished row lies in the pivot's arena span (~0u: nowhere, it is streamed forward)
+        auto relat = [&](int i) -> uint32_t { return !rel_u ? kKcRelForward : i < hc ? rel_u[i] : relt_u ? relt_u[i - hc] : kKcRelForward; };
         // slab rows: stride WSr, Wr words written per row.  EXPORT: the slab is slot q of the pool in the layout k_kc4_mfma reads (stride kc4m_stride(d) <= W)
         int WSr = WS, Wr = W;
         if constexpr (kCanExport && GLOBAL_ROWS)
@@ -1132,7 +1136,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                 const int i = i0 + tid;
                 bool fw = false;
                 if (i < d && i > 0) {  // (row 0 is empty: nobody is below the first member)
-                    const uint32_t r = (rel_u && i < hc) ? rel_u[i] : kKcRelForward;
+                    const uint32_t r = relat(i);
                     if (r != kKcRelForward) {
                         if constexpr (!EXPORT) {
                             const uint32_t *src = arow + r;
@@ -1141,6 +1145,9 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                         }
                     } else {
                         fw = true;
+#ifdef GMSX_KC_NO_TAIL_MEMBERS  // A/B build (wrong counts): what the forward rows of the TAIL members cost (they cannot be receivers: no bitset container)
+                        fw = i < hc;
+#endif
                     }
                 }
                 const unsigned long long m = __ballot(fw);
@@ -1155,7 +1162,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                 uint4 *dst = reinterpret_cast<uint4 *>(rows);
                 for (int x = tid; x < d * q4; x += nthreads) {
                     const int i = x / q4, c = (x - i * q4) << 2;
-                    const uint32_t r = (rel_u && i < hc && i > 0) ? rel_u[i] : kKcRelForward;
+                    const uint32_t r = i > 0 ? relat(i) : kKcRelForward;
                     if (r == kKcRelForward && i > 0) continue;
                     const uint32_t *src = arow + r;
                     const int nw = i > 0 ? (i + 31) >> 5 : 0;
@@ -1184,7 +1191,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                         const int i = base + tid;
                         const bool is_hub = i < hc;
                         const int32_t v = is_hub ? int32_t(hub_list[i]) : tail_list[i - hc];
-                        const uint32_t r = (rel_u && is_hub) ? rel_u[i] : kKcRelForward;
+                        const uint32_t r = relat(i);
                         const bool skip = r != kKcRelForward || i == 0;  // the row comes from the arena (copied here, by this one thread: the step stream is not the default BUILD) or is empty
                         if (r != kKcRelForward)
                             for (int t = 0; t < ((i + 31) >> 5); ++t) rows[size_t(i) * WS + t] = arow[r + t];
@@ -1232,7 +1239,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                 // are two cached loads and its "row" is empty, so every stage is a no-op for it.  LDS matrices walk the forward list only (pass 1 above).
                 const int K = kUseFwd ? nfwd : d;  // positions to walk
                 auto at = [&](int k) -> int { return !kUseFwd ? min(k, d - 1) : (nfwd > 0 ? int(fwd[min(k, nfwd - 1)]) : 0); };  // position -> member index (clamped)
-                auto relof = [&](int i) -> uint32_t { return (!kUseFwd && rel_u && i < hc) ? rel_u[i] : kKcRelForward; };
+                auto relof = [&](int i) -> uint32_t { return !kUseFwd ? relat(i) : kKcRelForward; };
                 auto piped = [&](int i, uint32_t r) -> int32_t { return (r != kKcRelForward || i == 0) ? 0 : member(i); };
                 // the pipeline (kc_load_ext / kc_load_first above): ids three members ahead, extents two, first units one
                 const int kg = wave * 4 + grp;
@@ -1318,7 +1325,7 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                     uint4 *dst = reinterpret_cast<uint4 *>(ex.pool + size_t(q) * size_t(ex.slot_words));
                     for (int x = tid; x < d * q4; x += nthreads) {
                         const int i = x / q4, c = (x - i * q4) << 2;
-                        const uint32_t r = (rel_u && i < hc && i > 0) ? rel_u[i] : kKcRelForward;  // (a row of the arena never went through LDS)
+                        const uint32_t r = i > 0 ? relat(i) : kKcRelForward;  // (a row of the arena never went through LDS)
                         const uint32_t *src = r != kKcRelForward ? arow + r : rows + kc_tri_off(i);
                         const int nw = r != kKcRelForward ? (i + 31) >> 5 : (i >> 5) + 1;
                         uint4 v;
@@ -1706,13 +1713,25 @@ __device__ __forceinline__ bool rev_is_cheaper(const int64_t *__restrict__ hoff,
     const int rev = 2 * i + 16 + 8 * rev_row_words(i) + 32;
     return factor10 * rev < 10 * fwd;  // (factor10 = 20: handed over when at least twice cheaper; 1, the default: unless ten times dearer)
 }
+// the TAIL receivers' side of the three passes (tl.rcnt == nullptr: none): counters by rank id - H
+struct KcrTail {
+    const int64_t *toff;
+    const int32_t *tadj;
+    int32_t H;
+    int min_edges;
+    uint32_t *relt;         // [toff[n]]
+    uint32_t *rcnt, *rcur;  // [n - H]
+    const int64_t *roff;    // [n - H + 1] (pass 3)
+    ulonglong2 *rec;        // two halves per record (pass 3)
+};
+static constexpr int kRevTailMaxI = 2048;  // a tail record's row is assembled in 64 words of LDS per group (wider pivots have next to no tail members)
 // pass 1 (MODE 0): mark the candidate edges (kc_rel = 0 / ~0) and count them per receiver.  pass 2 (MODE 1): the arena words of every pivot (the edges whose
 // receiver takes them).  pass 3 (MODE 2): relative offsets into kc_rel, records to the receivers.  One 16-lane group per pivot position of the d+ order.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_kcr_edges(int64_t n_piv, const int32_t *__restrict__ order, const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj,
                                                    int32_t dense_limit, int min_edges, int factor10, uint32_t *__restrict__ rel, uint32_t *__restrict__ rcnt,
                                                    int64_t *__restrict__ words /* by rank id */, const int64_t *__restrict__ aoff, const int64_t *__restrict__ roff,
-                                                   uint32_t *__restrict__ rcur, ulonglong2 *__restrict__ rec) {
+                                                   uint32_t *__restrict__ rcur, ulonglong2 *__restrict__ rec, KcrTail tl) {
     const int sub = threadIdx.x & 15;
     const int64_t g0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 4, ng = (int64_t(gridDim.x) * blockDim.x) >> 4;
     for (int64_t pos = g0; pos < n_piv; pos += ng) {
@@ -1757,16 +1776,70 @@ __global__ __launch_bounds__(256) void k_kcr_edges(int64_t n_piv, const int32_t 
                 run += tot;
             }
         }
+        // … and the tail members: member i = hc + k is handed to its receiver whenever that one qualifies (its row would be streamed forward through the
+        // pivot's bitmap AND tail set; the receiver streams hc + k ids).  Same arena span, behind the hub members' rows.
+        if (tl.rcnt) {
+            const int64_t tb = tl.toff[u];
+            const int tc = int(tl.toff[u + 1] - tb);
+            for (int k0 = 0; k0 < tc; k0 += 16) {
+                const int k = k0 + sub, i = hc + k;
+                bool take = false;
+                int32_t w = 0;
+                if (k < tc) {
+                    w = tl.tadj[tb + k];
+                    if (MODE == 0) {
+                        take = i >= 1 && i < kRevTailMaxI;
+                        tl.relt[tb + k] = take ? 0u : kRelForward;
+                        if (take) atomicAdd(&tl.rcnt[w - tl.H], 1u);
+                    } else {
+                        take = tl.relt[tb + k] != kRelForward && tl.rcnt[w - tl.H] >= uint32_t(tl.min_edges);
+                    }
+                }
+                if (MODE >= 1) {
+                    int wi = take ? rev_row_words(i) : 0, pre = wi;
+#pragma unroll
+                    for (int sft = 1; sft < 16; sft <<= 1) {
+                        const int t = __shfl_up(pre, sft, 16);
+                        if (sub >= sft) pre += t;
+                    }
+                    const int tot = __shfl(pre, 15, 16);
+                    if (MODE == 2 && k < tc) {
+                        const int64_t r = run + pre - wi;
+                        tl.relt[tb + k] = take ? uint32_t(r) : kRelForward;
+                        if (take) {
+                            const uint32_t slot = atomicAdd(&tl.rcur[w - tl.H], 1u);
+                            ulonglong2 e0, e1;
+                            e0.x = (unsigned long long)hb | ((unsigned long long)i << 40);
+                            e0.y = (unsigned long long)(aoff[u] + r) | ((unsigned long long)pos << 36);
+                            e1.x = (unsigned long long)tb | ((unsigned long long)hc << 40);
+                            e1.y = 0ull;
+                            const int64_t at = 2 * (tl.roff[w - tl.H] + slot);
+                            tl.rec[at] = e0;
+                            tl.rec[at + 1] = e1;
+                        }
+                    }
+                    run += tot;
+                }
+            }
+        }
         if (MODE == 1 && sub == 0) words[u] = run;
     }
 }
-__global__ void k_kcr_items(int32_t H, const int64_t *__restrict__ roff, const int64_t *__restrict__ ioff, uint4 *__restrict__ items) {
-    const int32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+// tail receivers: accepted records and work items per receiver (device-side: there can be millions of them)
+__global__ void k_kcr_tail_sizes(int64_t nt, const uint32_t *__restrict__ rcnt, int min_edges, int64_t *__restrict__ recs, int64_t *__restrict__ items) {
+    const int64_t x = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (x > nt) return;
+    const int64_t a = (x < nt && rcnt[x] >= uint32_t(min_edges)) ? int64_t(rcnt[x]) : 0;
+    recs[x] = a;
+    items[x] = (a + kRevItem - 1) / kRevItem;
+}
+__global__ void k_kcr_items(int64_t H, const int64_t *__restrict__ roff, const int64_t *__restrict__ ioff, uint4 *__restrict__ items, int32_t base) {
+    const int64_t w = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // receiver base + w
     if (w >= H) return;
     const int64_t first = roff[w], cnt = roff[w + 1] - first, i0 = ioff[w];
     for (int64_t t = 0; t * kRevItem < cnt; ++t) {
         const int64_t f = first + t * kRevItem;
-        items[i0 + t] = make_uint4(uint32_t(w), uint32_t(min<int64_t>(kRevItem, cnt - t * kRevItem)), uint32_t(f), uint32_t(f >> 32));
+        items[i0 + t] = make_uint4(uint32_t(base + w), uint32_t(min<int64_t>(kRevItem, cnt - t * kRevItem)), uint32_t(f), uint32_t(f >> 32));
     }
 }
 // Which shard a pivot belongs to: the pivots' kernels stride over the positions of THEIR BIN — position lo + q * nparts + part of the d+ order, lo = where the
@@ -1844,6 +1917,131 @@ __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ it
     }
 }
 
+// … the same for TAIL receivers (rank id >= 65 535: no bitset container).  Per work item the receiver's own two lists become its LDS images — the hub part a
+// 65 536-bit bitmap (atomic ORs), the tail part a 16 384-bit hash filter in front of a sorted copy (binary search only behind a filter hit; a list too long for
+// its 4 KB is searched where it lies) — and a 16-lane group per record assembles the row in its 256 bytes of LDS: the pivot's WHOLE hub list streamed through the
+// bitmap (every hub member lies below a tail member), one byte per lane and step as above; then the pivot's tail members below the receiver, one id per lane
+// and step, a set bit per find; then the row leaves for the arena.  Three records in flight per group, as above: the record of entry e + 32, the first hub
+// unit and the first tail id of entry e + 16, the probes of entry e (first version, every load behind its record: 230 ms at scale 26 for 363 M records).
+static constexpr int kRevTailList = 1024, kRevTailFilterWords = 512;
+__device__ __forceinline__ uint32_t kcr_tail_hash(int32_t id) { return (uint32_t(id) * 0x9E3779B1u) >> 18; }  // 14 bits
+__global__ __launch_bounds__(256) void k_kc_reverse_tail(const uint4 *__restrict__ items, int64_t n_items, const ulonglong2 *__restrict__ rec, const int64_t *__restrict__ hoff,
+                                                         const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
+                                                         uint32_t *__restrict__ arena, int nparts, int part, KcBins bins, unsigned int *__restrict__ queue) {
+    __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords];
+    __shared__ __attribute__((aligned(16))) uint32_t flt[kRevTailFilterWords];
+    __shared__ int32_t tl[kRevTailList];
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[16][kRevTailMaxI / 32];
+    __shared__ unsigned int s_item;
+    const int tid = threadIdx.x, grp = tid >> 4, sub = tid & 15;
+    while (true) {
+        __syncthreads();  // the previous item's probes are done with bm / flt / tl
+        if (tid == 0) s_item = atomicAdd(queue, 1u);
+        __syncthreads();
+        const int64_t it = s_item;
+        if (it >= n_items) break;
+        const uint4 item = items[it];
+        const int32_t w = int32_t(item.x);
+        const int cnt = int(item.y);
+        const int64_t first = int64_t(item.z) | (int64_t(item.w) << 32);
+        const int64_t whb = hoff[w], wtb = toff[w];
+        const int whl = int(hoff[w + 1] - whb), wtl = int(toff[w + 1] - wtb);
+        for (int t = tid; t < kBitmapWords / 4; t += 256) reinterpret_cast<uint4 *>(bm)[t] = make_uint4(0u, 0u, 0u, 0u);
+        if (tid < kRevTailFilterWords / 4) reinterpret_cast<uint4 *>(flt)[tid] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        for (int t = tid; t < whl; t += 256) {
+            const uint32_t id = hadj[whb + t];  // (a padding id 0xFFFF sets a bit no pivot's hub list asks for)
+            atomicOr(&bm[id >> 5], 1u << (id & 31u));
+        }
+        const bool tl_lds = wtl <= kRevTailList;
+        for (int t = tid; t < wtl; t += 256) {
+            const int32_t id = tadj[wtb + t];
+            if (tl_lds) tl[t] = id;
+            const uint32_t hsh = kcr_tail_hash(id);
+            atomicOr(&flt[hsh >> 5], 1u << (hsh & 31u));
+        }
+        __syncthreads();
+        const int32_t *tlist = tadj + wtb;
+        uint32_t *rb = rowbuf[grp];
+        unsigned char *rbb = reinterpret_cast<unsigned char *>(rb);
+        const int e_last = cnt - 1;
+        // stage 2 of an entry: its first hub unit and its first tail id (clamped: in bounds, masked / skipped below)
+        auto first_unit = [&](const ulonglong2 &a, const ulonglong2 &b) -> kc_u4u {
+            const int hc = int(b.x >> 40);
+            return *reinterpret_cast<const kc_u4u *>(hadj + (hc > 0 ? (a.x & ((1ull << 40) - 1ull)) : 0ull) + min(sub * 8, max(hc - 1, 0) & ~7));  // (no hub member: any unit)
+        };
+        auto first_tail = [&](const ulonglong2 &a, const ulonglong2 &b) -> int32_t {
+            const int k = int(a.x >> 40) - int(b.x >> 40);
+            return tadj[(b.x & ((1ull << 40) - 1ull)) + min(sub, max(k - 1, 0))];
+        };
+        int64_t e0i = first + min(grp, e_last), e1i = first + min(grp + 16, e_last);
+        ulonglong2 a0 = rec[2 * e0i], b0 = rec[2 * e0i + 1], a1 = rec[2 * e1i], b1 = rec[2 * e1i + 1];
+        kc_u4u u0 = first_unit(a0, b0);
+        int32_t t0 = first_tail(a0, b0);
+        for (int e = grp; e < cnt; e += 16) {
+            const int64_t e2i = first + min(e + 32, e_last);
+            const ulonglong2 a2 = rec[2 * e2i], b2 = rec[2 * e2i + 1];
+            const kc_u4u u1 = first_unit(a1, b1);
+            const int32_t t1 = first_tail(a1, b1);
+            const bool mine = nparts <= 1 || bins.part_of(int64_t(a0.y >> 36), nparts) == part;  // (another rank's pivot: skipped)
+            if (mine) {
+                const int i = int(a0.x >> 40), hc = int(b0.x >> 40), k = i - hc;  // member i = hc + k of its pivot
+                const uint16_t *hrow = hadj + (a0.x & ((1ull << 40) - 1ull));
+                const int32_t *trow = tadj + (b0.x & ((1ull << 40) - 1ull));
+                const int nwords = rev_row_words(i);
+                for (int t = sub; t < nwords; t += 16) rb[t] = 0u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // hub columns [0, hc): 8 ids per lane and step -> one byte of the row
+                const int hbytes = (hc + 7) >> 3, last = (hc - 1) & ~7;
+                for (int b = sub; b < hbytes; b += 16) {
+                    const int p0 = b * 8;
+                    const kc_u4u p = b == sub ? u0 : *reinterpret_cast<const kc_u4u *>(hrow + min(p0, last));
+                    uint32_t m = kc_bit_lo(bm, p.x) | (kc_bit_hi(bm, p.x) << 1) | (kc_bit_lo(bm, p.y) << 2) | (kc_bit_hi(bm, p.y) << 3) | (kc_bit_lo(bm, p.z) << 4) |
+                                 (kc_bit_hi(bm, p.z) << 5) | (kc_bit_lo(bm, p.w) << 6) | (kc_bit_hi(bm, p.w) << 7);
+                    const int valid = hc - p0;  // (>= 1)
+                    m = valid >= 8 ? m : (m & ((1u << valid) - 1u));
+                    rbb[b] = (unsigned char)m;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // tail columns [hc, i): the pivot's tail members below the receiver: filter bit, then the receiver's sorted tail list
+                for (int q = sub; q < k; q += 16) {
+                    const int32_t id = q == sub ? t0 : trow[q];
+                    const uint32_t hsh = kcr_tail_hash(id);
+                    if ((flt[hsh >> 5] >> (hsh & 31u)) & 1u) {
+                        int lo = 0, hi = wtl;
+                        if (tl_lds) {
+                            while (lo < hi) {
+                                const int mid = (lo + hi) >> 1;
+                                if (tl[mid] < id) lo = mid + 1; else hi = mid;
+                            }
+                            if (lo < wtl && tl[lo] == id) atomicOr(&rb[(hc + q) >> 5], 1u << ((hc + q) & 31));
+                        } else {
+                            while (lo < hi) {
+                                const int mid = (lo + hi) >> 1;
+                                if (tlist[mid] < id) lo = mid + 1; else hi = mid;
+                            }
+                            if (lo < wtl && tlist[lo] == id) atomicOr(&rb[(hc + q) >> 5], 1u << ((hc + q) & 31));
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                uint32_t *out = arena + (a0.y & ((1ull << 36) - 1ull));
+                for (int t = sub; t < nwords; t += 16) out[t] = rb[t];
+            }
+            a0 = a1; b0 = b1;
+            a1 = a2; b1 = b2;
+            u0 = u1;
+            t0 = t1;
+        }
+    }
+}
+
 // builds the lists above for the graph (once); leaves kc_rel == nullptr when no receiver qualifies or the option KC_REVERSE = 0 says no
 static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     if (g->kc_rev_tried) return GMSX_OK;
@@ -1865,6 +2063,7 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     const int32_t H = g->dense_limit;
     struct Dev { void *p = nullptr; ~Dev() { (void)hipFree(p); } };
     Dev d_rel, d_rcnt, d_words, d_aoff, d_roff, d_ioff, d_rec, d_item;
+    Dev d_relt, d_rcntt, d_sizes, d_rect, d_itemt;  // tail receivers (option KC_REV_TAIL = 0: none)
     auto fail = [&](int rc) { return rc; };
     if (hipMalloc(&d_rel.p, size_t(hub_total) * 4) != hipSuccess || hipMalloc(&d_rcnt.p, size_t(H + 1) * 4 * 2) != hipSuccess ||
         hipMalloc(&d_words.p, size_t(g->n + 1) * 8) != hipSuccess || hipMalloc(&d_aoff.p, size_t(g->n + 1) * 8) != hipSuccess) {
@@ -1878,14 +2077,32 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     GMSX_HIP(hipMemsetAsync(words, 0, size_t(g->n + 1) * 8, s));
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
     const int min_edges = int(std::max<long long>(1, opt_int("KC_REV_MIN", kRevMinEdges)));  // (option: a lower threshold lets small test graphs hand edges over)
+    // tail receivers: rank ids [H, n)
+    const int64_t nt = g->n - int64_t(H);
+    int64_t tail_total = 0;
+    GMSX_HIP(hipMemcpyAsync(&tail_total, g->toff + g->n, 8, hipMemcpyDeviceToHost, s));
+    GMSX_HIP(hipStreamSynchronize(s));
+    KcrTail tl{g->toff, g->tadj, H, int(std::max<long long>(1, opt_int("KC_REV_TAIL_MIN", 16))), nullptr, nullptr, nullptr, nullptr, nullptr};
+    const bool want_tail = nt > 0 && tail_total > 0 && !(opt("KC_REV_TAIL") && std::atoi(opt("KC_REV_TAIL")) == 0);
+    if (want_tail) {
+        if (hipMalloc(&d_relt.p, size_t(tail_total) * 4) == hipSuccess && hipMalloc(&d_rcntt.p, size_t(nt) * 4 * 2) == hipSuccess) {
+            tl.relt = static_cast<uint32_t *>(d_relt.p);
+            tl.rcnt = static_cast<uint32_t *>(d_rcntt.p);
+            tl.rcur = tl.rcnt + nt;
+            GMSX_HIP(hipMemsetAsync(tl.relt, 0xff, size_t(tail_total) * 4, s));
+            GMSX_HIP(hipMemsetAsync(tl.rcnt, 0, size_t(nt) * 8, s));
+        } else {
+            (void)hipGetLastError();  // no room: the tail members stay forward
+        }
+    }
     // (option: 10 x how much cheaper in BYTES the reverse side must be.  Default 1 — handed over unless it moves ten times the bytes — since the matrix-core count:
     //  a forward row's hits are resolved bit by bit (prefix popcount + LDS atomic, divergent per lane), a reverse row costs one LDS probe per prefix id, and
     //  with the count off the clock the BUILD is what a call waits for.  20 -> 1 at scales 22 / 24 / 26: 13.6 -> 11.3, 70.0 -> 59.3, 496 -> 470 ms, for lists + arena
     //  of 31.3 instead of 13.4 GB at scale 26 and 69 instead of 34 ms of one-off list build)
     const int factor10 = int(std::max<long long>(1, opt_int("KC_REV_FACTOR", 1)));
     const unsigned blocks = unsigned(std::min<int64_t>((n_piv + 15) / 16, int64_t(cu) * 32));
-    hipLaunchKernelGGL(k_kcr_edges<0>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, nullptr, nullptr, rcur, nullptr);
-    hipLaunchKernelGGL(k_kcr_edges<1>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, nullptr, nullptr, rcur, nullptr);
+    hipLaunchKernelGGL(k_kcr_edges<0>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, nullptr, nullptr, rcur, nullptr, tl);
+    hipLaunchKernelGGL(k_kcr_edges<1>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, nullptr, nullptr, rcur, nullptr, tl);
     GMSX_HIP(hipGetLastError());
     if (int rc = exclusive_scan_i64(words, aoff, g->n + 1, s)) return rc;
     // the receivers' side on the host: at most 65 535 counters
@@ -1905,12 +2122,36 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     }
     h_roff[size_t(H)] = recs;
     h_ioff[size_t(H)] = items;
-    if (recs == 0 || arena_words <= 0 || arena_words >= (int64_t(1) << 36)) return GMSX_OK;  // nothing worth handing over (small or flat graphs)
+    // the tail receivers' side on the device: sizes -> two scans (records, work items)
+    int64_t recs_t = 0, items_t = 0;
+    int64_t *rofft = nullptr, *iofft = nullptr;
+    if (tl.rcnt) {
+        if (hipMalloc(&d_sizes.p, size_t(nt + 1) * 8 * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            return GMSX_OK;
+        }
+        int64_t *sz_r = static_cast<int64_t *>(d_sizes.p), *sz_i = sz_r + (nt + 1);
+        rofft = sz_i + (nt + 1);
+        iofft = rofft + (nt + 1);
+        hipLaunchKernelGGL(k_kcr_tail_sizes, dim3(unsigned((nt + 1 + 255) / 256)), dim3(256), 0, s, nt, tl.rcnt, tl.min_edges, sz_r, sz_i);
+        GMSX_HIP(hipGetLastError());
+        if (int rc = exclusive_scan_i64(sz_r, rofft, nt + 1, s)) return rc;
+        if (int rc = exclusive_scan_i64(sz_i, iofft, nt + 1, s)) return rc;
+        GMSX_HIP(hipMemcpyAsync(&recs_t, rofft + nt, 8, hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipMemcpyAsync(&items_t, iofft + nt, 8, hipMemcpyDeviceToHost, s));
+        GMSX_HIP(hipStreamSynchronize(s));
+        tl.roff = rofft;
+    }
+    if (recs + recs_t == 0 || arena_words <= 0 || arena_words >= (int64_t(1) << 36)) return GMSX_OK;  // nothing worth handing over (small or flat graphs)
     if (hipMalloc(&d_roff.p, size_t(H + 1) * 8) != hipSuccess || hipMalloc(&d_ioff.p, size_t(H + 1) * 8) != hipSuccess ||
-        hipMalloc(&d_rec.p, size_t(recs) * sizeof(ulonglong2)) != hipSuccess || hipMalloc(&d_item.p, size_t(items) * sizeof(uint4)) != hipSuccess) {
+        hipMalloc(&d_rec.p, size_t(std::max<int64_t>(recs, 1)) * sizeof(ulonglong2)) != hipSuccess ||
+        hipMalloc(&d_item.p, size_t(std::max<int64_t>(items, 1)) * sizeof(uint4)) != hipSuccess ||
+        hipMalloc(&d_rect.p, size_t(std::max<int64_t>(recs_t, 1)) * 2 * sizeof(ulonglong2)) != hipSuccess ||
+        hipMalloc(&d_itemt.p, size_t(std::max<int64_t>(items_t, 1)) * sizeof(uint4)) != hipSuccess) {
         (void)hipGetLastError();
         return GMSX_OK;
     }
+    tl.rec = static_cast<ulonglong2 *>(d_rect.p);
     uint32_t *arena = nullptr;
     if (hipMalloc(reinterpret_cast<void **>(&arena), size_t(arena_words) * 4 + 64) != hipSuccess) {
         (void)hipGetLastError();
@@ -1922,10 +2163,19 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     GMSX_HIP(hipMemcpyAsync(roff, h_roff.data(), size_t(H + 1) * 8, hipMemcpyHostToDevice, s));
     GMSX_HIP(hipMemcpyAsync(ioff, h_ioff.data(), size_t(H + 1) * 8, hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_kcr_edges<2>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, aoff, roff, rcur,
-                       static_cast<ulonglong2 *>(d_rec.p));
-    hipLaunchKernelGGL(k_kcr_items, dim3(unsigned((H + 255) / 256)), dim3(256), 0, s, H, roff, ioff, static_cast<uint4 *>(d_item.p));
+                       static_cast<ulonglong2 *>(d_rec.p), tl);
+    hipLaunchKernelGGL(k_kcr_items, dim3(unsigned((H + 255) / 256)), dim3(256), 0, s, int64_t(H), roff, ioff, static_cast<uint4 *>(d_item.p), int32_t(0));
+    if (tl.rcnt && items_t > 0)
+        hipLaunchKernelGGL(k_kcr_items, dim3(unsigned((nt + 255) / 256)), dim3(256), 0, s, nt, rofft, iofft, static_cast<uint4 *>(d_itemt.p), int32_t(H));
     GMSX_HIP(hipGetLastError());
     GMSX_HIP(hipStreamSynchronize(s));
+    if (tl.rcnt && recs_t > 0) {
+        g->kc_relt = tl.relt; d_relt.p = nullptr;
+        g->kc_rect = tl.rec; d_rect.p = nullptr;
+        g->kc_itemt = static_cast<uint4 *>(d_itemt.p); d_itemt.p = nullptr;
+        g->kc_recst = recs_t;
+        g->kc_itemst = items_t;
+    }
     g->kc_rel = rel; d_rel.p = nullptr;
     g->kc_aoff = aoff; d_aoff.p = nullptr;
     g->kc_arena = arena; d_arena.p = nullptr;
@@ -1935,22 +2185,31 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     g->kc_items = items;
     g->kc_arena_words = arena_words;
     g->kc_rev_bytes = hub_total * 4 + (g->n + 1) * 8 + arena_words * 4 + 64 + recs * int64_t(sizeof(ulonglong2)) + items * int64_t(sizeof(uint4));
+    if (g->kc_relt) g->kc_rev_bytes += tail_total * 4 + recs_t * 2 * int64_t(sizeof(ulonglong2)) + items_t * int64_t(sizeof(uint4));
     const_cast<gmsx_graph *>(g)->device_bytes += g->kc_rev_bytes;
     g->kc_rev_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     if (opt_on("TIMING"))
-        std::fprintf(stderr, "[gmsx kclique] reverse rows: %lld of the hub edges of %lld pivots handed to %lld work items of hub receivers, arena %.3f GB, lists %.3f GB, built in %.1f ms\n",
-                     (long long)recs, (long long)n_piv, (long long)items, double(arena_words) * 4e-9, double(g->kc_rev_bytes - arena_words * 4) * 1e-9, g->kc_rev_build_ms);
+        std::fprintf(stderr, "[gmsx kclique] reverse rows: %lld of the hub edges of %lld pivots handed to %lld work items of hub receivers, %lld tail edges to %lld work items of tail receivers, arena %.3f GB, lists %.3f GB, built in %.1f ms\n",
+                     (long long)recs, (long long)n_piv, (long long)items, (long long)recs_t, (long long)items_t, double(arena_words) * 4e-9, double(g->kc_rev_bytes - arena_words * 4) * 1e-9, g->kc_rev_build_ms);
     return GMSX_OK;
 }
 // the receivers' pass of one call (inside the timed region, ahead of the pivots' kernels)
 static int launch_kc_reverse(const gmsx_graph *g, int part, int nparts, const KcBins &bins, unsigned long long *acc, int *launches, hipStream_t s) {
-    if (!g->kc_rel || g->kc_items <= 0) return GMSX_OK;
+    if (!g->kc_rel || (g->kc_items <= 0 && g->kc_itemst <= 0)) return GMSX_OK;
     Ctx &c = ctx();
     unsigned int *queue = reinterpret_cast<unsigned int *>(acc + (kAccSlots - 1) * kAccStride + 8);  // a spare word of the accumulator array (zeroed by the caller)
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
     const unsigned blocks = unsigned(std::min<int64_t>(g->kc_items, int64_t(cu) * 8));
-    hipLaunchKernelGGL(k_kc_reverse, dim3(blocks), dim3(256), 0, s, g->kc_item, g->kc_items, g->kc_rec, g->bmoff, g->bmpool, g->hadj, g->kc_arena, nparts, part, bins, queue);
-    ++*launches;
+    if (g->kc_items > 0) {
+        hipLaunchKernelGGL(k_kc_reverse, dim3(blocks), dim3(256), 0, s, g->kc_item, g->kc_items, g->kc_rec, g->bmoff, g->bmpool, g->hadj, g->kc_arena, nparts, part, bins, queue);
+        ++*launches;
+    }
+    if (g->kc_relt && g->kc_itemst > 0) {
+        const unsigned blocks_t = unsigned(std::min<int64_t>(g->kc_itemst, int64_t(cu) * 8));
+        hipLaunchKernelGGL(k_kc_reverse_tail, dim3(blocks_t), dim3(256), 0, s, g->kc_itemt, g->kc_itemst, g->kc_rect, g->hoff, g->hadj, g->toff, g->tadj, g->kc_arena, nparts, part, bins,
+                           queue + 1);
+        ++*launches;
+    }
     return GMSX_OK;
 }
 
@@ -2106,8 +2365,8 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             if (int rc = add(m_dmax[b])) return rc;
     }
     if (int rc = launch_kc_reverse(g, part, nparts, bins, acc, launches, rev_stream)) return rc;
-    const KcRev rv{g->kc_rel, g->kc_aoff, g->kc_arena};
-    if (g->kc_rel && g->kc_items > 0 && n_streams > 1) {
+    const KcRev rv{g->kc_rel, g->kc_aoff, g->kc_arena, g->kc_relt};
+    if (g->kc_rel && (g->kc_items > 0 || g->kc_itemst > 0) && n_streams > 1) {
         GMSX_HIP(hipEventRecord(ev_rev, rev_stream));
         GMSX_HIP(hipStreamWaitEvent(s, ev_rev, 0));
         for (int i = 0; i + 2 < kSides; ++i) GMSX_HIP(hipStreamWaitEvent(sides[i], ev_rev, 0));
@@ -2356,8 +2615,8 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
 // or 512 when the count runs on the matrix cores) writes its d x d bit-matrix to global memory and reads it back once.  One wave per pivot.
 __global__ __launch_bounds__(256) void k_stat_kc_bytes(int64_t n_min, int nparts, int part, const int32_t *__restrict__ order, const int32_t *__restrict__ dplus,
                                                      const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff,
-                                                     const int32_t *__restrict__ tadj, int32_t dense_limit, const uint32_t *__restrict__ rel, int slab_from,
-                                                     unsigned long long *__restrict__ out) {
+                                                     const int32_t *__restrict__ tadj, int32_t dense_limit, const uint32_t *__restrict__ rel, const uint32_t *__restrict__ relt,
+                                                     int slab_from, unsigned long long *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6, nwaves = (int64_t(gridDim.x) * blockDim.x) >> 6;
     unsigned long long b = 0;
@@ -2381,6 +2640,8 @@ __global__ __launch_bounds__(256) void k_stat_kc_bytes(int64_t n_min, int nparts
             else if (d > 32 && i == 0) b += 0ull;  // the first member has nobody below it: not streamed
             else if (is_hub && rel && rel[hb + i] != 0xffffffffu)  // a reverse row: the prefix streamed at the receiver, its record, the row written and read back
                 b += 2ull * (unsigned long long)i + 16ull + 8ull * (unsigned long long)((i + 31) >> 5);
+            else if (!is_hub && relt && relt[tb + (i - hc)] != 0xffffffffu)  // … of a tail receiver: the whole hub list + the tail members below it, a 32-byte record, the row
+                b += 2ull * (unsigned long long)hc + 4ull * (unsigned long long)(i - hc) + 32ull + 8ull * (unsigned long long)((i + 31) >> 5);
             else if (is_hub && v < dense_limit && int(bitset_words(v)) * 4 + 32 < hl * 2) b += 4ull * (unsigned long long)bitset_words(v);
             else {
                 if (hc > 0) b += 2ull * (unsigned long long)hl;
@@ -2448,7 +2709,7 @@ static int kclique_partial(const gmsx_graph *g, int k, int part, int nparts, uin
             GMSX_HIP(hipMemsetAsync(acc, 0, 8, s));
             const int cu = c.compute_units > 0 ? c.compute_units : 256;
             hipLaunchKernelGGL(k_stat_kc_bytes, dim3(unsigned(cu * 8)), dim3(256), 0, s, n_min, nparts, part, g->order, g->dplus, g->hoff, g->hadj, g->toff, g->tadj,
-                               g->dense_limit, g->kc_rel, (k == 4 && kc_tri_enabled()) ? ((kc_mfma_enabled() && kc_pool().base) ? 512 : kKcTriTop) : 1024, acc);
+                               g->dense_limit, g->kc_rel, g->kc_relt, (k == 4 && kc_tri_enabled()) ? ((kc_mfma_enabled() && kc_pool().base) ? 512 : kKcTriTop) : 1024, acc);
             GMSX_HIP(hipMemcpyAsync(&alg, acc, 8, hipMemcpyDeviceToHost, s));
             GMSX_HIP(hipStreamSynchronize(s));
         }

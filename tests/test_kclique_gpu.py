@@ -276,7 +276,7 @@ def test_reverse_rows_equal_forward_rows(gpu, oracle, rev_min):
             for k in (4, 3, 5, 6):
                 ordered, cliques, st = g.kclique_count(k, stats=True)
                 assert (ordered, cliques) == want[k][:2], (kind, scale, deg, hub_limit, k, rev_min)
-                assert st["stream_bytes"] <= want[k][2]["stream_bytes"], (kind, scale, k)   # handing an edge over never costs more bytes than streaming it
+                assert st["stream_bytes"] > 0
             assert np.array_equal(g.tc_vertex_count2(), vc0)
             # shards on a FRESH upload each (an arena that a whole-graph call filled before would hide a receiver pass that skips the wrong pivots:
             # the ranks of a multi-GPU run are separate processes that only ever run their own shard)
@@ -287,6 +287,19 @@ def test_reverse_rows_equal_forward_rows(gpu, oracle, rev_min):
                     total += gs.kclique_partial(4, p_, nparts)
                     gs.free()
                 assert total == want[4][1], (kind, scale, deg, hub_limit, nparts, rev_min)
+            # under the BYTE rule of rounds 6a (hub receivers only, handed over when at least twice cheaper) handing an edge over never costs more bytes than
+            # streaming it; the default since 6b prices the resolution of a forward row's hits too and hands over up to ten times the bytes
+            with gpu.options(KC_REV_MIN=rev_min, KC_REV_FACTOR=20, KC_REV_TAIL=0):
+                gb = gpu.DeviceGraph.from_csr(csr, flags=flags)
+                ordered, cliques, st = gb.kclique_count(4, stats=True)
+                assert (ordered, cliques) == want[4][:2] and st["stream_bytes"] <= want[4][2]["stream_bytes"], (kind, scale, rev_min)
+                gb.free()
+            with gpu.options(KC_REV_MIN=rev_min, KC_REV_TAIL_MIN=1):   # every tail member that can be handed over is
+                gt = gpu.DeviceGraph.from_csr(csr, flags=flags)
+                for k in (4, 5):
+                    assert gt.kclique_count(k)[:2] == want[k][:2], (kind, scale, deg, hub_limit, k, rev_min, "tail receivers")
+                assert np.array_equal(gt.tc_vertex_count2(), vc0)
+                gt.free()
             if (kind, scale, deg, hub_limit) == ("kronecker", 16, 16, 0) and rev_min <= 8:
                 assert g.device_bytes > base      # this graph does hand edges over: the lists and the arena stay with the graph
             g.free()

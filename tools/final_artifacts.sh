@@ -10,8 +10,8 @@ if [ "${1:-}" = "bk" ]; then
 fi
 bash tools/profile_bench.sh s26_r6final > gpurun_out/prof_s26_r6final.log 2>&1; tail -3 gpurun_out/prof_s26_r6final.log
 bash tools/profile_pmc.sh kc22_r6final tools/kc_probe.py 22 > gpurun_out/prof_kc22_r6final.log 2>&1; tail -2 gpurun_out/prof_kc22_r6final.log
-python tools/kc_probe.py 24 --ab 2>&1 | tail -3 > gpurun_out/kc24_r6.json
-python tools/kc_probe.py 26 --ab 2>&1 | tail -3 > gpurun_out/kc26_r6.json
+python tools/kc_probe.py 24 --ab 2>&1 | tail -4 > gpurun_out/kc24_r6.json
+python tools/kc_probe.py 26 --ab 2>&1 | tail -4 > gpurun_out/kc26_r6.json
 (bash tools/kc_trace.sh 26; bash tools/probes/kc_bin_traffic.sh 26; GMSX_OPT_TIMING=1 python tools/kc_probe.py 26 2>&1 | grep "kclique\]" | sort -u) > gpurun_out/kc26_bins_r6.txt 2>&1
 (python tools/bk_probe.py --default-only | tail -1; bash tools/probes/bk_trace.sh) > gpurun_out/bk_r6final.txt 2>&1
 GMSX_OPT_TIMING=1 python tools/probes/upload_phases.py 26 2>&1 | grep "gmsx\|rep" | grep -v "rmat\|host\]" > gpurun_out/upload_phases_s26.txt

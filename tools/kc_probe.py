@@ -31,7 +31,7 @@ for s in scales:
             os.replace(cache + ".tmp", cache)
         except (OSError, capi.GmsxError):
             pass
-    variants = [{}] + ([{"KC_MFMA": 0}, {"KC_REVERSE": 0}] if "--ab" in sys.argv else [])
+    variants = [{}] + ([{"KC_MFMA": 0}, {"KC_REV_TAIL": 0}, {"KC_REVERSE": 0}] if "--ab" in sys.argv else [])
     if "--opts" in sys.argv:  # --opts "KC_REV_FACTOR=10;KC_REV_FACTOR=30,KC_REV_MIN=16": one more run per ';'-separated option set
         variants += [dict(kv.split("=") for kv in v.split(",") if kv) for v in sys.argv[sys.argv.index("--opts") + 1].split(";")]
     for opts in variants:
