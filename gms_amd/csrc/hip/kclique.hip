@@ -1934,6 +1934,9 @@ __global__ __launch_bounds__(256) void k_kc_reverse_tail(const uint4 *__restrict
     __shared__ __attribute__((aligned(16))) uint32_t rowbuf[16][kRevTailMaxI / 32];
     __shared__ unsigned int s_item;
     const int tid = threadIdx.x, grp = tid >> 4, sub = tid & 15;
+    // (Measured and dropped: the next item's header, extents and first 256 ids of each list loaded while this item's records are probed — 440 against 427 ms at
+    //  scale 26.  What the per-item start costs is paid instead by the threshold: a receiver takes its edges from 256 records on (KC_REV_TAIL_MIN; 16: 434 ms,
+    //  64: 426, 256: 423 at scale 26; 60.6 / 58.1 / 59.3 at scale 24).)
     while (true) {
         __syncthreads();  // the previous item's probes are done with bm / flt / tl
         if (tid == 0) s_item = atomicAdd(queue, 1u);
@@ -2082,7 +2085,7 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     int64_t tail_total = 0;
     GMSX_HIP(hipMemcpyAsync(&tail_total, g->toff + g->n, 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
-    KcrTail tl{g->toff, g->tadj, H, int(std::max<long long>(1, opt_int("KC_REV_TAIL_MIN", 16))), nullptr, nullptr, nullptr, nullptr, nullptr};
+    KcrTail tl{g->toff, g->tadj, H, int(std::max<long long>(1, opt_int("KC_REV_TAIL_MIN", 256))), nullptr, nullptr, nullptr, nullptr, nullptr};
     const bool want_tail = nt > 0 && tail_total > 0 && !(opt("KC_REV_TAIL") && std::atoi(opt("KC_REV_TAIL")) == 0);
     if (want_tail) {
         if (hipMalloc(&d_relt.p, size_t(tail_total) * 4) == hipSuccess && hipMalloc(&d_rcntt.p, size_t(nt) * 4 * 2) == hipSuccess) {
