@@ -16,10 +16,10 @@
 // WSg = kc4m_stride(d) words (a multiple of 8: 32-byte rows, 16-byte loads); row i holds bits j < i only, words up to WSg zero-filled.  Rows >= d
 // are never written: their loads are clamped to row d - 1 (finite garbage in accumulators that the mask then drops).
 //
-// A wave owns a 128 x 128 block (bi >= bj) of the product: 4 x 4 accumulator tiles (256 registers), one wave per SIMD.  Per chunk of 8 column words each
-// lane loads 16 bytes of "its" row of every tile (lane l: row l & 31, words 4 (l >> 5) …) — four K-steps of fragments straight from global memory /
-// L2, no LDS staging, the next chunk's loads in flight.  The J rows are the instruction's A operand, the I rows its B operand: an accumulator's COLUMN
-// (the lane) is then a row i of L, so the mask bits L_ij of a whole block row are four words of the lane's own row — one 16-byte load per tile row.
+// A wave owns a (32 T) x (32 T) block (bi >= bj) of the product — T = 2 in the library: 2 x 2 accumulator tiles, four waves per SIMD.  Per chunk of 8 column words
+// each lane loads 16 bytes of "its" row of every tile (lane l: row l & 31, words 4 (l >> 5) …) — four K-steps of fragments straight from global memory /
+// L2, no LDS staging.  The J rows are the instruction's A operand, the I rows its B operand: an accumulator's COLUMN (the lane) is then a row i of L, so the
+// mask bits L_ij of a tile are one word of the lane's own row.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>

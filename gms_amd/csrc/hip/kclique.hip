@@ -1858,12 +1858,14 @@ struct KcBins {
 // the receivers' kernel: persistent workgroups take work items (<= 512 records of one receiver w) from a queue; w's bitset container over [0, w) goes to LDS
 // with 16-byte copies; a 16-lane group per record streams the pivot's prefix (16-byte loads, 8 ids per lane and step), tests every id's bit, and each lane
 // stores its 8 hit bits as ONE BYTE of the row — byte b of a row = local indices 8 b … 8 b + 7, i.e. exactly the little-endian words the BUILD copies.
+template <int GW /* lanes per record: 16, or 8 = twice the records in flight per wave (most prefixes fit one step of 64 ids) */>
 __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ items, int64_t n_items, const ulonglong2 *__restrict__ rec, const int64_t *__restrict__ bmoff,
                                                     const uint32_t *__restrict__ bmpool, const uint16_t *__restrict__ hadj, uint32_t *__restrict__ arena, int nparts,
                                                     int part, KcBins bins, unsigned int *__restrict__ queue) {
     __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords];
     __shared__ unsigned int s_item;
-    const int tid = threadIdx.x, grp = tid >> 4, sub = tid & 15;
+    const int tid = threadIdx.x, grp = tid / GW, sub = tid % GW;
+    constexpr int NG = 256 / GW;  // records per round
     while (true) {
         __syncthreads();  // the previous item's probes are done with bm
         if (tid == 0) s_item = atomicAdd(queue, 1u);
@@ -1886,10 +1888,10 @@ __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ it
             const int i = int(r.x >> 40);
             return *reinterpret_cast<const kc_u4u *>(hadj + (r.x & ((1ull << 40) - 1ull)) + min(sub * 8, (i - 1) & ~7));
         };
-        ulonglong2 r0 = rec[first + min(grp, e_last)], r1 = rec[first + min(grp + 16, e_last)];
+        ulonglong2 r0 = rec[first + min(grp, e_last)], r1 = rec[first + min(grp + NG, e_last)];
         kc_u4u u0 = unit_of(r0);
-        for (int e = grp; e < cnt; e += 16) {
-            const ulonglong2 r2 = rec[first + min(e + 32, e_last)];
+        for (int e = grp; e < cnt; e += NG) {
+            const ulonglong2 r2 = rec[first + min(e + 2 * NG, e_last)];
             const kc_u4u u1 = unit_of(r1);
             const ulonglong2 r = r0;
             const bool mine = nparts <= 1 || bins.part_of(int64_t(r.y >> 36), nparts) == part;  // (another rank's pivot: skipped)
@@ -1900,7 +1902,7 @@ __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ it
                 const int nbytes = rev_row_words(i) * 4, last = (i - 1) & ~7;  // i >= 1
                 // (round 6b, measured and dropped: two more units of a long prefix in flight behind the one being probed — 81.6 / 88.2 against 72.8 ms at scale 26,
                 //  always or only for prefixes beyond 128 ids: the kernel waits on its LDS probes, not on these loads)
-                for (int b = sub; b < nbytes; b += 16) {
+                for (int b = sub; b < nbytes; b += GW) {
                     const int p0 = b * 8;
                     const kc_u4u p = b == sub ? u0 : *reinterpret_cast<const kc_u4u *>(row + min(p0, last));  // (clamped: in bounds, its bits masked below)
                     uint32_t m = kc_bit_lo(bm, p.x) | (kc_bit_hi(bm, p.x) << 1) | (kc_bit_lo(bm, p.y) << 2) | (kc_bit_hi(bm, p.y) << 3) | (kc_bit_lo(bm, p.z) << 4) |
@@ -1925,15 +1927,17 @@ __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ it
 // unit and the first tail id of entry e + 16, the probes of entry e (first version, every load behind its record: 230 ms at scale 26 for 363 M records).
 static constexpr int kRevTailList = 1024, kRevTailFilterWords = 512;
 __device__ __forceinline__ uint32_t kcr_tail_hash(int32_t id) { return (uint32_t(id) * 0x9E3779B1u) >> 18; }  // 14 bits
+template <int GW>
 __global__ __launch_bounds__(256) void k_kc_reverse_tail(const uint4 *__restrict__ items, int64_t n_items, const ulonglong2 *__restrict__ rec, const int64_t *__restrict__ hoff,
                                                          const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                          uint32_t *__restrict__ arena, int nparts, int part, KcBins bins, unsigned int *__restrict__ queue) {
     __shared__ __attribute__((aligned(16))) uint32_t bm[kBitmapWords];
     __shared__ __attribute__((aligned(16))) uint32_t flt[kRevTailFilterWords];
     __shared__ int32_t tl[kRevTailList];
-    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[16][kRevTailMaxI / 32];
+    constexpr int NG = 256 / GW;  // records per round
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[NG][kRevTailMaxI / 32];
     __shared__ unsigned int s_item;
-    const int tid = threadIdx.x, grp = tid >> 4, sub = tid & 15;
+    const int tid = threadIdx.x, grp = tid / GW, sub = tid % GW;
     // (Measured and dropped: the next item's header, extents and first 256 ids of each list loaded while this item's records are probed — 440 against 427 ms at
     //  scale 26.  What the per-item start costs is paid instead by the threshold: a receiver takes its edges from 256 records on (KC_REV_TAIL_MIN; 16: 434 ms,
     //  64: 426, 256: 423 at scale 26; 60.6 / 58.1 / 59.3 at scale 24).)
@@ -1977,12 +1981,12 @@ __global__ __launch_bounds__(256) void k_kc_reverse_tail(const uint4 *__restrict
             const int k = int(a.x >> 40) - int(b.x >> 40);
             return tadj[(b.x & ((1ull << 40) - 1ull)) + min(sub, max(k - 1, 0))];
         };
-        int64_t e0i = first + min(grp, e_last), e1i = first + min(grp + 16, e_last);
+        int64_t e0i = first + min(grp, e_last), e1i = first + min(grp + NG, e_last);
         ulonglong2 a0 = rec[2 * e0i], b0 = rec[2 * e0i + 1], a1 = rec[2 * e1i], b1 = rec[2 * e1i + 1];
         kc_u4u u0 = first_unit(a0, b0);
         int32_t t0 = first_tail(a0, b0);
-        for (int e = grp; e < cnt; e += 16) {
-            const int64_t e2i = first + min(e + 32, e_last);
+        for (int e = grp; e < cnt; e += NG) {
+            const int64_t e2i = first + min(e + 2 * NG, e_last);
             const ulonglong2 a2 = rec[2 * e2i], b2 = rec[2 * e2i + 1];
             const kc_u4u u1 = first_unit(a1, b1);
             const int32_t t1 = first_tail(a1, b1);
@@ -1992,13 +1996,13 @@ __global__ __launch_bounds__(256) void k_kc_reverse_tail(const uint4 *__restrict
                 const uint16_t *hrow = hadj + (a0.x & ((1ull << 40) - 1ull));
                 const int32_t *trow = tadj + (b0.x & ((1ull << 40) - 1ull));
                 const int nwords = rev_row_words(i);
-                for (int t = sub; t < nwords; t += 16) rb[t] = 0u;
+                for (int t = sub; t < nwords; t += GW) rb[t] = 0u;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 // hub columns [0, hc): 8 ids per lane and step -> one byte of the row
                 const int hbytes = (hc + 7) >> 3, last = (hc - 1) & ~7;
-                for (int b = sub; b < hbytes; b += 16) {
+                for (int b = sub; b < hbytes; b += GW) {
                     const int p0 = b * 8;
                     const kc_u4u p = b == sub ? u0 : *reinterpret_cast<const kc_u4u *>(hrow + min(p0, last));
                     uint32_t m = kc_bit_lo(bm, p.x) | (kc_bit_hi(bm, p.x) << 1) | (kc_bit_lo(bm, p.y) << 2) | (kc_bit_hi(bm, p.y) << 3) | (kc_bit_lo(bm, p.z) << 4) |
@@ -2011,7 +2015,7 @@ __global__ __launch_bounds__(256) void k_kc_reverse_tail(const uint4 *__restrict
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 // tail columns [hc, i): the pivot's tail members below the receiver: filter bit, then the receiver's sorted tail list
-                for (int q = sub; q < k; q += 16) {
+                for (int q = sub; q < k; q += GW) {
                     const int32_t id = q == sub ? t0 : trow[q];
                     const uint32_t hsh = kcr_tail_hash(id);
                     if ((flt[hsh >> 5] >> (hsh & 31u)) & 1u) {
@@ -2035,7 +2039,7 @@ __global__ __launch_bounds__(256) void k_kc_reverse_tail(const uint4 *__restrict
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 uint32_t *out = arena + (a0.y & ((1ull << 36) - 1ull));
-                for (int t = sub; t < nwords; t += 16) out[t] = rb[t];
+                for (int t = sub; t < nwords; t += GW) out[t] = rb[t];
             }
             a0 = a1; b0 = b1;
             a1 = a2; b1 = b2;
@@ -2204,12 +2208,16 @@ static int launch_kc_reverse(const gmsx_graph *g, int part, int nparts, const Kc
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
     const unsigned blocks = unsigned(std::min<int64_t>(g->kc_items, int64_t(cu) * 8));
     if (g->kc_items > 0) {
-        hipLaunchKernelGGL(k_kc_reverse, dim3(blocks), dim3(256), 0, s, g->kc_item, g->kc_items, g->kc_rec, g->bmoff, g->bmpool, g->hadj, g->kc_arena, nparts, part, bins, queue);
+        const bool gw8 = !(opt("KC_REV_GW") && std::atoi(opt("KC_REV_GW")) == 16);
+        if (gw8) hipLaunchKernelGGL(k_kc_reverse<8>, dim3(blocks), dim3(256), 0, s, g->kc_item, g->kc_items, g->kc_rec, g->bmoff, g->bmpool, g->hadj, g->kc_arena, nparts, part, bins, queue);
+        else hipLaunchKernelGGL(k_kc_reverse<16>, dim3(blocks), dim3(256), 0, s, g->kc_item, g->kc_items, g->kc_rec, g->bmoff, g->bmpool, g->hadj, g->kc_arena, nparts, part, bins, queue);
         ++*launches;
     }
     if (g->kc_relt && g->kc_itemst > 0) {
         const unsigned blocks_t = unsigned(std::min<int64_t>(g->kc_itemst, int64_t(cu) * 8));
-        hipLaunchKernelGGL(k_kc_reverse_tail, dim3(blocks_t), dim3(256), 0, s, g->kc_itemt, g->kc_itemst, g->kc_rect, g->hoff, g->hadj, g->toff, g->tadj, g->kc_arena, nparts, part, bins,
+        const bool gw8 = !(opt("KC_REV_GW") && std::atoi(opt("KC_REV_GW")) == 16);
+        if (gw8) hipLaunchKernelGGL(k_kc_reverse_tail<8>, dim3(blocks_t), dim3(256), 0, s, g->kc_itemt, g->kc_itemst, g->kc_rect, g->hoff, g->hadj, g->toff, g->tadj, g->kc_arena, nparts, part, bins, queue + 1);
+        else hipLaunchKernelGGL(k_kc_reverse_tail<16>, dim3(blocks_t), dim3(256), 0, s, g->kc_itemt, g->kc_itemst, g->kc_rect, g->hoff, g->hadj, g->toff, g->tadj, g->kc_arena, nparts, part, bins,
                            queue + 1);
         ++*launches;
     }

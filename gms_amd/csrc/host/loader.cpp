@@ -767,7 +767,7 @@ Option g_options[] = {
     {"TC_PERSIST", "", false}, {"TC_ITEM_WGS", "", false}, {"SORT_CHUNK", "", false}, {"UPLOAD_STAGED", "", false}, {"INIT_LAZY", "", false},
     // k-clique (kclique.hip)
     {"KC_SLAB_MB", "", false}, {"KC_MAXD", "", false}, {"KC_STREAMS", "", false}, {"KC_PIPE_ALL", "", false}, {"KC_STREAM_BUILD", "", false},
-    {"KC_REVERSE", "", false}, {"KC_REV_MIN", "", false}, {"KC_REV_FACTOR", "", false}, {"KC_REV_TAIL", "", false}, {"KC_REV_TAIL_MIN", "", false}, {"KC_TRI", "", false}, {"KC_MFMA", "", false}, {"KC_POOL_MB", "", false},
+    {"KC_REVERSE", "", false}, {"KC_REV_MIN", "", false}, {"KC_REV_FACTOR", "", false}, {"KC_REV_TAIL", "", false}, {"KC_REV_TAIL_MIN", "", false}, {"KC_REV_GW", "", false}, {"KC_TRI", "", false}, {"KC_MFMA", "", false}, {"KC_POOL_MB", "", false},
     // Bron–Kerbosch (bk.hip)
     {"BK_MAXC", "", false}, {"BK_ARENA_MB", "", false}, {"BK_GROUPS", "", false}, {"BK_SMALL_P", "", false}, {"BK_SMALL_P_GROUPS", "", false},
     {"BK_BUDGET", "", false}, {"BK_BUDGET0", "", false}, {"BK_RESUME_GRAB", "", false}, {"BK_SPLIT_BUILD", "", false}, {"BK_TINY_ROOTS", "", false},
