@@ -2208,14 +2208,14 @@ static int launch_kc_reverse(const gmsx_graph *g, int part, int nparts, const Kc
     const int cu = c.compute_units > 0 ? c.compute_units : 256;
     const unsigned blocks = unsigned(std::min<int64_t>(g->kc_items, int64_t(cu) * 8));
     if (g->kc_items > 0) {
-        const bool gw8 = !(opt("KC_REV_GW") && std::atoi(opt("KC_REV_GW")) == 16);
+        const bool gw8 = opt("KC_REV_GW") && std::atoi(opt("KC_REV_GW")) == 8;  // (hub receivers: 16 lanes per record — 8: 84 against 71 ms at scale 26; option for A/B)
         if (gw8) hipLaunchKernelGGL(k_kc_reverse<8>, dim3(blocks), dim3(256), 0, s, g->kc_item, g->kc_items, g->kc_rec, g->bmoff, g->bmpool, g->hadj, g->kc_arena, nparts, part, bins, queue);
         else hipLaunchKernelGGL(k_kc_reverse<16>, dim3(blocks), dim3(256), 0, s, g->kc_item, g->kc_items, g->kc_rec, g->bmoff, g->bmpool, g->hadj, g->kc_arena, nparts, part, bins, queue);
         ++*launches;
     }
     if (g->kc_relt && g->kc_itemst > 0) {
         const unsigned blocks_t = unsigned(std::min<int64_t>(g->kc_itemst, int64_t(cu) * 8));
-        const bool gw8 = !(opt("KC_REV_GW") && std::atoi(opt("KC_REV_GW")) == 16);
+        const bool gw8 = opt("KC_REV_GW") && std::atoi(opt("KC_REV_GW")) == 8;  // (8 lanes per record: 94 against ~105 ms alone at scale 26, but 433 against 425 ms for the call — the passes overlap)
         if (gw8) hipLaunchKernelGGL(k_kc_reverse_tail<8>, dim3(blocks_t), dim3(256), 0, s, g->kc_itemt, g->kc_itemst, g->kc_rect, g->hoff, g->hadj, g->toff, g->tadj, g->kc_arena, nparts, part, bins, queue + 1);
         else hipLaunchKernelGGL(k_kc_reverse_tail<16>, dim3(blocks_t), dim3(256), 0, s, g->kc_itemt, g->kc_itemst, g->kc_rect, g->hoff, g->hadj, g->toff, g->tadj, g->kc_arena, nparts, part, bins,
                            queue + 1);
