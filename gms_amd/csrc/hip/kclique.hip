@@ -2106,7 +2106,7 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     //  a forward row's hits are resolved bit by bit (prefix popcount + LDS atomic, divergent per lane), a reverse row costs one LDS probe per prefix id, and
     //  with the count off the clock the BUILD is what a call waits for.  20 -> 1 at scales 22 / 24 / 26: 13.6 -> 11.3, 70.0 -> 59.3, 496 -> 470 ms, for lists + arena
     //  of 31.3 instead of 13.4 GB at scale 26 and 69 instead of 34 ms of one-off list build)
-    const int factor10 = int(std::max<long long>(1, opt_int("KC_REV_FACTOR", 1)));
+    const int factor10 = int(std::max<long long>(0, opt_int("KC_REV_FACTOR", 0)));  // (0: every hub edge whose receiver qualifies)
     const unsigned blocks = unsigned(std::min<int64_t>((n_piv + 15) / 16, int64_t(cu) * 32));
     hipLaunchKernelGGL(k_kcr_edges<0>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, nullptr, nullptr, rcur, nullptr, tl);
     hipLaunchKernelGGL(k_kcr_edges<1>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, nullptr, nullptr, rcur, nullptr, tl);
@@ -2250,6 +2250,9 @@ struct KcPool {
     int32_t *dpool = nullptr;
 };
 static constexpr int kKcPoolRegions = 3, kKcChunkMax = 65536;
+// words between the slots of a chunk: 2 048 x 64 and 4 096 x 128 words are powers of two — the workgroups of a BUILD (and the teams of a count) would walk their
+// slots in step on the same memory channels
+static constexpr size_t kKcSlotPad = 2080;
 static KcPool &kc_pool() {
     static KcPool p;
     return p;
@@ -2425,7 +2428,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             for (int b = 0; b < (tri ? 5 : 3); ++b) {
                 int64_t lo = 0, hi = 0;
                 if (int rc = range(froms[b], tos[b], &lo, &hi)) return rc;
-                needed += size_t(part_count(lo, hi, nparts, part)) * size_t(tos[b]) * size_t(kc4m_stride(tos[b])) * 4;
+                needed += size_t(part_count(lo, hi, nparts, part)) * (size_t(tos[b]) * size_t(kc4m_stride(tos[b])) + kKcSlotPad) * 4;
             }
         }
         if (needed > 0) {
@@ -2446,7 +2449,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
             auto export_bin = [&](int from, int dmax, int wpl, bool *done) -> int {
                 *done = false;
                 if (!pool.base) return GMSX_OK;
-                const size_t slot_words = size_t(dmax) * size_t(kc4m_stride(dmax));
+                const size_t slot_words = size_t(dmax) * size_t(kc4m_stride(dmax)) + kKcSlotPad;
                 const int64_t cap = std::min<int64_t>(int64_t(region_words / slot_words), kKcChunkMax);
                 if (cap < 1) return GMSX_OK;  // the pool cannot hold one matrix of this bin: it keeps its in-kernel count
                 int64_t lo = 0, hi = 0;
