@@ -130,7 +130,7 @@ int gmsx_set_host_threads(int n);
  *                   TC_PERSIST, TC_ITEM_WGS (launch shapes)
  *   k-clique        KC_MAXD (widest pivot of the bit-matrix kernels), KC_SLAB_MB (budget of the global slabs), KC_STREAMS, KC_PIPE_ALL,
  *                   KC_STREAM_BUILD (BUILD variants), KC_REVERSE (0 = every member row streamed forward: no reverse rows; like KC_REV_* read when the lists of a graph are built, i.e. at its first k-clique call), KC_REV_MIN (edges a hub
- *                   receiver must get to take them, default 64), KC_REV_FACTOR (10 x how much cheaper in bytes the reverse side must be, default 1: handed over unless ten times dearer),
+ *                   receiver must get to take them, default 64), KC_REV_FACTOR (10 x how much cheaper in bytes the reverse side must be; default 0: every hub edge whose receiver qualifies), KC_REV_GW (8 / 16 lanes per record in the receivers' kernels),
  *                   KC_REV_TAIL (0 = tail members — rank id >= 65 535 — never hand their row to a receiver), KC_REV_TAIL_MIN (edges a tail receiver must get, default 256),
  *                   KC_TRI (0 = k = 4 keeps rectangular LDS matrices up to d+ = 1024 and the global slab beyond, instead of triangular ones up to 1472),
  *                   KC_MFMA (0 = the k = 4 count of the pivots of d+ > 512 by AND + popcount inside their BUILD kernels instead of on the matrix cores),
