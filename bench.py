@@ -52,7 +52,7 @@ METRIC = "edges-intersected/sec + achieved HBM GB/s, RMAT-26 triangle count @1/2
 # per workload: the sources its kernels and containers are built from (every PMC figure carries the hash of what it was measured on)
 KERNEL_SOURCES = {
     "tc": ["gms_amd/csrc/hip/tc.hip", "gms_amd/csrc/hip/device_graph.hip", "gms_amd/csrc/hip/device_graph.hpp"],
-    "kc4": ["gms_amd/csrc/hip/kclique.hip", "gms_amd/csrc/hip/device_graph.hip", "gms_amd/csrc/hip/device_graph.hpp"],
+    "kc4": ["gms_amd/csrc/hip/kclique.hip", "gms_amd/csrc/hip/kc4_mfma.hpp", "gms_amd/csrc/hip/device_graph.hip", "gms_amd/csrc/hip/device_graph.hpp"],
     "bk": ["gms_amd/csrc/hip/bk.hip", "gms_amd/csrc/hip/device_graph.hip", "gms_amd/csrc/hip/device_graph.hpp"],
 }
 KERNEL_SOURCES["kc26"] = KERNEL_SOURCES["kc4"]
