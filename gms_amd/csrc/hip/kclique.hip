@@ -1308,7 +1308,10 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
                 }
             }
         }
-        if (GLOBAL_ROWS) {
+        if constexpr (GLOBAL_ROWS && EXPORT) {
+            // nobody reads the pool slot inside this kernel (the count is another launch): no fence — the agent-scope release / acquire pair below made every
+            // workgroup wait for the slot's 0.4 MB of stores at every pivot
+        } else if (GLOBAL_ROWS) {
             __threadfence();
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop L1 lines of the slab cached for an earlier pivot
