@@ -1312,7 +1312,9 @@ __global__ __launch_bounds__(1024) void k_kc_block(const int64_t *__restrict__ h
             // nobody reads the pool slot inside this kernel (the count is another launch): no fence — the agent-scope release / acquire pair below made every
             // workgroup wait for the slot's 0.4 MB of stores at every pivot
         } else if (GLOBAL_ROWS) {
-            __threadfence();
+            // the slab's readers are this workgroup's own waves: its stores only have to be done (the L1 writes through) — a workgroup-scope release; an agent-scope
+            // one (__threadfence) also waits for the L2 to write its dirty lines back, every workgroup's, at every pivot
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop L1 lines of the slab cached for an earlier pivot
         } else {
