@@ -845,7 +845,7 @@ __device__ __forceinline__ int kcs_find(const int32_t *keys, const unsigned char
 template <bool BUCKET>
 __device__ __forceinline__ void kcs_tail_rows(const int64_t *__restrict__ hoff, const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff,
                                               const int32_t *__restrict__ tadj, const int32_t *keys, const unsigned char *vals, uint32_t *rows,
-                                              int32_t my, int hc, int d, int lane) {
+                                              int32_t my, int hc, int d, int lane, uint32_t fwd_mask /* members whose row is not in the arena */) {
     const int grp = lane >> 4, sub = lane & 15;
     // the extents of the NEXT trip's rows are on their way while this trip's rows are streamed (round 5: extents, then rows — two dependent round trips
     // per trip of four members — were most of what a pivot of a dozen tail members waited for)
@@ -861,7 +861,7 @@ __device__ __forceinline__ void kcs_tail_rows(const int64_t *__restrict__ hoff, 
         n_he = hoff[vn + 1];
         n_tb = toff[vn];
         n_te = toff[vn + 1];
-        if (i >= d) continue;  // per group
+        if (i >= d || !((fwd_mask >> i) & 1u)) continue;  // per group
         uint32_t bits = 0;
         // (round 5) both parts of the row ascend, and only the members BELOW v can be in it: the hub part is of use up to the pivot's largest hub
         // member — not at all without hub members —, the tail part up to the tail member in front of v — not at all for the first tail member
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
                                                   const int64_t *__restrict__ bmoff, const uint32_t *__restrict__ bmpool,
                                                   const int32_t *__restrict__ order, int64_t first, int64_t end, int nparts,
                                                   int part, unsigned long long *__restrict__ acc, const int32_t *__restrict__ oldid,
-                                                  unsigned long long *__restrict__ vcounts) {
+                                                  unsigned long long *__restrict__ vcounts, KcRev rv) {
     constexpr int SIZE = 256;
     __shared__ __attribute__((aligned(16))) int32_t keys_all[4 * SIZE];
     __shared__ __attribute__((aligned(4))) unsigned char vals_all[4 * SIZE];
@@ -936,8 +936,17 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
         } else if (lane < d) {
             my = tadj[tb + (lane - hc)];
         }
+        // tail members whose receiver took their edge (round 6b: k_kc_reverse_tail serves the narrow pivots too): the finished row is ONE word of the arena;
+        // only the others are streamed forward — and only for them is the member set below built at all
+        uint32_t fwd_mask = 0u;
+        {
+            uint32_t r = kKcRelForward;
+            if (rv.relt && lane >= hc && lane < d && lane > 0) r = rv.relt[tb + (lane - hc)];
+            if (r != kKcRelForward) rows[lane] = rv.arena[rv.aoff[u] + r];
+            fwd_mask = uint32_t(__ballot(lane >= hc && lane < d && lane > 0 && r == kKcRelForward));
+        }
         bool bucketed = true;
-        if (tc > 0) {  // the member set is only probed by the streamed rows of tail members
+        if (fwd_mask) {  // the member set is only probed by the streamed rows of tail members
             bool ovf = false;
             if (lane < d) {
                 int32_t *b = keys + kcs_bucket(my) * 4;
@@ -984,11 +993,11 @@ __global__ __launch_bounds__(256) void k_kc_small(const int64_t *__restrict__ ho
                 }
             }
         }
-        if (tc > 0) {
+        if (fwd_mask) {
             if (bucketed)
-                kcs_tail_rows<true>(hoff, hadj, toff, tadj, keys, vals, rows, my, hc, d, lane);
+                kcs_tail_rows<true>(hoff, hadj, toff, tadj, keys, vals, rows, my, hc, d, lane, fwd_mask);
             else
-                kcs_tail_rows<false>(hoff, hadj, toff, tadj, keys, vals, rows, my, hc, d, lane);
+                kcs_tail_rows<false>(hoff, hadj, toff, tadj, keys, vals, rows, my, hc, d, lane, fwd_mask);
         }
         __builtin_amdgcn_wave_barrier();
         if constexpr (VTX) {
@@ -1728,6 +1737,7 @@ struct KcrTail {
     uint32_t *rcnt, *rcur;  // [n - H]
     const int64_t *roff;    // [n - H + 1] (pass 3)
     ulonglong2 *rec;        // two halves per record (pass 3)
+    int64_t n_all;          // positions of the d+ order the passes walk: [0, n_piv) all members, [n_piv, n_all) tail members only
 };
 static constexpr int kRevTailMaxI = 2048;  // a tail record's row is assembled in 64 words of LDS per group (wider pivots have next to no tail members)
 // pass 1 (MODE 0): mark the candidate edges (kc_rel = 0 / ~0) and count them per receiver.  pass 2 (MODE 1): the arena words of every pivot (the edges whose
@@ -1739,13 +1749,14 @@ __global__ __launch_bounds__(256) void k_kcr_edges(int64_t n_piv, const int32_t 
                                                    uint32_t *__restrict__ rcur, ulonglong2 *__restrict__ rec, KcrTail tl) {
     const int sub = threadIdx.x & 15;
     const int64_t g0 = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 4, ng = (int64_t(gridDim.x) * blockDim.x) >> 4;
-    for (int64_t pos = g0; pos < n_piv; pos += ng) {
+    for (int64_t pos = g0; pos < tl.n_all; pos += ng) {
         const int32_t u = order[pos];
         const int64_t hb = hoff[u];
         int hc = int(hoff[u + 1] - hb);
         if (hc > 0 && hadj[hb + hc - 1] == 0xFFFFu) --hc;
         int64_t run = 0;  // arena words of the accepted members in front (uniform per group)
-        for (int i0 = 0; i0 < hc; i0 += 16) {
+        // (positions [n_piv, n_all): the pivots of d+ <= 32 — the wave kernel builds their hub members' rows by gathers, only their tail members are handed over)
+        for (int i0 = 0; i0 < (pos < n_piv ? hc : 0); i0 += 16) {
             const int i = i0 + sub;
             bool take = false;
             int32_t w = 0;
@@ -2094,7 +2105,7 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     int64_t tail_total = 0;
     GMSX_HIP(hipMemcpyAsync(&tail_total, g->toff + g->n, 8, hipMemcpyDeviceToHost, s));
     GMSX_HIP(hipStreamSynchronize(s));
-    KcrTail tl{g->toff, g->tadj, H, int(std::max<long long>(1, opt_int("KC_REV_TAIL_MIN", 256))), nullptr, nullptr, nullptr, nullptr, nullptr};
+    KcrTail tl{g->toff, g->tadj, H, int(std::max<long long>(1, opt_int("KC_REV_TAIL_MIN", 256))), nullptr, nullptr, nullptr, nullptr, nullptr, n_piv};
     const bool want_tail = nt > 0 && tail_total > 0 && !(opt("KC_REV_TAIL") && std::atoi(opt("KC_REV_TAIL")) == 0);
     if (want_tail) {
         if (hipMalloc(&d_relt.p, size_t(tail_total) * 4) == hipSuccess && hipMalloc(&d_rcntt.p, size_t(nt) * 4 * 2) == hipSuccess) {
@@ -2103,6 +2114,8 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
             tl.rcur = tl.rcnt + nt;
             GMSX_HIP(hipMemsetAsync(tl.relt, 0xff, size_t(tail_total) * 4, s));
             GMSX_HIP(hipMemsetAsync(tl.rcnt, 0, size_t(nt) * 8, s));
+            if (int rc = count_dplus_ge(g, 2, &tl.n_all)) return rc;  // … the tail members of the narrow pivots too (k_kc_small)
+            tl.n_all = std::max(tl.n_all, n_piv);
         } else {
             (void)hipGetLastError();  // no room: the tail members stay forward
         }
@@ -2112,7 +2125,7 @@ static int ensure_kc_reverse(const gmsx_graph *g, int max_d) {
     //  with the count off the clock the BUILD is what a call waits for.  20 -> 1 at scales 22 / 24 / 26: 13.6 -> 11.3, 70.0 -> 59.3, 496 -> 470 ms, for lists + arena
     //  of 31.3 instead of 13.4 GB at scale 26 and 69 instead of 34 ms of one-off list build)
     const int factor10 = int(std::max<long long>(0, opt_int("KC_REV_FACTOR", 0)));  // (0: every hub edge whose receiver qualifies)
-    const unsigned blocks = unsigned(std::min<int64_t>((n_piv + 15) / 16, int64_t(cu) * 32));
+    const unsigned blocks = unsigned(std::min<int64_t>((tl.n_all + 15) / 16, int64_t(cu) * 32));
     hipLaunchKernelGGL(k_kcr_edges<0>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, nullptr, nullptr, rcur, nullptr, tl);
     hipLaunchKernelGGL(k_kcr_edges<1>, dim3(blocks), dim3(256), 0, s, n_piv, g->order, g->hoff, g->hadj, g->dense_limit, min_edges, factor10, rel, rcnt, words, nullptr, nullptr, rcur, nullptr, tl);
     GMSX_HIP(hipGetLastError());
@@ -2390,6 +2403,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         GMSX_HIP(hipEventRecord(ev_rev, rev_stream));
         GMSX_HIP(hipStreamWaitEvent(s, ev_rev, 0));
         for (int i = 0; i + 2 < kSides; ++i) GMSX_HIP(hipStreamWaitEvent(sides[i], ev_rev, 0));
+        if (g->kc_relt) GMSX_HIP(hipStreamWaitEvent(small_stream, ev_rev, 0));  // (the wave kernel reads its tail members' rows from the arena too)
     }
     int next_stream = 0;
     auto pick = [&]() -> hipStream_t {  // round robin over the launch stream and the side streams in use
@@ -2417,7 +2431,7 @@ static int launch_all(const gmsx_graph *g, int part, int nparts, unsigned long l
         if (cnt > 0) {
             const int64_t blocks = std::min<int64_t>((cnt + 3) / 4, int64_t(cu) * 32);
             hipLaunchKernelGGL((k_kc_small<LV, VTX>), dim3(unsigned(blocks)), dim3(256), 0, small_stream, g->hoff, g->hadj, g->toff, g->tadj, g->bmoff, g->bmpool,
-                               g->order, lo, hi, nparts, part, acc, g->oldid, vcounts);
+                               g->order, lo, hi, nparts, part, acc, g->oldid, vcounts, rv);
             ++*launches;
         }
     }
