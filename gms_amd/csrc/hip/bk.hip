@@ -513,7 +513,7 @@ __device__ __forceinline__ void bk_search(const uint32_t *Cadj, const uint32_t *
                     }
                 }
                 if (lane == 0) xfne_stack[depth] = (unsigned char)xf_ne;
-                if (global_structs) __threadfence();
+                if (global_structs) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (readers: this wave; an agent-scope fence also flushes the XCD's L2)
                 __builtin_amdgcn_wave_barrier();
                 // A level with b pending branch vertices becomes min(b, kBkSplit) records: the branches in ascending order, cut into
                 // equal runs; run j starts from the state its predecessors leave behind (their vertices moved from P to X —
@@ -904,7 +904,7 @@ __device__ __forceinline__ void bk_build(const int64_t *__restrict__ off, const 
                 for (size_t i = lane; i < n4; i += 64) z4[i] = make_uint4(0u, 0u, 0u, 0u);
                 for (size_t i = head + n4 * 4 + lane; i < nz; i += 64) Cadj[i] = 0;
             }
-            if (!LDS_SLAB) __threadfence();
+            if (!LDS_SLAB) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
             const int64_t hb = uni64(hoff[v]), tb = uni64(toff[v]);
             int hc = int(uni64(hoff[v + 1]) - hb);
@@ -915,7 +915,7 @@ __device__ __forceinline__ void bk_build(const int64_t *__restrict__ off, const 
                 const unsigned long long packed = ((unsigned long long)uint32_t(a) << 32) | (unsigned long long)uint32_t(i);
                 while (atomicCAS(&map[h], kEmptySlot, packed) != kEmptySlot) h = (h + 1) & mmask;
             }
-            if (!LDS_SLAB) __threadfence();
+            if (!LDS_SLAB) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
             // rows of the hub candidates (all of them have a bitset container): lane k asks "is candidate k in N+(a_i)?" with
             // one word gather; the candidate ids of a 64-chunk are loaded once, the rows go eight at a time (eight gathers
@@ -998,7 +998,7 @@ __device__ __forceinline__ void bk_build(const int64_t *__restrict__ off, const 
                 xbase += kept;
             }
             if (!LDS_SLAB) {
-                __threadfence();
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop L1 lines of the slab cached for an earlier task
             }
             __builtin_amdgcn_wave_barrier();
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(64) void k_bk_wave(const int64_t *__restrict__ off,
                 stack[w] = bits >= 32 ? 0xffffffffu : ((1u << bits) - 1u);
                 stack[cw + w] = 0u;
             }
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
             bk_search_mem(Cadj, XT, stack, c, x, x > 0 ? 1 : 0, lane, cnt);
         } else {
@@ -1559,10 +1559,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPL == 1 ? G
             for (int w = lane; w < xw; w += 64) stack[3 * cw + w] = rec[kRecHeader + 3 * cw + w];
         } else {
             for (int w = lane; w < xw; w += 64) stack[3 * cw + w] = 0u;
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (readers: this wave; an agent-scope fence also flushes the XCD's L2)
             __builtin_amdgcn_wave_barrier();
             for (int i = lane; i < pairs; i += 64) stack[3 * cw + rec[kRecHeader + 3 * cw + 2 * i]] = rec[kRecHeader + 3 * cw + 2 * i + 1];
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (readers: this wave; an agent-scope fence also flushes the XCD's L2)
         }
         __builtin_amdgcn_wave_barrier();
         bk_search<WPL>(Cadj, XT, stack, xfne_stack, v, c, x, P, Xc, ext, xf_ne, root, lane, cnt, sh, aoff, true, piv_P, piv_list, node_words);
@@ -1951,7 +1951,7 @@ __device__ __forceinline__ void bk_group_searches(const uint32_t *__restrict__ p
                         *reinterpret_cast<uint4 *>(pl) = uint4{pP, pXc, pext, uint32_t(pxfn)};
                         *reinterpret_cast<uint2 *>(pl + 4) = uint2{pridx, prval};
                     }
-                    __threadfence();
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (readers: this wave; an agent-scope fence also flushes the XCD's L2)
                     int nrec = 0;
                     for (uint32_t l = 0; l <= depth; ++l) nrec += min(bkg_sum<G>(__popc(level(l)[sub * kBkSlot + 2])), kBkSplit);
                     const unsigned long long rec_words = (unsigned long long)(kRecHeader + 3 * cw + xw);
@@ -2007,7 +2007,7 @@ __device__ __forceinline__ void bk_group_searches(const uint32_t *__restrict__ p
                                         else for (uint32_t i = sub; i < 2u * uint32_t(ln); i += G) ox[i] = src[i];
                                     } else {
                                         for (uint32_t w = sub; w < xw; w += G) ox[w] = 0u;
-                                        __threadfence();
+                                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // (readers: this wave; an agent-scope fence also flushes the XCD's L2)
                                         if (in_regs) { if (sub < ln) ox[lidx] = lval; }
                                         else for (uint32_t i = sub; i < uint32_t(ln); i += G) ox[src[2 * i]] = src[2 * i + 1];
                                     }
