@@ -1874,7 +1874,10 @@ struct KcBins {
 // the receivers' kernel: persistent workgroups take work items (<= 512 records of one receiver w) from a queue; w's bitset container over [0, w) goes to LDS
 // with 16-byte copies; a 16-lane group per record streams the pivot's prefix (16-byte loads, 8 ids per lane and step), tests every id's bit, and each lane
 // stores its 8 hit bits as ONE BYTE of the row — byte b of a row = local indices 8 b … 8 b + 7, i.e. exactly the little-endian words the BUILD copies.
-template <int GW /* lanes per record: 16, or 8 = twice the records in flight per wave (most prefixes fit one step of 64 ids) */>
+// SHARDED: the call is one rank's part of a multi-GPU count — records of other ranks' pivots are skipped.  A template parameter, not a run-time test: the
+// compiler evaluated KcBins::part_of (sixteen 64-bit compares and selects) for EVERY record ahead of `nparts <= 1 ||` — half the vector instructions of a kernel
+// that is bound by exactly those (SQ_INSTS_VALU x 4 cycles = 88 % of the SIMD cycles of the hub receivers' pass, 69 % of the tail receivers').
+template <int GW /* lanes per record: 16, or 8 = twice the records in flight per wave (most prefixes fit one step of 64 ids) */, bool SHARDED>
 __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ items, int64_t n_items, const ulonglong2 *__restrict__ rec, const int64_t *__restrict__ bmoff,
                                                     const uint32_t *__restrict__ bmpool, const uint16_t *__restrict__ hadj, uint32_t *__restrict__ arena, int nparts,
                                                     int part, KcBins bins, unsigned int *__restrict__ queue) {
@@ -1910,7 +1913,8 @@ __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ it
             const ulonglong2 r2 = rec[first + min(e + 2 * NG, e_last)];
             const kc_u4u u1 = unit_of(r1);
             const ulonglong2 r = r0;
-            const bool mine = nparts <= 1 || bins.part_of(int64_t(r.y >> 36), nparts) == part;  // (another rank's pivot: skipped)
+            bool mine = true;
+            if constexpr (SHARDED) mine = bins.part_of(int64_t(r.y >> 36), nparts) == part;  // (another rank's pivot: skipped)
             if (mine) {
                 const int i = int(r.x >> 40);
                 const uint16_t *row = hadj + (r.x & ((1ull << 40) - 1ull));
@@ -1943,7 +1947,7 @@ __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ it
 // unit and the first tail id of entry e + 16, the probes of entry e (first version, every load behind its record: 230 ms at scale 26 for 363 M records).
 static constexpr int kRevTailList = 1024, kRevTailFilterWords = 512;
 __device__ __forceinline__ uint32_t kcr_tail_hash(int32_t id) { return (uint32_t(id) * 0x9E3779B1u) >> 18; }  // 14 bits
-template <int GW>
+template <int GW, bool SHARDED>
 __global__ __launch_bounds__(256) void k_kc_reverse_tail(const uint4 *__restrict__ items, int64_t n_items, const ulonglong2 *__restrict__ rec, const int64_t *__restrict__ hoff,
                                                          const uint16_t *__restrict__ hadj, const int64_t *__restrict__ toff, const int32_t *__restrict__ tadj,
                                                          uint32_t *__restrict__ arena, int nparts, int part, KcBins bins, unsigned int *__restrict__ queue) {
@@ -2006,7 +2010,8 @@ __global__ __launch_bounds__(256) void k_kc_reverse_tail(const uint4 *__restrict
             const ulonglong2 a2 = rec[2 * e2i], b2 = rec[2 * e2i + 1];
             const kc_u4u u1 = first_unit(a1, b1);
             const int32_t t1 = first_tail(a1, b1);
-            const bool mine = nparts <= 1 || bins.part_of(int64_t(a0.y >> 36), nparts) == part;  // (another rank's pivot: skipped)
+            bool mine = true;
+            if constexpr (SHARDED) mine = bins.part_of(int64_t(a0.y >> 36), nparts) == part;  // (another rank's pivot: skipped)
             if (mine) {
                 const int i = int(a0.x >> 40), hc = int(b0.x >> 40), k = i - hc;  // member i = hc + k of its pivot
                 const uint16_t *hrow = hadj + (a0.x & ((1ull << 40) - 1ull));
@@ -2227,16 +2232,19 @@ static int launch_kc_reverse(const gmsx_graph *g, int part, int nparts, const Kc
     const unsigned blocks = unsigned(std::min<int64_t>(g->kc_items, int64_t(cu) * 8));
     if (g->kc_items > 0) {
         const bool gw8 = opt("KC_REV_GW") && std::atoi(opt("KC_REV_GW")) == 8;  // (hub receivers: 16 lanes per record — 8: 84 against 71 ms at scale 26; option for A/B)
-        if (gw8) hipLaunchKernelGGL(k_kc_reverse<8>, dim3(blocks), dim3(256), 0, s, g->kc_item, g->kc_items, g->kc_rec, g->bmoff, g->bmpool, g->hadj, g->kc_arena, nparts, part, bins, queue);
-        else hipLaunchKernelGGL(k_kc_reverse<16>, dim3(blocks), dim3(256), 0, s, g->kc_item, g->kc_items, g->kc_rec, g->bmoff, g->bmpool, g->hadj, g->kc_arena, nparts, part, bins, queue);
+        auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, s, g->kc_item, g->kc_items, g->kc_rec, g->bmoff, g->bmpool, g->hadj, g->kc_arena, nparts, part, bins, queue); };
+        if (nparts > 1) { if (gw8) go(k_kc_reverse<8, true>); else go(k_kc_reverse<16, true>); }
+        else { if (gw8) go(k_kc_reverse<8, false>); else go(k_kc_reverse<16, false>); }
         ++*launches;
     }
     if (g->kc_relt && g->kc_itemst > 0) {
         const unsigned blocks_t = unsigned(std::min<int64_t>(g->kc_itemst, int64_t(cu) * 8));
         const bool gw8 = opt("KC_REV_GW") && std::atoi(opt("KC_REV_GW")) == 8;  // (8 lanes per record: 94 against ~105 ms alone at scale 26, but 433 against 425 ms for the call — the passes overlap)
-        if (gw8) hipLaunchKernelGGL(k_kc_reverse_tail<8>, dim3(blocks_t), dim3(256), 0, s, g->kc_itemt, g->kc_itemst, g->kc_rect, g->hoff, g->hadj, g->toff, g->tadj, g->kc_arena, nparts, part, bins, queue + 1);
-        else hipLaunchKernelGGL(k_kc_reverse_tail<16>, dim3(blocks_t), dim3(256), 0, s, g->kc_itemt, g->kc_itemst, g->kc_rect, g->hoff, g->hadj, g->toff, g->tadj, g->kc_arena, nparts, part, bins,
-                           queue + 1);
+        auto go = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(blocks_t), dim3(256), 0, s, g->kc_itemt, g->kc_itemst, g->kc_rect, g->hoff, g->hadj, g->toff, g->tadj, g->kc_arena, nparts, part, bins, queue + 1);
+        };
+        if (nparts > 1) { if (gw8) go(k_kc_reverse_tail<8, true>); else go(k_kc_reverse_tail<16, true>); }
+        else { if (gw8) go(k_kc_reverse_tail<8, false>); else go(k_kc_reverse_tail<16, false>); }
         ++*launches;
     }
     return GMSX_OK;
