@@ -1875,8 +1875,9 @@ struct KcBins {
 // with 16-byte copies; a 16-lane group per record streams the pivot's prefix (16-byte loads, 8 ids per lane and step), tests every id's bit, and each lane
 // stores its 8 hit bits as ONE BYTE of the row — byte b of a row = local indices 8 b … 8 b + 7, i.e. exactly the little-endian words the BUILD copies.
 // SHARDED: the call is one rank's part of a multi-GPU count — records of other ranks' pivots are skipped.  A template parameter, not a run-time test: the
-// compiler evaluated KcBins::part_of (sixteen 64-bit compares and selects) for EVERY record ahead of `nparts <= 1 ||` — half the vector instructions of a kernel
-// that is bound by exactly those (SQ_INSTS_VALU x 4 cycles = 88 % of the SIMD cycles of the hub receivers' pass, 69 % of the tail receivers').
+// compiler evaluated KcBins::part_of (sixteen 64-bit compares and selects) for EVERY record ahead of `nparts <= 1 ||` — half the vector instructions of the
+// single-GPU kernel.  (Its run time did not move: 72.7 against 75 ms at scale 26 — the pass waits on memory, 77 % of its wave cycles, and what it pulls
+// through the fabric, ≈ 200 M KB of FETCH_SIZE per call, is the bandwidth of the box: every added load made it slower, every removed instruction left it as it was.)
 template <int GW /* lanes per record: 16, or 8 = twice the records in flight per wave (most prefixes fit one step of 64 ids) */, bool SHARDED>
 __global__ __launch_bounds__(256) void k_kc_reverse(const uint4 *__restrict__ items, int64_t n_items, const ulonglong2 *__restrict__ rec, const int64_t *__restrict__ bmoff,
                                                     const uint32_t *__restrict__ bmpool, const uint16_t *__restrict__ hadj, uint32_t *__restrict__ arena, int nparts,
