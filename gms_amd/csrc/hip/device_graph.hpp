@@ -13,7 +13,7 @@
 #if !defined(GMSX_DEV_HOOKS) &&                                                                                                               \
     (defined(GMSX_KC_NO_PROBE) || defined(GMSX_KC_NO_HITS) || defined(GMSX_KC_NO_TAIL) || defined(GMSX_KC_NO_INNER) || defined(GMSX_KC_CELLS_ONLY) ||   \
      defined(GMSX_KC_NO_ROWS) || defined(GMSX_KC_BUILD_ONLY) || defined(GMSX_KC_NO_SLAB_CALL) || defined(GMSX_KC_NO_PAIRS) || defined(GMSX_KC_SLAB_ROW_SCAN) || \
-     defined(GMSX_KC_NO_TAIL_MEMBERS) || defined(GMSX_BK_AB) || defined(GMSX_BK_NO_HIT_ATOMICS) || defined(GMSX_BK_STATS) || defined(GMSX_TC_NO_PROBE) || defined(GMSX_TC_STAGING_ONLY))
+     defined(GMSX_BK_AB) || defined(GMSX_BK_NO_HIT_ATOMICS) || defined(GMSX_BK_STATS) || defined(GMSX_TC_NO_PROBE) || defined(GMSX_TC_STAGING_ONLY))
 #error "A/B switches need -DGMSX_DEV_HOOKS (tools/ab_lib.sh sets it); the default build of libgmsx.so carries none of them"
 #endif
 

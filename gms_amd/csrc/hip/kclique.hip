@@ -16,6 +16,9 @@
 //      runs wave-cooperatively with one neighbour j per lane (kc4_row), slab matrices band by band through LDS.
 #include "device_graph.hpp"
 #include "kc4_mfma.hpp"
+#if defined(GMSX_KC_NO_TAIL_MEMBERS) && !defined(GMSX_DEV_HOOKS)  // (the A/B switches of device_graph.hpp's list + this round's: development builds only)
+#error "A/B switches need -DGMSX_DEV_HOOKS (tools/ab_lib.sh sets it)"
+#endif
 
 #include <algorithm>
 #include <chrono>
